@@ -1,0 +1,82 @@
+"""Import the reference's own Python modules on CPU (build container only).
+
+TEST INFRASTRUCTURE.  /root/reference does not exist on the GPU box, so nothing in
+tests/, smoke() or bench.py calls this at run time; it is used by
+oracle/make_golden.py to generate the committed fixtures under tests/golden/.
+Recipe follows SURVEY.md section 8(c): stub absent third-party imports, three patches.
+"""
+import os
+import sys
+import types
+
+REF = os.environ.get("DLE_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def have_reference():
+    return os.path.isdir(os.path.join(REF, "PyTorch"))
+
+
+def import_dlrm():
+    import torch
+    root = os.path.join(REF, "PyTorch/Recommendation/DLRM")
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    # absent: absl, apex, compiled dlrm.cuda_ext.* 
+    logging = _stub("absl.logging", WARNING=30, log_first_n=lambda *a, **k: None,
+                    warning=lambda *a, **k: None)
+    _stub("absl", logging=logging, app=types.SimpleNamespace(), flags=types.SimpleNamespace())
+    mlp = _stub("apex.mlp", MLP=torch.nn.Module, MlpFunction=torch.autograd.Function)
+    _stub("apex", mlp=mlp)
+    fge = _stub("dlrm.cuda_ext.fused_gather_embedding", BuckleEmbeddingFusedGatherFunction=None)
+    import dlrm  # noqa: the real package (pure python part)
+    ce = _stub("dlrm.cuda_ext", dotBasedInteract=None, fused_gather_embedding=fge,
+               JointSparseEmbedding=None)
+    dlrm.cuda_ext = ce
+    # interactions.py:53 calls .cuda() unconditionally
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    from dlrm.utils import distributed as dist_utils
+    from dlrm.nn import interactions, embeddings, mlps, parts
+    from dlrm.model import distributed as model_dist
+    return types.SimpleNamespace(dist_utils=dist_utils, interactions=interactions,
+                                 embeddings=embeddings, mlps=mlps, parts=parts,
+                                 model=model_dist)
+
+
+def import_bert():
+    import torch
+    import torch.nn.functional as F
+    root = os.path.join(REF, "PyTorch/LanguageModeling/BERT")
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    exc = _stub("botocore.exceptions", ClientError=Exception)
+    _stub("botocore", exceptions=exc)
+    _stub("boto3")
+    import modeling
+    # modeling.py:122 passes approximate=True (bool), rejected by torch>=2; semantics = "tanh"
+    modeling.ACT2FN["gelu"] = lambda x: F.gelu(x, approximate="tanh")
+    import schedulers
+    return types.SimpleNamespace(modeling=modeling, schedulers=schedulers)
+
+
+def import_convnets():
+    import torch
+    root = os.path.join(REF, "PyTorch/Classification/ConvNets")
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    verb = types.SimpleNamespace(DEFAULT=0, VERBOSE=1)
+    _stub("dllogger", Verbosity=verb, init=lambda *a, **k: None, log=lambda *a, **k: None,
+          metadata=lambda *a, **k: None, flush=lambda *a, **k: None,
+          StdOutBackend=object, JSONStreamBackend=object)
+    torch.cuda.synchronize = lambda *a, **k: None          # training.py:181 unconditional
+    from image_classification import models
+    from image_classification import training, optimizers, smoothing
+    return types.SimpleNamespace(models=models, training=training, optimizers=optimizers,
+                                 smoothing=smoothing)

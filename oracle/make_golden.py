@@ -1,0 +1,108 @@
+"""Generate tests/golden/* from the reference's own code (run in the build container).
+
+    python oracle/make_golden.py [dlrm] [bert] [rn50]
+
+TEST INFRASTRUCTURE.  Imports /root/reference (read-only) through oracle/_ref_import.py,
+runs the reference's eager CPU path on seeded inputs and stores inputs + outputs as small
+fixtures.  The fixtures travel to the GPU box; the reference does not.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import _ref_import as R  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
+CRITEO_F15 = [7912889, 33823, 582469, 245828, 11, 2209, 10667, 104, 4, 968, 15, 8165896, 17139,
+              2675940, 7156453, 302516, 12022, 97, 35, 7339, 20046, 4, 7105, 1382, 63, 5554114]
+
+
+def gen_dlrm():
+    ref = R.import_dlrm()
+    du = ref.dist_utils
+    out = {"device_mapping": [], "gpu_batch_sizes": [], "argsort": [], "tril": {}, "padding": {}}
+    size_sets = {
+        "criteo_f15": CRITEO_F15,
+        "default_26x100000": [100000] * 26,
+        "ties": [5, 5, 5, 3, 3, 9, 1, 1, 1, 1, 7],
+        "thirty": [(i * 7919) % 1000 + 1 for i in range(30)],
+        "ten": [10, 20, 30, 40, 50, 60, 70, 80, 90, 100],
+    }
+    for name, sizes in size_sets.items():
+        for n in (1, 2, 3, 4, 5, 8, 16):
+            if n - 1 > len(sizes):
+                continue
+            out["device_mapping"].append({"name": name, "sizes": sizes, "num_gpus": n,
+                                          "result": du.get_device_mapping(sizes, n)})
+    for gb, n in [(65536, 8), (65536, 1), (65536, 2), (65536, 4), (32768, 8), (2048, 2), (16384, 4),
+                  (65536 - 64, 8), (4096 + 128, 3)]:
+        try:
+            res = list(du.get_gpu_batch_sizes(gb, n))
+        except RuntimeError:
+            res = None
+        out["gpu_batch_sizes"].append({"global_batch": gb, "num_gpus": n, "result": res})
+    for seq in ([3, 1, 2], [5, 5, 1, 5], [1, 1, 1], list(range(10, 0, -1))):
+        out["argsort"].append({"seq": seq, "asc": du.argsort(seq), "desc": du.argsort(seq, True)})
+    for nv in (2, 3, 8, 27, 31, 32):
+        di = ref.interactions.DotInteraction(nv - 1, 128)
+        out["tril"][str(nv)] = di._tril_indices.tolist()
+        out["padding"][str(nv)] = {"num_interactions": di.num_interactions,
+                                   "raw": di._raw_num_interactions}
+    with open(os.path.join(GOLD, "dlrm_placement.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+
+    # dot interaction fwd/bwd through the reference's DotInteraction + autograd (fp32 CPU)
+    arrs = {}
+    g = torch.Generator().manual_seed(1234)
+    for (b, r, c) in [(16, 32, 32), (17, 31, 37), (15, 31, 37), (8, 27, 128), (3, 2, 8), (4, 27, 16)]:
+        di = ref.interactions.DotInteraction(r - 1, c)
+        x = torch.rand(b, r, c, generator=g, dtype=torch.float32).requires_grad_()
+        y = di.interact(x, x[:, 0, :])
+        ug = torch.rand(y.shape, generator=g, dtype=torch.float32)
+        y.backward(ug)
+        key = f"{b}x{r}x{c}"
+        arrs[key + "_x"] = x.detach().numpy()
+        arrs[key + "_y"] = y.detach().numpy()
+        arrs[key + "_ug"] = ug.numpy()
+        # total grad wrt x (includes the bottom-mlp slice landing on row 0)
+        arrs[key + "_gx_total"] = x.grad.numpy()
+    np.savez_compressed(os.path.join(GOLD, "dlrm_dot_interact.npz"), **arrs)
+
+    # joint embedding: index + offset (+ hash) arithmetic and the gathered rows
+    sizes = [11, 4, 968, 15, 97, 35, 63, 104]
+    emb = ref.embeddings.JointEmbedding(sizes, 16, device="cpu", hash_indices=True)
+    torch.manual_seed(7)
+    torch.nn.init.uniform_(emb.embedding.weight.data, -1, 1)
+    idx = torch.stack([torch.randint(0, 3 * s, (33,), generator=g) for s in sizes], dim=1)
+    idx_in = idx.clone()
+    out_e = emb(idx)[0]
+    lr = 0.5
+    opt = torch.optim.SGD(emb.parameters(), lr=lr)
+    ug = torch.rand(out_e.shape, generator=g)
+    w0 = emb.embedding.weight.detach().clone()
+    out_e.backward(ug)
+    opt.step()
+    np.savez_compressed(
+        os.path.join(GOLD, "dlrm_embedding.npz"),
+        sizes=np.asarray(sizes), offsets=emb.offsets.numpy(), idx_in=idx_in.numpy(),
+        idx_hashed=idx.numpy(), w0=w0.numpy(), out=out_e.detach().numpy(), ug=ug.numpy(),
+        lr=np.float32(lr), w1=emb.embedding.weight.detach().numpy())
+    print("dlrm golden written")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["dlrm", "lamb", "bert", "rn50"]
+    os.makedirs(GOLD, exist_ok=True)
+    if not R.have_reference():
+        sys.exit("reference not mounted; fixtures are generated in the build container only")
+    for w in which:
+        fn = globals().get("gen_" + w)
+        if fn is None:
+            print("skip", w)
+            continue
+        fn()
