@@ -1,0 +1,117 @@
+"""ctypes binding of libdle_mi355x.so (the C ABI declared in include/dle_mi355x.h).
+
+The product path has NO fallback: if the library is missing or a call fails this raises.
+(The reference's custom ops raise RuntimeError/ValueError through TORCH_CHECK /
+std::invalid_argument, e.g. DLRM/dlrm/cuda_src/sparse_gather/gather_gpu.cu:80-100,
+dot_based_interact_ampere/dot_based_interact_pytorch_types.cu:38,72 -- same behaviour here.)
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdle_mi355x.so")
+
+F32, F16, BF16 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD = 0, 1, 2, 3
+
+_DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+
+c_void_p, c_int, c_i64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/dle_mi355x.h one to one
+_SIGS = {
+    "dle_last_error": (ctypes.c_char_p, []),
+    "dle_abi_version": (c_int, []),
+    "dle_device_check": (c_int, [c_int, ctypes.c_char_p, c_int]),
+    "dle_dot_interact_out_width": (c_int, [c_int, c_int]),
+    "dle_dot_interact_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dle_dot_interact_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                     c_int, c_void_p]),
+    "dle_emb_gather_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int,
+                                   c_int, c_void_p]),
+    "dle_emb_offset_indices": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+    "dle_emb_grad_values": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+    "dle_emb_sparse_sgd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                   c_i64, c_int, c_int, c_void_p]),
+    "dle_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                         c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                         c_void_p]),
+    "dle_colsum": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p]),
+    "dle_mt_table_len": (c_i64, [c_int, c_int]),
+    "dle_mt_table_fill": (c_i64, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]),
+    "dle_mt_l2norm": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                              c_void_p, c_void_p]),
+    "dle_mt_lamb_stage1": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_void_p, c_float, c_float, c_float,
+                                   c_void_p, c_int, c_float, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                   c_void_p]),
+    "dle_mt_lamb_stage2": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_float, c_int, c_void_p]),
+    "dle_mt_sgd": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float,
+                           c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class DleError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises loudly when the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DleError(
+                "libdle_mi355x.so is not built (%s). Run `python -m deeplearningexamples_amd.build` "
+                "or __graft_entry__.build(); there is no CPU/eager fallback." % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(h, name)          # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def dt(t_or_dtype):
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    try:
+        return _DT[d]
+    except KeyError:
+        raise ValueError("unsupported dtype %s (f32/f16/bf16 only)" % d)
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    msg = lib().dle_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError("%s: %s" % (what, msg))
+    raise DleError("%s failed (hip error %d): %s" % (what, rc, msg))
+
+
+def call(name, *args):
+    rc = getattr(lib(), name)(*args)
+    check(rc, name)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise DleError("deeplearningexamples_amd ops run on the MI355X only (got a %s tensor); "
+                           "there is no CPU fallback in the product path" % t.device)

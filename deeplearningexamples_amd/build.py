@@ -1,0 +1,71 @@
+"""Build recipe for the gfx950 C-ABI library (explicit hipcc, in-tree, incremental).
+
+    python -m deeplearningexamples_amd.build [--force]
+
+Produces deeplearningexamples_amd/lib/libdle_mi355x.so from csrc/*.hip.  hipcc cross-compiles
+for gfx950 without a GPU present, so this also runs in the CPU-only build container.
+"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "lib", "obj")
+LIB = os.path.join(HERE, "lib", "libdle_mi355x.so")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+         "-Wno-unused-result", "-DNDEBUG"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, src[:-4] + ".o")
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    if not force and not _stale(obj, [os.path.join(CSRC, src)] + headers):
+        return obj, False
+    cmd = [hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout[-4000:], r.stderr[-8000:]))
+    return obj, True
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sources()
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        res = list(ex.map(lambda s: _compile(s, force), srcs))
+    objs = [o for o, _ in res]
+    if any(c for _, c in res) or _stale(LIB, objs):
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stderr[-8000:])
+        if verbose:
+            print("built", LIB, "(%d objects, %d recompiled)" % (len(objs), sum(c for _, c in res)))
+    elif verbose:
+        print("up to date:", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

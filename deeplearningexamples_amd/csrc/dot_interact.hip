@@ -1,0 +1,344 @@
+// DLRM dot-based feature interaction, forward + backward, for gfx950 (wave64 + MFMA).
+//
+// Replaces the reference's warp-32 WMMA kernels
+//   DLRM/dlrm/cuda_src/dot_based_interact/dot_based_interact_fp16_fwd.cu:160-271
+//   DLRM/dlrm/cuda_src/dot_based_interact/dot_based_interact_fp16_bwd.cu:180-332
+//   (+ the fp32 FMA kernels dot_based_interact_fp32_{fwd,bwd}.cu) behind
+//   dlrm.cuda_ext.interaction_*.dotBasedInteract{Fwd,Bwd}
+//   (dot_based_interact_ampere/pytorch_ops.cpp:3-12).
+//
+// Design (MI355X-first, not a translation):
+//  * one 64-lane wavefront owns one sample; 4 samples per 256-thread workgroup.
+//  * forward: Z = X X^T with v_mfma_f32_32x32x16.  A and B fragments of X X^T are the SAME
+//    registers (lane l holds row l&31, 8 consecutive columns) so X is loaded straight from
+//    HBM into MFMA operands -- no LDS staging of the input at all.  The 480-wide output row
+//    (bottom-mlp copy | strict lower triangle | zero pad) is assembled in LDS and leaves as
+//    one coalesced 16 B/lane store.
+//  * backward: grad = U_sym X (M=32, N=C, K=32).  U_sym (symmetric, zero diagonal) is built
+//    in LDS from the flat upstream gradient, X is staged once in LDS with coalesced 16 B
+//    loads and the K-strided B fragments are gathered from LDS; the result is re-staged in
+//    LDS so that HBM sees only full-width coalesced stores.
+//  * HBM-bound op: algorithmic bytes/sample fwd = R*C*e + OW*e, bwd = 2*R*C*e + OW*e + C*e.
+//  * shapes outside the MFMA envelope (R>32, C%16 (fwd) / C%32 (bwd) != 0, fp32) take a generic
+//    LDS kernel with fp32 FMA (still one workgroup per sample).
+#include "common.h"
+
+template <int DT> struct Mfma32;
+template <> struct Mfma32<DLE_F16> {
+  static __device__ __forceinline__ float16_t run(ushort8_t a, ushort8_t b, float16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a),
+                                                  __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma32<DLE_BF16> {
+  static __device__ __forceinline__ float16_t run(ushort8_t a, ushort8_t b, float16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+// strict-lower-triangle linear index t -> (i, j), i > j, row-major (interactions.py:50-53)
+__device__ __forceinline__ void tril_unrank(int t, int& i, int& j) {
+  int r = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)t)) * 0.5f);
+  while (r * (r - 1) / 2 > t) --r;
+  while ((r + 1) * r / 2 <= t) ++r;
+  i = r;
+  j = t - r * (r - 1) / 2;
+}
+
+// ------------------------------------------------------------------ forward, MFMA path
+// requires R <= 32, C % 16 == 0, OW % 8 == 0, 16-byte aligned x/out.
+template <int DT>
+__global__ __launch_bounds__(256) void dot_fwd_mfma(const unsigned short* __restrict__ x,
+                                                    unsigned short* __restrict__ out, int B, int R,
+                                                    int C, int OW) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  unsigned short* so = (unsigned short*)smem_raw + (size_t)wave * OW;
+  const int row = lane & 31, h = lane >> 5;
+  if (b < B) {
+    const unsigned short* xr = x + ((size_t)b * R + row) * C + h * 8;
+    float16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool live = row < R;
+    for (int k0 = 0; k0 < C; k0 += 16) {
+      ushort8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (live) v = *(const ushort8_t*)(xr + k0);
+      acc = Mfma32<DT>::run(v, v, acc);
+      if (row == 0) *(ushort8_t*)(so + k0 + h * 8) = v;   // bottom-MLP slice = row 0 of X
+    }
+    // strict lower triangle straight from the accumulator registers
+    // 32x32 C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int j = row;
+      if (i < R && j < i) so[C + i * (i - 1) / 2 + j] = Elem<DT>::from_f32(acc[r]);
+    }
+    const int ntril = R * (R - 1) / 2;
+    for (int p = C + ntril + lane; p < OW; p += 64) so[p] = 0;
+  }
+  __syncthreads();
+  if (b < B) {
+    unsigned short* o = out + (size_t)b * OW;
+    for (int q = lane * 8; q < OW; q += 512) *(ushort8_t*)(o + q) = *(const ushort8_t*)(so + q);
+  }
+}
+
+// ------------------------------------------------------------------ backward, MFMA path
+// requires R <= 32, C % 32 == 0, C <= 256, OW % 8 == 0.
+#define DOT_BWD_USTRIDE 40   // halves per U row (32 + 8 pad -> 80 B, keeps 16 B alignment)
+template <int DT>
+__global__ __launch_bounds__(256) void dot_bwd_mfma(const unsigned short* __restrict__ x,
+                                                    const unsigned short* __restrict__ ug,
+                                                    unsigned short* __restrict__ grad,
+                                                    unsigned short* __restrict__ mlp_grad, int B,
+                                                    int R, int C, int OW) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  const int XS = C + 8;                                  // halves per staged X row
+  const size_t per_wave = (size_t)32 * XS + 32 * DOT_BWD_USTRIDE;
+  unsigned short* xs = (unsigned short*)smem_raw + wave * per_wave;
+  unsigned short* us = xs + 32 * XS;
+  const int row = lane & 31, h = lane >> 5;
+  const bool act = b < B;
+  const int ntril = R * (R - 1) / 2;
+  if (act) {
+    // stage X (coalesced 16 B per lane), zero the pad rows R..31, zero U
+    const unsigned short* xb = x + (size_t)b * R * C;
+    const int cpr = C >> 3;                              // 16-byte chunks per row
+    for (int q = lane; q < 32 * cpr; q += 64) {
+      const int rr = q / cpr, cc = q - rr * cpr;
+      ushort8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (rr < R) v = *(const ushort8_t*)(xb + (size_t)rr * C + cc * 8);
+      *(ushort8_t*)(xs + rr * XS + cc * 8) = v;
+    }
+    for (int q = lane; q < 32 * DOT_BWD_USTRIDE / 8; q += 64) {
+      ushort8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+      *(ushort8_t*)(us + q * 8) = z;
+    }
+    // bottom-MLP gradient = first C entries of the upstream gradient
+    const unsigned short* ub = ug + (size_t)b * OW;
+    unsigned short* mg = mlp_grad + (size_t)b * C;
+    for (int q = lane * 8; q < C; q += 512) *(ushort8_t*)(mg + q) = *(const ushort8_t*)(ub + q);
+  }
+  __syncthreads();
+  if (act) {
+    const unsigned short* ub = ug + (size_t)b * OW + C;
+    for (int t = lane; t < ntril; t += 64) {
+      int i, j;
+      tril_unrank(t, i, j);
+      const unsigned short v = ub[t];
+      us[i * DOT_BWD_USTRIDE + j] = v;
+      us[j * DOT_BWD_USTRIDE + i] = v;
+    }
+  }
+  __syncthreads();
+  const int nb_n = C >> 5;   // 32-wide column blocks (<= 8)
+  float16_t acc[8];
+  if (act) {
+    ushort8_t a0 = *(const ushort8_t*)(us + row * DOT_BWD_USTRIDE + h * 8);
+    ushort8_t a1 = *(const ushort8_t*)(us + row * DOT_BWD_USTRIDE + 16 + h * 8);
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      if (nb < nb_n) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        ushort8_t b0, b1;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          b0[p] = xs[(h * 8 + p) * XS + nb * 32 + row];
+          b1[p] = xs[(16 + h * 8 + p) * XS + nb * 32 + row];
+        }
+        acc[nb] = Mfma32<DT>::run(a0, b0, acc[nb]);
+        acc[nb] = Mfma32<DT>::run(a1, b1, acc[nb]);
+      }
+    }
+  }
+  __syncthreads();   // every B-fragment read is done: reuse xs as the output stage
+  if (act) {
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      if (nb < nb_n) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+          xs[i * XS + nb * 32 + row] = Elem<DT>::from_f32(acc[nb][r]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (act) {
+    unsigned short* gb = grad + (size_t)b * R * C;
+    const int cpr = C >> 3;
+    for (int q = lane; q < R * cpr; q += 64) {
+      const int rr = q / cpr, cc = q - rr * cpr;
+      *(ushort8_t*)(gb + (size_t)rr * C + cc * 8) = *(const ushort8_t*)(xs + rr * XS + cc * 8);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ generic path (any R, C, dtype)
+template <int DT> struct IO;
+template <> struct IO<DLE_F32> {
+  typedef float T;
+  static __device__ __forceinline__ float ld(const T* p) { return *p; }
+  static __device__ __forceinline__ void st(T* p, float v) { *p = v; }
+};
+template <> struct IO<DLE_F16> {
+  typedef unsigned short T;
+  static __device__ __forceinline__ float ld(const T* p) { return Elem<DLE_F16>::to_f32(*p); }
+  static __device__ __forceinline__ void st(T* p, float v) { *p = Elem<DLE_F16>::from_f32(v); }
+};
+template <> struct IO<DLE_BF16> {
+  typedef unsigned short T;
+  static __device__ __forceinline__ float ld(const T* p) { return Elem<DLE_BF16>::to_f32(*p); }
+  static __device__ __forceinline__ void st(T* p, float v) { *p = Elem<DLE_BF16>::from_f32(v); }
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void dot_fwd_generic(const typename IO<DT>::T* __restrict__ x,
+                                                       typename IO<DT>::T* __restrict__ out, int B,
+                                                       int R, int C, int OW) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* xs = (float*)smem_raw;
+  const int b = blockIdx.x;
+  const typename IO<DT>::T* xb = x + (size_t)b * R * C;
+  typename IO<DT>::T* ob = out + (size_t)b * OW;
+  const int CP = C | 1;   // odd LDS row stride: conflict-free row-pair dot products
+  for (int q = threadIdx.x; q < R * C; q += blockDim.x) {
+    const int rr = q / C, cc = q - rr * C;
+    xs[rr * CP + cc] = IO<DT>::ld(xb + q);
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < C; q += blockDim.x) IO<DT>::st(ob + q, xs[q]);
+  const int ntril = R * (R - 1) / 2;
+  for (int t = threadIdx.x; t < ntril; t += blockDim.x) {
+    int i, j;
+    tril_unrank(t, i, j);
+    const float* a = xs + i * CP;
+    const float* c = xs + j * CP;
+    float s = 0.f;
+    for (int k = 0; k < C; ++k) s = fmaf(a[k], c[k], s);
+    IO<DT>::st(ob + C + t, s);
+  }
+  for (int p = C + ntril + threadIdx.x; p < OW; p += blockDim.x) IO<DT>::st(ob + p, 0.f);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void dot_bwd_generic(const typename IO<DT>::T* __restrict__ x,
+                                                       const typename IO<DT>::T* __restrict__ ug,
+                                                       typename IO<DT>::T* __restrict__ grad,
+                                                       typename IO<DT>::T* __restrict__ mlp_grad,
+                                                       int B, int R, int C, int OW) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* xs = (float*)smem_raw;        // [R][C]
+  float* us = xs + R * C;              // [R][R] symmetric, zero diagonal
+  const int b = blockIdx.x;
+  const typename IO<DT>::T* xb = x + (size_t)b * R * C;
+  const typename IO<DT>::T* ub = ug + (size_t)b * OW;
+  for (int q = threadIdx.x; q < R * C; q += blockDim.x) xs[q] = IO<DT>::ld(xb + q);
+  for (int q = threadIdx.x; q < R * R; q += blockDim.x) us[q] = 0.f;
+  for (int q = threadIdx.x; q < C; q += blockDim.x) IO<DT>::st(mlp_grad + (size_t)b * C + q, IO<DT>::ld(ub + q));
+  __syncthreads();
+  const int ntril = R * (R - 1) / 2;
+  for (int t = threadIdx.x; t < ntril; t += blockDim.x) {
+    int i, j;
+    tril_unrank(t, i, j);
+    const float v = IO<DT>::ld(ub + C + t);
+    us[i * R + j] = v;
+    us[j * R + i] = v;
+  }
+  __syncthreads();
+  typename IO<DT>::T* gb = grad + (size_t)b * R * C;
+  for (int q = threadIdx.x; q < R * C; q += blockDim.x) {
+    const int i = q / C, c = q - i * C;
+    float s = 0.f;
+    for (int k = 0; k < R; ++k) s = fmaf(us[i * R + k], xs[k * C + c], s);
+    IO<DT>::st(gb + q, s);
+  }
+}
+
+// ------------------------------------------------------------------ C ABI
+static int out_width(int R, int C) {
+  const int raw = R * (R - 1) / 2 + C;
+  return ((raw - 1) / 8 + 1) * 8;
+}
+
+extern "C" int dle_dot_interact_out_width(int rows, int cols) { return out_width(rows, cols); }
+
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+extern "C" int dle_dot_interact_fwd(const void* x, void* out, int batch, int rows, int cols,
+                                    int dtype, int force_generic, hipStream_t stream) {
+  DLE_CHECK_ARG(x && out, "dot_interact_fwd: null pointer");
+  DLE_CHECK_ARG(batch >= 0 && rows >= 1 && cols >= 1, "dot_interact_fwd: bad shape %d %d %d", batch, rows, cols);
+  DLE_CHECK_ARG(dtype == DLE_F32 || dtype == DLE_F16 || dtype == DLE_BF16, "dot_interact_fwd: bad dtype %d", dtype);
+  if (batch == 0) return 0;
+  const int OW = out_width(rows, cols);
+  const bool fast = !force_generic && dtype != DLE_F32 && rows <= 32 && (cols % 16) == 0 &&
+                    aligned16(x) && aligned16(out);
+  if (fast) {
+    const size_t lds = (size_t)4 * OW * 2;
+    DLE_CHECK_ARG(lds <= 64 * 1024, "dot_interact_fwd: row too wide for LDS (%d)", OW);
+    dim3 grid((batch + 3) / 4), block(256);
+    if (dtype == DLE_F16)
+      hipLaunchKernelGGL(dot_fwd_mfma<DLE_F16>, grid, block, lds, stream, (const unsigned short*)x,
+                         (unsigned short*)out, batch, rows, cols, OW);
+    else
+      hipLaunchKernelGGL(dot_fwd_mfma<DLE_BF16>, grid, block, lds, stream, (const unsigned short*)x,
+                         (unsigned short*)out, batch, rows, cols, OW);
+  } else {
+    const size_t lds = (size_t)rows * (cols | 1) * 4;
+    DLE_CHECK_ARG(lds <= 64 * 1024, "dot_interact_fwd: sample does not fit LDS (%d x %d)", rows, cols);
+    dim3 grid(batch), block(256);
+    if (dtype == DLE_F32)
+      hipLaunchKernelGGL(dot_fwd_generic<DLE_F32>, grid, block, lds, stream, (const float*)x, (float*)out, batch, rows, cols, OW);
+    else if (dtype == DLE_F16)
+      hipLaunchKernelGGL(dot_fwd_generic<DLE_F16>, grid, block, lds, stream, (const unsigned short*)x, (unsigned short*)out, batch, rows, cols, OW);
+    else
+      hipLaunchKernelGGL(dot_fwd_generic<DLE_BF16>, grid, block, lds, stream, (const unsigned short*)x, (unsigned short*)out, batch, rows, cols, OW);
+  }
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dle_dot_interact_bwd(const void* x, const void* upstream, void* grad, void* mlp_grad,
+                                    int batch, int rows, int cols, int dtype, int force_generic,
+                                    hipStream_t stream) {
+  DLE_CHECK_ARG(x && upstream && grad && mlp_grad, "dot_interact_bwd: null pointer");
+  DLE_CHECK_ARG(batch >= 0 && rows >= 1 && cols >= 1, "dot_interact_bwd: bad shape %d %d %d", batch, rows, cols);
+  DLE_CHECK_ARG(dtype == DLE_F32 || dtype == DLE_F16 || dtype == DLE_BF16, "dot_interact_bwd: bad dtype %d", dtype);
+  if (batch == 0) return 0;
+  const int OW = out_width(rows, cols);
+  const bool fast = !force_generic && dtype != DLE_F32 && rows <= 32 && (cols % 32) == 0 && cols <= 256 &&
+                    aligned16(x) && aligned16(upstream) && aligned16(grad) && aligned16(mlp_grad);
+  if (fast) {
+    const size_t lds = (size_t)4 * (32 * (cols + 8) + 32 * DOT_BWD_USTRIDE) * 2;
+    dim3 grid((batch + 3) / 4), block(256);
+    if (dtype == DLE_F16)
+      hipLaunchKernelGGL(dot_bwd_mfma<DLE_F16>, grid, block, lds, stream, (const unsigned short*)x,
+                         (const unsigned short*)upstream, (unsigned short*)grad, (unsigned short*)mlp_grad,
+                         batch, rows, cols, OW);
+    else
+      hipLaunchKernelGGL(dot_bwd_mfma<DLE_BF16>, grid, block, lds, stream, (const unsigned short*)x,
+                         (const unsigned short*)upstream, (unsigned short*)grad, (unsigned short*)mlp_grad,
+                         batch, rows, cols, OW);
+  } else {
+    const size_t lds = ((size_t)rows * cols + (size_t)rows * rows) * 4;
+    DLE_CHECK_ARG(lds <= 64 * 1024, "dot_interact_bwd: sample does not fit LDS (%d x %d)", rows, cols);
+    dim3 grid(batch), block(256);
+    if (dtype == DLE_F32)
+      hipLaunchKernelGGL(dot_bwd_generic<DLE_F32>, grid, block, lds, stream, (const float*)x, (const float*)upstream, (float*)grad, (float*)mlp_grad, batch, rows, cols, OW);
+    else if (dtype == DLE_F16)
+      hipLaunchKernelGGL(dot_bwd_generic<DLE_F16>, grid, block, lds, stream, (const unsigned short*)x, (const unsigned short*)upstream, (unsigned short*)grad, (unsigned short*)mlp_grad, batch, rows, cols, OW);
+    else
+      hipLaunchKernelGGL(dot_bwd_generic<DLE_BF16>, grid, block, lds, stream, (const unsigned short*)x, (const unsigned short*)upstream, (unsigned short*)grad, (unsigned short*)mlp_grad, batch, rows, cols, OW);
+  }
+  DLE_LAUNCH_CHECK();
+  return 0;
+}

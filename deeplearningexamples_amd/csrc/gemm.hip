@@ -1,0 +1,391 @@
+// MFMA GEMM with fused epilogues for gfx950 -- the dense contraction behind every Linear /
+// MLP layer of the hot path (BERT/modeling.py:130-165,316-318 Linear + bias + GELU;
+// DLRM apex mlp_cuda F1 = (GEMM + bias + ReLU) x L, DLRM/dlrm/nn/mlps.py:18-43; RN50 FC and the
+// 1x1 convolutions in NHWC, which are plain GEMMs).
+//
+//   C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )
+//
+// Operand storage (element (m,k) of A, (n,k) of B):
+//   A_KC = true : A stored [M][lda]  (k contiguous)      A_KC = false : A stored [K][lda] (m contiguous)
+//   B_KC = true : B stored [N][ldb]  (k contiguous)      B_KC = false : B stored [K][ldb] (n contiguous)
+// which covers forward  Y = X W^T          (A_KC, B_KC)
+//              dgrad    dX = dY W          (A_KC, !B_KC)
+//              wgrad    dW = dY^T X        (!A_KC, !B_KC)   -- no transposed copies in HBM.
+//
+// Structure (wave64 / CDNA4):
+//  * 128x128 output tile, BK = 64, 256 threads = 4 wavefronts in 2x2, 64x64 per wavefront as
+//    4x4 v_mfma_f32_16x16x32 tiles (64 fp32 accumulator VGPRs per lane).
+//  * LDS tiles are [row][64 k] halves (128 B rows) with the 16-byte chunk index XOR-swizzled by
+//    f(row) = (row ^ row>>3) & 7, so ds_read_b128 fragment reads and both loader kinds stay
+//    (almost) bank-conflict free; two LDS stages (64 KiB) -> 2 workgroups per CU.
+//  * register-staged software pipeline: the global loads of tile t+1 are issued before the MFMA
+//    block of tile t and written to the other LDS stage afterwards (one barrier per K-tile).
+//  * m/n-contiguous operands (dgrad/wgrad) are transposed on the fly: each thread loads 4 k-rows x
+//    8 elements and emits 8 ds_write_b64 (4 consecutive k for one row).
+//  * the MFMA is issued with swapped operands so every lane owns 4 consecutive output columns
+//    (8 B / 16 B stores); bias, ReLU, tanh-GELU (+ pre-activation side output), ReLU-backward
+//    masking, fp32 accumulation and split-K (fp32 atomics) are fused in the epilogue.
+//  * workgroup ids are remapped so the 8 XCDs each walk a contiguous band of tiles (private L2s).
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3 };
+
+struct GemmArgs {
+  const unsigned short* A;
+  const unsigned short* B;
+  void* C;
+  void* aux;                       // optional pre-activation output (same dtype/ld as C)
+  const float* bias;               // optional fp32 bias[N]
+  const unsigned short* mask_src;  // ACT_RELU_BWD: forward activation output, same shape/ld as C
+  int M, N, K;
+  long long lda, ldb, ldc;
+  int out_dtype;                   // DLE_F32 / DLE_F16 / DLE_BF16
+  int act;
+  int splitk;
+  int accumulate;                  // C += result (fp32 output only)
+  float alpha;
+};
+
+template <int DT> struct Mfma16;
+template <> struct Mfma16<DLE_F16> {
+  static __device__ __forceinline__ float4_t run(ushort8_t a, ushort8_t b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a),
+                                                  __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma16<DLE_BF16> {
+  static __device__ __forceinline__ float4_t run(ushort8_t a, ushort8_t b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
+
+// 8 consecutive elements along the contiguous dimension starting at p[0]; `n_valid` of them
+// are inside the matrix (0..8); vec = the 16-byte fast path is legal for this launch.
+__device__ __forceinline__ ushort8_t load8(const unsigned short* p, int n_valid, bool vec) {
+  ushort8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (n_valid >= 8 && vec) {
+    v = *(const ushort8_t*)p;
+  } else if (n_valid > 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < n_valid) v[j] = p[j];
+  }
+  return v;
+}
+
+// ---- tile loaders: global -> registers (4 x 16 B per thread per operand) ------------------
+// k-contiguous operand: rows = tile rows (m or n), ld = row stride.
+__device__ __forceinline__ void gload_kc(ushort8_t (&r)[4], const unsigned short* base, long long ld,
+                                         int row0, int nrows, int k0, int kend, bool vec) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int q = threadIdx.x + it * 256;
+    const int row = q >> 3, ch = q & 7;
+    const int g = row0 + row, gk = k0 + ch * 8;
+    int nv = kend - gk;
+    if (g >= nrows) nv = 0;
+    r[it] = load8(base + (long long)g * ld + gk, nv, vec);
+  }
+}
+__device__ __forceinline__ void swrite_kc(const ushort8_t (&r)[4], unsigned short* tile) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int q = threadIdx.x + it * 256;
+    const int row = q >> 3, ch = q & 7;
+    *(ushort8_t*)(tile + row * BK + ((ch ^ swz(row)) << 3)) = r[it];
+  }
+}
+// row-contiguous (transposed) operand: stored [K][ld], tile rows along the contiguous dim.
+__device__ __forceinline__ void gload_tr(ushort8_t (&r)[4], const unsigned short* base, long long ld,
+                                         int row0, int nrows, int k0, int kend, bool vec) {
+  const int kg = threadIdx.x & 15, mc = threadIdx.x >> 4;
+  const int g0 = row0 + mc * 8;
+  const int nv_row = nrows - g0;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int gk = k0 + kg * 4 + rr;
+    r[rr] = load8(base + (long long)gk * ld + g0, gk < kend ? nv_row : 0, vec);
+  }
+}
+__device__ __forceinline__ void swrite_tr(const ushort8_t (&r)[4], unsigned short* tile) {
+  const int kg = threadIdx.x & 15, mc = threadIdx.x >> 4;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int row = mc * 8 + j;
+    ushort4_t w = {r[0][j], r[1][j], r[2][j], r[3][j]};
+    *(ushort4_t*)(tile + row * BK + ((((kg >> 1) ^ swz(row))) << 3) + ((kg & 1) << 2)) = w;
+  }
+}
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  const float u = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+
+template <int DT, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* lds = (unsigned short*)smem_raw;   // [2 stages][A tile | B tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile walk: blocks b, b+8, b+16.. share an XCD -> give each XCD a contiguous band
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int ntiles = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // split-K range (multiples of BK)
+  const int ktiles = (p.K + BK - 1) / BK;
+  const int per = (ktiles + p.splitk - 1) / p.splitk;
+  const int kt0 = blockIdx.y * per;
+  int kt1 = kt0 + per;
+  if (kt1 > ktiles) kt1 = ktiles;
+  if (kt0 >= kt1 && p.splitk > 1) return;
+  const int kend = (kt1 * BK < p.K) ? kt1 * BK : p.K;
+
+  const bool vecA = ((p.lda & 7) == 0) && ((((uintptr_t)p.A) & 15) == 0);
+  const bool vecB = ((p.ldb & 7) == 0) && ((((uintptr_t)p.B) & 15) == 0);
+
+  float4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+  ushort8_t ra[4], rb[4];
+  auto issue = [&](int kt) {
+    const int k0 = kt * BK;
+    if (A_KC) gload_kc(ra, p.A, p.lda, m0, p.M, k0, kend, vecA);
+    else gload_tr(ra, p.A, p.lda, m0, p.M, k0, kend, vecA);
+    if (B_KC) gload_kc(rb, p.B, p.ldb, n0, p.N, k0, kend, vecB);
+    else gload_tr(rb, p.B, p.ldb, n0, p.N, k0, kend, vecB);
+  };
+  auto commit = [&](int stage) {
+    unsigned short* ta = lds + stage * (BM * BK + BN * BK);
+    unsigned short* tb = ta + BM * BK;
+    if (A_KC) swrite_kc(ra, ta); else swrite_tr(ra, ta);
+    if (B_KC) swrite_kc(rb, tb); else swrite_tr(rb, tb);
+  };
+
+  if (kt0 < kt1) {
+    issue(kt0);
+    commit(0);
+  }
+  __syncthreads();
+
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int stage = (kt - kt0) & 1;
+    if (kt + 1 < kt1) issue(kt + 1);
+    const unsigned short* ta = lds + stage * (BM * BK + BN * BK);
+    const unsigned short* tb = ta + BM * BK;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      ushort8_t fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + fr;
+        fa[i] = *(const ushort8_t*)(ta + row * BK + (((kk * 4 + fg) ^ swz(row)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wn * 64 + j * 16 + fr;
+        fb[j] = *(const ushort8_t*)(tb + row * BK + (((kk * 4 + fg) ^ swz(row)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Mfma16<DT>::run(fb[j], fa[i], acc[i][j]);
+    }
+    if (kt + 1 < kt1) commit(stage ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns C[m][n..n+3], m = fr-th row of the 16x16 tile, n = 4*fg + r
+  const bool vec_c = (p.ldc & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fg * 4;
+      if (n >= p.N) continue;
+      float4_t v = acc[i][j] * p.alpha;
+      const int nval = (p.N - n) < 4 ? (p.N - n) : 4;
+      const long long off = (long long)m * p.ldc + n;
+      if (p.splitk > 1) {
+        float* c = (float*)p.C + off;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < nval) unsafeAtomicAdd(c + r, v[r]);
+        continue;
+      }
+      if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < nval) v[r] += p.bias[n + r];
+      }
+      float4_t pre = v;
+      if (p.act == ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+      } else if (p.act == ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+      } else if (p.act == ACT_RELU_BWD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < nval) {
+            const float y = DT == DLE_F16 ? Elem<DLE_F16>::to_f32(p.mask_src[off + r])
+                                          : Elem<DLE_BF16>::to_f32(p.mask_src[off + r]);
+            v[r] = y > 0.f ? v[r] : 0.f;
+          }
+      }
+      if (p.out_dtype == DLE_F32) {
+        float* c = (float*)p.C + off;
+        if (p.accumulate) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < nval) v[r] += c[r];
+        }
+        if (nval == 4 && vec_c) *(float4_t*)c = v;
+        else
+          for (int r = 0; r < nval; ++r) c[r] = v[r];
+        if (p.aux) {
+          float* a = (float*)p.aux + off;
+          for (int r = 0; r < nval; ++r) a[r] = pre[r];
+        }
+      } else {
+        ushort4_t o, po;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (p.out_dtype == DLE_F16) { o[r] = Elem<DLE_F16>::from_f32(v[r]); po[r] = Elem<DLE_F16>::from_f32(pre[r]); }
+          else { o[r] = Elem<DLE_BF16>::from_f32(v[r]); po[r] = Elem<DLE_BF16>::from_f32(pre[r]); }
+        }
+        unsigned short* c = (unsigned short*)p.C + off;
+        if (nval == 4 && vec_c) *(ushort4_t*)c = o;
+        else
+          for (int r = 0; r < nval; ++r) c[r] = o[r];
+        if (p.aux) {
+          unsigned short* a = (unsigned short*)p.aux + off;
+          if (nval == 4 && vec_c) *(ushort4_t*)a = po;
+          else
+            for (int r = 0; r < nval; ++r) a[r] = po[r];
+        }
+      }
+    }
+  }
+}
+
+// ---- column sums: out[n] (+)= sum_m X[m][n]   (bias gradients), 16-bit or fp32 input -> fp32
+template <int DT>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, float* __restrict__ out,
+                                                     long long M, int N, long long ld, long long rows_per_block) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  float s = 0.f;
+  if (c < N) {
+    for (long long r = r0 + rl; r < r1; r += 4) {
+      if (DT == DLE_F32) s += ((const float*)x)[r * ld + c];
+      else if (DT == DLE_F16) s += Elem<DLE_F16>::to_f32(((const unsigned short*)x)[r * ld + c]);
+      else s += Elem<DLE_BF16>::to_f32(((const unsigned short*)x)[r * ld + c]);
+    }
+  }
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    unsafeAtomicAdd(out + c, t);
+  }
+}
+
+extern "C" int dle_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype,
+                          int accumulate, hipStream_t stream) {
+  DLE_CHECK_ARG(x && out && N > 0 && M >= 0, "colsum: bad args");
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)N * 4, stream);
+    if (e != hipSuccess) { dle_set_error("colsum memset: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  if (M == 0) return 0;
+  long long rpb = 512;
+  long long gy = (M + rpb - 1) / rpb;
+  if (gy > 1024) { gy = 1024; rpb = (M + gy - 1) / gy; }
+  dim3 grid((N + 63) / 64, (unsigned)gy), block(256);
+  if (dtype == DLE_F32) hipLaunchKernelGGL(colsum_kernel<DLE_F32>, grid, block, 0, stream, x, out, (long long)M, N, (long long)ld, rpb);
+  else if (dtype == DLE_F16) hipLaunchKernelGGL(colsum_kernel<DLE_F16>, grid, block, 0, stream, x, out, (long long)M, N, (long long)ld, rpb);
+  else if (dtype == DLE_BF16) hipLaunchKernelGGL(colsum_kernel<DLE_BF16>, grid, block, 0, stream, x, out, (long long)M, N, (long long)ld, rpb);
+  else { dle_set_error("colsum: bad dtype %d", dtype); return -1; }
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// C ABI.  a_kc / b_kc: operand stored with the contraction dimension contiguous (see header).
+extern "C" int dle_gemm(const void* A, const void* B, void* C, void* aux, const float* bias,
+                        const void* mask_src, int M, int N, int K, int64_t lda, int64_t ldb,
+                        int64_t ldc, int a_kc, int b_kc, int in_dtype, int out_dtype, int act,
+                        int splitk, int accumulate, float alpha, hipStream_t stream) {
+  DLE_CHECK_ARG(A && B && C, "gemm: null pointer");
+  DLE_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "gemm: negative dimension");
+  DLE_CHECK_ARG(in_dtype == DLE_F16 || in_dtype == DLE_BF16, "gemm: inputs must be f16/bf16 (got %d)", in_dtype);
+  DLE_CHECK_ARG(out_dtype == DLE_F32 || out_dtype == DLE_F16 || out_dtype == DLE_BF16, "gemm: bad out dtype");
+  DLE_CHECK_ARG(!(a_kc == 0 && b_kc != 0), "gemm: (A m-contiguous, B k-contiguous) is not a hot-path layout");
+  DLE_CHECK_ARG(act != ACT_RELU_BWD || mask_src, "gemm: ACT_RELU_BWD needs mask_src");
+  DLE_CHECK_ARG(act != ACT_RELU_BWD || out_dtype == in_dtype, "gemm: ACT_RELU_BWD mask dtype = in dtype = out dtype");
+  if (splitk < 1) splitk = 1;
+  if (splitk > 1) {
+    DLE_CHECK_ARG(out_dtype == DLE_F32 && !bias && act == ACT_NONE && !aux, "gemm: split-K needs a plain fp32 output");
+    if (!accumulate) {
+      // rows may be strided: clear row by row only when ldc != N
+      if (ldc == N) {
+        hipError_t e = hipMemsetAsync(C, 0, (size_t)M * N * 4, stream);
+        if (e != hipSuccess) { dle_set_error("gemm memset: %s", hipGetErrorString(e)); return (int)e; }
+      } else {
+        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, stream);
+        if (e != hipSuccess) { dle_set_error("gemm memset2d: %s", hipGetErrorString(e)); return (int)e; }
+      }
+    }
+  } else {
+    DLE_CHECK_ARG(!accumulate || out_dtype == DLE_F32, "gemm: accumulate needs fp32 output");
+  }
+  if (M == 0 || N == 0) return 0;
+  GemmArgs p;
+  p.A = (const unsigned short*)A; p.B = (const unsigned short*)B; p.C = C; p.aux = aux; p.bias = bias;
+  p.mask_src = (const unsigned short*)mask_src;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.out_dtype = out_dtype; p.act = act; p.splitk = splitk; p.accumulate = accumulate; p.alpha = alpha;
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  dim3 grid(tiles, splitk), block(256);
+  const size_t lds = 2 * (BM * BK + BN * BK) * 2;
+#define GO(DT, AK, BKC) hipLaunchKernelGGL((gemm_kernel<DT, AK, BKC>), grid, block, lds, stream, p)
+  if (in_dtype == DLE_F16) {
+    if (a_kc && b_kc) GO(DLE_F16, true, true);
+    else if (a_kc) GO(DLE_F16, true, false);
+    else GO(DLE_F16, false, false);
+  } else {
+    if (a_kc && b_kc) GO(DLE_BF16, true, true);
+    else if (a_kc) GO(DLE_BF16, true, false);
+    else GO(DLE_BF16, false, false);
+  }
+#undef GO
+  DLE_LAUNCH_CHECK();
+  return 0;
+}

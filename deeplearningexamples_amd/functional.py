@@ -1,0 +1,177 @@
+"""Thin tensor-level wrappers over the C ABI (allocation + argument marshalling only).
+
+Every function here launches hand-written HIP kernels from libdle_mi355x.so on the current
+torch stream; there is no eager fallback.  torch is used for memory, streams and autograd plumbing.
+"""
+import torch
+
+from . import _cabi as C
+
+
+# ------------------------------------------------------------------ DLRM dot interaction
+def dot_interact_out_width(rows, cols):
+    return C.lib().dle_dot_interact_out_width(rows, cols)
+
+
+def dot_interact_fwd(x, force_generic=False):
+    """x [B,R,C] -> [B, ceil8(R(R-1)/2 + C)]  (dotBasedInteractFwd)."""
+    C.require_cuda(x)
+    if x.dim() != 3:
+        raise ValueError("dot_interact: expected [batch, rows, cols], got %s" % (tuple(x.shape),))
+    x = x.contiguous()
+    b, r, c = x.shape
+    out = torch.empty((b, dot_interact_out_width(r, c)), dtype=x.dtype, device=x.device)
+    C.call("dle_dot_interact_fwd", C.ptr(x), C.ptr(out), b, r, c, C.dt(x), int(force_generic), C.stream())
+    return out
+
+
+def dot_interact_bwd(x, upstream, force_generic=False):
+    """-> (grad [B,R,C], mlp_grad [B,C])  (dotBasedInteractBwd)."""
+    C.require_cuda(x, upstream)
+    x = x.contiguous()
+    b, r, c = x.shape
+    ow = dot_interact_out_width(r, c)
+    if tuple(upstream.shape) != (b, ow):
+        raise ValueError("dot_interact_bwd: upstream grad must be [%d, %d], got %s" % (b, ow, tuple(upstream.shape)))
+    upstream = upstream.to(x.dtype).contiguous()
+    grad = torch.empty_like(x)
+    mlp_grad = torch.empty((b, c), dtype=x.dtype, device=x.device)
+    C.call("dle_dot_interact_bwd", C.ptr(x), C.ptr(upstream), C.ptr(grad), C.ptr(mlp_grad), b, r, c,
+           C.dt(x), int(force_generic), C.stream())
+    return grad, mlp_grad
+
+
+# ------------------------------------------------------------------ DLRM embeddings
+def _i64(t, name):
+    if t is None:
+        return None
+    if t.dtype != torch.int64:
+        raise ValueError("%s must be int64 (got %s)" % (name, t.dtype))
+    return t.contiguous()
+
+
+def emb_gather_fwd(weight, indices, offsets=None, hash_sizes=None, out_dtype=torch.float32):
+    """out[b,t,:] = W[(idx[b,t] mod size_t) + offsets[t], :]."""
+    C.require_cuda(weight, indices, offsets, hash_sizes)
+    if weight.dtype != torch.float32 or weight.dim() != 2:
+        raise ValueError("embedding table must be a 2-D fp32 tensor")
+    if indices.dim() != 2:
+        raise ValueError("indices must be [batch, tables]")
+    weight = weight.contiguous() if not weight.is_contiguous() else weight
+    indices, offsets, hash_sizes = _i64(indices, "indices"), _i64(offsets, "offsets"), _i64(hash_sizes, "hash_sizes")
+    b, t = indices.shape
+    d = weight.shape[1]
+    if offsets is not None and offsets.numel() < t:
+        raise ValueError("offsets has %d entries for %d tables" % (offsets.numel(), t))
+    out = torch.empty((b, t, d), dtype=out_dtype, device=weight.device)
+    C.call("dle_emb_gather_fwd", C.ptr(weight), C.ptr(indices), C.ptr(offsets), C.ptr(hash_sizes), C.ptr(out),
+           b, t, d, C.dt(out_dtype), C.stream())
+    return out
+
+
+def emb_offset_indices(indices, offsets=None, hash_sizes=None):
+    C.require_cuda(indices, offsets, hash_sizes)
+    indices, offsets, hash_sizes = _i64(indices, "indices"), _i64(offsets, "offsets"), _i64(hash_sizes, "hash_sizes")
+    b, t = indices.shape
+    rows = torch.empty_like(indices)
+    C.call("dle_emb_offset_indices", C.ptr(indices), C.ptr(offsets), C.ptr(hash_sizes), C.ptr(rows), b, t, C.stream())
+    return rows
+
+
+def emb_grad_values(grad, scale=None):
+    """fp32 COO values of the sparse embedding gradient (optionally * device scalar)."""
+    C.require_cuda(grad, scale)
+    grad = grad.contiguous()
+    values = torch.empty(grad.shape, dtype=torch.float32, device=grad.device)
+    C.call("dle_emb_grad_values", C.ptr(grad), C.ptr(values), C.ptr(scale), grad.numel(), C.dt(grad), C.stream())
+    return values
+
+
+def emb_sparse_sgd_(weight, rows, grad, lr, scale=None, skip_flag=None):
+    """In place: W[rows[i]] -= lr * scale * grad[i] (duplicates accumulate). lr: float or device tensor."""
+    C.require_cuda(weight, rows, grad, scale, skip_flag)
+    if weight.dtype != torch.float32 or not weight.is_contiguous():
+        raise ValueError("embedding table must be contiguous fp32")
+    rows = _i64(rows.reshape(-1), "rows")
+    d = weight.shape[1]
+    grad = grad.reshape(-1, d).contiguous()
+    if grad.shape[0] != rows.numel():
+        raise ValueError("sparse sgd: %d gradient rows for %d indices" % (grad.shape[0], rows.numel()))
+    lr_dev = lr if isinstance(lr, torch.Tensor) else None
+    lr_host = 0.0 if lr_dev is not None else float(lr)
+    C.call("dle_emb_sparse_sgd", C.ptr(weight), C.ptr(rows), C.ptr(grad), C.ptr(lr_dev), lr_host, C.ptr(scale),
+           C.ptr(skip_flag), rows.numel(), d, C.dt(grad), C.stream())
+    return weight
+
+
+# ------------------------------------------------------------------ GEMM
+def gemm(a, b, m, n, k, a_kc, b_kc, out=None, out_dtype=None, bias=None, act=C.ACT_NONE, aux=None,
+         mask_src=None, splitk=1, accumulate=False, alpha=1.0, lda=None, ldb=None):
+    """C[m,n] = act(alpha * A(m,k) B(n,k) + bias).  a/b are 2-D 16-bit tensors, row-major with
+    arbitrary leading dimension; a_kc/b_kc say whether the contraction dim is the contiguous one."""
+    C.require_cuda(a, b, out, bias, aux, mask_src)
+    if a.dtype != b.dtype or a.dtype not in (torch.float16, torch.bfloat16):
+        raise ValueError("gemm inputs must both be f16 or both bf16 (got %s, %s)" % (a.dtype, b.dtype))
+    if a.stride(-1) != 1 or b.stride(-1) != 1:
+        raise ValueError("gemm operands must have unit inner stride")
+    lda = a.stride(0) if lda is None else lda
+    ldb = b.stride(0) if ldb is None else ldb
+    if out is None:
+        out = torch.empty((m, n), dtype=out_dtype or a.dtype, device=a.device)
+    if out.stride(-1) != 1:
+        raise ValueError("gemm output must have unit inner stride")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != n):
+        raise ValueError("gemm bias must be fp32 [n]")
+    C.call("dle_gemm", C.ptr(a), C.ptr(b), C.ptr(out), C.ptr(aux), C.ptr(bias), C.ptr(mask_src), m, n, k,
+           lda, ldb, out.stride(0) if out.dim() == 2 else n, int(a_kc), int(b_kc), C.dt(a), C.dt(out), act,
+           splitk, int(accumulate), float(alpha), C.stream())
+    return out
+
+
+def colsum(x, out=None, accumulate=False):
+    """fp32 column sums of a 2-D tensor (bias gradient)."""
+    C.require_cuda(x, out)
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("colsum expects a 2-D tensor with unit inner stride")
+    m, n = x.shape
+    if out is None:
+        out = torch.empty((n,), dtype=torch.float32, device=x.device)
+        accumulate = False
+    C.call("dle_colsum", C.ptr(x), C.ptr(out), m, n, x.stride(0), C.dt(x), int(accumulate), C.stream())
+    return out
+
+
+def pick_splitk(m_out, n_out, k, target_blocks=512):
+    """Split the contraction so that a skinny wgrad still fills 256 CUs (K tiles of 64)."""
+    tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
+    ktiles = (k + 63) // 64
+    s = max(1, min(ktiles, target_blocks // max(tiles, 1)))
+    return s
+
+
+def linear_fwd(x, w, bias=None, act=C.ACT_NONE, want_pre=False):
+    """y = act(x @ w.T + bias); x [M,K], w [N,K] (both 16-bit).  Returns (y, pre or None)."""
+    m, k = x.shape
+    n = w.shape[0]
+    pre = torch.empty((m, n), dtype=x.dtype, device=x.device) if want_pre else None
+    y = gemm(x, w, m, n, k, True, True, bias=bias, act=act, aux=pre)
+    return y, pre
+
+
+def linear_dgrad(gy, w, mask_src=None):
+    """dx[M,K] = gy[M,N] @ w[N,K]  (optionally * (mask_src > 0))."""
+    m, n = gy.shape
+    k = w.shape[1]
+    return gemm(gy, w, m, k, n, True, False, act=C.ACT_RELU_BWD if mask_src is not None else C.ACT_NONE,
+                mask_src=mask_src)
+
+
+def linear_wgrad(gy, x, out=None, accumulate=False):
+    """dw[N,K] (fp32) = gy[M,N].T @ x[M,K]."""
+    m, n = gy.shape
+    k = x.shape[1]
+    sk = pick_splitk(n, k, m)
+    if out is None:
+        out = torch.empty((n, k), dtype=torch.float32, device=x.device)
+        accumulate = False
+    return gemm(gy, x, n, k, m, False, False, out=out, splitk=sk, accumulate=accumulate)

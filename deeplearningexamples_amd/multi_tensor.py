@@ -1,0 +1,97 @@
+"""Device-resident tensor-list tables + wrappers for the multi-tensor optimizer kernels.
+
+Host side of csrc/multi_tensor.hip.  Mirrors the call shapes of the reference's
+fused_lamb_CUDA.multi_tensor_l2norm / multi_tensor_lamb
+(BERT/lamb_amp_opt/csrc/frontend.cpp:3-32) used through apex's multi_tensor_applier
+(BERT/lamb_amp_opt/fused_lamb/fused_lamb.py:167-191,240-258).
+"""
+import numpy as np
+import torch
+
+from . import _cabi as C
+
+CHUNK = 2048 * 32   # apex multi_tensor_applier default chunk (65536 elements)
+
+
+class TensorTable:
+    """int64 device table {size[n] | chunk_start[n+1] | ptr[list][n]} for `lists` (list of lists)."""
+
+    def __init__(self, lists, chunk=CHUNK):
+        n = len(lists[0])
+        for lst in lists:
+            if len(lst) != n:
+                raise ValueError("tensor lists must have equal length")
+        dev = lists[0][0].device if n else torch.device("cuda")
+        for lst in lists:
+            for t, ref in zip(lst, lists[0]):
+                if not t.is_contiguous():
+                    raise ValueError("multi-tensor kernels need contiguous tensors")
+                if t.numel() != ref.numel() or t.device != dev:
+                    raise ValueError("tensors at the same list position must match in size and device")
+        C.require_cuda(*[t for lst in lists for t in lst])
+        self.n, self.n_lists, self.chunk = n, len(lists), chunk
+        sizes = np.asarray([t.numel() for t in lists[0]], dtype=np.int64)
+        nchunks = (sizes + chunk - 1) // chunk
+        start = np.concatenate([[0], np.cumsum(nchunks)]).astype(np.int64)
+        ptrs = np.asarray([[t.data_ptr() for t in lst] for lst in lists], dtype=np.int64).reshape(-1)
+        host = np.concatenate([sizes, start, ptrs]).astype(np.int64)
+        self.total_chunks = int(start[-1])
+        self.key = host.tobytes()
+        self.table = torch.from_numpy(host).to(dev)
+        self.dtypes = [lst[0].dtype if n else torch.float32 for lst in lists]
+        self.device = dev
+        self._keep = lists   # keep the tensors alive while the table exists
+
+    @staticmethod
+    def key_of(lists, chunk=CHUNK):
+        return (chunk,) + tuple(t.data_ptr() for lst in lists for t in lst) + tuple(t.numel() for t in lists[0])
+
+
+class TableCache:
+    """Re-use a device table while the tensor addresses are unchanged (grads may be reallocated)."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, tag, lists, chunk=CHUNK):
+        k = TensorTable.key_of(lists, chunk)
+        hit = self._d.get(tag)
+        if hit is not None and hit[0] == k:
+            return hit[1]
+        tab = TensorTable(lists, chunk)
+        self._d[tag] = (k, tab)
+        return tab
+
+
+def l2norm(table, noop_flag=None, per_tensor=False):
+    """-> (norm[1], per_tensor_norms[n] or empty): fused_lamb_CUDA.multi_tensor_l2norm."""
+    dev = table.device
+    ret = torch.empty(1, dtype=torch.float32, device=dev)
+    per = torch.empty(table.n if per_tensor else 0, dtype=torch.float32, device=dev)
+    scratch = torch.empty(max(table.total_chunks, 1), dtype=torch.float32, device=dev)
+    C.call("dle_mt_l2norm", C.ptr(table.table), table.n, table.total_chunks, table.chunk, C.dt(table.dtypes[0]),
+           C.ptr(scratch), C.ptr(ret), C.ptr(per) if per_tensor else 0, int(per_tensor), C.ptr(noop_flag),
+           C.stream())
+    return ret, per
+
+
+def lamb_stage1(table, noop_flag, beta1, beta2, beta3, step, bias_correction, eps, mode, weight_decay,
+                global_grad_norm, max_grad_norm, inv_scale):
+    C.call("dle_mt_lamb_stage1", C.ptr(table.table), table.n, table.total_chunks, table.chunk,
+           C.dt(table.dtypes[0]), C.ptr(noop_flag), beta1, beta2, beta3, C.ptr(step), int(bias_correction),
+           eps, int(mode), weight_decay, C.ptr(global_grad_norm), C.ptr(max_grad_norm), C.ptr(inv_scale),
+           C.stream())
+
+
+def lamb_stage2(table, noop_flag, param_norm, update_norm, lr, weight_decay, use_nvlamb):
+    C.call("dle_mt_lamb_stage2", C.ptr(table.table), table.n, table.total_chunks, table.chunk,
+           C.dt(table.dtypes[0]), int(table.n_lists == 3), C.ptr(noop_flag), C.ptr(param_norm),
+           C.ptr(update_norm), C.ptr(lr), weight_decay, int(bool(use_nvlamb)), C.stream())
+
+
+def sgd(table, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, first_step=False,
+        skip_flag=None, inv_scale=None):
+    lr_dev = lr if isinstance(lr, torch.Tensor) else None
+    C.call("dle_mt_sgd", C.ptr(table.table), table.n, table.total_chunks, table.chunk, C.dt(table.dtypes[0]),
+           int(table.n_lists >= 3), C.ptr(skip_flag), C.ptr(lr_dev), 0.0 if lr_dev is not None else float(lr),
+           momentum, dampening, weight_decay, int(nesterov), int(first_step), C.ptr(inv_scale), C.stream())

@@ -1,0 +1,115 @@
+/* dle_mi355x.h -- C ABI of libdle_mi355x.so, the MI355X (gfx950 / CDNA4) kernels behind the
+ * NVIDIA/DeepLearningExamples AMP+DDP train-step hot path (RN50, BERT-L, DLRM).
+ *
+ * Conventions:
+ *   - every entry point is extern "C", takes plain device pointers + sizes and a hipStream_t
+ *     (pass torch.cuda.current_stream().cuda_stream), returns int: 0 = ok, -1 = invalid argument,
+ *     >0 = hipError_t.  dle_last_error() returns the message (thread local).  Nothing exits the
+ *     process (the reference's CHK_CUDA calls std::exit, gather_gpu_fused.cu:6-14).
+ *   - inputs are borrowed, outputs are caller-allocated; no hidden allocation, no host sync,
+ *     no global state -> every call is hipGraph-capturable.
+ *   - dtype codes: DLE_F32 = 0, DLE_F16 = 1, DLE_BF16 = 2.
+ * Paths are relative to /root/reference/PyTorch/.
+ */
+#ifndef DLE_MI355X_H
+#define DLE_MI355X_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;
+
+enum { DLE_F32 = 0, DLE_F16 = 1, DLE_BF16 = 2 };
+enum { DLE_ACT_NONE = 0, DLE_ACT_RELU = 1, DLE_ACT_GELU = 2, DLE_ACT_RELU_BWD = 3 };
+
+/* ---- library plumbing ---------------------------------------------------------------------- */
+const char* dle_last_error(void);
+int dle_abi_version(void);
+int dle_device_check(int device, char* arch_name, int arch_name_len); /* 0 iff gfx950 */
+
+/* ---- DLRM dot interaction -------------------------------------------------------------------
+ * replaces dlrm.cuda_ext.interaction_{ampere,volta}.dotBasedInteractFwd / dotBasedInteractBwd
+ *   Recommendation/DLRM/dlrm/cuda_src/dot_based_interact_ampere/pytorch_ops.cpp:3-12
+ *   .../dot_based_interact_ampere/dot_based_interact_pytorch_types.cu:10-75
+ * x[B,R,C] -> out[B, OW], OW = ceil8(R(R-1)/2 + C): [x[:,0,:] | strict lower tri of X X^T | 0 pad]. */
+int dle_dot_interact_out_width(int rows, int cols);
+int dle_dot_interact_fwd(const void* x, void* out, int batch, int rows, int cols, int dtype,
+                         int force_generic, hipStream_t stream);
+/* grad[B,R,C] = U_sym X, mlp_grad[B,C] = upstream[:, :C]  (dotBasedInteractBwd returns both) */
+int dle_dot_interact_bwd(const void* x, const void* upstream, void* grad, void* mlp_grad,
+                         int batch, int rows, int cols, int dtype, int force_generic,
+                         hipStream_t stream);
+
+/* ---- DLRM embeddings --------------------------------------------------------------------------
+ * replaces dlrm.cuda_ext.fused_embedding.gather_gpu_fused_fwd / _bwd
+ *   Recommendation/DLRM/dlrm/cuda_src/pytorch_embedding_ops.cpp:3-21, gather_gpu_fused.cu:107-220
+ * and dlrm.cuda_ext.sparse_gather.gather_gpu_fwd / gather_gpu_bwd / gather_gpu_bwd_fuse_sgd
+ *   Recommendation/DLRM/dlrm/cuda_src/sparse_gather/sparse_pytorch_ops.cpp:1-15, gather_gpu.cu:79-171
+ * weight fp32 [sum rows, dim]; indices int64 [batch, tables]; offsets int64 [tables(+1)] or NULL when
+ * indices already address the joint table; hash_sizes int64 [tables] or NULL (idx %= size).       */
+int dle_emb_gather_fwd(const float* weight, const int64_t* indices, const int64_t* offsets,
+                       const int64_t* hash_sizes, void* out, int64_t batch, int tables, int dim,
+                       int out_dtype, hipStream_t stream);
+int dle_emb_offset_indices(const int64_t* indices, const int64_t* offsets, const int64_t* hash_sizes,
+                           int64_t* rows_out, int64_t batch, int tables, hipStream_t stream);
+/* fp32 COO values of the sparse weight gradient: values = (float)grad * (*scale_dev or 1) */
+int dle_emb_grad_values(const void* grad, float* values, const float* scale_dev, int64_t n_elems,
+                        int grad_dtype, hipStream_t stream);
+/* W[rows[i],:] -= lr * scale * grad[i,:]; lr from lr_dev if non-NULL else lr_host; whole update is
+ * skipped when *skip_flag_dev != 0 (GradScaler found_inf). */
+int dle_emb_sparse_sgd(float* weight, const int64_t* rows, const void* grad, const float* lr_dev,
+                       float lr_host, const float* scale_dev, const float* skip_flag_dev,
+                       int64_t n_rows, int dim, int grad_dtype, hipStream_t stream);
+
+/* ---- dense contraction with fused epilogue ---------------------------------------------------
+ * replaces cuBLAS GEMM + NVFuser/apex epilogues: apex.mlp (Recommendation/DLRM/dlrm/nn/mlps.py:18-43),
+ * F.linear + bias + gelu (LanguageModeling/BERT/modeling.py:130-165), RN50 fc.
+ * C[M,N] = act(alpha * A(m,k) B(n,k) + bias[n]); a_kc/b_kc = operand stored contraction-contiguous
+ * ([M][lda] / [N][ldb]) or not ([K][lda] / [K][ldb]).  aux = optional pre-activation output.
+ * DLE_ACT_RELU_BWD: C = (mask_src > 0) ? acc : 0.  splitk > 1 requires a plain fp32 output.       */
+int dle_gemm(const void* A, const void* B, void* C, void* aux, const float* bias,
+             const void* mask_src, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+             int a_kc, int b_kc, int in_dtype, int out_dtype, int act, int splitk, int accumulate,
+             float alpha, hipStream_t stream);
+/* out[n] (+)= sum_m x[m][n]  (bias gradients) */
+int dle_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, int accumulate,
+               hipStream_t stream);
+
+/* ---- multi-tensor optimizer kernels -----------------------------------------------------------
+ * replaces fused_lamb_CUDA.multi_tensor_l2norm / multi_tensor_lamb
+ *   LanguageModeling/BERT/lamb_amp_opt/csrc/frontend.cpp:3-32
+ *   .../csrc/multi_tensor_l2norm_kernel.cu:153-216, .../csrc/multi_tensor_lamb.cu:371-500
+ * and the dense SGD steps (apex FusedSGD, Recommendation/DLRM/dlrm/scripts/main.py:468-471;
+ * torch.optim.SGD, Classification/ConvNets/image_classification/optimizers.py:34-56).
+ * Tensor lists are described by a device-resident int64 table:
+ *   { size[n] | chunk_start[n+1] | ptr[list 0][n] | ptr[list 1][n] | ... }
+ * built on the host with dle_mt_table_fill and copied to the device once per address set.      */
+int64_t dle_mt_table_len(int n_tensors, int n_lists);
+int64_t dle_mt_table_fill(int64_t* table_host, int n_tensors, int n_lists, const int64_t* sizes,
+                          const void* const* ptrs, int chunk);
+int dle_mt_l2norm(const int64_t* table_dev, int n_tensors, int64_t total_chunks, int chunk, int dtype,
+                  float* partial_scratch, float* ret, float* ret_per_tensor, int per_tensor,
+                  int* noop_flag, hipStream_t stream);
+/* lists: g (grad_dtype; overwritten with the update), p, m, v (fp32) */
+int dle_mt_lamb_stage1(const int64_t* table_dev, int n_tensors, int64_t total_chunks, int chunk,
+                       int grad_dtype, const int* noop_flag, float beta1, float beta2, float beta3,
+                       const int* step_dev, int bias_correction, float eps, int mode,
+                       float weight_decay, const float* global_grad_norm, const float* max_grad_norm,
+                       const float* inv_scale, hipStream_t stream);
+/* lists: update (grad_dtype), p (fp32) [, low-precision model copy (grad_dtype)] */
+int dle_mt_lamb_stage2(const int64_t* table_dev, int n_tensors, int64_t total_chunks, int chunk,
+                       int grad_dtype, int has_model_copy, const int* noop_flag,
+                       const float* param_norm, const float* update_norm, const float* lr_dev,
+                       float weight_decay, int use_nvlamb, hipStream_t stream);
+/* lists: g (grad_dtype), p (fp32) [, momentum buffer (fp32)] */
+int dle_mt_sgd(const int64_t* table_dev, int n_tensors, int64_t total_chunks, int chunk, int grad_dtype,
+               int has_momentum, const float* skip_flag_dev, const float* lr_dev, float lr_host,
+               float momentum, float dampening, float weight_decay, int nesterov, int first_step,
+               const float* inv_scale_dev, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DLE_MI355X_H */

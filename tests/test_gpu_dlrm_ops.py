@@ -1,0 +1,152 @@
+"""HIP kernels (through the C ABI) vs the CPU oracle + the reference-generated fixtures. GPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dlrm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _F():
+    from deeplearningexamples_amd import functional as F
+    return F
+
+
+TOL = {torch.float16: dict(rtol=1e-3, atol=1e-3), torch.bfloat16: dict(rtol=8e-3, atol=8e-3),
+       torch.float32: dict(rtol=1e-4, atol=1e-4)}
+NP16 = {torch.float16: np.float16}
+
+
+def _round(x, dtype):
+    return torch.from_numpy(x).to(dtype)
+
+
+# (batch, rows, cols): the reference's test grid (dot_based_interact_ops_test.py:89-112) + Criteo shape
+SHAPES = [(16, 32, 32), (17, 31, 37), (15, 31, 37), (16, 31, 33), (16, 32, 31), (8, 27, 128), (5, 27, 128),
+          (3, 2, 8), (4, 27, 16), (1, 1, 16), (2048, 27, 128)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_dot_interact_fwd_bwd(cuda, shape, dtype, force_generic):
+    F = _F()
+    b, r, c = shape
+    g = torch.Generator().manual_seed(b * 1000 + r * 10 + c)
+    x = torch.rand(b, r, c, generator=g).to(dtype)
+    ow = O.interact_out_width(r, c)
+    assert F.dot_interact_out_width(r, c) == ow
+    ug = torch.rand(b, ow, generator=g).to(dtype)
+    y = F.dot_interact_fwd(x.to(cuda), force_generic).cpu()
+    ref = O.dot_interact_fwd(x.float().numpy(), np.float32)
+    np.testing.assert_allclose(y.float().numpy(), _round(ref, dtype).float().numpy(), **TOL[dtype])
+    # layout facts that must hold exactly
+    assert torch.equal(y[:, :c], x[:, 0, :])
+    assert (y[:, c + r * (r - 1) // 2:] == 0).all()
+    gx, gm = F.dot_interact_bwd(x.to(cuda), ug.to(cuda), force_generic)
+    rgx, rgm = O.dot_interact_bwd(x.float().numpy(), ug.float().numpy(), np.float32)
+    tol = dict(TOL[dtype])
+    tol["atol"] = tol["atol"] * max(1.0, r / 4)       # sums of r products of O(1) values
+    np.testing.assert_allclose(gx.cpu().float().numpy(), _round(rgx, dtype).float().numpy(), **tol)
+    assert torch.equal(gm.cpu(), ug[:, :c])
+
+
+def test_dot_interact_golden_fp32(cuda, golden_dir):
+    F = _F()
+    z = np.load(os.path.join(golden_dir, "dlrm_dot_interact.npz"))
+    for k in sorted({k.rsplit("_", 1)[0] for k in z.files if k.endswith("_x")}):
+        x = torch.from_numpy(z[k + "_x"]).to(cuda)
+        y = F.dot_interact_fwd(x)
+        np.testing.assert_allclose(y.cpu().numpy(), z[k + "_y"], rtol=1e-5, atol=1e-5)
+        gx, gm = F.dot_interact_bwd(x, torch.from_numpy(z[k + "_ug"]).to(cuda))
+        tot = gx.cpu().numpy()
+        tot[:, 0, :] += gm.cpu().numpy()
+        np.testing.assert_allclose(tot, z[k + "_gx_total"], rtol=1e-4, atol=1e-4)
+
+
+def test_dot_interact_empty_and_errors(cuda):
+    F = _F()
+    y = F.dot_interact_fwd(torch.empty(0, 27, 128, dtype=torch.float16, device=cuda))
+    assert y.shape == (0, 480)
+    with pytest.raises(ValueError):
+        F.dot_interact_fwd(torch.empty(4, 128, dtype=torch.float16, device=cuda))
+    with pytest.raises(ValueError):
+        F.dot_interact_bwd(torch.zeros(4, 27, 128, dtype=torch.float16, device=cuda),
+                           torch.zeros(4, 479, dtype=torch.float16, device=cuda))
+    with pytest.raises(RuntimeError):
+        F.dot_interact_fwd(torch.zeros(4, 27, 128, dtype=torch.float16))     # CPU tensor: no fallback
+
+
+def test_embedding_golden_bit_exact(cuda, golden_dir):
+    F = _F()
+    z = np.load(os.path.join(golden_dir, "dlrm_embedding.npz"))
+    w = torch.from_numpy(z["w0"]).to(cuda)
+    idx = torch.from_numpy(z["idx_in"]).to(cuda)
+    off = torch.from_numpy(z["offsets"]).to(cuda)
+    sizes = torch.from_numpy(z["sizes"]).to(cuda)
+    rows = F.emb_offset_indices(idx, off, sizes)
+    exp_rows = O.offset_indices(z["idx_hashed"], z["offsets"])
+    assert np.array_equal(rows.cpu().numpy(), exp_rows)                      # int64, bit exact
+    out = F.emb_gather_fwd(w, idx, off, sizes)
+    assert np.array_equal(out.cpu().numpy(), z["out"])                        # fp32 copy, bit exact
+    out2 = F.emb_gather_fwd(w, rows)                                          # joint table, pre-offset indices
+    assert np.array_equal(out2.cpu().numpy(), z["out"])
+    out16 = F.emb_gather_fwd(w, rows, out_dtype=torch.float16)
+    assert torch.equal(out16.cpu(), torch.from_numpy(z["out"]).half())
+    ug = torch.from_numpy(z["ug"]).to(cuda)
+    vals = F.emb_grad_values(ug)
+    assert torch.equal(vals, ug)
+    F.emb_sparse_sgd_(w, rows, ug, float(z["lr"]))
+    np.testing.assert_allclose(w.cpu().numpy(), z["w1"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dim", [128, 16, 4, 64])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_embedding_gather_random(cuda, dim, out_dtype):
+    F = _F()
+    sizes = [7, 1, 1000, 33, 5000, 2][: 6 if dim != 128 else 5]
+    rng = np.random.default_rng(dim)
+    off = O.table_offsets(sizes)
+    w = rng.standard_normal((int(off[-1]), dim)).astype(np.float32)
+    b = 777
+    idx = np.stack([rng.integers(0, s, b) for s in sizes], axis=1).astype(np.int64)
+    out = F.emb_gather_fwd(torch.from_numpy(w).to(cuda), torch.from_numpy(idx).to(cuda),
+                           torch.from_numpy(off).to(cuda), None, out_dtype)
+    exp = torch.from_numpy(O.embedding_gather(w, O.offset_indices(idx, off))).to(out_dtype)
+    assert torch.equal(out.cpu(), exp)
+
+
+def test_embedding_sgd_duplicates_scale_skip(cuda):
+    F = _F()
+    rng = np.random.default_rng(3)
+    w0 = rng.standard_normal((50, 128)).astype(np.float32)
+    rows = rng.integers(0, 50, (4096,)).astype(np.int64)          # heavy duplication -> atomics
+    g = (rng.standard_normal((4096, 128)) * 0.01).astype(np.float16)
+    w = torch.from_numpy(w0.copy()).to(cuda)
+    inv = torch.tensor([0.5], device=cuda)
+    lr = torch.tensor(2.0, device=cuda)
+    F.emb_sparse_sgd_(w, torch.from_numpy(rows).to(cuda), torch.from_numpy(g).to(cuda), lr, scale=inv)
+    exp = O.sparse_sgd(w0, rows, g.astype(np.float32) * 0.5, 2.0)
+    np.testing.assert_allclose(w.cpu().numpy(), exp, rtol=1e-4, atol=1e-4)
+    before = w.clone()
+    F.emb_sparse_sgd_(w, torch.from_numpy(rows).to(cuda), torch.from_numpy(g).to(cuda), lr,
+                      skip_flag=torch.ones(1, device=cuda))
+    assert torch.equal(w, before)
+
+
+def test_embedding_full_size_roundtrip(cuda):
+    """BASELINE-size property test: gather(W, idx) after W[idx] -= lr*g on unique rows changes exactly
+    those rows by exactly lr*g (size-independent property, 64k x 26 x 128)."""
+    F = _F()
+    torch.manual_seed(0)
+    rows_total, b, t, d = 2_000_000, 65536, 26, 128
+    w = torch.randn(rows_total, d, device=cuda)
+    perm = torch.randperm(rows_total, device=cuda)[: b * t].view(b, t)       # unique rows
+    before = F.emb_gather_fwd(w, perm)
+    g = torch.randn(b, t, d, device=cuda).half()
+    F.emb_sparse_sgd_(w, perm, g, 0.25)
+    after = F.emb_gather_fwd(w, perm)
+    assert torch.equal(after, before - 0.25 * g.float())

@@ -1,0 +1,95 @@
+"""MFMA GEMM + epilogues vs a float64 reference computed from the same 16-bit-rounded inputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _F():
+    from deeplearningexamples_amd import functional as F, _cabi as C
+    return F, C
+
+
+def _mk(shape, dtype, gen, scale=1.0):
+    return (torch.randn(*shape, generator=gen) * scale).to(dtype)
+
+
+CASES = [
+    # m, n, k
+    (128, 128, 64), (256, 384, 512), (100, 70, 40), (1, 1, 8), (300, 1, 256), (129, 257, 72),
+    (512, 1024, 480), (64, 512, 13), (2048, 256, 1024), (33, 65, 1000),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("mnk", CASES)
+def test_gemm_three_layouts(cuda, mnk, dtype):
+    F, C = _F()
+    m, n, k = mnk
+    gen = torch.Generator().manual_seed(m * 7 + n * 3 + k)
+    a = _mk((m, k), dtype, gen)          # A[m][k]
+    b = _mk((n, k), dtype, gen)          # B[n][k]
+    ref = (a.double() @ b.double().T)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    scale = np.sqrt(k)
+
+    def chk(out, what):
+        err = (out.cpu().double() - ref).abs().max().item()
+        assert err <= tol * scale, "%s: max err %g (m,n,k=%s)" % (what, err, mnk)
+
+    # forward layout: both k-contiguous, fp32 and 16-bit outputs
+    chk(F.gemm(a.to(cuda), b.to(cuda), m, n, k, True, True, out_dtype=torch.float32), "kc/kc f32")
+    chk(F.gemm(a.to(cuda), b.to(cuda), m, n, k, True, True), "kc/kc 16")
+    # dgrad layout: B stored [k][n]
+    bt = b.T.contiguous()
+    chk(F.gemm(a.to(cuda), bt.to(cuda), m, n, k, True, False, out_dtype=torch.float32), "kc/nc")
+    # wgrad layout: A stored [k][m], B stored [k][n]; also split-K
+    at = a.T.contiguous()
+    chk(F.gemm(at.to(cuda), bt.to(cuda), m, n, k, False, False, out_dtype=torch.float32), "mc/nc")
+    chk(F.gemm(at.to(cuda), bt.to(cuda), m, n, k, False, False, out_dtype=torch.float32, splitk=3), "mc/nc splitk")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gemm_epilogues(cuda, dtype):
+    F, C = _F()
+    m, n, k = 200, 136, 96
+    gen = torch.Generator().manual_seed(5)
+    a, b = _mk((m, k), dtype, gen, 0.5), _mk((n, k), dtype, gen, 0.5)
+    bias = torch.randn(n, generator=gen)
+    pre_ref = a.double() @ b.double().T + bias.double()
+    tol = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=3e-3, atol=3e-3)
+    y, pre = F.linear_fwd(a.to(cuda), b.to(cuda), bias.to(cuda), C.ACT_RELU, want_pre=True)
+    np.testing.assert_allclose(pre.cpu().double().numpy(), pre_ref.numpy(), **tol)
+    np.testing.assert_allclose(y.cpu().double().numpy(), pre_ref.clamp(min=0).numpy(), **tol)
+    y, pre = F.linear_fwd(a.to(cuda), b.to(cuda), bias.to(cuda), C.ACT_GELU, want_pre=True)
+    gelu = torch.nn.functional.gelu(pre_ref, approximate="tanh")
+    np.testing.assert_allclose(y.cpu().double().numpy(), gelu.numpy(), **tol)
+    # relu-backward masking in the dgrad epilogue
+    gy = _mk((m, n), dtype, gen, 0.5)
+    act_prev = _mk((m, k), dtype, gen)          # forward activation of the previous layer
+    dx = F.linear_dgrad(gy.to(cuda), b.to(cuda), mask_src=act_prev.to(cuda))
+    ref = (gy.double() @ b.double()) * (act_prev.double() > 0)
+    np.testing.assert_allclose(dx.cpu().double().numpy(), ref.numpy(), **tol)
+    # wgrad with accumulate and bias grad
+    dw0 = torch.randn(n, k, generator=gen)
+    dw = F.linear_wgrad(gy.to(cuda), a.to(cuda), out=dw0.clone().to(cuda), accumulate=True)
+    np.testing.assert_allclose(dw.cpu().double().numpy(), (dw0.double() + gy.double().T @ a.double()).numpy(),
+                               rtol=2e-2, atol=5e-2)
+    db = F.colsum(gy.to(cuda))
+    np.testing.assert_allclose(db.cpu().double().numpy(), gy.double().sum(0).numpy(), rtol=1e-3, atol=1e-2)
+
+
+def test_gemm_strided_and_errors(cuda):
+    F, C = _F()
+    gen = torch.Generator().manual_seed(9)
+    big = _mk((64, 300), torch.float16, gen).to(cuda)
+    a = big[:, 10:10 + 128]                      # lda = 300, misaligned start -> scalar loader path
+    b = _mk((32, 128), torch.float16, gen).to(cuda)
+    out = F.gemm(a, b, 64, 32, 128, True, True, out_dtype=torch.float32)
+    ref = a.cpu().double() @ b.cpu().double().T
+    assert (out.cpu().double() - ref).abs().max() < 0.05
+    with pytest.raises(ValueError):
+        F.gemm(a.float(), b.float(), 64, 32, 128, True, True)
+    with pytest.raises(ValueError):
+        F.gemm(a, b, 64, 32, 128, False, True)

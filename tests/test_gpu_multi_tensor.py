@@ -1,0 +1,128 @@
+"""Multi-tensor L2 norm / LAMB / SGD kernels vs oracle/lamb_oracle.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lamb_oracle as L
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(7,), (33, 5), (65536,), (65537,), (3, 3, 3), (200000,), (1,), (1024, 1024)]
+
+
+def _mt():
+    from deeplearningexamples_amd import multi_tensor as mt
+    return mt
+
+
+def _rand(rng, shapes, scale=1.0, dtype=np.float32, positive=False):
+    out = []
+    for s in shapes:
+        a = rng.standard_normal(s) * scale
+        out.append((np.abs(a) if positive else a).astype(dtype))
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_l2norm(cuda, dtype):
+    mt = _mt()
+    rng = np.random.default_rng(0)
+    xs = [torch.from_numpy(a).to(dtype) for a in _rand(rng, SHAPES)]
+    dev = [x.to(cuda) for x in xs]
+    noop = torch.zeros(1, dtype=torch.int32, device=cuda)
+    tot, per = mt.l2norm(mt.TensorTable([dev]), noop, per_tensor=True)
+    rt, rp = L.l2norm([x.float().numpy() for x in xs])
+    np.testing.assert_allclose(per.cpu().numpy(), rp, rtol=2e-5)
+    np.testing.assert_allclose(tot.cpu().numpy(), [rt], rtol=2e-5)
+    assert noop.item() == 0
+    dev[2][5] = float("inf")
+    mt.l2norm(mt.TensorTable([dev]), noop, per_tensor=False)
+    assert noop.item() == 1                                       # non-finite -> noop flag (l2norm_kernel.cu:103)
+
+
+@pytest.mark.parametrize("gdtype,copy", [(torch.float32, False), (torch.float16, True), (torch.bfloat16, True)])
+@pytest.mark.parametrize("mode,wd", [(1, 0.01), (1, 0.0), (0, 0.01)])
+def test_lamb_full_step(cuda, gdtype, copy, mode, wd):
+    mt = _mt()
+    rng = np.random.default_rng(1)
+    npdt = {torch.float32: np.float32, torch.float16: np.float16}.get(gdtype)
+    g32 = _rand(rng, SHAPES, 0.1)
+    g_t = [torch.from_numpy(a).to(gdtype) for a in g32]
+    g_np = [t.float().numpy() for t in g_t]
+    p, m, v = _rand(rng, SHAPES), _rand(rng, SHAPES, 0.05), _rand(rng, SHAPES, 0.01, positive=True)
+    lr, b1, b2, eps, step, scale = 6e-3, 0.9, 0.999, 1e-6, 4, 128.0
+    gs = [(t.float() * scale).to(gdtype).to(cuda) for t in g_t]      # scaled grads, as under GradScaler
+    g_np = [t.cpu().float().numpy() for t in gs]
+    ps = [torch.from_numpy(a.copy()).to(cuda) for a in p]
+    ms = [torch.from_numpy(a.copy()).to(cuda) for a in m]
+    vs = [torch.from_numpy(a.copy()).to(cuda) for a in v]
+    copies = [torch.zeros_like(x, dtype=gdtype) for x in ps] if copy else None
+    noop = torch.zeros(1, dtype=torch.int32, device=cuda)
+    gnorm, _ = mt.l2norm(mt.TensorTable([gs]), noop)
+    max_norm = torch.tensor([1.0 * scale], device=cuda)
+    inv_scale = torch.tensor([1.0 / scale], device=cuda)
+    step_t = torch.tensor([step], dtype=torch.int32, device=cuda)
+    lr_t = torch.tensor(lr, device=cuda)
+    # host sequence of multi_tensor_lamb_cuda (multi_tensor_lamb.cu:371-500)
+    _, pn = mt.l2norm(mt.TensorTable([ps]), noop, per_tensor=True)
+    mt.lamb_stage1(mt.TensorTable([gs, ps, ms, vs]), noop, b1, b2, 1 - b1, step_t, True, eps, mode, wd,
+                   gnorm, max_norm, inv_scale)
+    _, un = mt.l2norm(mt.TensorTable([gs]), noop, per_tensor=True)
+    lists = [gs, ps, copies] if copy else [gs, ps]
+    mt.lamb_stage2(mt.TensorTable(lists), noop, pn, un, lr_t, wd, False)
+
+    gn_ref, _ = L.l2norm(g_np)
+    to_np = (lambda a: a.astype(np.float16)) if gdtype == torch.float16 else None
+    class _BF:  # numpy has no bf16: emulate the cast through torch
+        pass
+    def cast(a):
+        return torch.from_numpy(a).to(gdtype).float().numpy()
+    upd, p2, m2, v2, _ = L.lamb_step(g_np, p, m, v, lr, b1, b2, eps, step, True, wd, True, mode, gn_ref,
+                                     np.float32(scale), inv_scale=1.0 / scale)
+    for i in range(len(SHAPES)):
+        np.testing.assert_allclose(ms[i].cpu().numpy(), m2[i], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(vs[i].cpu().numpy(), v2[i], rtol=1e-5, atol=1e-8)
+        tol = 1e-5 if gdtype == torch.float32 else (2e-3 if gdtype == torch.float16 else 1.6e-2)
+        np.testing.assert_allclose(gs[i].cpu().float().numpy(), cast(upd[i]), rtol=tol, atol=tol)
+        np.testing.assert_allclose(ps[i].cpu().numpy(), p2[i], rtol=tol, atol=tol * 1e-2 + 1e-6)
+        if copy:
+            assert torch.equal(copies[i], ps[i].to(gdtype))
+
+
+def test_lamb_noop_skips_everything(cuda):
+    mt = _mt()
+    g = [torch.ones(1000, device=cuda)]
+    p, m, v = [torch.ones(1000, device=cuda)], [torch.zeros(1000, device=cuda)], [torch.zeros(1000, device=cuda)]
+    noop = torch.ones(1, dtype=torch.int32, device=cuda)
+    one = torch.ones(1, device=cuda)
+    mt.lamb_stage1(mt.TensorTable([g, p, m, v]), noop, 0.9, 0.999, 0.1, torch.ones(1, dtype=torch.int32, device=cuda),
+                   True, 1e-6, 1, 0.01, one, one, one)
+    assert m[0].abs().sum() == 0 and (g[0] == 1).all()
+
+
+@pytest.mark.parametrize("gdtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("nesterov", [False, True])
+def test_sgd_momentum(cuda, gdtype, nesterov):
+    mt = _mt()
+    rng = np.random.default_rng(2)
+    p = _rand(rng, SHAPES)
+    ps = [torch.from_numpy(a.copy()).to(cuda) for a in p]
+    bufs = [torch.zeros_like(x) for x in ps]
+    ref_buf = [None] * len(p)
+    inv = torch.tensor([0.25], device=cuda)
+    for it in range(3):
+        g = [torch.from_numpy(a).to(gdtype) for a in _rand(rng, SHAPES)]
+        gs = [x.to(cuda) for x in g]
+        mt.sgd(mt.TensorTable([gs, ps, bufs]), torch.tensor(0.1, device=cuda), 0.875, 0.0, 3.0517578125e-05,
+               nesterov, first_step=(it == 0), inv_scale=inv)
+        for i in range(len(p)):
+            p[i], ref_buf[i] = L.sgd_step(g[i].float().numpy(), p[i], ref_buf[i], 0.1, 0.875, 0.0,
+                                          3.0517578125e-05, nesterov, first=(it == 0), inv_scale=0.25)
+            np.testing.assert_allclose(ps[i].cpu().numpy(), p[i], rtol=1e-5, atol=1e-6)
+    # plain SGD, host lr, skip flag
+    before = [x.clone() for x in ps]
+    mt.sgd(mt.TensorTable([gs, ps]), 0.1, skip_flag=torch.ones(1, device=cuda))
+    assert all(torch.equal(a, b) for a, b in zip(ps, before))
+    mt.sgd(mt.TensorTable([gs, ps]), 0.1)
+    for a, b, gg in zip(ps, before, gs):
+        np.testing.assert_allclose(a.cpu().numpy(), (b - 0.1 * gg.float()).cpu().numpy(), rtol=1e-6, atol=1e-6)
