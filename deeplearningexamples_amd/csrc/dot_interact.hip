@@ -275,10 +275,10 @@ static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 extern "C" int dle_dot_interact_fwd(const void* x, void* out, int batch, int rows, int cols,
                                     int dtype, int force_generic, hipStream_t stream) {
-  DLE_CHECK_ARG(x && out, "dot_interact_fwd: null pointer");
   DLE_CHECK_ARG(batch >= 0 && rows >= 1 && cols >= 1, "dot_interact_fwd: bad shape %d %d %d", batch, rows, cols);
   DLE_CHECK_ARG(dtype == DLE_F32 || dtype == DLE_F16 || dtype == DLE_BF16, "dot_interact_fwd: bad dtype %d", dtype);
-  if (batch == 0) return 0;
+  if (batch == 0) return 0;   // empty batch: pointers may legitimately be null
+  DLE_CHECK_ARG(x && out, "dot_interact_fwd: null pointer");
   const int OW = out_width(rows, cols);
   const bool fast = !force_generic && dtype != DLE_F32 && rows <= 32 && (cols % 16) == 0 &&
                     aligned16(x) && aligned16(out);
@@ -310,10 +310,10 @@ extern "C" int dle_dot_interact_fwd(const void* x, void* out, int batch, int row
 extern "C" int dle_dot_interact_bwd(const void* x, const void* upstream, void* grad, void* mlp_grad,
                                     int batch, int rows, int cols, int dtype, int force_generic,
                                     hipStream_t stream) {
-  DLE_CHECK_ARG(x && upstream && grad && mlp_grad, "dot_interact_bwd: null pointer");
   DLE_CHECK_ARG(batch >= 0 && rows >= 1 && cols >= 1, "dot_interact_bwd: bad shape %d %d %d", batch, rows, cols);
   DLE_CHECK_ARG(dtype == DLE_F32 || dtype == DLE_F16 || dtype == DLE_BF16, "dot_interact_bwd: bad dtype %d", dtype);
   if (batch == 0) return 0;
+  DLE_CHECK_ARG(x && upstream && grad && mlp_grad, "dot_interact_bwd: null pointer");
   const int OW = out_width(rows, cols);
   const bool fast = !force_generic && dtype != DLE_F32 && rows <= 32 && (cols % 32) == 0 && cols <= 256 &&
                     aligned16(x) && aligned16(upstream) && aligned16(grad) && aligned16(mlp_grad);

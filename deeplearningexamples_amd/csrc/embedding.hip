@@ -188,6 +188,8 @@ static int grid_for(long long work_items, int per_block) {
 extern "C" int dle_emb_gather_fwd(const float* weight, const int64_t* indices, const int64_t* offsets,
                                   const int64_t* hash_sizes, void* out, int64_t batch, int tables,
                                   int dim, int out_dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(batch >= 0 && tables > 0, "emb_gather_fwd: bad shape");
+  if (batch == 0) return 0;
   DLE_CHECK_ARG(weight && indices && out, "emb_gather_fwd: null pointer");
   DLE_CHECK_ARG(dim > 0 && dim % 4 == 0, "emb_gather_fwd: dim %d must be a multiple of 4", dim);
   DLE_CHECK_ARG(tables > 0 && batch >= 0, "emb_gather_fwd: bad shape");
@@ -213,9 +215,9 @@ extern "C" int dle_emb_gather_fwd(const float* weight, const int64_t* indices, c
 extern "C" int dle_emb_offset_indices(const int64_t* indices, const int64_t* offsets,
                                       const int64_t* hash_sizes, int64_t* rows_out, int64_t batch,
                                       int tables, hipStream_t stream) {
-  DLE_CHECK_ARG(indices && rows_out, "emb_offset_indices: null pointer");
   const long long n = (long long)batch * tables;
   if (n == 0) return 0;
+  DLE_CHECK_ARG(indices && rows_out, "emb_offset_indices: null pointer");
   hipLaunchKernelGGL(emb_offset_indices, dim3(grid_for(n, 256)), dim3(256), 0, stream,
                      (const long long*)indices, (const long long*)offsets, (const long long*)hash_sizes,
                      (long long*)rows_out, n, tables);
@@ -245,9 +247,9 @@ extern "C" int dle_emb_sparse_sgd(float* weight, const int64_t* rows, const void
                                   const float* lr_dev, float lr_host, const float* scale_dev,
                                   const float* skip_flag_dev, int64_t n_rows, int dim, int grad_dtype,
                                   hipStream_t stream) {
-  DLE_CHECK_ARG(weight && rows && grad, "emb_sparse_sgd: null pointer");
   DLE_CHECK_ARG(dim > 0 && dim % 4 == 0, "emb_sparse_sgd: dim %d must be a multiple of 4", dim);
   if (n_rows == 0) return 0;
+  DLE_CHECK_ARG(weight && rows && grad, "emb_sparse_sgd: null pointer");
   const int D4 = dim / 4;
   const int grid = grid_for(n_rows, 4 * 2);
   if (grad_dtype == DLE_F32)
