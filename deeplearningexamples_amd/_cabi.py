@@ -30,11 +30,21 @@ _SIGS = {
     "dle_dot_interact_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                      c_int, c_void_p]),
     "dle_emb_gather_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int,
-                                   c_int, c_void_p]),
+                                   c_int, c_i64, c_void_p]),
     "dle_emb_offset_indices": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "dle_emb_grad_values": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "dle_emb_sparse_sgd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
-                                   c_i64, c_int, c_int, c_void_p]),
+                                   c_i64, c_int, c_int, c_i64, c_int, c_void_p]),
+    "dle_emb_small_table_mask": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "dle_emb_sgd_dedup": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_float, c_void_p, c_void_p, c_i64, c_int, c_int, c_i64, c_int,
+                                  c_void_p]),
+    "dle_cast_rows": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_i64, c_i64, c_int, c_int, c_void_p]),
+    "dle_bce_logits": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p]),
+    "dle_amp_update_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int,
+                                     c_void_p]),
+    "dle_check_nonfinite": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+    "dle_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_i64, c_int, c_void_p]),
     "dle_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                          c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                          c_void_p]),
@@ -49,7 +59,7 @@ _SIGS = {
     "dle_mt_lamb_stage2": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_float, c_int, c_void_p]),
     "dle_mt_sgd": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float,
-                           c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
+                           c_float, c_float, c_int, c_int, c_void_p, c_int, c_void_p]),
 }
 
 _lib = None

@@ -122,8 +122,10 @@ __global__ __launch_bounds__(256) void dot_bwd_mfma(const unsigned short* __rest
     }
     // bottom-MLP gradient = first C entries of the upstream gradient
     const unsigned short* ub = ug + (size_t)b * OW;
-    unsigned short* mg = mlp_grad + (size_t)b * C;
-    for (int q = lane * 8; q < C; q += 512) *(ushort8_t*)(mg + q) = *(const ushort8_t*)(ub + q);
+    if (mlp_grad) {
+      unsigned short* mg = mlp_grad + (size_t)b * C;
+      for (int q = lane * 8; q < C; q += 512) *(ushort8_t*)(mg + q) = *(const ushort8_t*)(ub + q);
+    }
   }
   __syncthreads();
   if (act) {
@@ -166,7 +168,10 @@ __global__ __launch_bounds__(256) void dot_bwd_mfma(const unsigned short* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-          xs[i * XS + nb * 32 + row] = Elem<DT>::from_f32(acc[nb][r]);
+          float v = acc[nb][r];
+          // fused form (mlp_grad == NULL): row 0 also receives upstream[:, :C] (what autograd adds later)
+          if (!mlp_grad && i == 0) v += Elem<DT>::to_f32(ug[(size_t)b * OW + nb * 32 + row]);
+          xs[i * XS + nb * 32 + row] = Elem<DT>::from_f32(v);
         }
       }
     }
@@ -243,7 +248,8 @@ __global__ __launch_bounds__(256) void dot_bwd_generic(const typename IO<DT>::T*
   const typename IO<DT>::T* ub = ug + (size_t)b * OW;
   for (int q = threadIdx.x; q < R * C; q += blockDim.x) xs[q] = IO<DT>::ld(xb + q);
   for (int q = threadIdx.x; q < R * R; q += blockDim.x) us[q] = 0.f;
-  for (int q = threadIdx.x; q < C; q += blockDim.x) IO<DT>::st(mlp_grad + (size_t)b * C + q, IO<DT>::ld(ub + q));
+  if (mlp_grad)
+    for (int q = threadIdx.x; q < C; q += blockDim.x) IO<DT>::st(mlp_grad + (size_t)b * C + q, IO<DT>::ld(ub + q));
   __syncthreads();
   const int ntril = R * (R - 1) / 2;
   for (int t = threadIdx.x; t < ntril; t += blockDim.x) {
@@ -259,6 +265,7 @@ __global__ __launch_bounds__(256) void dot_bwd_generic(const typename IO<DT>::T*
     const int i = q / C, c = q - i * C;
     float s = 0.f;
     for (int k = 0; k < R; ++k) s = fmaf(us[i * R + k], xs[k * C + c], s);
+    if (!mlp_grad && i == 0) s += IO<DT>::ld(ub + c);
     IO<DT>::st(gb + q, s);
   }
 }
@@ -313,10 +320,10 @@ extern "C" int dle_dot_interact_bwd(const void* x, const void* upstream, void* g
   DLE_CHECK_ARG(batch >= 0 && rows >= 1 && cols >= 1, "dot_interact_bwd: bad shape %d %d %d", batch, rows, cols);
   DLE_CHECK_ARG(dtype == DLE_F32 || dtype == DLE_F16 || dtype == DLE_BF16, "dot_interact_bwd: bad dtype %d", dtype);
   if (batch == 0) return 0;
-  DLE_CHECK_ARG(x && upstream && grad && mlp_grad, "dot_interact_bwd: null pointer");
+  DLE_CHECK_ARG(x && upstream && grad, "dot_interact_bwd: null pointer");
   const int OW = out_width(rows, cols);
   const bool fast = !force_generic && dtype != DLE_F32 && rows <= 32 && (cols % 32) == 0 && cols <= 256 &&
-                    aligned16(x) && aligned16(upstream) && aligned16(grad) && aligned16(mlp_grad);
+                    aligned16(x) && aligned16(upstream) && aligned16(grad) && aligned16(mlp_grad);   /* NULL is aligned */
   if (fast) {
     const size_t lds = (size_t)4 * (32 * (cols + 8) + 32 * DOT_BWD_USTRIDE) * 2;
     dim3 grid((batch + 3) / 4), block(256);

@@ -1,0 +1,282 @@
+// Small HBM-bound kernels around the train step for gfx950: dtype casts with row padding,
+// BCE-with-logits loss forward+backward, GradScaler bookkeeping.
+//
+// Replaces (paths relative to /root/reference/PyTorch/):
+//   * autocast's per-forward fp32->fp16 casts of activations/weights (torch.cuda.amp.autocast,
+//     Recommendation/DLRM/dlrm/scripts/main.py:588; Classification/ConvNets/image_classification/training.py:91)
+//   * torch.nn.BCEWithLogitsLoss(reduction="mean") + its backward
+//     (Recommendation/DLRM/dlrm/scripts/main.py:556,589-592)
+//   * torch.cuda.amp.GradScaler.update() == torch._amp_update_scale_ (main.py:497,608)
+// All of them are 16 B/lane streaming kernels; the loss reduction is a wave64 shuffle reduction
+// followed by one atomic per workgroup.
+#include "common.h"
+
+// ---- cast rows [rows, cols] (ld_in) -> [rows, cols_out >= cols] (ld_out), zero padded columns -------
+template <int IDT, int ODT> struct CastIO;
+template <int DT> struct LdF {   // load one element as f32
+  static __device__ __forceinline__ float ld(const void* p, long long i) {
+    if (DT == DLE_F32) return ((const float*)p)[i];
+    if (DT == DLE_F16) return Elem<DLE_F16>::to_f32(((const unsigned short*)p)[i]);
+    return Elem<DLE_BF16>::to_f32(((const unsigned short*)p)[i]);
+  }
+};
+template <int DT> struct StF {
+  static __device__ __forceinline__ void st(void* p, long long i, float v) {
+    if (DT == DLE_F32) ((float*)p)[i] = v;
+    else if (DT == DLE_F16) ((unsigned short*)p)[i] = Elem<DLE_F16>::from_f32(v);
+    else ((unsigned short*)p)[i] = Elem<DLE_BF16>::from_f32(v);
+  }
+};
+
+template <int IDT, int ODT>
+__global__ __launch_bounds__(256) void cast_rows_kernel(const void* __restrict__ in, void* __restrict__ out,
+                                                        long long rows, int cols, int cols_out,
+                                                        long long ld_in, long long ld_out) {
+  const long long total = rows * cols_out;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cols_out;
+    const int c = (int)(i - r * cols_out);
+    const float v = c < cols ? LdF<IDT>::ld(in, r * ld_in + c) : 0.f;
+    StF<ODT>::st(out, r * ld_out + c, v);
+  }
+}
+
+// contiguous fast path: 4 elements per lane
+template <int IDT, int ODT>
+__global__ __launch_bounds__(256) void cast_flat_kernel(const void* __restrict__ in, void* __restrict__ out,
+                                                        long long n) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    float4_t v;
+    if (IDT == DLE_F32) v = ((const float4_t*)in)[i];
+    else {
+      const ushort4_t u = ((const ushort4_t*)in)[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = IDT == DLE_F16 ? Elem<DLE_F16>::to_f32(u[k]) : Elem<DLE_BF16>::to_f32(u[k]);
+    }
+    if (ODT == DLE_F32) ((float4_t*)out)[i] = v;
+    else {
+      ushort4_t u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) u[k] = ODT == DLE_F16 ? Elem<DLE_F16>::from_f32(v[k]) : Elem<DLE_BF16>::from_f32(v[k]);
+      ((ushort4_t*)out)[i] = u;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    StF<ODT>::st(out, i, LdF<IDT>::ld(in, i));
+  }
+}
+
+static int ew_grid(long long items, int per_block) {
+  long long g = (items + per_block - 1) / per_block;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+#define DISPATCH2(IDT, ODT, CALL)                                                     \
+  do {                                                                                \
+    bool ok__ = true;                                                                 \
+    if (IDT == DLE_F32 && ODT == DLE_F16) { CALL(DLE_F32, DLE_F16); }                 \
+    else if (IDT == DLE_F32 && ODT == DLE_BF16) { CALL(DLE_F32, DLE_BF16); }          \
+    else if (IDT == DLE_F16 && ODT == DLE_F32) { CALL(DLE_F16, DLE_F32); }            \
+    else if (IDT == DLE_BF16 && ODT == DLE_F32) { CALL(DLE_BF16, DLE_F32); }          \
+    else if (IDT == DLE_F32 && ODT == DLE_F32) { CALL(DLE_F32, DLE_F32); }            \
+    else if (IDT == DLE_F16 && ODT == DLE_F16) { CALL(DLE_F16, DLE_F16); }            \
+    else if (IDT == DLE_BF16 && ODT == DLE_BF16) { CALL(DLE_BF16, DLE_BF16); }        \
+    else if (IDT == DLE_F16 && ODT == DLE_BF16) { CALL(DLE_F16, DLE_BF16); }          \
+    else if (IDT == DLE_BF16 && ODT == DLE_F16) { CALL(DLE_BF16, DLE_F16); }          \
+    else ok__ = false;                                                                \
+    if (!ok__) { dle_set_error("cast: bad dtype pair %d -> %d", IDT, ODT); return -1; } \
+  } while (0)
+
+extern "C" int dle_cast_rows(const void* in, void* out, int64_t rows, int cols, int cols_out, int64_t ld_in,
+                             int64_t ld_out, int in_dtype, int out_dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(rows >= 0 && cols >= 0 && cols_out >= cols, "cast_rows: bad shape");
+  if (rows == 0 || cols_out == 0) return 0;
+  DLE_CHECK_ARG(in && out, "cast_rows: null pointer");
+  const int ein = in_dtype == DLE_F32 ? 4 : 2, eout = out_dtype == DLE_F32 ? 4 : 2;
+  const bool flat = cols == cols_out && ld_in == cols && ld_out == cols_out &&
+                    (((uintptr_t)in) % (4 * ein)) == 0 && (((uintptr_t)out) % (4 * eout)) == 0;
+  if (flat) {
+    const long long n = (long long)rows * cols;
+    const int grid = ew_grid(n / 4 + 1, 256);
+#define CALL(I, O) hipLaunchKernelGGL((cast_flat_kernel<I, O>), dim3(grid), dim3(256), 0, stream, in, out, n)
+    DISPATCH2(in_dtype, out_dtype, CALL);
+#undef CALL
+  } else {
+    const int grid = ew_grid((long long)rows * cols_out, 256);
+#define CALL(I, O) hipLaunchKernelGGL((cast_rows_kernel<I, O>), dim3(grid), dim3(256), 0, stream, in, out, (long long)rows, cols, cols_out, (long long)ld_in, (long long)ld_out)
+    DISPATCH2(in_dtype, out_dtype, CALL);
+#undef CALL
+  }
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- BCE with logits, mean reduction, forward + backward in one pass --------------------------------
+// loss = mean( max(x,0) - x*y + log1p(exp(-|x|)) )         (torch.nn.BCEWithLogitsLoss)
+// dx   = (sigmoid(x) - y) * (*grad_scale or 1) / n           (d mean / dx, times the AMP loss scale)
+// loss_out[0] must be zeroed by the caller side of this entry point (done here with a memset node).
+template <int DT>
+__global__ __launch_bounds__(256) void bce_logits_kernel(const void* __restrict__ logits,
+                                                         const float* __restrict__ target,
+                                                         float* __restrict__ loss_out, void* __restrict__ dlogits,
+                                                         const float* __restrict__ grad_scale, long long n,
+                                                         long long ld_logits) {
+  __shared__ float red[16];
+  const float gs = (grad_scale ? *grad_scale : 1.0f) / (float)n;
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float x = LdF<DT>::ld(logits, i * ld_logits);
+    const float y = target[i];
+    const float ax = fabsf(x);
+    const float e = __expf(-ax);
+    acc += fmaxf(x, 0.f) - x * y + log1pf(e);
+    if (dlogits) {
+      const float s = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+      StF<DT>::st(dlogits, i, (s - y) * gs);
+    }
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) unsafeAtomicAdd(loss_out, acc / (float)n);
+}
+
+extern "C" int dle_bce_logits(const void* logits, const float* target, float* loss_out, void* dlogits,
+                              const float* grad_scale_dev, int64_t n, int64_t ld_logits, int dtype,
+                              hipStream_t stream) {
+  DLE_CHECK_ARG(loss_out, "bce_logits: null loss pointer");
+  hipError_t e = hipMemsetAsync(loss_out, 0, 4, stream);
+  if (e != hipSuccess) { dle_set_error("bce memset: %s", hipGetErrorString(e)); return (int)e; }
+  if (n == 0) return 0;
+  DLE_CHECK_ARG(logits && target, "bce_logits: null pointer");
+  const int grid = ew_grid(n, 256 * 4);
+  if (dtype == DLE_F32) hipLaunchKernelGGL(bce_logits_kernel<DLE_F32>, dim3(grid), dim3(256), 0, stream, logits, target, loss_out, dlogits, grad_scale_dev, (long long)n, (long long)ld_logits);
+  else if (dtype == DLE_F16) hipLaunchKernelGGL(bce_logits_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, logits, target, loss_out, dlogits, grad_scale_dev, (long long)n, (long long)ld_logits);
+  else if (dtype == DLE_BF16) hipLaunchKernelGGL(bce_logits_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, logits, target, loss_out, dlogits, grad_scale_dev, (long long)n, (long long)ld_logits);
+  else { dle_set_error("bce_logits: bad dtype %d", dtype); return -1; }
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- GradScaler.update(): torch._amp_update_scale_ on device scalars -----------------------------------
+// found_inf > 0: scale *= backoff, tracker = 0; else tracker += 1 and, when it reaches the interval,
+// scale *= growth (kept if the product overflows), tracker = 0.  inv_scale (optional) = 1/scale for the
+// next step's unscale; found_inf is cleared for the next step when clear_found_inf != 0.
+__global__ void amp_update_scale_kernel(float* scale, int* growth_tracker, float* found_inf, float* inv_scale,
+                                        float growth, float backoff, int interval, int clear_found_inf) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = *scale;
+  if (*found_inf > 0.f) {
+    s *= backoff;
+    *growth_tracker = 0;
+  } else {
+    const int t = *growth_tracker + 1;
+    if (t == interval) {
+      const float ns = s * growth;
+      if (isfinite(ns)) s = ns;
+      *growth_tracker = 0;
+    } else {
+      *growth_tracker = t;
+    }
+  }
+  *scale = s;
+  if (inv_scale) *inv_scale = 1.0f / s;
+  if (clear_found_inf) *found_inf = 0.f;
+}
+
+extern "C" int dle_amp_update_scale(float* scale, int* growth_tracker, float* found_inf, float* inv_scale,
+                                    float growth_factor, float backoff_factor, int growth_interval,
+                                    int clear_found_inf, hipStream_t stream) {
+  DLE_CHECK_ARG(scale && growth_tracker && found_inf, "amp_update_scale: null pointer");
+  hipLaunchKernelGGL(amp_update_scale_kernel, dim3(1), dim3(64), 0, stream, scale, growth_tracker, found_inf,
+                     inv_scale, growth_factor, backoff_factor, growth_interval, clear_found_inf);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// found_inf |= any non-finite in x (16-bit or fp32), 16 B per lane.  Used on the embedding gradient
+// (GradScaler.unscale_ on the sparse grad values, main.py:605) without a separate multiply pass.
+template <int DT>
+__global__ __launch_bounds__(256) void nonfinite_kernel(const void* __restrict__ x, float* __restrict__ found_inf,
+                                                        long long n) {
+  bool bad = false;
+  if (DT == DLE_F32) {
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+      const uint4_t u = ((const uint4_t*)x)[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bad |= (u[k] & 0x7f800000u) == 0x7f800000u;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3))
+      bad |= (((const unsigned int*)x)[(n4 << 2) + threadIdx.x] & 0x7f800000u) == 0x7f800000u;
+  } else {
+    const unsigned int em = DT == DLE_F16 ? 0x7c00u : 0x7f80u;
+    const long long n8 = n >> 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+      const uint4_t u = ((const uint4_t*)x)[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bad |= ((u[k] & em) == em);
+        bad |= (((u[k] >> 16) & em) == em);
+      }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7))
+      bad |= (((const unsigned short*)x)[(n8 << 3) + threadIdx.x] & em) == em;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) *found_inf = 1.0f;
+}
+
+extern "C" int dle_check_nonfinite(const void* x, float* found_inf, int64_t n, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(found_inf, "check_nonfinite: null flag");
+  if (n == 0) return 0;
+  DLE_CHECK_ARG(x && (((uintptr_t)x) & 15) == 0, "check_nonfinite: null or misaligned pointer");
+  const int grid = ew_grid(n / 8 + 1, 256);
+  if (dtype == DLE_F32) hipLaunchKernelGGL(nonfinite_kernel<DLE_F32>, dim3(grid), dim3(256), 0, stream, x, found_inf, (long long)n);
+  else if (dtype == DLE_F16) hipLaunchKernelGGL(nonfinite_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, x, found_inf, (long long)n);
+  else if (dtype == DLE_BF16) hipLaunchKernelGGL(nonfinite_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, x, found_inf, (long long)n);
+  else { dle_set_error("check_nonfinite: bad dtype %d", dtype); return -1; }
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- ReLU backward on strided 2-D views: out[r,c] = y[r,c] > 0 ? g[r,c] : 0  (16-bit, 8 elems / lane) ----
+// (nn.ReLU(inplace=True) backward in TorchMlp, Recommendation/DLRM/dlrm/nn/mlps.py:85-87, where the
+//  gradient arrives from a non-GEMM producer; GEMM producers fuse the mask in their epilogue.)
+template <int DT>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const unsigned short* __restrict__ g,
+                                                       const unsigned short* __restrict__ y,
+                                                       unsigned short* __restrict__ out, long long rows, int cols8,
+                                                       long long ld_g, long long ld_y, long long ld_o) {
+  const long long total = rows * cols8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cols8;
+    const int c = (int)(i - r * cols8) * 8;
+    const ushort8_t gv = *(const ushort8_t*)(g + r * ld_g + c);
+    const ushort8_t yv = *(const ushort8_t*)(y + r * ld_y + c);
+    ushort8_t o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = Elem<DT>::to_f32(yv[k]) > 0.f ? gv[k] : (unsigned short)0;
+    *(ushort8_t*)(out + r * ld_o + c) = o;
+  }
+}
+
+extern "C" int dle_relu_bwd(const void* g, const void* y, void* out, int64_t rows, int cols, int64_t ld_g,
+                            int64_t ld_y, int64_t ld_out, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "relu_bwd: 16-bit dtypes only (got %d)", dtype);
+  DLE_CHECK_ARG(rows >= 0 && cols >= 0 && cols % 8 == 0, "relu_bwd: cols must be a multiple of 8");
+  if (rows == 0 || cols == 0) return 0;
+  DLE_CHECK_ARG(g && y && out, "relu_bwd: null pointer");
+  DLE_CHECK_ARG(((((uintptr_t)g) | ((uintptr_t)y) | ((uintptr_t)out)) & 15) == 0 && ld_g % 8 == 0 && ld_y % 8 == 0 && ld_out % 8 == 0,
+                "relu_bwd: rows must be 16-byte aligned");
+  const int grid = ew_grid((long long)rows * (cols / 8), 256);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(relu_bwd_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)g, (const unsigned short*)y, (unsigned short*)out, (long long)rows, cols / 8, (long long)ld_g, (long long)ld_y, (long long)ld_out);
+  else hipLaunchKernelGGL(relu_bwd_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)g, (const unsigned short*)y, (unsigned short*)out, (long long)rows, cols / 8, (long long)ld_g, (long long)ld_y, (long long)ld_out);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}

@@ -293,10 +293,10 @@ __global__ __launch_bounds__(MT_BLOCK) void mt_lamb_stage2(const long long* __re
 }
 
 // -------------------------------------------------------------------- SGD (+momentum, nesterov, wd)
-// lists: 0 = g (GT), 1 = p (fp32), [2 = momentum buffer (fp32)], [last = low-precision model copy]
+// lists: 0 = g (GT), 1 = p (fp32), [2 = momentum buffer (fp32)], [last = low-precision model copy (CT)]
 // torch.optim.SGD semantics (CN/image_classification/optimizers.py:34-56): d = g*inv_scale + wd*p;
 // buf = first ? d : mom*buf + (1-damp)*d; d = nesterov ? d + mom*buf : buf; p -= lr*d.
-template <int GT, bool HAS_MOM>
+template <int GT, bool HAS_MOM, int CT>
 __global__ __launch_bounds__(MT_BLOCK) void mt_sgd(const long long* __restrict__ table, int n, int chunk,
                                                    const float* __restrict__ skip_flag,
                                                    const float* __restrict__ lr_ptr, float lr_host, float momentum,
@@ -314,7 +314,9 @@ __global__ __launch_bounds__(MT_BLOCK) void mt_sgd(const long long* __restrict__
   const typename MtIO<GT>::T* g = (const typename MtIO<GT>::T*)t.ptr[0 * n + ti] + off;
   float* p = (float*)t.ptr[1 * n + ti] + off;
   float* mb = HAS_MOM ? (float*)t.ptr[2 * n + ti] + off : nullptr;
-  const bool vec = ((((uintptr_t)g) | ((uintptr_t)p) | ((uintptr_t)mb)) & 15) == 0;
+  // optional low-precision working copy of the parameter (the AMP "model weights"), last list
+  unsigned short* pc = CT >= 0 ? (unsigned short*)t.ptr[(HAS_MOM ? 3 : 2) * n + ti] + off : nullptr;
+  const bool vec = ((((uintptr_t)g) | ((uintptr_t)p) | ((uintptr_t)mb)) & 15) == 0 && ((((uintptr_t)pc) & 7) == 0);
   const long long len4 = len & ~3LL;
   for (long long i = (long long)threadIdx.x * 4; i < len; i += MT_BLOCK * 4) {
     const bool full = i < len4;
@@ -345,10 +347,12 @@ __global__ __launch_bounds__(MT_BLOCK) void mt_sgd(const long long* __restrict__
     if (full) {
       st4<DLE_F32>(p + i, rp, vec);
       if (HAS_MOM) st4<DLE_F32>(mb + i, rb, vec);
+      if (CT >= 0) st4<(CT >= 0 ? CT : DLE_F16)>(pc + i, rp, vec);
     } else {
       for (int k = 0; k < cnt; ++k) {
         p[i + k] = rp[k];
         if (HAS_MOM) mb[i + k] = rb[k];
+        if (CT >= 0) MtIO<(CT >= 0 ? CT : DLE_F16)>::st(pc + i + k, rp[k]);
       }
     }
   }
@@ -436,16 +440,19 @@ extern "C" int dle_mt_lamb_stage2(const int64_t* table_dev, int n_tensors, int64
 extern "C" int dle_mt_sgd(const int64_t* table_dev, int n_tensors, int64_t total_chunks, int chunk, int grad_dtype,
                           int has_momentum, const float* skip_flag_dev, const float* lr_dev, float lr_host,
                           float momentum, float dampening, float weight_decay, int nesterov, int first_step,
-                          const float* inv_scale_dev, hipStream_t stream) {
+                          const float* inv_scale_dev, int copy_dtype, hipStream_t stream) {
   DLE_CHECK_ARG(table_dev, "mt_sgd: null table");
+  DLE_CHECK_ARG(copy_dtype == -1 || copy_dtype == DLE_F16 || copy_dtype == DLE_BF16, "mt_sgd: bad copy dtype %d", copy_dtype);
   if (n_tensors == 0 || total_chunks == 0) return 0;
   dim3 grid((unsigned)total_chunks), block(MT_BLOCK);
-#define GO(GT, HM) hipLaunchKernelGGL((mt_sgd<GT, HM>), grid, block, 0, stream, (const long long*)table_dev, n_tensors, chunk, skip_flag_dev, lr_dev, lr_host, momentum, dampening, weight_decay, nesterov, first_step, inv_scale_dev)
+#define GO3(GT, HM, CT) hipLaunchKernelGGL((mt_sgd<GT, HM, CT>), grid, block, 0, stream, (const long long*)table_dev, n_tensors, chunk, skip_flag_dev, lr_dev, lr_host, momentum, dampening, weight_decay, nesterov, first_step, inv_scale_dev)
+#define GO(GT, HM) do { if (copy_dtype == DLE_F16) GO3(GT, HM, DLE_F16); else if (copy_dtype == DLE_BF16) GO3(GT, HM, DLE_BF16); else GO3(GT, HM, -1); } while (0)
   if (grad_dtype == DLE_F32) { if (has_momentum) GO(DLE_F32, true); else GO(DLE_F32, false); }
   else if (grad_dtype == DLE_F16) { if (has_momentum) GO(DLE_F16, true); else GO(DLE_F16, false); }
   else if (grad_dtype == DLE_BF16) { if (has_momentum) GO(DLE_BF16, true); else GO(DLE_BF16, false); }
   else { dle_set_error("mt_sgd: bad dtype %d", grad_dtype); return -1; }
 #undef GO
+#undef GO3
   DLE_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,216 @@
+"""DLRM train step on MI355X: forward, loss, backward, sparse + dense SGD, loss-scale update.
+
+Mirrors the reference's step (Recommendation/DLRM/dlrm/scripts/main.py):
+    forward_backward  :585-594   autocast forward, BCEWithLogits on this rank's label slice, scaled backward
+    weight_update     :596-608   scaler.step(mlp_optimizer); scaler.unscale_(embedding_optimizer);
+                                 embedding_optimizer.step(); scaler.update()
+    LR compensation   :444-452   model-parallel parts (embeddings, bottom MLP) use lr / world_size
+    CudaGraphWrapper  :194-274   whole-step capture  (here: HIP graph through torch.cuda.CUDAGraph)
+and the hybrid-parallel exchange (dlrm/model/distributed.py:25-98): one all-to-all forward, one backward,
+plus the data-parallel all-reduce (mean) of the top-MLP gradients, both through torch.distributed
+(backend "nccl" == RCCL over xGMI) on side streams overlapped with the remaining backward work.
+
+One deliberate difference: on a gradient overflow the reference still applies the embedding update
+(embedding_optimizer.step() is called directly, main.py:606); here the sparse update is skipped together
+with the dense one (found_inf gates both), the scale is backed off exactly as GradScaler does.
+"""
+from typing import Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from .. import functional as F
+from .. import multi_tensor as mt
+from .model import DistributedDlrm
+from .placement import ExchangePlan
+
+
+class GradScalerState:
+    """Device-resident loss-scale state (torch.cuda.amp.GradScaler semantics, main.py:497)."""
+
+    def __init__(self, device, enabled=True, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5,
+                 growth_interval=int(1e9)):
+        self.enabled = enabled
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        s = init_scale if enabled else 1.0
+        self.scale = torch.full((1,), s, dtype=torch.float32, device=device)
+        self.inv_scale = torch.full((1,), 1.0 / s, dtype=torch.float32, device=device)
+        self.found_inf = torch.zeros(1, dtype=torch.float32, device=device)
+        self.growth_tracker = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def update(self):
+        if self.enabled:
+            F.amp_update_scale_(self.scale, self.growth_tracker, self.found_inf, self.inv_scale,
+                                self.growth_factor, self.backoff_factor, min(self.growth_interval, 2 ** 31 - 1))
+
+
+class _FlatGrads:
+    """fp32 gradients of a list of Linear layers as views of ONE flat buffer (a single all-reduce bucket)."""
+
+    def __init__(self, linears, device):
+        n = sum(l.weight.numel() + l.bias.numel() for l in linears)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self.views = []
+        o = 0
+        for l in linears:
+            gw = self.flat[o:o + l.weight.numel()].view_as(l.weight)
+            o += l.weight.numel()
+            gb = self.flat[o:o + l.bias.numel()]
+            o += l.bias.numel()
+            self.views.append((gw, gb))
+
+    def tensors(self):
+        return [t for pair in self.views for t in pair]
+
+
+class DlrmTrainer:
+    def __init__(self, model: DistributedDlrm, lr: float, batch_sizes_per_gpu: Sequence[int],
+                 vectors_per_gpu: Optional[Sequence[int]] = None, rank: int = 0, world_size: int = 1,
+                 amp: bool = True, init_scale: float = 65536.0, freeze_mlps=False, freeze_embeddings=False,
+                 process_group=None):
+        self.model = model
+        self.rank, self.world = rank, world_size
+        self.device = model.top_model.out.weight.device
+        self.pg = process_group
+        self.freeze_mlps, self.freeze_embeddings = freeze_mlps, freeze_embeddings
+        d = model._embedding_dim
+        if vectors_per_gpu is None:
+            vectors_per_gpu = [model.bottom_model.num_feature_vectors]
+        self.plan = ExchangePlan(batch_sizes_per_gpu, vectors_per_gpu, d, rank)
+        self.scaler = GradScalerState(self.device, enabled=amp and model.compute_dtype == torch.float16,
+                                      init_scale=init_scale)
+        self.base_lr = lr
+        self.lr_factor = 1.0
+        # device-resident learning rates (no host sync / graph friendly)
+        self.lr_dp = torch.full((1,), lr, dtype=torch.float32, device=self.device)               # top model
+        self.lr_mp = torch.full((1,), lr / world_size, dtype=torch.float32, device=self.device)  # bottom parts
+        top = model.top_model
+        self.top_linears = top.mlp.linears + [top.out]
+        self.top_grads = _FlatGrads(self.top_linears, self.device)
+        bm = model.bottom_model.mlp
+        self.bot_linears = bm.linears if bm is not None else []
+        self.bot_grads = _FlatGrads(self.bot_linears, self.device) if bm is not None else None
+        model.refresh_working_copies()
+        self._tables = {}
+        self._build_tables()
+        self.noop = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.comm_stream = torch.cuda.Stream(device=self.device) if world_size > 1 else None
+        self.moving_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------ optimizer plumbing
+    def _build_tables(self):
+        top = self.model.top_model
+        w16 = top.mlp.working_copies() + [top.out_working_copy()]
+        # weights whose 16-bit copy has the same shape get the copy refreshed inside the SGD kernel
+        def split(linears, grads, copies):
+            same = [i for i, l in enumerate(linears) if copies[i].shape == l.weight.shape]
+            g, p, c = [], [], []
+            for i in same:
+                g.append(grads.views[i][0]); p.append(linears[i].weight.data); c.append(copies[i])
+            gb = [grads.views[i][1] for i in range(len(linears))]
+            pb = [l.bias.data for l in linears]
+            padded = [i for i in range(len(linears)) if i not in same]
+            gp = [grads.views[i][0] for i in padded]
+            pp = [linears[i].weight.data for i in padded]
+            return (mt.TensorTable([g, p, c]) if g else None,
+                    mt.TensorTable([gb + gp, pb + pp]), padded)
+        self.t_top_w, self.t_top_b, self.top_padded = split(self.top_linears, self.top_grads, w16)
+        if self.bot_grads is not None:
+            bw16 = self.model.bottom_model.mlp.working_copies()
+            self.t_bot_w, self.t_bot_b, self.bot_padded = split(self.bot_linears, self.bot_grads, bw16)
+        self.t_top_all = mt.TensorTable([[self.top_grads.flat]])
+
+    def set_lr_factor(self, factor: float):
+        """LearningRateScheduler.step() (dlrm/scripts/utils.py:278-286): lr = base * factor per group."""
+        if factor != self.lr_factor:
+            self.lr_factor = factor
+            self.lr_dp.fill_(self.base_lr * factor)
+            self.lr_mp.fill_(self.base_lr * factor / self.world)
+
+    def _dense_step(self):
+        sc = self.scaler
+        skip = sc.found_inf if sc.enabled else None
+        inv = sc.inv_scale if sc.enabled else None
+        if self.t_top_w is not None:
+            mt.sgd(self.t_top_w, self.lr_dp, skip_flag=skip, inv_scale=inv, has_momentum=False, model_copy=True)
+        mt.sgd(self.t_top_b, self.lr_dp, skip_flag=skip, inv_scale=inv, has_momentum=False)
+        top = self.model.top_model
+        for i in self.top_padded:
+            lin = self.top_linears[i]
+            copies = top.mlp.working_copies() + [top.out_working_copy()]
+            F.cast_rows(lin.weight.data, copies[i].dtype, cols_out=copies[i].shape[1], out=copies[i])
+        if self.bot_grads is not None:
+            if self.t_bot_w is not None:
+                mt.sgd(self.t_bot_w, self.lr_mp, skip_flag=skip, inv_scale=inv, has_momentum=False, model_copy=True)
+            mt.sgd(self.t_bot_b, self.lr_mp, skip_flag=skip, inv_scale=inv, has_momentum=False)
+            bm = self.model.bottom_model.mlp
+            for i in self.bot_padded:
+                c = bm.working_copies()[i]
+                F.cast_rows(self.bot_linears[i].weight.data, c.dtype, cols_out=c.shape[1], out=c)
+
+    # ------------------------------------------------------------------ hybrid-parallel exchange
+    def _bottom_to_top(self, local_out):
+        """[B_global, n_r, D] -> [B_r, n_total, D] (device feature order).  all_to_all_single over RCCL."""
+        p = self.plan
+        recv = torch.empty(sum(p.fwd_recv_splits), dtype=local_out.dtype, device=local_out.device)
+        dist.all_to_all_single(recv, local_out.view(-1), p.fwd_recv_splits, p.fwd_send_splits, group=self.pg)
+        x = torch.empty((p.local_batch, p.n_total, p.dim), dtype=local_out.dtype, device=local_out.device)
+        for s in range(p.world):
+            if p.vectors[s] == 0:
+                continue
+            blk = recv[p.recv_block_start[s]:p.recv_block_start[s] + p.fwd_recv_splits[s]]
+            F.copy_rows(blk.view(p.local_batch, p.vectors[s] * p.dim),
+                        x.view(p.local_batch, -1)[:, p.recv_feature_base[s] * p.dim:
+                                                  (p.recv_feature_base[s] + p.vectors[s]) * p.dim])
+        return x
+
+    def _top_to_bottom(self, grad_x):
+        """Reverse exchange of the gradient: [B_r, n_total, D] -> [B_global, n_r, D]."""
+        p = self.plan
+        send = torch.empty(sum(p.fwd_recv_splits), dtype=grad_x.dtype, device=grad_x.device)
+        for s in range(p.world):
+            if p.vectors[s] == 0:
+                continue
+            blk = send[p.recv_block_start[s]:p.recv_block_start[s] + p.fwd_recv_splits[s]]
+            F.copy_rows(grad_x.view(p.local_batch, -1)[:, p.recv_feature_base[s] * p.dim:
+                                                       (p.recv_feature_base[s] + p.vectors[s]) * p.dim],
+                        blk.view(p.local_batch, p.vectors[s] * p.dim))
+        out = torch.empty((p.global_batch, p.n_local, p.dim), dtype=grad_x.dtype, device=grad_x.device)
+        dist.all_to_all_single(out.view(-1), send, p.fwd_send_splits, p.fwd_recv_splits, group=self.pg)
+        return out
+
+    # ------------------------------------------------------------------ the step
+    def train_step(self, numerical_features, categorical_features, click):
+        """One optimisation step on a (global) batch.  Returns the device-resident fp32 loss [1]."""
+        m, p, sc = self.model, self.plan, self.scaler
+        bottom_out = m.bottom_model(numerical_features, categorical_features)
+        x = self._bottom_to_top(bottom_out) if self.world > 1 else bottom_out
+        logits = m.top_model(x)
+        labels = click[p.batch_start[self.rank]:p.batch_start[self.rank + 1]] if self.world > 1 else click
+        loss, dlogits = F.bce_with_logits(logits, labels, grad_scale=sc.scale if sc.enabled else None)
+        grad_x = m.top_model.backward(dlogits.view(-1, 1), grads=self.top_grads.views[:-1],
+                                      out_grads=self.top_grads.views[-1])
+        if self.world > 1:
+            # data-parallel mean of the top-MLP gradients, overlapped with the bottom backward
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(self.top_grads.flat, op=dist.ReduceOp.AVG, group=self.pg)
+            grad_bottom = self._top_to_bottom(grad_x)
+        else:
+            grad_bottom = grad_x
+        if sc.enabled:
+            F.check_nonfinite_(grad_bottom, sc.found_inf)
+        m.bottom_model.backward(grad_bottom, self.lr_mp, inv_scale=sc.inv_scale if sc.enabled else None,
+                                skip_flag=sc.found_inf if sc.enabled else None,
+                                mlp_grads=self.bot_grads.views if self.bot_grads is not None else None,
+                                freeze_embeddings=self.freeze_embeddings)
+        if self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if sc.enabled:
+            F.check_nonfinite_(self.top_grads.flat, sc.found_inf)
+            if self.bot_grads is not None:
+                F.check_nonfinite_(self.bot_grads.flat, sc.found_inf)
+        if not self.freeze_mlps:
+            self._dense_step()
+        sc.update()
+        return loss

@@ -1,0 +1,350 @@
+"""DLRM modules on the MI355X kernels, with the reference's module tree and state_dict key names.
+
+Mirrors (Recommendation/DLRM/):
+    dlrm/nn/mlps.py:78-114           TorchMlp        -> Mlp            (layers.{0,2,..}.weight/bias)
+    dlrm/nn/embeddings.py:163-224    FusedJointEmbedding -> JointEmbedding (weight [sum N, D], offsets)
+    dlrm/nn/interactions.py:40-101   DotInteraction / CudaDotInteraction -> DotInteraction
+    dlrm/nn/parts.py:27-136          DlrmBottom / DlrmTop
+    dlrm/model/distributed.py:104-179 DistributedDlrm
+Parameters are fp32 nn.Parameters (checkpoint compatible); every layer also keeps a 16-bit working copy
+that the optimizer kernel refreshes in the same pass that updates the master weight, replacing autocast's
+per-forward weight casts.  Compute is explicit forward()/backward() over the C-ABI kernels: the step is a
+fixed kernel sequence on one HIP stream (graph-capturable), not an autograd tape.
+The autograd-Function form of the individual ops (the reference's dlrm.cuda_ext boundary) lives in
+cuda_ext.py.
+"""
+import math
+from typing import List, Optional, Sequence
+
+import torch
+from torch import nn
+
+from .. import _cabi as C
+from .. import functional as F
+
+
+def _ceil_to(v, m):
+    return (v + m - 1) // m * m
+
+
+class Mlp(nn.Module):
+    """(Linear + ReLU) x L.  K of the first layer is zero-padded to a multiple of 8 in the 16-bit copies so
+    every operand row is 16-byte aligned for the MFMA GEMM loaders."""
+
+    def __init__(self, input_dim: int, sizes: Sequence[int], device="cuda", compute_dtype=torch.float16):
+        super().__init__()
+        layers = []
+        d = input_dim
+        for out_d in sizes:
+            layers.append(nn.Linear(d, out_d, device=device))
+            layers.append(nn.ReLU(inplace=True))   # placeholder module: keeps the reference's key numbering
+            d = out_d
+        self.layers = nn.Sequential(*layers)
+        self.input_dim = input_dim
+        self.sizes = list(sizes)
+        self.compute_dtype = compute_dtype
+        self._initialize_weights()
+        self._w16: List[torch.Tensor] = []
+        self._saved = None
+
+    def _initialize_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight.data, 0., math.sqrt(2. / (m.in_features + m.out_features)))
+                nn.init.normal_(m.bias.data, 0., math.sqrt(1. / m.out_features))
+
+    @property
+    def linears(self) -> List[nn.Linear]:
+        return [m for m in self.layers if isinstance(m, nn.Linear)]
+
+    @property
+    def weights(self):
+        return [m.weight for m in self.linears]
+
+    @property
+    def biases(self):
+        return [m.bias for m in self.linears]
+
+    # ---- 16-bit working copies ---------------------------------------------------------------
+    def k_padded(self, i):
+        return _ceil_to(self.linears[i].in_features, 8)
+
+    def refresh_working_copies(self):
+        """(Re)build the 16-bit weights from the fp32 masters (after init / checkpoint load)."""
+        self._w16 = []
+        for i, lin in enumerate(self.linears):
+            self._w16.append(F.cast_rows(lin.weight.data, self.compute_dtype, cols_out=self.k_padded(i)))
+        return self._w16
+
+    def working_copies(self):
+        if not self._w16:
+            self.refresh_working_copies()
+        return self._w16
+
+    # ---- explicit forward / backward ------------------------------------------------------------
+    def forward(self, x16: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x16 [B, k_padded(0)] 16-bit.  `out` (optional, may be a strided view) receives the last layer."""
+        w16 = self.working_copies()
+        acts = [x16]
+        h = x16
+        lins = self.linears
+        for i, lin in enumerate(lins):
+            m, k = h.shape[0], w16[i].shape[1]
+            n = lin.out_features
+            dst = out if (i == len(lins) - 1 and out is not None) else None
+            h = F.gemm(h, w16[i], m, n, k, True, True, out=dst, out_dtype=self.compute_dtype,
+                       bias=lin.bias.data, act=C.ACT_RELU)
+            acts.append(h)
+        self._saved = acts
+        return h
+
+    def backward(self, gy: torch.Tensor, need_input_grad: bool = False, grads=None, masked: bool = False):
+        """gy: gradient w.r.t. the (post-ReLU) output of the last layer, 16-bit, may be a strided view;
+        masked=True when the producer already applied the last ReLU's mask in its epilogue.
+        Writes fp32 weight/bias gradients into `grads` [(gw, gb), ...] (views of a flat bucket) or into
+        .grad.  Returns the input gradient when asked."""
+        acts, w16, lins = self._saved, self.working_copies(), self.linears
+        g = gy
+        for i in range(len(lins) - 1, -1, -1):
+            lin = lins[i]
+            y, x = acts[i + 1], acts[i]
+            m = x.shape[0]
+            if not masked:
+                g = F.relu_bwd(g, y)
+            gw, gb = grads[i] if grads is not None else (_grad_buf(lin.weight), _grad_buf(lin.bias))
+            kp = w16[i].shape[1]
+            # dW[n, k] = g[m, n]^T x[m, k]   (fp32, split-K)
+            gw_full = gw if kp == lin.in_features else torch.empty((lin.out_features, kp), dtype=torch.float32,
+                                                                   device=gw.device)
+            F.gemm(g, x, lin.out_features, kp, m, False, False, out=gw_full,
+                   splitk=F.pick_splitk(lin.out_features, kp, m))
+            if gw_full is not gw:
+                gw.copy_(gw_full[:, :lin.in_features])
+            F.colsum(g, out=gb)
+            if i > 0:
+                # dX = g W, masked by the ReLU of the previous layer in the epilogue
+                g = F.gemm(g, w16[i], m, kp, lin.out_features, True, False, out_dtype=self.compute_dtype,
+                           act=C.ACT_RELU_BWD, mask_src=acts[i])
+                masked = True
+            elif need_input_grad:
+                g = F.gemm(g, w16[i], m, kp, lin.out_features, True, False, out_dtype=self.compute_dtype)
+                return g
+        return None
+
+
+def _grad_buf(p: torch.Tensor) -> torch.Tensor:
+    if p.grad is None:
+        p.grad = torch.empty_like(p)
+    return p.grad
+
+
+class JointEmbedding(nn.Module):
+    """All local tables stacked in one fp32 matrix [sum N_t, D] + int64 offsets (FusedJointEmbedding layout).
+    forward() = row-id arithmetic (idx (mod N_t) + offset_t, int64) + gather; the update is the
+    duplicate-free sparse SGD applied straight from the 16-bit upstream gradient."""
+
+    def __init__(self, categorical_feature_sizes: Sequence[int], embedding_dim: int, device="cuda",
+                 hash_indices: bool = False, out_dtype=torch.float16):
+        super().__init__()
+        self._categorical_feature_sizes = list(categorical_feature_sizes)
+        self.embedding_dim = embedding_dim
+        self.hash_indices = hash_indices
+        self.out_dtype = out_dtype
+        off = torch.tensor([0] + list(categorical_feature_sizes), dtype=torch.int64).cumsum(0)
+        self.register_buffer("offsets", off.to(device))
+        self._offsets_host = off.numpy().copy()
+        self.weight = nn.Parameter(torch.empty((int(off[-1]), embedding_dim), device=device), requires_grad=True)
+        self._sizes_dev = torch.tensor(list(categorical_feature_sizes), dtype=torch.int64, device=device) \
+            if hash_indices else None
+        self._ws = None
+        self._rows = None
+
+    @property
+    def num_tables(self):
+        return len(self._categorical_feature_sizes)
+
+    @property
+    def weights(self):
+        o = self._offsets_host
+        return [self.weight.data[int(o[t]):int(o[t + 1])] for t in range(self.num_tables)]
+
+    def load_weights(self, weights):
+        for dst, src in zip(self.weights, weights):
+            dst.copy_(src)
+
+    def workspace(self):
+        if self._ws is None:
+            self._ws = F.EmbUpdateWorkspace(self._offsets_host, self.embedding_dim, self.weight.device)
+        return self._ws
+
+    def forward(self, categorical_inputs: torch.Tensor, out=None, out_batch_stride=0):
+        """categorical_inputs int64 [B, T] -> rows gathered into `out` (or a fresh [B,T,D])."""
+        self._rows = F.emb_offset_indices(categorical_inputs, self.offsets, self._sizes_dev)
+        return F.emb_gather_fwd(self.weight.data, self._rows, out_dtype=self.out_dtype, out=out,
+                                out_batch_stride=out_batch_stride)
+
+    def apply_sparse_sgd(self, grad, lr, inv_scale=None, skip_flag=None, grad_batch_stride=0):
+        F.emb_sgd_dedup_(self.weight.data, self._rows, grad, self.workspace(), lr, scale=inv_scale,
+                         skip_flag=skip_flag, grad_batch_stride=grad_batch_stride)
+
+
+class DotInteraction(nn.Module):
+    """[x0 | strict lower triangle of X X^T | zero pad to a multiple of 8]  (interactions.py:40-101)."""
+
+    def __init__(self, embedding_num: int, embedding_dim: int):
+        super().__init__()
+        self._num_interaction_inputs = embedding_num + 1
+        self._embedding_dim = embedding_dim
+        self._raw_num_interactions = (self._num_interaction_inputs * (self._num_interaction_inputs - 1) // 2
+                                      + embedding_dim)
+
+    @property
+    def num_interactions(self) -> int:
+        n = self._raw_num_interactions
+        return n + (((n - 1) // 8 + 1) * 8 - n)
+
+    def interact(self, bottom_output, bottom_mlp_output=None):
+        self._x = bottom_output
+        return F.dot_interact_fwd(bottom_output)
+
+    def backward(self, upstream, grad_out=None):
+        """-> grad [B, R, D] with the bottom-MLP slice already folded into row 0."""
+        g, _ = F.dot_interact_bwd(self._x, upstream, fuse_mlp_grad=True, grad_out=grad_out)
+        return g
+
+
+class DlrmBottom(nn.Module):
+    def __init__(self, num_numerical_features, categorical_feature_sizes, bottom_mlp_sizes=None,
+                 embedding_dim=128, hash_indices=False, device="cuda", compute_dtype=torch.float16):
+        super().__init__()
+        assert bottom_mlp_sizes is None or embedding_dim == bottom_mlp_sizes[-1], \
+            "The last bottom MLP layer must have same size as embedding."
+        self._embedding_dim = embedding_dim
+        self._categorical_feature_sizes = list(categorical_feature_sizes)
+        self.compute_dtype = compute_dtype
+        self.embeddings = (JointEmbedding(categorical_feature_sizes, embedding_dim, device, hash_indices,
+                                          out_dtype=compute_dtype)
+                           if len(categorical_feature_sizes) > 0 else None)
+        self.mlp = Mlp(num_numerical_features, bottom_mlp_sizes, device, compute_dtype) if bottom_mlp_sizes else None
+        if self.embeddings is not None:
+            for size, w in zip(categorical_feature_sizes, self.embeddings.weights):
+                nn.init.uniform_(w, -math.sqrt(1. / size), math.sqrt(1. / size))
+
+    @property
+    def num_categorical_features(self):
+        return len(self._categorical_feature_sizes)
+
+    @property
+    def num_feature_vectors(self):
+        return self.num_categorical_features + int(self.mlp is not None)
+
+    def forward(self, numerical_input, categorical_inputs, batch=None):
+        """-> [B, n_local, D] 16-bit: bottom-MLP output in slot 0 (if this rank owns it), then the tables."""
+        n_vec = self.num_feature_vectors
+        d = self._embedding_dim
+        b = numerical_input.shape[0] if numerical_input is not None else categorical_inputs.shape[0]
+        dev = self.embeddings.weight.device if self.embeddings is not None else numerical_input.device
+        out = torch.empty((b, n_vec, d), dtype=self.compute_dtype, device=dev)
+        slot = 0
+        if self.mlp is not None:
+            x16 = F.cast_rows(numerical_input, self.compute_dtype, cols_out=self.mlp.k_padded(0))
+            self.mlp(x16, out=out[:, 0, :])
+            slot = 1
+        if self.embeddings is not None:
+            self.embeddings(categorical_inputs, out=out[:, slot:, :], out_batch_stride=n_vec * d)
+        self._out = out
+        return out
+
+    def backward(self, grad_out, emb_lr, inv_scale=None, skip_flag=None, mlp_grads=None, freeze_embeddings=False):
+        """grad_out [B, n_local, D] 16-bit.  Embedding rows are updated in place (fused sparse SGD);
+        bottom-MLP gradients are produced for the dense optimizer."""
+        n_vec, d = self.num_feature_vectors, self._embedding_dim
+        slot = 1 if self.mlp is not None else 0
+        if self.embeddings is not None and not freeze_embeddings:
+            self.embeddings.apply_sparse_sgd(grad_out[:, slot:, :], emb_lr, inv_scale, skip_flag,
+                                             grad_batch_stride=n_vec * d)
+        if self.mlp is not None:
+            self.mlp.backward(grad_out[:, 0, :], grads=mlp_grads)
+
+
+class DlrmTop(nn.Module):
+    def __init__(self, top_mlp_sizes, interaction: DotInteraction, device="cuda", compute_dtype=torch.float16):
+        super().__init__()
+        self.interaction = interaction
+        self.mlp = Mlp(interaction.num_interactions, top_mlp_sizes[:-1], device, compute_dtype)
+        self.out = nn.Linear(top_mlp_sizes[-2], top_mlp_sizes[-1], device=device)
+        self.compute_dtype = compute_dtype
+        # weight facing the zero-padded interaction column stays zero for the whole training (parts.py:121-125)
+        nn.init.zeros_(self.mlp.weights[0][:, -1].data)
+        self._out_w16 = None
+
+    def out_working_copy(self):
+        if self._out_w16 is None:
+            self._out_w16 = F.cast_rows(self.out.weight.data, self.compute_dtype)
+        return self._out_w16
+
+    def refresh_working_copies(self):
+        self.mlp.refresh_working_copies()
+        self._out_w16 = None
+        self.out_working_copy()
+
+    def forward(self, bottom_output, bottom_mlp_output=None):
+        z = self.interaction.interact(bottom_output, bottom_mlp_output)
+        h = self.mlp(z)
+        self._h = h
+        w = self.out_working_copy()
+        return F.gemm(h, w, h.shape[0], w.shape[0], w.shape[1], True, True, out_dtype=self.compute_dtype,
+                      bias=self.out.bias.data)
+
+    def backward(self, dlogits, grads=None, out_grads=None, grad_x_out=None):
+        """dlogits [B, 1] 16-bit -> gradient of the interaction input [B, R, D]."""
+        h, w = self._h, self.out_working_copy()
+        m, n, k = h.shape[0], w.shape[0], w.shape[1]
+        gw, gb = out_grads if out_grads is not None else (_grad_buf(self.out.weight), _grad_buf(self.out.bias))
+        F.gemm(dlogits, h, n, k, m, False, False, out=gw, splitk=F.pick_splitk(n, k, m))
+        F.colsum(dlogits, out=gb)
+        gh = F.gemm(dlogits, w, m, k, n, True, False, out_dtype=self.compute_dtype, act=C.ACT_RELU_BWD,
+                    mask_src=h)
+        gz = self.mlp.backward(gh, need_input_grad=True, grads=grads, masked=True)
+        return self.interaction.backward(gz, grad_out=grad_x_out)
+
+
+class DistributedDlrm(nn.Module):
+    """Same constructor surface as the reference's DistributedDlrm (model/distributed.py:106-159); the
+    embedding/interaction/MLP implementations are fixed to the HIP kernels."""
+
+    def __init__(self, num_numerical_features, categorical_feature_sizes, bottom_mlp_sizes, top_mlp_sizes,
+                 vectors_per_gpu=None, embedding_device_mapping=None, world_num_categorical_features=None,
+                 embedding_type="joint_fused", embedding_dim=128, interaction_op="cuda_dot", hash_indices=False,
+                 use_cpp_mlp=True, fp16=True, bottom_features_ordered=False, device="cuda",
+                 compute_dtype=None, world_size=1):
+        super().__init__()
+        if interaction_op not in ("cuda_dot", "dot"):
+            raise ValueError("only the dot interaction is on the MI355X hot path (got %r)" % interaction_op)
+        self.distributed = world_size > 1
+        self._vectors_per_gpu = vectors_per_gpu
+        self._embedding_dim = embedding_dim
+        self._interaction_op = interaction_op
+        self._hash_indices = hash_indices
+        cd = compute_dtype or (torch.float16 if fp16 else torch.bfloat16)
+        self.compute_dtype = cd
+        if self.distributed:
+            order = torch.tensor([-1] + [i for bucket in embedding_device_mapping for i in bucket],
+                                 dtype=torch.long, device=device) + 1
+            self._device_feature_order = order if bottom_features_ordered else None
+            self._feature_order = order.argsort() if bottom_features_ordered else None
+        else:
+            world_num_categorical_features = len(categorical_feature_sizes)
+            self._device_feature_order = self._feature_order = None
+        interaction = DotInteraction(world_num_categorical_features, embedding_dim)
+        self.bottom_model = DlrmBottom(num_numerical_features, categorical_feature_sizes, bottom_mlp_sizes,
+                                       embedding_dim, hash_indices=hash_indices, device=device, compute_dtype=cd)
+        self.top_model = DlrmTop(top_mlp_sizes, interaction, device=device, compute_dtype=cd)
+
+    def extra_repr(self):
+        return f"interaction_op={self._interaction_op}, hash_indices={self._hash_indices}"
+
+    def refresh_working_copies(self):
+        if self.bottom_model.mlp is not None:
+            self.bottom_model.mlp.refresh_working_copies()
+        self.top_model.refresh_working_copies()

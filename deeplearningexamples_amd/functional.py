@@ -25,8 +25,9 @@ def dot_interact_fwd(x, force_generic=False):
     return out
 
 
-def dot_interact_bwd(x, upstream, force_generic=False):
-    """-> (grad [B,R,C], mlp_grad [B,C])  (dotBasedInteractBwd)."""
+def dot_interact_bwd(x, upstream, force_generic=False, fuse_mlp_grad=False, grad_out=None):
+    """-> (grad [B,R,C], mlp_grad [B,C])  (dotBasedInteractBwd).  fuse_mlp_grad: mlp_grad is added onto
+    grad[:,0,:] in the kernel and None is returned in its place."""
     C.require_cuda(x, upstream)
     x = x.contiguous()
     b, r, c = x.shape
@@ -34,8 +35,8 @@ def dot_interact_bwd(x, upstream, force_generic=False):
     if tuple(upstream.shape) != (b, ow):
         raise ValueError("dot_interact_bwd: upstream grad must be [%d, %d], got %s" % (b, ow, tuple(upstream.shape)))
     upstream = upstream.to(x.dtype).contiguous()
-    grad = torch.empty_like(x)
-    mlp_grad = torch.empty((b, c), dtype=x.dtype, device=x.device)
+    grad = torch.empty_like(x) if grad_out is None else grad_out
+    mlp_grad = None if fuse_mlp_grad else torch.empty((b, c), dtype=x.dtype, device=x.device)
     C.call("dle_dot_interact_bwd", C.ptr(x), C.ptr(upstream), C.ptr(grad), C.ptr(mlp_grad), b, r, c,
            C.dt(x), int(force_generic), C.stream())
     return grad, mlp_grad
@@ -50,8 +51,10 @@ def _i64(t, name):
     return t.contiguous()
 
 
-def emb_gather_fwd(weight, indices, offsets=None, hash_sizes=None, out_dtype=torch.float32):
-    """out[b,t,:] = W[(idx[b,t] mod size_t) + offsets[t], :]."""
+def emb_gather_fwd(weight, indices, offsets=None, hash_sizes=None, out_dtype=torch.float32, out=None,
+                   out_batch_stride=0):
+    """out[b,t,:] = W[(idx[b,t] mod size_t) + offsets[t], :].  `out` (+ out_batch_stride in elements) lets
+    the rows land inside a wider [B, 1+T, D] buffer."""
     C.require_cuda(weight, indices, offsets, hash_sizes)
     if weight.dtype != torch.float32 or weight.dim() != 2:
         raise ValueError("embedding table must be a 2-D fp32 tensor")
@@ -63,9 +66,10 @@ def emb_gather_fwd(weight, indices, offsets=None, hash_sizes=None, out_dtype=tor
     d = weight.shape[1]
     if offsets is not None and offsets.numel() < t:
         raise ValueError("offsets has %d entries for %d tables" % (offsets.numel(), t))
-    out = torch.empty((b, t, d), dtype=out_dtype, device=weight.device)
+    if out is None:
+        out = torch.empty((b, t, d), dtype=out_dtype, device=weight.device)
     C.call("dle_emb_gather_fwd", C.ptr(weight), C.ptr(indices), C.ptr(offsets), C.ptr(hash_sizes), C.ptr(out),
-           b, t, d, C.dt(out_dtype), C.stream())
+           b, t, d, C.dt(out.dtype), out_batch_stride, C.stream())
     return out
 
 
@@ -100,8 +104,104 @@ def emb_sparse_sgd_(weight, rows, grad, lr, scale=None, skip_flag=None):
     lr_dev = lr if isinstance(lr, torch.Tensor) else None
     lr_host = 0.0 if lr_dev is not None else float(lr)
     C.call("dle_emb_sparse_sgd", C.ptr(weight), C.ptr(rows), C.ptr(grad), C.ptr(lr_dev), lr_host, C.ptr(scale),
-           C.ptr(skip_flag), rows.numel(), d, C.dt(grad), C.stream())
+           C.ptr(skip_flag), rows.numel(), 1, d, 0, C.dt(grad), C.stream())
     return weight
+
+
+class EmbUpdateWorkspace:
+    """Persistent state of the duplicate-free sparse SGD: head[total_rows] (all -1 between calls),
+    next[batch*tables] scratch, the small-table mask and the host copy of the table offsets."""
+
+    def __init__(self, table_offsets, dim, device):
+        import ctypes
+        import numpy as np
+        off = np.ascontiguousarray(np.asarray(table_offsets, dtype=np.int64))
+        self.offsets_host = off
+        self.tables = off.size - 1
+        self.dim = dim
+        mask = np.zeros(self.tables, dtype=np.uint8)
+        C.call("dle_emb_small_table_mask", off.ctypes.data_as(ctypes.c_void_p), self.tables, dim,
+               mask.ctypes.data_as(ctypes.c_void_p))
+        self.mask_host = mask
+        self.is_small = torch.from_numpy(mask).to(device)
+        self.head = torch.full((int(off[-1]),), -1, dtype=torch.int32, device=device)
+        self.next = None
+
+    def next_for(self, n, device):
+        if self.next is None or self.next.numel() < n:
+            self.next = torch.empty(n, dtype=torch.int32, device=device)
+        return self.next
+
+
+def emb_sgd_dedup_(weight, rows, grad, ws, lr, scale=None, skip_flag=None, grad_batch_stride=0):
+    """In place W[rows[b,t]] -= lr*scale*grad[b,t] with duplicate rows summed first (no float atomics).
+    rows int64 [B,T]; grad: tensor whose element (b,t,0) sits at data_ptr + b*grad_batch_stride + t*dim."""
+    import ctypes
+    C.require_cuda(weight, rows, grad, scale, skip_flag)
+    if weight.dtype != torch.float32 or not weight.is_contiguous():
+        raise ValueError("embedding table must be contiguous fp32")
+    rows = _i64(rows, "rows")
+    b, t = rows.shape
+    if t != ws.tables or weight.shape[1] != ws.dim:
+        raise ValueError("workspace was built for %d tables x dim %d" % (ws.tables, ws.dim))
+    lr_dev = lr if isinstance(lr, torch.Tensor) else None
+    lr_host = 0.0 if lr_dev is not None else float(lr)
+    nxt = ws.next_for(b * t, weight.device)
+    C.call("dle_emb_sgd_dedup", C.ptr(weight), C.ptr(rows), C.ptr(grad), C.ptr(ws.head), C.ptr(nxt),
+           C.ptr(ws.is_small), ws.offsets_host.ctypes.data_as(ctypes.c_void_p), C.ptr(lr_dev), lr_host,
+           C.ptr(scale), C.ptr(skip_flag), b, t, ws.dim, grad_batch_stride, C.dt(grad), C.stream())
+    return weight
+
+
+# ------------------------------------------------------------------ small train-step kernels
+def cast_rows(x, out_dtype, cols_out=None, out=None):
+    """2-D cast with optional zero padding of the trailing columns (K padded to a multiple of 8/16)."""
+    C.require_cuda(x, out)
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("cast_rows expects a 2-D tensor with unit inner stride")
+    r, c = x.shape
+    co = c if cols_out is None else cols_out
+    if out is None:
+        out = torch.empty((r, co), dtype=out_dtype, device=x.device)
+    C.call("dle_cast_rows", C.ptr(x), C.ptr(out), r, c, co, x.stride(0), out.stride(0), C.dt(x), C.dt(out),
+           C.stream())
+    return out
+
+
+def cast(x, out_dtype, out=None):
+    """Flat dtype cast of a contiguous tensor."""
+    C.require_cuda(x, out)
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    n = x.numel()
+    C.call("dle_cast_rows", C.ptr(x), C.ptr(out), 1, n, n, n, n, C.dt(x), C.dt(out), C.stream())
+    return out
+
+
+def bce_with_logits(logits, target, grad_scale=None, want_grad=True, ld_logits=1):
+    """-> (loss fp32 [1], dlogits or None).  dlogits = d(mean BCE)/dlogits * grad_scale."""
+    C.require_cuda(logits, target, grad_scale)
+    if target.dtype != torch.float32:
+        raise ValueError("BCE targets must be fp32")
+    n = target.numel()
+    loss = torch.empty(1, dtype=torch.float32, device=target.device)
+    dl = torch.empty(n, dtype=logits.dtype, device=logits.device) if want_grad else None
+    C.call("dle_bce_logits", C.ptr(logits), C.ptr(target), C.ptr(loss), C.ptr(dl), C.ptr(grad_scale), n,
+           ld_logits, C.dt(logits), C.stream())
+    return loss, dl
+
+
+def amp_update_scale_(scale, growth_tracker, found_inf, inv_scale=None, growth_factor=2.0, backoff_factor=0.5,
+                      growth_interval=2000, clear_found_inf=True):
+    C.require_cuda(scale, growth_tracker, found_inf, inv_scale)
+    C.call("dle_amp_update_scale", C.ptr(scale), C.ptr(growth_tracker), C.ptr(found_inf), C.ptr(inv_scale),
+           float(growth_factor), float(backoff_factor), int(growth_interval), int(clear_found_inf), C.stream())
+
+
+def check_nonfinite_(x, found_inf):
+    C.require_cuda(x, found_inf)
+    C.call("dle_check_nonfinite", C.ptr(x), C.ptr(found_inf), x.numel(), C.dt(x), C.stream())
 
 
 # ------------------------------------------------------------------ GEMM
@@ -175,3 +275,27 @@ def linear_wgrad(gy, x, out=None, accumulate=False):
         out = torch.empty((n, k), dtype=torch.float32, device=x.device)
         accumulate = False
     return gemm(gy, x, n, k, m, False, False, out=out, splitk=sk, accumulate=accumulate)
+
+
+def relu_bwd(g, y, out=None):
+    """g * (y > 0) for 16-bit 2-D (possibly row-strided) views."""
+    C.require_cuda(g, y, out)
+    if g.dim() != 2 or g.shape != y.shape or g.stride(1) != 1 or y.stride(1) != 1:
+        raise ValueError("relu_bwd expects matching 2-D views with unit inner stride")
+    r, c = g.shape
+    if out is None:
+        out = torch.empty((r, c), dtype=g.dtype, device=g.device)
+    C.call("dle_relu_bwd", C.ptr(g), C.ptr(y), C.ptr(out), r, c, g.stride(0), y.stride(0), out.stride(0), C.dt(g),
+           C.stream())
+    return out
+
+
+def copy_rows(src, dst):
+    """dst[r, :] = src[r, :] for 2-D views with unit inner stride (row strides may differ)."""
+    C.require_cuda(src, dst)
+    if src.shape != dst.shape or src.dtype != dst.dtype:
+        raise ValueError("copy_rows: shape/dtype mismatch")
+    r, c = src.shape
+    C.call("dle_cast_rows", C.ptr(src), C.ptr(dst), r, c, c, src.stride(0), dst.stride(0), C.dt(src), C.dt(dst),
+           C.stream())
+    return dst

@@ -90,8 +90,13 @@ def lamb_stage2(table, noop_flag, param_norm, update_norm, lr, weight_decay, use
 
 
 def sgd(table, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, first_step=False,
-        skip_flag=None, inv_scale=None):
+        skip_flag=None, inv_scale=None, has_momentum=None, model_copy=False):
+    """lists: g, p [, momentum buffer] [, 16-bit model copy (model_copy=True -> last list)]."""
     lr_dev = lr if isinstance(lr, torch.Tensor) else None
+    if has_momentum is None:
+        has_momentum = (table.n_lists - int(model_copy)) >= 3
+    copy_dt = C.dt(table.dtypes[-1]) if model_copy else -1
     C.call("dle_mt_sgd", C.ptr(table.table), table.n, table.total_chunks, table.chunk, C.dt(table.dtypes[0]),
-           int(table.n_lists >= 3), C.ptr(skip_flag), C.ptr(lr_dev), 0.0 if lr_dev is not None else float(lr),
-           momentum, dampening, weight_decay, int(nesterov), int(first_step), C.ptr(inv_scale), C.stream())
+           int(has_momentum), C.ptr(skip_flag), C.ptr(lr_dev), 0.0 if lr_dev is not None else float(lr),
+           momentum, dampening, weight_decay, int(nesterov), int(first_step), C.ptr(inv_scale), copy_dt,
+           C.stream())

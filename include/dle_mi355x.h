@@ -37,7 +37,9 @@ int dle_device_check(int device, char* arch_name, int arch_name_len); /* 0 iff g
 int dle_dot_interact_out_width(int rows, int cols);
 int dle_dot_interact_fwd(const void* x, void* out, int batch, int rows, int cols, int dtype,
                          int force_generic, hipStream_t stream);
-/* grad[B,R,C] = U_sym X, mlp_grad[B,C] = upstream[:, :C]  (dotBasedInteractBwd returns both) */
+/* grad[B,R,C] = U_sym X, mlp_grad[B,C] = upstream[:, :C]  (dotBasedInteractBwd returns both).
+ * mlp_grad == NULL: fused form, upstream[:, :C] is added onto grad[:, 0, :] (the sum autograd forms
+ * because bottom_mlp_output and input[:,0] are the same tensor, dot_based_interact_fp16_bwd.cu:329-331). */
 int dle_dot_interact_bwd(const void* x, const void* upstream, void* grad, void* mlp_grad,
                          int batch, int rows, int cols, int dtype, int force_generic,
                          hipStream_t stream);
@@ -49,9 +51,11 @@ int dle_dot_interact_bwd(const void* x, const void* upstream, void* grad, void* 
  *   Recommendation/DLRM/dlrm/cuda_src/sparse_gather/sparse_pytorch_ops.cpp:1-15, gather_gpu.cu:79-171
  * weight fp32 [sum rows, dim]; indices int64 [batch, tables]; offsets int64 [tables(+1)] or NULL when
  * indices already address the joint table; hash_sizes int64 [tables] or NULL (idx %= size).       */
+/* out_batch_stride (elements, 0 = tables*dim): row (b,t) lands at out + b*stride + t*dim, so the gather
+ * can write straight into rows 1.. of the [B, 1+tables, dim] interaction input (no torch.cat).        */
 int dle_emb_gather_fwd(const float* weight, const int64_t* indices, const int64_t* offsets,
                        const int64_t* hash_sizes, void* out, int64_t batch, int tables, int dim,
-                       int out_dtype, hipStream_t stream);
+                       int out_dtype, int64_t out_batch_stride, hipStream_t stream);
 int dle_emb_offset_indices(const int64_t* indices, const int64_t* offsets, const int64_t* hash_sizes,
                            int64_t* rows_out, int64_t batch, int tables, hipStream_t stream);
 /* fp32 COO values of the sparse weight gradient: values = (float)grad * (*scale_dev or 1) */
@@ -61,7 +65,19 @@ int dle_emb_grad_values(const void* grad, float* values, const float* scale_dev,
  * skipped when *skip_flag_dev != 0 (GradScaler found_inf). */
 int dle_emb_sparse_sgd(float* weight, const int64_t* rows, const void* grad, const float* lr_dev,
                        float lr_host, const float* scale_dev, const float* skip_flag_dev,
-                       int64_t n_rows, int dim, int grad_dtype, hipStream_t stream);
+                       int64_t n_rows, int tables, int dim, int64_t grad_batch_stride, int grad_dtype,
+                       hipStream_t stream);
+/* Same update without float atomics (the train step's path): tiny tables are reduced in LDS, all other
+ * rows through per-row lists (one 4-byte atomicExch per lookup) and ONE plain row read-modify-write.
+ * head: int32[total rows] device workspace, all -1 on entry and restored on exit; next: int32[batch*tables]
+ * scratch; is_small: uint8[tables] device copy of dle_emb_small_table_mask(); table_offsets_host: HOST
+ * int64[tables+1].  grad row (b,t) at grad + b*grad_batch_stride + t*dim (stride 0 = tables*dim). */
+int dle_emb_small_table_mask(const int64_t* table_offsets_host, int tables, int dim, unsigned char* mask_host);
+int dle_emb_sgd_dedup(float* weight, const int64_t* rows, const void* grad, int32_t* head, int32_t* next,
+                      const unsigned char* is_small_dev, const int64_t* table_offsets_host,
+                      const float* lr_dev, float lr_host, const float* scale_dev,
+                      const float* skip_flag_dev, int64_t batch, int tables, int dim,
+                      int64_t grad_batch_stride, int grad_dtype, hipStream_t stream);
 
 /* ---- dense contraction with fused epilogue ---------------------------------------------------
  * replaces cuBLAS GEMM + NVFuser/apex epilogues: apex.mlp (Recommendation/DLRM/dlrm/nn/mlps.py:18-43),
@@ -103,11 +119,33 @@ int dle_mt_lamb_stage2(const int64_t* table_dev, int n_tensors, int64_t total_ch
                        int grad_dtype, int has_model_copy, const int* noop_flag,
                        const float* param_norm, const float* update_norm, const float* lr_dev,
                        float weight_decay, int use_nvlamb, hipStream_t stream);
-/* lists: g (grad_dtype), p (fp32) [, momentum buffer (fp32)] */
+/* lists: g (grad_dtype), p (fp32) [, momentum buffer (fp32)] [, low-precision model copy (copy_dtype)];
+ * copy_dtype = -1: no copy list.  The copy is the 16-bit working weight the next forward reads, written
+ * in the same pass (replaces autocast's per-forward weight cast). */
 int dle_mt_sgd(const int64_t* table_dev, int n_tensors, int64_t total_chunks, int chunk, int grad_dtype,
                int has_momentum, const float* skip_flag_dev, const float* lr_dev, float lr_host,
                float momentum, float dampening, float weight_decay, int nesterov, int first_step,
-               const float* inv_scale_dev, hipStream_t stream);
+               const float* inv_scale_dev, int copy_dtype, hipStream_t stream);
+
+/* ---- small train-step kernels (csrc/elementwise.hip) -------------------------------------------
+ * dle_cast_rows: out[r, c] = (out_dtype) in[r, c] for c < cols, 0 for cols <= c < cols_out; replaces
+ *   autocast's activation/weight casts (Recommendation/DLRM/dlrm/scripts/main.py:588).
+ * dle_bce_logits: torch.nn.BCEWithLogitsLoss(reduction="mean") forward + backward in one pass
+ *   (main.py:556,589-592): loss_out[0] = mean loss (fp32), dlogits[i] = (sigmoid(x_i) - y_i) * (*grad_scale)/n
+ *   in the logits' dtype (dlogits may be NULL); logits element i at logits[i*ld_logits].
+ * dle_amp_update_scale: GradScaler.update() = torch._amp_update_scale_ on device scalars (main.py:497,608).
+ * dle_check_nonfinite: found_inf = 1 if any element is inf/nan (GradScaler.unscale_'s check).        */
+int dle_cast_rows(const void* in, void* out, int64_t rows, int cols, int cols_out, int64_t ld_in,
+                  int64_t ld_out, int in_dtype, int out_dtype, hipStream_t stream);
+int dle_bce_logits(const void* logits, const float* target, float* loss_out, void* dlogits,
+                   const float* grad_scale_dev, int64_t n, int64_t ld_logits, int dtype, hipStream_t stream);
+int dle_amp_update_scale(float* scale, int* growth_tracker, float* found_inf, float* inv_scale,
+                         float growth_factor, float backoff_factor, int growth_interval,
+                         int clear_found_inf, hipStream_t stream);
+int dle_check_nonfinite(const void* x, float* found_inf, int64_t n, int dtype, hipStream_t stream);
+/* out[r,c] = y[r,c] > 0 ? g[r,c] : 0 on 16-bit strided views (nn.ReLU backward, dlrm/nn/mlps.py:85-87) */
+int dle_relu_bwd(const void* g, const void* y, void* out, int64_t rows, int cols, int64_t ld_g, int64_t ld_y,
+                 int64_t ld_out, int dtype, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -95,8 +95,63 @@ def gen_dlrm():
     print("dlrm golden written")
 
 
+def gen_dlrm_step():
+    """Per-step losses (+ final weights for the tiny case) of the REFERENCE's DistributedDlrm on CPU, fp32."""
+    from oracle import dlrm_step_oracle as SO
+    from oracle.dlrm_step_oracle import seeded_dlrm_state, seeded_dlrm_batch, DLRM_STEP_CONFIGS
+    ref = R.import_dlrm()
+    from dlrm.utils import distributed as du
+    du.get_world_size = lambda: 1          # no process group in the build container
+    for name, c in DLRM_STEP_CONFIGS.items():
+        model = ref.model.DistributedDlrm(
+            num_numerical_features=c["num"], categorical_feature_sizes=c["sizes"], bottom_mlp_sizes=c["bottom"],
+            top_mlp_sizes=c["top"], embedding_type="joint", embedding_dim=c["dim"], interaction_op="dot",
+            hash_indices=False, use_cpp_mlp=False, fp16=False, device="cpu")
+        state0 = seeded_dlrm_state(c["sizes"], c["dim"], c["bottom"], c["top"], c["num"], c["seed"])
+        with torch.no_grad():
+            for i, l in enumerate([m for m in model.bottom_model.mlp.layers if isinstance(m, torch.nn.Linear)]):
+                l.weight.copy_(state0[f"bottom_mlp.{i}.weight"]); l.bias.copy_(state0[f"bottom_mlp.{i}.bias"])
+            for i, l in enumerate([m for m in model.top_model.mlp.layers if isinstance(m, torch.nn.Linear)]):
+                l.weight.copy_(state0[f"top_mlp.{i}.weight"]); l.bias.copy_(state0[f"top_mlp.{i}.bias"])
+            model.top_model.out.weight.copy_(state0["out.weight"]); model.top_model.out.bias.copy_(state0["out.bias"])
+            model.bottom_model.embeddings.embedding.weight.copy_(state0["embedding"])
+        num, cat, click = seeded_dlrm_batch(c["sizes"], c["num"], c["batch"], c["seed"] + 1000)
+        mlp_params = list(model.top_model.parameters()) + list(model.bottom_model.mlp.parameters())
+        opt_mlp = torch.optim.SGD(mlp_params, lr=c["lr"])
+        opt_emb = torch.optim.SGD(model.bottom_model.embeddings.parameters(), lr=c["lr"])
+        loss_fn = torch.nn.BCEWithLogitsLoss(reduction="mean")
+        losses = []
+        for _ in range(c["steps"]):
+            for p_ in model.parameters():
+                p_.grad = None
+            out = model(num, cat.clone()).squeeze()
+            loss = loss_fn(out, click)
+            loss.backward()
+            opt_mlp.step()
+            opt_emb.step()
+            losses.append(float(loss.detach()))
+        # the restatement must reproduce the reference (same fp32 ops)
+        orc = SO.DlrmOracle(state0, c["sizes"], c["lr"])
+        ol = [orc.step(num, cat, click) for _ in range(c["steps"])]
+        assert np.allclose(ol, losses, rtol=5e-5, atol=1e-6), (name, ol, losses)
+        final = SO.state_from_reference(model)
+        for k in final:
+            fa, oa = final[k].numpy(), orc.p[k].detach().numpy()
+            assert np.abs(fa - oa).max() <= 2e-3 * max(np.abs(fa).max(), 1e-3), (name, k, np.abs(fa - oa).max())
+        arrs = {"losses": np.asarray(losses, np.float64)}
+        if name == "tiny":
+            for k, v in SO.state_to_numpy(final).items():
+                arrs["final." + k] = v
+        else:
+            arrs["final.out.weight"] = final["out.weight"].numpy()
+            arrs["final.bottom_mlp.0.weight"] = final["bottom_mlp.0.weight"].numpy()
+            arrs["final.embedding_head"] = final["embedding"][:64].numpy()
+        np.savez_compressed(os.path.join(GOLD, "dlrm_step_%s.npz" % name), **arrs)
+        print("dlrm_step", name, "losses", arrs["losses"])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dlrm", "lamb", "bert", "rn50"]
+    which = sys.argv[1:] or ["dlrm", "dlrm_step", "lamb", "bert", "rn50"]
     os.makedirs(GOLD, exist_ok=True)
     if not R.have_reference():
         sys.exit("reference not mounted; fixtures are generated in the build container only")

@@ -1,0 +1,93 @@
+"""Host-side DLRM logic of the product package (no GPU): placement vs the reference's outputs (bit exact),
+exchange plan, LR schedule, and the multi-rank all-to-all layout over gloo (world_size 2)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from deeplearningexamples_amd.dlrm import placement as P
+from deeplearningexamples_amd.dlrm.utils import LearningRateScheduler
+
+
+def _load(golden_dir, name):
+    return json.load(open(os.path.join(golden_dir, name)))
+
+
+def test_product_placement_bit_exact(golden_dir):
+    g = _load(golden_dir, "dlrm_placement.json")
+    for case in g["device_mapping"]:
+        assert P.get_device_mapping(case["sizes"], case["num_gpus"]) == case["result"], (case["name"], case["num_gpus"])
+    for case in g["gpu_batch_sizes"]:
+        try:
+            got = list(P.get_gpu_batch_sizes(case["global_batch"], case["num_gpus"]))
+        except RuntimeError:
+            got = None
+        assert got == case["result"], case
+    for case in g["argsort"]:
+        assert P.argsort(case["seq"]) == case["asc"]
+        assert P.argsort(case["seq"], True) == case["desc"]
+
+
+def test_exchange_plan_sizes():
+    plan = P.ExchangePlan([8192] * 8, [1, 4, 4, 4, 4, 4, 4, 2], 128, rank=3)
+    assert plan.global_batch == 65536 and plan.local_batch == 8192 and plan.n_total == 27 and plan.n_local == 4
+    assert plan.fwd_send_splits == [8192 * 4 * 128] * 8                      # 8 MiB in fp16
+    assert sum(plan.fwd_recv_splits) == 8192 * 27 * 128
+    assert plan.recv_feature_base == [0, 1, 5, 9, 13, 17, 21, 25]
+    assert [plan.source_of_feature(s) for s in (0, 1, 4, 5, 26)] == [0, 1, 1, 2, 7]
+
+
+def test_lr_schedule_matches_reference_formula():
+    # dlrm/scripts/utils.py:258-276 evaluated by hand
+    s = LearningRateScheduler(warmup_steps=4, warmup_factor=0, decay_steps=4, decay_start_step=6, decay_power=2)
+    got = [s.step() for _ in range(12)]
+    exp = [0.25, 0.5, 0.75, 1.0, 1, 1, (3 / 4) ** 2, (2 / 4) ** 2, (1 / 4) ** 2, 0.0, 0, 0]
+    np.testing.assert_allclose(got, exp)
+
+
+def _a2a_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        batch_sizes, vectors, d = [6, 10], [3, 2], 4
+        plan = P.ExchangePlan(batch_sizes, vectors, d, rank)
+        gb = sum(batch_sizes)
+        # feature f of sample b carries the value 1000*f + b in every column
+        feat0 = plan.recv_feature_base[rank]
+        local = torch.empty(gb, vectors[rank], d)
+        for j in range(vectors[rank]):
+            local[:, j, :] = (1000 * (feat0 + j) + torch.arange(gb).float())[:, None]
+        recv = torch.empty(sum(plan.fwd_recv_splits))
+        dist.all_to_all_single(recv, local.reshape(-1), plan.fwd_recv_splits, plan.fwd_send_splits)
+        x = torch.empty(plan.local_batch, plan.n_total, d)
+        for s in range(world):
+            blk = recv[plan.recv_block_start[s]:plan.recv_block_start[s] + plan.fwd_recv_splits[s]]
+            x[:, plan.recv_feature_base[s]:plan.recv_feature_base[s] + vectors[s], :] = \
+                blk.view(plan.local_batch, vectors[s], d)
+        b0 = plan.batch_start[rank]
+        exp = torch.empty_like(x)
+        for f in range(plan.n_total):
+            exp[:, f, :] = (1000 * f + b0 + torch.arange(plan.local_batch).float())[:, None]
+        ok_fwd = torch.equal(x, exp)
+        # reverse direction returns every rank's own slice of the gradient
+        send = torch.empty(sum(plan.fwd_recv_splits))
+        for s in range(world):
+            blk = send[plan.recv_block_start[s]:plan.recv_block_start[s] + plan.fwd_recv_splits[s]]
+            blk.view(plan.local_batch, vectors[s], d).copy_(x[:, plan.recv_feature_base[s]:plan.recv_feature_base[s] + vectors[s], :])
+        back = torch.empty(gb, vectors[rank], d)
+        dist.all_to_all_single(back.view(-1), send, plan.fwd_send_splits, plan.fwd_recv_splits)
+        ret[rank] = bool(ok_fwd and torch.equal(back, local))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_to_all_layout_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    port = 29500 + os.getpid() % 2000
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_a2a_worker, args=(2, port, ret), nprocs=2, join=True)
+        assert ret[0] and ret[1]
