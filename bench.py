@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""Headline benchmark: training samples/sec of the hot-path train step on N MI355X (one process per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dlrm|rn50|bert]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job samples/sec over exactly K
+steps bracketed by barrier + device sync, max over ranks; plus
+  "roofline":     dominant kernel of the step, HIP-event timed inside the timed region, vs the MI355X peak
+  "cpu_baseline": the CPU oracle (oracle/, a port of the reference's PyTorch-CPU path) timed on the host
+                  cores on a bounded sample, rank 0 at N=1 only.
+Inputs are synthetic, generated once and resident in HBM before the timed region (the reference's own
+synthetic loaders do the same: DLRM dlrm/data/datasets.py:32-61, RN50 dataloaders.py:520-549).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16/fp16 MFMA peak
+
+CRITEO_F15 = [7912889, 33823, 582469, 245828, 11, 2209, 10667, 104, 4, 968, 15, 8165896, 17139,
+              2675940, 7156453, 302516, 12022, 97, 35, 7339, 20046, 4, 7105, 1382, 63, 5554114]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default=os.environ.get("DLE_BENCH_WORKLOAD", "dlrm"),
+                    choices=["dlrm", "rn50", "bert"])
+    ap.add_argument("--batch", type=int, default=None, help="global batch (DLRM) / per-GPU batch (RN50, BERT)")
+    ap.add_argument("--dtype", default=None, choices=[None, "fp16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--max-table-size", type=int, default=None)
+    return ap.parse_args()
+
+
+def init_dist(n):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != n:
+        raise SystemExit("bench.py --gpus %d must be launched with WORLD_SIZE=%d (got %d); use "
+                         "python -m torch.distributed.run --nproc-per-node %d" % (n, n, world, n))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    return rank, world, torch.device("cuda", local)
+
+
+# ------------------------------------------------------------------------------------------- DLRM
+class DlrmWorkload:
+    """BASELINE.json configs[3]: DLRM Criteo-shape (13 numerical + 26 tables x dim 128, criteo_f15 cardinalities),
+    fp16 AMP, global batch 65536, SGD lr 24 with the reference's warm-up schedule; embeddings table-wise
+    hybrid-parallel over the ranks with an RCCL all-to-all (dlrm/scripts/main.py defaults :43-143)."""
+
+    name = "dlrm"
+
+    def __init__(self, args, rank, world, device):
+        from deeplearningexamples_amd.dlrm import placement as P
+        from deeplearningexamples_amd.dlrm.model import DistributedDlrm
+        from deeplearningexamples_amd.dlrm.engine import DlrmTrainer
+        from deeplearningexamples_amd.dlrm.utils import LearningRateScheduler
+        self.rank, self.world, self.device = rank, world, device
+        sizes = list(CRITEO_F15)
+        if args.max_table_size:
+            sizes = [min(s, args.max_table_size) for s in sizes]
+        self.sizes = sizes
+        self.global_batch = args.batch or 65536
+        self.dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+        mapping = P.get_device_mapping(sizes, world)
+        self.batch_sizes = P.get_gpu_batch_sizes(self.global_batch, world) if world > 1 else (self.global_batch,)
+        my_tables = mapping["embedding"][rank]
+        torch.manual_seed(12345 + rank)
+        self.model = DistributedDlrm(
+            num_numerical_features=13, categorical_feature_sizes=[sizes[t] for t in my_tables],
+            bottom_mlp_sizes=[512, 256, 128] if rank == mapping["bottom_mlp"] else None,
+            top_mlp_sizes=[1024, 1024, 512, 256, 1], vectors_per_gpu=mapping["vectors_per_gpu"],
+            embedding_device_mapping=mapping["embedding"], world_num_categorical_features=len(sizes),
+            embedding_dim=128, device=device, compute_dtype=self.dtype, world_size=world)
+        self.trainer = DlrmTrainer(self.model, lr=24.0, batch_sizes_per_gpu=self.batch_sizes,
+                                   vectors_per_gpu=mapping["vectors_per_gpu"], rank=rank, world_size=world, amp=True)
+        self.sched = LearningRateScheduler(warmup_steps=8000, warmup_factor=0, decay_steps=24000,
+                                           decay_start_step=48000, decay_power=2, end_lr_factor=0)
+        # SyntheticDataset: the same global batch on every rank (same seed), each rank keeps its own columns
+        g = torch.Generator(device="cpu").manual_seed(2024)
+        num = torch.rand((self.global_batch, 13), generator=g)
+        cat = torch.cat([torch.randint(0, s, (self.global_batch, 1), generator=g) for s in sizes], dim=1)
+        click = torch.randint(0, 2, (self.global_batch,), generator=g).float()
+        self.num = num.to(device) if rank == mapping["bottom_mlp"] else None
+        self.cat = cat[:, my_tables].contiguous().to(device) if my_tables else None
+        self.click = click.to(device)
+        self.samples_per_step = self.global_batch
+        self.scaling = "strong"      # the reference keeps the GLOBAL batch at 64k for 1..8 GPUs (README.md:905-924)
+        self.loss = None
+
+    def step(self):
+        self.trainer.set_lr_factor(self.sched.step())
+        self.loss = self.trainer.train_step(self.num, self.cat, self.click)
+
+    def config(self):
+        return {"workload": "DLRM Criteo-shape (criteo_f15 cardinalities, 26 tables x dim 128, 13 numerical), "
+                            "fp16 AMP, SGD lr 24 (BASELINE.json configs[3])",
+                "global_batch": self.global_batch, "tables": len(self.sizes),
+                "embedding_rows": int(sum(self.sizes)),
+                "parallelism": "single GPU" if self.world == 1 else
+                "hybrid: table-wise embeddings + all-to-all, data-parallel top MLP (dp%d)" % self.world}
+
+    def dtype_name(self):
+        return "fp16" if self.dtype == torch.float16 else "bf16"
+
+    def cpu_baseline(self):
+        """CPU oracle (port of the reference's PyTorch-CPU path) on a bounded sample of the same workload."""
+        from oracle import dlrm_step_oracle as SO
+        cap, batch, steps = 200000, 8192, 3
+        sizes = [min(s, cap) for s in CRITEO_F15]
+        state = SO.seeded_dlrm_state(sizes, 128, [512, 256, 128], [1024, 1024, 512, 256, 1], 13, 7)
+        num, cat, click = SO.seeded_dlrm_batch(sizes, 13, batch, 8)
+        orc = SO.DlrmOracle(state, sizes, 24.0 / 8000)
+        orc.step(num, cat, click)                      # warm-up
+        t0 = time.time()
+        for _ in range(steps):
+            orc.step(num, cat, click)
+        dt = time.time() - t0
+        return {"value": round(batch * steps / dt, 1), "unit": "samples/s", "cores": torch.get_num_threads(),
+                "kind": "port",
+                "sample": "oracle/dlrm_step_oracle.py (fp32 torch-CPU restatement of the reference step), %d steps "
+                          "of batch %d, table rows capped at %d (dense gradient on the capped table)" % (steps, batch, cap)}
+
+
+WORKLOADS = {"dlrm": DlrmWorkload}
+
+
+def roofline_from(timer_rows, steps):
+    """Dominant entry point of the step (largest total HIP-event time over the timed region)."""
+    if not timer_rows:
+        return None, []
+    top = timer_rows[0]
+    ms = top["ms"] / top["calls"]
+    flops, byts = top["flops"] / top["calls"], top["bytes"] / top["calls"]
+    intensity = flops / byts if byts else 0.0
+    # ridge of the MI355X roofline: 2500 TFLOP/s / 8 TB/s = 312 flop/byte
+    if flops and intensity > MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+        ach = flops / (ms * 1e-3) / 1e12
+        r = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": round(ach / MFMA_PEAK_TFLOPS, 4)}
+    else:
+        ach = byts / (ms * 1e-3) / 1e9
+        r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(ach / HBM_PEAK_GBS, 4)}
+    r.update({"traffic": None, "kernel": top["name"] + ("[" + top["tag"] + "]" if top["tag"] else ""),
+              "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": round(top["calls"] / steps, 2),
+              "algorithmic_bytes_per_launch": byts, "algorithmic_flops_per_launch": flops})
+    breakdown = [{"kernel": a["name"] + ("[" + a["tag"] + "]" if a["tag"] else ""),
+                  "ms_per_step": round(a["ms"] / steps, 4), "calls_per_step": round(a["calls"] / steps, 2)}
+                 for a in timer_rows[:12]]
+    return r, breakdown
+
+
+def main():
+    args = parse()
+    rank, world, device = init_dist(args.gpus)
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build_product()
+    if world > 1:
+        dist.barrier()
+    from deeplearningexamples_amd import _cabi
+    _cabi.lib()                                        # fail loudly if the HIP library is missing
+    if args.workload not in WORKLOADS:
+        raise SystemExit("workload %r is not built yet in this round" % args.workload)
+    wl = WORKLOADS[args.workload](args, rank, world, device)
+
+    for _ in range(args.warmup):
+        wl.step()
+    timer = None
+    if not args.no_kernel_timer and rank == 0:
+        timer = _cabi.KernelTimer()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    _cabi.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _cabi.set_timer(None)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(wl.loss.item()) if wl.loss is not None else None
+
+    if rank == 0:
+        roof, breakdown = roofline_from(timer.report() if timer else [], args.steps)
+        out = {"metric": "training samples/sec", "value": round(wl.samples_per_step * args.steps / elapsed, 1),
+               "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+               "scaling": wl.scaling, "vs_baseline": None, "dtype": wl.dtype_name(), "data": "synthetic",
+               "config": wl.config(), "final_loss": loss, "roofline": roof, "kernel_breakdown": breakdown}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = wl.cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -115,8 +115,56 @@ def check(rc, what):
     raise DleError("%s failed (hip error %d): %s" % (what, rc, msg))
 
 
+class KernelTimer:
+    """Optional per-entry-point HIP-event timing (bench.py's roofline leg).  Events are recorded on the
+    stream the kernels are launched on (torch's current stream); nothing is synchronised until report()."""
+
+    def __init__(self):
+        self.records = []          # (name, start_event, end_event, meta)
+        self.meta = None           # set by callers that know the algorithmic bytes/flops of the next call
+
+    def report(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, s, e, meta in self.records:
+            key = (name, meta.get("tag") if meta else None)
+            a = agg.setdefault(key, {"name": name, "tag": key[1], "calls": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0})
+            a["calls"] += 1
+            a["ms"] += s.elapsed_time(e)
+            if meta:
+                a["bytes"] += meta.get("bytes", 0.0)
+                a["flops"] += meta.get("flops", 0.0)
+        return sorted(agg.values(), key=lambda a: -a["ms"])
+
+
+_timer = None
+
+
+def set_timer(t):
+    """Install (or remove with None) a KernelTimer; returns the previous one."""
+    global _timer
+    old, _timer = _timer, t
+    return old
+
+
+def annotate(**meta):
+    """Attach algorithmic work (bytes=..., flops=..., tag=...) to the NEXT call() when a timer is active."""
+    if _timer is not None:
+        _timer.meta = meta
+
+
 def call(name, *args):
+    t = _timer
+    if t is None:
+        rc = getattr(lib(), name)(*args)
+        check(rc, name)
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
     rc = getattr(lib(), name)(*args)
+    e.record()
+    t.records.append((name, s, e, t.meta))
+    t.meta = None
     check(rc, name)
 
 

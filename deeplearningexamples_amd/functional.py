@@ -21,6 +21,7 @@ def dot_interact_fwd(x, force_generic=False):
     x = x.contiguous()
     b, r, c = x.shape
     out = torch.empty((b, dot_interact_out_width(r, c)), dtype=x.dtype, device=x.device)
+    C.annotate(bytes=float(b) * (r * c + out.shape[1]) * x.element_size())
     C.call("dle_dot_interact_fwd", C.ptr(x), C.ptr(out), b, r, c, C.dt(x), int(force_generic), C.stream())
     return out
 
@@ -37,6 +38,7 @@ def dot_interact_bwd(x, upstream, force_generic=False, fuse_mlp_grad=False, grad
     upstream = upstream.to(x.dtype).contiguous()
     grad = torch.empty_like(x) if grad_out is None else grad_out
     mlp_grad = None if fuse_mlp_grad else torch.empty((b, c), dtype=x.dtype, device=x.device)
+    C.annotate(bytes=float(b) * (2 * r * c + ow + (0 if fuse_mlp_grad else c)) * x.element_size())
     C.call("dle_dot_interact_bwd", C.ptr(x), C.ptr(upstream), C.ptr(grad), C.ptr(mlp_grad), b, r, c,
            C.dt(x), int(force_generic), C.stream())
     return grad, mlp_grad
@@ -68,6 +70,7 @@ def emb_gather_fwd(weight, indices, offsets=None, hash_sizes=None, out_dtype=tor
         raise ValueError("offsets has %d entries for %d tables" % (offsets.numel(), t))
     if out is None:
         out = torch.empty((b, t, d), dtype=out_dtype, device=weight.device)
+    C.annotate(bytes=float(b) * t * (d * 4 + d * out.element_size() + 8))
     C.call("dle_emb_gather_fwd", C.ptr(weight), C.ptr(indices), C.ptr(offsets), C.ptr(hash_sizes), C.ptr(out),
            b, t, d, C.dt(out.dtype), out_batch_stride, C.stream())
     return out
@@ -147,6 +150,8 @@ def emb_sgd_dedup_(weight, rows, grad, ws, lr, scale=None, skip_flag=None, grad_
     lr_dev = lr if isinstance(lr, torch.Tensor) else None
     lr_host = 0.0 if lr_dev is not None else float(lr)
     nxt = ws.next_for(b * t, weight.device)
+    # algorithmic: grad row read + table row read-modify-write + row id
+    C.annotate(bytes=float(b) * t * (ws.dim * grad.element_size() + 2 * ws.dim * 4 + 8))
     C.call("dle_emb_sgd_dedup", C.ptr(weight), C.ptr(rows), C.ptr(grad), C.ptr(ws.head), C.ptr(nxt),
            C.ptr(ws.is_small), ws.offsets_host.ctypes.data_as(ctypes.c_void_p), C.ptr(lr_dev), lr_host,
            C.ptr(scale), C.ptr(skip_flag), b, t, ws.dim, grad_batch_stride, C.dt(grad), C.stream())
@@ -222,6 +227,8 @@ def gemm(a, b, m, n, k, a_kc, b_kc, out=None, out_dtype=None, bias=None, act=C.A
         raise ValueError("gemm output must have unit inner stride")
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != n):
         raise ValueError("gemm bias must be fp32 [n]")
+    C.annotate(flops=2.0 * m * n * k, bytes=float(m * k + n * k) * a.element_size() + float(m * n) * out.element_size(),
+               tag="%dx%dx%d" % (m, n, k))
     C.call("dle_gemm", C.ptr(a), C.ptr(b), C.ptr(out), C.ptr(aux), C.ptr(bias), C.ptr(mask_src), m, n, k,
            lda, ldb, out.stride(0) if out.dim() == 2 else n, int(a_kc), int(b_kc), C.dt(a), C.dt(out), act,
            splitk, int(accumulate), float(alpha), C.stream())
