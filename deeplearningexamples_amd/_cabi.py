@@ -47,8 +47,8 @@ _SIGS = {
     "dle_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_i64, c_int, c_void_p]),
     "dle_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                          c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
-                         c_void_p]),
-    "dle_colsum": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p]),
+                         c_void_p, c_i64, c_void_p]),
+    "dle_colsum": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p, c_i64, c_void_p]),
     "dle_mt_table_len": (c_i64, [c_int, c_int]),
     "dle_mt_table_fill": (c_i64, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]),
     "dle_mt_l2norm": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,

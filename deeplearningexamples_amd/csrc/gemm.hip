@@ -27,6 +27,7 @@
 //    masking, fp32 accumulation and split-K (fp32 atomics) are fused in the epilogue.
 //  * workgroup ids are remapped so the 8 XCDs each walk a contiguous band of tiles (private L2s).
 #include "common.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -293,56 +294,146 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 }
 
 // ---- column sums: out[n] (+)= sum_m X[m][n]   (bias gradients), 16-bit or fp32 input -> fp32
+// 16 B per lane along the row (8 x 16-bit / 4 x fp32 columns per lane); LPR lanes cover one row, a wavefront
+// sweeps 64/LPR rows per trip; partial sums meet in LDS, one fp32 atomic per column per workgroup.
 template <int DT>
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, float* __restrict__ out,
-                                                     long long M, int N, long long ld, long long rows_per_block) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;
+                                                     long long M, int N, long long ld, long long rows_per_block,
+                                                     int lpr, float* __restrict__ partial) {
+  constexpr int V = DT == DLE_F32 ? 4 : 8;
+  __shared__ float red[256 * 8];
+  const int cl = threadIdx.x % lpr, rl = threadIdx.x / lpr, rstep = 256 / lpr;
+  const int c0 = (blockIdx.x * lpr + cl) * V;
   const long long r0 = (long long)blockIdx.y * rows_per_block;
   long long r1 = r0 + rows_per_block;
   if (r1 > M) r1 = M;
-  float s = 0.f;
-  if (c < N) {
-    for (long long r = r0 + rl; r < r1; r += 4) {
-      if (DT == DLE_F32) s += ((const float*)x)[r * ld + c];
-      else if (DT == DLE_F16) s += Elem<DLE_F16>::to_f32(((const unsigned short*)x)[r * ld + c]);
-      else s += Elem<DLE_BF16>::to_f32(((const unsigned short*)x)[r * ld + c]);
+  float s[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) s[k] = 0.f;
+  const bool vec = (ld % V) == 0 && (((uintptr_t)x) & 15) == 0 && c0 + V <= N;
+  if (c0 < N) {
+    long long r = r0 + rl;
+    if (vec && DT != DLE_F32) {
+      // 4 independent 16-byte loads in flight per lane
+      for (; r + 3LL * rstep < r1; r += 4LL * rstep) {
+        ushort8_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const ushort8_t*)((const unsigned short*)x + (r + (long long)u * rstep) * ld + c0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int k = 0; k < V; ++k) s[k] += DT == DLE_F16 ? Elem<DLE_F16>::to_f32(v[u][k]) : Elem<DLE_BF16>::to_f32(v[u][k]);
+      }
+    }
+    for (; r < r1; r += rstep) {
+      if (vec) {
+        if (DT == DLE_F32) {
+          const float4_t v = *(const float4_t*)((const float*)x + r * ld + c0);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) s[k] += v[k];
+        } else {
+          const ushort8_t v = *(const ushort8_t*)((const unsigned short*)x + r * ld + c0);
+#pragma unroll
+          for (int k = 0; k < V; ++k) s[k] += DT == DLE_F16 ? Elem<DLE_F16>::to_f32(v[k]) : Elem<DLE_BF16>::to_f32(v[k]);
+        }
+      } else {
+        for (int k = 0; k < V && c0 + k < N; ++k) {
+          if (DT == DLE_F32) s[k] += ((const float*)x)[r * ld + c0 + k];
+          else if (DT == DLE_F16) s[k] += Elem<DLE_F16>::to_f32(((const unsigned short*)x)[r * ld + c0 + k]);
+          else s[k] += Elem<DLE_BF16>::to_f32(((const unsigned short*)x)[r * ld + c0 + k]);
+        }
+      }
     }
   }
-  red[rl][threadIdx.x & 63] = s;
+#pragma unroll
+  for (int k = 0; k < V; ++k) red[threadIdx.x * 8 + k] = s[k];
   __syncthreads();
-  if (rl == 0 && c < N) {
-    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    unsafeAtomicAdd(out + c, t);
+  if (rl == 0 && c0 < N) {
+    for (int k = 0; k < V && c0 + k < N; ++k) {
+      float t = 0.f;
+      for (int q = 0; q < rstep; ++q) t += red[(q * lpr + cl) * 8 + k];
+      if (partial) partial[(long long)blockIdx.y * N + c0 + k] = t;
+      else unsafeAtomicAdd(out + c0 + k, t);
+    }
+  }
+}
+
+// out[n] (+)= sum_g partial[g][n]; 64 columns x 4 group slices per workgroup
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                            int N, int groups, int accumulate) {
+  __shared__ float red[256];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cl;
+  float s = 0.f;
+  if (n < N)
+    for (int g = sl; g < groups; g += 4) s += partial[(long long)g * N + n];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sl == 0 && n < N) {
+    const float t = red[cl] + red[64 + cl] + red[128 + cl] + red[192 + cl];
+    out[n] = accumulate ? out[n] + t : t;
   }
 }
 
 extern "C" int dle_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype,
-                          int accumulate, hipStream_t stream) {
+                          int accumulate, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   DLE_CHECK_ARG(x && out && N > 0 && M >= 0, "colsum: bad args");
-  if (!accumulate) {
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)N * 4, stream);
-    if (e != hipSuccess) { dle_set_error("colsum memset: %s", hipGetErrorString(e)); return (int)e; }
+  DLE_CHECK_ARG(dtype == DLE_F32 || dtype == DLE_F16 || dtype == DLE_BF16, "colsum: bad dtype %d", dtype);
+  if (M == 0) {
+    if (!accumulate) {
+      hipError_t e = hipMemsetAsync(out, 0, (size_t)N * 4, stream);
+      if (e != hipSuccess) { dle_set_error("colsum memset: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    return 0;
   }
-  if (M == 0) return 0;
-  long long rpb = 512;
+  const int V = dtype == DLE_F32 ? 4 : 8;
+  const int cols_v = (N + V - 1) / V;
+  int lpr = 1;
+  while (lpr < cols_v && lpr < 256) lpr <<= 1;           // lanes per row (power of two, <= 256)
+  const int gx = (cols_v + lpr - 1) / lpr;
+  long long want = 1024 / gx;                              // ~4 workgroups per CU in total
+  if (want < 1) want = 1;
+  long long rpb = (M + want - 1) / want;
+  const long long min_rows = 4LL * (256 / lpr);
+  if (rpb < min_rows) rpb = min_rows;
   long long gy = (M + rpb - 1) / rpb;
-  if (gy > 1024) { gy = 1024; rpb = (M + gy - 1) / gy; }
-  dim3 grid((N + 63) / 64, (unsigned)gy), block(256);
-  if (dtype == DLE_F32) hipLaunchKernelGGL(colsum_kernel<DLE_F32>, grid, block, 0, stream, x, out, (long long)M, N, (long long)ld, rpb);
-  else if (dtype == DLE_F16) hipLaunchKernelGGL(colsum_kernel<DLE_F16>, grid, block, 0, stream, x, out, (long long)M, N, (long long)ld, rpb);
-  else if (dtype == DLE_BF16) hipLaunchKernelGGL(colsum_kernel<DLE_BF16>, grid, block, 0, stream, x, out, (long long)M, N, (long long)ld, rpb);
-  else { dle_set_error("colsum: bad dtype %d", dtype); return -1; }
+  // Row groups meet through plain stores into the caller's workspace + a tiny finishing pass.  Without a
+  // workspace they meet through fp32 atomics on the SAME N addresses, which serialise per cache line, so
+  // the row split is kept coarse in that case.
+  float* partial = nullptr;
+  if (workspace && (((uintptr_t)workspace) & 3) == 0 && workspace_bytes >= gy * (long long)N * 4) {
+    partial = (float*)workspace;
+  } else {
+    if (gy > 64) { gy = 64; rpb = (M + gy - 1) / gy; gy = (M + rpb - 1) / rpb; }
+    if (!accumulate) {
+      hipError_t e = hipMemsetAsync(out, 0, (size_t)N * 4, stream);
+      if (e != hipSuccess) { dle_set_error("colsum memset: %s", hipGetErrorString(e)); return (int)e; }
+    }
+  }
+  dim3 grid(gx, (unsigned)gy), block(256);
+  if (dtype == DLE_F32) hipLaunchKernelGGL(colsum_kernel<DLE_F32>, grid, block, 0, stream, x, out, (long long)M, N, (long long)ld, rpb, lpr, partial);
+  else if (dtype == DLE_F16) hipLaunchKernelGGL(colsum_kernel<DLE_F16>, grid, block, 0, stream, x, out, (long long)M, N, (long long)ld, rpb, lpr, partial);
+  else hipLaunchKernelGGL(colsum_kernel<DLE_BF16>, grid, block, 0, stream, x, out, (long long)M, N, (long long)ld, rpb, lpr, partial);
   DLE_LAUNCH_CHECK();
+  if (partial) {
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, (const float*)partial, out, N, (int)gy, accumulate);
+    DLE_LAUNCH_CHECK();
+  }
   return 0;
 }
+
+extern "C" int dle_gemm_dma_try(const void* A, const void* B, void* C, void* aux, const float* bias,
+                                const void* mask_src, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                                int a_kc, int b_kc, int in_dtype, int out_dtype, int act, int splitk,
+                                int accumulate, float alpha, void* workspace, int64_t workspace_bytes,
+                                hipStream_t stream);
 
 // C ABI.  a_kc / b_kc: operand stored with the contraction dimension contiguous (see header).
 extern "C" int dle_gemm(const void* A, const void* B, void* C, void* aux, const float* bias,
                         const void* mask_src, int M, int N, int K, int64_t lda, int64_t ldb,
                         int64_t ldc, int a_kc, int b_kc, int in_dtype, int out_dtype, int act,
-                        int splitk, int accumulate, float alpha, hipStream_t stream) {
+                        int splitk, int accumulate, float alpha, void* workspace, int64_t workspace_bytes,
+                        hipStream_t stream) {
   DLE_CHECK_ARG(A && B && C, "gemm: null pointer");
   DLE_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "gemm: negative dimension");
   DLE_CHECK_ARG(in_dtype == DLE_F16 || in_dtype == DLE_BF16, "gemm: inputs must be f16/bf16 (got %d)", in_dtype);
@@ -351,22 +442,26 @@ extern "C" int dle_gemm(const void* A, const void* B, void* C, void* aux, const 
   DLE_CHECK_ARG(act != ACT_RELU_BWD || mask_src, "gemm: ACT_RELU_BWD needs mask_src");
   DLE_CHECK_ARG(act != ACT_RELU_BWD || out_dtype == in_dtype, "gemm: ACT_RELU_BWD mask dtype = in dtype = out dtype");
   if (splitk < 1) splitk = 1;
-  if (splitk > 1) {
+  if (splitk > 1)
     DLE_CHECK_ARG(out_dtype == DLE_F32 && !bias && act == ACT_NONE && !aux, "gemm: split-K needs a plain fp32 output");
-    if (!accumulate) {
-      // rows may be strided: clear row by row only when ldc != N
-      if (ldc == N) {
-        hipError_t e = hipMemsetAsync(C, 0, (size_t)M * N * 4, stream);
-        if (e != hipSuccess) { dle_set_error("gemm memset: %s", hipGetErrorString(e)); return (int)e; }
-      } else {
-        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, stream);
-        if (e != hipSuccess) { dle_set_error("gemm memset2d: %s", hipGetErrorString(e)); return (int)e; }
-      }
-    }
-  } else {
+  else
     DLE_CHECK_ARG(!accumulate || out_dtype == DLE_F32, "gemm: accumulate needs fp32 output");
-  }
   if (M == 0 || N == 0) return 0;
+  {
+    // fast path: LDS-DMA fed kernel (gemm_dma.hip); DLE_GEMM_LEGACY=1 pins the register-staged kernel
+    static const bool legacy = getenv("DLE_GEMM_LEGACY") != nullptr && getenv("DLE_GEMM_LEGACY")[0] == '1';
+    if (!legacy && K > 0) {
+      const int r = dle_gemm_dma_try(A, B, C, aux, bias, mask_src, M, N, K, lda, ldb, ldc, a_kc, b_kc, in_dtype,
+                                     out_dtype, act, splitk, accumulate, alpha, workspace, workspace_bytes, stream);
+      if (r == 1) return 0;
+      if (r != 0) return r;
+    }
+  }
+  if (splitk > 1 && !accumulate) {   // register-staged kernel: fp32 atomics into a cleared C
+    hipError_t e = ldc == N ? hipMemsetAsync(C, 0, (size_t)M * N * 4, stream)
+                            : hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, stream);
+    if (e != hipSuccess) { dle_set_error("gemm memset: %s", hipGetErrorString(e)); return (int)e; }
+  }
   GemmArgs p;
   p.A = (const unsigned short*)A; p.B = (const unsigned short*)B; p.C = C; p.aux = aux; p.bias = bias;
   p.mask_src = (const unsigned short*)mask_src;

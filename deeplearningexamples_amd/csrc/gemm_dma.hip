@@ -1,0 +1,437 @@
+// MFMA GEMM, LDS-DMA fed (buffer_load ... lds), for gfx950 -- the fast path behind dle_gemm.
+//
+//   C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )      (same contract as gemm.hip, which stays as the
+//                                                            fallback for unaligned / tiny shapes)
+// Why a second kernel: gemm.hip stages tiles through VGPRs (global_load -> ds_write), which costs staging
+// registers, a ds_write pass and VALU address work per tile; it tops out at 0.5-0.75 PFLOP/s.  Here
+//  * both operand tiles go HBM -> LDS by LDS-DMA (16 B/lane, 1 KiB per wave instruction, lane-linear LDS
+//    image, per-lane global address), double buffered: the DMA of tile t+1 flies under the MFMAs of tile t,
+//    one barrier per K tile; out-of-range rows / K tail / conv padding read as ZERO through the buffer
+//    descriptor's range check (forced out-of-range offset) -- no predicated code in the loop.
+//  * bank conflicts are removed on the SOURCE side (the DMA image is linear): LDS slot (row, c) holds the
+//    global 16-byte chunk c ^ f(row); fragment reads apply the same involution.
+//      k-contiguous operand  [128 rows][64 k]  : f(row) = (row >> 1) & 7, read with ds_read_b128
+//      row-contiguous operand [64 k][128 rows] : 32-byte pair index ^ ((k & 3) | ((k >> 3) & 1) << 2),
+//                                                read with ds_read_b64_tr_b16 (LDS transpose read), so
+//                                                dgrad/wgrad need no transposed copies and no register shuffles.
+//  * 128x128x64 tile, 4 wavefronts (2x2), 64x64 per wavefront as 2x2 v_mfma_f32_32x32x16 (64 acc VGPRs),
+//    2 workgroups per CU (64 KiB LDS each).  MFMA operands are swapped so a lane owns 4 consecutive output
+//    columns; the epilogue (bias, ReLU, tanh-GELU + pre-activation, ReLU-backward mask, fp32 accumulate,
+//    split-K atomics) is the one of gemm.hip.
+//  * XCD-aware tile walk (private L2 per XCD).
+// A_MODE: 0 = k-contiguous matrix, 1 = row-contiguous matrix, 2 = implicit im2col of an NHWC tensor
+// (convolution forward / data-gradient: A(m,k) = X[n, p*stride - pad + r, q*stride - pad + s, c]).
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3 };
+
+struct ConvGeom {        // A_MODE 2: m <-> (n, p, q), k <-> (r, s, c); requires C % 64 == 0
+  int H, W, C, P, Q, R, S, stride, pad;
+};
+
+struct Gemm2Args {
+  const unsigned short* A;
+  const unsigned short* B;
+  void* C;
+  void* aux;
+  const float* bias;
+  const unsigned short* mask_src;
+  int M, N, K;
+  long long lda, ldb, ldc;
+  int out_dtype, act, splitk, accumulate;
+  float alpha;
+  float* ws;             // split-K partial slabs [splitk][M][N] fp32 (NULL: fp32 atomics straight into C)
+  ConvGeom cg;
+};
+
+template <int DT> struct Mfma32x16;
+template <> struct Mfma32x16<DLE_F16> {
+  static __device__ __forceinline__ float16_t run(ushort8_t a, ushort8_t b, float16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma32x16<DLE_BF16> {
+  static __device__ __forceinline__ float16_t run(ushort8_t a, ushort8_t b, float16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+#define OOB_OFF 0xFFFFFFF0u
+
+__device__ __forceinline__ int swz_kc(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int swz_rc(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned short* lds_wave_base, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_wave_base, 16, voff, 0, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_tanh2(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  const float u = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+
+// ---- per-operand tile loader state: 4 DMA instructions per wave per K tile --------------------------
+// MODE 0 (k-contiguous):  tile image [128 rows][8 chunks]; instr j of wave w covers rows (4w+j)*8 .. +7.
+// MODE 1 (row-contiguous): tile image [64 k][16 chunks];   instr j of wave w covers k rows (4w+j)*4 .. +3.
+template <int MODE>
+struct Loader {
+  unsigned off[4];       // byte offset of this lane's 16 B relative to the K-tile base (MODE 0/1) or image (2)
+  int kin[4];            // MODE 0: k element offset inside the tile (for the K tail);  MODE 1: k row inside the tile
+  int h0[4], w0[4];      // MODE 2: top-left input coordinate of the lane's output pixel
+  bool row_ok[4];
+
+  __device__ __forceinline__ void init(int wave, int lane, int row0, int nrows, long long ld, const ConvGeom& cg) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (MODE == 0 || MODE == 2) {
+        const int row = (wave * 4 + j) * 8 + (lane >> 3), cpos = lane & 7;
+        const int chunk = cpos ^ swz_kc(row);
+        const int g = row0 + row;
+        row_ok[j] = g < nrows;
+        kin[j] = chunk * 8;
+        if (MODE == 0) {
+          off[j] = (unsigned)(((long long)row * ld + chunk * 8) * 2);
+        } else {
+          // decode the output pixel once: g = (n * P + p) * Q + q
+          const int q = g % cg.Q, t = g / cg.Q;
+          const int p = t % cg.P, n = t / cg.P;
+          h0[j] = p * cg.stride - cg.pad;
+          w0[j] = q * cg.stride - cg.pad;
+          off[j] = (unsigned)(((((long long)n * cg.H + h0[j]) * cg.W + w0[j]) * cg.C + chunk * 8) * 2);
+        }
+      } else {
+        const int kr = (wave * 4 + j) * 4 + (lane >> 4), cpos = lane & 15;
+        const int chunk = (((cpos >> 1) ^ swz_rc(kr)) << 1) | (cpos & 1);
+        const int g = row0 + chunk * 8;
+        row_ok[j] = g < nrows;
+        kin[j] = kr;
+        off[j] = (unsigned)(((long long)kr * ld + chunk * 8) * 2);
+      }
+    }
+  }
+
+  // base: pointer of (row0, k0) for MODE 0 [ld = row stride], of (k0, row0) for MODE 1, of the image for MODE 2
+  __device__ __forceinline__ void issue(const unsigned short* base, unsigned short* tile, int wave, int krem,
+                                        int k0, const ConvGeom& cg) {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xFFFFFFE0, 0x00020000);
+    int r = 0, s = 0, c0 = 0;
+    unsigned tap = 0;
+    if (MODE == 2) {
+      const int rs_i = k0 / cg.C;
+      c0 = k0 - rs_i * cg.C;
+      r = rs_i / cg.S;
+      s = rs_i - r * cg.S;
+      tap = (unsigned)(((r * cg.W + s) * cg.C + c0) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bool ok = row_ok[j] && kin[j] < krem;
+      unsigned o = off[j];
+      if (MODE == 2) {
+        const int h = h0[j] + r, w = w0[j] + s;
+        ok = ok && h >= 0 && h < cg.H && w >= 0 && w < cg.W;
+        o += tap;
+      }
+      dma16(rs, tile + (wave * 4 + j) * 512, ok ? o : OOB_OFF);
+    }
+  }
+};
+
+template <int DT, int A_MODE, int B_MODE>
+__global__ __launch_bounds__(256, 2) void gemm2_kernel(Gemm2Args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* lds = (unsigned short*)smem_raw;   // [2 stages][A tile 8192 halves | B tile 8192 halves]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int ntiles = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  // walk N fastest so that concurrently running tiles share the A rows (activations) through L2
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int ktiles = (p.K + BK - 1) / BK;
+  const int per = (ktiles + p.splitk - 1) / p.splitk;
+  const int kt0 = blockIdx.y * per;
+  int kt1 = kt0 + per;
+  if (kt1 > ktiles) kt1 = ktiles;
+  if (kt0 >= kt1 && p.splitk > 1) return;
+  const int kend = (kt1 * BK < p.K) ? kt1 * BK : p.K;
+
+  Loader<A_MODE> la;
+  Loader<B_MODE> lb;
+  la.init(wave, lane, m0, p.M, p.lda, p.cg);
+  lb.init(wave, lane, n0, p.N, p.ldb, p.cg);
+
+  auto issue = [&](int kt, int stage) {
+    const int k0 = kt * BK;
+    unsigned short* ta = lds + stage * (BM * BK + BN * BK);
+    unsigned short* tb = ta + BM * BK;
+    const unsigned short* ba = A_MODE == 0 ? p.A + (long long)m0 * p.lda + k0
+                             : A_MODE == 1 ? p.A + (long long)k0 * p.lda + m0 : p.A;
+    const unsigned short* bb = B_MODE == 0 ? p.B + (long long)n0 * p.ldb + k0 : p.B + (long long)k0 * p.ldb + n0;
+    la.issue(ba, ta, wave, kend - k0, k0, p.cg);
+    lb.issue(bb, tb, wave, kend - k0, k0, p.cg);
+  };
+
+  float16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (kt0 < kt1) issue(kt0, 0);
+
+  const int fr = lane & 31, fh = lane >> 5;          // 32x32x16 fragment: row fr, k group fh (8 elements)
+  const int tg = lane >> 4, ti = lane & 15;          // transpose-read addressing: 16-lane groups
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int stage = (kt - kt0) & 1;
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA pieces of tile kt have landed
+    __syncthreads();                      // ... and everybody's; everyone is done reading the other stage
+    if (kt + 1 < kt1) issue(kt + 1, stage ^ 1);
+    const unsigned short* ta = lds + stage * (BM * BK + BN * BK);
+    const unsigned short* tb = ta + BM * BK;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {      // 4 k-steps of 16
+      ushort8_t fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (A_MODE != 1) {
+          const int row = wm * 64 + i * 32 + fr;
+          fa[i] = *(const ushort8_t*)(ta + row * BK + (((ks * 2 + fh) ^ swz_kc(row)) << 3));
+        } else {
+          // lanes 0-15 / 16-31 -> rows +0..15 / +16..31 of the 32-row fragment, k group = lane >> 5
+          const int rbase = wm * 64 + i * 32 + ((tg & 1) << 4);
+          const int kb = ks * 16 + (tg >> 1) * 8 + (ti >> 2);
+          const int chunk = (rbase >> 3) + ((ti & 3) >> 1);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int k = kb + h * 4;
+            const int cpos = (((chunk >> 1) ^ swz_rc(k)) << 1) | (chunk & 1);
+            const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) short4_t*)(ta + k * BM + cpos * 8 + ((ti & 1) << 2)));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fa[i][h * 4 + e] = (unsigned short)v[e];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (B_MODE == 0) {
+          const int row = wn * 64 + j * 32 + fr;
+          fb[j] = *(const ushort8_t*)(tb + row * BK + (((ks * 2 + fh) ^ swz_kc(row)) << 3));
+        } else {
+          const int rbase = wn * 64 + j * 32 + ((tg & 1) << 4);
+          const int kb = ks * 16 + (tg >> 1) * 8 + (ti >> 2);
+          const int chunk = (rbase >> 3) + ((ti & 3) >> 1);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int k = kb + h * 4;
+            const int cpos = (((chunk >> 1) ^ swz_rc(k)) << 1) | (chunk & 1);
+            const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) short4_t*)(tb + k * BN + cpos * 8 + ((ti & 1) << 2)));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fb[j][h * 4 + e] = (unsigned short)v[e];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Mfma32x16<DT>::run(fb[j], fa[i], acc[i][j]);
+    }
+  }
+
+  // ---- epilogue: D = (B A^T) tile, so lane owns C[m = fr-th row][n = 8*(r>>2) + 4*fh + (r&3)] ----------
+  const bool vec_c = (p.ldc & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * 64 + i * 32 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int n = n0 + wn * 64 + j * 32 + qd * 8 + fh * 4;
+        if (n >= p.N) continue;
+        float4_t v = {acc[i][j][qd * 4 + 0], acc[i][j][qd * 4 + 1], acc[i][j][qd * 4 + 2], acc[i][j][qd * 4 + 3]};
+        v = v * p.alpha;
+        const int nval = (p.N - n) < 4 ? (p.N - n) : 4;
+        const long long off = (long long)m * p.ldc + n;
+        if (p.splitk > 1) {
+          if (p.ws) {
+            // plain stores of this K-slice's partial tile; summed by splitk_reduce_kernel (no float atomics:
+            // they run at ~76 G adds/s on this part, 10x slower than the slab round trip)
+            float* c = p.ws + ((long long)blockIdx.y * p.M + m) * p.N + n;
+            if (nval == 4 && (p.N & 3) == 0) *(float4_t*)c = v;
+            else
+              for (int r = 0; r < nval; ++r) c[r] = v[r];
+          } else {
+            float* c = (float*)p.C + off;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (r < nval) unsafeAtomicAdd(c + r, v[r]);
+          }
+          continue;
+        }
+        if (p.bias) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < nval) v[r] += p.bias[n + r];
+        }
+        float4_t pre = v;
+        if (p.act == ACT_RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+        } else if (p.act == ACT_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_tanh2(v[r]);
+        } else if (p.act == ACT_RELU_BWD) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < nval) {
+              const float y = DT == DLE_F16 ? Elem<DLE_F16>::to_f32(p.mask_src[off + r])
+                                            : Elem<DLE_BF16>::to_f32(p.mask_src[off + r]);
+              v[r] = y > 0.f ? v[r] : 0.f;
+            }
+        }
+        if (p.out_dtype == DLE_F32) {
+          float* c = (float*)p.C + off;
+          if (p.accumulate) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (r < nval) v[r] += c[r];
+          }
+          if (nval == 4 && vec_c) *(float4_t*)c = v;
+          else
+            for (int r = 0; r < nval; ++r) c[r] = v[r];
+          if (p.aux) {
+            float* a = (float*)p.aux + off;
+            for (int r = 0; r < nval; ++r) a[r] = pre[r];
+          }
+        } else {
+          ushort4_t o, po;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (p.out_dtype == DLE_F16) { o[r] = Elem<DLE_F16>::from_f32(v[r]); po[r] = Elem<DLE_F16>::from_f32(pre[r]); }
+            else { o[r] = Elem<DLE_BF16>::from_f32(v[r]); po[r] = Elem<DLE_BF16>::from_f32(pre[r]); }
+          }
+          unsigned short* c = (unsigned short*)p.C + off;
+          if (nval == 4 && vec_c) *(ushort4_t*)c = o;
+          else
+            for (int r = 0; r < nval; ++r) c[r] = o[r];
+          if (p.aux) {
+            unsigned short* a = (unsigned short*)p.aux + off;
+            if (nval == 4 && vec_c) *(ushort4_t*)a = po;
+            else
+              for (int r = 0; r < nval; ++r) a[r] = po[r];
+          }
+        }
+      }
+    }
+  }
+}
+
+// C[m][n] (+)= sum_z ws[z][m][n]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C,
+                                                            int M, int N, long long ldc, int splitk, int accumulate) {
+  const long long slab = (long long)M * N;
+  if ((N & 3) == 0 && (ldc & 3) == 0) {
+    const long long total4 = slab >> 2;
+    const int n4 = N >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+      float4_t s = ((const float4_t*)ws)[i];
+      for (int z = 1; z < splitk; ++z) s += ((const float4_t*)(ws + z * slab))[i];
+      const long long m = i / n4;
+      float4_t* c = (float4_t*)(C + m * ldc) + (i - m * n4);
+      if (accumulate) s += *c;
+      *c = s;
+    }
+  } else {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < slab; i += (long long)gridDim.x * blockDim.x) {
+      float s = ws[i];
+      for (int z = 1; z < splitk; ++z) s += ws[z * slab + i];
+      const long long m = i / N;
+      float* c = C + m * ldc + (i - m * N);
+      if (accumulate) s += *c;
+      *c = s;
+    }
+  }
+}
+
+// Returns 1 when the DMA kernel took the launch, 0 when the shape/alignment is outside its envelope
+// (caller falls back to gemm.hip), <0 / >1 on error.  Called from dle_gemm.
+extern "C" int dle_gemm_dma_try(const void* A, const void* B, void* C, void* aux, const float* bias,
+                                const void* mask_src, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                                int a_kc, int b_kc, int in_dtype, int out_dtype, int act, int splitk,
+                                int accumulate, float alpha, void* workspace, int64_t workspace_bytes,
+                                hipStream_t stream) {
+  const bool al = ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 && (lda & 7) == 0 && (ldb & 7) == 0;
+  if (!al || (K & 7) != 0) return 0;
+  if (!a_kc && (M & 7) != 0) return 0;         // row-contiguous operands are fetched in 8-row chunks
+  if (!b_kc && (N & 7) != 0) return 0;
+  if (M < 1 || N < 8 || K < 8) return 0;
+  // 32-bit byte offsets inside one operand tile panel
+  if ((long long)lda * (a_kc ? BM : BK) * 2 > 0x7FFFFFFFLL || (long long)ldb * (b_kc ? BN : BK) * 2 > 0x7FFFFFFFLL) return 0;
+  Gemm2Args p;
+  p.A = (const unsigned short*)A; p.B = (const unsigned short*)B; p.C = C; p.aux = aux; p.bias = bias;
+  p.mask_src = (const unsigned short*)mask_src;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.out_dtype = out_dtype; p.act = act; p.splitk = splitk; p.accumulate = accumulate; p.alpha = alpha;
+  p.cg = ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, 0};
+  p.ws = nullptr;
+  if (splitk > 1) {
+    const long long need = (long long)splitk * M * N * 4;
+    // every K slice must own at least one K tile, otherwise its slab would stay unwritten
+    const int ktiles = (K + BK - 1) / BK, per = (ktiles + splitk - 1) / splitk;
+    const bool full = (long long)(splitk - 1) * per < ktiles;
+    if (workspace && workspace_bytes >= need && full && (((uintptr_t)workspace) & 15) == 0) p.ws = (float*)workspace;
+    else if (!accumulate) {
+      hipError_t e = ldc == N ? hipMemsetAsync(C, 0, (size_t)M * N * 4, stream)
+                              : hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, stream);
+      if (e != hipSuccess) { dle_set_error("gemm memset: %s", hipGetErrorString(e)); return (int)e + 1000; }
+    }
+  }
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  dim3 grid(tiles, splitk), block(256);
+  const size_t lds = 2 * (BM * BK + BN * BK) * 2;
+#define GO(DT, AM, BMODE) hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE>), grid, block, lds, stream, p)
+  if (in_dtype == DLE_F16) {
+    if (a_kc && b_kc) GO(DLE_F16, 0, 0);
+    else if (a_kc) GO(DLE_F16, 0, 1);
+    else if (!b_kc) GO(DLE_F16, 1, 1);
+    else return 0;
+  } else {
+    if (a_kc && b_kc) GO(DLE_BF16, 0, 0);
+    else if (a_kc) GO(DLE_BF16, 0, 1);
+    else if (!b_kc) GO(DLE_BF16, 1, 1);
+    else return 0;
+  }
+#undef GO
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { dle_set_error("gemm_dma launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
+  if (p.ws) {
+    long long items = ((long long)M * N + 3) / 4;
+    long long g = (items + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float*)p.ws, (float*)C, M, N,
+                       (long long)ldc, splitk, accumulate);
+    e = hipGetLastError();
+    if (e != hipSuccess) { dle_set_error("splitk_reduce launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
+  }
+  return 1;
+}

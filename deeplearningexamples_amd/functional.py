@@ -217,10 +217,12 @@ def gemm(a, b, m, n, k, a_kc, b_kc, out=None, out_dtype=None, bias=None, act=C.A
     C.require_cuda(a, b, out, bias, aux, mask_src)
     if a.dtype != b.dtype or a.dtype not in (torch.float16, torch.bfloat16):
         raise ValueError("gemm inputs must both be f16 or both bf16 (got %s, %s)" % (a.dtype, b.dtype))
-    if a.stride(-1) != 1 or b.stride(-1) != 1:
-        raise ValueError("gemm operands must have unit inner stride")
-    lda = a.stride(0) if lda is None else lda
-    ldb = b.stride(0) if ldb is None else ldb
+    def _ld(t):
+        if t.shape[-1] != 1 and t.stride(-1) != 1:
+            raise ValueError("gemm operands must have unit inner stride")
+        return t.stride(0) if (t.shape[0] > 1 and t.stride(0) >= t.shape[-1]) else t.shape[-1]
+    lda = _ld(a) if lda is None else lda
+    ldb = _ld(b) if ldb is None else ldb
     if out is None:
         out = torch.empty((m, n), dtype=out_dtype or a.dtype, device=a.device)
     if out.stride(-1) != 1:
@@ -229,10 +231,23 @@ def gemm(a, b, m, n, k, a_kc, b_kc, out=None, out_dtype=None, bias=None, act=C.A
         raise ValueError("gemm bias must be fp32 [n]")
     C.annotate(flops=2.0 * m * n * k, bytes=float(m * k + n * k) * a.element_size() + float(m * n) * out.element_size(),
                tag="%dx%dx%d" % (m, n, k))
+    ws = splitk_workspace(a.device, splitk * m * n * 4) if splitk > 1 else None
     C.call("dle_gemm", C.ptr(a), C.ptr(b), C.ptr(out), C.ptr(aux), C.ptr(bias), C.ptr(mask_src), m, n, k,
            lda, ldb, out.stride(0) if out.dim() == 2 else n, int(a_kc), int(b_kc), C.dt(a), C.dt(out), act,
-           splitk, int(accumulate), float(alpha), C.stream())
+           splitk, int(accumulate), float(alpha), C.ptr(ws), ws.numel() * 4 if ws is not None else 0, C.stream())
     return out
+
+
+_splitk_ws = {}
+
+
+def splitk_workspace(device, nbytes):
+    """Per-device fp32 scratch for split-K partial slabs (grown on demand, reused by every GEMM on the stream)."""
+    w = _splitk_ws.get(device)
+    if w is None or w.numel() * 4 < nbytes:
+        w = torch.empty(max(nbytes // 4, 1 << 22), dtype=torch.float32, device=device)
+        _splitk_ws[device] = w
+    return w
 
 
 def colsum(x, out=None, accumulate=False):
@@ -244,7 +259,10 @@ def colsum(x, out=None, accumulate=False):
     if out is None:
         out = torch.empty((n,), dtype=torch.float32, device=x.device)
         accumulate = False
-    C.call("dle_colsum", C.ptr(x), C.ptr(out), m, n, x.stride(0), C.dt(x), int(accumulate), C.stream())
+    ws = splitk_workspace(x.device, 2048 * n * 4)
+    C.annotate(bytes=float(m) * n * x.element_size(), tag="%dx%d" % (m, n))
+    C.call("dle_colsum", C.ptr(x), C.ptr(out), m, n, x.stride(0) if m > 1 else n, C.dt(x), int(accumulate),
+           C.ptr(ws), ws.numel() * 4, C.stream())
     return out
 
 

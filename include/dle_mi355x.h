@@ -84,14 +84,17 @@ int dle_emb_sgd_dedup(float* weight, const int64_t* rows, const void* grad, int3
  * F.linear + bias + gelu (LanguageModeling/BERT/modeling.py:130-165), RN50 fc.
  * C[M,N] = act(alpha * A(m,k) B(n,k) + bias[n]); a_kc/b_kc = operand stored contraction-contiguous
  * ([M][lda] / [N][ldb]) or not ([K][lda] / [K][ldb]).  aux = optional pre-activation output.
- * DLE_ACT_RELU_BWD: C = (mask_src > 0) ? acc : 0.  splitk > 1 requires a plain fp32 output.       */
+ * DLE_ACT_RELU_BWD: C = (mask_src > 0) ? acc : 0.  splitk > 1 requires a plain fp32 output; with a
+ * caller-provided workspace of >= splitk*M*N*4 bytes the K slices are summed from fp32 slabs, without it by
+ * fp32 atomics (10x slower on this part).                                                             */
 int dle_gemm(const void* A, const void* B, void* C, void* aux, const float* bias,
              const void* mask_src, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
              int a_kc, int b_kc, int in_dtype, int out_dtype, int act, int splitk, int accumulate,
-             float alpha, hipStream_t stream);
-/* out[n] (+)= sum_m x[m][n]  (bias gradients) */
+             float alpha, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+/* out[n] (+)= sum_m x[m][n]  (bias gradients).  workspace (optional, fp32, >= 2048*N*4 bytes is always
+ * enough): row groups are combined through it instead of through same-address atomics. */
 int dle_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, int accumulate,
-               hipStream_t stream);
+               void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* ---- multi-tensor optimizer kernels -----------------------------------------------------------
  * replaces fused_lamb_CUDA.multi_tensor_l2norm / multi_tensor_lamb
