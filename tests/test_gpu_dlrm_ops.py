@@ -150,3 +150,39 @@ def test_embedding_full_size_roundtrip(cuda):
     F.emb_sparse_sgd_(w, perm, g, 0.25)
     after = F.emb_gather_fwd(w, perm)
     assert torch.equal(after, before - 0.25 * g.float())
+
+
+def test_cuda_ext_autograd_functions_match_torch(cuda):
+    """The reference's dlrm.cuda_ext boundary (autograd Functions) on the HIP kernels vs plain torch ops."""
+    from deeplearningexamples_amd.dlrm import cuda_ext as X
+    g = torch.Generator().manual_seed(21)
+    # dot interaction through autograd: both returned gradients land on the same leaf
+    x = torch.rand(6, 27, 128, generator=g).half().to(cuda).requires_grad_()
+    y = X.dotBasedInteract(x, x[:, 0, :])
+    ug = torch.rand(y.shape, generator=g).half().to(cuda)
+    y.backward(ug)
+    xr = x.detach().float().cpu().requires_grad_()
+    z = torch.bmm(xr, xr.transpose(1, 2))
+    ri, ci = [torch.from_numpy(a) for a in O.tril_pairs(27)]
+    yr = torch.cat([xr[:, 0, :], z[:, ri, ci], torch.zeros(6, 1)], dim=1)
+    yr.backward(ug.float().cpu())
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), yr.detach().numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(x.grad.float().cpu().numpy(), xr.grad.numpy(), rtol=1e-2, atol=3e-2)
+    # fused gather: sparse COO weight gradient like the reference's
+    sizes = [7, 50, 3]
+    off = torch.tensor([0] + sizes).cumsum(0).to(cuda)
+    w = torch.randn(60, 16, generator=g).to(cuda).requires_grad_()
+    idx = torch.stack([torch.randint(0, s, (9,), generator=g) for s in sizes], 1).to(cuda)
+    out = X.buckle_embedding_fused_gather(w, idx, off, False)
+    ug = torch.randn(out.shape, generator=g).to(cuda)
+    out.backward(ug)
+    assert w.grad.is_sparse
+    wr = w.detach().cpu().requires_grad_()
+    outr = wr[(idx.cpu() + off.cpu()[:-1])]
+    outr.backward(ug.cpu())
+    assert torch.equal(out.detach().cpu(), outr.detach())
+    np.testing.assert_allclose(w.grad.to_dense().cpu().numpy(), wr.grad.numpy(), rtol=1e-6, atol=1e-6)
+    emb = X.JointSparseEmbedding(sizes, 16, device=cuda)
+    o2 = emb(idx)
+    o2.sum().backward()
+    assert emb.weights.grad.is_sparse and o2.shape == (9, 3, 16)
