@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdle_mi355x.so")
 
 F32, F16, BF16 = 0, 1, 2
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_ADD = 0, 1, 2, 3, 4
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
@@ -48,6 +48,24 @@ _SIGS = {
     "dle_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                          c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                          c_void_p, c_i64, c_void_p]),
+    "dle_conv2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p]),
+    "dle_conv2d_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "dle_conv2d_wgrad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_i64, c_void_p]),
+    "dle_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p]),
+    "dle_bn_workspace_bytes": (c_i64, [c_i64, c_int]),
+    "dle_bn_fwd_stats": (c_int, [c_void_p, c_i64, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_i64, c_int, c_void_p]),
+    "dle_bn_fwd_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int,
+                                 c_int, c_int, c_void_p]),
+    "dle_bn_bwd_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int,
+                                  c_int, c_void_p, c_i64, c_int, c_void_p]),
+    "dle_bn_bwd_apply": (c_int, [c_void_p] * 10 + [c_i64, c_int, c_int, c_void_p]),
+    "dle_maxpool_fwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "dle_maxpool_bwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "dle_avgpool_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
+    "dle_avgpool_bwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
+    "dle_softmax_xent": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64,
+                                 c_i64, c_float, c_i64, c_int, c_void_p]),
     "dle_colsum": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p, c_i64, c_void_p]),
     "dle_mt_table_len": (c_i64, [c_int, c_int]),
     "dle_mt_table_fill": (c_i64, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]),

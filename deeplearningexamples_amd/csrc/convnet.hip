@@ -1,0 +1,597 @@
+// HBM-bound kernels of the ResNet-50 train step for gfx950 (NHWC, 16-bit activations, fp32 statistics):
+// input layout conversion, BatchNorm (training mode) forward/backward fused with ReLU and the residual add,
+// 3x3/2 max pooling, global average pooling, softmax cross entropy with label smoothing.
+//
+// Replace (paths relative to /root/reference/PyTorch/Classification/ConvNets/image_classification/):
+//   nn.BatchNorm2d + nn.ReLU(inplace) + `out += residual`   models/resnet.py:148-175, models/common.py:107-128
+//   nn.MaxPool2d(3, 2, 1), nn.AdaptiveAvgPool2d(1)           models/resnet.py:270,299
+//   LabelSmoothing / nn.CrossEntropyLoss                      smoothing.py:18-40, main.py:453-457
+//   channels_last conversion of the input batch               training.py:60-61 (memory_format)
+// (cuDNN / ATen kernels in the reference).  All kernels move 16 B per lane (8 channels), reductions over the
+// N*H*W axis keep per-lane fp32 partial sums, meet in LDS, and are combined across workgroups through a
+// caller-provided workspace (plain stores, no same-address atomics) and finished in fp64.
+#include "common.h"
+
+template <int DT> __device__ __forceinline__ float up16(unsigned short u) { return Elem<DT>::to_f32(u); }
+template <int DT> __device__ __forceinline__ unsigned short dn16(float f) { return Elem<DT>::from_f32(f); }
+
+static int cn_grid(long long items, int per_block, int cap = 2048) {
+  long long g = (items + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------- NCHW fp32 -> NHWC 16-bit (channels padded)
+template <int DT>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, unsigned short* __restrict__ y,
+                                                           long long N, int C, long long HW, int Cp) {
+  const long long total = N * HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / HW, hw = i - n * HW;
+    for (int c8 = 0; c8 < Cp; c8 += 8) {
+      ushort8_t o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = c8 + k;
+        o[k] = c < C ? dn16<DT>(x[(n * C + c) * HW + hw]) : (unsigned short)0;
+      }
+      *(ushort8_t*)(y + i * Cp + c8) = o;
+    }
+  }
+}
+
+extern "C" int dle_nchw_to_nhwc(const float* x, void* y, int64_t N, int C, int64_t HW, int C_padded, int out_dtype,
+                                hipStream_t stream) {
+  DLE_CHECK_ARG(out_dtype == DLE_F16 || out_dtype == DLE_BF16, "nchw_to_nhwc: 16-bit output only");
+  DLE_CHECK_ARG(C > 0 && C_padded >= C && C_padded % 8 == 0, "nchw_to_nhwc: padded channel count must be a multiple of 8");
+  if (N * HW == 0) return 0;
+  DLE_CHECK_ARG(x && y, "nchw_to_nhwc: null pointer");
+  const int grid = cn_grid(N * HW, 256);
+  if (out_dtype == DLE_F16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, x, (unsigned short*)y, (long long)N, C, (long long)HW, C_padded);
+  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, x, (unsigned short*)y, (long long)N, C, (long long)HW, C_padded);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- column reductions over [M][C]
+// MODE 0: s0 = sum x, s1 = sum x^2                                  (BN forward statistics)
+// MODE 1: g = dy * (y > 0 if y) ; s0 = sum g, s1 = sum g * xhat     (BN backward reductions)
+struct BnRedArgs {
+  const unsigned short* x;
+  const unsigned short* dy;
+  const unsigned short* y;      // post-activation output for the ReLU mask (NULL: no ReLU)
+  const float* mean;
+  const float* rstd;
+  float* partial;               // [groups][2][C]
+  long long M;
+  int C;
+  long long rows_per_block;
+  int lpr;                      // lanes per row = pow2 >= C/8 (<= 256)
+};
+
+template <int DT, int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(BnRedArgs a) {
+  __shared__ float red[2][256 * 8];
+  const int cl = threadIdx.x % a.lpr, rl = threadIdx.x / a.lpr, rstep = 256 / a.lpr;
+  const int c0 = (blockIdx.x * a.lpr + cl) * 8;
+  const long long r0 = (long long)blockIdx.y * a.rows_per_block;
+  long long r1 = r0 + a.rows_per_block;
+  if (r1 > a.M) r1 = a.M;
+  float s0[8], s1[8], mu[8], rs[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s0[k] = 0.f; s1[k] = 0.f; mu[k] = 0.f; rs[k] = 1.f; }
+  if (c0 < a.C) {
+    if (MODE == 1) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { mu[k] = a.mean[c0 + k]; rs[k] = a.rstd[c0 + k]; }
+    }
+    for (long long r = r0 + rl; r < r1; r += rstep) {
+      const ushort8_t xv = *(const ushort8_t*)(a.x + r * a.C + c0);
+      if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float v = up16<DT>(xv[k]); s0[k] += v; s1[k] += v * v; }
+      } else {
+        const ushort8_t gv = *(const ushort8_t*)(a.dy + r * a.C + c0);
+        ushort8_t yv = {1, 1, 1, 1, 1, 1, 1, 1};
+        if (a.y) yv = *(const ushort8_t*)(a.y + r * a.C + c0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float g = up16<DT>(gv[k]);
+          if (a.y && !(up16<DT>(yv[k]) > 0.f)) g = 0.f;
+          s0[k] += g;
+          s1[k] += g * (up16<DT>(xv[k]) - mu[k]) * rs[k];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][threadIdx.x * 8 + k] = s0[k]; red[1][threadIdx.x * 8 + k] = s1[k]; }
+  __syncthreads();
+  if (rl == 0 && c0 < a.C) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float t0 = 0.f, t1 = 0.f;
+      for (int q = 0; q < rstep; ++q) { t0 += red[0][(q * a.lpr + cl) * 8 + k]; t1 += red[1][(q * a.lpr + cl) * 8 + k]; }
+      a.partial[((long long)blockIdx.y * 2 + 0) * a.C + c0 + k] = t0;
+      a.partial[((long long)blockIdx.y * 2 + 1) * a.C + c0 + k] = t1;
+    }
+  }
+}
+
+// finish of MODE 0: mean, biased var -> rstd; running stats (momentum, unbiased var) like nn.BatchNorm2d
+__global__ __launch_bounds__(256) void bn_stats_finish_kernel(const float* __restrict__ partial, int groups, int C,
+                                                              long long M, float eps, float momentum,
+                                                              float* __restrict__ mean, float* __restrict__ rstd,
+                                                              float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var) {
+  __shared__ double red[2][256];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C)
+    for (int g = sl; g < groups; g += 4) { s0 += partial[((long long)g * 2) * C + c]; s1 += partial[((long long)g * 2 + 1) * C + c]; }
+  red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    const double t0 = red[0][cl] + red[0][64 + cl] + red[0][128 + cl] + red[0][192 + cl];
+    const double t1 = red[1][cl] + red[1][64 + cl] + red[1][128 + cl] + red[1][192 + cl];
+    const double m = t0 / (double)M;
+    double var = t1 / (double)M - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+      const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  }
+}
+
+// finish of MODE 1: dgamma = sum g xhat, dbeta = sum g
+__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float* __restrict__ partial, int groups, int C,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int accumulate) {
+  __shared__ double red[2][256];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C)
+    for (int g = sl; g < groups; g += 4) { s0 += partial[((long long)g * 2) * C + c]; s1 += partial[((long long)g * 2 + 1) * C + c]; }
+  red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    const float t0 = (float)(red[0][cl] + red[0][64 + cl] + red[0][128 + cl] + red[0][192 + cl]);
+    const float t1 = (float)(red[1][cl] + red[1][64 + cl] + red[1][128 + cl] + red[1][192 + cl]);
+    dbeta[c] = accumulate ? dbeta[c] + t0 : t0;
+    dgamma[c] = accumulate ? dgamma[c] + t1 : t1;
+  }
+}
+
+static int bn_reduce_geometry(long long M, int C, int& lpr, int& gx, long long& rpb, long long& gy) {
+  const int cols_v = C / 8;
+  lpr = 1;
+  while (lpr < cols_v && lpr < 256) lpr <<= 1;
+  gx = (cols_v + lpr - 1) / lpr;
+  long long want = 1024 / gx;
+  if (want < 1) want = 1;
+  rpb = (M + want - 1) / want;
+  const long long min_rows = 8LL * (256 / lpr);
+  if (rpb < min_rows) rpb = min_rows;
+  gy = (M + rpb - 1) / rpb;
+  return 0;
+}
+
+// workspace: fp32, >= dle_bn_workspace_bytes(M, C)
+extern "C" int64_t dle_bn_workspace_bytes(int64_t M, int C) {
+  int lpr, gx; long long rpb, gy;
+  if (C <= 0 || C % 8 != 0 || M <= 0) return 0;
+  bn_reduce_geometry(M, C, lpr, gx, rpb, gy);
+  return gy * 2 * (int64_t)C * 4;
+}
+
+extern "C" int dle_bn_fwd_stats(const void* x, int64_t M, int C, float eps, float momentum, float* mean, float* rstd,
+                                float* running_mean, float* running_var, void* workspace, int64_t workspace_bytes,
+                                int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "bn_fwd_stats: 16-bit activations only");
+  DLE_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0, "bn_fwd_stats: bad shape (C must be a multiple of 8)");
+  DLE_CHECK_ARG(x && mean && rstd && workspace, "bn_fwd_stats: null pointer");
+  DLE_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_fwd_stats: running stats come in pairs");
+  int lpr, gx; long long rpb, gy;
+  bn_reduce_geometry(M, C, lpr, gx, rpb, gy);
+  DLE_CHECK_ARG(workspace_bytes >= gy * 2 * (long long)C * 4, "bn_fwd_stats: workspace too small");
+  BnRedArgs a = {(const unsigned short*)x, nullptr, nullptr, nullptr, nullptr, (float*)workspace, (long long)M, C, rpb, lpr};
+  dim3 grid(gx, (unsigned)gy), block(256);
+  if (dtype == DLE_F16) hipLaunchKernelGGL((bn_reduce_kernel<DLE_F16, 0>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((bn_reduce_kernel<DLE_BF16, 0>), grid, block, 0, stream, a);
+  DLE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, (const float*)workspace, (int)gy, C,
+                     (long long)M, eps, momentum, mean, rstd, running_mean, running_var);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// y = act( (x - mean) * rstd * gamma + beta (+ residual) ),  act = ReLU when relu != 0
+template <int DT>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __restrict__ x,
+                                                       const unsigned short* __restrict__ res,
+                                                       unsigned short* __restrict__ y, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, long long total8, int C8,
+                                                       int relu) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total8;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % C8) * 8;
+    const ushort8_t xv = ((const ushort8_t*)x)[i];
+    ushort8_t rv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (res) rv = ((const ushort8_t*)res)[i];
+    ushort8_t o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float sc = rstd[c0 + k] * gamma[c0 + k];
+      float v = (up16<DT>(xv[k]) - mean[c0 + k]) * sc + beta[c0 + k];
+      if (res) v += up16<DT>(rv[k]);
+      if (relu) v = v > 0.f ? v : 0.f;
+      o[k] = dn16<DT>(v);
+    }
+    ((ushort8_t*)y)[i] = o;
+  }
+}
+
+extern "C" int dle_bn_fwd_apply(const void* x, const void* residual, void* y, const float* mean, const float* rstd,
+                                const float* gamma, const float* beta, int64_t M, int C, int relu, int dtype,
+                                hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "bn_fwd_apply: 16-bit activations only");
+  DLE_CHECK_ARG(M >= 0 && C > 0 && C % 8 == 0, "bn_fwd_apply: bad shape");
+  if (M == 0) return 0;
+  DLE_CHECK_ARG(x && y && mean && rstd && gamma && beta, "bn_fwd_apply: null pointer");
+  const long long total8 = (long long)M * (C / 8);
+  const int grid = cn_grid(total8, 256);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(bn_apply_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)residual, (unsigned short*)y, mean, rstd, gamma, beta, total8, C / 8, relu);
+  else hipLaunchKernelGGL(bn_apply_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)residual, (unsigned short*)y, mean, rstd, gamma, beta, total8, C / 8, relu);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// backward pass 1: dgamma / dbeta (fp32) with the ReLU mask taken from the saved output y (NULL: no ReLU)
+extern "C" int dle_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
+                                 float* dgamma, float* dbeta, int64_t M, int C, int accumulate, void* workspace,
+                                 int64_t workspace_bytes, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "bn_bwd_reduce: 16-bit activations only");
+  DLE_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0, "bn_bwd_reduce: bad shape");
+  DLE_CHECK_ARG(dy && x && mean && rstd && dgamma && dbeta && workspace, "bn_bwd_reduce: null pointer");
+  int lpr, gx; long long rpb, gy;
+  bn_reduce_geometry(M, C, lpr, gx, rpb, gy);
+  DLE_CHECK_ARG(workspace_bytes >= gy * 2 * (long long)C * 4, "bn_bwd_reduce: workspace too small");
+  BnRedArgs a = {(const unsigned short*)x, (const unsigned short*)dy, (const unsigned short*)y, mean, rstd,
+                 (float*)workspace, (long long)M, C, rpb, lpr};
+  dim3 grid(gx, (unsigned)gy), block(256);
+  if (dtype == DLE_F16) hipLaunchKernelGGL((bn_reduce_kernel<DLE_F16, 1>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((bn_reduce_kernel<DLE_BF16, 1>), grid, block, 0, stream, a);
+  DLE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, (const float*)workspace, (int)gy, C,
+                     dgamma, dbeta, accumulate);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// backward pass 2: dx = gamma * rstd * (g - dbeta/M - xhat * dgamma/M), g = dy * (y > 0);
+// g_out (optional) receives g: the gradient that flows into the residual branch.
+template <int DT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* __restrict__ dy,
+                                                           const unsigned short* __restrict__ y,
+                                                           const unsigned short* __restrict__ x,
+                                                           unsigned short* __restrict__ dx,
+                                                           unsigned short* __restrict__ g_out,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                                           const float* __restrict__ dbeta, long long total8, int C8,
+                                                           float inv_m) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total8;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % C8) * 8;
+    const ushort8_t gv = ((const ushort8_t*)dy)[i];
+    const ushort8_t xv = ((const ushort8_t*)x)[i];
+    ushort8_t yv = {1, 1, 1, 1, 1, 1, 1, 1};
+    if (y) yv = ((const ushort8_t*)y)[i];
+    ushort8_t o, go;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float g = up16<DT>(gv[k]);
+      if (y && !(up16<DT>(yv[k]) > 0.f)) g = 0.f;
+      go[k] = dn16<DT>(g);
+      const float rs = rstd[c0 + k];
+      const float xh = (up16<DT>(xv[k]) - mean[c0 + k]) * rs;
+      o[k] = dn16<DT>(gamma[c0 + k] * rs * (g - dbeta[c0 + k] * inv_m - xh * dgamma[c0 + k] * inv_m));
+    }
+    ((ushort8_t*)dx)[i] = o;
+    if (g_out) ((ushort8_t*)g_out)[i] = go;
+  }
+}
+
+extern "C" int dle_bn_bwd_apply(const void* dy, const void* y, const void* x, void* dx, void* g_out, const float* mean,
+                                const float* rstd, const float* gamma, const float* dgamma, const float* dbeta,
+                                int64_t M, int C, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "bn_bwd_apply: 16-bit activations only");
+  DLE_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0, "bn_bwd_apply: bad shape");
+  DLE_CHECK_ARG(dy && x && dx && mean && rstd && gamma && dgamma && dbeta, "bn_bwd_apply: null pointer");
+  const long long total8 = (long long)M * (C / 8);
+  const int grid = cn_grid(total8, 256);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(bn_bwd_apply_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned short*)y, (const unsigned short*)x, (unsigned short*)dx, (unsigned short*)g_out, mean, rstd, gamma, dgamma, dbeta, total8, C / 8, 1.0f / (float)M);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned short*)y, (const unsigned short*)x, (unsigned short*)dx, (unsigned short*)g_out, mean, rstd, gamma, dgamma, dbeta, total8, C / 8, 1.0f / (float)M);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- max pooling (NHWC, kernel k, stride s, pad p)
+// argmax[n,p,q,c] = window-scan index (r * k + s) of the FIRST maximum (ATen's tie rule), uint8.
+template <int DT>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* __restrict__ x,
+                                                          unsigned short* __restrict__ y,
+                                                          unsigned char* __restrict__ amax, int N, int H, int W, int C8,
+                                                          int P, int Q, int ks, int st, int pad) {
+  const long long total = (long long)N * P * Q * C8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    long long t = i / C8;
+    const int q = (int)(t % Q); t /= Q;
+    const int p = (int)(t % P);
+    const int n = (int)(t / P);
+    float best[8];
+    unsigned char bi[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; bi[k] = 0; }
+    for (int r = 0; r < ks; ++r) {
+      const int h = p * st - pad + r;
+      if (h < 0 || h >= H) continue;
+      for (int s = 0; s < ks; ++s) {
+        const int w = q * st - pad + s;
+        if (w < 0 || w >= W) continue;
+        const ushort8_t v = *(const ushort8_t*)(x + ((((long long)n * H + h) * W + w) * C8 + c8) * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float f = up16<DT>(v[k]);
+          if (f > best[k] || f != f) { best[k] = f; bi[k] = (unsigned char)(r * ks + s); }
+        }
+      }
+    }
+    ushort8_t o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = dn16<DT>(best[k]);
+    ((ushort8_t*)y)[i] = o;
+    uint2_t packed;
+    packed[0] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | ((unsigned)bi[3] << 24);
+    packed[1] = bi[4] | (bi[5] << 8) | (bi[6] << 16) | ((unsigned)bi[7] << 24);
+    ((uint2_t*)amax)[i] = packed;
+  }
+}
+
+// gather form (no atomics): each input pixel visits the <= ceil(k/s)^2 windows that cover it
+template <int DT>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned short* __restrict__ dy,
+                                                          const unsigned char* __restrict__ amax,
+                                                          unsigned short* __restrict__ dx, int N, int H, int W, int C8,
+                                                          int P, int Q, int ks, int st, int pad) {
+  const long long total = (long long)N * H * W * C8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    long long t = i / C8;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int r = 0; r < ks; ++r) {
+      const int hp = h + pad - r;
+      if (hp < 0 || hp % st != 0) continue;
+      const int p = hp / st;
+      if (p >= P) continue;
+      for (int s = 0; s < ks; ++s) {
+        const int wp = w + pad - s;
+        if (wp < 0 || wp % st != 0) continue;
+        const int q = wp / st;
+        if (q >= Q) continue;
+        const long long o = (((long long)n * P + p) * Q + q) * C8 + c8;
+        const ushort8_t g = ((const ushort8_t*)dy)[o];
+        const uint2_t am = ((const uint2_t*)amax)[o];
+        const unsigned char want = (unsigned char)(r * ks + s);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const unsigned char a = (unsigned char)((am[k >> 2] >> ((k & 3) * 8)) & 0xff);
+          if (a == want) acc[k] += up16<DT>(g[k]);
+        }
+      }
+    }
+    ushort8_t o8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o8[k] = dn16<DT>(acc[k]);
+    ((ushort8_t*)dx)[i] = o8;
+  }
+}
+
+extern "C" int dle_maxpool_fwd(const void* x, void* y, void* argmax, int N, int H, int W, int C, int ksize, int stride,
+                               int pad, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "maxpool_fwd: 16-bit activations only");
+  DLE_CHECK_ARG(C % 8 == 0 && ksize > 0 && ksize * ksize <= 255 && stride > 0, "maxpool_fwd: bad geometry");
+  if (N == 0) return 0;
+  DLE_CHECK_ARG(x && y && argmax, "maxpool_fwd: null pointer");
+  const int P = (H + 2 * pad - ksize) / stride + 1, Q = (W + 2 * pad - ksize) / stride + 1;
+  const int grid = cn_grid((long long)N * P * Q * (C / 8), 256, 8192);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(maxpool_fwd_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, (unsigned char*)argmax, N, H, W, C / 8, P, Q, ksize, stride, pad);
+  else hipLaunchKernelGGL(maxpool_fwd_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, (unsigned char*)argmax, N, H, W, C / 8, P, Q, ksize, stride, pad);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dle_maxpool_bwd(const void* dy, const void* argmax, void* dx, int N, int H, int W, int C, int ksize,
+                               int stride, int pad, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "maxpool_bwd: 16-bit activations only");
+  DLE_CHECK_ARG(C % 8 == 0 && ksize > 0 && stride > 0, "maxpool_bwd: bad geometry");
+  if (N == 0) return 0;
+  DLE_CHECK_ARG(dy && dx && argmax, "maxpool_bwd: null pointer");
+  const int P = (H + 2 * pad - ksize) / stride + 1, Q = (W + 2 * pad - ksize) / stride + 1;
+  const int grid = cn_grid((long long)N * H * W * (C / 8), 256, 8192);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(maxpool_bwd_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned char*)argmax, (unsigned short*)dx, N, H, W, C / 8, P, Q, ksize, stride, pad);
+  else hipLaunchKernelGGL(maxpool_bwd_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned char*)argmax, (unsigned short*)dx, N, H, W, C / 8, P, Q, ksize, stride, pad);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- global average pooling [N, HW, C] <-> [N, C]
+template <int DT>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const unsigned short* __restrict__ x,
+                                                          unsigned short* __restrict__ y, long long N, int HW, int C8) {
+  const long long total = N * C8;
+  const float inv = 1.0f / (float)HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / C8;
+    const int c8 = (int)(i - n * C8);
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int p = 0; p < HW; ++p) {
+      const ushort8_t v = ((const ushort8_t*)x)[(n * HW + p) * C8 + c8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += up16<DT>(v[k]);
+    }
+    ushort8_t o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = dn16<DT>(acc[k] * inv);
+    ((ushort8_t*)y)[i] = o;
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const unsigned short* __restrict__ dy,
+                                                          unsigned short* __restrict__ dx, long long N, int HW, int C8) {
+  const long long total = N * HW * C8;
+  const float inv = 1.0f / (float)HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    const long long n = i / ((long long)HW * C8);
+    const ushort8_t g = ((const ushort8_t*)dy)[n * C8 + c8];
+    ushort8_t o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = dn16<DT>(up16<DT>(g[k]) * inv);
+    ((ushort8_t*)dx)[i] = o;
+  }
+}
+
+extern "C" int dle_avgpool_fwd(const void* x, void* y, int64_t N, int HW, int C, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "avgpool_fwd: 16-bit activations only");
+  DLE_CHECK_ARG(C % 8 == 0 && HW > 0, "avgpool_fwd: bad shape");
+  if (N == 0) return 0;
+  DLE_CHECK_ARG(x && y, "avgpool_fwd: null pointer");
+  const int grid = cn_grid(N * (C / 8), 256);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(avgpool_fwd_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, (long long)N, HW, C / 8);
+  else hipLaunchKernelGGL(avgpool_fwd_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, (long long)N, HW, C / 8);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dle_avgpool_bwd(const void* dy, void* dx, int64_t N, int HW, int C, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "avgpool_bwd: 16-bit activations only");
+  DLE_CHECK_ARG(C % 8 == 0 && HW > 0, "avgpool_bwd: bad shape");
+  if (N == 0) return 0;
+  DLE_CHECK_ARG(dy && dx, "avgpool_bwd: null pointer");
+  const int grid = cn_grid(N * HW * (C / 8), 256);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(avgpool_bwd_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (unsigned short*)dx, (long long)N, HW, C / 8);
+  else hipLaunchKernelGGL(avgpool_bwd_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (unsigned short*)dx, (long long)N, HW, C / 8);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- softmax cross entropy with label smoothing
+// logits fp32 [N, ld] (first `classes` columns valid); one wavefront per row.
+//   loss_row = (1 - s) * (lse - x[t]) + s * (lse - mean(x));   loss = mean over rows with t != ignore_index
+//   dlogits  = (softmax - (1 - s) * onehot(t) - s / classes) * (*grad_scale) / n_valid   (16-bit or fp32)
+// (LabelSmoothing.forward smoothing.py:33-40; s = 0 gives nn.CrossEntropyLoss, ignore_index as in
+//  BertPretrainingCriterion, LanguageModeling/BERT/run_pretraining.py:75-95.)
+template <int ODT>
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ logits,
+                                                           const long long* __restrict__ target,
+                                                           float* __restrict__ loss_sum, void* __restrict__ dlogits,
+                                                           const float* __restrict__ grad_scale,
+                                                           const int* __restrict__ n_valid_dev, long long rows,
+                                                           int classes, long long ld, long long ld_out, float smoothing,
+                                                           long long ignore_index) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* x = logits + row * ld;
+  const long long t = target[row];
+  const bool valid = t != ignore_index;
+  float mx = -INFINITY;
+  for (int c = lane; c < classes; c += 64) mx = fmaxf(mx, x[c]);
+  mx = wave_max(mx);
+  float se = 0.f, sx = 0.f;
+  for (int c = lane; c < classes; c += 64) { se += __expf(x[c] - mx); sx += x[c]; }
+  se = wave_sum(se);
+  sx = wave_sum(sx);
+  const float lse = mx + __logf(se);
+  if (lane == 0 && valid) {
+    const float nll = lse - x[t];
+    const float smooth = lse - sx / (float)classes;
+    unsafeAtomicAdd(loss_sum, (1.f - smoothing) * nll + smoothing * smooth);
+  }
+  if (dlogits) {
+    const float nv = (float)(*n_valid_dev > 0 ? *n_valid_dev : 1);
+    const float gs = valid ? (grad_scale ? *grad_scale : 1.0f) / nv : 0.f;
+    const float inv_se = 1.0f / se, sm = smoothing / (float)classes;
+    for (int c = lane; c < ld_out; c += 64) {
+      float g = 0.f;
+      if (c < classes) g = (__expf(x[c] - mx) * inv_se - (c == t ? 1.f - smoothing : 0.f) - sm) * gs;
+      if (ODT == DLE_F32) ((float*)dlogits)[row * ld_out + c] = g;
+      else ((unsigned short*)dlogits)[row * ld_out + c] = ODT == DLE_F16 ? Elem<DLE_F16>::from_f32(g) : Elem<DLE_BF16>::from_f32(g);
+    }
+  }
+}
+
+__global__ void count_valid_kernel(const long long* __restrict__ target, long long rows, long long ignore_index,
+                                   int* __restrict__ n_valid) {
+  __shared__ float red[16];
+  float c = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (long long)gridDim.x * blockDim.x)
+    c += target[i] != ignore_index ? 1.f : 0.f;
+  c = block_sum(c, red);
+  if (threadIdx.x == 0) atomicAdd(n_valid, (int)(c + 0.5f));
+}
+
+__global__ void xent_finish_kernel(float* loss_sum, const int* n_valid) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *loss_sum = *loss_sum / (float)(*n_valid > 0 ? *n_valid : 1);
+}
+
+// scratch: int32[1] device word (valid-row counter).  loss_out[0] = mean loss.
+extern "C" int dle_softmax_xent(const float* logits, const int64_t* target, float* loss_out, void* dlogits,
+                                const float* grad_scale_dev, int* scratch, int64_t rows, int classes, int64_t ld,
+                                int64_t ld_out, float smoothing, int64_t ignore_index, int dlogits_dtype,
+                                hipStream_t stream) {
+  DLE_CHECK_ARG(loss_out && scratch, "softmax_xent: null loss/scratch pointer");
+  hipError_t e = hipMemsetAsync(loss_out, 0, 4, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(scratch, 0, 4, stream);
+  if (e != hipSuccess) { dle_set_error("softmax_xent memset: %s", hipGetErrorString(e)); return (int)e; }
+  if (rows == 0) return 0;
+  DLE_CHECK_ARG(logits && target && classes > 0 && ld >= classes, "softmax_xent: bad arguments");
+  DLE_CHECK_ARG(!dlogits || ld_out >= classes, "softmax_xent: dlogits row too short");
+  hipLaunchKernelGGL(count_valid_kernel, dim3(cn_grid(rows, 256, 256)), dim3(256), 0, stream, (const long long*)target,
+                     (long long)rows, (long long)ignore_index, scratch);
+  DLE_LAUNCH_CHECK();
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define GO(ODT) hipLaunchKernelGGL(softmax_xent_kernel<ODT>, grid, block, 0, stream, logits, (const long long*)target, loss_out, dlogits, grad_scale_dev, (const int*)scratch, (long long)rows, classes, (long long)ld, (long long)ld_out, smoothing, (long long)ignore_index)
+  if (dlogits_dtype == DLE_F32) GO(DLE_F32);
+  else if (dlogits_dtype == DLE_F16) GO(DLE_F16);
+  else if (dlogits_dtype == DLE_BF16) GO(DLE_BF16);
+  else { dle_set_error("softmax_xent: bad dlogits dtype %d", dlogits_dtype); return -1; }
+#undef GO
+  DLE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(xent_finish_kernel, dim3(1), dim3(64), 0, stream, loss_out, (const int*)scratch);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}

@@ -27,10 +27,13 @@
 #define BN 128
 #define BK 64
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_ADD = 4 };
 
-struct ConvGeom {        // A_MODE 2: m <-> (n, p, q), k <-> (r, s, c); requires C % 64 == 0
-  int H, W, C, P, Q, R, S, stride, pad;
+struct ConvGeom {        // implicit-GEMM operand geometry (NHWC tensors, KRSC weights)
+  int H, W, C;           // spatial size / channels of the tensor the im2col operand reads
+  int P, Q;              // spatial size of the convolution OUTPUT (forward sense)
+  int R, S, stride, pad;
+  int Ko;                // output channels (forward sense)
 };
 
 struct Gemm2Args {
@@ -78,19 +81,25 @@ __device__ __forceinline__ float gelu_tanh2(float x) {
 }
 
 // ---- per-operand tile loader state: 4 DMA instructions per wave per K tile --------------------------
-// MODE 0 (k-contiguous):  tile image [128 rows][8 chunks]; instr j of wave w covers rows (4w+j)*8 .. +7.
-// MODE 1 (row-contiguous): tile image [64 k][16 chunks];   instr j of wave w covers k rows (4w+j)*4 .. +3.
+// k-contiguous images  [128 rows][8 chunks]: instr j of wave w covers rows (4w+j)*8 .. +7     (modes 0, 2, 4)
+// row-contiguous images [64 k][16 chunks]:   instr j of wave w covers k rows (4w+j)*4 .. +3   (modes 1, 3, 5)
+//   0  matrix, k contiguous                1  matrix, rows contiguous
+//   2  im2col, forward:   A(m=(n,p,q), k=(r,s,c))  = X[n, p*st-pad+r, q*st-pad+s, c]
+//   4  im2col, data grad: A(m=(n,h,w), k=(r,s,ko)) = dY[n, (h+pad-r)/st, (w+pad-s)/st, ko]   (0 unless divisible)
+//   3  im2col, weight grad B operand: B(n'=(r,s,c), k=pixel(n,p,q)) = X[n, p*st-pad+r, q*st-pad+s, c]
+//   5  KRSC weights as the data-grad B operand: B(c, k=(r,s,ko)) = W[ko][r][s][c]
 template <int MODE>
 struct Loader {
-  unsigned off[4];       // byte offset of this lane's 16 B relative to the K-tile base (MODE 0/1) or image (2)
-  int kin[4];            // MODE 0: k element offset inside the tile (for the K tail);  MODE 1: k row inside the tile
-  int h0[4], w0[4];      // MODE 2: top-left input coordinate of the lane's output pixel
+  static constexpr bool RC = (MODE == 1 || MODE == 3 || MODE == 5);
+  unsigned off[4];       // mode 0/1: byte offset inside the K-tile panel; conv modes: lane-constant part
+  int kin[4];            // KC: k element offset inside the tile; RC: k row inside the tile
+  int a0[4], a1[4];      // mode 2: (h0, w0) of the output pixel; mode 4: (h, w); mode 3: (r, s) of the lane's tap
   bool row_ok[4];
 
   __device__ __forceinline__ void init(int wave, int lane, int row0, int nrows, long long ld, const ConvGeom& cg) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (MODE == 0 || MODE == 2) {
+      if (!RC) {
         const int row = (wave * 4 + j) * 8 + (lane >> 3), cpos = lane & 7;
         const int chunk = cpos ^ swz_kc(row);
         const int g = row0 + row;
@@ -98,13 +107,18 @@ struct Loader {
         kin[j] = chunk * 8;
         if (MODE == 0) {
           off[j] = (unsigned)(((long long)row * ld + chunk * 8) * 2);
-        } else {
-          // decode the output pixel once: g = (n * P + p) * Q + q
-          const int q = g % cg.Q, t = g / cg.Q;
+        } else if (MODE == 2) {
+          const int q = g % cg.Q, t = g / cg.Q;          // g = (n * P + p) * Q + q
           const int p = t % cg.P, n = t / cg.P;
-          h0[j] = p * cg.stride - cg.pad;
-          w0[j] = q * cg.stride - cg.pad;
-          off[j] = (unsigned)(((((long long)n * cg.H + h0[j]) * cg.W + w0[j]) * cg.C + chunk * 8) * 2);
+          a0[j] = p * cg.stride - cg.pad;
+          a1[j] = q * cg.stride - cg.pad;
+          off[j] = (unsigned)((((long long)n * cg.H + a0[j]) * cg.W + a1[j]) * cg.C * 2);
+        } else {                                          // MODE 4: g = (n * H + h) * W + w  (dX pixel)
+          const int w = g % cg.W, t = g / cg.W;
+          const int h = t % cg.H, n = t / cg.H;
+          a0[j] = h + cg.pad;
+          a1[j] = w + cg.pad;
+          off[j] = (unsigned)n;                           // image index; pixel offset is rebuilt per tap
         }
       } else {
         const int kr = (wave * 4 + j) * 4 + (lane >> 4), cpos = lane & 15;
@@ -112,32 +126,54 @@ struct Loader {
         const int g = row0 + chunk * 8;
         row_ok[j] = g < nrows;
         kin[j] = kr;
-        off[j] = (unsigned)(((long long)kr * ld + chunk * 8) * 2);
+        if (MODE == 1) {
+          off[j] = (unsigned)(((long long)kr * ld + chunk * 8) * 2);
+        } else if (MODE == 3) {                           // g = (r * S + s) * C + c
+          const int tap = g / cg.C, c = g - tap * cg.C;
+          a0[j] = tap / cg.S;
+          a1[j] = tap - a0[j] * cg.S;
+          off[j] = (unsigned)(c * 2);
+        } else {                                          // MODE 5: g = input channel c
+          off[j] = (unsigned)(g * 2);
+        }
       }
     }
   }
 
-  // base: pointer of (row0, k0) for MODE 0 [ld = row stride], of (k0, row0) for MODE 1, of the image for MODE 2
+  // base: (row0, k0) panel for mode 0, (k0, row0) panel for mode 1, tensor base for the conv modes
   __device__ __forceinline__ void issue(const unsigned short* base, unsigned short* tile, int wave, int krem,
                                         int k0, const ConvGeom& cg) {
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xFFFFFFE0, 0x00020000);
-    int r = 0, s = 0, c0 = 0;
-    unsigned tap = 0;
-    if (MODE == 2) {
-      const int rs_i = k0 / cg.C;
-      c0 = k0 - rs_i * cg.C;
-      r = rs_i / cg.S;
-      s = rs_i - r * cg.S;
-      tap = (unsigned)(((r * cg.W + s) * cg.C + c0) * 2);
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       bool ok = row_ok[j] && kin[j] < krem;
       unsigned o = off[j];
       if (MODE == 2) {
-        const int h = h0[j] + r, w = w0[j] + s;
+        const int k = k0 + kin[j];
+        const int tap = k / cg.C, c = k - tap * cg.C;
+        const int r = tap / cg.S, s = tap - r * cg.S;
+        const int h = a0[j] + r, w = a1[j] + s;
         ok = ok && h >= 0 && h < cg.H && w >= 0 && w < cg.W;
-        o += tap;
+        o += (unsigned)(((r * cg.W + s) * cg.C + c) * 2);
+      } else if (MODE == 4) {
+        const int k = k0 + kin[j];
+        const int tap = k / cg.Ko, ko = k - tap * cg.Ko;
+        const int r = tap / cg.S, s = tap - r * cg.S;
+        const int hp = a0[j] - r, wp = a1[j] - s;
+        const int p = hp / cg.stride, q = wp / cg.stride;
+        ok = ok && hp >= 0 && wp >= 0 && p * cg.stride == hp && q * cg.stride == wp && p < cg.P && q < cg.Q;
+        o = (unsigned)(((((long long)off[j] * cg.P + p) * cg.Q + q) * cg.Ko + ko) * 2);
+      } else if (MODE == 3) {
+        const int pix = k0 + kin[j];
+        const int q = pix % cg.Q, t = pix / cg.Q;
+        const int p = t % cg.P, n = t / cg.P;
+        const int h = p * cg.stride - cg.pad + a0[j], w = q * cg.stride - cg.pad + a1[j];
+        ok = ok && h >= 0 && h < cg.H && w >= 0 && w < cg.W;
+        o += (unsigned)((((long long)n * cg.H + h) * cg.W + w) * cg.C * 2);
+      } else if (MODE == 5) {
+        const int k = k0 + kin[j];
+        const int tap = k / cg.Ko, ko = k - tap * cg.Ko;
+        o += (unsigned)((((long long)ko * cg.R * cg.S + tap) * cg.C) * 2);
       }
       dma16(rs, tile + (wave * 4 + j) * 512, ok ? o : OOB_OFF);
     }
@@ -181,7 +217,8 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(Gemm2Args p) {
     unsigned short* tb = ta + BM * BK;
     const unsigned short* ba = A_MODE == 0 ? p.A + (long long)m0 * p.lda + k0
                              : A_MODE == 1 ? p.A + (long long)k0 * p.lda + m0 : p.A;
-    const unsigned short* bb = B_MODE == 0 ? p.B + (long long)n0 * p.ldb + k0 : p.B + (long long)k0 * p.ldb + n0;
+    const unsigned short* bb = B_MODE == 0 ? p.B + (long long)n0 * p.ldb + k0
+                             : B_MODE == 1 ? p.B + (long long)k0 * p.ldb + n0 : p.B;
     la.issue(ba, ta, wave, kend - k0, k0, p.cg);
     lb.issue(bb, tb, wave, kend - k0, k0, p.cg);
   };
@@ -210,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(Gemm2Args p) {
       ushort8_t fa[2], fb[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        if (A_MODE != 1) {
+        if (!Loader<A_MODE>::RC) {
           const int row = wm * 64 + i * 32 + fr;
           fa[i] = *(const ushort8_t*)(ta + row * BK + (((ks * 2 + fh) ^ swz_kc(row)) << 3));
         } else {
@@ -231,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(Gemm2Args p) {
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        if (B_MODE == 0) {
+        if (!Loader<B_MODE>::RC) {
           const int row = wn * 64 + j * 32 + fr;
           fb[j] = *(const ushort8_t*)(tb + row * BK + (((ks * 2 + fh) ^ swz_kc(row)) << 3));
         } else {
@@ -308,6 +345,11 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(Gemm2Args p) {
                                             : Elem<DLE_BF16>::to_f32(p.mask_src[off + r]);
               v[r] = y > 0.f ? v[r] : 0.f;
             }
+        } else if (p.act == ACT_ADD) {          // C = acc + addend (residual-branch gradient sum)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < nval)
+              v[r] += DT == DLE_F16 ? Elem<DLE_F16>::to_f32(p.mask_src[off + r]) : Elem<DLE_BF16>::to_f32(p.mask_src[off + r]);
         }
         if (p.out_dtype == DLE_F32) {
           float* c = (float*)p.C + off;
@@ -392,7 +434,7 @@ extern "C" int dle_gemm_dma_try(const void* A, const void* B, void* C, void* aux
   p.mask_src = (const unsigned short*)mask_src;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.out_dtype = out_dtype; p.act = act; p.splitk = splitk; p.accumulate = accumulate; p.alpha = alpha;
-  p.cg = ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, 0};
+  p.cg = ConvGeom{};
   p.ws = nullptr;
   if (splitk > 1) {
     const long long need = (long long)splitk * M * N * 4;
@@ -434,4 +476,104 @@ extern "C" int dle_gemm_dma_try(const void* A, const void* B, void* C, void* aux
     if (e != hipSuccess) { dle_set_error("splitk_reduce launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
   }
   return 1;
+}
+
+
+// ---- convolutions as implicit GEMM (NHWC activations, KRSC weights, 16-bit in, fp32 accumulate) -------------
+// Replace cuDNN's conv fwd / bwd-data / bwd-filter behind nn.Conv2d(bias=False)
+// (Classification/ConvNets/image_classification/models/common.py:31-60, resnet.py:126-175).
+static int conv_launch(Gemm2Args& p, int in_dtype, int amode, int bmode, hipStream_t stream) {
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  dim3 grid(tiles, p.splitk), block(256);
+  const size_t lds = 2 * (BM * BK + BN * BK) * 2;
+#define GO(DT, AM, BMODE) hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE>), grid, block, lds, stream, p)
+  if (in_dtype == DLE_F16) {
+    if (amode == 2) GO(DLE_F16, 2, 0); else if (amode == 4) GO(DLE_F16, 4, 5); else GO(DLE_F16, 1, 3);
+  } else {
+    if (amode == 2) GO(DLE_BF16, 2, 0); else if (amode == 4) GO(DLE_BF16, 4, 5); else GO(DLE_BF16, 1, 3);
+  }
+#undef GO
+  (void)bmode;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { dle_set_error("conv launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+static int conv_check(const char* what, int N, int H, int W, int C, int Ko, int R, int S, int stride, int pad,
+                      int P, int Q, int dtype) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "%s: 16-bit dtypes only (got %d)", what, dtype);
+  DLE_CHECK_ARG(N > 0 && H > 0 && W > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0, "%s: bad geometry", what);
+  DLE_CHECK_ARG(C % 8 == 0 && Ko % 8 == 0, "%s: channel counts must be multiples of 8 (C=%d, K=%d)", what, C, Ko);
+  DLE_CHECK_ARG(P == (H + 2 * pad - R) / stride + 1 && Q == (W + 2 * pad - S) / stride + 1, "%s: output size mismatch", what);
+  DLE_CHECK_ARG((long long)N * H * W * C * 2 < 0xFFFFFFE0LL && (long long)N * P * Q * Ko * 2 < 0xFFFFFFE0LL,
+                "%s: tensors above 4 GiB are not addressable by this kernel", what);
+  return 0;
+}
+
+// y[N,P,Q,Ko] = conv(x[N,H,W,C], w[Ko,R,S,C]); act/aux/bias as in dle_gemm (bias per output channel).
+extern "C" int dle_conv2d_fwd(const void* x, const void* w, void* y, const float* bias, int N, int H, int W, int C,
+                              int Ko, int R, int S, int stride, int pad, int dtype, int out_dtype, int act,
+                              hipStream_t stream) {
+  const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+  if (int rc = conv_check("conv2d_fwd", N, H, W, C, Ko, R, S, stride, pad, P, Q, dtype)) return rc;
+  DLE_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
+  DLE_CHECK_ARG(act == ACT_NONE || act == ACT_RELU, "conv2d_fwd: unsupported epilogue %d", act);
+  Gemm2Args p = {};
+  p.A = (const unsigned short*)x; p.B = (const unsigned short*)w; p.C = y; p.bias = bias;
+  p.M = N * P * Q; p.N = Ko; p.K = R * S * C; p.lda = 0; p.ldb = (long long)R * S * C; p.ldc = Ko;
+  p.out_dtype = out_dtype; p.act = act; p.splitk = 1; p.accumulate = 0; p.alpha = 1.f;
+  p.cg = ConvGeom{H, W, C, P, Q, R, S, stride, pad, Ko};
+  return conv_launch(p, dtype, 2, 0, stream);
+}
+
+// dx[N,H,W,C] = conv_transpose(dy[N,P,Q,Ko], w[Ko,R,S,C]) (+ addend[N,H,W,C] when non-NULL)
+extern "C" int dle_conv2d_dgrad(const void* dy, const void* w, void* dx, const void* addend, int N, int H, int W,
+                                int C, int Ko, int R, int S, int stride, int pad, int dtype, hipStream_t stream) {
+  const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+  if (int rc = conv_check("conv2d_dgrad", N, H, W, C, Ko, R, S, stride, pad, P, Q, dtype)) return rc;
+  DLE_CHECK_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
+  Gemm2Args p = {};
+  p.A = (const unsigned short*)dy; p.B = (const unsigned short*)w; p.C = dx;
+  p.mask_src = (const unsigned short*)addend;
+  p.M = N * H * W; p.N = C; p.K = R * S * Ko; p.lda = 0; p.ldb = 0; p.ldc = C;
+  p.out_dtype = dtype; p.act = addend ? ACT_ADD : ACT_NONE; p.splitk = 1; p.accumulate = 0; p.alpha = 1.f;
+  p.cg = ConvGeom{H, W, C, P, Q, R, S, stride, pad, Ko};
+  return conv_launch(p, dtype, 4, 5, stream);
+}
+
+// dw[Ko,R,S,C] (fp32) (+)= sum over pixels dy[N,P,Q,Ko]^T im2col(x[N,H,W,C]); workspace: split-K slabs.
+extern "C" int dle_conv2d_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, int C, int Ko, int R,
+                                int S, int stride, int pad, int dtype, int splitk, int accumulate, void* workspace,
+                                int64_t workspace_bytes, hipStream_t stream) {
+  const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+  if (int rc = conv_check("conv2d_wgrad", N, H, W, C, Ko, R, S, stride, pad, P, Q, dtype)) return rc;
+  DLE_CHECK_ARG(dy && x && dw, "conv2d_wgrad: null pointer");
+  Gemm2Args p = {};
+  p.A = (const unsigned short*)dy; p.B = (const unsigned short*)x; p.C = dw;
+  p.M = Ko; p.N = R * S * C; p.K = N * P * Q; p.lda = Ko; p.ldb = 0; p.ldc = (long long)R * S * C;
+  p.out_dtype = DLE_F32; p.act = ACT_NONE; p.accumulate = accumulate; p.alpha = 1.f;
+  p.cg = ConvGeom{H, W, C, P, Q, R, S, stride, pad, Ko};
+  const int ktiles = (p.K + BK - 1) / BK;
+  if (splitk < 1) splitk = 1;
+  if (splitk > ktiles) splitk = ktiles;
+  while (splitk > 1 && (long long)(splitk - 1) * ((ktiles + splitk - 1) / splitk) >= ktiles) --splitk;
+  p.splitk = splitk;
+  if (splitk > 1) {
+    const long long need = (long long)splitk * p.M * p.N * 4;
+    if (workspace && workspace_bytes >= need && (((uintptr_t)workspace) & 15) == 0) p.ws = (float*)workspace;
+    else if (!accumulate) {
+      hipError_t e = hipMemsetAsync(dw, 0, (size_t)p.M * p.N * 4, stream);
+      if (e != hipSuccess) { dle_set_error("conv2d_wgrad memset: %s", hipGetErrorString(e)); return (int)e; }
+    }
+  }
+  if (int rc = conv_launch(p, dtype, 1, 3, stream)) return rc;
+  if (p.ws) {
+    long long g = (((long long)p.M * p.N + 3) / 4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float*)p.ws, dw, p.M, p.N,
+                       p.ldc, splitk, accumulate);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { dle_set_error("splitk_reduce launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  return 0;
 }

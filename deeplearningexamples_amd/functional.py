@@ -324,3 +324,178 @@ def copy_rows(src, dst):
     C.call("dle_cast_rows", C.ptr(src), C.ptr(dst), r, c, c, src.stride(0), dst.stride(0), C.dt(src), C.dt(dst),
            C.stream())
     return dst
+
+
+# ------------------------------------------------------------------ convolutions (NHWC / KRSC, implicit GEMM)
+def _conv_out(h, w, r, s, stride, pad):
+    return (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
+
+
+def conv2d_fwd(x, w, stride=1, pad=0, bias=None, act=C.ACT_NONE, out=None, out_dtype=None):
+    """x [N,H,W,C], w [Ko,R,S,C] (both 16-bit, contiguous) -> y [N,P,Q,Ko]."""
+    C.require_cuda(x, w, bias, out)
+    n, h, wd, c = x.shape
+    ko, r, s, c2 = w.shape
+    if c2 != c or not x.is_contiguous() or not w.is_contiguous() or x.dtype != w.dtype:
+        raise ValueError("conv2d_fwd: x must be NHWC-contiguous and w KRSC-contiguous with matching C/dtype")
+    p, q = _conv_out(h, wd, r, s, stride, pad)
+    if out is None:
+        out = torch.empty((n, p, q, ko), dtype=out_dtype or x.dtype, device=x.device)
+    C.annotate(flops=2.0 * n * p * q * ko * r * s * c, tag="fwd %dx%dx%dx%d k%d %dx%d s%d" % (n, h, wd, c, ko, r, s, stride),
+               bytes=float(x.numel() + w.numel() + out.numel()) * 2)
+    C.call("dle_conv2d_fwd", C.ptr(x), C.ptr(w), C.ptr(out), C.ptr(bias), n, h, wd, c, ko, r, s, stride, pad,
+           C.dt(x), C.dt(out), act, C.stream())
+    return out
+
+
+def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, addend=None, out=None):
+    """dy [N,P,Q,Ko], w [Ko,R,S,C] -> dx [N,H,W,C] (+ addend)."""
+    C.require_cuda(dy, w, addend, out)
+    n, p, q, ko = dy.shape
+    ko2, r, s, c = w.shape
+    h, wd = in_hw
+    if ko2 != ko or not dy.is_contiguous() or not w.is_contiguous() or (p, q) != _conv_out(h, wd, r, s, stride, pad):
+        raise ValueError("conv2d_dgrad: shape mismatch")
+    if out is None:
+        out = torch.empty((n, h, wd, c), dtype=dy.dtype, device=dy.device)
+    if addend is not None and (addend.shape != out.shape or not addend.is_contiguous() or addend.dtype != dy.dtype):
+        raise ValueError("conv2d_dgrad: addend must match dx")
+    C.annotate(flops=2.0 * n * p * q * ko * r * s * c, tag="dgrad %dx%dx%dx%d k%d %dx%d s%d" % (n, h, wd, c, ko, r, s, stride),
+               bytes=float(dy.numel() + w.numel() + out.numel()) * 2)
+    C.call("dle_conv2d_dgrad", C.ptr(dy), C.ptr(w), C.ptr(out), C.ptr(addend), n, h, wd, c, ko, r, s, stride, pad,
+           C.dt(dy), C.stream())
+    return out
+
+
+def conv2d_wgrad(dy, x, rs, stride=1, pad=0, out=None, accumulate=False, splitk=None):
+    """dy [N,P,Q,Ko], x [N,H,W,C] -> dw [Ko,R,S,C] fp32."""
+    C.require_cuda(dy, x, out)
+    n, p, q, ko = dy.shape
+    n2, h, wd, c = x.shape
+    r, s = rs
+    if n2 != n or not dy.is_contiguous() or not x.is_contiguous() or (p, q) != _conv_out(h, wd, r, s, stride, pad):
+        raise ValueError("conv2d_wgrad: shape mismatch")
+    if out is None:
+        out = torch.empty((ko, r, s, c), dtype=torch.float32, device=x.device)
+        accumulate = False
+    m_out, n_out, k = ko, r * s * c, n * p * q
+    if splitk is None:
+        splitk = pick_splitk(m_out, n_out, k, target_blocks=1024)
+    ws = splitk_workspace(x.device, splitk * m_out * n_out * 4) if splitk > 1 else None
+    C.annotate(flops=2.0 * n * p * q * ko * r * s * c, tag="wgrad %dx%dx%dx%d k%d %dx%d s%d" % (n, h, wd, c, ko, r, s, stride),
+               bytes=float(dy.numel() + x.numel()) * 2 + out.numel() * 4.0)
+    C.call("dle_conv2d_wgrad", C.ptr(dy), C.ptr(x), C.ptr(out), n, h, wd, c, ko, r, s, stride, pad, C.dt(x), splitk,
+           int(accumulate), C.ptr(ws), ws.numel() * 4 if ws is not None else 0, C.stream())
+    return out
+
+
+# ------------------------------------------------------------------ ResNet HBM-bound ops (NHWC, 16-bit)
+def nchw_to_nhwc(x, out_dtype, c_padded=None):
+    """fp32 [N,C,H,W] -> 16-bit [N,H,W,Cp] with zero-filled padding channels."""
+    C.require_cuda(x)
+    if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
+        raise ValueError("nchw_to_nhwc expects a contiguous fp32 NCHW tensor")
+    n, c, h, w = x.shape
+    cp = c_padded or (c + 7) // 8 * 8
+    y = torch.empty((n, h, w, cp), dtype=out_dtype, device=x.device)
+    C.call("dle_nchw_to_nhwc", C.ptr(x), C.ptr(y), n, c, h * w, cp, C.dt(y), C.stream())
+    return y
+
+
+def _bn_ws(x2d):
+    m, c = x2d.shape
+    nbytes = C.lib().dle_bn_workspace_bytes(m, c)
+    return splitk_workspace(x2d.device, nbytes)
+
+
+def bn_fwd(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, residual=None, relu=True,
+           out=None):
+    """Training-mode BatchNorm over the leading dims of NHWC x (+ residual, + ReLU).  -> (y, mean, rstd)."""
+    C.require_cuda(x, gamma, beta, running_mean, running_var, residual, out)
+    c = x.shape[-1]
+    m = x.numel() // c
+    x2 = x.reshape(m, c)
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(c, dtype=torch.float32, device=x.device)
+    ws = _bn_ws(x2)
+    C.annotate(bytes=float(x.numel()) * 2, tag="C%d" % c)
+    C.call("dle_bn_fwd_stats", C.ptr(x), m, c, eps, momentum, C.ptr(mean), C.ptr(rstd), C.ptr(running_mean),
+           C.ptr(running_var), C.ptr(ws), ws.numel() * 4, C.dt(x), C.stream())
+    y = torch.empty_like(x) if out is None else out
+    C.annotate(bytes=float(x.numel()) * 2 * (3 if residual is not None else 2), tag="C%d" % c)
+    C.call("dle_bn_fwd_apply", C.ptr(x), C.ptr(residual), C.ptr(y), C.ptr(mean), C.ptr(rstd), C.ptr(gamma),
+           C.ptr(beta), m, c, int(relu), C.dt(x), C.stream())
+    return y, mean, rstd
+
+
+def bn_bwd(dy, y, x, mean, rstd, gamma, dgamma, dbeta, want_skip_grad=False, dx_out=None):
+    """-> (dx, g) ; y = saved post-ReLU output (None when the BN had no ReLU); g = dy*(y>0) if requested."""
+    C.require_cuda(dy, y, x, mean, rstd, gamma, dgamma, dbeta)
+    c = x.shape[-1]
+    m = x.numel() // c
+    ws = _bn_ws(x.reshape(m, c))
+    C.annotate(bytes=float(x.numel()) * 2 * (3 if y is not None else 2), tag="C%d" % c)
+    C.call("dle_bn_bwd_reduce", C.ptr(dy), C.ptr(y), C.ptr(x), C.ptr(mean), C.ptr(rstd), C.ptr(dgamma), C.ptr(dbeta),
+           m, c, 0, C.ptr(ws), ws.numel() * 4, C.dt(x), C.stream())
+    dx = torch.empty_like(x) if dx_out is None else dx_out
+    g = torch.empty_like(x) if want_skip_grad else None
+    C.annotate(bytes=float(x.numel()) * 2 * ((4 if y is not None else 3) + int(want_skip_grad)), tag="C%d" % c)
+    C.call("dle_bn_bwd_apply", C.ptr(dy), C.ptr(y), C.ptr(x), C.ptr(dx), C.ptr(g), C.ptr(mean), C.ptr(rstd),
+           C.ptr(gamma), C.ptr(dgamma), C.ptr(dbeta), m, c, C.dt(x), C.stream())
+    return dx, g
+
+
+def maxpool_fwd(x, ksize=3, stride=2, pad=1):
+    C.require_cuda(x)
+    n, h, w, c = x.shape
+    p, q = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+    y = torch.empty((n, p, q, c), dtype=x.dtype, device=x.device)
+    am = torch.empty((n, p, q, c), dtype=torch.uint8, device=x.device)
+    C.annotate(bytes=float(x.numel() + y.numel()) * 2 + am.numel())
+    C.call("dle_maxpool_fwd", C.ptr(x), C.ptr(y), C.ptr(am), n, h, w, c, ksize, stride, pad, C.dt(x), C.stream())
+    return y, am
+
+
+def maxpool_bwd(dy, argmax, in_hw, ksize=3, stride=2, pad=1):
+    C.require_cuda(dy, argmax)
+    n, p, q, c = dy.shape
+    h, w = in_hw
+    dx = torch.empty((n, h, w, c), dtype=dy.dtype, device=dy.device)
+    C.annotate(bytes=float(dx.numel() + dy.numel()) * 2 + argmax.numel())
+    C.call("dle_maxpool_bwd", C.ptr(dy), C.ptr(argmax), C.ptr(dx), n, h, w, c, ksize, stride, pad, C.dt(dy), C.stream())
+    return dx
+
+
+def avgpool_fwd(x):
+    C.require_cuda(x)
+    n, h, w, c = x.shape
+    y = torch.empty((n, c), dtype=x.dtype, device=x.device)
+    C.call("dle_avgpool_fwd", C.ptr(x), C.ptr(y), n, h * w, c, C.dt(x), C.stream())
+    return y
+
+
+def avgpool_bwd(dy, hw):
+    C.require_cuda(dy)
+    n, c = dy.shape
+    h, w = hw
+    dx = torch.empty((n, h, w, c), dtype=dy.dtype, device=dy.device)
+    C.call("dle_avgpool_bwd", C.ptr(dy), C.ptr(dx), n, h * w, c, C.dt(dy), C.stream())
+    return dx
+
+
+def softmax_xent(logits, target, smoothing=0.0, ignore_index=-100, grad_scale=None, grad_dtype=None, ld_out=None):
+    """logits fp32 [rows, classes(+pad)], target int64 [rows] -> (mean loss [1], dlogits or None)."""
+    C.require_cuda(logits, target, grad_scale)
+    if logits.dtype != torch.float32 or logits.dim() != 2 or logits.stride(1) != 1 or target.dtype != torch.int64:
+        raise ValueError("softmax_xent expects fp32 [rows, classes] logits and int64 targets")
+    rows, classes = logits.shape
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    scratch = torch.empty(1, dtype=torch.int32, device=logits.device)
+    dl = None
+    ldo = ld_out or classes
+    if grad_dtype is not None:
+        dl = torch.empty((rows, ldo), dtype=grad_dtype, device=logits.device)
+    C.call("dle_softmax_xent", C.ptr(logits), C.ptr(target), C.ptr(loss), C.ptr(dl), C.ptr(grad_scale), C.ptr(scratch),
+           rows, classes, logits.stride(0), ldo, float(smoothing), int(ignore_index),
+           C.dt(grad_dtype) if grad_dtype is not None else 0, C.stream())
+    return loss, dl

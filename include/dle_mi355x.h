@@ -22,7 +22,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 
 enum { DLE_F32 = 0, DLE_F16 = 1, DLE_BF16 = 2 };
-enum { DLE_ACT_NONE = 0, DLE_ACT_RELU = 1, DLE_ACT_GELU = 2, DLE_ACT_RELU_BWD = 3 };
+enum { DLE_ACT_NONE = 0, DLE_ACT_RELU = 1, DLE_ACT_GELU = 2, DLE_ACT_RELU_BWD = 3, DLE_ACT_ADD = 4 };
 
 /* ---- library plumbing ---------------------------------------------------------------------- */
 const char* dle_last_error(void);
@@ -91,6 +91,23 @@ int dle_gemm(const void* A, const void* B, void* C, void* aux, const float* bias
              const void* mask_src, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
              int a_kc, int b_kc, int in_dtype, int out_dtype, int act, int splitk, int accumulate,
              float alpha, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+/* ---- convolutions as implicit GEMM (csrc/gemm_dma.hip) ------------------------------------------------
+ * replace cuDNN conv forward / backward-data / backward-filter behind nn.Conv2d(bias=False)
+ *   Classification/ConvNets/image_classification/models/common.py:31-60, models/resnet.py:126-175
+ * Layouts: activations NHWC, weights KRSC (= torch channels_last memory of an OIHW tensor), 16-bit in,
+ * fp32 accumulate.  C and Ko multiples of 8; each tensor < 4 GiB.  P = (H+2*pad-R)/stride+1.
+ *   fwd:   y[N,P,Q,Ko]  = conv(x[N,H,W,C], w[Ko,R,S,C]) (+bias, DLE_ACT_RELU optional)
+ *   dgrad: dx[N,H,W,C]  = conv_transpose(dy[N,P,Q,Ko], w) (+ addend[N,H,W,C] if non-NULL: skip-branch sum)
+ *   wgrad: dw[Ko,R,S,C] (fp32) (+)= dy^T * im2col(x); split-K slabs through the workspace                */
+int dle_conv2d_fwd(const void* x, const void* w, void* y, const float* bias, int N, int H, int W, int C,
+                   int Ko, int R, int S, int stride, int pad, int dtype, int out_dtype, int act,
+                   hipStream_t stream);
+int dle_conv2d_dgrad(const void* dy, const void* w, void* dx, const void* addend, int N, int H, int W, int C,
+                     int Ko, int R, int S, int stride, int pad, int dtype, hipStream_t stream);
+int dle_conv2d_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, int C, int Ko, int R, int S,
+                     int stride, int pad, int dtype, int splitk, int accumulate, void* workspace,
+                     int64_t workspace_bytes, hipStream_t stream);
+
 /* out[n] (+)= sum_m x[m][n]  (bias gradients).  workspace (optional, fp32, >= 2048*N*4 bytes is always
  * enough): row groups are combined through it instead of through same-address atomics. */
 int dle_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, int accumulate,
@@ -149,6 +166,46 @@ int dle_check_nonfinite(const void* x, float* found_inf, int64_t n, int dtype, h
 /* out[r,c] = y[r,c] > 0 ? g[r,c] : 0 on 16-bit strided views (nn.ReLU backward, dlrm/nn/mlps.py:85-87) */
 int dle_relu_bwd(const void* g, const void* y, void* out, int64_t rows, int cols, int64_t ld_g, int64_t ld_y,
                  int64_t ld_out, int dtype, hipStream_t stream);
+
+/* ---- ResNet-50 HBM-bound kernels (csrc/convnet.hip), NHWC 16-bit activations, fp32 statistics ----------------
+ * replace nn.BatchNorm2d(train) + nn.ReLU + residual add, nn.MaxPool2d(3,2,1), nn.AdaptiveAvgPool2d(1)
+ *   Classification/ConvNets/image_classification/models/resnet.py:148-175,270,299, models/common.py:107-128
+ * and LabelSmoothing / CrossEntropyLoss (smoothing.py:18-40, main.py:453-457; ignore_index as used by
+ * LanguageModeling/BERT/run_pretraining.py:75-95).  M = N*H*W rows of C channels (C % 8 == 0).
+ * BN workspace: fp32 scratch of dle_bn_workspace_bytes(M, C).                                              */
+int dle_nchw_to_nhwc(const float* x, void* y, int64_t N, int C, int64_t HW, int C_padded, int out_dtype,
+                     hipStream_t stream);
+int64_t dle_bn_workspace_bytes(int64_t M, int C);
+/* mean/rstd (biased var, eps) of x over M; running stats updated with `momentum` (unbiased var) when non-NULL */
+int dle_bn_fwd_stats(const void* x, int64_t M, int C, float eps, float momentum, float* mean, float* rstd,
+                     float* running_mean, float* running_var, void* workspace, int64_t workspace_bytes,
+                     int dtype, hipStream_t stream);
+/* y = act((x - mean) * rstd * gamma + beta (+ residual)), act = ReLU when relu != 0 */
+int dle_bn_fwd_apply(const void* x, const void* residual, void* y, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, int64_t M, int C, int relu, int dtype,
+                     hipStream_t stream);
+/* g = dy * (y > 0) (y == NULL: g = dy);  dgamma = sum g*xhat, dbeta = sum g */
+int dle_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
+                      float* dgamma, float* dbeta, int64_t M, int C, int accumulate, void* workspace,
+                      int64_t workspace_bytes, int dtype, hipStream_t stream);
+/* dx = gamma*rstd*(g - dbeta/M - xhat*dgamma/M); g_out (optional) = g, the skip-branch gradient */
+int dle_bn_bwd_apply(const void* dy, const void* y, const void* x, void* dx, void* g_out, const float* mean,
+                     const float* rstd, const float* gamma, const float* dgamma, const float* dbeta, int64_t M,
+                     int C, int dtype, hipStream_t stream);
+/* argmax: uint8 [N,P,Q,C] window-scan index of the first maximum (ATen tie rule) */
+int dle_maxpool_fwd(const void* x, void* y, void* argmax, int N, int H, int W, int C, int ksize, int stride,
+                    int pad, int dtype, hipStream_t stream);
+int dle_maxpool_bwd(const void* dy, const void* argmax, void* dx, int N, int H, int W, int C, int ksize,
+                    int stride, int pad, int dtype, hipStream_t stream);
+int dle_avgpool_fwd(const void* x, void* y, int64_t N, int HW, int C, int dtype, hipStream_t stream);
+int dle_avgpool_bwd(const void* dy, void* dx, int64_t N, int HW, int C, int dtype, hipStream_t stream);
+/* loss_out[0] = mean over rows with target != ignore_index of (1-s)*nll + s*(lse - mean logits);
+ * dlogits (optional, dlogits_dtype, row stride ld_out) = d loss / d logits * (*grad_scale_dev).
+ * scratch: one int32 device word.                                                                           */
+int dle_softmax_xent(const float* logits, const int64_t* target, float* loss_out, void* dlogits,
+                     const float* grad_scale_dev, int* scratch, int64_t rows, int classes, int64_t ld,
+                     int64_t ld_out, float smoothing, int64_t ignore_index, int dlogits_dtype,
+                     hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,100 @@
+"""ResNet HBM-bound kernels (BN fwd/bwd + ReLU + residual, max/avg pooling, label-smoothing CE, layout
+conversion) vs the same torch ops on the CPU in float64/float32.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DT = [torch.bfloat16, torch.float16]
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(4, 64, 9, 7), (2, 256, 5, 5), (3, 8, 6, 6), (2, 2048, 2, 2)])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
+def test_batchnorm_fwd_bwd(cuda, dtype, shape, relu, res):
+    from deeplearningexamples_amd import functional as F
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c + h)
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.3).to(dtype)
+    r = torch.randn(shape, generator=g).to(dtype) if res else None
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2
+    dy = torch.randn(shape, generator=g).to(dtype)
+    xr = x.double().requires_grad_()
+    gr, br = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    rr = r.double().requires_grad_() if res else None
+    rm, rv = torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64)
+    yr = torch.nn.functional.batch_norm(xr, rm, rv, gr, br, training=True, momentum=0.1, eps=1e-5)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(dy.double())
+    run_m, run_v = torch.zeros(c, device=cuda), torch.ones(c, device=cuda)
+    y, mean, rstd = F.bn_fwd(_nhwc(x).to(cuda), gamma.to(cuda), beta.to(cuda), run_m, run_v,
+                             residual=_nhwc(r).to(cuda) if res else None, relu=relu)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    ref_y = _nhwc(yr.detach())
+    assert (y.double().cpu() - ref_y).abs().max() <= 3 * eps * max(1.0, float(ref_y.abs().max()))
+    np.testing.assert_allclose(run_m.cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(run_v.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-5)
+    dgamma, dbeta = torch.empty(c, device=cuda), torch.empty(c, device=cuda)
+    dx, gskip = F.bn_bwd(_nhwc(dy).to(cuda), y if relu else None, _nhwc(x).to(cuda), mean, rstd, gamma.to(cuda),
+                         dgamma, dbeta, want_skip_grad=res)
+    m = n * h * w
+    tol = 6 * eps * np.sqrt(m)
+    assert (dgamma.double().cpu() - gr.grad).abs().max() <= tol * max(1.0, float(gr.grad.abs().max()))
+    assert (dbeta.double().cpu() - br.grad).abs().max() <= tol * max(1.0, float(br.grad.abs().max()))
+    ref_dx = _nhwc(xr.grad)
+    assert (dx.double().cpu() - ref_dx).abs().max() <= 6 * eps * max(1.0, float(ref_dx.abs().max()))
+    if res:
+        assert (gskip.double().cpu() - _nhwc(rr.grad)).abs().max() <= 2 * eps * float(rr.grad.abs().max())
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_pools_and_layout(cuda, dtype):
+    from deeplearningexamples_amd import functional as F
+    g = torch.Generator().manual_seed(4)
+    x = torch.relu(torch.randn(3, 16, 13, 11, generator=g)).to(dtype)          # many exact ties at 0 after ReLU
+    xr = x.float().requires_grad_()
+    yr = torch.nn.functional.max_pool2d(xr, 3, 2, 1)
+    dy = torch.randn(yr.shape, generator=g).to(dtype)
+    yr.backward(dy.float())
+    y, am = F.maxpool_fwd(_nhwc(x).to(cuda))
+    assert torch.equal(y.cpu(), _nhwc(yr.detach()).to(dtype))
+    dx = F.maxpool_bwd(_nhwc(dy).to(cuda), am, (13, 11))
+    np.testing.assert_allclose(dx.float().cpu().numpy(), _nhwc(xr.grad).to(dtype).float().numpy(), rtol=1e-2, atol=1e-2)
+    a = torch.randn(5, 64, 7, 7, generator=g).to(dtype)
+    p = F.avgpool_fwd(_nhwc(a).to(cuda))
+    np.testing.assert_allclose(p.float().cpu().numpy(), a.float().mean((2, 3)).to(dtype).float().numpy(), rtol=1e-2, atol=1e-2)
+    gp = torch.randn(5, 64, generator=g).to(dtype)
+    ga = F.avgpool_bwd(gp.to(cuda), (7, 7))
+    np.testing.assert_allclose(ga.float().cpu().numpy(), (gp.float() / 49)[:, None, None, :].expand(5, 7, 7, 64).to(dtype).float().numpy(),
+                               rtol=1e-2, atol=1e-4)
+    img = torch.randn(2, 3, 10, 12, generator=g)
+    z = F.nchw_to_nhwc(img.to(cuda), dtype, 8).cpu()
+    assert torch.equal(z[..., :3], _nhwc(img).to(dtype)) and (z[..., 3:] == 0).all()
+
+
+@pytest.mark.parametrize("smoothing,ignore", [(0.1, -100), (0.0, -1)])
+def test_softmax_xent(cuda, smoothing, ignore):
+    from deeplearningexamples_amd import functional as F
+    g = torch.Generator().manual_seed(8)
+    rows, classes = 37, 1000
+    x = torch.randn(rows, classes, generator=g) * 3
+    t = torch.randint(0, classes, (rows,), generator=g)
+    if ignore == -1:
+        t[::3] = -1
+    xr = x.double().requires_grad_()
+    lp = torch.log_softmax(xr, -1)
+    valid = t != ignore
+    nll = -lp[valid].gather(1, t[valid, None]).squeeze(1)
+    loss_r = ((1 - smoothing) * nll + smoothing * (-lp[valid].mean(-1))).mean()
+    loss_r.backward()
+    loss, dl = F.softmax_xent(x.to(cuda), t.to(cuda), smoothing, ignore, grad_scale=torch.tensor([4.0], device=cuda),
+                              grad_dtype=torch.float32)
+    assert abs(loss.item() - loss_r.item()) < 1e-5 * max(1, abs(loss_r.item()))
+    np.testing.assert_allclose(dl.cpu().numpy(), (xr.grad * 4).float().numpy(), rtol=1e-4, atol=1e-7)
