@@ -1,0 +1,259 @@
+"""ResNet-50 train step on MI355X: forward, label-smoothing loss, backward, SGD with momentum.
+
+Mirrors the reference's step (Classification/ConvNets/image_classification/):
+    training.py:86-96     Executor._fwd_bwd_fn: autocast forward, loss / divide_loss, scaler.scale(loss).backward()
+    training.py:167-186   Trainer.train_step: scaler.step(optimizer); scaler.update(); zero_grad; synchronize
+    optimizers.py:34-56   SGD(momentum, nesterov, weight_decay), no weight decay for names containing "bn"
+    optimizers.py:82-130  step / linear / cosine LR policies with linear warm-up (per epoch)
+    utils.py:117-123      loss all-reduce across ranks (here: only when asked, never inside the step)
+Data parallelism: one process per GPU, the fp32 gradient bucket(s) are all-reduced (mean) with
+torch.distributed (backend nccl = RCCL over xGMI) on a side stream, bucket by bucket while the backward of the
+earlier layers is still running (the reference uses torch DDP's reducer, training.py:78-84).
+The step is a fixed kernel sequence (HIP-graph capturable): activations NHWC 16-bit, statistics and master
+weights fp32, gradients fp32 in ONE flat buffer whose element order matches the parameters' memory order.
+"""
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import functional as F
+from .. import multi_tensor as mt
+from ..dlrm.engine import GradScalerState
+from .resnet import ResNet50
+
+
+def lr_cosine_policy(base_lr, warmup_length, epochs, end_lr=0.0):
+    def fn(iteration, epoch):
+        if epoch < warmup_length:
+            return base_lr * (epoch + 1) / warmup_length
+        e, es = epoch - warmup_length, epochs - warmup_length
+        return end_lr + 0.5 * (1 + np.cos(np.pi * e / es)) * (base_lr - end_lr)
+    return fn
+
+
+def lr_step_policy(base_lr, steps, decay_factor, warmup_length):
+    def fn(iteration, epoch):
+        if epoch < warmup_length:
+            return base_lr * (epoch + 1) / warmup_length
+        lr = base_lr
+        for s in steps:
+            if epoch >= s:
+                lr *= decay_factor
+        return lr
+    return fn
+
+
+def lr_linear_policy(base_lr, warmup_length, epochs):
+    def fn(iteration, epoch):
+        if epoch < warmup_length:
+            return base_lr * (epoch + 1) / warmup_length
+        return base_lr * (1 - (epoch - warmup_length) / (epochs - warmup_length))
+    return fn
+
+
+class ResNetTrainer:
+    def __init__(self, model: ResNet50, lr: float, momentum=0.875, weight_decay=3.0517578125e-05, nesterov=False,
+                 label_smoothing=0.1, compute_dtype=torch.bfloat16, bn_weight_decay=False, static_loss_scale=1.0,
+                 world_size=1, process_group=None, bucket_mb=25):
+        self.model = model
+        self.dev = model.fc.weight.device
+        self.dtype = compute_dtype
+        self.momentum, self.wd, self.nesterov, self.smoothing = momentum, weight_decay, nesterov, label_smoothing
+        self.world, self.pg = world_size, process_group
+        self.stem, self.blocks = model.units()
+        self.scaler = GradScalerState(self.dev, enabled=compute_dtype == torch.float16, init_scale=static_loss_scale,
+                                      growth_interval=int(1e9))   # static scale, as configs.yml AMP (128)
+        self.lr = torch.full((1,), lr, dtype=torch.float32, device=self.dev)
+        self.first_step = True
+        self.steps_done = 0
+        # ---- parameters in backward-completion order (fc first ... stem last) for bucketed all-reduce
+        named = dict(model.named_parameters())
+        order = ["fc.weight", "fc.bias"]
+        for (u1, u2, u3, ud) in reversed(self.blocks):
+            for u in ([u3, ud] if ud is not None else [u3]) + [u2, u1]:
+                order += [u.name_conv + ".weight", u.name_bn + ".weight", u.name_bn + ".bias"]
+        order += ["conv1.weight", "bn1.weight", "bn1.bias"]
+        assert sorted(order) == sorted(named), "parameter bookkeeping out of sync with the module tree"
+        self.names = order
+        self.params = [named[n] for n in order]
+        total = sum(p.numel() for p in self.params)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.dev)
+        self.flat_mom = torch.zeros(total, dtype=torch.float32, device=self.dev)
+        self.gview, self.mview, self.offset = {}, {}, {}
+        o = 0
+        for n, p in zip(order, self.params):
+            self.offset[n] = o
+            self.gview[n] = self.flat_grad[o:o + p.numel()]
+            self.mview[n] = self.flat_mom[o:o + p.numel()]
+            o += p.numel()
+        # buckets of ~bucket_mb MB of fp32 gradients, cut at parameter boundaries
+        self.buckets, start, lim = [], 0, bucket_mb * (1 << 20) // 4
+        for n, p in zip(order, self.params):
+            end = self.offset[n] + p.numel()
+            if end - start >= lim:
+                self.buckets.append((start, end, n))
+                start = end
+        if start < total:
+            self.buckets.append((start, total, order[-1]))
+        self._bucket_after = {b[2]: i for i, b in enumerate(self.buckets)}
+        self.comm_stream = torch.cuda.Stream(device=self.dev) if world_size > 1 else None
+        # ---- 16-bit working copies (KRSC order == the channels_last master's memory order)
+        self.w16 = {}
+        units = [self.stem] + [u for blk in self.blocks for u in blk if u is not None]
+        self.units = units
+        for u in units:
+            w = named[u.name_conv + ".weight"]
+            ko, ci, r, s = w.shape
+            cp = (ci + 7) // 8 * 8
+            u.w16 = torch.zeros((ko, r, s, cp), dtype=compute_dtype, device=self.dev)
+            self.w16[u.name_conv + ".weight"] = u.w16
+            u.ggamma = self.gview[u.name_bn + ".weight"]
+            u.gbeta = self.gview[u.name_bn + ".bias"]
+            if cp == ci:
+                u.gw = self.gview[u.name_conv + ".weight"].view(ko, r, s, ci)
+            else:                                   # stem: gradient of the channel-padded weight, cropped later
+                u.gw = torch.zeros((ko, r, s, cp), dtype=torch.float32, device=self.dev)
+        self.fc_w16 = torch.empty(model.fc.weight.shape, dtype=compute_dtype, device=self.dev)
+        self.w16["fc.weight"] = self.fc_w16
+        self.refresh_working_copies()
+        self._build_tables()
+
+    # ------------------------------------------------------------------ parameter plumbing
+    @staticmethod
+    def _phys(p):
+        """Flat view of a parameter in MEMORY order (channels_last conv weights -> KRSC)."""
+        if p.dim() == 4:
+            return p.data.permute(0, 2, 3, 1).reshape(-1)
+        return p.data.reshape(-1)
+
+    def refresh_working_copies(self):
+        for u in self.units:
+            w = dict(self.model.named_parameters())[u.name_conv + ".weight"]
+            ko, ci, r, s = w.shape
+            F.cast_rows(self._phys(w).view(ko * r * s, ci), self.dtype, cols_out=u.w16.shape[-1],
+                        out=u.w16.view(ko * r * s, -1))
+        F.cast(self.model.fc.weight.data, self.dtype, out=self.fc_w16)
+
+    def _build_tables(self):
+        named = dict(zip(self.names, self.params))
+        decay_copy, decay_plain, nodecay = ([], [], [], []), ([], [], []), ([], [], [])
+        for n, p in named.items():
+            g, m, ph = self.gview[n], self.mview[n], self._phys(p)
+            assert ph.data_ptr() == p.data_ptr(), "parameter %s is not dense in memory order" % n
+            if "bn" in n:                                              # optimizers.py:42-43 (name based)
+                for lst, t in zip(nodecay, (g, ph, m)):
+                    lst.append(t)
+            elif n in self.w16 and self.w16[n].numel() == p.numel():
+                for lst, t in zip(decay_copy, (g, ph, m, self.w16[n].view(-1))):
+                    lst.append(t)
+            else:
+                for lst, t in zip(decay_plain, (g, ph, m)):
+                    lst.append(t)
+        self.t_decay_copy = mt.TensorTable(list(decay_copy))
+        self.t_decay_plain = mt.TensorTable(list(decay_plain))
+        self.t_nodecay = mt.TensorTable(list(nodecay))
+
+    def set_lr(self, lr: float):
+        self.lr.fill_(lr)
+
+    # ------------------------------------------------------------------ communication
+    def _maybe_reduce(self, finished_param_name):
+        """Launch the all-reduce of a gradient bucket once its last gradient has been produced."""
+        if self.world == 1:
+            return
+        i = self._bucket_after.get(finished_param_name)
+        if i is None:
+            return
+        s, e, _ = self.buckets[i]
+        self.comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm_stream):
+            dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.AVG, group=self.pg)
+
+    # ------------------------------------------------------------------ the step
+    def forward(self, images):
+        """images fp32 NCHW (as produced by the reference's loaders) -> fp32 logits [N, classes]."""
+        x = F.nchw_to_nhwc(images, self.dtype, 8)
+        a0 = self.stem.forward(x)
+        m0, self._amax = F.maxpool_fwd(a0)
+        self._pool_in_hw = a0.shape[1:3]
+        h = m0
+        for (u1, u2, u3, ud) in self.blocks:
+            res = ud.forward(h) if ud is not None else h
+            o = u2.forward(u1.forward(h))
+            h = u3.forward(o, residual=res)
+        self._feat_hw = h.shape[1:3]
+        self._pooled = F.avgpool_fwd(h)
+        n = self._pooled.shape[0]
+        logits = F.gemm(self._pooled, self.fc_w16, n, self.fc_w16.shape[0], self.fc_w16.shape[1], True, True,
+                        out_dtype=torch.float32, bias=self.model.fc.bias.data)
+        return logits
+
+    def backward(self, dlogits):
+        n = dlogits.shape[0]
+        fcw = self.fc_w16
+        F.gemm(dlogits, self._pooled, fcw.shape[0], fcw.shape[1], n, False, False,
+               out=self.gview["fc.weight"].view(fcw.shape), splitk=F.pick_splitk(fcw.shape[0], fcw.shape[1], n))
+        F.colsum(dlogits, out=self.gview["fc.bias"])
+        self._maybe_reduce("fc.weight"); self._maybe_reduce("fc.bias")
+        gp = F.gemm(dlogits, fcw, n, fcw.shape[1], fcw.shape[0], True, False)
+        g = F.avgpool_bwd(gp, self._feat_hw)
+        for (u1, u2, u3, ud) in reversed(self.blocks):
+            g3, gskip = u3.backward(g, want_skip_grad=True)
+            self._done(u3)
+            if ud is not None:
+                gskip, _ = ud.backward(gskip)
+                self._done(ud)
+            g2, _ = u2.backward(g3)
+            self._done(u2)
+            g, _ = u1.backward(g2, dx_addend=gskip)
+            self._done(u1)
+        g = F.maxpool_bwd(g, self._amax, self._pool_in_hw)
+        self.stem.backward(g, need_dx=False)
+        gw = self.stem.gw
+        ko, r, s, cp = gw.shape
+        F.copy_rows(gw.view(ko * r * s, cp)[:, :3], self.gview["conv1.weight"].view(ko * r * s, 3))
+        self._done(self.stem)
+
+    def _done(self, u):
+        for suffix, nm in ((".weight", u.name_conv), (".weight", u.name_bn), (".bias", u.name_bn)):
+            self._maybe_reduce(nm + suffix)
+
+    def optimizer_step(self):
+        sc = self.scaler
+        skip = sc.found_inf if sc.enabled else None
+        inv = sc.inv_scale if sc.enabled else None
+        kw = dict(momentum=self.momentum, nesterov=self.nesterov, first_step=self.first_step, skip_flag=skip,
+                  inv_scale=inv, has_momentum=self.momentum != 0)
+        mt.sgd(self.t_decay_copy, self.lr, weight_decay=self.wd, model_copy=True, **kw)
+        mt.sgd(self.t_decay_plain, self.lr, weight_decay=self.wd, **kw)
+        mt.sgd(self.t_nodecay, self.lr, weight_decay=0.0, **kw)
+        # channel-padded stem weight: refresh its working copy from the master
+        u = self.stem
+        w = self.model.conv1.weight
+        ko, ci, r, s = w.shape
+        F.cast_rows(self._phys(w).view(ko * r * s, ci), self.dtype, cols_out=u.w16.shape[-1], out=u.w16.view(ko * r * s, -1))
+        self.first_step = False
+
+    def train_step(self, images, target):
+        """One optimisation step.  Returns the device-resident fp32 loss [1] (no host sync)."""
+        sc = self.scaler
+        logits = self.forward(images)
+        loss, dlogits = F.softmax_xent(logits, target, smoothing=self.smoothing,
+                                       grad_scale=sc.scale if sc.enabled else None, grad_dtype=self.dtype)
+        self.backward(dlogits)
+        if self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if sc.enabled:
+            F.check_nonfinite_(self.flat_grad, sc.found_inf)
+        self.optimizer_step()
+        sc.update()
+        self.steps_done += 1          # BatchNorm.num_batches_tracked is materialised by sync_counters()
+        return loss
+
+    def sync_counters(self):
+        """Write the step count into every BatchNorm's num_batches_tracked (before saving a checkpoint)."""
+        for u in self.units:
+            u.bn.num_batches_tracked.fill_(self.steps_done)

@@ -1,0 +1,135 @@
+"""ResNet-50 v1.5 on the MI355X kernels: parameter container with the reference's module tree / state_dict
+names + explicit forward/backward over NHWC 16-bit activations.
+
+Mirrors (Classification/ConvNets/image_classification/):
+    models/resnet.py:107-175   Bottleneck (1x1 -> 3x3(stride) -> 1x1, BN after each, ReLU, `out += residual`)
+    models/resnet.py:211-322   ResNet: stem 7x7/2 + BN + ReLU + MaxPool(3,2,1), layers [3,4,6,3], avgpool, fc
+    models/common.py:31-128    LayerBuilder: Conv2d(bias=False, padding=k//2, kaiming_normal fan_in), BN gamma 1 / 0
+The nn.Conv2d / nn.BatchNorm2d / nn.Linear submodules exist only to own the parameters and buffers under the
+reference's names (checkpoint compatible); conv weights are kept in channels_last memory so that the fp32
+master, its gradient and the 16-bit working copy all share the KRSC element order the kernels read.
+"""
+from typing import List
+
+import torch
+from torch import nn
+
+from .. import _cabi as C
+from .. import functional as F
+
+LAYERS, WIDTHS, EXPANSION = [3, 4, 6, 3], [64, 128, 256, 512], 4
+
+
+def _conv(cin, cout, k, stride, device):
+    m = nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=(k - 1) // 2, bias=False, device=device)
+    nn.init.kaiming_normal_(m.weight, mode="fan_in", nonlinearity="relu")
+    m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    return m
+
+
+def _bn(c, device, zero_init=False):
+    m = nn.BatchNorm2d(c, device=device)
+    nn.init.constant_(m.weight, 0 if zero_init else 1)
+    nn.init.constant_(m.bias, 0)
+    return m
+
+
+class ConvBN:
+    """One conv + BN (+ ReLU) (+ residual) unit of the step: forward keeps what backward needs."""
+
+    def __init__(self, conv: nn.Conv2d, bn: nn.BatchNorm2d, name_conv: str, name_bn: str, relu: bool):
+        self.conv, self.bn, self.name_conv, self.name_bn, self.relu = conv, bn, name_conv, name_bn, relu
+        self.k = conv.kernel_size[0]
+        self.stride, self.pad = conv.stride[0], conv.padding[0]
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+        self.w16 = None                 # [Ko, R, S, Cp] 16-bit working copy (Cp = cin padded to 8)
+        self.gw = self.ggamma = self.gbeta = None   # fp32 gradient views (set by the trainer)
+        self.saved = None
+
+    def forward(self, x, residual=None):
+        n, h, w, c = x.shape
+        if self.k == 1 and self.stride == 1:
+            t = F.gemm(x.view(-1, c), self.w16.view(self.cout, c), n * h * w, self.cout, c, True, True)
+            t = t.view(n, h, w, self.cout)
+        else:
+            t = F.conv2d_fwd(x, self.w16, self.stride, self.pad)
+        y, mean, rstd = F.bn_fwd(t, self.bn.weight.data, self.bn.bias.data, self.bn.running_mean, self.bn.running_var,
+                                 eps=self.bn.eps, momentum=self.bn.momentum, residual=residual, relu=self.relu)
+        self.saved = (x, t, y, mean, rstd)
+        return y
+
+    def backward(self, dy, need_dx=True, dx_addend=None, want_skip_grad=False):
+        """dy: gradient w.r.t. the unit's output.  Returns (dx or None, skip-branch gradient or None)."""
+        x, t, y, mean, rstd = self.saved
+        self.saved = None
+        gt, gskip = F.bn_bwd(dy, y if self.relu else None, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta,
+                             want_skip_grad=want_skip_grad)
+        n, h, w, c = x.shape
+        if self.k == 1 and self.stride == 1:
+            m = n * h * w
+            g2, x2 = gt.view(m, self.cout), x.view(m, c)
+            F.gemm(g2, x2, self.cout, c, m, False, False, out=self.gw.view(self.cout, c),
+                   splitk=F.pick_splitk(self.cout, c, m, target_blocks=1024))
+            dx = None
+            if need_dx:
+                dx = F.gemm(g2, self.w16.view(self.cout, c), m, c, self.cout, True, False,
+                            act=C.ACT_ADD if dx_addend is not None else C.ACT_NONE,
+                            mask_src=dx_addend.view(m, c) if dx_addend is not None else None).view(n, h, w, c)
+        else:
+            F.conv2d_wgrad(gt, x, (self.k, self.k), self.stride, self.pad, out=self.gw)
+            dx = F.conv2d_dgrad(gt, self.w16, (h, w), self.stride, self.pad, addend=dx_addend) if need_dx else None
+        return dx, gskip
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, inplanes, planes, stride, downsample, device, last_bn_0_init=False):
+        super().__init__()
+        self.conv1 = _conv(inplanes, planes, 1, 1, device)
+        self.bn1 = _bn(planes, device)
+        self.conv2 = _conv(planes, planes, 3, stride, device)
+        self.bn2 = _bn(planes, device)
+        self.conv3 = _conv(planes, planes * EXPANSION, 1, 1, device)
+        self.bn3 = _bn(planes * EXPANSION, device, zero_init=last_bn_0_init)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class ResNet50(nn.Module):
+    def __init__(self, num_classes=1000, last_bn_0_init=False, device="cuda"):
+        super().__init__()
+        self.conv1 = _conv(3, 64, 7, 2, device)
+        self.bn1 = _bn(64, device)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        inplanes = 64
+        layers = []
+        for i, (w, n) in enumerate(zip(WIDTHS, LAYERS)):
+            blocks = []
+            for b in range(n):
+                stride = (1 if i == 0 else 2) if b == 0 else 1
+                down = None
+                if b == 0:
+                    down = nn.Sequential(_conv(inplanes, w * EXPANSION, 1, stride, device), _bn(w * EXPANSION, device))
+                blocks.append(Bottleneck(inplanes, w, stride, down, device, last_bn_0_init))
+                inplanes = w * EXPANSION
+            layers.append(nn.Sequential(*blocks))
+        self.layers = nn.Sequential(*layers)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(512 * EXPANSION, num_classes, device=device)
+
+    def units(self) -> List:
+        """(stem, [(conv1, conv2, conv3, downsample or None) per block]) as ConvBN units with parameter names."""
+        stem = ConvBN(self.conv1, self.bn1, "conv1", "bn1", relu=True)
+        blocks = []
+        for li, layer in enumerate(self.layers):
+            for bi, blk in enumerate(layer):
+                pre = "layers.%d.%d." % (li, bi)
+                u1 = ConvBN(blk.conv1, blk.bn1, pre + "conv1", pre + "bn1", True)
+                u2 = ConvBN(blk.conv2, blk.bn2, pre + "conv2", pre + "bn2", True)
+                u3 = ConvBN(blk.conv3, blk.bn3, pre + "conv3", pre + "bn3", True)     # ReLU after the residual add
+                ud = None
+                if blk.downsample is not None:
+                    ud = ConvBN(blk.downsample[0], blk.downsample[1], pre + "downsample.0", pre + "downsample.1", False)
+                blocks.append((u1, u2, u3, ud))
+        return stem, blocks

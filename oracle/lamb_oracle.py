@@ -19,7 +19,7 @@ def l2norm(tensors):
 
 def lamb_step(g_list, p_list, m_list, v_list, lr, beta1, beta2, eps, step, bias_correction, weight_decay,
               grad_averaging, mode, global_grad_norm, max_grad_norm, use_nvlamb=False, inv_scale=1.0,
-              grad_dtype=np.float32, model_copy_dtype=None):
+              grad_dtype=np.float32, model_copy_dtype=None, round_update=None):
     """csrc/multi_tensor_lamb.cu:371-500 host sequence for one param group:
        per-tensor ||p|| -> stage1 (:43-245) -> per-tensor ||update|| -> stage2 (:251-368).
     Returns (updates_in_grad_buffer, new_p, new_m, new_v, model_copies)."""
@@ -44,7 +44,9 @@ def lamb_step(g_list, p_list, m_list, v_list, lr, beta1, beta2, eps, step, bias_
             m2 = m * beta1 + beta3 * sg
             v2 = v * beta2 + (f32(1) - beta2) * sg * sg
             u = (m2 / b1c) / (np.sqrt(v2 / b2c) + eps) + decay * pp
-        upd.append(u.astype(grad_dtype))                                        # :163 update stored in g's dtype
+        # :163 the update is stored back INTO the gradient buffer, i.e. rounded to the gradient's dtype, and
+        # stage 2 / the update norm read that rounded value (round_update emulates dtypes numpy lacks, bf16)
+        upd.append(round_update(u) if round_update is not None else u.astype(grad_dtype))
         new_m.append(m2.astype(f32))
         new_v.append(v2.astype(f32))
     _, u_norms = l2norm([u.astype(f32) for u in upd])                           # :457

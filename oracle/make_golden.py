@@ -150,8 +150,47 @@ def gen_dlrm_step():
         print("dlrm_step", name, "losses", arrs["losses"])
 
 
+def gen_rn50():
+    """Per-step losses of the REFERENCE's resnet50 + LabelSmoothing + get_sgd_optimizer on CPU (fp32)."""
+    from oracle import resnet_oracle as RO
+    ref = R.import_convnets()
+    c = RO.RN50_STEP_CONFIG
+    model = ref.models.resnet50(pretrained=False)
+    state0 = RO.seeded_state(c["seed"])
+    sd = model.state_dict()
+    assert [n for n, _ in model.named_parameters()] == [n for n, _ in RO.param_shapes()], "parameter names/order differ"
+    for k, v in state0.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    model.load_state_dict({k: v.clone() for k, v in state0.items()}, strict=False)
+    model.train()
+    x, y = RO.seeded_batch(c["seed"] + 100, c["batch"], c["size"])
+    loss_fn = ref.smoothing.LabelSmoothing(0.1)
+    opt = ref.optimizers.get_sgd_optimizer(list(model.named_parameters()), c["lr"], momentum=0.875,
+                                           weight_decay=3.0517578125e-05)
+    losses = []
+    for _ in range(c["steps"]):
+        opt.zero_grad()
+        loss = loss_fn(model(x), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    orc = RO.ResNet50Oracle(state0, c["lr"])
+    ol = [orc.step(x, y) for _ in range(c["steps"])]
+    assert np.allclose(ol[:2], losses[:2], rtol=1e-4), (ol, losses)
+    orc2 = RO.ResNet50Oracle(state0, c["lr"])
+    lp = [orc2.step(x * (1 + 1e-6), y) for _ in range(c["steps"])]
+    sens = [abs(u - v) / abs(u) for u, v in zip(ol, lp)]
+    fin = {k: v.detach().numpy() for k, v in model.state_dict().items()}
+    np.savez_compressed(os.path.join(GOLD, "rn50_step.npz"), losses=np.asarray(losses, np.float64),
+                        oracle_losses=np.asarray(ol, np.float64), sensitivity=np.asarray(sens, np.float64),
+                        final_fc_bias=fin["fc.bias"], final_bn1_weight=fin["bn1.weight"],
+                        final_bn1_running_mean=fin["bn1.running_mean"], final_bn1_running_var=fin["bn1.running_var"],
+                        final_conv1_weight=fin["conv1.weight"])
+    print("rn50 losses", losses, "oracle", ol, "sensitivity to 1e-6 input noise", sens)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dlrm", "dlrm_step", "lamb", "bert", "rn50"]
+    which = sys.argv[1:] or ["dlrm", "dlrm_step", "rn50", "lamb", "bert"]
     os.makedirs(GOLD, exist_ok=True)
     if not R.have_reference():
         sys.exit("reference not mounted; fixtures are generated in the build container only")

@@ -1,0 +1,92 @@
+"""ResNet-50 v1.5 train step on the HIP kernels vs the reference's own module run on CPU in fp32
+(tests/golden/rn50_step.npz, oracle/make_golden.py gen_rn50) and vs the CPU oracle run live.  GPU only.
+
+Configuration: batch 32, 64x64 synthetic images, seeded weights with damped residual branches (bn3 gamma in
+0.1..0.3 -- with gamma ~ 1 a random-init ResNet-50 amplifies 16-bit rounding ~20x and is chaotic from step to
+step, measured in oracle/resnet_oracle.py; the damped network is well conditioned: fixture `sensitivity` ~1e-7).
+Tolerances (relative, per-step loss): fp16 1e-3 (BASELINE north_star), bf16 4e-3 (3 fewer mantissa bits)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import resnet_oracle as RO
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(cuda, dtype, lr, state):
+    from deeplearningexamples_amd.convnets.resnet import ResNet50
+    from deeplearningexamples_amd.convnets.engine import ResNetTrainer
+    model = ResNet50(device=cuda)
+    missing = model.load_state_dict({k: v.clone() for k, v in state.items()}, strict=False)
+    assert not missing.unexpected_keys and all("running" in k or "num_batches" in k for k in missing.missing_keys)
+    tr = ResNetTrainer(model, lr=lr, compute_dtype=dtype, static_loss_scale=128.0)
+    return model, tr
+
+
+@pytest.mark.parametrize("dtype,bar", [(torch.float16, 1e-3), (torch.bfloat16, 4e-3)])
+def test_rn50_losses_match_reference(cuda, golden_dir, dtype, bar):
+    c = RO.RN50_STEP_CONFIG
+    gold = np.load(os.path.join(golden_dir, "rn50_step.npz"))
+    assert gold["sensitivity"].max() < 1e-5            # the configuration itself is not chaotic
+    state = RO.seeded_state(c["seed"])
+    model, tr = _build(cuda, dtype, c["lr"], state)
+    x, y = RO.seeded_batch(c["seed"] + 100, c["batch"], c["size"])
+    x, y = x.to(cuda), y.to(cuda)
+    losses = [float(tr.train_step(x, y).item()) for _ in range(c["steps"])]
+    print(dtype, "losses", losses, "reference", gold["losses"].tolist())
+    np.testing.assert_allclose(losses, gold["losses"], rtol=bar)
+    assert losses[-1] < losses[0]
+    tr.sync_counters()
+    assert int(model.bn1.num_batches_tracked.item()) == c["steps"]
+    np.testing.assert_allclose(model.bn1.running_mean.cpu().numpy(), gold["final_bn1_running_mean"], rtol=2e-2, atol=2e-3)
+    np.testing.assert_allclose(model.bn1.running_var.cpu().numpy(), gold["final_bn1_running_var"], rtol=2e-2, atol=2e-3)
+    # parameters after 4 steps (memory order of conv1 is KRSC)
+    w = model.conv1.weight.detach().cpu().numpy()
+    assert np.abs(w - gold["final_conv1_weight"]).max() <= 2e-2 * np.abs(gold["final_conv1_weight"]).max()
+    np.testing.assert_allclose(model.fc.bias.detach().cpu().numpy(), gold["final_fc_bias"], rtol=5e-2, atol=2e-4)
+
+
+@pytest.mark.parametrize("dtype,lbar", [(torch.float16, 1e-3), (torch.bfloat16, 4e-3)])
+def test_rn50_first_step_gradients_vs_oracle(cuda, dtype, lbar):
+    """Logits, loss and EVERY parameter gradient of the first step vs torch autograd on the CPU oracle.
+
+    Gradient bar: at batch 8 the gradient of this network in 16-bit storage differs from the fp32 gradient by
+    5-15 % (fp16) in relative L2 -- measured on the CPU by the SAME oracle with activations / weights / activation
+    gradients rounded where the AMP path stores 16 bits (storage_dtype).  The HIP path must be no worse than
+    that floor: err(hip, fp32) <= 1.3 * err(16-bit-storage oracle, fp32) + 0.01 for every parameter."""
+    from deeplearningexamples_amd import functional as F
+    c = dict(RO.RN50_STEP_CONFIG, batch=8)
+    state = RO.seeded_state(c["seed"])
+    model, tr = _build(cuda, dtype, 0.0, state)
+    x, y = RO.seeded_batch(77, c["batch"], c["size"])
+    orc = RO.ResNet50Oracle(state, lr=0.0)
+    lo = orc.step(x, y)
+    emu = RO.ResNet50Oracle(state, lr=0.0, storage_dtype=dtype)
+    emu.step(x, y)
+    with torch.no_grad():
+        ref_logits = orc.forward(x)
+    logits = tr.forward(x.to(cuda))
+    err = float((logits.cpu() - ref_logits).abs().max() / ref_logits.abs().max())
+    loss, dl = F.softmax_xent(logits, y.to(cuda), smoothing=0.1, grad_dtype=dtype, grad_scale=tr.scaler.scale)
+    print("max logit error / max logit %.3e, loss hip %.6f oracle %.6f" % (err, loss.item(), lo))
+    assert err <= 20 * lbar
+    assert abs(loss.item() - lo) <= lbar * lo
+    scale = float(tr.scaler.scale.item())
+    tr.backward(dl)
+    torch.cuda.synchronize()
+    report, bad = [], []
+    for n, p in model.named_parameters():
+        ph = lambda t: (t.permute(0, 2, 3, 1) if t.dim() == 4 else t).reshape(-1).double()      # memory (KRSC) order
+        g = tr.gview[n].view(-1).cpu().double() / scale
+        r32, r16 = ph(orc.p[n].grad), ph(emu.p[n].grad)
+        e_hip = float((g - r32).norm() / (r32.norm() + 1e-12))
+        e_floor = float((r16 - r32).norm() / (r32.norm() + 1e-12))
+        report.append((n, round(e_hip, 4), round(e_floor, 4)))
+        if e_hip > 1.3 * e_floor + 0.01:
+            bad.append(report[-1])
+    print("(name, hip-vs-fp32, 16-bit-storage-floor) every 9th:", report[::9])
+    assert not bad, bad[:10]
+    assert report[-2][1] < (0.01 if dtype == torch.float16 else 0.04)    # fc.weight: one GEMM away from the loss
