@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--workload", default=os.environ.get("DLE_BENCH_WORKLOAD", "dlrm"),
+    ap.add_argument("--workload", default=os.environ.get("DLE_BENCH_WORKLOAD", "rn50"),
                     choices=["dlrm", "rn50", "bert"])
     ap.add_argument("--batch", type=int, default=None, help="global batch (DLRM) / per-GPU batch (RN50, BERT)")
     ap.add_argument("--dtype", default=None, choices=[None, "fp16", "bf16"])
@@ -143,7 +143,67 @@ class DlrmWorkload:
                           "of batch %d, table rows capped at %d (dense gradient on the capped table)" % (steps, batch, cap)}
 
 
-WORKLOADS = {"dlrm": DlrmWorkload}
+# ------------------------------------------------------------------------------------------- RN50
+class Rn50Workload:
+    """BASELINE.json configs[1]: ResNet-50 v1.5, bf16 AMP, batch 256 per GPU, synthetic ImageNet 224x224
+    (SynteticDataLoader: one fixed randn batch + randint labels, dataloaders.py:520-549), label smoothing 0.1,
+    SGD momentum 0.875, wd 3.0517578125e-05, lr 0.256 per 256 images, cosine schedule with 8 warm-up epochs
+    (configs.yml:66-91,152-157); data parallel over the ranks (gradient all-reduce, mean)."""
+
+    name = "rn50"
+
+    def __init__(self, args, rank, world, device):
+        from deeplearningexamples_amd.convnets.resnet import ResNet50
+        from deeplearningexamples_amd.convnets.engine import ResNetTrainer, lr_cosine_policy
+        self.rank, self.world, self.device = rank, world, device
+        self.batch = args.batch or 256
+        self.dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+        torch.manual_seed(0)                      # same initial weights on every rank (DDP broadcasts rank 0's)
+        self.model = ResNet50(device=device)
+        base_lr = 0.256 * world * self.batch / 256
+        self.trainer = ResNetTrainer(self.model, lr=base_lr, momentum=0.875, weight_decay=3.0517578125e-05,
+                                     label_smoothing=0.1, compute_dtype=self.dtype, static_loss_scale=128.0,
+                                     world_size=world)
+        self.lr_fn = lr_cosine_policy(base_lr, 8, 250)
+        g = torch.Generator(device="cpu").manual_seed(1000 + rank)     # each rank its own batch (main.py:381-384)
+        self.x = torch.randn((self.batch, 3, 224, 224), generator=g).to(device)
+        self.y = torch.randint(0, 1000, (self.batch,), generator=g).to(device)
+        self.samples_per_step = self.batch * world
+        self.scaling = "weak"
+        self.loss = None
+        self.it = 0
+
+    def step(self):
+        self.trainer.set_lr(float(self.lr_fn(self.it, 0)))
+        self.loss = self.trainer.train_step(self.x, self.y)
+        self.it += 1
+
+    def config(self):
+        return {"workload": "ResNet-50 v1.5 (PyTorch/Classification/ConvNets) synthetic ImageNet 224x224, "
+                            "label smoothing 0.1, SGD momentum 0.875 (BASELINE.json configs[1])",
+                "batch_per_gpu": self.batch, "global_batch": self.batch * self.world, "image": [3, 224, 224],
+                "layout": "NHWC", "parallelism": "single GPU" if self.world == 1 else "dp%d" % self.world}
+
+    def dtype_name(self):
+        return "fp16" if self.dtype == torch.float16 else "bf16"
+
+    def cpu_baseline(self):
+        from oracle import resnet_oracle as RO
+        batch, steps = 32, 2
+        orc = RO.ResNet50Oracle(RO.seeded_state(3), lr=0.032)
+        x, y = RO.seeded_batch(4, batch, 224)
+        orc.step(x, y)
+        t0 = time.time()
+        for _ in range(steps):
+            orc.step(x, y)
+        dt = time.time() - t0
+        return {"value": round(batch * steps / dt, 2), "unit": "samples/s", "cores": torch.get_num_threads(),
+                "kind": "port",
+                "sample": "oracle/resnet_oracle.py (fp32 torch-CPU restatement of the reference step, pinned against "
+                          "the reference module), %d steps of batch %d at 224x224 after 1 warm-up step" % (steps, batch)}
+
+
+WORKLOADS = {"dlrm": DlrmWorkload, "rn50": Rn50Workload}
 
 
 def roofline_from(timer_rows, steps):

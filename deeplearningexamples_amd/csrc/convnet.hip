@@ -214,6 +214,8 @@ extern "C" int dle_bn_fwd_stats(const void* x, int64_t M, int C, float eps, floa
 }
 
 // y = act( (x - mean) * rstd * gamma + beta (+ residual) ),  act = ReLU when relu != 0
+// The grid stride (gridDim * 256 lanes) is a multiple of C/8 (a power of two <= 256 ... or any divisor of the
+// stride), so a lane keeps the SAME 8 channels for its whole sweep: scale/shift live in registers.
 template <int DT>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __restrict__ x,
                                                        const unsigned short* __restrict__ res,
@@ -221,17 +223,26 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, long long total8, int C8,
                                                        int relu) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total8;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % C8) * 8;
+  const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const bool invariant = (stride % C8) == 0;
+  float sc[8], sh[8];
+  int c0 = (int)(first % C8) * 8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sc[k] = rstd[c0 + k] * gamma[c0 + k]; sh[k] = beta[c0 + k] - mean[c0 + k] * sc[k]; }
+  for (long long i = first; i < total8; i += stride) {
+    if (!invariant) {
+      c0 = (int)(i % C8) * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { sc[k] = rstd[c0 + k] * gamma[c0 + k]; sh[k] = beta[c0 + k] - mean[c0 + k] * sc[k]; }
+    }
     const ushort8_t xv = ((const ushort8_t*)x)[i];
     ushort8_t rv = {0, 0, 0, 0, 0, 0, 0, 0};
     if (res) rv = ((const ushort8_t*)res)[i];
     ushort8_t o;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float sc = rstd[c0 + k] * gamma[c0 + k];
-      float v = (up16<DT>(xv[k]) - mean[c0 + k]) * sc + beta[c0 + k];
+      float v = up16<DT>(xv[k]) * sc[k] + sh[k];
       if (res) v += up16<DT>(rv[k]);
       if (relu) v = v > 0.f ? v : 0.f;
       o[k] = dn16<DT>(v);
@@ -289,9 +300,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
                                                            const float* __restrict__ gamma, const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, long long total8, int C8,
                                                            float inv_m) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total8;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % C8) * 8;
+  const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const bool invariant = (stride % C8) == 0;
+  // dx = a * g + b * x + c   with  a = gamma*rstd,  b = -a * rstd^2 * dgamma/M ... written per channel:
+  //   xhat = (x - mean) * rstd ;  dx = a * (g - dbeta/M - xhat * dgamma/M)
+  float ka[8], kmu[8], krs[8], kb[8], kg[8];
+  auto load = [&](int c0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      krs[k] = rstd[c0 + k];
+      kmu[k] = mean[c0 + k];
+      ka[k] = gamma[c0 + k] * krs[k];
+      kb[k] = dbeta[c0 + k] * inv_m;
+      kg[k] = dgamma[c0 + k] * inv_m;
+    }
+  };
+  load((int)(first % C8) * 8);
+  for (long long i = first; i < total8; i += stride) {
+    if (!invariant) load((int)(i % C8) * 8);
     const ushort8_t gv = ((const ushort8_t*)dy)[i];
     const ushort8_t xv = ((const ushort8_t*)x)[i];
     ushort8_t yv = {1, 1, 1, 1, 1, 1, 1, 1};
@@ -302,9 +329,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
       float g = up16<DT>(gv[k]);
       if (y && !(up16<DT>(yv[k]) > 0.f)) g = 0.f;
       go[k] = dn16<DT>(g);
-      const float rs = rstd[c0 + k];
-      const float xh = (up16<DT>(xv[k]) - mean[c0 + k]) * rs;
-      o[k] = dn16<DT>(gamma[c0 + k] * rs * (g - dbeta[c0 + k] * inv_m - xh * dgamma[c0 + k] * inv_m));
+      const float xh = (up16<DT>(xv[k]) - kmu[k]) * krs[k];
+      o[k] = dn16<DT>(ka[k] * (g - kb[k] - xh * kg[k]));
     }
     ((ushort8_t*)dx)[i] = o;
     if (g_out) ((ushort8_t*)g_out)[i] = go;

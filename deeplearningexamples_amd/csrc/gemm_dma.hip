@@ -26,6 +26,8 @@
 #define BM 128
 #define BN 128
 #define BK 64
+// operand stages (2 x 32 KiB); the fp32 epilogue staging tile 64 x (128+4) reuses them
+#define GEMM2_LDS_BYTES (2 * (BM * BK + BN * BK) * 2)
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_ADD = 4 };
 
@@ -293,98 +295,117 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(Gemm2Args p) {
     }
   }
 
-  // ---- epilogue: D = (B A^T) tile, so lane owns C[m = fr-th row][n = 8*(r>>2) + 4*fh + (r&3)] ----------
-  const bool vec_c = (p.ldc & 3) == 0;
+  // ---- epilogue.  D = (B A^T) tile: lane owns C[m = fr-th row][n = 8*(r>>2) + 4*fh + (r&3)].
+  // The fp32 tile is transposed through LDS (row stride 132 floats: conflict-free ds_write_b128) so that the
+  // bias / activation / mask / addend math and the global stores run with 8 consecutive columns per lane:
+  // 16-byte loads of mask/addend, 16-byte stores of C, 256-byte contiguous row segments per 16 lanes.
+  // Two passes of 64 rows (the wm = 0 waves, then the wm = 1 waves) keep the staging tile at 33 KiB.
+  constexpr int ES = BN + 4;
+  float* epi = (float*)smem_raw;
+  const bool vec16 = (p.ldc & 7) == 0 && ((((uintptr_t)p.C) | ((uintptr_t)p.aux) | ((uintptr_t)p.mask_src)) & 15) == 0;
+  for (int half = 0; half < 2; ++half) {
+  __syncthreads();                       // operand stages (half 0) / previous half's tile are no longer read
+  if (wm == half) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wm * 64 + i * 32 + fr;
-    if (m >= p.M) continue;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int n = n0 + wn * 64 + j * 32 + qd * 8 + fh * 4;
-        if (n >= p.N) continue;
-        float4_t v = {acc[i][j][qd * 4 + 0], acc[i][j][qd * 4 + 1], acc[i][j][qd * 4 + 2], acc[i][j][qd * 4 + 3]};
-        v = v * p.alpha;
-        const int nval = (p.N - n) < 4 ? (p.N - n) : 4;
-        const long long off = (long long)m * p.ldc + n;
-        if (p.splitk > 1) {
-          if (p.ws) {
-            // plain stores of this K-slice's partial tile; summed by splitk_reduce_kernel (no float atomics:
-            // they run at ~76 G adds/s on this part, 10x slower than the slab round trip)
-            float* c = p.ws + ((long long)blockIdx.y * p.M + m) * p.N + n;
-            if (nval == 4 && (p.N & 3) == 0) *(float4_t*)c = v;
-            else
-              for (int r = 0; r < nval; ++r) c[r] = v[r];
-          } else {
-            float* c = (float*)p.C + off;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (r < nval) unsafeAtomicAdd(c + r, v[r]);
-          }
-          continue;
+        for (int qd = 0; qd < 4; ++qd) {
+          float4_t v = {acc[i][j][qd * 4 + 0], acc[i][j][qd * 4 + 1], acc[i][j][qd * 4 + 2], acc[i][j][qd * 4 + 3]};
+          *(float4_t*)(epi + (i * 32 + fr) * ES + wn * 64 + j * 32 + qd * 8 + fh * 4) = v * p.alpha;
         }
-        if (p.bias) {
+  }
+  __syncthreads();
+#pragma unroll 2
+  for (int it = 0; it < 4; ++it) {
+    const int idx = it * 256 + tid;
+    const int ml = idx >> 4, nl = (idx & 15) << 3;
+    const int m = m0 + half * 64 + ml, n = n0 + nl;
+    if (m >= p.M || n >= p.N) continue;
+    const int nval = (p.N - n) < 8 ? (p.N - n) : 8;
+    float v[8];
+    {
+      const float4_t lo = *(const float4_t*)(epi + ml * ES + nl), hi = *(const float4_t*)(epi + ml * ES + nl + 4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (r < nval) v[r] += p.bias[n + r];
-        }
-        float4_t pre = v;
-        if (p.act == ACT_RELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-        } else if (p.act == ACT_GELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_tanh2(v[r]);
-        } else if (p.act == ACT_RELU_BWD) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (r < nval) {
-              const float y = DT == DLE_F16 ? Elem<DLE_F16>::to_f32(p.mask_src[off + r])
-                                            : Elem<DLE_BF16>::to_f32(p.mask_src[off + r]);
-              v[r] = y > 0.f ? v[r] : 0.f;
-            }
-        } else if (p.act == ACT_ADD) {          // C = acc + addend (residual-branch gradient sum)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (r < nval)
-              v[r] += DT == DLE_F16 ? Elem<DLE_F16>::to_f32(p.mask_src[off + r]) : Elem<DLE_BF16>::to_f32(p.mask_src[off + r]);
-        }
-        if (p.out_dtype == DLE_F32) {
-          float* c = (float*)p.C + off;
-          if (p.accumulate) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (r < nval) v[r] += c[r];
-          }
-          if (nval == 4 && vec_c) *(float4_t*)c = v;
-          else
-            for (int r = 0; r < nval; ++r) c[r] = v[r];
-          if (p.aux) {
-            float* a = (float*)p.aux + off;
-            for (int r = 0; r < nval; ++r) a[r] = pre[r];
-          }
+      for (int r = 0; r < 4; ++r) { v[r] = lo[r]; v[4 + r] = hi[r]; }
+    }
+    const long long off = (long long)m * p.ldc + n;
+    if (p.splitk > 1) {
+      if (p.ws) {
+        float* c = p.ws + ((long long)blockIdx.y * p.M + m) * p.N + n;
+        if (nval == 8 && (p.N & 3) == 0) {
+          *(float4_t*)c = (float4_t){v[0], v[1], v[2], v[3]};
+          *(float4_t*)(c + 4) = (float4_t){v[4], v[5], v[6], v[7]};
         } else {
-          ushort4_t o, po;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (p.out_dtype == DLE_F16) { o[r] = Elem<DLE_F16>::from_f32(v[r]); po[r] = Elem<DLE_F16>::from_f32(pre[r]); }
-            else { o[r] = Elem<DLE_BF16>::from_f32(v[r]); po[r] = Elem<DLE_BF16>::from_f32(pre[r]); }
-          }
-          unsigned short* c = (unsigned short*)p.C + off;
-          if (nval == 4 && vec_c) *(ushort4_t*)c = o;
-          else
-            for (int r = 0; r < nval; ++r) c[r] = o[r];
-          if (p.aux) {
-            unsigned short* a = (unsigned short*)p.aux + off;
-            if (nval == 4 && vec_c) *(ushort4_t*)a = po;
-            else
-              for (int r = 0; r < nval; ++r) a[r] = po[r];
-          }
+          for (int r = 0; r < nval; ++r) c[r] = v[r];
         }
+      } else {
+        float* c = (float*)p.C + off;
+        for (int r = 0; r < nval; ++r) unsafeAtomicAdd(c + r, v[r]);
+      }
+      continue;
+    }
+    const bool full = nval == 8 && vec16;
+    if (p.bias) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (r < nval) v[r] += p.bias[n + r];
+    }
+    float pre[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) pre[r] = v[r];
+    if (p.act == ACT_RELU) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+    } else if (p.act == ACT_GELU) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = gelu_tanh2(v[r]);
+    } else if (p.act == ACT_RELU_BWD || p.act == ACT_ADD) {
+      ushort8_t sv = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (full) sv = *(const ushort8_t*)(p.mask_src + off);
+      else
+        for (int r = 0; r < nval; ++r) sv[r] = p.mask_src[off + r];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float y = DT == DLE_F16 ? Elem<DLE_F16>::to_f32(sv[r]) : Elem<DLE_BF16>::to_f32(sv[r]);
+        if (p.act == ACT_RELU_BWD) v[r] = y > 0.f ? v[r] : 0.f;
+        else v[r] += y;
       }
     }
+    if (p.out_dtype == DLE_F32) {
+      float* c = (float*)p.C + off;
+      if (p.accumulate)
+        for (int r = 0; r < nval; ++r) v[r] += c[r];
+      if (nval == 8 && (p.ldc & 3) == 0) {
+        *(float4_t*)c = (float4_t){v[0], v[1], v[2], v[3]};
+        *(float4_t*)(c + 4) = (float4_t){v[4], v[5], v[6], v[7]};
+      } else {
+        for (int r = 0; r < nval; ++r) c[r] = v[r];
+      }
+      if (p.aux) {
+        float* a = (float*)p.aux + off;
+        for (int r = 0; r < nval; ++r) a[r] = pre[r];
+      }
+    } else {
+      ushort8_t o, po;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        if (p.out_dtype == DLE_F16) { o[r] = Elem<DLE_F16>::from_f32(v[r]); po[r] = Elem<DLE_F16>::from_f32(pre[r]); }
+        else { o[r] = Elem<DLE_BF16>::from_f32(v[r]); po[r] = Elem<DLE_BF16>::from_f32(pre[r]); }
+      }
+      unsigned short* c = (unsigned short*)p.C + off;
+      if (full) *(ushort8_t*)c = o;
+      else
+        for (int r = 0; r < nval; ++r) c[r] = o[r];
+      if (p.aux) {
+        unsigned short* a = (unsigned short*)p.aux + off;
+        if (full) *(ushort8_t*)a = po;
+        else
+          for (int r = 0; r < nval; ++r) a[r] = po[r];
+      }
+    }
+  }
   }
 }
 
@@ -450,7 +471,7 @@ extern "C" int dle_gemm_dma_try(const void* A, const void* B, void* C, void* aux
   }
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   dim3 grid(tiles, splitk), block(256);
-  const size_t lds = 2 * (BM * BK + BN * BK) * 2;
+  const size_t lds = GEMM2_LDS_BYTES;
 #define GO(DT, AM, BMODE) hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE>), grid, block, lds, stream, p)
   if (in_dtype == DLE_F16) {
     if (a_kc && b_kc) GO(DLE_F16, 0, 0);
@@ -485,7 +506,7 @@ extern "C" int dle_gemm_dma_try(const void* A, const void* B, void* C, void* aux
 static int conv_launch(Gemm2Args& p, int in_dtype, int amode, int bmode, hipStream_t stream) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   dim3 grid(tiles, p.splitk), block(256);
-  const size_t lds = 2 * (BM * BK + BN * BK) * 2;
+  const size_t lds = GEMM2_LDS_BYTES;
 #define GO(DT, AM, BMODE) hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE>), grid, block, lds, stream, p)
   if (in_dtype == DLE_F16) {
     if (amode == 2) GO(DLE_F16, 2, 0); else if (amode == 4) GO(DLE_F16, 4, 5); else GO(DLE_F16, 1, 3);
