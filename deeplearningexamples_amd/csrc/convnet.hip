@@ -130,8 +130,17 @@ __global__ __launch_bounds__(256) void bn_stats_finish_kernel(const float* __res
   const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   double s0 = 0.0, s1 = 0.0;
-  if (c < C)
-    for (int g = sl; g < groups; g += 4) { s0 += partial[((long long)g * 2) * C + c]; s1 += partial[((long long)g * 2 + 1) * C + c]; }
+  if (c < C) {
+    int g = sl;
+    for (; g + 28 < groups; g += 32) {          // 8 independent loads per stream in flight
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a[u] = partial[((long long)(g + 4 * u) * 2) * C + c]; b[u] = partial[((long long)(g + 4 * u) * 2 + 1) * C + c]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s0 += a[u]; s1 += b[u]; }
+    }
+    for (; g < groups; g += 4) { s0 += partial[((long long)g * 2) * C + c]; s1 += partial[((long long)g * 2 + 1) * C + c]; }
+  }
   red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
   __syncthreads();
   if (sl == 0 && c < C) {
@@ -158,8 +167,17 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float* __restr
   const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   double s0 = 0.0, s1 = 0.0;
-  if (c < C)
-    for (int g = sl; g < groups; g += 4) { s0 += partial[((long long)g * 2) * C + c]; s1 += partial[((long long)g * 2 + 1) * C + c]; }
+  if (c < C) {
+    int g = sl;
+    for (; g + 28 < groups; g += 32) {          // 8 independent loads per stream in flight
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a[u] = partial[((long long)(g + 4 * u) * 2) * C + c]; b[u] = partial[((long long)(g + 4 * u) * 2 + 1) * C + c]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s0 += a[u]; s1 += b[u]; }
+    }
+    for (; g < groups; g += 4) { s0 += partial[((long long)g * 2) * C + c]; s1 += partial[((long long)g * 2 + 1) * C + c]; }
+  }
   red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
   __syncthreads();
   if (sl == 0 && c < C) {
@@ -175,7 +193,7 @@ static int bn_reduce_geometry(long long M, int C, int& lpr, int& gx, long long& 
   lpr = 1;
   while (lpr < cols_v && lpr < 256) lpr <<= 1;
   gx = (cols_v + lpr - 1) / lpr;
-  long long want = 1024 / gx;
+  long long want = 512 / gx;
   if (want < 1) want = 1;
   rpb = (M + want - 1) / want;
   const long long min_rows = 8LL * (256 / lpr);

@@ -32,6 +32,7 @@
 #define BM 128
 #define BN 128
 #define BK 64
+#define SLAB_MODE(p) false
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3 };
 
@@ -150,12 +151,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int m0 = tm * BM, n0 = tn * BN;
 
   // split-K range (multiples of BK)
+  // balanced K slices: slice z owns k tiles [z*T/S, (z+1)*T/S) -- non-empty for every z when S <= T
   const int ktiles = (p.K + BK - 1) / BK;
-  const int per = (ktiles + p.splitk - 1) / p.splitk;
-  const int kt0 = blockIdx.y * per;
-  int kt1 = kt0 + per;
-  if (kt1 > ktiles) kt1 = ktiles;
-  if (kt0 >= kt1 && p.splitk > 1) return;
+  const int kt0 = (int)((long long)blockIdx.y * ktiles / p.splitk);
+  const int kt1 = (int)((long long)(blockIdx.y + 1) * ktiles / p.splitk);
+  if (kt0 >= kt1 && p.splitk > 1 && !SLAB_MODE(p)) return;
   const int kend = (kt1 * BK < p.K) ? kt1 * BK : p.K;
 
   const bool vecA = ((p.lda & 7) == 0) && ((((uintptr_t)p.A) & 15) == 0);
@@ -442,6 +442,10 @@ extern "C" int dle_gemm(const void* A, const void* B, void* C, void* aux, const 
   DLE_CHECK_ARG(act != ACT_RELU_BWD || mask_src, "gemm: ACT_RELU_BWD needs mask_src");
   DLE_CHECK_ARG(act != ACT_RELU_BWD || out_dtype == in_dtype, "gemm: ACT_RELU_BWD mask dtype = in dtype = out dtype");
   if (splitk < 1) splitk = 1;
+  {
+    const int kt = K > 0 ? (K + BK - 1) / BK : 1;
+    if (splitk > kt) splitk = kt;          // every K slice owns at least one K tile
+  }
   if (splitk > 1)
     DLE_CHECK_ARG(out_dtype == DLE_F32 && !bias && act == ACT_NONE && !aux, "gemm: split-K needs a plain fp32 output");
   else

@@ -26,6 +26,7 @@
 #define BM 128
 #define BN 128
 #define BK 64
+#define SLAB_MODE(p) ((p).ws != nullptr)
 // operand stages (2 x 32 KiB); the fp32 epilogue staging tile 64 x (128+4) reuses them
 #define GEMM2_LDS_BYTES (2 * (BM * BK + BN * BK) * 2)
 
@@ -200,12 +201,11 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(Gemm2Args p) {
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
+  // balanced K slices: slice z owns k tiles [z*T/S, (z+1)*T/S) -- non-empty for every z when S <= T
   const int ktiles = (p.K + BK - 1) / BK;
-  const int per = (ktiles + p.splitk - 1) / p.splitk;
-  const int kt0 = blockIdx.y * per;
-  int kt1 = kt0 + per;
-  if (kt1 > ktiles) kt1 = ktiles;
-  if (kt0 >= kt1 && p.splitk > 1) return;
+  const int kt0 = (int)((long long)blockIdx.y * ktiles / p.splitk);
+  const int kt1 = (int)((long long)(blockIdx.y + 1) * ktiles / p.splitk);
+  if (kt0 >= kt1 && p.splitk > 1 && !SLAB_MODE(p)) return;
   const int kend = (kt1 * BK < p.K) ? kt1 * BK : p.K;
 
   Loader<A_MODE> la;
@@ -459,10 +459,8 @@ extern "C" int dle_gemm_dma_try(const void* A, const void* B, void* C, void* aux
   p.ws = nullptr;
   if (splitk > 1) {
     const long long need = (long long)splitk * M * N * 4;
-    // every K slice must own at least one K tile, otherwise its slab would stay unwritten
-    const int ktiles = (K + BK - 1) / BK, per = (ktiles + splitk - 1) / splitk;
-    const bool full = (long long)(splitk - 1) * per < ktiles;
-    if (workspace && workspace_bytes >= need && full && (((uintptr_t)workspace) & 15) == 0) p.ws = (float*)workspace;
+    // (an empty K slice still writes its all-zero slab: the kernel does not early-out in slab mode)
+    if (workspace && workspace_bytes >= need && (((uintptr_t)workspace) & 15) == 0) p.ws = (float*)workspace;
     else if (!accumulate) {
       hipError_t e = ldc == N ? hipMemsetAsync(C, 0, (size_t)M * N * 4, stream)
                               : hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, stream);
@@ -577,7 +575,6 @@ extern "C" int dle_conv2d_wgrad(const void* dy, const void* x, float* dw, int N,
   const int ktiles = (p.K + BK - 1) / BK;
   if (splitk < 1) splitk = 1;
   if (splitk > ktiles) splitk = ktiles;
-  while (splitk > 1 && (long long)(splitk - 1) * ((ktiles + splitk - 1) / splitk) >= ktiles) --splitk;
   p.splitk = splitk;
   if (splitk > 1) {
     const long long need = (long long)splitk * p.M * p.N * 4;
