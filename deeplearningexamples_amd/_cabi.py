@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdle_mi355x.so")
 
 F32, F16, BF16 = 0, 1, 2
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_ADD = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_ADD, ACT_GELU_BWD, ACT_TANH, ACT_TANH_BWD = 0, 1, 2, 3, 4, 5, 6, 7
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
@@ -66,6 +66,19 @@ _SIGS = {
     "dle_avgpool_bwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
     "dle_softmax_xent": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64,
                                  c_i64, c_float, c_i64, c_int, c_void_p]),
+    "dle_gemm_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_int, c_int,
+                                 c_int, c_int, c_float, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_void_p]),
+    "dle_layernorm_fwd": (c_int, [c_void_p] * 8 + [c_i64, c_int, c_float, c_int, c_void_p]),
+    "dle_layernorm_workspace_bytes": (c_i64, [c_int]),
+    "dle_layernorm_bwd": (c_int, [c_void_p] * 8 + [c_i64, c_int, c_int, c_void_p, c_i64, c_int, c_void_p]),
+    "dle_embed_sum": (c_int, [c_void_p] * 6 + [c_i64, c_int, c_int, c_int, c_void_p]),
+    "dle_embed_scatter_add": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p]),
+    "dle_rows_select_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_i64, c_int,
+                                    c_void_p]),
+    "dle_rows_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p]),
+    "dle_rows_scatter": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
+    "dle_softmax_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_float, c_int, c_void_p]),
+    "dle_softmax_bwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_float, c_int, c_void_p]),
     "dle_colsum": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p, c_i64, c_void_p]),
     "dle_mt_table_len": (c_i64, [c_int, c_int]),
     "dle_mt_table_fill": (c_i64, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]),

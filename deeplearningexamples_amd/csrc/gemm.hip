@@ -439,8 +439,10 @@ extern "C" int dle_gemm(const void* A, const void* B, void* C, void* aux, const 
   DLE_CHECK_ARG(in_dtype == DLE_F16 || in_dtype == DLE_BF16, "gemm: inputs must be f16/bf16 (got %d)", in_dtype);
   DLE_CHECK_ARG(out_dtype == DLE_F32 || out_dtype == DLE_F16 || out_dtype == DLE_BF16, "gemm: bad out dtype");
   DLE_CHECK_ARG(!(a_kc == 0 && b_kc != 0), "gemm: (A m-contiguous, B k-contiguous) is not a hot-path layout");
-  DLE_CHECK_ARG(act != ACT_RELU_BWD || mask_src, "gemm: ACT_RELU_BWD needs mask_src");
-  DLE_CHECK_ARG(act != ACT_RELU_BWD || out_dtype == in_dtype, "gemm: ACT_RELU_BWD mask dtype = in dtype = out dtype");
+  const bool needs_src = act == ACT_RELU_BWD || act == 4 || act == 5 || act == 7;   // RELU_BWD, ADD, GELU_BWD, TANH_BWD
+  DLE_CHECK_ARG(act >= 0 && act <= 7, "gemm: unknown epilogue %d", act);
+  DLE_CHECK_ARG(!needs_src || mask_src, "gemm: this epilogue needs mask_src");
+  DLE_CHECK_ARG(!needs_src || out_dtype == in_dtype, "gemm: mask_src dtype = in dtype = out dtype");
   if (splitk < 1) splitk = 1;
   {
     const int kt = K > 0 ? (K + BK - 1) / BK : 1;
@@ -461,6 +463,8 @@ extern "C" int dle_gemm(const void* A, const void* B, void* C, void* aux, const 
       if (r != 0) return r;
     }
   }
+  DLE_CHECK_ARG(act <= ACT_RELU_BWD, "gemm: epilogue %d needs the aligned (LDS-DMA) path: K, lda, ldb multiples of 8, 16-byte "
+                "aligned operands", act);
   if (splitk > 1 && !accumulate) {   // register-staged kernel: fp32 atomics into a cleared C
     hipError_t e = ldc == N ? hipMemsetAsync(C, 0, (size_t)M * N * 4, stream)
                             : hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, stream);

@@ -30,7 +30,8 @@
 // operand stages (2 x 32 KiB); the fp32 epilogue staging tile 64 x (128+4) reuses them
 #define GEMM2_LDS_BYTES (2 * (BM * BK + BN * BK) * 2)
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_ADD = 4 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_ADD = 4, ACT_GELU_BWD = 5, ACT_TANH = 6,
+       ACT_TANH_BWD = 7 };
 
 struct ConvGeom {        // implicit-GEMM operand geometry (NHWC tensors, KRSC weights)
   int H, W, C;           // spatial size / channels of the tensor the im2col operand reads
@@ -52,6 +53,10 @@ struct Gemm2Args {
   float alpha;
   float* ws;             // split-K partial slabs [splitk][M][N] fp32 (NULL: fp32 atomics straight into C)
   ConvGeom cg;
+  // batched mode (grid.z = batch): operand z = (zo, zi) = (z / batch_inner, z % batch_inner) starts at
+  // base + zo * stride_outer + zi * stride_inner (elements) -- e.g. (sequence, head) slices of a [T, 3H] buffer
+  int batch_inner;
+  long long sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
 };
 
 template <int DT> struct Mfma32x16;
@@ -189,6 +194,13 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(Gemm2Args p) {
   unsigned short* lds = (unsigned short*)smem_raw;   // [2 stages][A tile 8192 halves | B tile 8192 halves]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  if (p.batch_inner > 0) {
+    const int zo = blockIdx.z / p.batch_inner, zi = blockIdx.z - zo * p.batch_inner;
+    p.A += zo * p.sa_o + zi * p.sa_i;
+    p.B += zo * p.sb_o + zi * p.sb_i;
+    const long long co = zo * p.sc_o + zi * p.sc_i;
+    p.C = p.out_dtype == DLE_F32 ? (void*)((float*)p.C + co) : (void*)((unsigned short*)p.C + co);
+  }
 
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int ntiles = tiles_m * tiles_n;
@@ -361,7 +373,10 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(Gemm2Args p) {
     } else if (p.act == ACT_GELU) {
 #pragma unroll
       for (int r = 0; r < 8; ++r) v[r] = gelu_tanh2(v[r]);
-    } else if (p.act == ACT_RELU_BWD || p.act == ACT_ADD) {
+    } else if (p.act == ACT_TANH) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = tanhf(v[r]);
+    } else if (p.act == ACT_RELU_BWD || p.act == ACT_ADD || p.act == ACT_GELU_BWD || p.act == ACT_TANH_BWD) {
       ushort8_t sv = {0, 0, 0, 0, 0, 0, 0, 0};
       if (full) sv = *(const ushort8_t*)(p.mask_src + off);
       else
@@ -370,7 +385,13 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(Gemm2Args p) {
       for (int r = 0; r < 8; ++r) {
         const float y = DT == DLE_F16 ? Elem<DLE_F16>::to_f32(sv[r]) : Elem<DLE_BF16>::to_f32(sv[r]);
         if (p.act == ACT_RELU_BWD) v[r] = y > 0.f ? v[r] : 0.f;
-        else v[r] += y;
+        else if (p.act == ACT_ADD) v[r] += y;
+        else if (p.act == ACT_TANH_BWD) v[r] *= (1.f - y * y);           // y = tanh output of the forward
+        else {                                                            // y = GELU pre-activation
+          const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+          const float th = tanhf(k0 * (y + k1 * y * y * y));
+          v[r] *= 0.5f * (1.f + th) + 0.5f * y * (1.f - th * th) * k0 * (1.f + 3.f * k1 * y * y);
+        }
       }
     }
     if (p.out_dtype == DLE_F32) {
@@ -457,6 +478,7 @@ extern "C" int dle_gemm_dma_try(const void* A, const void* B, void* C, void* aux
   p.out_dtype = out_dtype; p.act = act; p.splitk = splitk; p.accumulate = accumulate; p.alpha = alpha;
   p.cg = ConvGeom{};
   p.ws = nullptr;
+  p.batch_inner = 0;
   if (splitk > 1) {
     const long long need = (long long)splitk * M * N * 4;
     // (an empty K slice still writes its all-zero slab: the kernel does not early-out in slab mode)
@@ -592,6 +614,52 @@ extern "C" int dle_conv2d_wgrad(const void* dy, const void* x, float* dw, int N,
                        p.ldc, splitk, accumulate);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { dle_set_error("splitk_reduce launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  return 0;
+}
+
+
+// Batched GEMM over (outer, inner) slices -- the attention contractions of BERT (torch.bmm in the reference,
+// LanguageModeling/BERT/modeling.py:354,373): C[z] = alpha * A[z](m,k) B[z](n,k).  Strides in elements.
+extern "C" int dle_gemm_batched(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb,
+                                int64_t ldc, int a_kc, int b_kc, int in_dtype, int out_dtype, float alpha, int batch,
+                                int batch_inner, int64_t sa_o, int64_t sa_i, int64_t sb_o, int64_t sb_i, int64_t sc_o,
+                                int64_t sc_i, hipStream_t stream) {
+  DLE_CHECK_ARG(in_dtype == DLE_F16 || in_dtype == DLE_BF16, "gemm_batched: 16-bit inputs only");
+  DLE_CHECK_ARG(out_dtype == DLE_F32 || out_dtype == in_dtype, "gemm_batched: output fp32 or the input dtype");
+  DLE_CHECK_ARG(batch >= 0 && batch_inner > 0 && batch <= 65535 * 64, "gemm_batched: bad batch");
+  if (batch == 0 || M == 0 || N == 0) return 0;
+  DLE_CHECK_ARG(A && B && C, "gemm_batched: null pointer");
+  const bool al = ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 &&
+                  ((sa_o | sa_i | sb_o | sb_i) & 7) == 0;
+  DLE_CHECK_ARG(al && (K & 7) == 0 && (a_kc || (M & 7) == 0) && (b_kc || (N & 7) == 0) && !(a_kc == 0 && b_kc != 0),
+                "gemm_batched: operands must be 16-byte aligned with K (and row-contiguous dims) multiples of 8");
+  Gemm2Args p = {};
+  p.A = (const unsigned short*)A; p.B = (const unsigned short*)B; p.C = C;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.out_dtype = out_dtype; p.act = ACT_NONE; p.splitk = 1; p.accumulate = 0; p.alpha = alpha;
+  p.batch_inner = batch_inner; p.sa_o = sa_o; p.sa_i = sa_i; p.sb_o = sb_o; p.sb_i = sb_i; p.sc_o = sc_o; p.sc_i = sc_i;
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  const size_t lds = GEMM2_LDS_BYTES;
+  for (int z0 = 0; z0 < batch; z0 += 65535) {        // grid.z limit
+    const int nz = batch - z0 < 65535 ? batch - z0 : 65535;
+    DLE_CHECK_ARG(z0 == 0 || (65535 % batch_inner) == 0, "gemm_batched: batch above 65535 needs batch_inner | 65535");
+    Gemm2Args q = p;
+    if (z0) {
+      const int zo = z0 / batch_inner;
+      q.A += zo * sa_o; q.B += zo * sb_o;
+      q.C = out_dtype == DLE_F32 ? (void*)((float*)C + zo * sc_o) : (void*)((unsigned short*)C + zo * sc_o);
+    }
+    dim3 grid(tiles, 1, nz), block(256);
+#define GO(DT, AM, BMODE) hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE>), grid, block, lds, stream, q)
+    if (in_dtype == DLE_F16) {
+      if (a_kc && b_kc) GO(DLE_F16, 0, 0); else if (a_kc) GO(DLE_F16, 0, 1); else GO(DLE_F16, 1, 1);
+    } else {
+      if (a_kc && b_kc) GO(DLE_BF16, 0, 0); else if (a_kc) GO(DLE_BF16, 0, 1); else GO(DLE_BF16, 1, 1);
+    }
+#undef GO
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { dle_set_error("gemm_batched launch failed: %s", hipGetErrorString(e)); return (int)e; }
   }
   return 0;
 }

@@ -1,0 +1,503 @@
+// HBM-bound kernels of the BERT pre-training step for gfx950: fused embedding-sum + LayerNorm, LayerNorm
+// (+ residual) forward/backward, masked softmax forward/backward for the attention scores, row gather/scatter
+// (dense MLM head, pooler), embedding-gradient scatter.
+//
+// Replace (paths relative to /root/reference/PyTorch/LanguageModeling/BERT/):
+//   modeling.py:285-301   BertEmbeddings.forward   (3 gathers + sum + LayerNorm(eps 1e-12))
+//   modeling.py:394-398, 430-434  BertSelfOutput / BertOutput: LayerNorm(dense(x) + residual)
+//   modeling.py:354-373   scores / sqrt(d) + mask -> softmax(dim=-1)      (torch.bmm + F.softmax in the reference)
+//   modeling.py:587-595   index_select of the masked rows before the MLM head (sequence_output_is_dense)
+//   modeling.py:518-524   pooler input = hidden state of token 0
+// (ATen / NVFuser kernels in the reference, run_pretraining.py:56-60,419-420).
+// Layout: hidden states are [tokens = B*S, H] row-major 16-bit; statistics fp32.  One wavefront per row with
+// 16-byte lanes; row reductions are wave64 shuffles; column reductions (gamma/beta gradients) accumulate per
+// lane over the rows a workgroup sweeps, meet in LDS and leave through a workspace (no same-address atomics).
+#include "common.h"
+
+template <int DT> __device__ __forceinline__ float tf_up(unsigned short u) { return Elem<DT>::to_f32(u); }
+template <int DT> __device__ __forceinline__ unsigned short tf_dn(float f) { return Elem<DT>::from_f32(f); }
+
+static int tf_grid(long long items, int per_block, int cap = 2048) {
+  long long g = (items + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+#define LN_MAX_CHUNKS 8      // H <= 64 lanes * 8 chunks * 8 elements = 4096
+
+// ------------------------------------------------------------------ LayerNorm forward (+ residual)
+// z = x + res (res optional);  y = (z - mean) * rstd * gamma + beta.   z_out (optional) receives z in 16 bits
+// (the tensor the backward pass needs); mean / rstd fp32 per row.
+template <int DT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __restrict__ x,
+                                                     const unsigned short* __restrict__ res,
+                                                     unsigned short* __restrict__ z_out, unsigned short* __restrict__ y,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, long long rows,
+                                                     int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+  const int nch = H >> 3;                              // 16-byte chunks per row
+  for (long long r = wave; r < rows; r += nwaves) {
+    float v[LN_MAX_CHUNKS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+        const ushort8_t xv = *(const ushort8_t*)(x + r * H + c * 8);
+        ushort8_t rv = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (res) rv = *(const ushort8_t*)(res + r * H + c * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float t = tf_up<DT>(xv[k]);
+          if (res) t = tf_up<DT>(tf_dn<DT>(t + tf_up<DT>(rv[k])));     // z is what backward will see (16-bit)
+          v[i][k] = t;
+          s += t;
+        }
+        if (z_out && res) {
+          ushort8_t zo;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) zo[k] = tf_dn<DT>(v[i][k]);
+          *(ushort8_t*)(z_out + r * H + c * 8) = zo;
+        }
+      }
+    }
+    s = wave_sum(s);
+    const float mu = s / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i)
+      if (lane + i * 64 < nch)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
+    q = wave_sum(q);
+    const float rs = rsqrtf(q / (float)H + eps);
+    if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+        const float4_t g0 = *(const float4_t*)(gamma + c * 8), g1 = *(const float4_t*)(gamma + c * 8 + 4);
+        const float4_t b0 = *(const float4_t*)(beta + c * 8), b1 = *(const float4_t*)(beta + c * 8 + 4);
+        ushort8_t o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float g = k < 4 ? g0[k & 3] : g1[k & 3], b = k < 4 ? b0[k & 3] : b1[k & 3];
+          o[k] = tf_dn<DT>((v[i][k] - mu) * rs * g + b);
+        }
+        *(ushort8_t*)(y + r * H + c * 8) = o;
+      }
+    }
+  }
+}
+
+extern "C" int dle_layernorm_fwd(const void* x, const void* residual, void* z_out, void* y, const float* gamma,
+                                 const float* beta, float* mean, float* rstd, int64_t rows, int H, float eps,
+                                 int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "layernorm_fwd: 16-bit activations only");
+  DLE_CHECK_ARG(H > 0 && H % 8 == 0 && H <= 64 * LN_MAX_CHUNKS * 8, "layernorm_fwd: H must be a multiple of 8, <= 4096");
+  if (rows == 0) return 0;
+  DLE_CHECK_ARG(x && y && gamma && beta && mean && rstd, "layernorm_fwd: null pointer");
+  const int grid = tf_grid(rows, 4, 4096);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(ln_fwd_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)residual, (unsigned short*)z_out, (unsigned short*)y, gamma, beta, mean, rstd, (long long)rows, H, eps);
+  else hipLaunchKernelGGL(ln_fwd_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)residual, (unsigned short*)z_out, (unsigned short*)y, gamma, beta, mean, rstd, (long long)rows, H, eps);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ LayerNorm backward
+// xhat = (z - mean) * rstd;  dz = rstd * (dy*gamma - mean_H(dy*gamma) - xhat * mean_H(dy*gamma*xhat));
+// partial[block][0][c] = sum_rows dy (dbeta), partial[block][1][c] = sum_rows dy * xhat (dgamma).
+// ZT = dtype of z (16-bit) or fp32 reconstruction is done by the embedding variant below.
+template <int DT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __restrict__ dy,
+                                                     const unsigned short* __restrict__ z,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, unsigned short* __restrict__ dz,
+                                                     float* __restrict__ partial, long long rows, int H) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* red = (float*)smem_raw;                       // [4 waves][2][H]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long wave = (long long)blockIdx.x * 4 + w, nwaves = (long long)gridDim.x * 4;
+  const int nch = H >> 3;
+  float ag[LN_MAX_CHUNKS][8], ab[LN_MAX_CHUNKS][8];
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ag[i][k] = 0.f; ab[i][k] = 0.f; }
+  for (long long r = wave; r < rows; r += nwaves) {
+    const float mu = mean[r], rs = rstd[r];
+    float g[LN_MAX_CHUNKS][8], xh[LN_MAX_CHUNKS][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+        const ushort8_t dv = *(const ushort8_t*)(dy + r * H + c * 8);
+        const ushort8_t zv = *(const ushort8_t*)(z + r * H + c * 8);
+        const float4_t g0 = *(const float4_t*)(gamma + c * 8), g1 = *(const float4_t*)(gamma + c * 8 + 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float d = tf_up<DT>(dv[k]);
+          const float xx = (tf_up<DT>(zv[k]) - mu) * rs;
+          const float gm = k < 4 ? g0[k & 3] : g1[k & 3];
+          ab[i][k] += d;
+          ag[i][k] += d * xx;
+          g[i][k] = d * gm;
+          xh[i][k] = xx;
+          s1 += g[i][k];
+          s2 += g[i][k] * xx;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+        ushort8_t o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = tf_dn<DT>(rs * (g[i][k] - s1 - xh[i][k] * s2));
+        *(ushort8_t*)(dz + r * H + c * 8) = o;
+      }
+    }
+  }
+  // column partials: waves of the block meet in LDS
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int c = lane + i * 64;
+    if (c < nch)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        red[(w * 2 + 0) * H + c * 8 + k] = ab[i][k];
+        red[(w * 2 + 1) * H + c * 8 + k] = ag[i][k];
+      }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * H; c += 256) {
+    const int which = c / H, col = c - which * H;
+    const float t = red[(0 * 2 + which) * H + col] + red[(1 * 2 + which) * H + col] + red[(2 * 2 + which) * H + col] +
+                    red[(3 * 2 + which) * H + col];
+    partial[((long long)blockIdx.x * 2 + which) * H + col] = t;
+  }
+}
+
+// dgamma / dbeta = sum over blocks of the partials (fp64 accumulation), 64 columns x 4 slices per workgroup
+__global__ __launch_bounds__(256) void colpair_finish_kernel(const float* __restrict__ partial, int groups, int C,
+                                                             float* __restrict__ out1, float* __restrict__ out0,
+                                                             int accumulate) {
+  __shared__ double red[2][256];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C)
+    for (int g = sl; g < groups; g += 4) { s0 += partial[((long long)g * 2) * C + c]; s1 += partial[((long long)g * 2 + 1) * C + c]; }
+  red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    const float t0 = (float)(red[0][cl] + red[0][64 + cl] + red[0][128 + cl] + red[0][192 + cl]);
+    const float t1 = (float)(red[1][cl] + red[1][64 + cl] + red[1][128 + cl] + red[1][192 + cl]);
+    out0[c] = accumulate ? out0[c] + t0 : t0;
+    out1[c] = accumulate ? out1[c] + t1 : t1;
+  }
+}
+
+#define LN_BWD_BLOCKS 256
+extern "C" int64_t dle_layernorm_workspace_bytes(int H) { return (int64_t)LN_BWD_BLOCKS * 2 * H * 4; }
+
+extern "C" int dle_layernorm_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                                 void* dz, float* dgamma, float* dbeta, int64_t rows, int H, int accumulate,
+                                 void* workspace, int64_t workspace_bytes, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "layernorm_bwd: 16-bit activations only");
+  DLE_CHECK_ARG(H > 0 && H % 8 == 0 && H <= 64 * LN_MAX_CHUNKS * 8, "layernorm_bwd: H must be a multiple of 8, <= 4096");
+  DLE_CHECK_ARG(rows > 0 && dy && z && mean && rstd && gamma && dz && dgamma && dbeta && workspace, "layernorm_bwd: null pointer / empty");
+  int blocks = (int)((rows + 3) / 4);
+  if (blocks > LN_BWD_BLOCKS) blocks = LN_BWD_BLOCKS;
+  DLE_CHECK_ARG(workspace_bytes >= (long long)blocks * 2 * H * 4, "layernorm_bwd: workspace too small");
+  const size_t lds = (size_t)4 * 2 * H * 4;
+  if (dtype == DLE_F16) hipLaunchKernelGGL(ln_bwd_kernel<DLE_F16>, dim3(blocks), dim3(256), lds, stream, (const unsigned short*)dy, (const unsigned short*)z, mean, rstd, gamma, (unsigned short*)dz, (float*)workspace, (long long)rows, H);
+  else hipLaunchKernelGGL(ln_bwd_kernel<DLE_BF16>, dim3(blocks), dim3(256), lds, stream, (const unsigned short*)dy, (const unsigned short*)z, mean, rstd, gamma, (unsigned short*)dz, (float*)workspace, (long long)rows, H);
+  DLE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colpair_finish_kernel, dim3((H + 63) / 64), dim3(256), 0, stream, (const float*)workspace, blocks, H,
+                     dgamma, dbeta, accumulate);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ embeddings: gather-sum (fp32) -> 16-bit z
+// z[t] = word[ids[t]] + pos[t mod S] + type[tt[t]]   (fp32 tables; the LayerNorm that follows reads z)
+template <int DT>
+__global__ __launch_bounds__(256) void embed_sum_kernel(const float* __restrict__ word, const float* __restrict__ pos,
+                                                        const float* __restrict__ type, const long long* __restrict__ ids,
+                                                        const long long* __restrict__ tt, unsigned short* __restrict__ z,
+                                                        long long tokens, int S, int H) {
+  const int nch = H >> 3;
+  const long long total = tokens * nch;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long t = i / nch;
+    const int c = (int)(i - t * nch) * 8;
+    const float* w = word + ids[t] * H + c;
+    const float* p = pos + (t % S) * H + c;
+    const float* y = type + tt[t] * H + c;
+    ushort8_t o;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float4_t a = *(const float4_t*)(w + 4 * h), b = *(const float4_t*)(p + 4 * h), d = *(const float4_t*)(y + 4 * h);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[4 * h + k] = tf_dn<DT>(a[k] + b[k] + d[k]);
+    }
+    *(ushort8_t*)(z + t * H + c) = o;
+  }
+}
+
+extern "C" int dle_embed_sum(const float* word, const float* pos, const float* type, const int64_t* ids,
+                             const int64_t* token_type, void* z, int64_t tokens, int S, int H, int dtype,
+                             hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "embed_sum: 16-bit output only");
+  DLE_CHECK_ARG(H % 8 == 0 && S > 0, "embed_sum: bad shape");
+  if (tokens == 0) return 0;
+  DLE_CHECK_ARG(word && pos && type && ids && token_type && z, "embed_sum: null pointer");
+  const int grid = tf_grid(tokens * (H / 8), 256);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(embed_sum_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, word, pos, type, (const long long*)ids, (const long long*)token_type, (unsigned short*)z, (long long)tokens, S, H);
+  else hipLaunchKernelGGL(embed_sum_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, word, pos, type, (const long long*)ids, (const long long*)token_type, (unsigned short*)z, (long long)tokens, S, H);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// word-embedding gradient: gw[ids[t], :] += dz[t, :]  (fp32 atomics, once per step);
+// type gradient selector sums are done with dle_rows_select_sum below, position gradient with dle_colsum.
+template <int DT>
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const unsigned short* __restrict__ dz,
+                                                            const long long* __restrict__ ids, float* __restrict__ gw,
+                                                            long long tokens, int H) {
+  const int nch = H >> 3;
+  const long long total = tokens * nch;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long t = i / nch;
+    const int c = (int)(i - t * nch) * 8;
+    const ushort8_t v = *(const ushort8_t*)(dz + t * H + c);
+    float* dst = gw + ids[t] * H + c;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) unsafeAtomicAdd(dst + k, tf_up<DT>(v[k]));
+  }
+}
+
+extern "C" int dle_embed_scatter_add(const void* dz, const int64_t* ids, float* grad_word, int64_t tokens, int H,
+                                     int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "embed_scatter_add: 16-bit gradients only");
+  DLE_CHECK_ARG(H % 8 == 0, "embed_scatter_add: H must be a multiple of 8");
+  if (tokens == 0) return 0;
+  DLE_CHECK_ARG(dz && ids && grad_word, "embed_scatter_add: null pointer");
+  const int grid = tf_grid(tokens * (H / 8), 256);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(embed_scatter_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dz, (const long long*)ids, grad_word, (long long)tokens, H);
+  else hipLaunchKernelGGL(embed_scatter_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dz, (const long long*)ids, grad_word, (long long)tokens, H);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[k][c] = sum over rows t with sel[t] == k of x[t][c], k in [0, K) (K small: token types).  Partials via workspace.
+template <int DT, int KMAX>
+__global__ __launch_bounds__(256) void rows_select_sum_kernel(const unsigned short* __restrict__ x,
+                                                              const long long* __restrict__ sel, float* __restrict__ partial,
+                                                              long long rows, int H, int K, long long rows_per_block) {
+  const int nch = H >> 3;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= nch) return;
+  float acc[KMAX][8];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[k][e] = 0.f;
+  for (long long r = r0; r < r1; ++r) {
+    const int s = (int)sel[r];
+    const ushort8_t v = *(const ushort8_t*)(x + r * H + c * 8);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k == s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[k][e] += tf_up<DT>(v[e]);
+  }
+  for (int k = 0; k < K && k < KMAX; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) partial[((long long)blockIdx.y * K + k) * H + c * 8 + e] = acc[k][e];
+}
+
+__global__ __launch_bounds__(256) void select_sum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                                int groups, int KH, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= KH) return;
+  float s = accumulate ? out[i] : 0.f;
+  for (int g = 0; g < groups; ++g) s += partial[(long long)g * KH + i];
+  out[i] = s;
+}
+
+#define SELSUM_GROUPS 128
+extern "C" int dle_rows_select_sum(const void* x, const int64_t* sel, float* out, int64_t rows, int H, int K,
+                                   int accumulate, void* workspace, int64_t workspace_bytes, int dtype,
+                                   hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "rows_select_sum: 16-bit input only");
+  DLE_CHECK_ARG(H % 8 == 0 && K >= 1 && K <= 4, "rows_select_sum: K must be 1..4, H a multiple of 8");
+  DLE_CHECK_ARG(rows > 0 && x && sel && out && workspace, "rows_select_sum: null pointer / empty");
+  long long rpb = (rows + SELSUM_GROUPS - 1) / SELSUM_GROUPS;
+  const int gy = (int)((rows + rpb - 1) / rpb);
+  DLE_CHECK_ARG(workspace_bytes >= (long long)gy * K * H * 4, "rows_select_sum: workspace too small");
+  dim3 grid((H / 8 + 255) / 256, gy), block(256);
+  if (dtype == DLE_F16) hipLaunchKernelGGL((rows_select_sum_kernel<DLE_F16, 4>), grid, block, 0, stream, (const unsigned short*)x, (const long long*)sel, (float*)workspace, (long long)rows, H, K, rpb);
+  else hipLaunchKernelGGL((rows_select_sum_kernel<DLE_BF16, 4>), grid, block, 0, stream, (const unsigned short*)x, (const long long*)sel, (float*)workspace, (long long)rows, H, K, rpb);
+  DLE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(select_sum_finish_kernel, dim3((K * H + 255) / 256), dim3(256), 0, stream, (const float*)workspace, out, gy, K * H, accumulate);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ row gather / scatter (16-bit rows)
+// gather:  dst[i, :] = src[idx[i], :]          scatter: dst[idx[i], :] (+)= src[i, :]   (idx unique per call)
+template <int ADD, int DT>
+__global__ __launch_bounds__(256) void rows_move_kernel(const unsigned short* __restrict__ src,
+                                                        const long long* __restrict__ idx, unsigned short* __restrict__ dst,
+                                                        long long n, int H, int gather) {
+  const int nch = H >> 3;
+  const long long total = n * nch;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / nch;
+    const int c = (int)(i - r * nch) * 8;
+    const long long far = idx[r];
+    const unsigned short* s = gather ? src + far * H + c : src + r * H + c;
+    unsigned short* d = gather ? dst + r * H + c : dst + far * H + c;
+    ushort8_t v = *(const ushort8_t*)s;
+    if (ADD) {
+      const ushort8_t o = *(const ushort8_t*)d;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = tf_dn<DT>(tf_up<DT>(v[k]) + tf_up<DT>(o[k]));
+    }
+    *(ushort8_t*)d = v;
+  }
+}
+
+extern "C" int dle_rows_gather(const void* src, const int64_t* idx, void* dst, int64_t n, int H, int dtype,
+                               hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "rows_gather: 16-bit rows only");
+  DLE_CHECK_ARG(H % 8 == 0, "rows_gather: H must be a multiple of 8");
+  if (n == 0) return 0;
+  DLE_CHECK_ARG(src && idx && dst, "rows_gather: null pointer");
+  hipLaunchKernelGGL((rows_move_kernel<0, DLE_F16>), dim3(tf_grid(n * (H / 8), 256)), dim3(256), 0, stream,
+                     (const unsigned short*)src, (const long long*)idx, (unsigned short*)dst, (long long)n, H, 1);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dle_rows_scatter(const void* src, const int64_t* idx, void* dst, int64_t n, int H, int accumulate,
+                                int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "rows_scatter: 16-bit rows only");
+  DLE_CHECK_ARG(H % 8 == 0, "rows_scatter: H must be a multiple of 8");
+  if (n == 0) return 0;
+  DLE_CHECK_ARG(src && idx && dst, "rows_scatter: null pointer");
+  const int grid = tf_grid(n * (H / 8), 256);
+  if (!accumulate) hipLaunchKernelGGL((rows_move_kernel<0, DLE_F16>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)src, (const long long*)idx, (unsigned short*)dst, (long long)n, H, 0);
+  else if (dtype == DLE_F16) hipLaunchKernelGGL((rows_move_kernel<1, DLE_F16>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)src, (const long long*)idx, (unsigned short*)dst, (long long)n, H, 0);
+  else hipLaunchKernelGGL((rows_move_kernel<1, DLE_BF16>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)src, (const long long*)idx, (unsigned short*)dst, (long long)n, H, 0);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ masked softmax over attention scores
+// scores [batch*heads][S][L] 16-bit in place:  p = softmax(s * scale + mask_add[b][col]) along L.
+// L/8 lanes per row (L = 128 -> 16 lanes, 4 rows per wavefront); mask_add fp32 [batch][L] (0 / -10000).
+template <int DT>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(unsigned short* __restrict__ s, const float* __restrict__ mask_add,
+                                                          long long rows, int L, int rows_per_batch, float scale) {
+  const int lpr = L >> 3;
+  const int rpw = 64 / lpr;
+  const int lane = threadIdx.x & 63, sub = lane / lpr, cl = lane % lpr;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+  for (long long r0 = wave * rpw; r0 < rows; r0 += nwaves * rpw) {
+    const long long r = r0 + sub;
+    const bool ok = r < rows;
+    float v[8];
+    float mx = -INFINITY;
+    if (ok) {
+      const ushort8_t x = *(const ushort8_t*)(s + r * L + cl * 8);
+      const float* m = mask_add ? mask_add + (r / rows_per_batch) * L + cl * 8 : nullptr;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[k] = tf_up<DT>(x[k]) * scale + (m ? m[k] : 0.f);
+        mx = fmaxf(mx, v[k]);
+      }
+    }
+    for (int o = lpr >> 1; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    if (ok)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { v[k] = __expf(v[k] - mx); sum += v[k]; }
+    for (int o = lpr >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (ok) {
+      const float inv = 1.0f / sum;
+      ushort8_t o8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o8[k] = tf_dn<DT>(v[k] * inv);
+      *(ushort8_t*)(s + r * L + cl * 8) = o8;
+    }
+  }
+}
+
+// dS = P * (dP - sum_j dP_j P_j) * scale, written over dP
+template <int DT>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const unsigned short* __restrict__ p, unsigned short* __restrict__ dp,
+                                                          long long rows, int L, float scale) {
+  const int lpr = L >> 3;
+  const int rpw = 64 / lpr;
+  const int lane = threadIdx.x & 63, sub = lane / lpr, cl = lane % lpr;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+  for (long long r0 = wave * rpw; r0 < rows; r0 += nwaves * rpw) {
+    const long long r = r0 + sub;
+    const bool ok = r < rows;
+    float pv[8], gv[8];
+    float dot = 0.f;
+    if (ok) {
+      const ushort8_t a = *(const ushort8_t*)(p + r * L + cl * 8), b = *(const ushort8_t*)(dp + r * L + cl * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { pv[k] = tf_up<DT>(a[k]); gv[k] = tf_up<DT>(b[k]); dot += pv[k] * gv[k]; }
+    }
+    for (int o = lpr >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    if (ok) {
+      ushort8_t o8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o8[k] = tf_dn<DT>(pv[k] * (gv[k] - dot) * scale);
+      *(ushort8_t*)(dp + r * L + cl * 8) = o8;
+    }
+  }
+}
+
+static bool softmax_len_ok(int L) { return L == 8 || L == 16 || L == 32 || L == 64 || L == 128 || L == 256 || L == 512; }
+
+extern "C" int dle_softmax_fwd(void* scores, const float* mask_add, int64_t rows, int L, int rows_per_batch, float scale,
+                               int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "softmax_fwd: 16-bit scores only");
+  DLE_CHECK_ARG(softmax_len_ok(L), "softmax_fwd: row length %d must be a power of two in [8, 512]", L);
+  if (rows == 0) return 0;
+  DLE_CHECK_ARG(scores && rows_per_batch > 0, "softmax_fwd: bad arguments");
+  const int grid = tf_grid(rows, 4 * (64 / (L / 8)), 4096);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(softmax_fwd_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (unsigned short*)scores, mask_add, (long long)rows, L, rows_per_batch, scale);
+  else hipLaunchKernelGGL(softmax_fwd_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (unsigned short*)scores, mask_add, (long long)rows, L, rows_per_batch, scale);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dle_softmax_bwd(const void* probs, void* dprobs, int64_t rows, int L, float scale, int dtype,
+                               hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "softmax_bwd: 16-bit scores only");
+  DLE_CHECK_ARG(softmax_len_ok(L), "softmax_bwd: row length %d must be a power of two in [8, 512]", L);
+  if (rows == 0) return 0;
+  DLE_CHECK_ARG(probs && dprobs, "softmax_bwd: null pointer");
+  const int grid = tf_grid(rows, 4 * (64 / (L / 8)), 4096);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(softmax_bwd_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)probs, (unsigned short*)dprobs, (long long)rows, L, scale);
+  else hipLaunchKernelGGL(softmax_bwd_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)probs, (unsigned short*)dprobs, (long long)rows, L, scale);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}

@@ -499,3 +499,96 @@ def softmax_xent(logits, target, smoothing=0.0, ignore_index=-100, grad_scale=No
            rows, classes, logits.stride(0), ldo, float(smoothing), int(ignore_index),
            C.dt(grad_dtype) if grad_dtype is not None else 0, C.stream())
     return loss, dl
+
+
+# ------------------------------------------------------------------ BERT ops (hidden states [tokens, H], 16-bit)
+def gemm_batched(a, b, c, m, n, k, lda, ldb, ldc, a_kc, b_kc, batch, batch_inner, sa, sb, sc, alpha=1.0):
+    """C[z] = alpha * A[z](m,k) B[z](n,k) for z = (zo, zi); sa/sb/sc = (outer, inner) element strides."""
+    C.require_cuda(a, b, c)
+    C.annotate(flops=2.0 * m * n * k * batch, tag="b%dx%dx%dx%d" % (batch, m, n, k),
+               bytes=float(batch) * (m * k + n * k + m * n) * 2)
+    C.call("dle_gemm_batched", C.ptr(a), C.ptr(b), C.ptr(c), m, n, k, lda, ldb, ldc, int(a_kc), int(b_kc), C.dt(a),
+           C.dt(c), float(alpha), batch, batch_inner, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], C.stream())
+    return c
+
+
+def layernorm_fwd(x, gamma, beta, residual=None, eps=1e-12, write_z=True):
+    """y = LN(x + residual).  -> (y, z, mean, rstd); z is x itself when there is no residual."""
+    C.require_cuda(x, gamma, beta, residual)
+    rows, h = x.shape
+    y = torch.empty_like(x)
+    z = torch.empty_like(x) if (residual is not None and write_z) else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    C.annotate(bytes=float(x.numel()) * 2 * (4 if residual is not None else 2), tag="H%d" % h)
+    C.call("dle_layernorm_fwd", C.ptr(x), C.ptr(residual), C.ptr(z), C.ptr(y), C.ptr(gamma), C.ptr(beta), C.ptr(mean),
+           C.ptr(rstd), rows, h, float(eps), C.dt(x), C.stream())
+    return y, (z if z is not None else x), mean, rstd
+
+
+def layernorm_bwd(dy, z, mean, rstd, gamma, dgamma, dbeta, accumulate=False):
+    C.require_cuda(dy, z, mean, rstd, gamma, dgamma, dbeta)
+    rows, h = z.shape
+    dz = torch.empty_like(z)
+    ws = splitk_workspace(z.device, C.lib().dle_layernorm_workspace_bytes(h))
+    C.annotate(bytes=float(z.numel()) * 2 * 3, tag="H%d" % h)
+    C.call("dle_layernorm_bwd", C.ptr(dy), C.ptr(z), C.ptr(mean), C.ptr(rstd), C.ptr(gamma), C.ptr(dz), C.ptr(dgamma),
+           C.ptr(dbeta), rows, h, int(accumulate), C.ptr(ws), ws.numel() * 4, C.dt(z), C.stream())
+    return dz
+
+
+def embed_sum(word, pos, typ, ids, token_type, seq_len, out_dtype):
+    C.require_cuda(word, pos, typ, ids, token_type)
+    t = ids.numel()
+    h = word.shape[1]
+    z = torch.empty((t, h), dtype=out_dtype, device=word.device)
+    C.call("dle_embed_sum", C.ptr(word), C.ptr(pos), C.ptr(typ), C.ptr(ids), C.ptr(token_type), C.ptr(z), t, seq_len, h,
+           C.dt(z), C.stream())
+    return z
+
+
+def embed_scatter_add_(grad_word, dz, ids):
+    C.require_cuda(grad_word, dz, ids)
+    C.call("dle_embed_scatter_add", C.ptr(dz), C.ptr(ids), C.ptr(grad_word), ids.numel(), dz.shape[1], C.dt(dz), C.stream())
+
+
+def rows_select_sum(x, sel, k, out, accumulate=False):
+    C.require_cuda(x, sel, out)
+    rows, h = x.shape
+    ws = splitk_workspace(x.device, 128 * k * h * 4)
+    C.call("dle_rows_select_sum", C.ptr(x), C.ptr(sel), C.ptr(out), rows, h, k, int(accumulate), C.ptr(ws),
+           ws.numel() * 4, C.dt(x), C.stream())
+    return out
+
+
+def rows_gather(src, idx):
+    C.require_cuda(src, idx)
+    dst = torch.empty((idx.numel(), src.shape[1]), dtype=src.dtype, device=src.device)
+    C.call("dle_rows_gather", C.ptr(src), C.ptr(idx), C.ptr(dst), idx.numel(), src.shape[1], C.dt(src), C.stream())
+    return dst
+
+
+def rows_scatter_(dst, src, idx, accumulate=False):
+    C.require_cuda(dst, src, idx)
+    C.call("dle_rows_scatter", C.ptr(src), C.ptr(idx), C.ptr(dst), idx.numel(), src.shape[1], int(accumulate), C.dt(src),
+           C.stream())
+    return dst
+
+
+def softmax_fwd_(scores, mask_add, rows_per_batch, scale):
+    """In place over scores [..., L]."""
+    C.require_cuda(scores, mask_add)
+    l = scores.shape[-1]
+    rows = scores.numel() // l
+    C.annotate(bytes=float(scores.numel()) * 4, tag="L%d" % l)
+    C.call("dle_softmax_fwd", C.ptr(scores), C.ptr(mask_add), rows, l, rows_per_batch, float(scale), C.dt(scores), C.stream())
+    return scores
+
+
+def softmax_bwd_(probs, dprobs, scale):
+    C.require_cuda(probs, dprobs)
+    l = probs.shape[-1]
+    rows = probs.numel() // l
+    C.annotate(bytes=float(probs.numel()) * 6, tag="L%d" % l)
+    C.call("dle_softmax_bwd", C.ptr(probs), C.ptr(dprobs), rows, l, float(scale), C.dt(probs), C.stream())
+    return dprobs

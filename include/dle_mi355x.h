@@ -22,7 +22,8 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 
 enum { DLE_F32 = 0, DLE_F16 = 1, DLE_BF16 = 2 };
-enum { DLE_ACT_NONE = 0, DLE_ACT_RELU = 1, DLE_ACT_GELU = 2, DLE_ACT_RELU_BWD = 3, DLE_ACT_ADD = 4 };
+enum { DLE_ACT_NONE = 0, DLE_ACT_RELU = 1, DLE_ACT_GELU = 2, DLE_ACT_RELU_BWD = 3, DLE_ACT_ADD = 4,
+       DLE_ACT_GELU_BWD = 5, DLE_ACT_TANH = 6, DLE_ACT_TANH_BWD = 7 };
 
 /* ---- library plumbing ---------------------------------------------------------------------- */
 const char* dle_last_error(void);
@@ -91,6 +92,15 @@ int dle_gemm(const void* A, const void* B, void* C, void* aux, const float* bias
              const void* mask_src, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
              int a_kc, int b_kc, int in_dtype, int out_dtype, int act, int splitk, int accumulate,
              float alpha, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+/* Epilogues that read mask_src (same shape/ld as C): RELU_BWD (mask by mask_src > 0), ADD (C = acc + mask_src),
+ * GELU_BWD (acc * gelu'(mask_src), mask_src = saved pre-activation), TANH_BWD (acc * (1 - mask_src^2)).
+ * Batched form (attention contractions, torch.bmm at LanguageModeling/BERT/modeling.py:354,373):
+ * slice z = (z / batch_inner, z % batch_inner) of X starts at X + zo*sx_o + zi*sx_i (elements).              */
+int dle_gemm_batched(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb,
+                     int64_t ldc, int a_kc, int b_kc, int in_dtype, int out_dtype, float alpha, int batch,
+                     int batch_inner, int64_t sa_o, int64_t sa_i, int64_t sb_o, int64_t sb_i, int64_t sc_o,
+                     int64_t sc_i, hipStream_t stream);
+
 /* ---- convolutions as implicit GEMM (csrc/gemm_dma.hip) ------------------------------------------------
  * replace cuDNN conv forward / backward-data / backward-filter behind nn.Conv2d(bias=False)
  *   Classification/ConvNets/image_classification/models/common.py:31-60, models/resnet.py:126-175
@@ -206,6 +216,37 @@ int dle_softmax_xent(const float* logits, const int64_t* target, float* loss_out
                      const float* grad_scale_dev, int* scratch, int64_t rows, int classes, int64_t ld,
                      int64_t ld_out, float smoothing, int64_t ignore_index, int dlogits_dtype,
                      hipStream_t stream);
+
+/* ---- BERT HBM-bound kernels (csrc/transformer.hip): hidden states [tokens, H] 16-bit, statistics fp32 --------
+ * replace LayerNorm(dense(x) + residual) (LanguageModeling/BERT/modeling.py:394-398,430-434), BertEmbeddings
+ * (modeling.py:285-301), scores/sqrt(d) + mask -> softmax (modeling.py:354-366), the masked-row index_select of
+ * the dense MLM head (modeling.py:587-595) and the pooler's token-0 slice (modeling.py:518-524).               */
+int dle_layernorm_fwd(const void* x, const void* residual, void* z_out, void* y, const float* gamma,
+                      const float* beta, float* mean, float* rstd, int64_t rows, int H, float eps, int dtype,
+                      hipStream_t stream);
+int64_t dle_layernorm_workspace_bytes(int H);
+/* dz = d/dz of LN; dgamma/dbeta (fp32, (+)= when accumulate) */
+int dle_layernorm_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                      void* dz, float* dgamma, float* dbeta, int64_t rows, int H, int accumulate, void* workspace,
+                      int64_t workspace_bytes, int dtype, hipStream_t stream);
+/* z[t] = word[ids[t]] + pos[t mod S] + type[token_type[t]]  (fp32 tables -> 16-bit) */
+int dle_embed_sum(const float* word, const float* pos, const float* type, const int64_t* ids,
+                  const int64_t* token_type, void* z, int64_t tokens, int S, int H, int dtype, hipStream_t stream);
+/* grad_word[ids[t], :] += dz[t, :] (fp32) */
+int dle_embed_scatter_add(const void* dz, const int64_t* ids, float* grad_word, int64_t tokens, int H, int dtype,
+                          hipStream_t stream);
+/* out[k, :] (+)= sum of rows t with sel[t] == k, k < K <= 4; workspace >= 128*K*H*4 bytes */
+int dle_rows_select_sum(const void* x, const int64_t* sel, float* out, int64_t rows, int H, int K, int accumulate,
+                        void* workspace, int64_t workspace_bytes, int dtype, hipStream_t stream);
+int dle_rows_gather(const void* src, const int64_t* idx, void* dst, int64_t n, int H, int dtype, hipStream_t stream);
+int dle_rows_scatter(const void* src, const int64_t* idx, void* dst, int64_t n, int H, int accumulate, int dtype,
+                     hipStream_t stream);
+/* in place: p = softmax(s * scale + mask_add[row / rows_per_batch][col]); rows of length L (power of two <= 512) */
+int dle_softmax_fwd(void* scores, const float* mask_add, int64_t rows, int L, int rows_per_batch, float scale,
+                    int dtype, hipStream_t stream);
+/* in place over dprobs: dS = P * (dP - sum(dP * P)) * scale */
+int dle_softmax_bwd(const void* probs, void* dprobs, int64_t rows, int L, float scale, int dtype,
+                    hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,168 @@
+"""CPU restatement of the reference's BERT pre-training step (TEST INFRASTRUCTURE ONLY).
+
+Follows, in fp32 torch functional ops on the CPU (paths relative to /root/reference/PyTorch/LanguageModeling/BERT/):
+    modeling.py:285-301    BertEmbeddings (word + position + token-type, LayerNorm eps 1e-12, dropout)
+    modeling.py:340-384    BertSelfAttention (QK^T / sqrt(d) + (1-mask)*-10000, softmax, PV)
+    modeling.py:394-434    BertSelfOutput / BertIntermediate (tanh-GELU) / BertOutput
+    modeling.py:518-524    BertPooler (token 0, dense + tanh)
+    modeling.py:545-595    MLM head on the masked rows only (dense+GELU+LayerNorm, tied decoder + bias), NSP head
+    run_pretraining.py:75-95   BertPretrainingCriterion = CE(ignore_index=-1) MLM + CE NSP
+    lamb_amp_opt/fused_lamb/fused_lamb.py:131-258 + csrc/multi_tensor_lamb.cu  LAMB step (oracle/lamb_oracle.py)
+    schedulers.py:123-136  PolyWarmUpScheduler
+Dropout probabilities are 0 in parity runs (CPU and GPU RNG streams differ).
+Pinned by tests/golden/bert_step.npz: per-step losses of the reference's own BertForPreTraining module with the
+oracle's LAMB (the reference has no CPU LAMB), oracle/make_golden.py gen_bert.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as TF
+
+from . import lamb_oracle as L
+
+
+def param_shapes(cfg):
+    h, i, v, p, t = cfg["hidden"], cfg["intermediate"], cfg["vocab"], cfg["max_pos"], cfg["type_vocab"]
+    out = [("bert.embeddings.word_embeddings.weight", (v, h)), ("bert.embeddings.position_embeddings.weight", (p, h)),
+           ("bert.embeddings.token_type_embeddings.weight", (t, h)),
+           ("bert.embeddings.LayerNorm.weight", (h,)), ("bert.embeddings.LayerNorm.bias", (h,))]
+    for l in range(cfg["layers"]):
+        pre = "bert.encoder.layer.%d." % l
+        for nm in ("query", "key", "value"):
+            out += [(pre + "attention.self.%s.weight" % nm, (h, h)), (pre + "attention.self.%s.bias" % nm, (h,))]
+        out += [(pre + "attention.output.dense.weight", (h, h)), (pre + "attention.output.dense.bias", (h,)),
+                (pre + "attention.output.LayerNorm.weight", (h,)), (pre + "attention.output.LayerNorm.bias", (h,)),
+                (pre + "intermediate.dense_act.weight", (i, h)), (pre + "intermediate.dense_act.bias", (i,)),
+                (pre + "output.dense.weight", (h, i)), (pre + "output.dense.bias", (h,)),
+                (pre + "output.LayerNorm.weight", (h,)), (pre + "output.LayerNorm.bias", (h,))]
+    out += [("bert.pooler.dense_act.weight", (h, h)), ("bert.pooler.dense_act.bias", (h,)),
+            ("cls.predictions.bias", (v,)),
+            ("cls.predictions.transform.dense_act.weight", (h, h)), ("cls.predictions.transform.dense_act.bias", (h,)),
+            ("cls.predictions.transform.LayerNorm.weight", (h,)), ("cls.predictions.transform.LayerNorm.bias", (h,)),
+            ("cls.seq_relationship.weight", (2, h)), ("cls.seq_relationship.bias", (2,))]
+    return out
+
+
+def seeded_state(cfg, seed):
+    """normal(0, 0.02) weights like init_bert_weights (modeling.py:705-720), non-trivial LayerNorm affine and
+    small biases so that parity tests exercise them."""
+    rng = np.random.default_rng(seed)
+    st = {}
+    for name, shape in param_shapes(cfg):
+        if "LayerNorm.weight" in name:
+            a = rng.uniform(0.8, 1.2, shape)
+        elif name.endswith(".bias"):
+            a = rng.standard_normal(shape) * 0.02
+        else:
+            a = rng.standard_normal(shape) * 0.02
+        st[name] = torch.from_numpy(a.astype(np.float32))
+    return st
+
+
+def seeded_batch(cfg, seed, batch, masked_per_seq=None):
+    """lddl-shaped synthetic batch (run_pretraining.py:603-609): int64 ids/types/mask/labels, NSP labels."""
+    rng = np.random.default_rng(seed)
+    s, v = cfg["seq"], cfg["real_vocab"]
+    ids = rng.integers(0, v, (batch, s)).astype(np.int64)
+    split = rng.integers(s // 4, 3 * s // 4, batch)
+    tt = (np.arange(s)[None, :] >= split[:, None]).astype(np.int64)
+    lens = rng.integers(3 * s // 4, s + 1, batch)
+    mask = (np.arange(s)[None, :] < lens[:, None]).astype(np.int64)
+    labels = -np.ones((batch, s), np.int64)
+    k = masked_per_seq or max(1, (20 * s) // 128)
+    for b in range(batch):
+        pos = rng.choice(int(lens[b]), k, replace=False)
+        labels[b, pos] = rng.integers(0, v, k)
+    nsp = rng.integers(0, 2, batch).astype(np.int64)
+    return tuple(torch.from_numpy(a) for a in (ids, tt, mask, labels, nsp))
+
+
+def gelu(x):
+    return TF.gelu(x, approximate="tanh")
+
+
+def poly_warmup_lr(step_after, base_lr, warmup, total_steps, degree=0.5):
+    """schedulers.py:123-136 with last_epoch = step + 1."""
+    progress = step_after / total_steps
+    return base_lr * progress / warmup if progress < warmup else base_lr * ((1.0 - progress) ** degree)
+
+
+class BertOracle:
+    def __init__(self, cfg, state, lr=6e-3, warmup=0.2843, total_steps=7038, weight_decay=0.01, max_grad_norm=1.0):
+        self.cfg = cfg
+        self.p = {k: v.clone().float().requires_grad_(True) for k, v in state.items()}
+        self.m = {k: np.zeros(tuple(v.shape), np.float32) for k, v in state.items()}
+        self.v = {k: np.zeros(tuple(v.shape), np.float32) for k, v in state.items()}
+        self.step_count = 0
+        self.lr, self.warmup, self.total, self.wd, self.max_norm = lr, warmup, total_steps, weight_decay, max_grad_norm
+
+    def forward(self, ids, tt, mask, labels):
+        p, c = self.p, self.cfg
+        b, s = ids.shape
+        h, nh = c["hidden"], c["heads"]
+        d = h // nh
+        e = (p["bert.embeddings.word_embeddings.weight"][ids] + p["bert.embeddings.position_embeddings.weight"][:s][None]
+             + p["bert.embeddings.token_type_embeddings.weight"][tt])
+        x = TF.layer_norm(e, (h,), p["bert.embeddings.LayerNorm.weight"], p["bert.embeddings.LayerNorm.bias"], 1e-12)
+        ext = (1.0 - mask.float())[:, None, None, :] * -10000.0
+        for l in range(c["layers"]):
+            pre = "bert.encoder.layer.%d." % l
+            lin = lambda t, n: TF.linear(t, p[pre + n + ".weight"], p[pre + n + ".bias"])
+            q = lin(x, "attention.self.query").view(b, s, nh, d).transpose(1, 2)
+            k = lin(x, "attention.self.key").view(b, s, nh, d).transpose(1, 2)
+            v = lin(x, "attention.self.value").view(b, s, nh, d).transpose(1, 2)
+            sc = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d) + ext
+            ctx = torch.matmul(torch.softmax(sc, -1), v).transpose(1, 2).reshape(b, s, h)
+            a = TF.layer_norm(lin(ctx, "attention.output.dense") + x, (h,), p[pre + "attention.output.LayerNorm.weight"],
+                              p[pre + "attention.output.LayerNorm.bias"], 1e-12)
+            it = gelu(lin(a, "intermediate.dense_act"))
+            x = TF.layer_norm(lin(it, "output.dense") + a, (h,), p[pre + "output.LayerNorm.weight"],
+                              p[pre + "output.LayerNorm.bias"], 1e-12)
+        pooled = torch.tanh(TF.linear(x[:, 0], p["bert.pooler.dense_act.weight"], p["bert.pooler.dense_act.bias"]))
+        flat = x.reshape(-1, h)
+        sel = torch.nonzero(labels.reshape(-1) != -1).squeeze(1)
+        t = gelu(TF.linear(flat[sel], p["cls.predictions.transform.dense_act.weight"],
+                           p["cls.predictions.transform.dense_act.bias"]))
+        t = TF.layer_norm(t, (h,), p["cls.predictions.transform.LayerNorm.weight"],
+                          p["cls.predictions.transform.LayerNorm.bias"], 1e-12)
+        scores = TF.linear(t, p["bert.embeddings.word_embeddings.weight"]) + p["cls.predictions.bias"]
+        nsp = TF.linear(pooled, p["cls.seq_relationship.weight"], p["cls.seq_relationship.bias"])
+        return scores, nsp, sel
+
+    def loss(self, ids, tt, mask, labels, nsp_labels):
+        scores, nsp, sel = self.forward(ids, tt, mask, labels)
+        mlm = TF.cross_entropy(scores, labels.reshape(-1)[sel])
+        return mlm + TF.cross_entropy(nsp, nsp_labels)
+
+    def step(self, ids, tt, mask, labels, nsp_labels):
+        for v in self.p.values():
+            v.grad = None
+        loss = self.loss(ids, tt, mask, labels, nsp_labels)
+        loss.backward()
+        self.lamb_update({k: v.grad.numpy() for k, v in self.p.items()})
+        return float(loss.detach())
+
+    def lamb_update(self, grads):
+        """FusedLAMBAMP.step (fused_lamb.py:131-258): global grad norm over ALL params, two groups (decay / no decay
+        for bias, LayerNorm: run_pretraining.py:422-427), adam_w_mode, grad averaging, bias correction."""
+        names = list(self.p)
+        gn, _ = L.l2norm([grads[k] for k in names])
+        self.step_count += 1
+        lr = poly_warmup_lr(self.step_count, self.lr, self.warmup, self.total)
+        no_decay = ("bias", "gamma", "beta", "LayerNorm")
+        for group_wd, sel in ((self.wd, [k for k in names if not any(nd in k for nd in no_decay)]),
+                              (0.0, [k for k in names if any(nd in k for nd in no_decay)])):
+            g = [grads[k] for k in sel]
+            pp = [self.p[k].detach().numpy() for k in sel]
+            _, p2, m2, v2, _ = L.lamb_step(g, pp, [self.m[k] for k in sel], [self.v[k] for k in sel], lr, 0.9, 0.999,
+                                           1e-6, self.step_count, True, group_wd, True, 1, gn, np.float32(self.max_norm))
+            for k, a, b, c in zip(sel, p2, m2, v2):
+                with torch.no_grad():
+                    self.p[k].copy_(torch.from_numpy(a))
+                self.m[k], self.v[k] = b, c
+
+
+BERT_TINY = dict(hidden=256, heads=4, layers=2, intermediate=1024, vocab=1024, real_vocab=1000, max_pos=512,
+                 type_vocab=2, seq=128)
+BERT_STEP_CONFIG = dict(cfg=BERT_TINY, seed=21, batch=4, steps=5, lr=6e-3, warmup=0.2843, total_steps=20)

@@ -189,6 +189,53 @@ def gen_rn50():
     print("rn50 losses", losses, "oracle", ol, "sensitivity to 1e-6 input noise", sens)
 
 
+def gen_bert():
+    """Per-step losses of the REFERENCE's BertForPreTraining (eager CPU, dropout 0) + the oracle's LAMB."""
+    from oracle import bert_oracle as BO
+    ref = R.import_bert()
+    c = BO.BERT_STEP_CONFIG
+    cfg = c["cfg"]
+    conf = ref.modeling.BertConfig(cfg["vocab"], hidden_size=cfg["hidden"], num_hidden_layers=cfg["layers"],
+                                   num_attention_heads=cfg["heads"], intermediate_size=cfg["intermediate"],
+                                   hidden_act="gelu", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                                   max_position_embeddings=cfg["max_pos"], type_vocab_size=cfg["type_vocab"])
+    conf.output_all_encoded_layers = False
+    model = ref.modeling.BertForPreTraining(conf, sequence_output_is_dense=True)
+    state0 = BO.seeded_state(cfg, c["seed"])
+    names = [n for n, _ in model.named_parameters()]
+    assert sorted(names) == sorted(state0), (set(names) ^ set(state0))
+    model.load_state_dict({k: v.clone() for k, v in state0.items()}, strict=False)
+    model.train()
+    ids, tt, mask, labels, nsp = BO.seeded_batch(cfg, c["seed"] + 1, c["batch"])
+    orc = BO.BertOracle(cfg, state0, c["lr"], c["warmup"], c["total_steps"])
+    loss_fn = torch.nn.CrossEntropyLoss(ignore_index=-1)
+    losses, ol = [], []
+    for _ in range(c["steps"]):
+        # reference forward/backward on the oracle's current weights (LAMB has no CPU reference implementation)
+        model.load_state_dict({k: v.detach().clone() for k, v in orc.p.items()}, strict=False)
+        model.zero_grad()
+        scores, nsp_scores = model(ids, tt, mask, labels)
+        flat = labels.view(-1)
+        loss = loss_fn(scores.view(-1, cfg["vocab"]), flat[flat != -1]) + loss_fn(nsp_scores.view(-1, 2), nsp.view(-1))
+        loss.backward()
+        losses.append(float(loss.detach()))
+        lo = orc.loss(ids, tt, mask, labels, nsp)
+        ol.append(float(lo.detach()))
+        for v in orc.p.values():
+            v.grad = None
+        lo.backward()
+        # gradients of the restatement == gradients of the reference module
+        for k, v in model.named_parameters():
+            assert torch.allclose(v.grad, orc.p[k].grad, rtol=2e-3, atol=2e-6), k
+        orc.lamb_update({k: v.grad.numpy() for k, v in model.named_parameters()})
+    assert np.allclose(ol, losses, rtol=1e-5), (ol, losses)
+    np.savez_compressed(os.path.join(GOLD, "bert_step.npz"), losses=np.asarray(losses, np.float64),
+                        final_pooler_bias=orc.p["bert.pooler.dense_act.bias"].detach().numpy(),
+                        final_ln_weight=orc.p["bert.encoder.layer.1.output.LayerNorm.weight"].detach().numpy(),
+                        final_query_row=orc.p["bert.encoder.layer.0.attention.self.query.weight"].detach().numpy()[:4])
+    print("bert losses", losses)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dlrm", "dlrm_step", "rn50", "lamb", "bert"]
     os.makedirs(GOLD, exist_ok=True)
