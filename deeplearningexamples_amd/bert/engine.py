@@ -1,0 +1,353 @@
+"""BERT pre-training step on MI355X: BertForPreTraining forward, MLM + NSP loss, backward, LAMB.
+
+Mirrors the reference's step (LanguageModeling/BERT/):
+    run_pretraining.py:518-524   take_training_step: autocast forward, criterion, scaled backward
+    run_pretraining.py:527-536   take_optimizer_step: lr_scheduler.step(); grad_scaler.step(LAMB); update; zero_grad
+    run_pretraining.py:75-95     BertPretrainingCriterion (dense MLM rows, CE ignore_index -1, + NSP CE)
+    modeling.py:263-595,788-958  the model (module tree / parameter names in model.py)
+    lamb_amp_opt/fused_lamb/fused_lamb.py:131-258  FusedLAMBAMP.step: global grad norm (of the SCALED grads) vs
+                                 max_grad_norm * scale, step += (found_inf == 0), two param groups
+    schedulers.py:109-136        PolyWarmUpScheduler (degree 0.5)
+    run_pretraining.py:679-681   gradient accumulation with no_sync (here: `accumulate` micro-steps add into the flat
+                                 fp32 gradient; the data-parallel all-reduce runs once per optimizer step)
+Token-major layout [B*S, H]; the per-(sequence, head) attention contractions are batched GEMMs over strided
+slices of the fused QKV activation, scores/probabilities are kept for the backward pass.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from .. import _cabi as C
+from .. import functional as F
+from .. import multi_tensor as mt
+from ..dlrm.engine import GradScalerState
+from .model import BertForPreTraining
+
+NO_DECAY = ("bias", "gamma", "beta", "LayerNorm")      # run_pretraining.py:423
+
+
+class BertTrainer:
+    def __init__(self, model: BertForPreTraining, lr=6e-3, warmup=0.2843, total_steps=7038, weight_decay=0.01,
+                 max_grad_norm=1.0, compute_dtype=torch.bfloat16, init_loss_scale=2.0 ** 20, world_size=1,
+                 process_group=None):
+        self.model, self.cfg = model, model.config
+        self.dev = model.bert.embeddings.word_embeddings.weight.device
+        self.dtype = compute_dtype
+        self.base_lr, self.warmup, self.total = lr, warmup, total_steps
+        self.wd, self.max_norm = weight_decay, max_grad_norm
+        self.world, self.pg = world_size, process_group
+        self.scaler = GradScalerState(self.dev, enabled=compute_dtype == torch.float16, init_scale=init_loss_scale,
+                                      growth_interval=2000)
+        dev = self.dev
+        model.fuse_qkv_storage()
+        named = self._ordered_named_parameters(model)
+        self.names = [n for n, _ in named]
+        self.params = [p for _, p in named]
+        total = sum(p.numel() for p in self.params)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.gview, o = {}, 0
+        for n, p in named:
+            self.gview[n] = self.flat_grad[o:o + p.numel()].view(p.shape)
+            o += p.numel()
+        self._qkv_grad_contiguity_check()
+        self.exp_avg = {n: torch.zeros_like(p.data) for n, p in named}
+        self.exp_avg_sq = {n: torch.zeros_like(p.data) for n, p in named}
+        # 16-bit working copies of every matrix that feeds a GEMM
+        self.w16 = {}
+        h = self.cfg["hidden"]
+        for l, layer in enumerate(model.bert.encoder.layer):
+            pre = "bert.encoder.layer.%d." % l
+            qkv16 = torch.empty((3 * h, h), dtype=compute_dtype, device=dev)
+            for i, nm in enumerate(("query", "key", "value")):
+                self.w16[pre + "attention.self.%s.weight" % nm] = qkv16[i * h:(i + 1) * h]
+            layer.qkv16 = qkv16
+            for nm in ("attention.output.dense", "intermediate.dense_act", "output.dense"):
+                self.w16[pre + nm + ".weight"] = torch.empty_like(dict(named)[pre + nm + ".weight"].data, dtype=compute_dtype)
+        for nm in ("bert.pooler.dense_act.weight", "cls.predictions.transform.dense_act.weight",
+                   "bert.embeddings.word_embeddings.weight"):
+            self.w16[nm] = torch.empty_like(dict(named)[nm].data, dtype=compute_dtype)
+        self.names = [n for n, _ in named]
+        self.nsp16 = torch.zeros((8, h), dtype=compute_dtype, device=dev)          # 2 -> 8 rows (16-byte rows of dlogits)
+        self.w16["cls.seq_relationship.weight"] = self.nsp16[:2]
+        self.nsp_bias8 = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.refresh_working_copies()
+        self._build_tables()
+        self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.lr_t = torch.zeros((), dtype=torch.float32, device=dev)
+        self.max_norm_t = torch.full((1,), max_grad_norm, dtype=torch.float32, device=dev)
+        self.one = torch.ones(1, dtype=torch.float32, device=dev)
+        self.noop = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.opt_steps = 0
+        self._batch_key, self._sel, self._idx0, self._mask_add, self._dense_labels = None, None, None, None, None
+        self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
+
+    # ------------------------------------------------------------------ plumbing
+    @staticmethod
+    def _ordered_named_parameters(model):
+        """named_parameters() with each layer's q/k/v weights (then biases) adjacent, so their gradients form one
+        [3H, H] / [3H] block of the flat gradient buffer (the fused QKV wgrad writes it in one GEMM)."""
+        named = list(model.named_parameters())
+        out, seen = [], set()
+        d = dict(named)
+        for n, p in named:
+            if n in seen:
+                continue
+            if ".attention.self." in n:
+                pre = n[:n.index(".attention.self.") + len(".attention.self.")]
+                for suffix in ("weight", "bias"):
+                    for nm in ("query", "key", "value"):
+                        k = pre + nm + "." + suffix
+                        out.append((k, d[k])); seen.add(k)
+            else:
+                out.append((n, p)); seen.add(n)
+        return out
+
+    def _qkv_grad_contiguity_check(self):
+        for l in range(self.cfg["layers"]):
+            pre = "bert.encoder.layer.%d.attention.self." % l
+            gq, gk, gv = (self.gview[pre + n + ".weight"] for n in ("query", "key", "value"))
+            assert gk.data_ptr() == gq.data_ptr() + gq.numel() * 4 and gv.data_ptr() == gk.data_ptr() + gk.numel() * 4
+            bq, bk, bv = (self.gview[pre + n + ".bias"] for n in ("query", "key", "value"))
+            assert bk.data_ptr() == bq.data_ptr() + bq.numel() * 4 and bv.data_ptr() == bk.data_ptr() + bk.numel() * 4
+
+    def refresh_working_copies(self):
+        named = dict(self.model.named_parameters())
+        for n, c in self.w16.items():
+            F.cast(named[n].data, self.dtype, out=c)
+        self.nsp_bias8[:2].copy_(named["cls.seq_relationship.bias"].data)
+
+    def _build_tables(self):
+        named = dict(zip(self.names, self.params))
+        groups = {"decay_copy": ([], [], [], [], []), "decay": ([], [], [], []), "nodecay": ([], [], [], [])}
+        for n, p in named.items():
+            key = "nodecay" if any(nd in n for nd in NO_DECAY) else ("decay_copy" if n in self.w16 else "decay")
+            lists = groups[key]
+            for lst, t in zip(lists, (self.gview[n], p.data, self.exp_avg[n], self.exp_avg_sq[n])):
+                lst.append(t)
+            if key == "decay_copy":
+                lists[4].append(self.w16[n])
+        self.tables = {}
+        for key, lists in groups.items():
+            if not lists[0]:
+                continue
+            g, p, m, v = lists[:4]
+            self.tables[key] = dict(
+                wd=0.0 if key == "nodecay" else self.wd,
+                t_p=mt.TensorTable([p]), t_g=mt.TensorTable([g]), t_s1=mt.TensorTable([g, p, m, v]),
+                t_s2=mt.TensorTable([g, p, lists[4]] if key == "decay_copy" else [g, p]))
+        self.t_all_grads = mt.TensorTable([[self.flat_grad]])
+
+    def _prepare_batch(self, input_ids, attention_mask, labels):
+        key = (input_ids.data_ptr(), labels.data_ptr(), attention_mask.data_ptr(), tuple(input_ids.shape))
+        if key == self._batch_key:
+            return
+        b, s = input_ids.shape
+        flat = labels.reshape(-1)
+        self._sel = torch.nonzero(flat != -1).squeeze(1)            # data-dependent size: one host sync per new batch,
+        self._dense_labels = flat[self._sel].contiguous()          # like the reference's index_select (modeling.py:590)
+        self._idx0 = torch.arange(b, device=self.dev, dtype=torch.int64) * s
+        self._mask_add = ((1.0 - attention_mask.to(torch.float32)) * -10000.0).contiguous()
+        self._batch_key = key
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input_ids, token_type_ids, attention_mask, labels, next_sentence_labels):
+        cfg, m, dt = self.cfg, self.model, self.dtype
+        h, nh, inter, v = cfg["hidden"], cfg["heads"], cfg["intermediate"], cfg["vocab"]
+        d = h // nh
+        b, s = input_ids.shape
+        t = b * s
+        self._prepare_batch(input_ids, attention_mask, labels)
+        emb = m.bert.embeddings
+        ids, tts = input_ids.reshape(-1).contiguous(), token_type_ids.reshape(-1).contiguous()
+        z0 = F.embed_sum(emb.word_embeddings.weight.data, emb.position_embeddings.weight.data,
+                         emb.token_type_embeddings.weight.data, ids, tts, s, dt)
+        x, _, mean0, rstd0 = F.layernorm_fwd(z0, emb.LayerNorm.weight.data, emb.LayerNorm.bias.data)
+        sv = {"ids": ids, "tt": tts, "z0": z0, "ln0": (mean0, rstd0), "layers": [], "b": b, "s": s}
+        scale = 1.0 / math.sqrt(d)
+        for l, layer in enumerate(m.bert.encoder.layer):
+            pre = "bert.encoder.layer.%d." % l
+            att = layer.attention
+            qkv = F.gemm(x, layer.qkv16, t, 3 * h, h, True, True, bias=layer.qkv_bias)
+            probs = torch.empty((b * nh, s, s), dtype=dt, device=self.dev)
+            F.gemm_batched(qkv, qkv[:, h:], probs, s, s, d, 3 * h, 3 * h, s, True, True, b * nh, nh,
+                           (s * 3 * h, d), (s * 3 * h, d), (nh * s * s, s * s))
+            F.softmax_fwd_(probs, self._mask_add, nh * s, scale)
+            ctx = torch.empty((t, h), dtype=dt, device=self.dev)
+            F.gemm_batched(probs, qkv[:, 2 * h:], ctx, s, d, s, s, 3 * h, h, True, False, b * nh, nh,
+                           (nh * s * s, s * s), (s * 3 * h, d), (s * h, d))
+            ao = F.gemm(ctx, self.w16[pre + "attention.output.dense.weight"], t, h, h, True, True,
+                        bias=att.output.dense.bias.data)
+            x1, z1, m1, r1 = F.layernorm_fwd(ao, att.output.LayerNorm.weight.data, att.output.LayerNorm.bias.data, residual=x)
+            pre_act = torch.empty((t, inter), dtype=dt, device=self.dev)
+            it = F.gemm(x1, self.w16[pre + "intermediate.dense_act.weight"], t, inter, h, True, True,
+                        bias=layer.intermediate.dense_act.bias.data, act=C.ACT_GELU, aux=pre_act)
+            o2 = F.gemm(it, self.w16[pre + "output.dense.weight"], t, h, inter, True, True, bias=layer.output.dense.bias.data)
+            x2, z2, m2, r2 = F.layernorm_fwd(o2, layer.output.LayerNorm.weight.data, layer.output.LayerNorm.bias.data, residual=x1)
+            sv["layers"].append(dict(x=x, qkv=qkv, probs=probs, ctx=ctx, z1=z1, ln1=(m1, r1), x1=x1, pre=pre_act, it=it,
+                                     z2=z2, ln2=(m2, r2)))
+            x = x2
+        sv["seq"] = x
+        # pooler + NSP head
+        first = F.rows_gather(x, self._idx0)
+        pooled = F.gemm(first, self.w16["bert.pooler.dense_act.weight"], b, h, h, True, True,
+                        bias=m.bert.pooler.dense_act.bias.data, act=C.ACT_TANH)
+        nsp_logits = F.gemm(pooled, self.nsp16, b, 8, h, True, True, out_dtype=torch.float32, bias=self.nsp_bias8)
+        # dense MLM head on the masked rows
+        n = self._sel.numel()
+        hm = F.rows_gather(x, self._sel)
+        tr = m.cls.predictions.transform
+        tpre = torch.empty((n, h), dtype=dt, device=self.dev)
+        tg = F.gemm(hm, self.w16["cls.predictions.transform.dense_act.weight"], n, h, h, True, True,
+                    bias=tr.dense_act.bias.data, act=C.ACT_GELU, aux=tpre)
+        tl, _, mt_, rt = F.layernorm_fwd(tg, tr.LayerNorm.weight.data, tr.LayerNorm.bias.data)
+        logits = F.gemm(tl, self.w16["bert.embeddings.word_embeddings.weight"], n, v, h, True, True,
+                        out_dtype=torch.float32, bias=m.cls.predictions.bias.data)
+        sv.update(first=first, pooled=pooled, hm=hm, tpre=tpre, tg=tg, lnt=(mt_, rt), tl=tl)
+        self._sv = sv
+        gs = self.scaler.scale if self.scaler.enabled else None
+        loss_mlm, dlogits = F.softmax_xent(logits, self._dense_labels, ignore_index=-1, grad_scale=gs, grad_dtype=dt)
+        loss_nsp, dnsp = F.softmax_xent(nsp_logits[:, :2], next_sentence_labels, ignore_index=-1, grad_scale=gs,
+                                        grad_dtype=dt, ld_out=8)
+        return loss_mlm + loss_nsp, dlogits, dnsp
+
+    # ------------------------------------------------------------------ backward
+    def _wgrad(self, name, g, x, accumulate):
+        gw = self.gview[name]
+        nout, kin = gw.shape
+        F.gemm(g, x, nout, kin, g.shape[0], False, False, out=gw, splitk=F.pick_splitk(nout, kin, g.shape[0], 1024),
+               accumulate=accumulate)
+
+    def _bgrad(self, name, g, accumulate):
+        F.colsum(g, out=self.gview[name], accumulate=accumulate)
+
+    def backward(self, dlogits, dnsp, accumulate=False):
+        cfg, m, sv, dt = self.cfg, self.model, self._sv, self.dtype
+        h, nh, inter, v = cfg["hidden"], cfg["heads"], cfg["intermediate"], cfg["vocab"]
+        d = h // nh
+        b, s = sv["b"], sv["s"]
+        t = b * s
+        acc = accumulate
+        n = dlogits.shape[0]
+        # ---- MLM head
+        self._wgrad("bert.embeddings.word_embeddings.weight", dlogits, sv["tl"], acc)          # tied decoder
+        self._bgrad("cls.predictions.bias", dlogits, acc)
+        dtl = F.gemm(dlogits, self.w16["bert.embeddings.word_embeddings.weight"], n, h, v, True, False)
+        tr = m.cls.predictions.transform
+        dtg = F.layernorm_bwd(dtl, sv["tg"], sv["lnt"][0], sv["lnt"][1], tr.LayerNorm.weight.data,
+                              self.gview["cls.predictions.transform.LayerNorm.weight"],
+                              self.gview["cls.predictions.transform.LayerNorm.bias"], acc)
+        dtpre = F.act_bwd(dtg, sv["tpre"], C.ACT_GELU_BWD)
+        self._wgrad("cls.predictions.transform.dense_act.weight", dtpre, sv["hm"], acc)
+        self._bgrad("cls.predictions.transform.dense_act.bias", dtpre, acc)
+        dhm = F.gemm(dtpre, self.w16["cls.predictions.transform.dense_act.weight"], n, h, h, True, False)
+        dseq = torch.zeros((t, h), dtype=dt, device=self.dev)
+        F.rows_scatter_(dseq, dhm, self._sel)
+        # ---- NSP head + pooler
+        gnsp8 = torch.empty((8, h), dtype=torch.float32, device=self.dev)
+        F.gemm(dnsp, sv["pooled"], 8, h, b, False, False, out=gnsp8)
+        gw = self.gview["cls.seq_relationship.weight"]
+        if acc:
+            gw.add_(gnsp8[:2])
+        else:
+            gw.copy_(gnsp8[:2])
+        gb8 = F.colsum(dnsp)
+        gb = self.gview["cls.seq_relationship.bias"]
+        if acc:
+            gb.add_(gb8[:2])
+        else:
+            gb.copy_(gb8[:2])
+        dpool_pre = F.gemm(dnsp, self.nsp16, b, h, 8, True, False, act=C.ACT_TANH_BWD, mask_src=sv["pooled"])
+        self._wgrad("bert.pooler.dense_act.weight", dpool_pre, sv["first"], acc)
+        self._bgrad("bert.pooler.dense_act.bias", dpool_pre, acc)
+        dfirst = F.gemm(dpool_pre, self.w16["bert.pooler.dense_act.weight"], b, h, h, True, False)
+        F.rows_scatter_(dseq, dfirst, self._idx0, accumulate=True)
+        # ---- encoder
+        dx = dseq
+        scale = 1.0 / math.sqrt(d)
+        for l in range(cfg["layers"] - 1, -1, -1):
+            layer, a = m.bert.encoder.layer[l], sv["layers"][l]
+            pre = "bert.encoder.layer.%d." % l
+            dz2 = F.layernorm_bwd(dx, a["z2"], a["ln2"][0], a["ln2"][1], layer.output.LayerNorm.weight.data,
+                                  self.gview[pre + "output.LayerNorm.weight"], self.gview[pre + "output.LayerNorm.bias"], acc)
+            self._wgrad(pre + "output.dense.weight", dz2, a["it"], acc)
+            self._bgrad(pre + "output.dense.bias", dz2, acc)
+            dpre = F.gemm(dz2, self.w16[pre + "output.dense.weight"], t, inter, h, True, False, act=C.ACT_GELU_BWD,
+                          mask_src=a["pre"])
+            self._wgrad(pre + "intermediate.dense_act.weight", dpre, a["x1"], acc)
+            self._bgrad(pre + "intermediate.dense_act.bias", dpre, acc)
+            dx1 = F.gemm(dpre, self.w16[pre + "intermediate.dense_act.weight"], t, h, inter, True, False, act=C.ACT_ADD,
+                         mask_src=dz2)
+            dz1 = F.layernorm_bwd(dx1, a["z1"], a["ln1"][0], a["ln1"][1], layer.attention.output.LayerNorm.weight.data,
+                                  self.gview[pre + "attention.output.LayerNorm.weight"],
+                                  self.gview[pre + "attention.output.LayerNorm.bias"], acc)
+            self._wgrad(pre + "attention.output.dense.weight", dz1, a["ctx"], acc)
+            self._bgrad(pre + "attention.output.dense.bias", dz1, acc)
+            dctx = F.gemm(dz1, self.w16[pre + "attention.output.dense.weight"], t, h, h, True, False)
+            qkv, probs = a["qkv"], a["probs"]
+            dprobs = torch.empty_like(probs)
+            F.gemm_batched(dctx, qkv[:, 2 * h:], dprobs, s, s, d, h, 3 * h, s, True, True, b * nh, nh,
+                           (s * h, d), (s * 3 * h, d), (nh * s * s, s * s))
+            F.softmax_bwd_(probs, dprobs, scale)
+            dqkv = torch.empty((t, 3 * h), dtype=dt, device=self.dev)
+            F.gemm_batched(dprobs, qkv[:, h:], dqkv, s, d, s, s, 3 * h, 3 * h, True, False, b * nh, nh,
+                           (nh * s * s, s * s), (s * 3 * h, d), (s * 3 * h, d))                         # dQ = dS K
+            F.gemm_batched(dprobs, qkv, dqkv[:, h:], s, d, s, s, 3 * h, 3 * h, False, False, b * nh, nh,
+                           (nh * s * s, s * s), (s * 3 * h, d), (s * 3 * h, d))                         # dK = dS^T Q
+            F.gemm_batched(probs, dctx, dqkv[:, 2 * h:], s, d, s, s, h, 3 * h, False, False, b * nh, nh,
+                           (nh * s * s, s * s), (s * h, d), (s * 3 * h, d))                             # dV = P^T dO
+            gq = self.gview[pre + "attention.self.query.weight"]
+            gqkv = torch.as_strided(gq, (3 * h, h), (h, 1))
+            F.gemm(dqkv, a["x"], 3 * h, h, t, False, False, out=gqkv, splitk=F.pick_splitk(3 * h, h, t, 1024), accumulate=acc)
+            gbq = self.gview[pre + "attention.self.query.bias"]
+            F.colsum(dqkv, out=torch.as_strided(gbq, (3 * h,), (1,)), accumulate=acc)
+            dx = F.gemm(dqkv, layer.qkv16, t, h, 3 * h, True, False, act=C.ACT_ADD, mask_src=dz1)
+        # ---- embeddings
+        emb = m.bert.embeddings
+        dz0 = F.layernorm_bwd(dx, sv["z0"], sv["ln0"][0], sv["ln0"][1], emb.LayerNorm.weight.data,
+                              self.gview["bert.embeddings.LayerNorm.weight"], self.gview["bert.embeddings.LayerNorm.bias"], acc)
+        F.embed_scatter_add_(self.gview["bert.embeddings.word_embeddings.weight"], dz0, sv["ids"])
+        gpos = self.gview["bert.embeddings.position_embeddings.weight"]
+        if not acc:
+            gpos[s:].zero_()
+        F.colsum(dz0.view(b, s * h), out=gpos[:s].view(-1), accumulate=acc)
+        F.rows_select_sum(dz0, sv["tt"], cfg["type_vocab"], self.gview["bert.embeddings.token_type_embeddings.weight"], acc)
+        self._sv = None
+
+    # ------------------------------------------------------------------ optimizer
+    def current_lr(self):
+        progress = (self.opt_steps + 1) / self.total
+        if progress < self.warmup:
+            return self.base_lr * progress / self.warmup
+        return self.base_lr * ((1.0 - progress) ** 0.5)
+
+    def optimizer_step(self):
+        sc = self.scaler
+        if self.world > 1:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.AVG, group=self.pg)
+        self.noop.zero_()
+        if sc.enabled:
+            F.check_nonfinite_(self.flat_grad, sc.found_inf)
+            self.noop.copy_(sc.found_inf.to(torch.int32))
+        self.lr_t.fill_(self.current_lr())
+        self.step_t += (1 - self.noop)
+        gnorm, _ = mt.l2norm(self.t_all_grads, self.noop)
+        scale = sc.scale if sc.enabled else self.one
+        inv = sc.inv_scale if sc.enabled else self.one
+        max_norm = self.max_norm_t * scale
+        for key, tb in self.tables.items():
+            _, pn = mt.l2norm(tb["t_p"], self.noop, per_tensor=True)
+            mt.lamb_stage1(tb["t_s1"], self.noop, 0.9, 0.999, 1.0 - 0.9, self.step_t, True, 1e-6, 1, tb["wd"], gnorm,
+                           max_norm, inv)
+            _, un = mt.l2norm(tb["t_g"], self.noop, per_tensor=True)
+            mt.lamb_stage2(tb["t_s2"], self.noop, pn, un, self.lr_t, tb["wd"], False)
+        self.nsp_bias8[:2].copy_(self.model.cls.seq_relationship.bias.data)
+        sc.update()
+        self.opt_steps += 1
+
+    def train_step(self, input_ids, token_type_ids, attention_mask, labels, next_sentence_labels):
+        """One optimizer step on one micro-batch.  Returns the device-resident fp32 loss [1]."""
+        loss, dlogits, dnsp = self.forward(input_ids, token_type_ids, attention_mask, labels, next_sentence_labels)
+        self.backward(dlogits, dnsp)
+        self.optimizer_step()
+        return loss

@@ -280,3 +280,43 @@ extern "C" int dle_relu_bwd(const void* g, const void* y, void* out, int64_t row
   DLE_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- activation backward on flat 16-bit arrays: out = g * act'(src) ---------------------------------------
+// act = 5 (DLE_ACT_GELU_BWD): src = pre-activation of the tanh-GELU (LanguageModeling/BERT/modeling.py:121-122)
+// act = 7 (DLE_ACT_TANH_BWD): src = tanh output.  Used where the incoming gradient is not produced by a GEMM
+// (after a LayerNorm backward); GEMM producers fuse the same math in their epilogue.
+template <int DT>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const unsigned short* __restrict__ g,
+                                                      const unsigned short* __restrict__ src,
+                                                      unsigned short* __restrict__ out, long long n8, int act) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const ushort8_t gv = ((const ushort8_t*)g)[i], sv = ((const ushort8_t*)src)[i];
+    ushort8_t o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float y = Elem<DT>::to_f32(sv[k]);
+      float d;
+      if (act == 7) d = 1.f - y * y;
+      else {
+        const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+        const float th = tanhf(k0 * (y + k1 * y * y * y));
+        d = 0.5f * (1.f + th) + 0.5f * y * (1.f - th * th) * k0 * (1.f + 3.f * k1 * y * y);
+      }
+      o[k] = Elem<DT>::from_f32(Elem<DT>::to_f32(gv[k]) * d);
+    }
+    ((ushort8_t*)out)[i] = o;
+  }
+}
+
+extern "C" int dle_act_bwd(const void* g, const void* src, void* out, int64_t n, int act, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "act_bwd: 16-bit dtypes only");
+  DLE_CHECK_ARG(act == 5 || act == 7, "act_bwd: act must be DLE_ACT_GELU_BWD or DLE_ACT_TANH_BWD");
+  DLE_CHECK_ARG(n >= 0 && n % 8 == 0, "act_bwd: element count must be a multiple of 8");
+  if (n == 0) return 0;
+  DLE_CHECK_ARG(g && src && out, "act_bwd: null pointer");
+  const int grid = ew_grid(n / 8, 256);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(act_bwd_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)g, (const unsigned short*)src, (unsigned short*)out, (long long)(n / 8), act);
+  else hipLaunchKernelGGL(act_bwd_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)g, (const unsigned short*)src, (unsigned short*)out, (long long)(n / 8), act);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}

@@ -248,8 +248,10 @@ __global__ __launch_bounds__(MT_BLOCK) void mt_lamb_stage1(const long long* __re
 }
 
 // -------------------------------------------------------------------- LAMB stage 2
-// lists: 0 = update (GT), 1 = p (fp32), [2 = low-precision model copy (GT)]   multi_tensor_lamb.cu:251-368
-template <int GT, bool HAS_OUT>
+// lists: 0 = update (GT), 1 = p (fp32), [2 = low-precision model copy (CT)]   multi_tensor_lamb.cu:251-368
+// CT = -1: no copy.  (The reference's copy always has the gradient's dtype -- fp16 params with fp16 grads,
+// multi_tensor_lamb.cu:320-327; here fp32 gradients may feed a 16-bit working copy, so CT is independent.)
+template <int GT, int CT>
 __global__ __launch_bounds__(MT_BLOCK) void mt_lamb_stage2(const long long* __restrict__ table, int n, int chunk,
                                                            const int* __restrict__ noop,
                                                            const float* __restrict__ param_norm,
@@ -271,8 +273,10 @@ __global__ __launch_bounds__(MT_BLOCK) void mt_lamb_stage2(const long long* __re
   }
   const typename MtIO<GT>::T* u = (const typename MtIO<GT>::T*)t.ptr[0 * n + ti] + off;
   float* p = (float*)t.ptr[1 * n + ti] + off;
-  typename MtIO<GT>::T* o = HAS_OUT ? (typename MtIO<GT>::T*)t.ptr[2 * n + ti] + off : nullptr;
-  const bool vec = ((((uintptr_t)u) | ((uintptr_t)p) | ((uintptr_t)o)) & 15) == 0;
+  constexpr bool HAS_OUT = CT >= 0;
+  constexpr int OT = CT >= 0 ? CT : DLE_F32;
+  typename MtIO<OT>::T* o = HAS_OUT ? (typename MtIO<OT>::T*)t.ptr[2 * n + ti] + off : nullptr;
+  const bool vec = ((((uintptr_t)u) | ((uintptr_t)p)) & 15) == 0 && (((uintptr_t)o) & (OT == DLE_F32 ? 15 : 7)) == 0;
   const long long len4 = len & ~3LL;
   for (long long i = (long long)threadIdx.x * 4; i < len; i += MT_BLOCK * 4) {
     if (i < len4) {
@@ -281,12 +285,12 @@ __global__ __launch_bounds__(MT_BLOCK) void mt_lamb_stage2(const long long* __re
 #pragma unroll
       for (int k = 0; k < 4; ++k) rp[k] = rp[k] - ratio * ru[k];
       st4<DLE_F32>(p + i, rp, vec);
-      if (HAS_OUT) st4<GT>(o + i, rp, vec);
+      if (HAS_OUT) st4<OT>(o + i, rp, vec);
     } else {
       for (long long k = i; k < len; ++k) {
         const float np = p[k] - ratio * MtIO<GT>::ld(u + k);
         p[k] = np;
-        if (HAS_OUT) MtIO<GT>::st(o + k, np);
+        if (HAS_OUT) MtIO<OT>::st(o + k, np);
       }
     }
   }
@@ -421,17 +425,20 @@ extern "C" int dle_mt_lamb_stage1(const int64_t* table_dev, int n_tensors, int64
 }
 
 extern "C" int dle_mt_lamb_stage2(const int64_t* table_dev, int n_tensors, int64_t total_chunks, int chunk,
-                                  int grad_dtype, int has_model_copy, const int* noop_flag, const float* param_norm,
+                                  int grad_dtype, int copy_dtype, const int* noop_flag, const float* param_norm,
                                   const float* update_norm, const float* lr_dev, float weight_decay, int use_nvlamb,
                                   hipStream_t stream) {
+  DLE_CHECK_ARG(copy_dtype >= -1 && copy_dtype <= DLE_BF16, "mt_lamb_stage2: bad copy dtype %d", copy_dtype);
   DLE_CHECK_ARG(table_dev && param_norm && update_norm && lr_dev, "mt_lamb_stage2: null pointer");
   if (n_tensors == 0 || total_chunks == 0) return 0;
   dim3 grid((unsigned)total_chunks), block(MT_BLOCK);
-#define GO(GT, HO) hipLaunchKernelGGL((mt_lamb_stage2<GT, HO>), grid, block, 0, stream, (const long long*)table_dev, n_tensors, chunk, noop_flag, param_norm, update_norm, lr_dev, weight_decay, use_nvlamb)
-  if (grad_dtype == DLE_F32) { if (has_model_copy) GO(DLE_F32, true); else GO(DLE_F32, false); }
-  else if (grad_dtype == DLE_F16) { if (has_model_copy) GO(DLE_F16, true); else GO(DLE_F16, false); }
-  else if (grad_dtype == DLE_BF16) { if (has_model_copy) GO(DLE_BF16, true); else GO(DLE_BF16, false); }
+#define GO2(GT, CT) hipLaunchKernelGGL((mt_lamb_stage2<GT, CT>), grid, block, 0, stream, (const long long*)table_dev, n_tensors, chunk, noop_flag, param_norm, update_norm, lr_dev, weight_decay, use_nvlamb)
+#define GO(GT) do { if (copy_dtype == -1) GO2(GT, -1); else if (copy_dtype == DLE_F32) GO2(GT, DLE_F32); else if (copy_dtype == DLE_F16) GO2(GT, DLE_F16); else GO2(GT, DLE_BF16); } while (0)
+  if (grad_dtype == DLE_F32) GO(DLE_F32);
+  else if (grad_dtype == DLE_F16) GO(DLE_F16);
+  else if (grad_dtype == DLE_BF16) GO(DLE_BF16);
   else { dle_set_error("mt_lamb_stage2: bad dtype %d", grad_dtype); return -1; }
+#undef GO2
 #undef GO
   DLE_LAUNCH_CHECK();
   return 0;

@@ -592,3 +592,11 @@ def softmax_bwd_(probs, dprobs, scale):
     C.annotate(bytes=float(probs.numel()) * 6, tag="L%d" % l)
     C.call("dle_softmax_bwd", C.ptr(probs), C.ptr(dprobs), rows, l, float(scale), C.dt(probs), C.stream())
     return dprobs
+
+
+def act_bwd(g, src, act):
+    """g * act'(src): act = C.ACT_GELU_BWD (src = pre-activation) or C.ACT_TANH_BWD (src = tanh output)."""
+    C.require_cuda(g, src)
+    out = torch.empty_like(g)
+    C.call("dle_act_bwd", C.ptr(g), C.ptr(src), C.ptr(out), g.numel(), act, C.dt(g), C.stream())
+    return out

@@ -85,7 +85,7 @@ def lamb_stage1(table, noop_flag, beta1, beta2, beta3, step, bias_correction, ep
 
 def lamb_stage2(table, noop_flag, param_norm, update_norm, lr, weight_decay, use_nvlamb):
     C.call("dle_mt_lamb_stage2", C.ptr(table.table), table.n, table.total_chunks, table.chunk,
-           C.dt(table.dtypes[0]), int(table.n_lists == 3), C.ptr(noop_flag), C.ptr(param_norm),
+           C.dt(table.dtypes[0]), C.dt(table.dtypes[2]) if table.n_lists == 3 else -1, C.ptr(noop_flag), C.ptr(param_norm),
            C.ptr(update_norm), C.ptr(lr), weight_decay, int(bool(use_nvlamb)), C.stream())
 
 

@@ -144,9 +144,9 @@ int dle_mt_lamb_stage1(const int64_t* table_dev, int n_tensors, int64_t total_ch
                        const int* step_dev, int bias_correction, float eps, int mode,
                        float weight_decay, const float* global_grad_norm, const float* max_grad_norm,
                        const float* inv_scale, hipStream_t stream);
-/* lists: update (grad_dtype), p (fp32) [, low-precision model copy (grad_dtype)] */
+/* lists: update (grad_dtype), p (fp32) [, model copy (copy_dtype; -1 = no copy list)] */
 int dle_mt_lamb_stage2(const int64_t* table_dev, int n_tensors, int64_t total_chunks, int chunk,
-                       int grad_dtype, int has_model_copy, const int* noop_flag,
+                       int grad_dtype, int copy_dtype, const int* noop_flag,
                        const float* param_norm, const float* update_norm, const float* lr_dev,
                        float weight_decay, int use_nvlamb, hipStream_t stream);
 /* lists: g (grad_dtype), p (fp32) [, momentum buffer (fp32)] [, low-precision model copy (copy_dtype)];
@@ -173,6 +173,8 @@ int dle_amp_update_scale(float* scale, int* growth_tracker, float* found_inf, fl
                          float growth_factor, float backoff_factor, int growth_interval,
                          int clear_found_inf, hipStream_t stream);
 int dle_check_nonfinite(const void* x, float* found_inf, int64_t n, int dtype, hipStream_t stream);
+/* out = g * act'(src) on flat 16-bit arrays; act = DLE_ACT_GELU_BWD (src = pre-activation) or DLE_ACT_TANH_BWD */
+int dle_act_bwd(const void* g, const void* src, void* out, int64_t n, int act, int dtype, hipStream_t stream);
 /* out[r,c] = y[r,c] > 0 ? g[r,c] : 0 on 16-bit strided views (nn.ReLU backward, dlrm/nn/mlps.py:85-87) */
 int dle_relu_bwd(const void* g, const void* y, void* out, int64_t rows, int cols, int64_t ld_g, int64_t ld_y,
                  int64_t ld_out, int dtype, hipStream_t stream);
