@@ -203,7 +203,69 @@ class Rn50Workload:
                           "the reference module), %d steps of batch %d at 224x224 after 1 warm-up step" % (steps, batch)}
 
 
-WORKLOADS = {"dlrm": DlrmWorkload, "rn50": Rn50Workload}
+# ------------------------------------------------------------------------------------------- BERT
+class BertWorkload:
+    """BASELINE.json configs[2]: BERT-Large phase-1 pre-training, seq 128, 20 masked tokens per sequence, bf16,
+    LAMB lr 6e-3 / warm-up 0.2843 / 7038 steps (scripts/configs/pretrain_config.sh:18-28), dropout 0,
+    synthetic Wikipedia-shaped batch (run_pretraining.py:603-609); one optimizer step per micro-batch, data
+    parallel over the ranks (gradient all-reduce, mean)."""
+
+    name = "bert"
+
+    def __init__(self, args, rank, world, device):
+        from deeplearningexamples_amd.bert.model import BertForPreTraining, LARGE
+        from deeplearningexamples_amd.bert.engine import BertTrainer
+        self.rank, self.world, self.device = rank, world, device
+        self.batch = args.batch or 128
+        self.dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+        torch.manual_seed(0)
+        self.model = BertForPreTraining(LARGE, device=device)
+        self.trainer = BertTrainer(self.model, lr=6e-3, warmup=0.2843, total_steps=7038, compute_dtype=self.dtype,
+                                   world_size=world)
+        g = torch.Generator(device="cpu").manual_seed(500 + rank)
+        b, s, v = self.batch, 128, LARGE["real_vocab"]
+        ids = torch.randint(0, v, (b, s), generator=g)
+        split = torch.randint(s // 4, 3 * s // 4, (b, 1), generator=g)
+        tt = (torch.arange(s)[None, :] >= split).long()
+        mask = torch.ones((b, s), dtype=torch.long)
+        labels = torch.full((b, s), -1, dtype=torch.long)
+        for i in range(b):
+            pos = torch.randperm(s, generator=g)[:20]
+            labels[i, pos] = torch.randint(0, v, (20,), generator=g)
+        nsp = torch.randint(0, 2, (b,), generator=g)
+        self.data = [t.to(device) for t in (ids, tt, mask, labels, nsp)]
+        self.samples_per_step = self.batch * world
+        self.scaling = "weak"
+        self.loss = None
+
+    def step(self):
+        self.loss = self.trainer.train_step(*self.data)
+
+    def config(self):
+        return {"workload": "BERT-Large phase-1 pre-training (PyTorch/LanguageModeling/BERT), seq 128, 20 masked "
+                            "tokens/sequence, LAMB, synthetic Wikipedia-shaped batch (BASELINE.json configs[2])",
+                "batch_per_gpu": self.batch, "global_batch": self.batch * self.world, "seq_len": 128,
+                "dropout": 0.0, "parallelism": "single GPU" if self.world == 1 else "dp%d" % self.world}
+
+    def dtype_name(self):
+        return "fp16" if self.dtype == torch.float16 else "bf16"
+
+    def cpu_baseline(self):
+        from oracle import bert_oracle as BO
+        from deeplearningexamples_amd.bert.model import LARGE
+        batch = 4
+        orc = BO.BertOracle(LARGE, BO.seeded_state(LARGE, 1))
+        data = BO.seeded_batch(LARGE, 2, batch)
+        orc.step(*data)
+        t0 = time.time()
+        orc.step(*data)
+        dt = time.time() - t0
+        return {"value": round(batch / dt, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": "oracle/bert_oracle.py (fp32 torch-CPU restatement of the reference step incl. LAMB, pinned "
+                          "against the reference module), 1 step of batch %d x seq 128 after 1 warm-up step" % batch}
+
+
+WORKLOADS = {"dlrm": DlrmWorkload, "rn50": Rn50Workload, "bert": BertWorkload}
 
 
 def roofline_from(timer_rows, steps):
