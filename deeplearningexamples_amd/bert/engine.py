@@ -22,6 +22,7 @@ from .. import _cabi as C
 from .. import functional as F
 from .. import multi_tensor as mt
 from ..dlrm.engine import GradScalerState
+from ..utils.buckets import allreduce_mean_
 from .model import BertForPreTraining
 
 NO_DECAY = ("bias", "gamma", "beta", "LayerNorm")      # run_pretraining.py:423
@@ -79,6 +80,7 @@ class BertTrainer:
         self.one = torch.ones(1, dtype=torch.float32, device=dev)
         self.noop = torch.zeros(1, dtype=torch.int32, device=dev)
         self.opt_steps = 0
+        self.grad_divisor = 1          # gradient-accumulation micro-steps summed into the flat gradient
         self._batch_key, self._sel, self._idx0, self._mask_add, self._dense_labels = None, None, None, None, None
         self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
 
@@ -319,12 +321,15 @@ class BertTrainer:
         progress = (self.opt_steps + 1) / self.total
         if progress < self.warmup:
             return self.base_lr * progress / self.warmup
-        return self.base_lr * ((1.0 - progress) ** 0.5)
+        return self.base_lr * (max(1.0 - progress, 0.0) ** 0.5)
 
     def optimizer_step(self):
         sc = self.scaler
+        if self.grad_divisor != 1:
+            # each micro-step's loss is divided by the accumulation count in the reference (run_pretraining.py:521)
+            self.flat_grad.mul_(1.0 / self.grad_divisor)
         if self.world > 1:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.AVG, group=self.pg)
+            allreduce_mean_(self.flat_grad, self.pg)
         self.noop.zero_()
         if sc.enabled:
             F.check_nonfinite_(self.flat_grad, sc.found_inf)

@@ -1,0 +1,110 @@
+"""BERT pre-training entry point on MI355X with the reference's CLI (subset that drives the train step).
+
+Mirrors LanguageModeling/BERT/run_pretraining.py:140-321 (flags), :323-375 (setup_training), :377-486
+(prepare_model_and_optimizer), :658-736 (loop with gradient accumulation) and its dllogger keys
+(average_loss, learning_rate, training_sequences_per_second, e2e_train_time, final_loss, raw_train_time).
+The lddl loader (un-vendored) is replaced by a synthetic loader with the same 5-key int64 batch
+(run_pretraining.py:603-609).
+    python -m torch.distributed.run --nproc-per-node 8 -m deeplearningexamples_amd.bert.run_pretraining \
+        --train_batch_size 256 --gradient_accumulation_steps 2 --max_steps 20 --bf16
+"""
+import argparse
+import time
+
+import torch
+
+from ..utils import dllogger
+from ..utils.dist import init_from_env, is_main_process
+from .engine import BertTrainer
+from .model import LARGE, BertForPreTraining, config_from_json
+
+
+def parse_arguments(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--config_file", default=None, type=str, help="BERT model config json (default: BERT-Large)")
+    p.add_argument("--max_seq_length", default=128, type=int)
+    p.add_argument("--max_predictions_per_seq", default=20, type=int)
+    p.add_argument("--train_batch_size", default=32, type=int, help="per-GPU batch of one optimizer step")
+    p.add_argument("--learning_rate", default=6e-3, type=float)
+    p.add_argument("--max_steps", default=1000, type=float)
+    p.add_argument("--warmup_proportion", default=0.2843, type=float)
+    p.add_argument("--gradient_accumulation_steps", type=int, default=1)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--fp16", action="store_true")
+    p.add_argument("--bf16", action="store_true")
+    p.add_argument("--init_loss_scale", type=int, default=2 ** 20)
+    p.add_argument("--log_freq", type=float, default=1.0)
+    p.add_argument("--steps_this_run", type=int, default=-1)
+    p.add_argument("--json-summary", type=str, default="dllogger.json")
+    p.add_argument("--disable_progress_bar", action="store_true")
+    p.add_argument("--skip_checkpoint", action="store_true")
+    args = p.parse_args(argv)
+    if args.steps_this_run < 0:
+        args.steps_this_run = int(args.max_steps)
+    if args.train_batch_size % args.gradient_accumulation_steps:
+        raise ValueError("train_batch_size must be divisible by gradient_accumulation_steps")
+    return args
+
+
+def synthetic_batches(cfg, micro_batch, seq, max_pred, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    v = cfg["real_vocab"]
+    ids = torch.randint(0, v, (micro_batch, seq), generator=g)
+    split = torch.randint(seq // 4, 3 * seq // 4, (micro_batch, 1), generator=g)
+    tt = (torch.arange(seq)[None, :] >= split).long()
+    mask = torch.ones((micro_batch, seq), dtype=torch.long)
+    labels = torch.full((micro_batch, seq), -1, dtype=torch.long)
+    for i in range(micro_batch):
+        pos = torch.randperm(seq, generator=g)[:max_pred]
+        labels[i, pos] = torch.randint(0, v, (max_pred,), generator=g)
+    nsp = torch.randint(0, 2, (micro_batch,), generator=g)
+    batch = {"input_ids": ids, "token_type_ids": tt, "attention_mask": mask, "labels": labels, "next_sentence_labels": nsp}
+    batch = {k: t.to(device) for k, t in batch.items()}
+    while True:
+        yield batch
+
+
+def main(argv=None):
+    args = parse_arguments(argv)
+    rank, world, local = init_from_env()
+    device = torch.device("cuda", local)
+    torch.manual_seed(args.seed)
+    cfg = dict(config_from_json(args.config_file) if args.config_file else LARGE, seq=args.max_seq_length)
+    if is_main_process():
+        dllogger.init([dllogger.JSONStreamBackend(dllogger.Verbosity.VERBOSE, args.json_summary),
+                       dllogger.StdOutBackend(dllogger.Verbosity.DEFAULT)])
+        dllogger.log(step="PARAMETER", data={"Config": [str(vars(args))]})
+    model = BertForPreTraining(cfg, device=device)
+    dtype = torch.float16 if args.fp16 else torch.bfloat16
+    trainer = BertTrainer(model, lr=args.learning_rate, warmup=args.warmup_proportion, total_steps=int(args.max_steps),
+                          compute_dtype=dtype, init_loss_scale=float(args.init_loss_scale), world_size=world)
+    acc = args.gradient_accumulation_steps
+    micro = args.train_batch_size // acc
+    it = synthetic_batches(cfg, micro, args.max_seq_length, args.max_predictions_per_seq, device, args.seed + rank)
+    avg_loss = torch.zeros(1, device=device)
+    t0 = time.time()
+    for step in range(args.steps_this_run):
+        for micro_step in range(acc):
+            b = next(it)
+            loss, dlog, dnsp = trainer.forward(b["input_ids"], b["token_type_ids"], b["attention_mask"], b["labels"],
+                                               b["next_sentence_labels"])
+            trainer.backward(dlog, dnsp, accumulate=micro_step > 0)       # no_sync on accumulation micro-steps
+            avg_loss += loss / acc
+        trainer.grad_divisor = acc
+        trainer.optimizer_step()
+        if (step + 1) % max(int(args.log_freq), 1) == 0 and is_main_process():
+            dllogger.log(step=(0, step + 1), data={"average_loss": float(avg_loss.item()) / max(int(args.log_freq), 1),
+                                                   "learning_rate": trainer.current_lr()})
+            avg_loss.zero_()
+    torch.cuda.synchronize()
+    secs = time.time() - t0
+    if is_main_process():
+        seqs = args.train_batch_size * world * args.steps_this_run
+        dllogger.log(step=tuple(), data={"e2e_train_time": secs, "training_sequences_per_second": seqs / secs,
+                                         "final_loss": float(loss.item()), "raw_train_time": secs})
+        dllogger.flush()
+    return trainer
+
+
+if __name__ == "__main__":
+    main()

@@ -22,6 +22,7 @@ import torch.distributed as dist
 from .. import functional as F
 from .. import multi_tensor as mt
 from ..dlrm.engine import GradScalerState
+from ..utils.buckets import GradBuckets
 from .resnet import ResNet50
 
 
@@ -89,17 +90,9 @@ class ResNetTrainer:
             self.gview[n] = self.flat_grad[o:o + p.numel()]
             self.mview[n] = self.flat_mom[o:o + p.numel()]
             o += p.numel()
-        # buckets of ~bucket_mb MB of fp32 gradients, cut at parameter boundaries
-        self.buckets, start, lim = [], 0, bucket_mb * (1 << 20) // 4
-        for n, p in zip(order, self.params):
-            end = self.offset[n] + p.numel()
-            if end - start >= lim:
-                self.buckets.append((start, end, n))
-                start = end
-        if start < total:
-            self.buckets.append((start, total, order[-1]))
-        self._bucket_after = {b[2]: i for i, b in enumerate(self.buckets)}
         self.comm_stream = torch.cuda.Stream(device=self.dev) if world_size > 1 else None
+        self.buckets = GradBuckets(self.flat_grad, [(n, p.numel()) for n, p in zip(order, self.params)], bucket_mb,
+                                   process_group, self.comm_stream) if world_size > 1 else None
         # ---- 16-bit working copies (KRSC order == the channels_last master's memory order)
         self.w16 = {}
         units = [self.stem] + [u for blk in self.blocks for u in blk if u is not None]
@@ -162,15 +155,8 @@ class ResNetTrainer:
     # ------------------------------------------------------------------ communication
     def _maybe_reduce(self, finished_param_name):
         """Launch the all-reduce of a gradient bucket once its last gradient has been produced."""
-        if self.world == 1:
-            return
-        i = self._bucket_after.get(finished_param_name)
-        if i is None:
-            return
-        s, e, _ = self.buckets[i]
-        self.comm_stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.comm_stream):
-            dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.AVG, group=self.pg)
+        if self.buckets is not None:
+            self.buckets.grad_ready(finished_param_name)
 
     # ------------------------------------------------------------------ the step
     def forward(self, images):
@@ -244,8 +230,8 @@ class ResNetTrainer:
         loss, dlogits = F.softmax_xent(logits, target, smoothing=self.smoothing,
                                        grad_scale=sc.scale if sc.enabled else None, grad_dtype=self.dtype)
         self.backward(dlogits)
-        if self.world > 1:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.buckets is not None:
+            self.buckets.wait()
         if sc.enabled:
             F.check_nonfinite_(self.flat_grad, sc.found_inf)
         self.optimizer_step()

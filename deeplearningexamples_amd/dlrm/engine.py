@@ -21,6 +21,7 @@ import torch.distributed as dist
 
 from .. import functional as F
 from .. import multi_tensor as mt
+from ..utils.buckets import allreduce_mean_
 from .model import DistributedDlrm
 from .placement import ExchangePlan
 
@@ -194,7 +195,7 @@ class DlrmTrainer:
             # data-parallel mean of the top-MLP gradients, overlapped with the bottom backward
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(self.top_grads.flat, op=dist.ReduceOp.AVG, group=self.pg)
+                allreduce_mean_(self.top_grads.flat, self.pg)
             grad_bottom = self._top_to_bottom(grad_x)
         else:
             grad_bottom = grad_x

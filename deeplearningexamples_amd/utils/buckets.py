@@ -1,0 +1,63 @@
+"""Gradient buckets over one flat fp32 buffer + mean all-reduce (the data-parallel exchange of the train step).
+
+Replaces torch DDP's reducer (Classification/ConvNets/image_classification/training.py:78-84: 25 MB buckets;
+LanguageModeling/BERT/run_pretraining.py:455-475: one bucket + pre-divide hook).  Parameters are laid out in the
+flat buffer in the order their gradients become final during backward, buckets are cut at parameter
+boundaries, and a bucket is all-reduced (mean) as soon as its last gradient exists -- on a side stream when a
+CUDA stream is given, so RCCL traffic over xGMI overlaps the rest of the backward pass.
+"""
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def cut_buckets(named_numels: Sequence[Tuple[str, int]], bucket_bytes: int) -> List[Tuple[int, int, str]]:
+    """-> [(start, end, name of the parameter that completes the bucket)], element offsets into the flat buffer."""
+    out, start, pos, lim = [], 0, 0, max(bucket_bytes // 4, 1)
+    last = None
+    for name, n in named_numels:
+        pos += n
+        last = name
+        if pos - start >= lim:
+            out.append((start, pos, name))
+            start = pos
+    if start < pos:
+        out.append((start, pos, last))
+    return out
+
+
+def allreduce_mean_(t: torch.Tensor, group=None):
+    """In-place mean over the ranks.  NCCL/RCCL has a native AVG; gloo (CPU tests) sums and scales."""
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t.div_(dist.get_world_size(group))
+    return t
+
+
+class GradBuckets:
+    def __init__(self, flat: torch.Tensor, named_numels, bucket_mb=25, group=None, comm_stream=None):
+        self.flat, self.group, self.stream = flat, group, comm_stream
+        self.buckets = cut_buckets(named_numels, bucket_mb * (1 << 20))
+        self._by_last = {b[2]: i for i, b in enumerate(self.buckets)}
+        assert self.buckets[-1][1] == flat.numel() and self.buckets[0][0] == 0
+
+    def grad_ready(self, name):
+        """Call when the gradient of `name` has been written; fires the bucket that this parameter completes."""
+        i = self._by_last.get(name)
+        if i is None:
+            return False
+        s, e, _ = self.buckets[i]
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                allreduce_mean_(self.flat[s:e], self.group)
+        else:
+            allreduce_mean_(self.flat[s:e], self.group)
+        return True
+
+    def wait(self):
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
