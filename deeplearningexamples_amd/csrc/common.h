@@ -56,13 +56,47 @@ template <> struct Elem<DLE_BF16> {
     return __builtin_bit_cast(float, ((unsigned int)u) << 16);
   }
   static __device__ __forceinline__ unsigned short from_f32(float f) {
-    unsigned int x = __builtin_bit_cast(unsigned int, f);
-    if ((x & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((x >> 16) | 0x40);  // quiet NaN
-    unsigned int lsb = (x >> 16) & 1u;
-    x += 0x7fffu + lsb;           // round-to-nearest-even
-    return (unsigned short)(x >> 16);
+    return __builtin_bit_cast(unsigned short, (__bf16)f);   // v_cvt_pk_bf16_f32: round-to-nearest-even in hardware
   }
 };
+
+// 8 fp32 -> 8 packed 16-bit values with the paired hardware converts (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32):
+// 4 VALU instructions instead of ~50 for the bit-twiddled rounding -- the conversions, not HBM, were the limit
+// of every 16-byte-per-lane epilogue / elementwise kernel before this.
+typedef __attribute__((ext_vector_type(2))) float float2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+template <int DT>
+__device__ __forceinline__ ushort8_t pack8(const float* v) {
+  uint4_t o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float2_t f = {v[2 * i], v[2 * i + 1]};
+    if (DT == DLE_F16) {
+      // scalar converts + pack: the paired float2 -> half2 convert (v_cvt_pk_f16_f32 as emitted by hipcc 7.2 for
+      // __builtin_convertvector) returns wrong values on gfx950 (tools/probes: half of the elements differ)
+      o[i] = (unsigned int)Elem<DLE_F16>::from_f32(f[0]) | ((unsigned int)Elem<DLE_F16>::from_f32(f[1]) << 16);
+    } else {
+      o[i] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f, bf16x2_t));
+    }
+  }
+  return __builtin_bit_cast(ushort8_t, o);
+}
+// 8 packed 16-bit values -> 8 fp32 (bf16: one shift / mask per element)
+template <int DT>
+__device__ __forceinline__ void unpack8(ushort8_t u8, float* v) {
+  const uint4_t u = __builtin_bit_cast(uint4_t, u8);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (DT == DLE_F16) {
+      // element-wise on purpose (see pack8): vector half2 <-> float2 converts are miscompiled for gfx950
+      v[2 * i] = Elem<DLE_F16>::to_f32((unsigned short)(u[i] & 0xffffu));
+      v[2 * i + 1] = Elem<DLE_F16>::to_f32((unsigned short)(u[i] >> 16));
+    } else {
+      v[2 * i] = __builtin_bit_cast(float, u[i] << 16);
+      v[2 * i + 1] = __builtin_bit_cast(float, u[i] & 0xffff0000u);
+    }
+  }
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
