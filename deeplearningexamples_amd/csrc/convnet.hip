@@ -88,20 +88,21 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(BnRedArgs a) {
       for (int k = 0; k < 8; ++k) { mu[k] = a.mean[c0 + k]; rs[k] = a.rstd[c0 + k]; }
     }
     for (long long r = r0 + rl; r < r1; r += rstep) {
-      const ushort8_t xv = *(const ushort8_t*)(a.x + r * a.C + c0);
+      float xf[8];
+      unpack8<DT>(*(const ushort8_t*)(a.x + r * a.C + c0), xf);
       if (MODE == 0) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const float v = up16<DT>(xv[k]); s0[k] += v; s1[k] += v * v; }
+        for (int k = 0; k < 8; ++k) { s0[k] += xf[k]; s1[k] += xf[k] * xf[k]; }
       } else {
-        const ushort8_t gv = *(const ushort8_t*)(a.dy + r * a.C + c0);
-        ushort8_t yv = {1, 1, 1, 1, 1, 1, 1, 1};
-        if (a.y) yv = *(const ushort8_t*)(a.y + r * a.C + c0);
+        float gf[8], yf[8];
+        unpack8<DT>(*(const ushort8_t*)(a.dy + r * a.C + c0), gf);
+        if (a.y) unpack8<DT>(*(const ushort8_t*)(a.y + r * a.C + c0), yf);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          float g = up16<DT>(gv[k]);
-          if (a.y && !(up16<DT>(yv[k]) > 0.f)) g = 0.f;
+          float g = gf[k];
+          if (a.y && !(yf[k] > 0.f)) g = 0.f;
           s0[k] += g;
-          s1[k] += g * (up16<DT>(xv[k]) - mu[k]) * rs[k];
+          s1[k] += g * (xf[k] - mu[k]) * rs[k];
         }
       }
     }
@@ -254,18 +255,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
 #pragma unroll
       for (int k = 0; k < 8; ++k) { sc[k] = rstd[c0 + k] * gamma[c0 + k]; sh[k] = beta[c0 + k] - mean[c0 + k] * sc[k]; }
     }
-    const ushort8_t xv = ((const ushort8_t*)x)[i];
-    ushort8_t rv = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (res) rv = ((const ushort8_t*)res)[i];
-    ushort8_t o;
+    float xf[8], rf[8], of[8];
+    unpack8<DT>(((const ushort8_t*)x)[i], xf);
+    if (res) unpack8<DT>(((const ushort8_t*)res)[i], rf);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      float v = up16<DT>(xv[k]) * sc[k] + sh[k];
-      if (res) v += up16<DT>(rv[k]);
+      float v = xf[k] * sc[k] + sh[k];
+      if (res) v += rf[k];
       if (relu) v = v > 0.f ? v : 0.f;
-      o[k] = dn16<DT>(v);
+      of[k] = v;
     }
-    ((ushort8_t*)y)[i] = o;
+    ((ushort8_t*)y)[i] = pack8<DT>(of);
   }
 }
 
@@ -337,21 +337,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
   load((int)(first % C8) * 8);
   for (long long i = first; i < total8; i += stride) {
     if (!invariant) load((int)(i % C8) * 8);
-    const ushort8_t gv = ((const ushort8_t*)dy)[i];
-    const ushort8_t xv = ((const ushort8_t*)x)[i];
-    ushort8_t yv = {1, 1, 1, 1, 1, 1, 1, 1};
-    if (y) yv = ((const ushort8_t*)y)[i];
-    ushort8_t o, go;
+    float gf[8], xf[8], yf[8], of[8];
+    unpack8<DT>(((const ushort8_t*)dy)[i], gf);
+    unpack8<DT>(((const ushort8_t*)x)[i], xf);
+    if (y) unpack8<DT>(((const ushort8_t*)y)[i], yf);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      float g = up16<DT>(gv[k]);
-      if (y && !(up16<DT>(yv[k]) > 0.f)) g = 0.f;
-      go[k] = dn16<DT>(g);
-      const float xh = (up16<DT>(xv[k]) - kmu[k]) * krs[k];
-      o[k] = dn16<DT>(ka[k] * (g - kb[k] - xh * kg[k]));
+      if (y && !(yf[k] > 0.f)) gf[k] = 0.f;
+      const float xh = (xf[k] - kmu[k]) * krs[k];
+      of[k] = ka[k] * (gf[k] - kb[k] - xh * kg[k]);
     }
-    ((ushort8_t*)dx)[i] = o;
-    if (g_out) ((ushort8_t*)g_out)[i] = go;
+    ((ushort8_t*)dx)[i] = pack8<DT>(of);
+    if (g_out) ((ushort8_t*)g_out)[i] = pack8<DT>(gf);
   }
 }
 

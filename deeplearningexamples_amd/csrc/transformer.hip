@@ -29,7 +29,7 @@ static int tf_grid(long long items, int per_block, int cap = 2048) {
 // ------------------------------------------------------------------ LayerNorm forward (+ residual)
 // z = x + res (res optional);  y = (z - mean) * rstd * gamma + beta.   z_out (optional) receives z in 16 bits
 // (the tensor the backward pass needs); mean / rstd fp32 per row.
-template <int DT>
+template <int DT, int CH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __restrict__ x,
                                                      const unsigned short* __restrict__ res,
                                                      unsigned short* __restrict__ z_out, unsigned short* __restrict__ y,
@@ -40,35 +40,31 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
   const int nch = H >> 3;                              // 16-byte chunks per row
   for (long long r = wave; r < rows; r += nwaves) {
-    float v[LN_MAX_CHUNKS][8];
+    float v[CH][8];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    for (int i = 0; i < CH; ++i) {
       const int c = lane + i * 64;
       if (c < nch) {
-        const ushort8_t xv = *(const ushort8_t*)(x + r * H + c * 8);
-        ushort8_t rv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (res) rv = *(const ushort8_t*)(res + r * H + c * 8);
+        float xf[8], rf[8];
+        unpack8<DT>(*(const ushort8_t*)(x + r * H + c * 8), xf);
+        if (res) {
+          unpack8<DT>(*(const ushort8_t*)(res + r * H + c * 8), rf);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          float t = tf_up<DT>(xv[k]);
-          if (res) t = tf_up<DT>(tf_dn<DT>(t + tf_up<DT>(rv[k])));     // z is what backward will see (16-bit)
-          v[i][k] = t;
-          s += t;
+          for (int k = 0; k < 8; ++k) xf[k] += rf[k];
+          const ushort8_t zo = pack8<DT>(xf);                      // z is what backward will see (16-bit)
+          if (z_out) *(ushort8_t*)(z_out + r * H + c * 8) = zo;
+          unpack8<DT>(zo, xf);
         }
-        if (z_out && res) {
-          ushort8_t zo;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) zo[k] = tf_dn<DT>(v[i][k]);
-          *(ushort8_t*)(z_out + r * H + c * 8) = zo;
-        }
+        for (int k = 0; k < 8; ++k) { v[i][k] = xf[k]; s += xf[k]; }
       }
     }
     s = wave_sum(s);
     const float mu = s / (float)H;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i)
+    for (int i = 0; i < CH; ++i)
       if (lane + i * 64 < nch)
 #pragma unroll
         for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
@@ -76,18 +72,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
     const float rs = rsqrtf(q / (float)H + eps);
     if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    for (int i = 0; i < CH; ++i) {
       const int c = lane + i * 64;
       if (c < nch) {
         const float4_t g0 = *(const float4_t*)(gamma + c * 8), g1 = *(const float4_t*)(gamma + c * 8 + 4);
         const float4_t b0 = *(const float4_t*)(beta + c * 8), b1 = *(const float4_t*)(beta + c * 8 + 4);
-        ushort8_t o;
+        float of[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const float g = k < 4 ? g0[k & 3] : g1[k & 3], b = k < 4 ? b0[k & 3] : b1[k & 3];
-          o[k] = tf_dn<DT>((v[i][k] - mu) * rs * g + b);
+          of[k] = (v[i][k] - mu) * rs * g + b;
         }
-        *(ushort8_t*)(y + r * H + c * 8) = o;
+        *(ushort8_t*)(y + r * H + c * 8) = pack8<DT>(of);
       }
     }
   }
@@ -101,8 +97,12 @@ extern "C" int dle_layernorm_fwd(const void* x, const void* residual, void* z_ou
   if (rows == 0) return 0;
   DLE_CHECK_ARG(x && y && gamma && beta && mean && rstd, "layernorm_fwd: null pointer");
   const int grid = tf_grid(rows, 4, 4096);
-  if (dtype == DLE_F16) hipLaunchKernelGGL(ln_fwd_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)residual, (unsigned short*)z_out, (unsigned short*)y, gamma, beta, mean, rstd, (long long)rows, H, eps);
-  else hipLaunchKernelGGL(ln_fwd_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)residual, (unsigned short*)z_out, (unsigned short*)y, gamma, beta, mean, rstd, (long long)rows, H, eps);
+  const int ch = (H / 8 + 63) / 64;           // 16-byte chunks per lane: register arrays are sized for exactly this
+#define GO(DT, CH) hipLaunchKernelGGL((ln_fwd_kernel<DT, CH>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)residual, (unsigned short*)z_out, (unsigned short*)y, gamma, beta, mean, rstd, (long long)rows, H, eps)
+#define PICK(DT) do { if (ch <= 1) GO(DT, 1); else if (ch <= 2) GO(DT, 2); else if (ch <= 4) GO(DT, 4); else GO(DT, 8); } while (0)
+  if (dtype == DLE_F16) PICK(DLE_F16); else PICK(DLE_BF16);
+#undef GO
+#undef PICK
   DLE_LAUNCH_CHECK();
   return 0;
 }
@@ -111,7 +111,7 @@ extern "C" int dle_layernorm_fwd(const void* x, const void* residual, void* z_ou
 // xhat = (z - mean) * rstd;  dz = rstd * (dy*gamma - mean_H(dy*gamma) - xhat * mean_H(dy*gamma*xhat));
 // partial[block][0][c] = sum_rows dy (dbeta), partial[block][1][c] = sum_rows dy * xhat (dgamma).
 // ZT = dtype of z (16-bit) or fp32 reconstruction is done by the embedding variant below.
-template <int DT>
+template <int DT, int CH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __restrict__ dy,
                                                      const unsigned short* __restrict__ z,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -122,26 +122,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __res
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long wave = (long long)blockIdx.x * 4 + w, nwaves = (long long)gridDim.x * 4;
   const int nch = H >> 3;
-  float ag[LN_MAX_CHUNKS][8], ab[LN_MAX_CHUNKS][8];
+  float ag[CH][8], ab[CH][8];
 #pragma unroll
-  for (int i = 0; i < LN_MAX_CHUNKS; ++i)
+  for (int i = 0; i < CH; ++i)
 #pragma unroll
     for (int k = 0; k < 8; ++k) { ag[i][k] = 0.f; ab[i][k] = 0.f; }
   for (long long r = wave; r < rows; r += nwaves) {
     const float mu = mean[r], rs = rstd[r];
-    float g[LN_MAX_CHUNKS][8], xh[LN_MAX_CHUNKS][8];
+    float g[CH][8], xh[CH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    for (int i = 0; i < CH; ++i) {
       const int c = lane + i * 64;
       if (c < nch) {
-        const ushort8_t dv = *(const ushort8_t*)(dy + r * H + c * 8);
-        const ushort8_t zv = *(const ushort8_t*)(z + r * H + c * 8);
+        float df[8], zf[8];
+        unpack8<DT>(*(const ushort8_t*)(dy + r * H + c * 8), df);
+        unpack8<DT>(*(const ushort8_t*)(z + r * H + c * 8), zf);
         const float4_t g0 = *(const float4_t*)(gamma + c * 8), g1 = *(const float4_t*)(gamma + c * 8 + 4);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const float d = tf_up<DT>(dv[k]);
-          const float xx = (tf_up<DT>(zv[k]) - mu) * rs;
+          const float d = df[k];
+          const float xx = (zf[k] - mu) * rs;
           const float gm = k < 4 ? g0[k & 3] : g1[k & 3];
           ab[i][k] += d;
           ag[i][k] += d * xx;
@@ -155,19 +156,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __res
     s1 = wave_sum(s1) / (float)H;
     s2 = wave_sum(s2) / (float)H;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    for (int i = 0; i < CH; ++i) {
       const int c = lane + i * 64;
       if (c < nch) {
-        ushort8_t o;
+        float of[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = tf_dn<DT>(rs * (g[i][k] - s1 - xh[i][k] * s2));
-        *(ushort8_t*)(dz + r * H + c * 8) = o;
+        for (int k = 0; k < 8; ++k) of[k] = rs * (g[i][k] - s1 - xh[i][k] * s2);
+        *(ushort8_t*)(dz + r * H + c * 8) = pack8<DT>(of);
       }
     }
   }
   // column partials: waves of the block meet in LDS
 #pragma unroll
-  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+  for (int i = 0; i < CH; ++i) {
     const int c = lane + i * 64;
     if (c < nch)
 #pragma unroll
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void colpair_finish_kernel(const float* __rest
   }
 }
 
-#define LN_BWD_BLOCKS 256
+#define LN_BWD_BLOCKS 1024
 extern "C" int64_t dle_layernorm_workspace_bytes(int H) { return (int64_t)LN_BWD_BLOCKS * 2 * H * 4; }
 
 extern "C" int dle_layernorm_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
@@ -218,8 +219,12 @@ extern "C" int dle_layernorm_bwd(const void* dy, const void* z, const float* mea
   if (blocks > LN_BWD_BLOCKS) blocks = LN_BWD_BLOCKS;
   DLE_CHECK_ARG(workspace_bytes >= (long long)blocks * 2 * H * 4, "layernorm_bwd: workspace too small");
   const size_t lds = (size_t)4 * 2 * H * 4;
-  if (dtype == DLE_F16) hipLaunchKernelGGL(ln_bwd_kernel<DLE_F16>, dim3(blocks), dim3(256), lds, stream, (const unsigned short*)dy, (const unsigned short*)z, mean, rstd, gamma, (unsigned short*)dz, (float*)workspace, (long long)rows, H);
-  else hipLaunchKernelGGL(ln_bwd_kernel<DLE_BF16>, dim3(blocks), dim3(256), lds, stream, (const unsigned short*)dy, (const unsigned short*)z, mean, rstd, gamma, (unsigned short*)dz, (float*)workspace, (long long)rows, H);
+  const int ch = (H / 8 + 63) / 64;
+#define GO(DT, CH) hipLaunchKernelGGL((ln_bwd_kernel<DT, CH>), dim3(blocks), dim3(256), lds, stream, (const unsigned short*)dy, (const unsigned short*)z, mean, rstd, gamma, (unsigned short*)dz, (float*)workspace, (long long)rows, H)
+#define PICK(DT) do { if (ch <= 1) GO(DT, 1); else if (ch <= 2) GO(DT, 2); else if (ch <= 4) GO(DT, 4); else GO(DT, 8); } while (0)
+  if (dtype == DLE_F16) PICK(DLE_F16); else PICK(DLE_BF16);
+#undef GO
+#undef PICK
   DLE_LAUNCH_CHECK();
   hipLaunchKernelGGL(colpair_finish_kernel, dim3((H + 63) / 64), dim3(256), 0, stream, (const float*)workspace, blocks, H,
                      dgamma, dbeta, accumulate);
@@ -422,11 +427,11 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(unsigned short* __rest
     float v[8];
     float mx = -INFINITY;
     if (ok) {
-      const ushort8_t x = *(const ushort8_t*)(s + r * L + cl * 8);
+      unpack8<DT>(*(const ushort8_t*)(s + r * L + cl * 8), v);
       const float* m = mask_add ? mask_add + (r / rows_per_batch) * L + cl * 8 : nullptr;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        v[k] = tf_up<DT>(x[k]) * scale + (m ? m[k] : 0.f);
+        v[k] = v[k] * scale + (m ? m[k] : 0.f);
         mx = fmaxf(mx, v[k]);
       }
     }
@@ -438,10 +443,9 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(unsigned short* __rest
     for (int o = lpr >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     if (ok) {
       const float inv = 1.0f / sum;
-      ushort8_t o8;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) o8[k] = tf_dn<DT>(v[k] * inv);
-      *(ushort8_t*)(s + r * L + cl * 8) = o8;
+      for (int k = 0; k < 8; ++k) v[k] *= inv;
+      *(ushort8_t*)(s + r * L + cl * 8) = pack8<DT>(v);
     }
   }
 }
@@ -460,16 +464,17 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const unsigned short* 
     float pv[8], gv[8];
     float dot = 0.f;
     if (ok) {
-      const ushort8_t a = *(const ushort8_t*)(p + r * L + cl * 8), b = *(const ushort8_t*)(dp + r * L + cl * 8);
+      unpack8<DT>(*(const ushort8_t*)(p + r * L + cl * 8), pv);
+      unpack8<DT>(*(const ushort8_t*)(dp + r * L + cl * 8), gv);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { pv[k] = tf_up<DT>(a[k]); gv[k] = tf_up<DT>(b[k]); dot += pv[k] * gv[k]; }
+      for (int k = 0; k < 8; ++k) dot += pv[k] * gv[k];
     }
     for (int o = lpr >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
     if (ok) {
-      ushort8_t o8;
+      float of[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) o8[k] = tf_dn<DT>(pv[k] * (gv[k] - dot) * scale);
-      *(ushort8_t*)(dp + r * L + cl * 8) = o8;
+      for (int k = 0; k < 8; ++k) of[k] = pv[k] * (gv[k] - dot) * scale;
+      *(ushort8_t*)(dp + r * L + cl * 8) = pack8<DT>(of);
     }
   }
 }
