@@ -98,6 +98,13 @@ __device__ __forceinline__ void unpack8(ushort8_t u8, float* v) {
   }
 }
 
+// tanh(x) = 1 - 2 / (exp(2x) + 1): one v_exp_f32 + one v_rcp_f32.  Absolute error ~1e-7 (saturates cleanly to
+// +-1 for large |x|), far below the 16-bit rounding of every tensor it feeds.
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);      // exp(2x) = 2^(2x log2 e)
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const unsigned short* __re
       if (act == 7) d = 1.f - y * y;
       else {
         const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-        const float th = tanhf(k0 * (y + k1 * y * y * y));
+        const float th = fast_tanh(k0 * (y + k1 * y * y * y));
         d = 0.5f * (1.f + th) + 0.5f * y * (1.f - th * th) * k0 * (1.f + 3.f * k1 * y * y);
       }
       o[k] = Elem<DT>::from_f32(Elem<DT>::to_f32(gv[k]) * d);

@@ -129,7 +129,7 @@ __device__ __forceinline__ void swrite_tr(const ushort8_t (&r)[4], unsigned shor
 __device__ __forceinline__ float gelu_tanh(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
   const float u = k0 * (x + k1 * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(u));
+  return 0.5f * x * (1.0f + fast_tanh(u));
 }
 
 template <int DT, bool A_KC, bool B_KC>
@@ -314,15 +314,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
   if (c0 < N) {
     long long r = r0 + rl;
     if (vec && DT != DLE_F32) {
-      // 4 independent 16-byte loads in flight per lane
-      for (; r + 3LL * rstep < r1; r += 4LL * rstep) {
-        ushort8_t v[4];
+      // 8 independent 16-byte loads in flight per lane
+      for (; r + 7LL * rstep < r1; r += 8LL * rstep) {
+        ushort8_t v[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *(const ushort8_t*)((const unsigned short*)x + (r + (long long)u * rstep) * ld + c0);
+        for (int u = 0; u < 8; ++u) v[u] = *(const ushort8_t*)((const unsigned short*)x + (r + (long long)u * rstep) * ld + c0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 8; ++u) {
+          float f[8];
+          unpack8<DT == DLE_F32 ? DLE_BF16 : DT>(v[u], f);
 #pragma unroll
-          for (int k = 0; k < V; ++k) s[k] += DT == DLE_F16 ? Elem<DLE_F16>::to_f32(v[u][k]) : Elem<DLE_BF16>::to_f32(v[u][k]);
+          for (int k = 0; k < V; ++k) s[k] += f[k];
+        }
       }
     }
     for (; r < r1; r += rstep) {
@@ -358,19 +361,30 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
   }
 }
 
-// out[n] (+)= sum_g partial[g][n]; 64 columns x 4 group slices per workgroup
+// out[n] (+)= sum_g partial[g][n]; 16 columns x 16 group slices per workgroup (latency-bound: spread wide,
+// 4 loads in flight per lane)
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                             int N, int groups, int accumulate) {
   __shared__ float red[256];
-  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + cl;
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int n = blockIdx.x * 16 + cl;
   float s = 0.f;
-  if (n < N)
-    for (int g = sl; g < groups; g += 4) s += partial[(long long)g * N + n];
+  if (n < N) {
+    int g = sl;
+    for (; g + 48 < groups; g += 64) {
+      float a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = partial[(long long)(g + 16 * u) * N + n];
+      s += (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    for (; g < groups; g += 16) s += partial[(long long)g * N + n];
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   if (sl == 0 && n < N) {
-    const float t = red[cl] + red[64 + cl] + red[128 + cl] + red[192 + cl];
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q * 16 + cl];
     out[n] = accumulate ? out[n] + t : t;
   }
 }
@@ -391,10 +405,10 @@ extern "C" int dle_colsum(const void* x, float* out, int64_t M, int N, int64_t l
   int lpr = 1;
   while (lpr < cols_v && lpr < 256) lpr <<= 1;           // lanes per row (power of two, <= 256)
   const int gx = (cols_v + lpr - 1) / lpr;
-  long long want = 1024 / gx;                              // ~4 workgroups per CU in total
+  long long want = 512 / gx;                               // ~2 workgroups per CU in total
   if (want < 1) want = 1;
   long long rpb = (M + want - 1) / want;
-  const long long min_rows = 4LL * (256 / lpr);
+  const long long min_rows = 8LL * (256 / lpr);
   if (rpb < min_rows) rpb = min_rows;
   long long gy = (M + rpb - 1) / rpb;
   // Row groups meet through plain stores into the caller's workspace + a tiny finishing pass.  Without a
@@ -416,7 +430,7 @@ extern "C" int dle_colsum(const void* x, float* out, int64_t M, int N, int64_t l
   else hipLaunchKernelGGL(colsum_kernel<DLE_BF16>, grid, block, 0, stream, x, out, (long long)M, N, (long long)ld, rpb, lpr, partial);
   DLE_LAUNCH_CHECK();
   if (partial) {
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, (const float*)partial, out, N, (int)gy, accumulate);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, (const float*)partial, out, N, (int)gy, accumulate);
     DLE_LAUNCH_CHECK();
   }
   return 0;

@@ -87,7 +87,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned short*
 __device__ __forceinline__ float gelu_tanh2(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
   const float u = k0 * (x + k1 * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(u));
+  return 0.5f * x * (1.0f + fast_tanh(u));
 }
 
 // ---- per-operand tile loader state: 4 DMA instructions per wave per K tile --------------------------
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm2_kernel(Gemm2Ar
       for (int r = 0; r < 8; ++r) v[r] = gelu_tanh2(v[r]);
     } else if (p.act == ACT_TANH) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = tanhf(v[r]);
+      for (int r = 0; r < 8; ++r) v[r] = fast_tanh(v[r]);
     } else if (p.act == ACT_RELU_BWD || p.act == ACT_ADD || p.act == ACT_GELU_BWD || p.act == ACT_TANH_BWD) {
       ushort8_t sv = {0, 0, 0, 0, 0, 0, 0, 0};
       if (full) sv = *(const ushort8_t*)(p.mask_src + off);
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm2_kernel(Gemm2Ar
         else if (p.act == ACT_TANH_BWD) v[r] *= (1.f - y * y);           // y = tanh output of the forward
         else {                                                            // y = GELU pre-activation
           const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-          const float th = tanhf(k0 * (y + k1 * y * y * y));
+          const float th = fast_tanh(k0 * (y + k1 * y * y * y));
           v[r] *= 0.5f * (1.f + th) + 0.5f * y * (1.f - th * th) * k0 * (1.f + 3.f * k1 * y * y);
         }
       }
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(320, 3) void gemm3_kernel(Gemm2Args p) {
           for (int r = 0; r < 8; ++r) v[r] = gelu_tanh2(v[r]);
         } else if (p.act == ACT_TANH) {
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = tanhf(v[r]);
+          for (int r = 0; r < 8; ++r) v[r] = fast_tanh(v[r]);
         } else if (p.act == ACT_RELU_BWD || p.act == ACT_ADD || p.act == ACT_GELU_BWD || p.act == ACT_TANH_BWD) {
           ushort8_t sv = {0, 0, 0, 0, 0, 0, 0, 0};
           if (full) sv = *(const ushort8_t*)(p.mask_src + off);
@@ -801,7 +801,7 @@ __global__ __launch_bounds__(320, 3) void gemm3_kernel(Gemm2Args p) {
             else if (p.act == ACT_TANH_BWD) v[r] *= (1.f - y * y);
             else {
               const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-              const float th = tanhf(k0 * (y + k1 * y * y * y));
+              const float th = fast_tanh(k0 * (y + k1 * y * y * y));
               v[r] *= 0.5f * (1.f + th) + 0.5f * y * (1.f - th * th) * k0 * (1.f + 3.f * k1 * y * y);
             }
           }

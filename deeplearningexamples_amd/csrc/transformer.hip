@@ -112,15 +112,15 @@ extern "C" int dle_layernorm_fwd(const void* x, const void* residual, void* z_ou
 // partial[block][0][c] = sum_rows dy (dbeta), partial[block][1][c] = sum_rows dy * xhat (dgamma).
 // ZT = dtype of z (16-bit) or fp32 reconstruction is done by the embedding variant below.
 template <int DT, int CH>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __restrict__ dy,
+__global__ __launch_bounds__(512) void ln_bwd_kernel(const unsigned short* __restrict__ dy,
                                                      const unsigned short* __restrict__ z,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, unsigned short* __restrict__ dz,
                                                      float* __restrict__ partial, long long rows, int H) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* red = (float*)smem_raw;                       // [4 waves][2][H]
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long long wave = (long long)blockIdx.x * 4 + w, nwaves = (long long)gridDim.x * 4;
+  float* red = (float*)smem_raw;                       // [waves][2][H]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  const long long wave = (long long)blockIdx.x * nwv + w, nwaves = (long long)gridDim.x * nwv;
   const int nch = H >> 3;
   float ag[CH][8], ab[CH][8];
 #pragma unroll
@@ -178,35 +178,49 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __res
       }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < 2 * H; c += 256) {
+  for (int c = threadIdx.x; c < 2 * H; c += blockDim.x) {
     const int which = c / H, col = c - which * H;
-    const float t = red[(0 * 2 + which) * H + col] + red[(1 * 2 + which) * H + col] + red[(2 * 2 + which) * H + col] +
-                    red[(3 * 2 + which) * H + col];
+    float t = 0.f;
+    for (int q = 0; q < nwv; ++q) t += red[(q * 2 + which) * H + col];
     partial[((long long)blockIdx.x * 2 + which) * H + col] = t;
   }
 }
 
-// dgamma / dbeta = sum over blocks of the partials (fp64 accumulation), 64 columns x 4 slices per workgroup
+// dgamma / dbeta = sum over blocks of the partials (fp64 accumulation).  16 columns x 16 group slices per
+// workgroup: the pass is latency-bound, so it is spread over C/16 workgroups with 4 loads in flight per lane.
 __global__ __launch_bounds__(256) void colpair_finish_kernel(const float* __restrict__ partial, int groups, int C,
                                                              float* __restrict__ out1, float* __restrict__ out0,
                                                              int accumulate) {
   __shared__ double red[2][256];
-  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double s0 = 0.0, s1 = 0.0;
-  if (c < C)
-    for (int g = sl; g < groups; g += 4) { s0 += partial[((long long)g * 2) * C + c]; s1 += partial[((long long)g * 2 + 1) * C + c]; }
+  if (c < C) {
+    int g = sl;
+    for (; g + 48 < groups; g += 64) {
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = partial[((long long)(g + 16 * u) * 2) * C + c];
+        b[u] = partial[((long long)(g + 16 * u) * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s0 += a[u]; s1 += b[u]; }
+    }
+    for (; g < groups; g += 16) { s0 += partial[((long long)g * 2) * C + c]; s1 += partial[((long long)g * 2 + 1) * C + c]; }
+  }
   red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
   __syncthreads();
   if (sl == 0 && c < C) {
-    const float t0 = (float)(red[0][cl] + red[0][64 + cl] + red[0][128 + cl] + red[0][192 + cl]);
-    const float t1 = (float)(red[1][cl] + red[1][64 + cl] + red[1][128 + cl] + red[1][192 + cl]);
-    out0[c] = accumulate ? out0[c] + t0 : t0;
-    out1[c] = accumulate ? out1[c] + t1 : t1;
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { t0 += red[0][q * 16 + cl]; t1 += red[1][q * 16 + cl]; }
+    out0[c] = accumulate ? out0[c] + (float)t0 : (float)t0;
+    out1[c] = accumulate ? out1[c] + (float)t1 : (float)t1;
   }
 }
 
-#define LN_BWD_BLOCKS 1024
+#define LN_BWD_BLOCKS 512
 extern "C" int64_t dle_layernorm_workspace_bytes(int H) { return (int64_t)LN_BWD_BLOCKS * 2 * H * 4; }
 
 extern "C" int dle_layernorm_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
@@ -215,18 +229,19 @@ extern "C" int dle_layernorm_bwd(const void* dy, const void* z, const float* mea
   DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "layernorm_bwd: 16-bit activations only");
   DLE_CHECK_ARG(H > 0 && H % 8 == 0 && H <= 64 * LN_MAX_CHUNKS * 8, "layernorm_bwd: H must be a multiple of 8, <= 4096");
   DLE_CHECK_ARG(rows > 0 && dy && z && mean && rstd && gamma && dz && dgamma && dbeta && workspace, "layernorm_bwd: null pointer / empty");
-  int blocks = (int)((rows + 3) / 4);
+  const int nwv = H <= 1024 ? 8 : H <= 2048 ? 4 : 2;          // waves per workgroup: [waves][2][H] fp32 fits 64 KiB of LDS
+  int blocks = (int)((rows + nwv - 1) / nwv);
   if (blocks > LN_BWD_BLOCKS) blocks = LN_BWD_BLOCKS;
   DLE_CHECK_ARG(workspace_bytes >= (long long)blocks * 2 * H * 4, "layernorm_bwd: workspace too small");
-  const size_t lds = (size_t)4 * 2 * H * 4;
+  const size_t lds = (size_t)nwv * 2 * H * 4;
   const int ch = (H / 8 + 63) / 64;
-#define GO(DT, CH) hipLaunchKernelGGL((ln_bwd_kernel<DT, CH>), dim3(blocks), dim3(256), lds, stream, (const unsigned short*)dy, (const unsigned short*)z, mean, rstd, gamma, (unsigned short*)dz, (float*)workspace, (long long)rows, H)
+#define GO(DT, CH) hipLaunchKernelGGL((ln_bwd_kernel<DT, CH>), dim3(blocks), dim3(64 * nwv), lds, stream, (const unsigned short*)dy, (const unsigned short*)z, mean, rstd, gamma, (unsigned short*)dz, (float*)workspace, (long long)rows, H)
 #define PICK(DT) do { if (ch <= 1) GO(DT, 1); else if (ch <= 2) GO(DT, 2); else if (ch <= 4) GO(DT, 4); else GO(DT, 8); } while (0)
   if (dtype == DLE_F16) PICK(DLE_F16); else PICK(DLE_BF16);
 #undef GO
 #undef PICK
   DLE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colpair_finish_kernel, dim3((H + 63) / 64), dim3(256), 0, stream, (const float*)workspace, blocks, H,
+  hipLaunchKernelGGL(colpair_finish_kernel, dim3((H + 15) / 16), dim3(256), 0, stream, (const float*)workspace, blocks, H,
                      dgamma, dbeta, accumulate);
   DLE_LAUNCH_CHECK();
   return 0;
