@@ -11,7 +11,8 @@
 //  * bank conflicts are removed on the SOURCE side (the DMA image is linear): LDS slot (row, c) holds the
 //    global 16-byte chunk c ^ f(row); fragment reads apply the same involution.
 //      k-contiguous operand  [128 rows][64 k]  : f(row) = (row >> 1) & 7, read with ds_read_b128
-//      row-contiguous operand [64 k][128 rows] : 32-byte pair index ^ ((k & 3) | ((k >> 3) & 1) << 2),
+//      row-contiguous operand [64 k][128|256 rows] : 32-byte pair index ^ ((k & 3) << 1) -- the 8 (k line, 16-row
+//                                                half) pairs a 32-lane read group touches land in 8 distinct 32-byte bank slots,
 //                                                read with ds_read_b64_tr_b16 (LDS transpose read), so
 //                                                dgrad/wgrad need no transposed copies and no register shuffles.
 //  * 128x128x64 tile, 4 wavefronts (2x2), 64x64 per wavefront as 2x2 v_mfma_f32_32x32x16 (64 acc VGPRs),
@@ -23,6 +24,7 @@
 // (convolution forward / data-gradient: A(m,k) = X[n, p*stride - pad + r, q*stride - pad + s, c]).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define BM 128
 #define BN 128
@@ -78,7 +80,7 @@ typedef __attribute__((ext_vector_type(4))) short short4_t;
 #define OOB_OFF 0xFFFFFFF0u
 
 __device__ __forceinline__ int swz_kc(int row) { return (row >> 1) & 7; }
-__device__ __forceinline__ int swz_rc(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+__device__ __forceinline__ int swz_rc(int k) { return (k & 3) << 1; }
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned short* lds_wave_base, unsigned voff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_wave_base, 16, voff, 0, 0, 0);
@@ -98,19 +100,23 @@ __device__ __forceinline__ float gelu_tanh2(float x) {
 //   4  im2col, data grad: A(m=(n,h,w), k=(r,s,ko)) = dY[n, (h+pad-r)/st, (w+pad-s)/st, ko]   (0 unless divisible)
 //   3  im2col, weight grad B operand: B(n'=(r,s,c), k=pixel(n,p,q)) = X[n, p*st-pad+r, q*st-pad+s, c]
 //   5  KRSC weights as the data-grad B operand: B(c, k=(r,s,ko)) = W[ko][r][s][c]
-template <int MODE>
+template <int MODE, int TILE, int NW>
 struct Loader {
+  // the operand tile has TILE rows (128 or 256) x 64 k = TILE/8 DMA pieces of 1 KiB; NW waves own NP pieces each
   static constexpr bool RC = (MODE == 1 || MODE == 3 || MODE == 5);
-  unsigned off[4];       // mode 0/1: byte offset inside the K-tile panel; conv modes: lane-constant part
-  int kin[4];            // KC: k element offset inside the tile; RC: k row inside the tile
-  int a0[4], a1[4];      // mode 2: (h0, w0) of the output pixel; mode 4: (h, w); mode 3: (r, s) of the lane's tap
-  bool row_ok[4];
+  static constexpr int NP = TILE / 8 / NW;
+  static constexpr int CPL = TILE / 8;       // 16-byte chunks per k line of a row-contiguous image
+  static constexpr int KPP = 64 / CPL;       // k lines per piece (row-contiguous image)
+  unsigned off[NP];      // mode 0/1: byte offset inside the K-tile panel; conv modes: lane-constant part
+  int kin[NP];           // KC: k element offset inside the tile; RC: k row inside the tile
+  int a0[NP], a1[NP];    // mode 2: (h0, w0) of the output pixel; mode 4: (h, w); mode 3: (r, s) of the lane's tap
+  bool row_ok[NP];
 
   __device__ __forceinline__ void init(int wave, int lane, int row0, int nrows, long long ld, const ConvGeom& cg) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NP; ++j) {
       if (!RC) {
-        const int row = (wave * 4 + j) * 8 + (lane >> 3), cpos = lane & 7;
+        const int row = (wave * NP + j) * 8 + (lane >> 3), cpos = lane & 7;
         const int chunk = cpos ^ swz_kc(row);
         const int g = row0 + row;
         row_ok[j] = g < nrows;
@@ -131,7 +137,7 @@ struct Loader {
           off[j] = (unsigned)n;                           // image index; pixel offset is rebuilt per tap
         }
       } else {
-        const int kr = (wave * 4 + j) * 4 + (lane >> 4), cpos = lane & 15;
+        const int kr = (wave * NP + j) * KPP + lane / CPL, cpos = lane % CPL;
         const int chunk = (((cpos >> 1) ^ swz_rc(kr)) << 1) | (cpos & 1);
         const int g = row0 + chunk * 8;
         row_ok[j] = g < nrows;
@@ -151,11 +157,13 @@ struct Loader {
   }
 
   // base: (row0, k0) panel for mode 0, (k0, row0) panel for mode 1, tensor base for the conv modes
+  // pieces [J0, J1) of this wave
+  template <int J0, int J1>
   __device__ __forceinline__ void issue(const unsigned short* base, unsigned short* tile, int wave, int krem,
                                         int k0, const ConvGeom& cg) {
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xFFFFFFE0, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = J0; j < J1; ++j) {
       bool ok = row_ok[j] && kin[j] < krem;
       unsigned o = off[j];
       if (MODE == 2) {
@@ -185,21 +193,70 @@ struct Loader {
         const int tap = k / cg.Ko, ko = k - tap * cg.Ko;
         o += (unsigned)((((long long)ko * cg.R * cg.S + tap) * cg.C) * 2);
       }
-      dma16(rs, tile + (wave * 4 + j) * 512, ok ? o : OOB_OFF);
+      dma16(rs, tile + (wave * NP + j) * 512, ok ? o : OOB_OFF);
     }
   }
 };
 
-// NSTAGE = 2: double-buffered operand stages (64 KiB LDS, 2 workgroups per CU).
-// NSTAGE = 1: one stage (32 KiB) and a 128-VGPR budget -> 4 workgroups per CU.  For K <= 128 a tile is one or two K
-// tiles: its lifetime is dominated by the DMA latency at the start and the store drain at the end, so the bytes in
-// flight per CU (= resident workgroups) set the throughput, not the overlap inside one workgroup.
-template <int DT, int A_MODE, int B_MODE, int NSTAGE>
-__global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm2_kernel(Gemm2Args p) {
+// One MFMA operand fragment (32 rows x 16 k, 8 halves per lane) out of a TILE x 64 LDS image.
+template <bool RC, int TILE>
+__device__ __forceinline__ ushort8_t read_frag(const unsigned short* t, int rbase32, int ks, int lane) {
+  if (!RC) {
+    const int row = rbase32 + (lane & 31);
+    return *(const ushort8_t*)(t + row * BK + (((ks * 2 + (lane >> 5)) ^ swz_kc(row)) << 3));
+  } else {
+    // transpose read: lanes 0-15 / 16-31 -> rows +0..15 / +16..31 of the 32-row fragment, k group = lane >> 5
+    const int tg = lane >> 4, ti = lane & 15;
+    const int rbase = rbase32 + ((tg & 1) << 4);
+    const int kb = ks * 16 + (tg >> 1) * 8 + (ti >> 2);
+    const int chunk = (rbase >> 3) + ((ti & 3) >> 1);
+    ushort8_t f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = kb + h * 4;
+      const int cpos = (((chunk >> 1) ^ swz_rc(k)) << 1) | (chunk & 1);
+      const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) short4_t*)(t + k * TILE + cpos * 8 + ((ti & 1) << 2)));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f[h * 4 + e] = (unsigned short)v[e];
+    }
+    return f;
+  }
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    static_for<I + 1, N>(f);
+  }
+}
+
+// BIG = 0: 128x128 tile, 4 wavefronts (2x2), 64x64 per wavefront (64 accumulator VGPRs), 2 stages of 32 KiB, two
+//          workgroups per CU.
+// BIG = 1: 256x256 tile, 8 wavefronts (2x4), 128x64 per wavefront (128 accumulator VGPRs), 2 stages of 64 KiB, ONE
+//          workgroup per CU = two wavefronts per SIMD.  Four times the flops per DMA byte and half the LDS fragment
+//          bytes per flop of the 128x128 tile; the second wavefront of each SIMD keeps the matrix pipe busy while the
+//          first one sits in an LDS-DMA issue, an LDS wait or the barrier.  The variant for the big compute-bound GEMMs
+//          (BERT / DLRM linear layers).
+// NSTAGE = 2: double-buffered operand stages.
+// NSTAGE = 1 (BIG = 0 only): one stage (32 KiB) and a 128-VGPR budget -> 4 workgroups per CU.  For K <= 128 a tile is
+// one or two K tiles: its lifetime is dominated by the DMA latency at the start and the store drain at the end, so the
+// bytes in flight per CU (= resident workgroups) set the throughput, not the overlap inside one workgroup.
+template <int DT, int A_MODE, int B_MODE, int NSTAGE, int BIG>
+__global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) void gemm2_kernel(Gemm2Args p) {
+  constexpr int WGN = BIG ? 4 : 2;                     // wave grid 2 x WGN
+  constexpr int NW = 2 * WGN, NT = 64 * NW;
+  constexpr int WTM = BIG ? 4 : 2, WTN = 2;            // 32x32 MFMA blocks per wave (rows, columns)
+  constexpr int TM = 2 * WTM * 32, TN = WGN * WTN * 32;   // workgroup tile: 128x128 / 256x256
+  constexpr int STAGE = (TM + TN) * BK;                // halves per stage (A tile | B tile)
+  typedef Loader<A_MODE, TM, NW> LA;
+  typedef Loader<B_MODE, TN, NW> LB;
+  static_assert(LA::NP == 4 && LB::NP == 4, "4 DMA pieces per wave per operand per K tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned short* lds = (unsigned short*)smem_raw;   // [2 stages][A tile 8192 halves | B tile 8192 halves]
+  unsigned short* lds = (unsigned short*)smem_raw;   // [stages][A tile | B tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   if (p.batch_inner > 0) {
     const int zo = blockIdx.z / p.batch_inner, zi = blockIdx.z - zo * p.batch_inner;
     p.A += zo * p.sa_o + zi * p.sa_i;
@@ -208,16 +265,27 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm2_kernel(Gemm2Ar
     p.C = p.out_dtype == DLE_F32 ? (void*)((float*)p.C + co) : (void*)((unsigned short*)p.C + co);
   }
 
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + TM - 1) / TM, tiles_n = (p.N + TN - 1) / TN;
   const int ntiles = tiles_m * tiles_n;
   int bid = blockIdx.x;
   {
     const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  // walk N fastest so that concurrently running tiles share the A rows (activations) through L2
-  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  // Each XCD (private L2) works through a contiguous chunk of the tile list; the list is ordered in groups of GM tile
+  // rows walked column by column, so the ~32-64 tiles an XCD runs at once form a GM x (32..64/GM) block: per K step
+  // they pull GM A tiles + a few B tiles through L2 instead of 1 + 32 (a 1 x 32 strip re-reads the whole B matrix
+  // once per tile row: 4 GB of L2 fills for an 8192^3 GEMM).
+  constexpr int GM = 8;
+  int tm, tn;
+  {
+    const int per_group = GM * tiles_n;
+    const int g = bid / per_group, r = bid - g * per_group;
+    const int rows = (tiles_m - g * GM) < GM ? (tiles_m - g * GM) : GM;
+    tm = g * GM + r % rows;
+    tn = r / rows;
+  }
+  const int m0 = tm * TM, n0 = tn * TN;
 
   // balanced K slices: slice z owns k tiles [z*T/S, (z+1)*T/S) -- non-empty for every z when S <= T
   const int ktiles = (p.K + BK - 1) / BK;
@@ -226,134 +294,174 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm2_kernel(Gemm2Ar
   if (kt0 >= kt1 && p.splitk > 1 && !SLAB_MODE(p)) return;
   const int kend = (kt1 * BK < p.K) ? kt1 * BK : p.K;
 
-  Loader<A_MODE> la;
-  Loader<B_MODE> lb;
+  LA la;
+  LB lb;
   la.init(wave, lane, m0, p.M, p.lda, p.cg);
   lb.init(wave, lane, n0, p.N, p.ldb, p.cg);
 
-  auto issue = [&](int kt, int stage) {
+  // DMA piece J of operand A / B of K tile kt into `stage` (one wave instruction each)
+  auto issue_a = [&](int kt, int stage, auto J) {
     const int k0 = kt * BK;
-    unsigned short* ta = lds + stage * (BM * BK + BN * BK);
-    unsigned short* tb = ta + BM * BK;
     const unsigned short* ba = A_MODE == 0 ? p.A + (long long)m0 * p.lda + k0
                              : A_MODE == 1 ? p.A + (long long)k0 * p.lda + m0 : p.A;
+    la.template issue<decltype(J)::value, decltype(J)::value + 1>(ba, lds + stage * STAGE, wave, kend - k0, k0, p.cg);
+  };
+  auto issue_b = [&](int kt, int stage, auto J) {
+    const int k0 = kt * BK;
     const unsigned short* bb = B_MODE == 0 ? p.B + (long long)n0 * p.ldb + k0
                              : B_MODE == 1 ? p.B + (long long)k0 * p.ldb + n0 : p.B;
-    if (p.debug_skip & 2) return;
-    la.issue(ba, ta, wave, kend - k0, k0, p.cg);
-    lb.issue(bb, tb, wave, kend - k0, k0, p.cg);
+    lb.template issue<decltype(J)::value, decltype(J)::value + 1>(bb, lds + stage * STAGE + TM * BK, wave, kend - k0, k0, p.cg);
+  };
+  auto issue_all = [&](int kt, int stage) {
+    static_for<0, 4>([&](auto J) { issue_a(kt, stage, J); });
+    static_for<0, 4>([&](auto J) { issue_b(kt, stage, J); });
   };
 
-  float16_t acc[2][2];
+  float16_t acc[WTM][WTN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WTM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WTN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (kt0 < kt1) issue(kt0, 0);
+  if (kt0 < kt1) issue_all(kt0, 0);
 
   const int fr = lane & 31, fh = lane >> 5;          // 32x32x16 fragment: row fr, k group fh (8 elements)
-  const int tg = lane >> 4, ti = lane & 15;          // transpose-read addressing: 16-lane groups
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int stage = NSTAGE == 1 ? 0 : (kt - kt0) & 1;
-    if (NSTAGE == 1 && kt > kt0) {
-      __syncthreads();                    // everyone is done reading the single stage
-      issue(kt, 0);
+  constexpr bool RCA = LA::RC, RCB = LB::RC;
+  constexpr int NM = WTM * WTN, NR = WTM + WTN;      // MFMAs / fragment reads per k-step
+  if constexpr (!BIG) {
+    // 128x128 tile: DMA of the next K tile at the top, then 4 k-steps; hipcc schedules the body (2-4 workgroups
+    // per CU overlap each other's bubbles)
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int stage = NSTAGE == 1 ? 0 : (kt - kt0) & 1;
+      if (NSTAGE == 1 && kt > kt0) {
+        __syncthreads();                    // everyone is done reading the single stage
+        issue_all(kt, 0);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA pieces of tile kt have landed
+      __syncthreads();                      // ... and everybody's; everyone is done reading the other stage
+      if (NSTAGE == 2 && kt + 1 < kt1) issue_all(kt + 1, stage ^ 1);
+      const unsigned short* ta = lds + stage * STAGE;
+      const unsigned short* tb = ta + TM * BK;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {      // 4 k-steps of 16
+        ushort8_t fa[WTM], fb[WTN];
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) fa[i] = read_frag<RCA, TM>(ta, wm * (WTM * 32) + i * 32, ks, lane);
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) fb[j] = read_frag<RCB, TN>(tb, wn * (WTN * 32) + j * 32, ks, lane);
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) acc[i][j] = Mfma32x16<DT>::run(fb[j], fa[i], acc[i][j]);
+      }
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA pieces of tile kt have landed
-    __syncthreads();                      // ... and everybody's; everyone is done reading the other stage
-    if (NSTAGE == 2 && kt + 1 < kt1) issue(kt + 1, stage ^ 1);
-    const unsigned short* ta = lds + stage * (BM * BK + BN * BK);
-    const unsigned short* tb = ta + BM * BK;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {      // 4 k-steps of 16
-      ushort8_t fa[2], fb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (!Loader<A_MODE>::RC) {
-          const int row = wm * 64 + i * 32 + fr;
-          fa[i] = *(const ushort8_t*)(ta + row * BK + (((ks * 2 + fh) ^ swz_kc(row)) << 3));
-        } else {
-          // lanes 0-15 / 16-31 -> rows +0..15 / +16..31 of the 32-row fragment, k group = lane >> 5
-          const int rbase = wm * 64 + i * 32 + ((tg & 1) << 4);
-          const int kb = ks * 16 + (tg >> 1) * 8 + (ti >> 2);
-          const int chunk = (rbase >> 3) + ((ti & 3) >> 1);
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int k = kb + h * 4;
-            const int cpos = (((chunk >> 1) ^ swz_rc(k)) << 1) | (chunk & 1);
-            const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) short4_t*)(ta + k * BM + cpos * 8 + ((ti & 1) << 2)));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) fa[i][h * 4 + e] = (unsigned short)v[e];
+  } else {
+    // 256x256 tile, two waves per SIMD.  The K loop is laid out by hand, one MFMA per slot, and pinned with
+    // sched_barrier (hipcc otherwise bunches the DMA issues and the LDS reads):
+    //  * fragments are double-buffered in registers; the LDS reads of the next k-step sit behind the MFMAs of the
+    //    FIRST half of the current one, so the last read has half a k-step of matrix time to come back;
+    //  * ONE barrier per K tile, after k-step 2: by then every wave has finished reading the current stage (its
+    //    k-step-3 fragments are in registers: lgkmcnt(0)) and its DMA pieces of the next tile have landed
+    //    (vmcnt(0)).  k-step 3 then overlaps its MFMAs with the first fragment reads of the NEXT tile, so no LDS
+    //    round trip is exposed at the tile boundary;
+    //  * the 8 LDS-DMA pieces per wave of a tile are spread one per MFMA or two over k-step 3 of the previous tile
+    //    and k-step 0 of the current one (a piece costs ~60-180 issue cycles during which this wave issues nothing
+    //    else -- never in a burst), which leaves them two k-steps to land before the barrier.  Past the last K
+    //    tile every piece is out of range and zero-fills the idle stage (no branch in the loop).
+    ushort8_t fa[2][WTM], fb[2][WTN];
+    auto kstep = [&](auto CUR, const unsigned short* ra, const unsigned short* rb, auto RKS, int dkt, int dstage,
+                     auto HALF) {
+      constexpr int cur = decltype(CUR)::value, nxt = cur ^ 1, rks = decltype(RKS)::value, half = decltype(HALF)::value;
+      static_for<0, NM>([&](auto MI) {
+        constexpr int m = decltype(MI)::value;
+        constexpr int i = m / WTN, j = m % WTN;
+        acc[i][j] = Mfma32x16<DT>::run(fb[cur][j], fa[cur][i], acc[i][j]);
+        static_for<0, NR>([&](auto U) {
+          constexpr int u = decltype(U)::value;
+          if constexpr ((u * (NM / 2)) / NR == m) {
+            if constexpr (u < WTM) fa[nxt][u] = read_frag<RCA, TM>(ra, wm * (WTM * 32) + u * 32, rks, lane);
+            else fb[nxt][u - WTM] = read_frag<RCB, TN>(rb, wn * (WTN * 32) + (u - WTM) * 32, rks, lane);
           }
+        });
+        if constexpr (half >= 0) {
+          static_for<0, 4>([&](auto D) {
+            constexpr int d = decltype(D)::value;
+            if constexpr (((2 * d + 1) * NM) / 8 == m) {
+              if constexpr ((d & 1) == 0) issue_a(dkt, dstage, std::integral_constant<int, 2 * half + (d >> 1)>());
+              else issue_b(dkt, dstage, std::integral_constant<int, 2 * half + (d >> 1)>());
+            }
+          });
         }
-      }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    typedef std::integral_constant<int, 0> C0;
+    typedef std::integral_constant<int, 1> C1;
+    typedef std::integral_constant<int, 2> C2;
+    typedef std::integral_constant<int, 3> C3;
+    typedef std::integral_constant<int, -1> CN;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (!Loader<B_MODE>::RC) {
-          const int row = wn * 64 + j * 32 + fr;
-          fb[j] = *(const ushort8_t*)(tb + row * BK + (((ks * 2 + fh) ^ swz_kc(row)) << 3));
-        } else {
-          const int rbase = wn * 64 + j * 32 + ((tg & 1) << 4);
-          const int kb = ks * 16 + (tg >> 1) * 8 + (ti >> 2);
-          const int chunk = (rbase >> 3) + ((ti & 3) >> 1);
+    for (int i = 0; i < WTM; ++i) fa[0][i] = read_frag<RCA, TM>(lds, wm * (WTM * 32) + i * 32, 0, lane);
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int k = kb + h * 4;
-            const int cpos = (((chunk >> 1) ^ swz_rc(k)) << 1) | (chunk & 1);
-            const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) short4_t*)(tb + k * BN + cpos * 8 + ((ti & 1) << 2)));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) fb[j][h * 4 + e] = (unsigned short)v[e];
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          if (!(p.debug_skip & 4)) acc[i][j] = Mfma32x16<DT>::run(fb[j], fa[i], acc[i][j]);
+    for (int j = 0; j < WTN; ++j) fb[0][j] = read_frag<RCB, TN>(lds + TM * BK, wn * (WTN * 32) + j * 32, 0, lane);
+    static_for<0, 2>([&](auto J) { issue_a(kt0 + 1, 1, J); issue_b(kt0 + 1, 1, J); });
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int stage = (kt - kt0) & 1;
+      const unsigned short* ta = lds + stage * STAGE;
+      const unsigned short* tb = ta + TM * BK;
+      const unsigned short* na = lds + (stage ^ 1) * STAGE;
+      const unsigned short* nb = na + TM * BK;
+      kstep(C0(), ta, tb, C1(), kt + 1, stage ^ 1, C1());     // k-step 0 | read k-step 1 | DMA 2nd half of tile kt+1
+      kstep(C1(), ta, tb, C2(), 0, 0, CN());                  // k-step 1 | read k-step 2
+      kstep(C0(), ta, tb, C3(), 0, 0, CN());                  // k-step 2 | read k-step 3
+      __builtin_amdgcn_s_waitcnt(0x0070);                     // vmcnt(0) & lgkmcnt(0)
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      kstep(C1(), na, nb, C0(), kt + 2, stage, C0());         // k-step 3 | read k-step 0 of tile kt+1 | DMA 1st half of kt+2
     }
   }
 
   // ---- epilogue.  D = (B A^T) tile: lane owns C[m = fr-th row][n = 8*(r>>2) + 4*fh + (r&3)].
-  // The fp32 tile is transposed through LDS (row stride 132 floats: conflict-free ds_write_b128) so that the
-  // bias / activation / mask / addend math and the global stores run with 8 consecutive columns per lane:
-  // 16-byte loads of mask/addend, 16-byte stores of C, 256-byte contiguous row segments per 16 lanes.
-  // Two passes of 64 rows (the wm = 0 waves, then the wm = 1 waves); 16-byte slots XOR-swizzled by the row keep the
-  // staging tile at exactly 32 KiB with conflict-free ds_write_b128 / ds_read_b128.
+  // The fp32 tile is transposed through LDS so that the bias / activation / mask / addend math and the global
+  // stores run with 8 consecutive columns per lane: 16-byte loads of mask/addend, 16-byte stores of C, 256-byte
+  // contiguous row segments per 16 lanes.  Two passes of TM/2 rows (the wm = 0 waves, then the wm = 1 waves);
+  // 16-byte slots XOR-swizzled by the row keep the staging tile at exactly the size of the operand stages
+  // (32 KiB / 128 KiB) with conflict-free ds_write_b128 / ds_read_b128.
   float* epi = (float*)smem_raw;
   const bool vec16 = (p.ldc & 7) == 0 && ((((uintptr_t)p.C) | ((uintptr_t)p.aux) | ((uintptr_t)p.mask_src)) & 15) == 0;
+  __builtin_amdgcn_s_waitcnt(0x0F70);    // the zero-fill DMA issued under the last K tile has landed
   for (int half = 0; half < 2; ++half) {
   __syncthreads();                       // operand stages (half 0) / previous half's tile are no longer read
   if (wm == half) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WTM; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < WTN; ++j)
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           float4_t v = {acc[i][j][qd * 4 + 0], acc[i][j][qd * 4 + 1], acc[i][j][qd * 4 + 2], acc[i][j][qd * 4 + 3]};
-          const int row = i * 32 + fr, c4 = (wn * 64 + j * 32 + qd * 8 + fh * 4) >> 2;
-          *(float4_t*)(epi + row * BN + ((c4 ^ (row & 31)) << 2)) = v * p.alpha;
+          const int row = i * 32 + fr, c4 = (wn * (WTN * 32) + j * 32 + qd * 8 + fh * 4) >> 2;
+          *(float4_t*)(epi + row * TN + ((c4 ^ (row & 31)) << 2)) = v * p.alpha;
         }
   }
   __syncthreads();
 #pragma unroll 2
-  for (int it = 0; it < 4; ++it) {
-    const int idx = it * 256 + tid;
-    const int ml = idx >> 4, nl = (idx & 15) << 3;
-    const int m = m0 + half * 64 + ml, n = n0 + nl;
+  for (int it = 0; it < (TM / 2) * (TN / 8) / NT; ++it) {
+    const int idx = it * NT + tid;
+    const int ml = idx / (TN / 8), nl = (idx % (TN / 8)) << 3;
+    const int m = m0 + half * (TM / 2) + ml, n = n0 + nl;
     if (m >= p.M || n >= p.N) continue;
     const int nval = (p.N - n) < 8 ? (p.N - n) : 8;
     float v[8];
     {
       const int c4 = nl >> 2;
-      const float4_t lo = *(const float4_t*)(epi + ml * BN + ((c4 ^ (ml & 31)) << 2));
-      const float4_t hi = *(const float4_t*)(epi + ml * BN + (((c4 + 1) ^ (ml & 31)) << 2));
+      const float4_t lo = *(const float4_t*)(epi + ml * TN + ((c4 ^ (ml & 31)) << 2));
+      const float4_t hi = *(const float4_t*)(epi + ml * TN + (((c4 + 1) ^ (ml & 31)) << 2));
 #pragma unroll
       for (int r = 0; r < 4; ++r) { v[r] = lo[r]; v[4 + r] = hi[r]; }
     }
@@ -374,7 +482,6 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm2_kernel(Gemm2Ar
       continue;
     }
     const bool full = nval == 8 && vec16;
-    if ((p.debug_skip & 1) && v[0] != 12345.678f) continue;
     if (p.bias) {
 #pragma unroll
       for (int r = 0; r < 8; ++r)
@@ -864,12 +971,36 @@ static int launch_gemm(const Gemm2Args& p_in, int in_dtype, int amode, int bmode
   const size_t lds = GEMM2_LDS_BYTES;
   if (v2) {
     p.batch_count = batch;
-    dim3 grid(tiles, p.splitk, batch > 0 ? batch : 1), block(256);
     const int kt_per_item = ((p.K + BK - 1) / BK + p.splitk - 1) / p.splitk;
+    // 256x256 tile (one workgroup per CU): plain matrix operands, enough K tiles to amortise the 128 KiB epilogue,
+    // enough tiles to cover most of the chip.  DLE_GEMM_BIG=0 disables it, =1 forces it whenever the shape allows.
+    {
+      static const int big_mode = getenv("DLE_GEMM_BIG") ? atoi(getenv("DLE_GEMM_BIG")) : -1;
+      const long long tiles_big = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.splitk * (batch > 0 ? batch : 1);
+      const bool fits = amode <= 1 && bmode <= 1 && p.M >= 256 && p.N >= 256 &&
+                        p.lda * 512 <= 0x7FFFFFFFLL && p.ldb * 512 <= 0x7FFFFFFFLL;
+      const bool want = big_mode == 1 || (big_mode != 0 && kt_per_item >= 4 && tiles_big >= 160);
+      if (fits && want) {
+        dim3 grid((unsigned)(((p.M + 255) / 256) * ((p.N + 255) / 256)), p.splitk, batch > 0 ? batch : 1), block(512);
+        const size_t lds_big = 2 * (256 * BK + 256 * BK) * 2;
+#define GOBIG(DT, AM, BMODE) do { static bool attr_set = false; \
+          if (!attr_set) { hipFuncSetAttribute((const void*)gemm2_kernel<DT, AM, BMODE, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big); attr_set = true; } \
+          hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE, 2, 1>), grid, block, lds_big, stream, p); } while (0)
+#define PICKBIG(DT) do { if (amode == 0 && bmode == 0) GOBIG(DT, 0, 0); else if (amode == 0) GOBIG(DT, 0, 1); else GOBIG(DT, 1, 1); } while (0)
+        if (amode == 1 && bmode == 0) { dle_set_error("gemm: unsupported operand layout"); return 1; }
+        if (in_dtype == DLE_F16) PICKBIG(DLE_F16); else PICKBIG(DLE_BF16);
+#undef GOBIG
+#undef PICKBIG
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { dle_set_error("gemm launch failed: %s", hipGetErrorString(e)); return (int)e; }
+        return 0;
+      }
+    }
+    dim3 grid(tiles, p.splitk, batch > 0 ? batch : 1), block(256);
     static const int one_stage_max = getenv("DLE_GEMM_1STAGE_MAX") ? atoi(getenv("DLE_GEMM_1STAGE_MAX")) : 2;
     const bool one = kt_per_item <= one_stage_max;
-#define GO(DT, AM, BMODE) do { if (one) hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE, 1>), grid, block, lds / 2, stream, p); \
-                               else hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE, 2>), grid, block, lds, stream, p); } while (0)
+#define GO(DT, AM, BMODE) do { if (one) hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE, 1, 0>), grid, block, lds / 2, stream, p); \
+                               else hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE, 2, 0>), grid, block, lds, stream, p); } while (0)
 #define PICK(DT) do { if (amode == 0 && bmode == 0) GO(DT, 0, 0); else if (amode == 0) GO(DT, 0, 1); else if (amode == 1 && bmode == 1) GO(DT, 1, 1); \
       else if (amode == 2) GO(DT, 2, 0); else if (amode == 4) GO(DT, 4, 5); else GO(DT, 1, 3); } while (0)
     if (in_dtype == DLE_F16) PICK(DLE_F16); else PICK(DLE_BF16);

@@ -84,6 +84,25 @@ def bench_gemm():
             report("hipblaslt_ref_fwd_" + nm, t, flops=2.0 * m * n * k, mnk=[m, n, k])
 
 
+def bench_gemmbert():
+    """The BERT-Large / DLRM linear-layer shapes, forward / data-grad / weight-grad, bf16."""
+    shapes = [(16384, 4096, 1024), (16384, 1024, 4096), (16384, 3072, 1024), (16384, 1024, 1024),
+              (65536, 1024, 1024), (65536, 512, 1024), (8192, 8192, 8192)]
+    dtype = torch.bfloat16
+    for m, n, k in shapes:
+        a = torch.randn(m, k, device=dev).to(dtype)
+        b = torch.randn(n, k, device=dev).to(dtype)
+        gy = torch.randn(m, n, device=dev).to(dtype)
+        t = timeit(lambda: F.gemm(a, b, m, n, k, True, True), iters=10, warmup=3)
+        report("gemm_fwd_bf16", t, flops=2.0 * m * n * k, mnk=[m, n, k])
+        t = timeit(lambda: F.linear_dgrad(gy, b), iters=10, warmup=3)
+        report("gemm_dgrad_bf16", t, flops=2.0 * m * n * k, mnk=[m, n, k])
+        t = timeit(lambda: F.linear_wgrad(gy, a), iters=10, warmup=3)
+        report("gemm_wgrad_bf16", t, flops=2.0 * m * n * k, mnk=[m, n, k])
+        t = timeit(lambda: torch.nn.functional.linear(a, b), iters=10, warmup=3)
+        report("hipblaslt_ref_fwd_bf16", t, flops=2.0 * m * n * k, mnk=[m, n, k])
+
+
 def bench_mt():
     n = 336_000_000 // 4
     sizes = [n // 64] * 64
