@@ -59,7 +59,7 @@ struct Gemm2Args {
   // batched mode (grid.z = batch): operand z = (zo, zi) = (z / batch_inner, z % batch_inner) starts at
   // base + zo * stride_outer + zi * stride_inner (elements) -- e.g. (sequence, head) slices of a [T, 3H] buffer
   int batch_inner, batch_count;
-  int debug_skip;        // ablation switches for profiling (DLE_GEMM_SKIP): 1 = no global stores, 2 = no DMA, 4 = no MFMA
+  int debug_skip;        // reserved (profiling ablations)
   long long sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
 };
 
@@ -223,6 +223,99 @@ __device__ __forceinline__ ushort8_t read_frag(const unsigned short* t, int rbas
     return f;
   }
 }
+
+// Epilogue of 8 consecutive output columns of row m (v = alpha * accumulators): split-K partials, or bias /
+// activation / mask / addend math and the 16-byte stores of C (+ the pre-activation side output).
+template <int DT>
+__device__ __forceinline__ void epi_store8(const Gemm2Args& p, float* v, int m, int n, int nval, bool vec16, int ky) {
+  const long long off = (long long)m * p.ldc + n;
+  if (p.splitk > 1) {
+    if (p.ws) {
+      float* c = p.ws + ((long long)ky * p.M + m) * p.N + n;
+      if (nval == 8 && (p.N & 3) == 0) {
+        *(float4_t*)c = (float4_t){v[0], v[1], v[2], v[3]};
+        *(float4_t*)(c + 4) = (float4_t){v[4], v[5], v[6], v[7]};
+      } else {
+        for (int r = 0; r < nval; ++r) c[r] = v[r];
+      }
+    } else {
+      float* c = (float*)p.C + off;
+      for (int r = 0; r < nval; ++r) unsafeAtomicAdd(c + r, v[r]);
+    }
+    return;
+  }
+  const bool full = nval == 8 && vec16;
+  if (p.bias) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (r < nval) v[r] += p.bias[n + r];
+  }
+  float pre[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) pre[r] = v[r];
+  if (p.act == ACT_RELU) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+  } else if (p.act == ACT_GELU) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = gelu_tanh2(v[r]);
+  } else if (p.act == ACT_TANH) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = fast_tanh(v[r]);
+  } else if (p.act == ACT_RELU_BWD || p.act == ACT_ADD || p.act == ACT_GELU_BWD || p.act == ACT_TANH_BWD) {
+    ushort8_t sv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (full) sv = *(const ushort8_t*)(p.mask_src + off);
+    else
+      for (int r = 0; r < nval; ++r) sv[r] = p.mask_src[off + r];
+    float yv[8];
+    unpack8<DT>(sv, yv);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float y = yv[r];
+      if (p.act == ACT_RELU_BWD) v[r] = y > 0.f ? v[r] : 0.f;
+      else if (p.act == ACT_ADD) v[r] += y;
+      else if (p.act == ACT_TANH_BWD) v[r] *= (1.f - y * y);           // y = tanh output of the forward
+      else {                                                            // y = GELU pre-activation
+        const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+        const float th = fast_tanh(k0 * (y + k1 * y * y * y));
+        v[r] *= 0.5f * (1.f + th) + 0.5f * y * (1.f - th * th) * k0 * (1.f + 3.f * k1 * y * y);
+      }
+    }
+  }
+  if (p.out_dtype == DLE_F32) {
+    float* c = (float*)p.C + off;
+    if (p.accumulate)
+      for (int r = 0; r < nval; ++r) v[r] += c[r];
+    if (nval == 8 && (p.ldc & 3) == 0) {
+      *(float4_t*)c = (float4_t){v[0], v[1], v[2], v[3]};
+      *(float4_t*)(c + 4) = (float4_t){v[4], v[5], v[6], v[7]};
+    } else {
+      for (int r = 0; r < nval; ++r) c[r] = v[r];
+    }
+    if (p.aux) {
+      float* a = (float*)p.aux + off;
+      for (int r = 0; r < nval; ++r) a[r] = pre[r];
+    }
+  } else {
+    const ushort8_t o = p.out_dtype == DLE_F16 ? pack8<DLE_F16>(v) : pack8<DLE_BF16>(v);
+    ushort8_t po = o;
+    if (p.aux) po = p.out_dtype == DLE_F16 ? pack8<DLE_F16>(pre) : pack8<DLE_BF16>(pre);
+    unsigned short* c = (unsigned short*)p.C + off;
+    if (full) *(ushort8_t*)c = o;
+    else
+      for (int r = 0; r < nval; ++r) c[r] = o[r];
+    if (p.aux) {
+      unsigned short* a = (unsigned short*)p.aux + off;
+      if (full) *(ushort8_t*)a = po;
+      else
+        for (int r = 0; r < nval; ++r) a[r] = po[r];
+    }
+  }
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory (s_waitcnt vmcnt(0)):
+// in an epilogue that would wait for every output store of the previous pass to be acknowledged by L2.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -434,9 +527,72 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
   // (32 KiB / 128 KiB) with conflict-free ds_write_b128 / ds_read_b128.
   float* epi = (float*)smem_raw;
   const bool vec16 = (p.ldc & 7) == 0 && ((((uintptr_t)p.C) | ((uintptr_t)p.aux) | ((uintptr_t)p.mask_src)) & 15) == 0;
+  // Fast path (interior tile, 16-bit output of the input type, 16-byte aligned rows, no split-K): everything that does
+  // not depend on the row -- the lane's 8 columns, its bias values, the swizzled LDS slots, the activation kind -- is
+  // hoisted out of the store loop, which is then ~30 VALU instructions per 16-byte store instead of ~100 VALU + 60
+  // SALU (the generic loop below re-decides every runtime flag per store; a K <= 256 GEMM was instruction-bound in it).
+  const bool fast = p.splitk == 1 && p.out_dtype == DT && vec16 && m0 + TM <= p.M && n0 + TN <= p.N;
+  constexpr int RPI = NT / (TN / 8), ITERS = (TM / 2) / RPI;      // rows per store-loop trip (16), trips per half
+  const int f_ml0 = tid / (TN / 8), f_nl = (tid % (TN / 8)) << 3;
+  float fbias[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) fbias[r] = 0.f;
+  if (fast && p.bias) {
+    const float4_t b0 = *(const float4_t*)(p.bias + n0 + f_nl), b1 = *(const float4_t*)(p.bias + n0 + f_nl + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { fbias[r] = b0[r]; fbias[4 + r] = b1[r]; }
+  }
+  auto fast_pass = [&](auto ACTC, int half) {
+    constexpr int act = decltype(ACTC)::value;
+    constexpr bool needs_src = act == ACT_RELU_BWD || act == ACT_ADD || act == ACT_GELU_BWD || act == ACT_TANH_BWD;
+    const float* e0 = epi + f_ml0 * TN;
+    const int c4 = f_nl >> 2;
+    const int olo = (c4 ^ f_ml0) << 2, ohi = ((c4 + 1) ^ f_ml0) << 2;
+    const long long off0 = (long long)(m0 + half * (TM / 2) + f_ml0) * p.ldc + n0 + f_nl;
+    const long long step = (long long)RPI * p.ldc;
+    unsigned short* c = (unsigned short*)p.C + off0;
+    unsigned short* ax = p.aux ? (unsigned short*)p.aux + off0 : nullptr;
+    const unsigned short* ms = needs_src ? p.mask_src + off0 : nullptr;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const float* e = e0 + it * RPI * TN;
+      const int x = (it & 1) << 6;                       // row & 31 alternates between ml0 and ml0 + 16
+      const float4_t lo = *(const float4_t*)(e + (olo ^ x)), hi = *(const float4_t*)(e + (ohi ^ x));
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r] = lo[r] + fbias[r]; v[4 + r] = hi[r] + fbias[4 + r]; }
+      if (ax) *(ushort8_t*)(ax + it * step) = pack8<DT>(v);      // pre-activation side output
+      if constexpr (act == ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+      } else if constexpr (act == ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = gelu_tanh2(v[r]);
+      } else if constexpr (act == ACT_TANH) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = fast_tanh(v[r]);
+      } else if constexpr (needs_src) {
+        float yv[8];
+        unpack8<DT>(*(const ushort8_t*)(ms + it * step), yv);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float y = yv[r];
+          if constexpr (act == ACT_RELU_BWD) v[r] = y > 0.f ? v[r] : 0.f;
+          else if constexpr (act == ACT_ADD) v[r] += y;
+          else if constexpr (act == ACT_TANH_BWD) v[r] *= (1.f - y * y);
+          else {
+            const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+            const float th = fast_tanh(k0 * (y + k1 * y * y * y));
+            v[r] *= 0.5f * (1.f + th) + 0.5f * y * (1.f - th * th) * k0 * (1.f + 3.f * k1 * y * y);
+          }
+        }
+      }
+      *(ushort8_t*)(c + it * step) = pack8<DT>(v);
+    }
+  };
   __builtin_amdgcn_s_waitcnt(0x0F70);    // the zero-fill DMA issued under the last K tile has landed
   for (int half = 0; half < 2; ++half) {
-  __syncthreads();                       // operand stages (half 0) / previous half's tile are no longer read
+  lds_barrier();                         // operand stages (half 0) / previous half's tile are no longer read
   if (wm == half) {
 #pragma unroll
     for (int i = 0; i < WTM; ++i)
@@ -449,7 +605,20 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
           *(float4_t*)(epi + row * TN + ((c4 ^ (row & 31)) << 2)) = v * p.alpha;
         }
   }
-  __syncthreads();
+  lds_barrier();
+  if (fast) {
+    switch (p.act) {
+      case ACT_NONE: fast_pass(std::integral_constant<int, ACT_NONE>(), half); break;
+      case ACT_RELU: fast_pass(std::integral_constant<int, ACT_RELU>(), half); break;
+      case ACT_GELU: fast_pass(std::integral_constant<int, ACT_GELU>(), half); break;
+      case ACT_RELU_BWD: fast_pass(std::integral_constant<int, ACT_RELU_BWD>(), half); break;
+      case ACT_ADD: fast_pass(std::integral_constant<int, ACT_ADD>(), half); break;
+      case ACT_GELU_BWD: fast_pass(std::integral_constant<int, ACT_GELU_BWD>(), half); break;
+      case ACT_TANH: fast_pass(std::integral_constant<int, ACT_TANH>(), half); break;
+      default: fast_pass(std::integral_constant<int, ACT_TANH_BWD>(), half); break;
+    }
+    continue;
+  }
 #pragma unroll 2
   for (int it = 0; it < (TM / 2) * (TN / 8) / NT; ++it) {
     const int idx = it * NT + tid;
@@ -465,552 +634,51 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
 #pragma unroll
       for (int r = 0; r < 4; ++r) { v[r] = lo[r]; v[4 + r] = hi[r]; }
     }
-    const long long off = (long long)m * p.ldc + n;
-    if (p.splitk > 1) {
-      if (p.ws) {
-        float* c = p.ws + ((long long)blockIdx.y * p.M + m) * p.N + n;
-        if (nval == 8 && (p.N & 3) == 0) {
-          *(float4_t*)c = (float4_t){v[0], v[1], v[2], v[3]};
-          *(float4_t*)(c + 4) = (float4_t){v[4], v[5], v[6], v[7]};
-        } else {
-          for (int r = 0; r < nval; ++r) c[r] = v[r];
-        }
-      } else {
-        float* c = (float*)p.C + off;
-        for (int r = 0; r < nval; ++r) unsafeAtomicAdd(c + r, v[r]);
-      }
-      continue;
-    }
-    const bool full = nval == 8 && vec16;
-    if (p.bias) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r)
-        if (r < nval) v[r] += p.bias[n + r];
-    }
-    float pre[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) pre[r] = v[r];
-    if (p.act == ACT_RELU) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-    } else if (p.act == ACT_GELU) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = gelu_tanh2(v[r]);
-    } else if (p.act == ACT_TANH) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = fast_tanh(v[r]);
-    } else if (p.act == ACT_RELU_BWD || p.act == ACT_ADD || p.act == ACT_GELU_BWD || p.act == ACT_TANH_BWD) {
-      ushort8_t sv = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (full) sv = *(const ushort8_t*)(p.mask_src + off);
-      else
-        for (int r = 0; r < nval; ++r) sv[r] = p.mask_src[off + r];
-      float yv[8];
-      unpack8<DT>(sv, yv);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const float y = yv[r];
-        if (p.act == ACT_RELU_BWD) v[r] = y > 0.f ? v[r] : 0.f;
-        else if (p.act == ACT_ADD) v[r] += y;
-        else if (p.act == ACT_TANH_BWD) v[r] *= (1.f - y * y);           // y = tanh output of the forward
-        else {                                                            // y = GELU pre-activation
-          const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-          const float th = fast_tanh(k0 * (y + k1 * y * y * y));
-          v[r] *= 0.5f * (1.f + th) + 0.5f * y * (1.f - th * th) * k0 * (1.f + 3.f * k1 * y * y);
-        }
-      }
-    }
-    if (p.out_dtype == DLE_F32) {
-      float* c = (float*)p.C + off;
-      if (p.accumulate)
-        for (int r = 0; r < nval; ++r) v[r] += c[r];
-      if (nval == 8 && (p.ldc & 3) == 0) {
-        *(float4_t*)c = (float4_t){v[0], v[1], v[2], v[3]};
-        *(float4_t*)(c + 4) = (float4_t){v[4], v[5], v[6], v[7]};
-      } else {
-        for (int r = 0; r < nval; ++r) c[r] = v[r];
-      }
-      if (p.aux) {
-        float* a = (float*)p.aux + off;
-        for (int r = 0; r < nval; ++r) a[r] = pre[r];
-      }
-    } else {
-      const ushort8_t o = p.out_dtype == DLE_F16 ? pack8<DLE_F16>(v) : pack8<DLE_BF16>(v);
-      ushort8_t po = o;
-      if (p.aux) po = p.out_dtype == DLE_F16 ? pack8<DLE_F16>(pre) : pack8<DLE_BF16>(pre);
-      unsigned short* c = (unsigned short*)p.C + off;
-      if (full) *(ushort8_t*)c = o;
-      else
-        for (int r = 0; r < nval; ++r) c[r] = o[r];
-      if (p.aux) {
-        unsigned short* a = (unsigned short*)p.aux + off;
-        if (full) *(ushort8_t*)a = po;
-        else
-          for (int r = 0; r < nval; ++r) a[r] = po[r];
-      }
-    }
+    epi_store8<DT>(p, v, m, n, nval, vec16, blockIdx.y);
   }
   }
-}
-
-// =====================================================================================================
-// Wave-specialised persistent variant (the default launch path).
-//
-// The kernel above pays, per 128x128 output tile, the HBM latency of its first DMA and the tail of its stores;
-// with K <= 1024 (every ResNet 1x1 conv, the attention slices, the DLRM MLPs) that fixed cost is most of the
-// time (~10 us per tile against ~0.3 us of MFMA per K tile).  Here
-//  * a workgroup is 5 wavefronts: waves 0-3 are CONSUMERS (MFMA + epilogue, 64x64 each as before), wave 4 is the
-//    PRODUCER: it owns every LDS-DMA instruction (32 per K tile: 16 for A, 16 for B) and all their address math;
-//  * workgroups are PERSISTENT (2 per CU) and walk the item list (batch slice x K slice x output tile) round
-//    robin; the producer runs exactly one K tile ahead ACROSS item boundaries, so the next item's first tile
-//    lands while the consumers finish the MFMAs and the epilogue of the current one;
-//  * only the producer ever waits on vmcnt (it has no stores, so vmcnt(0) means "my DMA landed"); consumers
-//    synchronise with it through one s_barrier per K tile and never drain their own global stores (CDNA4's
-//    vmcnt counts stores: a consumer-side vmcnt(0) would serialise the store latency of the previous tile);
-//  * every wavefront executes the SAME barrier sequence: one per K tile + four per item (epilogue staging).
-template <int MODE>
-struct Loader16 {
-  static constexpr bool RC = (MODE == 1 || MODE == 3 || MODE == 5);
-  unsigned off[16];
-  int a0[16], a1[16];
-  unsigned ok_mask;
-
-  __device__ __forceinline__ static int kin_of(int j, int lane) {
-    if (!RC) { const int row = j * 8 + (lane >> 3); return (((lane & 7) ^ swz_kc(row))) * 8; }
-    return j * 4 + (lane >> 4);
-  }
-
-  __device__ __forceinline__ void init(int lane, int row0, int nrows, long long ld, const ConvGeom& cg) {
-    ok_mask = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      if (!RC) {
-        const int row = j * 8 + (lane >> 3), cpos = lane & 7;
-        const int chunk = cpos ^ swz_kc(row);
-        const int g = row0 + row;
-        if (g < nrows) ok_mask |= 1u << j;
-        if (MODE == 0) {
-          off[j] = (unsigned)(((long long)row * ld + chunk * 8) * 2);
-        } else if (MODE == 2) {
-          const int q = g % cg.Q, t = g / cg.Q;
-          const int pp = t % cg.P, n = t / cg.P;
-          a0[j] = pp * cg.stride - cg.pad;
-          a1[j] = q * cg.stride - cg.pad;
-          off[j] = (unsigned)((((long long)n * cg.H + a0[j]) * cg.W + a1[j]) * cg.C * 2);
-        } else {
-          const int w = g % cg.W, t = g / cg.W;
-          const int h = t % cg.H, n = t / cg.H;
-          a0[j] = h + cg.pad;
-          a1[j] = w + cg.pad;
-          off[j] = (unsigned)n;
-        }
-      } else {
-        const int kr = j * 4 + (lane >> 4), cpos = lane & 15;
-        const int chunk = (((cpos >> 1) ^ swz_rc(kr)) << 1) | (cpos & 1);
-        const int g = row0 + chunk * 8;
-        if (g < nrows) ok_mask |= 1u << j;
-        if (MODE == 1) {
-          off[j] = (unsigned)(((long long)kr * ld + chunk * 8) * 2);
-        } else if (MODE == 3) {
-          const int tap = g / cg.C, c = g - tap * cg.C;
-          a0[j] = tap / cg.S;
-          a1[j] = tap - a0[j] * cg.S;
-          off[j] = (unsigned)(c * 2);
-        } else {
-          off[j] = (unsigned)(g * 2);
-        }
-      }
-    }
-  }
-
-  __device__ __forceinline__ void issue(const unsigned short* base, unsigned short* tile, int lane, int krem, int k0,
-                                        const ConvGeom& cg) {
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xFFFFFFE0, 0x00020000);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int kin = kin_of(j, lane);
-      bool ok = ((ok_mask >> j) & 1u) && kin < krem;
-      unsigned o = off[j];
-      if (MODE == 2) {
-        const int k = k0 + kin;
-        const int tap = k / cg.C, c = k - tap * cg.C;
-        const int r = tap / cg.S, s2 = tap - r * cg.S;
-        const int h = a0[j] + r, w = a1[j] + s2;
-        ok = ok && h >= 0 && h < cg.H && w >= 0 && w < cg.W;
-        o += (unsigned)(((r * cg.W + s2) * cg.C + c) * 2);
-      } else if (MODE == 4) {
-        const int k = k0 + kin;
-        const int tap = k / cg.Ko, ko = k - tap * cg.Ko;
-        const int r = tap / cg.S, s2 = tap - r * cg.S;
-        const int hp = a0[j] - r, wp = a1[j] - s2;
-        const int pp = hp / cg.stride, q = wp / cg.stride;
-        ok = ok && hp >= 0 && wp >= 0 && pp * cg.stride == hp && q * cg.stride == wp && pp < cg.P && q < cg.Q;
-        o = (unsigned)(((((long long)off[j] * cg.P + pp) * cg.Q + q) * cg.Ko + ko) * 2);
-      } else if (MODE == 3) {
-        const int pix = k0 + kin;
-        const int q = pix % cg.Q, t = pix / cg.Q;
-        const int pp = t % cg.P, n = t / cg.P;
-        const int h = pp * cg.stride - cg.pad + a0[j], w = q * cg.stride - cg.pad + a1[j];
-        ok = ok && h >= 0 && h < cg.H && w >= 0 && w < cg.W;
-        o += (unsigned)((((long long)n * cg.H + h) * cg.W + w) * cg.C * 2);
-      } else if (MODE == 5) {
-        const int k = k0 + kin;
-        const int tap = k / cg.Ko, ko = k - tap * cg.Ko;
-        o += (unsigned)((((long long)ko * cg.R * cg.S + tap) * cg.C) * 2);
-      }
-      dma16(rs, tile + j * 512, ok ? o : OOB_OFF);
-    }
-  }
-};
-
-struct WsItem {
-  const unsigned short* A;
-  const unsigned short* B;
-  long long c_off;
-  int m0, n0, kt0, kt1, kend, z;
-};
-
-template <int DT, int A_MODE, int B_MODE>
-__global__ __launch_bounds__(320, 3) void gemm3_kernel(Gemm2Args p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned short* lds = (unsigned short*)smem_raw;   // [2 stages][A tile 8192 halves | B tile 8192 halves]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const int ntiles = tiles_m * tiles_n;
-  const int ktiles = (p.K + BK - 1) / BK;
-  const int per_slice = ntiles * p.splitk;
-  const int nbatch = p.batch_inner > 0 ? p.batch_count : 1;
-  const long long nitems = (long long)per_slice * nbatch;
-  const int G = gridDim.x;
-  int bid = blockIdx.x;
-  if ((G & 7) == 0) bid = (bid & 7) * (G >> 3) + (bid >> 3);   // one XCD = one contiguous band of each round
-
-  auto decode = [&](long long w, WsItem& it) {
-    const int zb = (int)(w / per_slice);
-    const int r = (int)(w - (long long)zb * per_slice);
-    const int z = r / ntiles, t = r - z * ntiles;
-    const int tm = t / tiles_n, tn = t - tm * tiles_n;   // N fastest: concurrent tiles share the A rows
-    it.m0 = tm * BM; it.n0 = tn * BN; it.z = z;
-    it.kt0 = (int)((long long)z * ktiles / p.splitk);      // balanced K slices
-    it.kt1 = (int)((long long)(z + 1) * ktiles / p.splitk);
-    it.kend = (it.kt1 * BK < p.K) ? it.kt1 * BK : p.K;
-    it.A = p.A; it.B = p.B; it.c_off = 0;
-    if (p.batch_inner > 0) {
-      const int zo = zb / p.batch_inner, zi = zb - zo * p.batch_inner;
-      it.A += zo * p.sa_o + zi * p.sa_i;
-      it.B += zo * p.sb_o + zi * p.sb_i;
-      it.c_off = zo * p.sc_o + zi * p.sc_i;
-    }
-  };
-
-  if (wave == 4) {
-    // ------------------------------------------------------------------ producer
-    Loader16<A_MODE> la;
-    Loader16<B_MODE> lb;
-    int stage = 0;
-    bool first = true;
-    for (long long w = bid; w < nitems; w += G) {
-      WsItem it;
-      decode(w, it);
-      la.init(lane, it.m0, p.M, p.lda, p.cg);
-      lb.init(lane, it.n0, p.N, p.ldb, p.cg);
-      for (int kt = it.kt0; kt < it.kt1; ++kt) {
-        const int k0 = kt * BK;
-        // slot barrier of the PREVIOUS slot: consumers are done with the stage this tile goes into
-        if (!first) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // previous slot has landed ...
-          __builtin_amdgcn_s_barrier();                       // ... and is handed to the consumers
-        }
-        unsigned short* ta = lds + stage * (BM * BK + BN * BK);
-        unsigned short* tb = ta + BM * BK;
-        const unsigned short* ba = A_MODE == 0 ? it.A + (long long)it.m0 * p.lda + k0
-                                 : A_MODE == 1 ? it.A + (long long)k0 * p.lda + it.m0 : it.A;
-        const unsigned short* bb = B_MODE == 0 ? it.B + (long long)it.n0 * p.ldb + k0
-                                 : B_MODE == 1 ? it.B + (long long)k0 * p.ldb + it.n0 : it.B;
-        la.issue(ba, ta, lane, it.kend - k0, k0, p.cg);
-        lb.issue(bb, tb, lane, it.kend - k0, k0, p.cg);
-        stage ^= 1;
-        first = false;
-        if (kt == it.kt0 && w != bid) {
-          // this was the first tile of a new item, issued right after the slot barrier of the previous item's
-          // last tile: the consumers now run that item's epilogue (4 barriers)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) __builtin_amdgcn_s_barrier();
-        }
-      }
-    }
-    if (!first) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                           // hand over the last slot
-#pragma unroll
-      for (int e = 0; e < 4; ++e) __builtin_amdgcn_s_barrier();   // last item's epilogue
-    }
-    return;
-  }
-
-  // -------------------------------------------------------------------- consumers
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fr = lane & 31, fh = lane >> 5;          // 32x32x16 fragment: row fr, k group fh (8 elements)
-  const int tg = lane >> 4, ti = lane & 15;          // transpose-read addressing: 16-lane groups
-  const bool vec16 = (p.ldc & 7) == 0 && ((((uintptr_t)p.C) | ((uintptr_t)p.aux) | ((uintptr_t)p.mask_src)) & 15) == 0 &&
-                     (p.batch_inner == 0 || ((p.sc_o | p.sc_i) & 7) == 0);
-  int stage = 0;
-  for (long long w = bid; w < nitems; w += G) {
-    WsItem cur;
-    decode(w, cur);
-    float16_t acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    for (int kt = cur.kt0; kt < cur.kt1; ++kt) {
-      __builtin_amdgcn_s_barrier();          // slot barrier: the producer saw this tile land
-      const unsigned short* ta = lds + stage * (BM * BK + BN * BK);
-      const unsigned short* tb = ta + BM * BK;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        ushort8_t fa[2], fb[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          if (!Loader16<A_MODE>::RC) {
-            const int row = wm * 64 + i * 32 + fr;
-            fa[i] = *(const ushort8_t*)(ta + row * BK + (((ks * 2 + fh) ^ swz_kc(row)) << 3));
-          } else {
-            const int rbase = wm * 64 + i * 32 + ((tg & 1) << 4);
-            const int kb = ks * 16 + (tg >> 1) * 8 + (ti >> 2);
-            const int chunk = (rbase >> 3) + ((ti & 3) >> 1);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const int k = kb + h * 4;
-              const int cpos = (((chunk >> 1) ^ swz_rc(k)) << 1) | (chunk & 1);
-              const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                  (__attribute__((address_space(3))) short4_t*)(ta + k * BM + cpos * 8 + ((ti & 1) << 2)));
-#pragma unroll
-              for (int e = 0; e < 4; ++e) fa[i][h * 4 + e] = (unsigned short)v[e];
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (!Loader16<B_MODE>::RC) {
-            const int row = wn * 64 + j * 32 + fr;
-            fb[j] = *(const ushort8_t*)(tb + row * BK + (((ks * 2 + fh) ^ swz_kc(row)) << 3));
-          } else {
-            const int rbase = wn * 64 + j * 32 + ((tg & 1) << 4);
-            const int kb = ks * 16 + (tg >> 1) * 8 + (ti >> 2);
-            const int chunk = (rbase >> 3) + ((ti & 3) >> 1);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const int k = kb + h * 4;
-              const int cpos = (((chunk >> 1) ^ swz_rc(k)) << 1) | (chunk & 1);
-              const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                  (__attribute__((address_space(3))) short4_t*)(tb + k * BN + cpos * 8 + ((ti & 1) << 2)));
-#pragma unroll
-              for (int e = 0; e < 4; ++e) fb[j][h * 4 + e] = (unsigned short)v[e];
-            }
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = Mfma32x16<DT>::run(fb[j], fa[i], acc[i][j]);
-      }
-      stage ^= 1;
-    }
-
-    // ---- epilogue.  D = (B A^T) tile: lane owns C[m = fr-th row][n = 8*(r>>2) + 4*fh + (r&3)].
-    // The stage just consumed is free (the other one receives the next item's first K tile) and serves as the
-    // fp32 staging tile: 64 rows x 128 columns, 16-byte slots XOR-swizzled by the row (exactly 32 KiB,
-    // conflict-free ds_write_b128 / ds_read_b128), two passes (the wm = 0 waves, then the wm = 1 waves); the
-    // bias / activation / mask / addend math and the global traffic run with 8 consecutive columns per lane.
-    float* epi = (float*)(lds + (stage ^ 1) * (BM * BK + BN * BK));
-    const int m0 = cur.m0, n0 = cur.n0;
-    for (int half = 0; half < 2; ++half) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();          // E1 / E3: operand reads (previous half's tile reads) are done
-      if (wm == half) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-              float4_t v = {acc[i][j][qd * 4 + 0], acc[i][j][qd * 4 + 1], acc[i][j][qd * 4 + 2], acc[i][j][qd * 4 + 3]};
-              const int row = i * 32 + fr, c4 = (wn * 64 + j * 32 + qd * 8 + fh * 4) >> 2;
-              *(float4_t*)(epi + row * BN + ((c4 ^ (row & 31)) << 2)) = v * p.alpha;
-            }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();          // E2 / E4: the staged tile is visible
-#pragma unroll 2
-      for (int it = 0; it < 4; ++it) {
-        const int idx = it * 256 + tid;
-        const int ml = idx >> 4, nl = (idx & 15) << 3;
-        const int m = m0 + half * 64 + ml, n = n0 + nl;
-        if (m >= p.M || n >= p.N) continue;
-        const int nval = (p.N - n) < 8 ? (p.N - n) : 8;
-        float v[8];
-        {
-          const int c4 = nl >> 2;
-          const float4_t lo = *(const float4_t*)(epi + ml * BN + ((c4 ^ (ml & 31)) << 2));
-          const float4_t hi = *(const float4_t*)(epi + ml * BN + (((c4 + 1) ^ (ml & 31)) << 2));
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { v[r] = lo[r]; v[4 + r] = hi[r]; }
-        }
-        const long long off = cur.c_off + (long long)m * p.ldc + n;
-        if (p.splitk > 1) {
-          if (p.ws) {
-            float* c = p.ws + ((long long)cur.z * p.M + m) * p.N + n;
-            if (nval == 8 && (p.N & 3) == 0) {
-              *(float4_t*)c = (float4_t){v[0], v[1], v[2], v[3]};
-              *(float4_t*)(c + 4) = (float4_t){v[4], v[5], v[6], v[7]};
-            } else {
-              for (int r = 0; r < nval; ++r) c[r] = v[r];
-            }
-          } else {
-            float* c = (float*)p.C + off;
-            for (int r = 0; r < nval; ++r) unsafeAtomicAdd(c + r, v[r]);
-          }
-          continue;
-        }
-        const bool full = nval == 8 && vec16;
-        if (p.bias) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r)
-            if (r < nval) v[r] += p.bias[n + r];
-        }
-        float pre[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) pre[r] = v[r];
-        if (p.act == ACT_RELU) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-        } else if (p.act == ACT_GELU) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = gelu_tanh2(v[r]);
-        } else if (p.act == ACT_TANH) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = fast_tanh(v[r]);
-        } else if (p.act == ACT_RELU_BWD || p.act == ACT_ADD || p.act == ACT_GELU_BWD || p.act == ACT_TANH_BWD) {
-          ushort8_t sv = {0, 0, 0, 0, 0, 0, 0, 0};
-          if (full) sv = *(const ushort8_t*)(p.mask_src + off);
-          else
-            for (int r = 0; r < nval; ++r) sv[r] = p.mask_src[off + r];
-          float yv[8];
-          unpack8<DT>(sv, yv);
-#pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            const float y = yv[r];
-            if (p.act == ACT_RELU_BWD) v[r] = y > 0.f ? v[r] : 0.f;
-            else if (p.act == ACT_ADD) v[r] += y;
-            else if (p.act == ACT_TANH_BWD) v[r] *= (1.f - y * y);
-            else {
-              const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-              const float th = fast_tanh(k0 * (y + k1 * y * y * y));
-              v[r] *= 0.5f * (1.f + th) + 0.5f * y * (1.f - th * th) * k0 * (1.f + 3.f * k1 * y * y);
-            }
-          }
-        }
-        if (p.out_dtype == DLE_F32) {
-          float* c = (float*)p.C + off;
-          if (p.accumulate)
-            for (int r = 0; r < nval; ++r) v[r] += c[r];
-          if (nval == 8 && (p.ldc & 3) == 0 && (cur.c_off & 3) == 0) {
-            *(float4_t*)c = (float4_t){v[0], v[1], v[2], v[3]};
-            *(float4_t*)(c + 4) = (float4_t){v[4], v[5], v[6], v[7]};
-          } else {
-            for (int r = 0; r < nval; ++r) c[r] = v[r];
-          }
-          if (p.aux) {
-            float* a = (float*)p.aux + off;
-            for (int r = 0; r < nval; ++r) a[r] = pre[r];
-          }
-        } else {
-          const ushort8_t o = p.out_dtype == DLE_F16 ? pack8<DLE_F16>(v) : pack8<DLE_BF16>(v);
-          ushort8_t po = o;
-          if (p.aux) po = p.out_dtype == DLE_F16 ? pack8<DLE_F16>(pre) : pack8<DLE_BF16>(pre);
-          unsigned short* c = (unsigned short*)p.C + off;
-          if (full) *(ushort8_t*)c = o;
-          else
-            for (int r = 0; r < nval; ++r) c[r] = o[r];
-          if (p.aux) {
-            unsigned short* a = (unsigned short*)p.aux + off;
-            if (full) *(ushort8_t*)a = po;
-            else
-              for (int r = 0; r < nval; ++r) a[r] = po[r];
-          }
-        }
-      }
-    }
-  }
-}
-
-// grid size of the persistent kernel: two workgroups per CU (64 KiB LDS each), never more than the items
-static int gemm3_grid(long long items) {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  const long long cap = 2LL * cus;
-  return (int)(items < cap ? items : cap);
 }
 
 // One launcher for every entry point.  modes: (A_MODE, B_MODE) in {(0,0),(0,1),(1,1),(2,0),(4,5),(1,3)}.
-// DLE_GEMM_WS=1 selects the wave-specialised persistent kernel (experimental: one producer wave cannot issue
-// 32 KiB of LDS-DMA per K tile fast enough -- ~60 cycles per 1 KiB piece -- so it loses to the kernel above).
+//  * plain matrix operands, M, N >= 256, >= 4 K tiles per slice and enough 256x256 tiles to cover most of the chip:
+//    the 256x256 tile (DLE_GEMM_BIG=0 disables it, =1 forces it whenever the shape allows);
+//  * everything else (convolutions, batched attention slices, small / skinny shapes): the 128x128 tile.
+// (A persistent variant of the 256x256 kernel -- one workgroup per CU walking the tile list, the K pipeline running
+//  across tile boundaries, the epilogue through the 32 KiB of LDS the stages leave free -- measured 8% SLOWER at
+//  16384x4096x1024: its output stores still meet a vmcnt(0) three k-steps later and the 8-pass epilogue costs more
+//  than the tile turnover it saves; it was removed.)
 static int launch_gemm(const Gemm2Args& p_in, int in_dtype, int amode, int bmode, int batch, hipStream_t stream) {
-  static const bool v2 = !(getenv("DLE_GEMM_WS") != nullptr && getenv("DLE_GEMM_WS")[0] == '1');
   Gemm2Args p = p_in;
-  { const char* d = getenv("DLE_GEMM_SKIP"); p.debug_skip = d ? atoi(d) : 0; }
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  const size_t lds = GEMM2_LDS_BYTES;
-  if (v2) {
-    p.batch_count = batch;
-    const int kt_per_item = ((p.K + BK - 1) / BK + p.splitk - 1) / p.splitk;
-    // 256x256 tile (one workgroup per CU): plain matrix operands, enough K tiles to amortise the 128 KiB epilogue,
-    // enough tiles to cover most of the chip.  DLE_GEMM_BIG=0 disables it, =1 forces it whenever the shape allows.
-    {
-      static const int big_mode = getenv("DLE_GEMM_BIG") ? atoi(getenv("DLE_GEMM_BIG")) : -1;
-      const long long tiles_big = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.splitk * (batch > 0 ? batch : 1);
-      const bool fits = amode <= 1 && bmode <= 1 && p.M >= 256 && p.N >= 256 &&
-                        p.lda * 512 <= 0x7FFFFFFFLL && p.ldb * 512 <= 0x7FFFFFFFLL;
-      const bool want = big_mode == 1 || (big_mode != 0 && kt_per_item >= 4 && tiles_big >= 160);
-      if (fits && want) {
-        dim3 grid((unsigned)(((p.M + 255) / 256) * ((p.N + 255) / 256)), p.splitk, batch > 0 ? batch : 1), block(512);
-        const size_t lds_big = 2 * (256 * BK + 256 * BK) * 2;
+  p.debug_skip = 0;
+  p.batch_count = batch;
+  const int ktiles = (p.K + BK - 1) / BK;
+  const int kt_per_item = (ktiles + p.splitk - 1) / p.splitk;
+  if (amode == 1 && bmode == 0) { dle_set_error("gemm: unsupported operand layout"); return 1; }
+  static const int big_mode = getenv("DLE_GEMM_BIG") ? atoi(getenv("DLE_GEMM_BIG")) : -1;
+  const long long tiles_big = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  const bool fits = amode <= 1 && bmode <= 1 && p.M >= 256 && p.N >= 256 &&
+                    p.lda * 512 <= 0x7FFFFFFFLL && p.ldb * 512 <= 0x7FFFFFFFLL;
+  // (split-K weight gradients stay on the 128x128 tile: measured faster there -- more, smaller slabs in flight)
+  const bool want = big_mode >= 1 || (big_mode != 0 && p.splitk == 1 && kt_per_item >= 4 && tiles_big * (batch > 0 ? batch : 1) >= 160);
+  if (fits && want) {
+    dim3 grid((unsigned)tiles_big, p.splitk, batch > 0 ? batch : 1), block(512);
+    const size_t lds_big = 2 * (256 * BK + 256 * BK) * 2;
 #define GOBIG(DT, AM, BMODE) do { static bool attr_set = false; \
-          if (!attr_set) { hipFuncSetAttribute((const void*)gemm2_kernel<DT, AM, BMODE, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big); attr_set = true; } \
-          hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE, 2, 1>), grid, block, lds_big, stream, p); } while (0)
+      if (!attr_set) { hipFuncSetAttribute((const void*)gemm2_kernel<DT, AM, BMODE, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big); attr_set = true; } \
+      hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE, 2, 1>), grid, block, lds_big, stream, p); } while (0)
 #define PICKBIG(DT) do { if (amode == 0 && bmode == 0) GOBIG(DT, 0, 0); else if (amode == 0) GOBIG(DT, 0, 1); else GOBIG(DT, 1, 1); } while (0)
-        if (amode == 1 && bmode == 0) { dle_set_error("gemm: unsupported operand layout"); return 1; }
-        if (in_dtype == DLE_F16) PICKBIG(DLE_F16); else PICKBIG(DLE_BF16);
+    if (in_dtype == DLE_F16) PICKBIG(DLE_F16); else PICKBIG(DLE_BF16);
 #undef GOBIG
 #undef PICKBIG
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { dle_set_error("gemm launch failed: %s", hipGetErrorString(e)); return (int)e; }
-        return 0;
-      }
-    }
+  } else {
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const size_t lds = GEMM2_LDS_BYTES;
     dim3 grid(tiles, p.splitk, batch > 0 ? batch : 1), block(256);
-    static const int one_stage_max = getenv("DLE_GEMM_1STAGE_MAX") ? atoi(getenv("DLE_GEMM_1STAGE_MAX")) : 2;
-    const bool one = kt_per_item <= one_stage_max;
-#define GO(DT, AM, BMODE) do { if (one) hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE, 1, 0>), grid, block, lds / 2, stream, p); \
-                               else hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE, 2, 0>), grid, block, lds, stream, p); } while (0)
+    // (a single-stage, 4-workgroups-per-CU variant for K <= 128 existed; with the hoisted epilogue it measured 2x
+    //  SLOWER than this one -- 802816x256x64: 295 vs 144 us -- its 128-VGPR budget spilled; removed)
+#define GO(DT, AM, BMODE) hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE, 2, 0>), grid, block, lds, stream, p)
 #define PICK(DT) do { if (amode == 0 && bmode == 0) GO(DT, 0, 0); else if (amode == 0) GO(DT, 0, 1); else if (amode == 1 && bmode == 1) GO(DT, 1, 1); \
       else if (amode == 2) GO(DT, 2, 0); else if (amode == 4) GO(DT, 4, 5); else GO(DT, 1, 3); } while (0)
-    if (in_dtype == DLE_F16) PICK(DLE_F16); else PICK(DLE_BF16);
-#undef GO
-  } else {
-    p.batch_count = batch > 0 ? batch : 1;
-    if (batch <= 0) p.batch_inner = 0;
-    const long long items = (long long)tiles * p.splitk * p.batch_count;
-    dim3 grid(gemm3_grid(items)), block(320);
-#define GO(DT, AM, BMODE) hipLaunchKernelGGL((gemm3_kernel<DT, AM, BMODE>), grid, block, lds, stream, p)
     if (in_dtype == DLE_F16) PICK(DLE_F16); else PICK(DLE_BF16);
 #undef GO
 #undef PICK

@@ -269,11 +269,6 @@ def colsum(x, out=None, accumulate=False):
 def pick_splitk(m_out, n_out, k, target_blocks=512):
     """Split the contraction so that a skinny wgrad still fills 256 CUs (K tiles of 64)."""
     ktiles = (k + 63) // 64
-    if m_out >= 256 and n_out >= 256 and ktiles >= 16:
-        # the 256x256 tile kernel (one workgroup per CU) takes it: aim at >= one full wave of 256 workgroups,
-        # keeping >= 4 K tiles per slice (csrc/gemm_dma.hip launch_gemm)
-        tiles = ((m_out + 255) // 256) * ((n_out + 255) // 256)
-        return max(1, min(ktiles // 4, -(-256 // tiles)))
     tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
     s = max(1, min(ktiles, target_blocks // max(tiles, 1)))
     return s

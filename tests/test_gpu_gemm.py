@@ -93,3 +93,36 @@ def test_gemm_strided_and_errors(cuda):
         F.gemm(a.float(), b.float(), 64, 32, 128, True, True)
     with pytest.raises(ValueError):
         F.gemm(a, b, 64, 32, 128, False, True)
+
+
+# Shapes the launcher routes to the 256x256 eight-wave tile (>= 160 tiles x slices, >= 4 K tiles per slice): full and
+# ragged tiles, K tail, all three operand layouts, split-K slabs, and the fused epilogues.
+BIG_CASES = [(4096, 2560, 256), (2824, 3848, 328), (1024, 1024, 4096)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("mnk", BIG_CASES)
+def test_gemm_big_tile(cuda, mnk, dtype):
+    F, C = _F()
+    m, n, k = mnk
+    gen = torch.Generator().manual_seed(m + n + k)
+    a = _mk((m, k), dtype, gen).to(cuda)
+    b = _mk((n, k), dtype, gen).to(cuda)
+    bias = torch.randn(n, generator=gen).to(cuda)
+    ref = a.double() @ b.double().T                                    # fp64 on the GPU through torch (orientation only)
+    tol = (2e-3 if dtype == torch.float16 else 1.6e-2) * np.sqrt(k)
+    sk = 16 if k >= 4096 else 1                                         # 16 tiles x 16 slices for the K-heavy case
+
+    def chk(out, what, r=ref):
+        err = (out.double() - r).abs().max().item()
+        assert err <= tol, "%s: max err %g (m,n,k=%s)" % (what, err, mnk)
+
+    chk(F.gemm(a, b, m, n, k, True, True, out_dtype=torch.float32, splitk=sk), "kc/kc f32")
+    if sk == 1:
+        y = F.gemm(a, b, m, n, k, True, True, bias=bias, act=C.ACT_RELU)
+        chk(y, "kc/kc 16 bias relu", (ref + bias.double()).clamp(min=0))
+    bt = b.T.contiguous()
+    chk(F.gemm(a, bt, m, n, k, True, False, out_dtype=torch.float32, splitk=sk), "kc/nc")
+    at = a.T.contiguous()
+    chk(F.gemm(at, bt, m, n, k, False, False, out_dtype=torch.float32, splitk=sk), "mc/nc")
+    chk(F.gemm(at, bt, m, n, k, False, False, out_dtype=torch.float32, splitk=max(sk, 2)), "mc/nc splitk")
