@@ -87,16 +87,16 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(BnRedArgs a) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) { mu[k] = a.mean[c0 + k]; rs[k] = a.rstd[c0 + k]; }
     }
-    for (long long r = r0 + rl; r < r1; r += rstep) {
+    auto accum = [&](ushort8_t xv, ushort8_t gv, ushort8_t yv) {
       float xf[8];
-      unpack8<DT>(*(const ushort8_t*)(a.x + r * a.C + c0), xf);
+      unpack8<DT>(xv, xf);
       if (MODE == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) { s0[k] += xf[k]; s1[k] += xf[k] * xf[k]; }
       } else {
         float gf[8], yf[8];
-        unpack8<DT>(*(const ushort8_t*)(a.dy + r * a.C + c0), gf);
-        if (a.y) unpack8<DT>(*(const ushort8_t*)(a.y + r * a.C + c0), yf);
+        unpack8<DT>(gv, gf);
+        if (a.y) unpack8<DT>(yv, yf);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           float g = gf[k];
@@ -105,6 +105,31 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(BnRedArgs a) {
           s1[k] += g * (xf[k] - mu[k]) * rs[k];
         }
       }
+    };
+    constexpr int U = MODE == 0 ? 8 : 4;          // rows in flight per lane (8 / 12 independent 16-byte loads)
+    long long r = r0 + rl;
+    for (; r + (long long)(U - 1) * rstep < r1; r += (long long)U * rstep) {
+      ushort8_t xv[U], gv[U], yv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long o = (r + (long long)u * rstep) * a.C + c0;
+        xv[u] = *(const ushort8_t*)(a.x + o);
+        if (MODE == 1) {
+          gv[u] = *(const ushort8_t*)(a.dy + o);
+          if (a.y) yv[u] = *(const ushort8_t*)(a.y + o);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) accum(xv[u], gv[u], yv[u]);
+    }
+    for (; r < r1; r += rstep) {
+      const long long o = r * a.C + c0;
+      ushort8_t gv = {}, yv = {};
+      if (MODE == 1) {
+        gv = *(const ushort8_t*)(a.dy + o);
+        if (a.y) yv = *(const ushort8_t*)(a.y + o);
+      }
+      accum(*(const ushort8_t*)(a.x + o), gv, yv);
     }
   }
 #pragma unroll
@@ -249,15 +274,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
   int c0 = (int)(first % C8) * 8;
 #pragma unroll
   for (int k = 0; k < 8; ++k) { sc[k] = rstd[c0 + k] * gamma[c0 + k]; sh[k] = beta[c0 + k] - mean[c0 + k] * sc[k]; }
-  for (long long i = first; i < total8; i += stride) {
-    if (!invariant) {
-      c0 = (int)(i % C8) * 8;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { sc[k] = rstd[c0 + k] * gamma[c0 + k]; sh[k] = beta[c0 + k] - mean[c0 + k] * sc[k]; }
-    }
+  auto one = [&](long long i, ushort8_t xv, ushort8_t rv) {
     float xf[8], rf[8], of[8];
-    unpack8<DT>(((const ushort8_t*)x)[i], xf);
-    if (res) unpack8<DT>(((const ushort8_t*)res)[i], rf);
+    unpack8<DT>(xv, xf);
+    if (res) unpack8<DT>(rv, rf);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       float v = xf[k] * sc[k] + sh[k];
@@ -266,6 +286,30 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
       of[k] = v;
     }
     ((ushort8_t*)y)[i] = pack8<DT>(of);
+  };
+  long long i = first;
+  if (invariant) {
+    // 4 trips in flight per lane (4-8 independent 16-byte loads): a lane alone does not cover the HBM latency
+    for (; i + 3 * stride < total8; i += 4 * stride) {
+      ushort8_t xv[4], rv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xv[u] = ((const ushort8_t*)x)[i + u * stride];
+        if (res) rv[u] = ((const ushort8_t*)res)[i + u * stride];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(i + u * stride, xv[u], rv[u]);
+    }
+  }
+  for (; i < total8; i += stride) {
+    if (!invariant) {
+      c0 = (int)(i % C8) * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { sc[k] = rstd[c0 + k] * gamma[c0 + k]; sh[k] = beta[c0 + k] - mean[c0 + k] * sc[k]; }
+    }
+    ushort8_t rv = {};
+    if (res) rv = ((const ushort8_t*)res)[i];
+    one(i, ((const ushort8_t*)x)[i], rv);
   }
 }
 
@@ -335,12 +379,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
     }
   };
   load((int)(first % C8) * 8);
-  for (long long i = first; i < total8; i += stride) {
-    if (!invariant) load((int)(i % C8) * 8);
+  auto one = [&](long long i, ushort8_t gv, ushort8_t xv, ushort8_t yv) {
     float gf[8], xf[8], yf[8], of[8];
-    unpack8<DT>(((const ushort8_t*)dy)[i], gf);
-    unpack8<DT>(((const ushort8_t*)x)[i], xf);
-    if (y) unpack8<DT>(((const ushort8_t*)y)[i], yf);
+    unpack8<DT>(gv, gf);
+    unpack8<DT>(xv, xf);
+    if (y) unpack8<DT>(yv, yf);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       if (y && !(yf[k] > 0.f)) gf[k] = 0.f;
@@ -349,6 +392,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
     }
     ((ushort8_t*)dx)[i] = pack8<DT>(of);
     if (g_out) ((ushort8_t*)g_out)[i] = pack8<DT>(gf);
+  };
+  long long i = first;
+  if (invariant) {
+    for (; i + 2 * stride < total8; i += 3 * stride) {        // 3 trips = 6-9 independent 16-byte loads in flight
+      ushort8_t gv[3], xv[3], yv[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        gv[u] = ((const ushort8_t*)dy)[i + u * stride];
+        xv[u] = ((const ushort8_t*)x)[i + u * stride];
+        if (y) yv[u] = ((const ushort8_t*)y)[i + u * stride];
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) one(i + u * stride, gv[u], xv[u], yv[u]);
+    }
+  }
+  for (; i < total8; i += stride) {
+    if (!invariant) load((int)(i % C8) * 8);
+    ushort8_t yv = {};
+    if (y) yv = ((const ushort8_t*)y)[i];
+    one(i, ((const ushort8_t*)dy)[i], ((const ushort8_t*)x)[i], yv);
   }
 }
 

@@ -36,12 +36,42 @@
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_ADD = 4, ACT_GELU_BWD = 5, ACT_TANH = 6,
        ACT_TANH_BWD = 7 };
 
+// Division by a launch-time constant as multiply-high + shift (exact for 0 <= n < 2^31): the im2col loaders
+// decompose k -> (tap, channel) and pixel -> (n, p, q) for every DMA piece of every K tile; with generic integer
+// division (~40 VALU instructions each) the 3x3 convolutions were bound by their address arithmetic.
+struct FastDiv {
+  unsigned mul, shr;
+  int d;
+};
+static FastDiv make_fastdiv(int d) {
+  FastDiv f;
+  f.d = d;
+  if (d <= 1) { f.mul = 0; f.shr = 0; return f; }
+  unsigned lg = 0;
+  while ((1u << lg) < (unsigned)d) ++lg;                 // ceil(log2 d)
+  const unsigned p = 31 + lg;
+  f.mul = (unsigned)(((1ull << p) + (unsigned)d - 1) / (unsigned)d);
+  f.shr = p - 32;
+  return f;
+}
+__device__ __forceinline__ int fd_div(int n, const FastDiv& f) {
+  return f.d <= 1 ? n : (int)(__umulhi((unsigned)n, f.mul) >> f.shr);
+}
+
 struct ConvGeom {        // implicit-GEMM operand geometry (NHWC tensors, KRSC weights)
   int H, W, C;           // spatial size / channels of the tensor the im2col operand reads
   int P, Q;              // spatial size of the convolution OUTPUT (forward sense)
   int R, S, stride, pad;
   int Ko;                // output channels (forward sense)
+  FastDiv dC, dS, dKo, dQ, dP, dW, dH, dStride;
 };
+static ConvGeom make_geom(int H, int W, int C, int P, int Q, int R, int S, int stride, int pad, int Ko) {
+  ConvGeom g;
+  g.H = H; g.W = W; g.C = C; g.P = P; g.Q = Q; g.R = R; g.S = S; g.stride = stride; g.pad = pad; g.Ko = Ko;
+  g.dC = make_fastdiv(C); g.dS = make_fastdiv(S); g.dKo = make_fastdiv(Ko); g.dQ = make_fastdiv(Q);
+  g.dP = make_fastdiv(P); g.dW = make_fastdiv(W); g.dH = make_fastdiv(H); g.dStride = make_fastdiv(stride);
+  return g;
+}
 
 struct Gemm2Args {
   const unsigned short* A;
@@ -124,14 +154,14 @@ struct Loader {
         if (MODE == 0) {
           off[j] = (unsigned)(((long long)row * ld + chunk * 8) * 2);
         } else if (MODE == 2) {
-          const int q = g % cg.Q, t = g / cg.Q;          // g = (n * P + p) * Q + q
-          const int p = t % cg.P, n = t / cg.P;
+          const int t = fd_div(g, cg.dQ), q = g - t * cg.Q;      // g = (n * P + p) * Q + q
+          const int n = fd_div(t, cg.dP), p = t - n * cg.P;
           a0[j] = p * cg.stride - cg.pad;
           a1[j] = q * cg.stride - cg.pad;
           off[j] = (unsigned)((((long long)n * cg.H + a0[j]) * cg.W + a1[j]) * cg.C * 2);
         } else {                                          // MODE 4: g = (n * H + h) * W + w  (dX pixel)
-          const int w = g % cg.W, t = g / cg.W;
-          const int h = t % cg.H, n = t / cg.H;
+          const int t = fd_div(g, cg.dW), w = g - t * cg.W;
+          const int n = fd_div(t, cg.dH), h = t - n * cg.H;
           a0[j] = h + cg.pad;
           a1[j] = w + cg.pad;
           off[j] = (unsigned)n;                           // image index; pixel offset is rebuilt per tap
@@ -145,8 +175,8 @@ struct Loader {
         if (MODE == 1) {
           off[j] = (unsigned)(((long long)kr * ld + chunk * 8) * 2);
         } else if (MODE == 3) {                           // g = (r * S + s) * C + c
-          const int tap = g / cg.C, c = g - tap * cg.C;
-          a0[j] = tap / cg.S;
+          const int tap = fd_div(g, cg.dC), c = g - tap * cg.C;
+          a0[j] = fd_div(tap, cg.dS);
           a1[j] = tap - a0[j] * cg.S;
           off[j] = (unsigned)(c * 2);
         } else {                                          // MODE 5: g = input channel c
@@ -168,29 +198,29 @@ struct Loader {
       unsigned o = off[j];
       if (MODE == 2) {
         const int k = k0 + kin[j];
-        const int tap = k / cg.C, c = k - tap * cg.C;
-        const int r = tap / cg.S, s = tap - r * cg.S;
+        const int tap = fd_div(k, cg.dC), c = k - tap * cg.C;
+        const int r = fd_div(tap, cg.dS), s = tap - r * cg.S;
         const int h = a0[j] + r, w = a1[j] + s;
         ok = ok && h >= 0 && h < cg.H && w >= 0 && w < cg.W;
         o += (unsigned)(((r * cg.W + s) * cg.C + c) * 2);
       } else if (MODE == 4) {
         const int k = k0 + kin[j];
-        const int tap = k / cg.Ko, ko = k - tap * cg.Ko;
-        const int r = tap / cg.S, s = tap - r * cg.S;
+        const int tap = fd_div(k, cg.dKo), ko = k - tap * cg.Ko;
+        const int r = fd_div(tap, cg.dS), s = tap - r * cg.S;
         const int hp = a0[j] - r, wp = a1[j] - s;
-        const int p = hp / cg.stride, q = wp / cg.stride;
+        const int p = fd_div(hp, cg.dStride), q = fd_div(wp, cg.dStride);      // (negative hp / wp are rejected below)
         ok = ok && hp >= 0 && wp >= 0 && p * cg.stride == hp && q * cg.stride == wp && p < cg.P && q < cg.Q;
         o = (unsigned)(((((long long)off[j] * cg.P + p) * cg.Q + q) * cg.Ko + ko) * 2);
       } else if (MODE == 3) {
         const int pix = k0 + kin[j];
-        const int q = pix % cg.Q, t = pix / cg.Q;
-        const int p = t % cg.P, n = t / cg.P;
+        const int t = fd_div(pix, cg.dQ), q = pix - t * cg.Q;
+        const int n = fd_div(t, cg.dP), p = t - n * cg.P;
         const int h = p * cg.stride - cg.pad + a0[j], w = q * cg.stride - cg.pad + a1[j];
         ok = ok && h >= 0 && h < cg.H && w >= 0 && w < cg.W;
         o += (unsigned)((((long long)n * cg.H + h) * cg.W + w) * cg.C * 2);
       } else if (MODE == 5) {
         const int k = k0 + kin[j];
-        const int tap = k / cg.Ko, ko = k - tap * cg.Ko;
+        const int tap = fd_div(k, cg.dKo), ko = k - tap * cg.Ko;
         o += (unsigned)((((long long)ko * cg.R * cg.S + tap) * cg.C) * 2);
       }
       dma16(rs, tile + (wave * NP + j) * 512, ok ? o : OOB_OFF);
@@ -532,6 +562,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
   // hoisted out of the store loop, which is then ~30 VALU instructions per 16-byte store instead of ~100 VALU + 60
   // SALU (the generic loop below re-decides every runtime flag per store; a K <= 256 GEMM was instruction-bound in it).
   const bool fast = p.splitk == 1 && p.out_dtype == DT && vec16 && m0 + TM <= p.M && n0 + TN <= p.N;
+  const bool fast_slab = p.splitk > 1 && p.ws != nullptr && (p.N & 3) == 0 && m0 + TM <= p.M && n0 + TN <= p.N;
   constexpr int RPI = NT / (TN / 8), ITERS = (TM / 2) / RPI;      // rows per store-loop trip (16), trips per half
   const int f_ml0 = tid / (TN / 8), f_nl = (tid % (TN / 8)) << 3;
   float fbias[8];
@@ -606,6 +637,22 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
         }
   }
   lds_barrier();
+  if (fast_slab) {                                   // split-K partial tile -> fp32 slab, two 16-byte stores per trip
+    const float* e0 = epi + f_ml0 * TN;
+    const int c4 = f_nl >> 2;
+    const int olo = (c4 ^ f_ml0) << 2, ohi = ((c4 + 1) ^ f_ml0) << 2;
+    float* c = p.ws + ((long long)blockIdx.y * p.M + m0 + half * (TM / 2) + f_ml0) * p.N + n0 + f_nl;
+    const long long step = (long long)RPI * p.N;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const float* e = e0 + it * RPI * TN;
+      const int x = (it & 1) << 6;
+      const float4_t lo = *(const float4_t*)(e + (olo ^ x)), hi = *(const float4_t*)(e + (ohi ^ x));
+      *(float4_t*)(c + it * step) = lo;
+      *(float4_t*)(c + it * step + 4) = hi;
+    }
+    continue;
+  }
   if (fast) {
     switch (p.act) {
       case ACT_NONE: fast_pass(std::integral_constant<int, ACT_NONE>(), half); break;
@@ -734,7 +781,7 @@ extern "C" int dle_gemm_dma_try(const void* A, const void* B, void* C, void* aux
   p.mask_src = (const unsigned short*)mask_src;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.out_dtype = out_dtype; p.act = act; p.splitk = splitk; p.accumulate = accumulate; p.alpha = alpha;
-  p.cg = ConvGeom{};
+  p.cg = make_geom(1, 1, 1, 1, 1, 1, 1, 1, 0, 1);
   p.ws = nullptr;
   p.batch_inner = 0;
   if (splitk > 1) {
@@ -793,7 +840,7 @@ extern "C" int dle_conv2d_fwd(const void* x, const void* w, void* y, const float
   p.A = (const unsigned short*)x; p.B = (const unsigned short*)w; p.C = y; p.bias = bias;
   p.M = N * P * Q; p.N = Ko; p.K = R * S * C; p.lda = 0; p.ldb = (long long)R * S * C; p.ldc = Ko;
   p.out_dtype = out_dtype; p.act = act; p.splitk = 1; p.accumulate = 0; p.alpha = 1.f;
-  p.cg = ConvGeom{H, W, C, P, Q, R, S, stride, pad, Ko};
+  p.cg = make_geom(H, W, C, P, Q, R, S, stride, pad, Ko);
   return conv_launch(p, dtype, 2, 0, stream);
 }
 
@@ -808,7 +855,7 @@ extern "C" int dle_conv2d_dgrad(const void* dy, const void* w, void* dx, const v
   p.mask_src = (const unsigned short*)addend;
   p.M = N * H * W; p.N = C; p.K = R * S * Ko; p.lda = 0; p.ldb = 0; p.ldc = C;
   p.out_dtype = dtype; p.act = addend ? ACT_ADD : ACT_NONE; p.splitk = 1; p.accumulate = 0; p.alpha = 1.f;
-  p.cg = ConvGeom{H, W, C, P, Q, R, S, stride, pad, Ko};
+  p.cg = make_geom(H, W, C, P, Q, R, S, stride, pad, Ko);
   return conv_launch(p, dtype, 4, 5, stream);
 }
 
@@ -823,7 +870,7 @@ extern "C" int dle_conv2d_wgrad(const void* dy, const void* x, float* dw, int N,
   p.A = (const unsigned short*)dy; p.B = (const unsigned short*)x; p.C = dw;
   p.M = Ko; p.N = R * S * C; p.K = N * P * Q; p.lda = Ko; p.ldb = 0; p.ldc = (long long)R * S * C;
   p.out_dtype = DLE_F32; p.act = ACT_NONE; p.accumulate = accumulate; p.alpha = 1.f;
-  p.cg = ConvGeom{H, W, C, P, Q, R, S, stride, pad, Ko};
+  p.cg = make_geom(H, W, C, P, Q, R, S, stride, pad, Ko);
   const int ktiles = (p.K + BK - 1) / BK;
   if (splitk < 1) splitk = 1;
   if (splitk > ktiles) splitk = ktiles;

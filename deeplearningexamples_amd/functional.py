@@ -418,11 +418,11 @@ def bn_fwd(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, moment
     mean = torch.empty(c, dtype=torch.float32, device=x.device)
     rstd = torch.empty(c, dtype=torch.float32, device=x.device)
     ws = _bn_ws(x2)
-    C.annotate(bytes=float(x.numel()) * 2, tag="C%d" % c)
+    C.annotate(bytes=float(x.numel()) * 2, tag="M%dxC%d" % (x.numel() // c, c))
     C.call("dle_bn_fwd_stats", C.ptr(x), m, c, eps, momentum, C.ptr(mean), C.ptr(rstd), C.ptr(running_mean),
            C.ptr(running_var), C.ptr(ws), ws.numel() * 4, C.dt(x), C.stream())
     y = torch.empty_like(x) if out is None else out
-    C.annotate(bytes=float(x.numel()) * 2 * (3 if residual is not None else 2), tag="C%d" % c)
+    C.annotate(bytes=float(x.numel()) * 2 * (3 if residual is not None else 2), tag="M%dxC%d%s" % (x.numel() // c, c, "+res" if residual is not None else ""))
     C.call("dle_bn_fwd_apply", C.ptr(x), C.ptr(residual), C.ptr(y), C.ptr(mean), C.ptr(rstd), C.ptr(gamma),
            C.ptr(beta), m, c, int(relu), C.dt(x), C.stream())
     return y, mean, rstd
@@ -434,12 +434,12 @@ def bn_bwd(dy, y, x, mean, rstd, gamma, dgamma, dbeta, want_skip_grad=False, dx_
     c = x.shape[-1]
     m = x.numel() // c
     ws = _bn_ws(x.reshape(m, c))
-    C.annotate(bytes=float(x.numel()) * 2 * (3 if y is not None else 2), tag="C%d" % c)
+    C.annotate(bytes=float(x.numel()) * 2 * (3 if y is not None else 2), tag="M%dxC%d%s" % (x.numel() // c, c, "+relu" if y is not None else ""))
     C.call("dle_bn_bwd_reduce", C.ptr(dy), C.ptr(y), C.ptr(x), C.ptr(mean), C.ptr(rstd), C.ptr(dgamma), C.ptr(dbeta),
            m, c, 0, C.ptr(ws), ws.numel() * 4, C.dt(x), C.stream())
     dx = torch.empty_like(x) if dx_out is None else dx_out
     g = torch.empty_like(x) if want_skip_grad else None
-    C.annotate(bytes=float(x.numel()) * 2 * ((4 if y is not None else 3) + int(want_skip_grad)), tag="C%d" % c)
+    C.annotate(bytes=float(x.numel()) * 2 * ((4 if y is not None else 3) + int(want_skip_grad)), tag="M%dxC%d%s%s" % (x.numel() // c, c, "+relu" if y is not None else "", "+skip" if want_skip_grad else ""))
     C.call("dle_bn_bwd_apply", C.ptr(dy), C.ptr(y), C.ptr(x), C.ptr(dx), C.ptr(g), C.ptr(mean), C.ptr(rstd),
            C.ptr(gamma), C.ptr(dgamma), C.ptr(dbeta), m, c, C.dt(x), C.stream())
     return dx, g
@@ -520,7 +520,7 @@ def layernorm_fwd(x, gamma, beta, residual=None, eps=1e-12, write_z=True):
     z = torch.empty_like(x) if (residual is not None and write_z) else None
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    C.annotate(bytes=float(x.numel()) * 2 * (4 if residual is not None else 2), tag="H%d" % h)
+    C.annotate(bytes=float(x.numel()) * 2 * (4 if residual is not None else 2), tag="R%dxH%d" % (x.numel() // h, h))
     C.call("dle_layernorm_fwd", C.ptr(x), C.ptr(residual), C.ptr(z), C.ptr(y), C.ptr(gamma), C.ptr(beta), C.ptr(mean),
            C.ptr(rstd), rows, h, float(eps), C.dt(x), C.stream())
     return y, (z if z is not None else x), mean, rstd
@@ -531,7 +531,7 @@ def layernorm_bwd(dy, z, mean, rstd, gamma, dgamma, dbeta, accumulate=False):
     rows, h = z.shape
     dz = torch.empty_like(z)
     ws = splitk_workspace(z.device, C.lib().dle_layernorm_workspace_bytes(h))
-    C.annotate(bytes=float(z.numel()) * 2 * 3, tag="H%d" % h)
+    C.annotate(bytes=float(z.numel()) * 2 * 3, tag="R%dxH%d" % (rows, h))
     C.call("dle_layernorm_bwd", C.ptr(dy), C.ptr(z), C.ptr(mean), C.ptr(rstd), C.ptr(gamma), C.ptr(dz), C.ptr(dgamma),
            C.ptr(dbeta), rows, h, int(accumulate), C.ptr(ws), ws.numel() * 4, C.dt(z), C.stream())
     return dz
@@ -580,7 +580,7 @@ def softmax_fwd_(scores, mask_add, rows_per_batch, scale):
     C.require_cuda(scores, mask_add)
     l = scores.shape[-1]
     rows = scores.numel() // l
-    C.annotate(bytes=float(scores.numel()) * 4, tag="L%d" % l)
+    C.annotate(bytes=float(scores.numel()) * 4, tag="R%dxL%d" % (rows, l))
     C.call("dle_softmax_fwd", C.ptr(scores), C.ptr(mask_add), rows, l, rows_per_batch, float(scale), C.dt(scores), C.stream())
     return scores
 
@@ -589,7 +589,7 @@ def softmax_bwd_(probs, dprobs, scale):
     C.require_cuda(probs, dprobs)
     l = probs.shape[-1]
     rows = probs.numel() // l
-    C.annotate(bytes=float(probs.numel()) * 6, tag="L%d" % l)
+    C.annotate(bytes=float(probs.numel()) * 6, tag="R%dxL%d" % (rows, l))
     C.call("dle_softmax_bwd", C.ptr(probs), C.ptr(dprobs), rows, l, float(scale), C.dt(probs), C.stream())
     return dprobs
 
