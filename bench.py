@@ -206,7 +206,7 @@ class Rn50Workload:
 # ------------------------------------------------------------------------------------------- BERT
 class BertWorkload:
     """BASELINE.json configs[2]: BERT-Large phase-1 pre-training, seq 128, 20 masked tokens per sequence, bf16,
-    LAMB lr 6e-3 / warm-up 0.2843 / 7038 steps (scripts/configs/pretrain_config.sh:18-28), dropout 0,
+    LAMB lr 6e-3 / warm-up 0.2843 / 7038 steps (scripts/configs/pretrain_config.sh:18-28), hidden / attention dropout 0.1 (bert_config.json; counter-based Philox masks),
     synthetic Wikipedia-shaped batch (run_pretraining.py:603-609); one optimizer step per micro-batch, data
     parallel over the ranks (gradient all-reduce, mean)."""
 
@@ -221,7 +221,7 @@ class BertWorkload:
         torch.manual_seed(0)
         self.model = BertForPreTraining(LARGE, device=device)
         self.trainer = BertTrainer(self.model, lr=6e-3, warmup=0.2843, total_steps=7038, compute_dtype=self.dtype,
-                                   world_size=world)
+                                   world_size=world, hidden_dropout=0.1, attention_dropout=0.1, seed=42, rank=rank)
         g = torch.Generator(device="cpu").manual_seed(500 + rank)
         b, s, v = self.batch, 128, LARGE["real_vocab"]
         ids = torch.randint(0, v, (b, s), generator=g)
@@ -245,7 +245,7 @@ class BertWorkload:
         return {"workload": "BERT-Large phase-1 pre-training (PyTorch/LanguageModeling/BERT), seq 128, 20 masked "
                             "tokens/sequence, LAMB, synthetic Wikipedia-shaped batch (BASELINE.json configs[2])",
                 "batch_per_gpu": self.batch, "global_batch": self.batch * self.world, "seq_len": 128,
-                "dropout": 0.0, "parallelism": "single GPU" if self.world == 1 else "dp%d" % self.world}
+                "dropout": 0.1, "parallelism": "single GPU" if self.world == 1 else "dp%d" % self.world}
 
     def dtype_name(self):
         return "fp16" if self.dtype == torch.float16 else "bf16"

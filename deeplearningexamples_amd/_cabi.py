@@ -19,6 +19,7 @@ ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_ADD, ACT_GELU_BWD, ACT_TANH, ACT
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
 c_void_p, c_int, c_i64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+c_u64 = ctypes.c_uint64
 
 # name -> (restype, argtypes); mirrors include/dle_mi355x.h one to one
 _SIGS = {
@@ -80,6 +81,11 @@ _SIGS = {
     "dle_rows_scatter": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
     "dle_softmax_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_float, c_int, c_void_p]),
     "dle_softmax_bwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_float, c_int, c_void_p]),
+    "dle_dropout_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_float, c_u64, c_u64, c_int, c_void_p]),
+    "dle_dropout_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_float, c_int, c_void_p]),
+    "dle_dropout_add_layernorm_fwd": (c_int, [c_void_p] * 9 + [c_i64, c_int, c_float, c_float, c_u64, c_u64, c_int, c_void_p]),
+    "dle_softmax_dropout_fwd": (c_int, [c_void_p] * 4 + [c_i64, c_int, c_int, c_float, c_float, c_u64, c_u64, c_int, c_void_p]),
+    "dle_softmax_dropout_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float, c_float, c_int, c_void_p]),
     "dle_colsum": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p, c_i64, c_void_p]),
     "dle_mt_table_len": (c_i64, [c_int, c_int]),
     "dle_mt_table_fill": (c_i64, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]),

@@ -31,13 +31,19 @@ NO_DECAY = ("bias", "gamma", "beta", "LayerNorm")      # run_pretraining.py:423
 class BertTrainer:
     def __init__(self, model: BertForPreTraining, lr=6e-3, warmup=0.2843, total_steps=7038, weight_decay=0.01,
                  max_grad_norm=1.0, compute_dtype=torch.bfloat16, init_loss_scale=2.0 ** 20, world_size=1,
-                 process_group=None):
+                 process_group=None, hidden_dropout=None, attention_dropout=None, seed=42, rank=0):
         self.model, self.cfg = model, model.config
         self.dev = model.bert.embeddings.word_embeddings.weight.device
         self.dtype = compute_dtype
         self.base_lr, self.warmup, self.total = lr, warmup, total_steps
         self.wd, self.max_norm = weight_decay, max_grad_norm
         self.world, self.pg = world_size, process_group
+        # nn.Dropout sites of the model (modeling.py:276,320,392,428; bert_config.json: 0.1 / 0.1).  Every call
+        # draws a fresh 64-bit offset of the counter-based RNG; ranks use different seeds (different data, same as
+        # torch.manual_seed(seed + rank) in run_pretraining.py:342).
+        self.p_hidden = model.config.get("hidden_dropout", 0.1) if hidden_dropout is None else hidden_dropout
+        self.p_attn = model.config.get("attention_dropout", 0.1) if attention_dropout is None else attention_dropout
+        self.rng_seed, self._rng_offset = int(seed) + int(rank), 0
         self.scaler = GradScalerState(self.dev, enabled=compute_dtype == torch.float16, init_scale=init_loss_scale,
                                       growth_interval=2000)
         dev = self.dev
@@ -152,6 +158,10 @@ class BertTrainer:
         self._mask_add = ((1.0 - attention_mask.to(torch.float32)) * -10000.0).contiguous()
         self._batch_key = key
 
+    def _next_offset(self):
+        self._rng_offset += 1
+        return self._rng_offset
+
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids, token_type_ids, attention_mask, labels, next_sentence_labels):
         cfg, m, dt = self.cfg, self.model, self.dtype
@@ -165,7 +175,11 @@ class BertTrainer:
         z0 = F.embed_sum(emb.word_embeddings.weight.data, emb.position_embeddings.weight.data,
                          emb.token_type_embeddings.weight.data, ids, tts, s, dt)
         x, _, mean0, rstd0 = F.layernorm_fwd(z0, emb.LayerNorm.weight.data, emb.LayerNorm.bias.data)
-        sv = {"ids": ids, "tt": tts, "z0": z0, "ln0": (mean0, rstd0), "layers": [], "b": b, "s": s}
+        ph, pa, seed = self.p_hidden, self.p_attn, self.rng_seed
+        mask0 = None
+        if ph > 0:
+            x, mask0 = F.dropout_fwd(x, ph, seed, self._next_offset())
+        sv = {"ids": ids, "tt": tts, "z0": z0, "ln0": (mean0, rstd0), "mask0": mask0, "layers": [], "b": b, "s": s}
         scale = 1.0 / math.sqrt(d)
         for l, layer in enumerate(m.bert.encoder.layer):
             pre = "bert.encoder.layer.%d." % l
@@ -174,20 +188,35 @@ class BertTrainer:
             probs = torch.empty((b * nh, s, s), dtype=dt, device=self.dev)
             F.gemm_batched(qkv, qkv[:, h:], probs, s, s, d, 3 * h, 3 * h, s, True, True, b * nh, nh,
                            (s * 3 * h, d), (s * 3 * h, d), (nh * s * s, s * s))
-            F.softmax_fwd_(probs, self._mask_add, nh * s, scale)
+            mask_a, mask_1, mask_2 = None, None, None
+            if pa > 0:
+                pdrop, mask_a = F.softmax_dropout_fwd_(probs, self._mask_add, nh * s, scale, pa, seed, self._next_offset())
+            else:
+                F.softmax_fwd_(probs, self._mask_add, nh * s, scale)
+                pdrop = probs
             ctx = torch.empty((t, h), dtype=dt, device=self.dev)
-            F.gemm_batched(probs, qkv[:, 2 * h:], ctx, s, d, s, s, 3 * h, h, True, False, b * nh, nh,
+            F.gemm_batched(pdrop, qkv[:, 2 * h:], ctx, s, d, s, s, 3 * h, h, True, False, b * nh, nh,
                            (nh * s * s, s * s), (s * 3 * h, d), (s * h, d))
             ao = F.gemm(ctx, self.w16[pre + "attention.output.dense.weight"], t, h, h, True, True,
                         bias=att.output.dense.bias.data)
-            x1, z1, m1, r1 = F.layernorm_fwd(ao, att.output.LayerNorm.weight.data, att.output.LayerNorm.bias.data, residual=x)
+            if ph > 0:
+                x1, z1, m1, r1, mask_1 = F.dropout_add_layernorm_fwd(ao, att.output.LayerNorm.weight.data,
+                                                                      att.output.LayerNorm.bias.data, x, ph, seed,
+                                                                      self._next_offset())
+            else:
+                x1, z1, m1, r1 = F.layernorm_fwd(ao, att.output.LayerNorm.weight.data, att.output.LayerNorm.bias.data, residual=x)
             pre_act = torch.empty((t, inter), dtype=dt, device=self.dev)
             it = F.gemm(x1, self.w16[pre + "intermediate.dense_act.weight"], t, inter, h, True, True,
                         bias=layer.intermediate.dense_act.bias.data, act=C.ACT_GELU, aux=pre_act)
             o2 = F.gemm(it, self.w16[pre + "output.dense.weight"], t, h, inter, True, True, bias=layer.output.dense.bias.data)
-            x2, z2, m2, r2 = F.layernorm_fwd(o2, layer.output.LayerNorm.weight.data, layer.output.LayerNorm.bias.data, residual=x1)
-            sv["layers"].append(dict(x=x, qkv=qkv, probs=probs, ctx=ctx, z1=z1, ln1=(m1, r1), x1=x1, pre=pre_act, it=it,
-                                     z2=z2, ln2=(m2, r2)))
+            if ph > 0:
+                x2, z2, m2, r2, mask_2 = F.dropout_add_layernorm_fwd(o2, layer.output.LayerNorm.weight.data,
+                                                                      layer.output.LayerNorm.bias.data, x1, ph, seed,
+                                                                      self._next_offset())
+            else:
+                x2, z2, m2, r2 = F.layernorm_fwd(o2, layer.output.LayerNorm.weight.data, layer.output.LayerNorm.bias.data, residual=x1)
+            sv["layers"].append(dict(x=x, qkv=qkv, probs=probs, pdrop=pdrop, ctx=ctx, z1=z1, ln1=(m1, r1), x1=x1,
+                                     pre=pre_act, it=it, z2=z2, ln2=(m2, r2), mask_a=mask_a, mask_1=mask_1, mask_2=mask_2))
             x = x2
         sv["seq"] = x
         # pooler + NSP head
@@ -272,9 +301,11 @@ class BertTrainer:
             pre = "bert.encoder.layer.%d." % l
             dz2 = F.layernorm_bwd(dx, a["z2"], a["ln2"][0], a["ln2"][1], layer.output.LayerNorm.weight.data,
                                   self.gview[pre + "output.LayerNorm.weight"], self.gview[pre + "output.LayerNorm.bias"], acc)
-            self._wgrad(pre + "output.dense.weight", dz2, a["it"], acc)
-            self._bgrad(pre + "output.dense.bias", dz2, acc)
-            dpre = F.gemm(dz2, self.w16[pre + "output.dense.weight"], t, inter, h, True, False, act=C.ACT_GELU_BWD,
+            # dz2 flows unchanged into the residual branch; the dense branch sees it through the dropout mask
+            do2 = F.dropout_bwd(dz2, a["mask_2"], self.p_hidden) if a["mask_2"] is not None else dz2
+            self._wgrad(pre + "output.dense.weight", do2, a["it"], acc)
+            self._bgrad(pre + "output.dense.bias", do2, acc)
+            dpre = F.gemm(do2, self.w16[pre + "output.dense.weight"], t, inter, h, True, False, act=C.ACT_GELU_BWD,
                           mask_src=a["pre"])
             self._wgrad(pre + "intermediate.dense_act.weight", dpre, a["x1"], acc)
             self._bgrad(pre + "intermediate.dense_act.bias", dpre, acc)
@@ -283,21 +314,25 @@ class BertTrainer:
             dz1 = F.layernorm_bwd(dx1, a["z1"], a["ln1"][0], a["ln1"][1], layer.attention.output.LayerNorm.weight.data,
                                   self.gview[pre + "attention.output.LayerNorm.weight"],
                                   self.gview[pre + "attention.output.LayerNorm.bias"], acc)
-            self._wgrad(pre + "attention.output.dense.weight", dz1, a["ctx"], acc)
-            self._bgrad(pre + "attention.output.dense.bias", dz1, acc)
-            dctx = F.gemm(dz1, self.w16[pre + "attention.output.dense.weight"], t, h, h, True, False)
+            dao = F.dropout_bwd(dz1, a["mask_1"], self.p_hidden) if a["mask_1"] is not None else dz1
+            self._wgrad(pre + "attention.output.dense.weight", dao, a["ctx"], acc)
+            self._bgrad(pre + "attention.output.dense.bias", dao, acc)
+            dctx = F.gemm(dao, self.w16[pre + "attention.output.dense.weight"], t, h, h, True, False)
             qkv, probs = a["qkv"], a["probs"]
             dprobs = torch.empty_like(probs)
             F.gemm_batched(dctx, qkv[:, 2 * h:], dprobs, s, s, d, h, 3 * h, s, True, True, b * nh, nh,
                            (s * h, d), (s * 3 * h, d), (nh * s * s, s * s))
-            F.softmax_bwd_(probs, dprobs, scale)
+            if a["mask_a"] is not None:
+                F.softmax_dropout_bwd_(probs, dprobs, a["mask_a"], scale, self.p_attn)
+            else:
+                F.softmax_bwd_(probs, dprobs, scale)
             dqkv = torch.empty((t, 3 * h), dtype=dt, device=self.dev)
             F.gemm_batched(dprobs, qkv[:, h:], dqkv, s, d, s, s, 3 * h, 3 * h, True, False, b * nh, nh,
                            (nh * s * s, s * s), (s * 3 * h, d), (s * 3 * h, d))                         # dQ = dS K
             F.gemm_batched(dprobs, qkv, dqkv[:, h:], s, d, s, s, 3 * h, 3 * h, False, False, b * nh, nh,
                            (nh * s * s, s * s), (s * 3 * h, d), (s * 3 * h, d))                         # dK = dS^T Q
-            F.gemm_batched(probs, dctx, dqkv[:, 2 * h:], s, d, s, s, h, 3 * h, False, False, b * nh, nh,
-                           (nh * s * s, s * s), (s * h, d), (s * 3 * h, d))                             # dV = P^T dO
+            F.gemm_batched(a["pdrop"], dctx, dqkv[:, 2 * h:], s, d, s, s, h, 3 * h, False, False, b * nh, nh,
+                           (nh * s * s, s * s), (s * h, d), (s * 3 * h, d))                             # dV = dropout(P)^T dO
             gq = self.gview[pre + "attention.self.query.weight"]
             gqkv = torch.as_strided(gq, (3 * h, h), (h, 1))
             F.gemm(dqkv, a["x"], 3 * h, h, t, False, False, out=gqkv, splitk=F.pick_splitk(3 * h, h, t, 1024), accumulate=acc)
@@ -306,6 +341,8 @@ class BertTrainer:
             dx = F.gemm(dqkv, layer.qkv16, t, h, 3 * h, True, False, act=C.ACT_ADD, mask_src=dz1)
         # ---- embeddings
         emb = m.bert.embeddings
+        if sv["mask0"] is not None:
+            dx = F.dropout_bwd(dx, sv["mask0"], self.p_hidden)
         dz0 = F.layernorm_bwd(dx, sv["z0"], sv["ln0"][0], sv["ln0"][1], emb.LayerNorm.weight.data,
                               self.gview["bert.embeddings.LayerNorm.weight"], self.gview["bert.embeddings.LayerNorm.bias"], acc)
         F.embed_scatter_add_(self.gview["bert.embeddings.word_embeddings.weight"], dz0, sv["ids"])
@@ -314,6 +351,7 @@ class BertTrainer:
             gpos[s:].zero_()
         F.colsum(dz0.view(b, s * h), out=gpos[:s].view(-1), accumulate=acc)
         F.rows_select_sum(dz0, sv["tt"], cfg["type_vocab"], self.gview["bert.embeddings.token_type_embeddings.weight"], acc)
+        self._last_sv = sv if getattr(self, "keep_activations", False) else None     # tests read the dropout masks
         self._sv = None
 
     # ------------------------------------------------------------------ optimizer

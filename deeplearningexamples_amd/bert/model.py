@@ -20,7 +20,8 @@ def config_from_json(path):
     v = c["vocab_size"]
     return dict(hidden=c["hidden_size"], heads=c["num_attention_heads"], layers=c["num_hidden_layers"],
                 intermediate=c["intermediate_size"], vocab=(v + 7) // 8 * 8, real_vocab=v,
-                max_pos=c["max_position_embeddings"], type_vocab=c["type_vocab_size"], seq=128)
+                max_pos=c["max_position_embeddings"], type_vocab=c["type_vocab_size"], seq=128,
+                hidden_dropout=c.get("hidden_dropout_prob", 0.1), attention_dropout=c.get("attention_probs_dropout_prob", 0.1))
 
 
 class _LinearAct(nn.Module):          # LinearActivation: weight [out, in] + bias

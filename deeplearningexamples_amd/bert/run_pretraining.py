@@ -77,7 +77,8 @@ def main(argv=None):
     model = BertForPreTraining(cfg, device=device)
     dtype = torch.float16 if args.fp16 else torch.bfloat16
     trainer = BertTrainer(model, lr=args.learning_rate, warmup=args.warmup_proportion, total_steps=int(args.max_steps),
-                          compute_dtype=dtype, init_loss_scale=float(args.init_loss_scale), world_size=world)
+                          compute_dtype=dtype, init_loss_scale=float(args.init_loss_scale), world_size=world,
+                          seed=args.seed, rank=rank)
     acc = args.gradient_accumulation_steps
     micro = args.train_batch_size // acc
     it = synthetic_batches(cfg, micro, args.max_seq_length, args.max_predictions_per_seq, device, args.seed + rank)

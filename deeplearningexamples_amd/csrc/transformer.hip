@@ -26,6 +26,58 @@ static int tf_grid(long long items, int per_block, int cap = 2048) {
 
 #define LN_MAX_CHUNKS 8      // H <= 64 lanes * 8 chunks * 8 elements = 4096
 
+// ------------------------------------------------------------------ dropout (nn.Dropout, modeling.py:276,320,392,428)
+// Counter-based RNG: Philox4x32-10 keyed by the 64-bit seed, counter = (16-byte chunk index of the tensor, 64-bit
+// call offset).  One call yields the 8 keep decisions of one 8-element chunk: a 16-bit uniform per element is
+// compared with thr = round(p * 65536) (so the drop probability is quantised to 1/65536: p = 0.1 -> 0.100006).
+// The mask is stored bit-packed, bit k of byte i <-> element 8 i + k, 1 = kept; kept values are scaled by
+// 1 / (1 - thr / 65536).  Torch draws from its own Philox stream, so masks differ from the reference's bit for bit;
+// the step is checked against the oracle with THESE masks (tests/test_gpu_bert_step.py).
+struct DropArgs {
+  unsigned char* mask;     // NULL: no dropout
+  unsigned thr;
+  float inv_keep;
+  unsigned seed_lo, seed_hi, off_lo, off_hi;
+};
+
+__device__ __forceinline__ uint4_t philox4x32_10(uint4_t c, unsigned k0, unsigned k1) {
+  const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0], hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    c = (uint4_t){hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0};
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
+// keep bits of the 8 elements of chunk `chunk`
+__device__ __forceinline__ unsigned drop_bits(const DropArgs& d, long long chunk) {
+  const uint4_t r = philox4x32_10((uint4_t){(unsigned)chunk, (unsigned)((unsigned long long)chunk >> 32), d.off_lo, d.off_hi},
+                                  d.seed_lo, d.seed_hi);
+  unsigned bits = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    bits |= ((r[k] & 0xffffu) >= d.thr ? 1u : 0u) << (2 * k);
+    bits |= ((r[k] >> 16) >= d.thr ? 1u : 0u) << (2 * k + 1);
+  }
+  return bits;
+}
+
+static DropArgs make_drop(void* mask, float p, unsigned long long seed, unsigned long long offset) {
+  DropArgs d;
+  d.mask = (unsigned char*)mask;
+  long long thr = (long long)(p * 65536.0f + 0.5f);
+  if (thr < 0) thr = 0;
+  if (thr > 65535) thr = 65535;
+  d.thr = (unsigned)thr;
+  d.inv_keep = 65536.0f / (float)(65536 - thr);
+  d.seed_lo = (unsigned)seed; d.seed_hi = (unsigned)(seed >> 32);
+  d.off_lo = (unsigned)offset; d.off_hi = (unsigned)(offset >> 32);
+  return d;
+}
+
 // ------------------------------------------------------------------ LayerNorm forward (+ residual)
 // z = x + res (res optional);  y = (z - mean) * rstd * gamma + beta.   z_out (optional) receives z in 16 bits
 // (the tensor the backward pass needs); mean / rstd fp32 per row.
@@ -35,7 +87,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
                                                      unsigned short* __restrict__ z_out, unsigned short* __restrict__ y,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ mean, float* __restrict__ rstd, long long rows,
-                                                     int H, float eps) {
+                                                     int H, float eps, DropArgs drop) {
   const int lane = threadIdx.x & 63;
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
   const int nch = H >> 3;                              // 16-byte chunks per row
@@ -48,6 +100,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
       if (c < nch) {
         float xf[8], rf[8];
         unpack8<DT>(*(const ushort8_t*)(x + r * H + c * 8), xf);
+        if (drop.mask) {                                             // y = LN(dropout(x) + res)
+          const long long chunk = (r * H >> 3) + c;
+          const unsigned bits = drop_bits(drop, chunk);
+          drop.mask[chunk] = (unsigned char)bits;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) xf[k] = ((bits >> k) & 1u) ? xf[k] * drop.inv_keep : 0.f;
+          unpack8<DT>(pack8<DT>(xf), xf);                            // the dropped tensor is a 16-bit tensor in the reference
+        }
         if (res) {
           unpack8<DT>(*(const ushort8_t*)(res + r * H + c * 8), rf);
 #pragma unroll
@@ -89,6 +149,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
   }
 }
 
+static int ln_fwd_launch(const void* x, const void* residual, void* z_out, void* y, const float* gamma, const float* beta,
+                         float* mean, float* rstd, int64_t rows, int H, float eps, DropArgs drop, int dtype,
+                         hipStream_t stream) {
+  const int grid = tf_grid(rows, 4, 4096);
+  const int ch = (H / 8 + 63) / 64;           // 16-byte chunks per lane: register arrays are sized for exactly this
+#define GO(DT, CH) hipLaunchKernelGGL((ln_fwd_kernel<DT, CH>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)residual, (unsigned short*)z_out, (unsigned short*)y, gamma, beta, mean, rstd, (long long)rows, H, eps, drop)
+#define PICK(DT) do { if (ch <= 1) GO(DT, 1); else if (ch <= 2) GO(DT, 2); else if (ch <= 4) GO(DT, 4); else GO(DT, 8); } while (0)
+  if (dtype == DLE_F16) PICK(DLE_F16); else PICK(DLE_BF16);
+#undef GO
+#undef PICK
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int dle_layernorm_fwd(const void* x, const void* residual, void* z_out, void* y, const float* gamma,
                                  const float* beta, float* mean, float* rstd, int64_t rows, int H, float eps,
                                  int dtype, hipStream_t stream) {
@@ -96,15 +170,21 @@ extern "C" int dle_layernorm_fwd(const void* x, const void* residual, void* z_ou
   DLE_CHECK_ARG(H > 0 && H % 8 == 0 && H <= 64 * LN_MAX_CHUNKS * 8, "layernorm_fwd: H must be a multiple of 8, <= 4096");
   if (rows == 0) return 0;
   DLE_CHECK_ARG(x && y && gamma && beta && mean && rstd, "layernorm_fwd: null pointer");
-  const int grid = tf_grid(rows, 4, 4096);
-  const int ch = (H / 8 + 63) / 64;           // 16-byte chunks per lane: register arrays are sized for exactly this
-#define GO(DT, CH) hipLaunchKernelGGL((ln_fwd_kernel<DT, CH>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)residual, (unsigned short*)z_out, (unsigned short*)y, gamma, beta, mean, rstd, (long long)rows, H, eps)
-#define PICK(DT) do { if (ch <= 1) GO(DT, 1); else if (ch <= 2) GO(DT, 2); else if (ch <= 4) GO(DT, 4); else GO(DT, 8); } while (0)
-  if (dtype == DLE_F16) PICK(DLE_F16); else PICK(DLE_BF16);
-#undef GO
-#undef PICK
-  DLE_LAUNCH_CHECK();
-  return 0;
+  return ln_fwd_launch(x, residual, z_out, y, gamma, beta, mean, rstd, rows, H, eps, make_drop(nullptr, 0.f, 0, 0), dtype, stream);
+}
+
+// y = LayerNorm(dropout(x) + residual): BertSelfOutput / BertOutput in training mode (modeling.py:394-398,430-434).
+// mask receives rows * H / 8 bytes.  p == 0 degenerates to dle_layernorm_fwd (mask all ones).
+extern "C" int dle_dropout_add_layernorm_fwd(const void* x, const void* residual, void* z_out, void* y, void* mask,
+                                             const float* gamma, const float* beta, float* mean, float* rstd,
+                                             int64_t rows, int H, float eps, float p, uint64_t seed, uint64_t offset,
+                                             int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "dropout_add_layernorm_fwd: 16-bit activations only");
+  DLE_CHECK_ARG(H > 0 && H % 8 == 0 && H <= 64 * LN_MAX_CHUNKS * 8, "dropout_add_layernorm_fwd: H must be a multiple of 8, <= 4096");
+  DLE_CHECK_ARG(p >= 0.f && p < 1.f, "dropout_add_layernorm_fwd: p must be in [0, 1)");
+  if (rows == 0) return 0;
+  DLE_CHECK_ARG(x && y && gamma && beta && mean && rstd && mask, "dropout_add_layernorm_fwd: null pointer");
+  return ln_fwd_launch(x, residual, z_out, y, gamma, beta, mean, rstd, rows, H, eps, make_drop(mask, p, seed, offset), dtype, stream);
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
@@ -431,7 +511,8 @@ extern "C" int dle_rows_scatter(const void* src, const int64_t* idx, void* dst, 
 // L/8 lanes per row (L = 128 -> 16 lanes, 4 rows per wavefront); mask_add fp32 [batch][L] (0 / -10000).
 template <int DT>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(unsigned short* __restrict__ s, const float* __restrict__ mask_add,
-                                                          long long rows, int L, int rows_per_batch, float scale) {
+                                                          long long rows, int L, int rows_per_batch, float scale,
+                                                          unsigned short* __restrict__ dropped, DropArgs drop) {
   const int lpr = L >> 3;
   const int rpw = 64 / lpr;
   const int lane = threadIdx.x & 63, sub = lane / lpr, cl = lane % lpr;
@@ -460,7 +541,17 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(unsigned short* __rest
       const float inv = 1.0f / sum;
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] *= inv;
-      *(ushort8_t*)(s + r * L + cl * 8) = pack8<DT>(v);
+      const ushort8_t pv = pack8<DT>(v);
+      *(ushort8_t*)(s + r * L + cl * 8) = pv;
+      if (drop.mask) {                                   // second output: dropout(probs) for the P V contraction
+        const long long chunk = (r * L >> 3) + cl;
+        const unsigned bits = drop_bits(drop, chunk);
+        drop.mask[chunk] = (unsigned char)bits;
+        unpack8<DT>(pv, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = ((bits >> k) & 1u) ? v[k] * drop.inv_keep : 0.f;
+        *(ushort8_t*)(dropped + r * L + cl * 8) = pack8<DT>(v);
+      }
     }
   }
 }
@@ -468,7 +559,8 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(unsigned short* __rest
 // dS = P * (dP - sum_j dP_j P_j) * scale, written over dP
 template <int DT>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const unsigned short* __restrict__ p, unsigned short* __restrict__ dp,
-                                                          long long rows, int L, float scale) {
+                                                          long long rows, int L, float scale,
+                                                          const unsigned char* __restrict__ mask, float inv_keep) {
   const int lpr = L >> 3;
   const int rpw = 64 / lpr;
   const int lane = threadIdx.x & 63, sub = lane / lpr, cl = lane % lpr;
@@ -481,6 +573,12 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const unsigned short* 
     if (ok) {
       unpack8<DT>(*(const ushort8_t*)(p + r * L + cl * 8), pv);
       unpack8<DT>(*(const ushort8_t*)(dp + r * L + cl * 8), gv);
+      if (mask) {                                        // gradient through dropout(probs) first
+        const unsigned bits = mask[(r * L >> 3) + cl];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gv[k] = ((bits >> k) & 1u) ? gv[k] * inv_keep : 0.f;
+        unpack8<DT>(pack8<DT>(gv), gv);
+      }
 #pragma unroll
       for (int k = 0; k < 8; ++k) dot += pv[k] * gv[k];
     }
@@ -503,8 +601,27 @@ extern "C" int dle_softmax_fwd(void* scores, const float* mask_add, int64_t rows
   if (rows == 0) return 0;
   DLE_CHECK_ARG(scores && rows_per_batch > 0, "softmax_fwd: bad arguments");
   const int grid = tf_grid(rows, 4 * (64 / (L / 8)), 4096);
-  if (dtype == DLE_F16) hipLaunchKernelGGL(softmax_fwd_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (unsigned short*)scores, mask_add, (long long)rows, L, rows_per_batch, scale);
-  else hipLaunchKernelGGL(softmax_fwd_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (unsigned short*)scores, mask_add, (long long)rows, L, rows_per_batch, scale);
+  const DropArgs nodrop = make_drop(nullptr, 0.f, 0, 0);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(softmax_fwd_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (unsigned short*)scores, mask_add, (long long)rows, L, rows_per_batch, scale, (unsigned short*)nullptr, nodrop);
+  else hipLaunchKernelGGL(softmax_fwd_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (unsigned short*)scores, mask_add, (long long)rows, L, rows_per_batch, scale, (unsigned short*)nullptr, nodrop);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// probs = softmax(scores * scale + mask) in place, dropped = dropout(probs) (the P V operand), mask: rows * L / 8 bytes
+// (modeling.py:366-370: attention_probs = self.dropout(self.softmax(attention_scores)))
+extern "C" int dle_softmax_dropout_fwd(void* scores, void* dropped, void* mask, const float* mask_add, int64_t rows, int L,
+                                       int rows_per_batch, float scale, float p, uint64_t seed, uint64_t offset,
+                                       int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "softmax_dropout_fwd: 16-bit scores only");
+  DLE_CHECK_ARG(softmax_len_ok(L), "softmax_dropout_fwd: row length %d must be a power of two in [8, 512]", L);
+  DLE_CHECK_ARG(p >= 0.f && p < 1.f, "softmax_dropout_fwd: p must be in [0, 1)");
+  if (rows == 0) return 0;
+  DLE_CHECK_ARG(scores && dropped && mask && rows_per_batch > 0, "softmax_dropout_fwd: bad arguments");
+  const int grid = tf_grid(rows, 4 * (64 / (L / 8)), 4096);
+  const DropArgs d = make_drop(mask, p, seed, offset);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(softmax_fwd_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (unsigned short*)scores, mask_add, (long long)rows, L, rows_per_batch, scale, (unsigned short*)dropped, d);
+  else hipLaunchKernelGGL(softmax_fwd_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (unsigned short*)scores, mask_add, (long long)rows, L, rows_per_batch, scale, (unsigned short*)dropped, d);
   DLE_LAUNCH_CHECK();
   return 0;
 }
@@ -516,8 +633,70 @@ extern "C" int dle_softmax_bwd(const void* probs, void* dprobs, int64_t rows, in
   if (rows == 0) return 0;
   DLE_CHECK_ARG(probs && dprobs, "softmax_bwd: null pointer");
   const int grid = tf_grid(rows, 4 * (64 / (L / 8)), 4096);
-  if (dtype == DLE_F16) hipLaunchKernelGGL(softmax_bwd_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)probs, (unsigned short*)dprobs, (long long)rows, L, scale);
-  else hipLaunchKernelGGL(softmax_bwd_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)probs, (unsigned short*)dprobs, (long long)rows, L, scale);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(softmax_bwd_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)probs, (unsigned short*)dprobs, (long long)rows, L, scale, (const unsigned char*)nullptr, 1.0f);
+  else hipLaunchKernelGGL(softmax_bwd_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)probs, (unsigned short*)dprobs, (long long)rows, L, scale, (const unsigned char*)nullptr, 1.0f);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// dS = P * (g - sum_j g_j P_j) * scale with g = dropout_backward(dP) (mask bits of dle_softmax_dropout_fwd), over dP
+extern "C" int dle_softmax_dropout_bwd(const void* probs, void* dprobs, const void* mask, int64_t rows, int L, float scale,
+                                       float p, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "softmax_dropout_bwd: 16-bit scores only");
+  DLE_CHECK_ARG(softmax_len_ok(L), "softmax_dropout_bwd: row length %d must be a power of two in [8, 512]", L);
+  if (rows == 0) return 0;
+  DLE_CHECK_ARG(probs && dprobs && mask, "softmax_dropout_bwd: null pointer");
+  const int grid = tf_grid(rows, 4 * (64 / (L / 8)), 4096);
+  const DropArgs d = make_drop(nullptr, p, 0, 0);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(softmax_bwd_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)probs, (unsigned short*)dprobs, (long long)rows, L, scale, (const unsigned char*)mask, d.inv_keep);
+  else hipLaunchKernelGGL(softmax_bwd_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)probs, (unsigned short*)dprobs, (long long)rows, L, scale, (const unsigned char*)mask, d.inv_keep);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// ------------------------------------------------------------------ standalone dropout (embedding output, modeling.py:296)
+template <int DT, bool BWD>
+__global__ __launch_bounds__(256) void dropout_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
+                                                      unsigned char* __restrict__ mask, long long chunks, DropArgs drop) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (long long)gridDim.x * blockDim.x) {
+    float v[8];
+    unpack8<DT>(((const ushort8_t*)x)[i], v);
+    unsigned bits;
+    if (BWD) bits = mask[i];
+    else { bits = drop_bits(drop, i); mask[i] = (unsigned char)bits; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = ((bits >> k) & 1u) ? v[k] * drop.inv_keep : 0.f;
+    ((ushort8_t*)y)[i] = pack8<DT>(v);
+  }
+}
+
+// y = dropout(x): n elements (multiple of 8), mask n / 8 bytes.  x == y is allowed.
+extern "C" int dle_dropout_fwd(const void* x, void* y, void* mask, int64_t n, float p, uint64_t seed, uint64_t offset,
+                               int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "dropout_fwd: 16-bit tensors only");
+  DLE_CHECK_ARG(n >= 0 && n % 8 == 0, "dropout_fwd: n must be a multiple of 8");
+  DLE_CHECK_ARG(p >= 0.f && p < 1.f, "dropout_fwd: p must be in [0, 1)");
+  if (n == 0) return 0;
+  DLE_CHECK_ARG(x && y && mask, "dropout_fwd: null pointer");
+  const DropArgs d = make_drop(mask, p, seed, offset);
+  const int grid = tf_grid(n / 8, 256);
+  if (dtype == DLE_F16) hipLaunchKernelGGL((dropout_kernel<DLE_F16, false>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, (unsigned char*)mask, (long long)(n / 8), d);
+  else hipLaunchKernelGGL((dropout_kernel<DLE_BF16, false>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, (unsigned char*)mask, (long long)(n / 8), d);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// dx = dy * mask / (1 - p)   (dy == dx allowed)
+extern "C" int dle_dropout_bwd(const void* dy, const void* mask, void* dx, int64_t n, float p, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "dropout_bwd: 16-bit tensors only");
+  DLE_CHECK_ARG(n >= 0 && n % 8 == 0, "dropout_bwd: n must be a multiple of 8");
+  if (n == 0) return 0;
+  DLE_CHECK_ARG(dy && dx && mask, "dropout_bwd: null pointer");
+  const DropArgs d = make_drop(nullptr, p, 0, 0);
+  const int grid = tf_grid(n / 8, 256);
+  if (dtype == DLE_F16) hipLaunchKernelGGL((dropout_kernel<DLE_F16, true>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (unsigned short*)dx, (unsigned char*)mask, (long long)(n / 8), d);
+  else hipLaunchKernelGGL((dropout_kernel<DLE_BF16, true>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (unsigned short*)dx, (unsigned char*)mask, (long long)(n / 8), d);
   DLE_LAUNCH_CHECK();
   return 0;
 }

@@ -600,3 +600,69 @@ def act_bwd(g, src, act):
     out = torch.empty_like(g)
     C.call("dle_act_bwd", C.ptr(g), C.ptr(src), C.ptr(out), g.numel(), act, C.dt(g), C.stream())
     return out
+
+
+# ------------------------------------------------------------------ dropout (BERT training mode)
+def dropout_fwd(x, p, seed, offset):
+    """y = dropout(x) with the C-ABI's counter-based RNG.  Returns (y, mask) -- mask is bit-packed uint8 [numel/8]."""
+    C.require_cuda(x)
+    n = x.numel()
+    y = torch.empty_like(x)
+    mask = torch.empty(n // 8, dtype=torch.uint8, device=x.device)
+    C.annotate(bytes=float(n) * 2 * 2 + n / 8, tag="N%d" % n)
+    C.call("dle_dropout_fwd", C.ptr(x), C.ptr(y), C.ptr(mask), n, float(p), int(seed), int(offset), C.dt(x), C.stream())
+    return y, mask
+
+
+def dropout_bwd(dy, mask, p):
+    C.require_cuda(dy, mask)
+    dx = torch.empty_like(dy)
+    n = dy.numel()
+    C.annotate(bytes=float(n) * 2 * 2 + n / 8, tag="N%d" % n)
+    C.call("dle_dropout_bwd", C.ptr(dy), C.ptr(mask), C.ptr(dx), n, float(p), C.dt(dy), C.stream())
+    return dx
+
+
+def dropout_add_layernorm_fwd(x, gamma, beta, residual, p, seed, offset, eps=1e-12):
+    """y = LayerNorm(dropout(x) + residual).  Returns (y, z, mean, rstd, mask)."""
+    C.require_cuda(x, gamma, beta, residual)
+    rows, h = x.shape
+    y = torch.empty_like(x)
+    z = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    mask = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device)
+    C.annotate(bytes=float(x.numel()) * 2 * 4 + x.numel() / 8, tag="R%dxH%d+drop" % (rows, h))
+    C.call("dle_dropout_add_layernorm_fwd", C.ptr(x), C.ptr(residual), C.ptr(z), C.ptr(y), C.ptr(mask), C.ptr(gamma),
+           C.ptr(beta), C.ptr(mean), C.ptr(rstd), rows, h, float(eps), float(p), int(seed), int(offset), C.dt(x),
+           C.stream())
+    return y, z, mean, rstd, mask
+
+
+def softmax_dropout_fwd_(scores, mask_add, rows_per_batch, scale, p, seed, offset):
+    """scores -> probs in place; returns (dropped = dropout(probs), mask)."""
+    C.require_cuda(scores, mask_add)
+    l = scores.shape[-1]
+    rows = scores.numel() // l
+    dropped = torch.empty_like(scores)
+    mask = torch.empty(scores.numel() // 8, dtype=torch.uint8, device=scores.device)
+    C.annotate(bytes=float(scores.numel()) * 6 + scores.numel() / 8, tag="R%dxL%d+drop" % (rows, l))
+    C.call("dle_softmax_dropout_fwd", C.ptr(scores), C.ptr(dropped), C.ptr(mask), C.ptr(mask_add), rows, l,
+           rows_per_batch, float(scale), float(p), int(seed), int(offset), C.dt(scores), C.stream())
+    return dropped, mask
+
+
+def softmax_dropout_bwd_(probs, dprobs, mask, scale, p):
+    C.require_cuda(probs, dprobs, mask)
+    l = probs.shape[-1]
+    rows = probs.numel() // l
+    C.annotate(bytes=float(probs.numel()) * 6 + probs.numel() / 8, tag="R%dxL%d+drop" % (rows, l))
+    C.call("dle_softmax_dropout_bwd", C.ptr(probs), C.ptr(dprobs), C.ptr(mask), rows, l, float(scale), float(p),
+           C.dt(probs), C.stream())
+    return dprobs
+
+
+def unpack_dropout_mask(mask, shape):
+    """Bit-packed keep mask -> bool tensor of `shape` (bit k of byte i <-> flat element 8 i + k)."""
+    bits = (mask.to(torch.int32).unsqueeze(1) >> torch.arange(8, device=mask.device, dtype=torch.int32)) & 1
+    return bits.reshape(shape).bool()

@@ -250,6 +250,29 @@ int dle_softmax_fwd(void* scores, const float* mask_add, int64_t rows, int L, in
 int dle_softmax_bwd(const void* probs, void* dprobs, int64_t rows, int L, float scale, int dtype,
                     hipStream_t stream);
 
+/* ---- dropout (training-mode nn.Dropout of the BERT path: modeling.py:276,296 embeddings; :320,369 attention
+ * probabilities; :392-396, :428-432 BertSelfOutput / BertOutput before the residual LayerNorm).
+ * Counter-based Philox4x32-10: key = seed, counter = (8-element chunk index, offset); the caller advances `offset`
+ * per call site and per step.  Masks are bit-packed (bit k of byte i <-> element 8 i + k, 1 = kept), n / 8 bytes;
+ * the drop probability is quantised to round(p * 65536) / 65536 and kept values are scaled by its complement.
+ * The reference draws from torch's CUDA Philox stream, so masks are NOT bit-identical to the reference's; parity of
+ * the step is checked against the oracle under the masks these entry points produce.                            */
+int dle_dropout_fwd(const void* x, void* y, void* mask, int64_t n, float p, uint64_t seed, uint64_t offset,
+                    int dtype, hipStream_t stream);
+int dle_dropout_bwd(const void* dy, const void* mask, void* dx, int64_t n, float p, int dtype, hipStream_t stream);
+/* y = LayerNorm(dropout(x) + residual); z_out = dropout(x) + residual (16-bit, for the backward pass) */
+int dle_dropout_add_layernorm_fwd(const void* x, const void* residual, void* z_out, void* y, void* mask,
+                                  const float* gamma, const float* beta, float* mean, float* rstd, int64_t rows,
+                                  int H, float eps, float p, uint64_t seed, uint64_t offset, int dtype,
+                                  hipStream_t stream);
+/* scores -> probs in place; dropped = dropout(probs) is the operand of the P V contraction */
+int dle_softmax_dropout_fwd(void* scores, void* dropped, void* mask, const float* mask_add, int64_t rows, int L,
+                            int rows_per_batch, float scale, float p, uint64_t seed, uint64_t offset, int dtype,
+                            hipStream_t stream);
+/* in place over dprobs: g = dP * mask / (1 - p); dS = P * (g - sum(g * P)) * scale */
+int dle_softmax_dropout_bwd(const void* probs, void* dprobs, const void* mask, int64_t rows, int L, float scale,
+                            float p, int dtype, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

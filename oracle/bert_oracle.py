@@ -9,7 +9,10 @@ Follows, in fp32 torch functional ops on the CPU (paths relative to /root/refere
     run_pretraining.py:75-95   BertPretrainingCriterion = CE(ignore_index=-1) MLM + CE NSP
     lamb_amp_opt/fused_lamb/fused_lamb.py:131-258 + csrc/multi_tensor_lamb.cu  LAMB step (oracle/lamb_oracle.py)
     schedulers.py:123-136  PolyWarmUpScheduler
-Dropout probabilities are 0 in parity runs (CPU and GPU RNG streams differ).
+Dropout: the golden fixture runs with probabilities 0 (the reference's CUDA Philox stream cannot be reproduced on the
+CPU).  The dropout sites themselves (modeling.py:296 embeddings, :369 attention probabilities,
+:396 / :432 before the residual LayerNorms) are restated here with EXTERNALLY supplied keep masks, so the HIP step in
+training mode is checked against this oracle under the masks the HIP RNG produced.
 Pinned by tests/golden/bert_step.npz: per-step losses of the reference's own BertForPreTraining module with the
 oracle's LAMB (the reference has no CPU LAMB), oracle/make_golden.py gen_bert.
 """
@@ -97,14 +100,19 @@ class BertOracle:
         self.step_count = 0
         self.lr, self.warmup, self.total, self.wd, self.max_norm = lr, warmup, total_steps, weight_decay, max_grad_norm
 
-    def forward(self, ids, tt, mask, labels):
+    def forward(self, ids, tt, mask, labels, masks=None, p_hidden=0.0, p_attn=0.0):
+        """masks (optional): {"emb": bool [b,s,h], "attn<l>": bool [b,nh,s,s], "out1_<l>" / "out2_<l>": bool [b,s,h]}
+        keep masks of the nn.Dropout sites; kept values are scaled by 1/(1-p) with p quantised like the C ABI."""
         p, c = self.p, self.cfg
+        q16 = lambda pr: round(pr * 65536.0) / 65536.0
+        drop = lambda t, key, pr: t if masks is None or pr <= 0 else t * masks[key].to(t.dtype) / (1.0 - q16(pr))
         b, s = ids.shape
         h, nh = c["hidden"], c["heads"]
         d = h // nh
         e = (p["bert.embeddings.word_embeddings.weight"][ids] + p["bert.embeddings.position_embeddings.weight"][:s][None]
              + p["bert.embeddings.token_type_embeddings.weight"][tt])
         x = TF.layer_norm(e, (h,), p["bert.embeddings.LayerNorm.weight"], p["bert.embeddings.LayerNorm.bias"], 1e-12)
+        x = drop(x, "emb", p_hidden)
         ext = (1.0 - mask.float())[:, None, None, :] * -10000.0
         for l in range(c["layers"]):
             pre = "bert.encoder.layer.%d." % l
@@ -113,12 +121,13 @@ class BertOracle:
             k = lin(x, "attention.self.key").view(b, s, nh, d).transpose(1, 2)
             v = lin(x, "attention.self.value").view(b, s, nh, d).transpose(1, 2)
             sc = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d) + ext
-            ctx = torch.matmul(torch.softmax(sc, -1), v).transpose(1, 2).reshape(b, s, h)
-            a = TF.layer_norm(lin(ctx, "attention.output.dense") + x, (h,), p[pre + "attention.output.LayerNorm.weight"],
-                              p[pre + "attention.output.LayerNorm.bias"], 1e-12)
+            probs = drop(torch.softmax(sc, -1), "attn%d" % l, p_attn)
+            ctx = torch.matmul(probs, v).transpose(1, 2).reshape(b, s, h)
+            a = TF.layer_norm(drop(lin(ctx, "attention.output.dense"), "out1_%d" % l, p_hidden) + x, (h,),
+                              p[pre + "attention.output.LayerNorm.weight"], p[pre + "attention.output.LayerNorm.bias"], 1e-12)
             it = gelu(lin(a, "intermediate.dense_act"))
-            x = TF.layer_norm(lin(it, "output.dense") + a, (h,), p[pre + "output.LayerNorm.weight"],
-                              p[pre + "output.LayerNorm.bias"], 1e-12)
+            x = TF.layer_norm(drop(lin(it, "output.dense"), "out2_%d" % l, p_hidden) + a, (h,),
+                              p[pre + "output.LayerNorm.weight"], p[pre + "output.LayerNorm.bias"], 1e-12)
         pooled = torch.tanh(TF.linear(x[:, 0], p["bert.pooler.dense_act.weight"], p["bert.pooler.dense_act.bias"]))
         flat = x.reshape(-1, h)
         sel = torch.nonzero(labels.reshape(-1) != -1).squeeze(1)
@@ -130,8 +139,8 @@ class BertOracle:
         nsp = TF.linear(pooled, p["cls.seq_relationship.weight"], p["cls.seq_relationship.bias"])
         return scores, nsp, sel
 
-    def loss(self, ids, tt, mask, labels, nsp_labels):
-        scores, nsp, sel = self.forward(ids, tt, mask, labels)
+    def loss(self, ids, tt, mask, labels, nsp_labels, masks=None, p_hidden=0.0, p_attn=0.0):
+        scores, nsp, sel = self.forward(ids, tt, mask, labels, masks, p_hidden, p_attn)
         mlm = TF.cross_entropy(scores, labels.reshape(-1)[sel])
         return mlm + TF.cross_entropy(nsp, nsp_labels)
 

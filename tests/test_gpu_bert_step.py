@@ -12,14 +12,14 @@ from oracle import bert_oracle as BO
 pytestmark = pytest.mark.gpu
 
 
-def _build(cuda, dtype, c, state):
+def _build(cuda, dtype, c, state, p_hidden=0.0, p_attn=0.0):
     from deeplearningexamples_amd.bert.model import BertForPreTraining
     from deeplearningexamples_amd.bert.engine import BertTrainer
     model = BertForPreTraining(c["cfg"], device=cuda)
     res = model.load_state_dict({k: v.clone() for k, v in state.items()}, strict=False)
     assert not res.unexpected_keys and res.missing_keys == ["cls.predictions.decoder.weight"] or not res.missing_keys
     tr = BertTrainer(model, lr=c["lr"], warmup=c["warmup"], total_steps=c["total_steps"], compute_dtype=dtype,
-                     init_loss_scale=1024.0)
+                     init_loss_scale=1024.0, hidden_dropout=p_hidden, attention_dropout=p_attn, seed=1234)
     return model, tr
 
 
@@ -71,3 +71,84 @@ def test_bert_first_step_gradients_vs_oracle(cuda, dtype, bar):
             bad.append(report[-1])
     print("relative L2 gradient errors (every 5th):", report[::5])
     assert not bad, bad[:12]
+
+
+def _masks_from(tr, cfg, b, s):
+    """Unpack the keep masks of the last forward/backward (engine keeps them when keep_activations is set)."""
+    from deeplearningexamples_amd import functional as F
+    sv = tr._last_sv
+    h, nh = cfg["hidden"], cfg["heads"]
+    masks = {"emb": F.unpack_dropout_mask(sv["mask0"], (b, s, h)).cpu()}
+    for l, a in enumerate(sv["layers"]):
+        masks["attn%d" % l] = F.unpack_dropout_mask(a["mask_a"], (b, nh, s, s)).cpu()
+        masks["out1_%d" % l] = F.unpack_dropout_mask(a["mask_1"], (b, s, h)).cpu()
+        masks["out2_%d" % l] = F.unpack_dropout_mask(a["mask_2"], (b, s, h)).cpu()
+    return masks
+
+
+@pytest.mark.parametrize("dtype,bar", [(torch.float16, 0.03), (torch.bfloat16, 0.12)])
+def test_bert_training_mode_dropout_vs_oracle(cuda, dtype, bar):
+    """Training mode (hidden / attention dropout 0.1, the reference's bert_config.json): loss and every gradient
+    against the oracle under the SAME keep masks; keep rate, determinism and mask freshness of the RNG."""
+    c = BO.BERT_STEP_CONFIG
+    cfg = c["cfg"]
+    state = BO.seeded_state(cfg, c["seed"])
+    model, tr = _build(cuda, dtype, c, state, 0.1, 0.1)
+    tr.keep_activations = True
+    cpu_batch = BO.seeded_batch(cfg, 99, 3)
+    b, s = cpu_batch[0].shape
+    loss, dlog, dnsp = tr.forward(*[t.to(cuda) for t in cpu_batch])
+    tr.backward(dlog, dnsp)
+    torch.cuda.synchronize()
+    masks = _masks_from(tr, cfg, b, s)
+    keep = np.mean([float(m.float().mean()) for m in masks.values()])
+    assert abs(keep - 0.9) < 5e-3, keep
+    assert not torch.equal(masks["out1_0"], masks["out2_0"]) and not torch.equal(masks["out1_0"], masks["out1_1"])
+    orc = BO.BertOracle(cfg, state)
+    lo = orc.loss(*cpu_batch, masks=masks, p_hidden=0.1, p_attn=0.1)
+    lo.backward()
+    assert abs(loss.item() - float(lo)) <= (1e-3 if dtype == torch.float16 else 3e-3) * float(lo), (loss.item(), float(lo))
+    scale = float(tr.scaler.scale.item()) if tr.scaler.enabled else 1.0
+    bad = []
+    for n, p in orc.p.items():
+        g = tr.gview[n].reshape(-1).cpu().double() / scale
+        r = p.grad.reshape(-1).double()
+        if float(r.norm()) < 1e-6:
+            continue
+        rel = float((g - r).norm() / (r.norm() + 1e-12))
+        if rel > bar:
+            bad.append((n, round(rel, 4)))
+    assert not bad, bad[:12]
+    # same seed, same call sequence -> same masks; the next step draws new ones
+    model2, tr2 = _build(cuda, dtype, c, state, 0.1, 0.1)
+    tr2.keep_activations = True
+    l2, d2, n2 = tr2.forward(*[t.to(cuda) for t in cpu_batch])
+    tr2.backward(d2, n2)
+    m2 = _masks_from(tr2, cfg, b, s)
+    assert all(torch.equal(masks[k], m2[k]) for k in masks)
+    assert abs(float(l2.item()) - float(loss.item())) <= 1e-6 * float(loss.item())      # (loss reduction uses fp32 atomics)
+    l3, d3, n3 = tr2.forward(*[t.to(cuda) for t in cpu_batch])
+    tr2.backward(d3, n3)
+    m3 = _masks_from(tr2, cfg, b, s)
+    assert not torch.equal(m3["emb"], m2["emb"])
+
+
+def test_dropout_entry_points(cuda):
+    """dle_dropout_fwd / bwd: scaling, bit-packed mask layout, p quantisation, offsets decorrelate."""
+    from deeplearningexamples_amd import functional as F
+    x = torch.randn(4096, 64).to(torch.bfloat16).to(cuda)
+    y, m = F.dropout_fwd(x, 0.1, 7, 1)
+    keep = F.unpack_dropout_mask(m, x.shape)
+    inv = 65536.0 / (65536 - round(0.1 * 65536))
+    ref = torch.where(keep, x.float() * inv, torch.zeros_like(x, dtype=torch.float32)).to(torch.bfloat16)
+    assert torch.equal(y, ref)
+    assert abs(float(keep.float().mean()) - 0.9) < 3e-3
+    dx = F.dropout_bwd(x, m, 0.1)
+    assert torch.equal(dx, ref)
+    y2, m2 = F.dropout_fwd(x, 0.1, 7, 2)
+    agree = float((F.unpack_dropout_mask(m2, x.shape) == keep).float().mean())
+    assert abs(agree - (0.81 + 0.01)) < 5e-3, agree          # independent masks agree with prob p^2 + (1-p)^2
+    y3, m3 = F.dropout_fwd(x, 0.1, 7, 1)
+    assert torch.equal(m3, m)
+    y0, m0 = F.dropout_fwd(x, 0.0, 7, 1)
+    assert torch.equal(y0, x) and int(m0.min()) == 255
