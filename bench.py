@@ -268,6 +268,19 @@ class BertWorkload:
 WORKLOADS = {"dlrm": DlrmWorkload, "rn50": Rn50Workload, "bert": BertWorkload}
 
 
+def lookup_traffic(kernel_key):
+    """HBM-side bytes per launch of `kernel_key` from the committed PMC passes (profiles/traffic.json, written by
+    tools/collect_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs over a replay of exactly this
+    launch, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when that launch was not profiled."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+    try:
+        table = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    rec = table.get(kernel_key)
+    return float(rec["traffic_bytes_per_launch"]) if rec else None
+
+
 def roofline_from(timer, steps):
     """Dominant entry point of the step.  Candidates are ranked by their HIP-event time over the instrumented
     steps; the top ones are then re-timed by replaying the recorded launch back to back (one event pair around 20
@@ -297,7 +310,8 @@ def roofline_from(timer, steps):
         ach = byts / (ms * 1e-3) / 1e9
         r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(ach / HBM_PEAK_GBS, 4)}
-    r.update({"traffic": None, "kernel": top["name"] + ("[" + top["tag"] + "]" if top["tag"] else ""),
+    kname = top["name"] + ("[" + top["tag"] + "]" if top["tag"] else "")
+    r.update({"traffic": lookup_traffic(kname), "kernel": kname,
               "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": round(top["calls"] / steps, 2),
               "timing": top["timing"],
               "algorithmic_bytes_per_launch": byts, "algorithmic_flops_per_launch": flops})

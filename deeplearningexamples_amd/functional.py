@@ -229,8 +229,11 @@ def gemm(a, b, m, n, k, a_kc, b_kc, out=None, out_dtype=None, bias=None, act=C.A
         raise ValueError("gemm output must have unit inner stride")
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != n):
         raise ValueError("gemm bias must be fp32 [n]")
-    C.annotate(flops=2.0 * m * n * k, bytes=float(m * k + n * k) * a.element_size() + float(m * n) * out.element_size(),
-               tag="%dx%dx%d" % (m, n, k))
+    extra = (float(m * n) * mask_src.element_size() if mask_src is not None else 0.0) + \
+            (float(m * n) * aux.element_size() if aux is not None else 0.0)
+    C.annotate(flops=2.0 * m * n * k,
+               bytes=float(m * k + n * k) * a.element_size() + float(m * n) * out.element_size() + extra,
+               tag="%dx%dx%d%s%s" % (m, n, k, "+src" if mask_src is not None else "", "+aux" if aux is not None else ""))
     ws = splitk_workspace(a.device, splitk * m * n * 4) if splitk > 1 else None
     C.call("dle_gemm", C.ptr(a), C.ptr(b), C.ptr(out), C.ptr(aux), C.ptr(bias), C.ptr(mask_src), m, n, k,
            lda, ldb, out.stride(0) if out.dim() == 2 else n, int(a_kc), int(b_kc), C.dt(a), C.dt(out), act,
