@@ -140,7 +140,9 @@ struct Loader {
   unsigned off[NP];      // mode 0/1: byte offset inside the K-tile panel; conv modes: lane-constant part
   int kin[NP];           // KC: k element offset inside the tile; RC: k row inside the tile
   int a0[NP], a1[NP];    // mode 2: (h0, w0) of the output pixel; mode 4: (h, w); mode 3: (r, s) of the lane's tap
+  unsigned fo[NP];       // modes 2 / 4 / 5, channels % 64 == 0: lane part of the offset with the k position folded in
   bool row_ok[NP];
+  bool tap_uniform;      // a 64-deep K tile lies inside ONE filter tap: (r, s) are scalars, no per-lane division
 
   __device__ __forceinline__ void init(int wave, int lane, int row0, int nrows, long long ld, const ConvGeom& cg) {
 #pragma unroll
@@ -184,6 +186,16 @@ struct Loader {
         }
       }
     }
+    tap_uniform = (MODE == 2 && (cg.C & 63) == 0) || (MODE == 4 && (cg.Ko & 63) == 0 && cg.stride == 1) ||
+                  (MODE == 5 && (cg.Ko & 63) == 0);
+    if (MODE == 2 || MODE == 4 || MODE == 5) {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        if (MODE == 2) fo[j] = off[j] + (unsigned)(kin[j] * 2);
+        else if (MODE == 4) fo[j] = (unsigned)(((((long long)off[j] * cg.P + a0[j]) * cg.Q + a1[j]) * cg.Ko + kin[j]) * 2);
+        else fo[j] = off[j] + (unsigned)(((long long)kin[j] * cg.R * cg.S * cg.C) * 2);
+      }
+    }
   }
 
   // base: (row0, k0) panel for mode 0, (k0, row0) panel for mode 1, tensor base for the conv modes
@@ -192,6 +204,30 @@ struct Loader {
   __device__ __forceinline__ void issue(const unsigned short* base, unsigned short* tile, int wave, int krem,
                                         int k0, const ConvGeom& cg) {
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xFFFFFFE0, 0x00020000);
+    if ((MODE == 2 || MODE == 4 || MODE == 5) && tap_uniform) {
+      // the whole K tile belongs to one tap: (tap, r, s) and the tap's offset are wave-uniform scalars
+      const int ch = MODE == 2 ? cg.C : cg.Ko;
+      int tap;
+      if (MODE == 2) tap = fd_div(k0, cg.dC); else tap = fd_div(k0, cg.dKo);
+      const int c0 = k0 - tap * ch;
+      const int r = fd_div(tap, cg.dS), s2 = tap - r * cg.S;
+      const unsigned delta = MODE == 2 ? (unsigned)(((r * cg.W + s2) * cg.C + c0) * 2)
+                           : MODE == 4 ? (unsigned)((c0 - (r * cg.Q + s2) * cg.Ko) * 2)
+                                       : (unsigned)((((long long)c0 * cg.R * cg.S + tap) * cg.C) * 2);
+#pragma unroll
+      for (int j = J0; j < J1; ++j) {
+        bool ok = row_ok[j] && kin[j] < krem;
+        if (MODE == 2) {
+          const int h = a0[j] + r, w = a1[j] + s2;
+          ok = ok && h >= 0 && h < cg.H && w >= 0 && w < cg.W;
+        } else if (MODE == 4) {
+          const int hp = a0[j] - r, wp = a1[j] - s2;
+          ok = ok && hp >= 0 && wp >= 0 && hp < cg.P && wp < cg.Q;
+        }
+        dma16(rs, tile + (wave * NP + j) * 512, ok ? fo[j] + delta : OOB_OFF);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = J0; j < J1; ++j) {
       bool ok = row_ok[j] && kin[j] < krem;
@@ -423,21 +459,21 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
   lb.init(wave, lane, n0, p.N, p.ldb, p.cg);
 
   // DMA piece J of operand A / B of K tile kt into `stage` (one wave instruction each)
-  auto issue_a = [&](int kt, int stage, auto J) {
+  auto issue_a = [&](int kt, int stage, auto J) __attribute__((always_inline)) {
     const int k0 = kt * BK;
     const unsigned short* ba = A_MODE == 0 ? p.A + (long long)m0 * p.lda + k0
                              : A_MODE == 1 ? p.A + (long long)k0 * p.lda + m0 : p.A;
     la.template issue<decltype(J)::value, decltype(J)::value + 1>(ba, lds + stage * STAGE, wave, kend - k0, k0, p.cg);
   };
-  auto issue_b = [&](int kt, int stage, auto J) {
+  auto issue_b = [&](int kt, int stage, auto J) __attribute__((always_inline)) {
     const int k0 = kt * BK;
     const unsigned short* bb = B_MODE == 0 ? p.B + (long long)n0 * p.ldb + k0
                              : B_MODE == 1 ? p.B + (long long)k0 * p.ldb + n0 : p.B;
     lb.template issue<decltype(J)::value, decltype(J)::value + 1>(bb, lds + stage * STAGE + TM * BK, wave, kend - k0, k0, p.cg);
   };
-  auto issue_all = [&](int kt, int stage) {
-    static_for<0, 4>([&](auto J) { issue_a(kt, stage, J); });
-    static_for<0, 4>([&](auto J) { issue_b(kt, stage, J); });
+  auto issue_all = [&](int kt, int stage) __attribute__((always_inline)) {
+    static_for<0, 4>([&](auto J) __attribute__((always_inline)) { issue_a(kt, stage, J); });
+    static_for<0, 4>([&](auto J) __attribute__((always_inline)) { issue_b(kt, stage, J); });
   };
 
   float16_t acc[WTM][WTN];
@@ -561,19 +597,21 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
   // not depend on the row -- the lane's 8 columns, its bias values, the swizzled LDS slots, the activation kind -- is
   // hoisted out of the store loop, which is then ~30 VALU instructions per 16-byte store instead of ~100 VALU + 60
   // SALU (the generic loop below re-decides every runtime flag per store; a K <= 256 GEMM was instruction-bound in it).
-  const bool fast = p.splitk == 1 && p.out_dtype == DT && vec16 && m0 + TM <= p.M && n0 + TN <= p.N;
-  const bool fast_slab = p.splitk > 1 && p.ws != nullptr && (p.N & 3) == 0 && m0 + TM <= p.M && n0 + TN <= p.N;
+  // (edge tiles included: N % 8 == 0 makes every 8-column group entirely inside or outside, rows are checked per trip)
+  const bool fast = p.splitk == 1 && p.out_dtype == DT && vec16 && (p.N & 7) == 0;
+  const bool fast_slab = p.splitk > 1 && p.ws != nullptr && (p.N & 7) == 0;
   constexpr int RPI = NT / (TN / 8), ITERS = (TM / 2) / RPI;      // rows per store-loop trip (16), trips per half
   const int f_ml0 = tid / (TN / 8), f_nl = (tid % (TN / 8)) << 3;
   float fbias[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) fbias[r] = 0.f;
-  if (fast && p.bias) {
+  const bool f_col_ok = n0 + f_nl < p.N;
+  if (fast && p.bias && f_col_ok) {
     const float4_t b0 = *(const float4_t*)(p.bias + n0 + f_nl), b1 = *(const float4_t*)(p.bias + n0 + f_nl + 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { fbias[r] = b0[r]; fbias[4 + r] = b1[r]; }
   }
-  auto fast_pass = [&](auto ACTC, int half) {
+  auto fast_pass = [&](auto ACTC, int half) __attribute__((always_inline)) {
     constexpr int act = decltype(ACTC)::value;
     constexpr bool needs_src = act == ACT_RELU_BWD || act == ACT_ADD || act == ACT_GELU_BWD || act == ACT_TANH_BWD;
     const float* e0 = epi + f_ml0 * TN;
@@ -584,8 +622,11 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
     unsigned short* c = (unsigned short*)p.C + off0;
     unsigned short* ax = p.aux ? (unsigned short*)p.aux + off0 : nullptr;
     const unsigned short* ms = needs_src ? p.mask_src + off0 : nullptr;
+    const int rows_left = p.M - (m0 + half * (TM / 2) + f_ml0);      // trips with it * RPI < rows_left are inside
+    if (!f_col_ok) return;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
+      if (it * RPI >= rows_left) break;
       const float* e = e0 + it * RPI * TN;
       const int x = (it & 1) << 6;                       // row & 31 alternates between ml0 and ml0 + 16
       const float4_t lo = *(const float4_t*)(e + (olo ^ x)), hi = *(const float4_t*)(e + (ohi ^ x));
@@ -643,13 +684,17 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
     const int olo = (c4 ^ f_ml0) << 2, ohi = ((c4 + 1) ^ f_ml0) << 2;
     float* c = p.ws + ((long long)blockIdx.y * p.M + m0 + half * (TM / 2) + f_ml0) * p.N + n0 + f_nl;
     const long long step = (long long)RPI * p.N;
+    const int rows_left = p.M - (m0 + half * (TM / 2) + f_ml0);
+    if (n0 + f_nl < p.N) {
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      const float* e = e0 + it * RPI * TN;
-      const int x = (it & 1) << 6;
-      const float4_t lo = *(const float4_t*)(e + (olo ^ x)), hi = *(const float4_t*)(e + (ohi ^ x));
-      *(float4_t*)(c + it * step) = lo;
-      *(float4_t*)(c + it * step + 4) = hi;
+      for (int it = 0; it < ITERS; ++it) {
+        if (it * RPI >= rows_left) break;
+        const float* e = e0 + it * RPI * TN;
+        const int x = (it & 1) << 6;
+        const float4_t lo = *(const float4_t*)(e + (olo ^ x)), hi = *(const float4_t*)(e + (ohi ^ x));
+        *(float4_t*)(c + it * step) = lo;
+        *(float4_t*)(c + it * step + 4) = hi;
+      }
     }
     continue;
   }
