@@ -90,7 +90,9 @@ __global__ __launch_bounds__(256) void dot_fwd_mfma(const unsigned short* __rest
 // ------------------------------------------------------------------ backward, MFMA path
 // requires R <= 32, C % 32 == 0, C <= 256, OW % 8 == 0.
 #define DOT_BWD_USTRIDE 40   // halves per U row (32 + 8 pad -> 80 B, keeps 16 B alignment)
-template <int DT>
+// NB = 32-wide column blocks of the gradient kept in accumulators (C <= 32 NB); sized per launch so that a C = 128
+// sample costs 64 accumulator registers, not the 128 of the C = 256 maximum (which left one wave per SIMD).
+template <int DT, int NB>
 __global__ __launch_bounds__(256) void dot_bwd_mfma(const unsigned short* __restrict__ x,
                                                     const unsigned short* __restrict__ ug,
                                                     unsigned short* __restrict__ grad,
@@ -140,38 +142,59 @@ __global__ __launch_bounds__(256) void dot_bwd_mfma(const unsigned short* __rest
   }
   __syncthreads();
   const int nb_n = C >> 5;   // 32-wide column blocks (<= 8)
-  float16_t acc[8];
+  float16_t acc[NB];
   if (act) {
-    ushort8_t a0 = *(const ushort8_t*)(us + row * DOT_BWD_USTRIDE + h * 8);
-    ushort8_t a1 = *(const ushort8_t*)(us + row * DOT_BWD_USTRIDE + 16 + h * 8);
+    // grad = U X.  U rows are k-contiguous in LDS (one 16-byte read per fragment); X is the contraction-strided
+    // operand, B(n, k) = X[k][n], read with the LDS transpose read (4 k lines x 4 columns per 16-lane group) instead
+    // of 16 two-byte reads.  Operands are swapped (D = X^T-fragment x U-fragment) so that a lane owns 4 CONSECUTIVE
+    // columns of one gradient row: register r <-> column 8 (r >> 2) + 4 h + (r & 3), lane & 31 <-> row i.
+    const ushort8_t a0 = *(const ushort8_t*)(us + row * DOT_BWD_USTRIDE + h * 8);
+    const ushort8_t a1 = *(const ushort8_t*)(us + row * DOT_BWD_USTRIDE + 16 + h * 8);
+    const int tg = lane >> 4, ti = lane & 15;
+    typedef __attribute__((ext_vector_type(4))) short short4_t;
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
       if (nb < nb_n) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-        ushort8_t b0, b1;
+        ushort8_t bf[2];
+        const int ncol = nb * 32 + ((tg & 1) << 4) + ((ti & 3) << 2);
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-          b0[p] = xs[(h * 8 + p) * XS + nb * 32 + row];
-          b1[p] = xs[(16 + h * 8 + p) * XS + nb * 32 + row];
-        }
-        acc[nb] = Mfma32<DT>::run(a0, b0, acc[nb]);
-        acc[nb] = Mfma32<DT>::run(a1, b1, acc[nb]);
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const int k = ks * 16 + (tg >> 1) * 8 + (ti >> 2) + hh * 4;
+            const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) short4_t*)(xs + k * XS + ncol));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bf[ks][hh * 4 + e] = (unsigned short)v[e];
+          }
+        acc[nb] = Mfma32<DT>::run(bf[0], a0, acc[nb]);
+        acc[nb] = Mfma32<DT>::run(bf[1], a1, acc[nb]);
       }
     }
   }
   __syncthreads();   // every B-fragment read is done: reuse xs as the output stage
-  if (act) {
+  if (act && row < R) {
+    typedef __attribute__((ext_vector_type(4))) unsigned short ushort4_t;
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
       if (nb < nb_n) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-          float v = acc[nb][r];
+        for (int q = 0; q < 4; ++q) {
+          const int n = nb * 32 + 8 * q + 4 * h;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[nb][q * 4 + e];
           // fused form (mlp_grad == NULL): row 0 also receives upstream[:, :C] (what autograd adds later)
-          if (!mlp_grad && i == 0) v += Elem<DT>::to_f32(ug[(size_t)b * OW + nb * 32 + row]);
-          xs[i * XS + nb * 32 + row] = Elem<DT>::from_f32(v);
+          if (!mlp_grad && row == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += Elem<DT>::to_f32(ug[(size_t)b * OW + n + e]);
+          }
+          ushort4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = Elem<DT>::from_f32(v[e]);
+          *(ushort4_t*)(xs + row * XS + n) = o;
         }
       }
     }
@@ -327,14 +350,12 @@ extern "C" int dle_dot_interact_bwd(const void* x, const void* upstream, void* g
   if (fast) {
     const size_t lds = (size_t)4 * (32 * (cols + 8) + 32 * DOT_BWD_USTRIDE) * 2;
     dim3 grid((batch + 3) / 4), block(256);
-    if (dtype == DLE_F16)
-      hipLaunchKernelGGL(dot_bwd_mfma<DLE_F16>, grid, block, lds, stream, (const unsigned short*)x,
-                         (const unsigned short*)upstream, (unsigned short*)grad, (unsigned short*)mlp_grad,
-                         batch, rows, cols, OW);
-    else
-      hipLaunchKernelGGL(dot_bwd_mfma<DLE_BF16>, grid, block, lds, stream, (const unsigned short*)x,
-                         (const unsigned short*)upstream, (unsigned short*)grad, (unsigned short*)mlp_grad,
-                         batch, rows, cols, OW);
+#define GO(DT, NB) hipLaunchKernelGGL((dot_bwd_mfma<DT, NB>), grid, block, lds, stream, (const unsigned short*)x, \
+                         (const unsigned short*)upstream, (unsigned short*)grad, (unsigned short*)mlp_grad, batch, rows, cols, OW)
+#define PICK(DT) do { if (cols <= 32) GO(DT, 1); else if (cols <= 64) GO(DT, 2); else if (cols <= 128) GO(DT, 4); else GO(DT, 8); } while (0)
+    if (dtype == DLE_F16) PICK(DLE_F16); else PICK(DLE_BF16);
+#undef GO
+#undef PICK
   } else {
     const size_t lds = ((size_t)rows * cols + (size_t)rows * rows) * 4;
     DLE_CHECK_ARG(lds <= 64 * 1024, "dot_interact_bwd: sample does not fit LDS (%d x %d)", rows, cols);

@@ -780,20 +780,43 @@ static int launch_gemm(const Gemm2Args& p_in, int in_dtype, int amode, int bmode
   return 0;
 }
 
-// C[m][n] (+)= sum_z ws[z][m][n]
+// C[m][n] (+)= sum_z ws[z][m][n].  A weight gradient is small (M x N <= a few 10^5) and deep (up to 512 slabs), so
+// the pass is spread over BOTH axes: 16 lanes x 16 bytes cover 64 consecutive elements, the 16 lane rows of a workgroup
+// take every 16th slab (4 loads in flight each) and meet in LDS.  (The first version gave one thread all slabs of its
+// element: 16 workgroups doing 512 dependent loads each, 50 us for 33 MB.)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C,
                                                             int M, int N, long long ldc, int splitk, int accumulate) {
   const long long slab = (long long)M * N;
   if ((N & 3) == 0 && (ldc & 3) == 0) {
+    __shared__ float4_t red[256];
     const long long total4 = slab >> 2;
     const int n4 = N >> 2;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
-      float4_t s = ((const float4_t*)ws)[i];
-      for (int z = 1; z < splitk; ++z) s += ((const float4_t*)(ws + z * slab))[i];
-      const long long m = i / n4;
-      float4_t* c = (float4_t*)(C + m * ldc) + (i - m * n4);
-      if (accumulate) s += *c;
-      *c = s;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    for (long long i0 = (long long)blockIdx.x * 16; i0 < total4; i0 += (long long)gridDim.x * 16) {
+      const long long i = i0 + tx;
+      float4_t s = {0.f, 0.f, 0.f, 0.f};
+      if (i < total4) {
+        int z = ty;
+        for (; z + 48 < splitk; z += 64) {
+          const float4_t a = ((const float4_t*)(ws + (long long)z * slab))[i];
+          const float4_t b = ((const float4_t*)(ws + (long long)(z + 16) * slab))[i];
+          const float4_t c = ((const float4_t*)(ws + (long long)(z + 32) * slab))[i];
+          const float4_t d = ((const float4_t*)(ws + (long long)(z + 48) * slab))[i];
+          s += (a + b) + (c + d);
+        }
+        for (; z < splitk; z += 16) s += ((const float4_t*)(ws + (long long)z * slab))[i];
+      }
+      red[threadIdx.x] = s;
+      __syncthreads();
+      if (ty == 0 && i < total4) {
+#pragma unroll
+        for (int q = 1; q < 16; ++q) s += red[q * 16 + tx];
+        const long long m = i / n4;
+        float4_t* c = (float4_t*)(C + m * ldc) + (i - m * n4);
+        if (accumulate) s += *c;
+        *c = s;
+      }
+      __syncthreads();
     }
   } else {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < slab; i += (long long)gridDim.x * blockDim.x) {
@@ -844,8 +867,8 @@ extern "C" int dle_gemm_dma_try(const void* A, const void* B, void* C, void* aux
   { const int rc = launch_gemm(p, in_dtype, amode, bmode, 0, stream); if (rc) return rc + 1000; }
   if (p.ws) {
     long long items = ((long long)M * N + 3) / 4;
-    long long g = (items + 255) / 256;
-    if (g > 2048) g = 2048;
+    long long g = ((N & 3) == 0 && (ldc & 3) == 0) ? (items + 15) / 16 : (items + 63) / 64;
+    if (g > 4096) g = 4096;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float*)p.ws, (float*)C, M, N,
                        (long long)ldc, splitk, accumulate);
     hipError_t e = hipGetLastError();
@@ -930,8 +953,8 @@ extern "C" int dle_conv2d_wgrad(const void* dy, const void* x, float* dw, int N,
   }
   if (int rc = conv_launch(p, dtype, 1, 3, stream)) return rc;
   if (p.ws) {
-    long long g = (((long long)p.M * p.N + 3) / 4 + 255) / 256;
-    if (g > 2048) g = 2048;
+    long long g = (((long long)p.M * p.N + 3) / 4 + 15) / 16;         // 16 float4 elements per workgroup trip
+    if (g > 4096) g = 4096;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float*)p.ws, dw, p.M, p.N,
                        p.ldc, splitk, accumulate);
     hipError_t e = hipGetLastError();
