@@ -318,7 +318,7 @@ def roofline_from(timer, steps):
     breakdown = [{"kernel": a["name"] + ("[" + a["tag"] + "]" if a["tag"] else ""),
                   "ms_per_step": round(a["avg_ms"] * a["calls"] / steps, 4),
                   "calls_per_step": round(a["calls"] / steps, 2), "timing": a["timing"]}
-                 for a in rows[:12]]
+                 for a in rows[:int(os.environ.get("DLE_BENCH_BREAKDOWN", "12"))]]
     return r, breakdown
 
 

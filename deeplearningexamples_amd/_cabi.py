@@ -57,11 +57,9 @@ _SIGS = {
     "dle_bn_workspace_bytes": (c_i64, [c_i64, c_int]),
     "dle_bn_fwd_stats": (c_int, [c_void_p, c_i64, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_i64, c_int, c_void_p]),
-    "dle_bn_fwd_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int,
-                                 c_int, c_int, c_void_p]),
-    "dle_bn_bwd_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int,
-                                  c_int, c_void_p, c_i64, c_int, c_void_p]),
-    "dle_bn_bwd_apply": (c_int, [c_void_p] * 10 + [c_i64, c_int, c_int, c_void_p]),
+    "dle_bn_fwd_apply": (c_int, [c_void_p] * 8 + [c_i64, c_int, c_int, c_int, c_void_p]),
+    "dle_bn_bwd_reduce": (c_int, [c_void_p] * 8 + [c_i64, c_int, c_int, c_void_p, c_i64, c_int, c_void_p]),
+    "dle_bn_bwd_apply": (c_int, [c_void_p] * 11 + [c_i64, c_int, c_int, c_void_p]),
     "dle_maxpool_fwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "dle_maxpool_bwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "dle_avgpool_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),

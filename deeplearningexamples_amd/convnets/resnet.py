@@ -53,17 +53,19 @@ class ConvBN:
             t = t.view(n, h, w, self.cout)
         else:
             t = F.conv2d_fwd(x, self.w16, self.stride, self.pad)
-        y, mean, rstd = F.bn_fwd(t, self.bn.weight.data, self.bn.bias.data, self.bn.running_mean, self.bn.running_var,
-                                 eps=self.bn.eps, momentum=self.bn.momentum, residual=residual, relu=self.relu)
-        self.saved = (x, t, y, mean, rstd)
+        # the backward pass rebuilds the ReLU mask from 1 bit per element instead of re-reading y twice
+        y, mean, rstd, mask = F.bn_fwd(t, self.bn.weight.data, self.bn.bias.data, self.bn.running_mean,
+                                       self.bn.running_var, eps=self.bn.eps, momentum=self.bn.momentum,
+                                       residual=residual, relu=self.relu, want_mask=True)
+        self.saved = (x, t, mask, mean, rstd)
         return y
 
     def backward(self, dy, need_dx=True, dx_addend=None, want_skip_grad=False):
         """dy: gradient w.r.t. the unit's output.  Returns (dx or None, skip-branch gradient or None)."""
-        x, t, y, mean, rstd = self.saved
+        x, t, mask, mean, rstd = self.saved
         self.saved = None
-        gt, gskip = F.bn_bwd(dy, y if self.relu else None, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta,
-                             want_skip_grad=want_skip_grad)
+        gt, gskip = F.bn_bwd(dy, None, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta,
+                             want_skip_grad=want_skip_grad, relu_mask=mask if self.relu else None)
         n, h, w, c = x.shape
         if self.k == 1 and self.stride == 1:
             m = n * h * w

@@ -61,7 +61,8 @@ extern "C" int dle_nchw_to_nhwc(const float* x, void* y, int64_t N, int C, int64
 struct BnRedArgs {
   const unsigned short* x;
   const unsigned short* dy;
-  const unsigned short* y;      // post-activation output for the ReLU mask (NULL: no ReLU)
+  const unsigned short* y;      // post-activation output for the ReLU mask (NULL: no ReLU, or mask given)
+  const unsigned char* mask;    // bit-packed ReLU mask written by bn_fwd_apply (1 bit / element instead of 2 bytes)
   const float* mean;
   const float* rstd;
   float* partial;               // [groups][2][C]
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(BnRedArgs a) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) { mu[k] = a.mean[c0 + k]; rs[k] = a.rstd[c0 + k]; }
     }
-    auto accum = [&](ushort8_t xv, ushort8_t gv, ushort8_t yv) {
+    auto accum = [&](ushort8_t xv, ushort8_t gv, ushort8_t yv, unsigned bits) {
       float xf[8];
       unpack8<DT>(xv, xf);
       if (MODE == 0) {
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(BnRedArgs a) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           float g = gf[k];
-          if (a.y && !(yf[k] > 0.f)) g = 0.f;
+          if (a.mask ? !((bits >> k) & 1u) : (a.y && !(yf[k] > 0.f))) g = 0.f;
           s0[k] += g;
           s1[k] += g * (xf[k] - mu[k]) * rs[k];
         }
@@ -110,26 +111,31 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(BnRedArgs a) {
     long long r = r0 + rl;
     for (; r + (long long)(U - 1) * rstep < r1; r += (long long)U * rstep) {
       ushort8_t xv[U], gv[U], yv[U];
+      unsigned mb[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const long long o = (r + (long long)u * rstep) * a.C + c0;
         xv[u] = *(const ushort8_t*)(a.x + o);
+        mb[u] = 0;
         if (MODE == 1) {
           gv[u] = *(const ushort8_t*)(a.dy + o);
-          if (a.y) yv[u] = *(const ushort8_t*)(a.y + o);
+          if (a.mask) mb[u] = a.mask[o >> 3];
+          else if (a.y) yv[u] = *(const ushort8_t*)(a.y + o);
         }
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) accum(xv[u], gv[u], yv[u]);
+      for (int u = 0; u < U; ++u) accum(xv[u], gv[u], yv[u], mb[u]);
     }
     for (; r < r1; r += rstep) {
       const long long o = r * a.C + c0;
       ushort8_t gv = {}, yv = {};
+      unsigned mb = 0;
       if (MODE == 1) {
         gv = *(const ushort8_t*)(a.dy + o);
-        if (a.y) yv = *(const ushort8_t*)(a.y + o);
+        if (a.mask) mb = a.mask[o >> 3];
+        else if (a.y) yv = *(const ushort8_t*)(a.y + o);
       }
-      accum(*(const ushort8_t*)(a.x + o), gv, yv);
+      accum(*(const ushort8_t*)(a.x + o), gv, yv, mb);
     }
   }
 #pragma unroll
@@ -246,7 +252,7 @@ extern "C" int dle_bn_fwd_stats(const void* x, int64_t M, int C, float eps, floa
   int lpr, gx; long long rpb, gy;
   bn_reduce_geometry(M, C, lpr, gx, rpb, gy);
   DLE_CHECK_ARG(workspace_bytes >= gy * 2 * (long long)C * 4, "bn_fwd_stats: workspace too small");
-  BnRedArgs a = {(const unsigned short*)x, nullptr, nullptr, nullptr, nullptr, (float*)workspace, (long long)M, C, rpb, lpr};
+  BnRedArgs a = {(const unsigned short*)x, nullptr, nullptr, nullptr, nullptr, nullptr, (float*)workspace, (long long)M, C, rpb, lpr};
   dim3 grid(gx, (unsigned)gy), block(256);
   if (dtype == DLE_F16) hipLaunchKernelGGL((bn_reduce_kernel<DLE_F16, 0>), grid, block, 0, stream, a);
   else hipLaunchKernelGGL((bn_reduce_kernel<DLE_BF16, 0>), grid, block, 0, stream, a);
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
                                                        unsigned short* __restrict__ y, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, long long total8, int C8,
-                                                       int relu) {
+                                                       int relu, unsigned char* __restrict__ mask_out) {
   const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;
   const bool invariant = (stride % C8) == 0;
@@ -286,6 +292,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
       of[k] = v;
     }
     ((ushort8_t*)y)[i] = pack8<DT>(of);
+    if (mask_out) {                      // ReLU mask for the backward pass: 1 bit per element instead of re-reading y
+      unsigned bits = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) bits |= (of[k] > 0.f ? 1u : 0u) << k;
+      mask_out[i] = (unsigned char)bits;
+    }
   };
   long long i = first;
   if (invariant) {
@@ -313,7 +325,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
   }
 }
 
-extern "C" int dle_bn_fwd_apply(const void* x, const void* residual, void* y, const float* mean, const float* rstd,
+extern "C" int dle_bn_fwd_apply(const void* x, const void* residual, void* y, void* relu_mask, const float* mean, const float* rstd,
                                 const float* gamma, const float* beta, int64_t M, int C, int relu, int dtype,
                                 hipStream_t stream) {
   DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "bn_fwd_apply: 16-bit activations only");
@@ -322,14 +334,14 @@ extern "C" int dle_bn_fwd_apply(const void* x, const void* residual, void* y, co
   DLE_CHECK_ARG(x && y && mean && rstd && gamma && beta, "bn_fwd_apply: null pointer");
   const long long total8 = (long long)M * (C / 8);
   const int grid = cn_grid(total8, 256);
-  if (dtype == DLE_F16) hipLaunchKernelGGL(bn_apply_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)residual, (unsigned short*)y, mean, rstd, gamma, beta, total8, C / 8, relu);
-  else hipLaunchKernelGGL(bn_apply_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)residual, (unsigned short*)y, mean, rstd, gamma, beta, total8, C / 8, relu);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(bn_apply_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)residual, (unsigned short*)y, mean, rstd, gamma, beta, total8, C / 8, relu, (unsigned char*)relu_mask);
+  else hipLaunchKernelGGL(bn_apply_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)residual, (unsigned short*)y, mean, rstd, gamma, beta, total8, C / 8, relu, (unsigned char*)relu_mask);
   DLE_LAUNCH_CHECK();
   return 0;
 }
 
 // backward pass 1: dgamma / dbeta (fp32) with the ReLU mask taken from the saved output y (NULL: no ReLU)
-extern "C" int dle_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
+extern "C" int dle_bn_bwd_reduce(const void* dy, const void* y, const void* relu_mask, const void* x, const float* mean, const float* rstd,
                                  float* dgamma, float* dbeta, int64_t M, int C, int accumulate, void* workspace,
                                  int64_t workspace_bytes, int dtype, hipStream_t stream) {
   DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "bn_bwd_reduce: 16-bit activations only");
@@ -338,8 +350,8 @@ extern "C" int dle_bn_bwd_reduce(const void* dy, const void* y, const void* x, c
   int lpr, gx; long long rpb, gy;
   bn_reduce_geometry(M, C, lpr, gx, rpb, gy);
   DLE_CHECK_ARG(workspace_bytes >= gy * 2 * (long long)C * 4, "bn_bwd_reduce: workspace too small");
-  BnRedArgs a = {(const unsigned short*)x, (const unsigned short*)dy, (const unsigned short*)y, mean, rstd,
-                 (float*)workspace, (long long)M, C, rpb, lpr};
+  BnRedArgs a = {(const unsigned short*)x, (const unsigned short*)dy, (const unsigned short*)y,
+                 (const unsigned char*)relu_mask, mean, rstd, (float*)workspace, (long long)M, C, rpb, lpr};
   dim3 grid(gx, (unsigned)gy), block(256);
   if (dtype == DLE_F16) hipLaunchKernelGGL((bn_reduce_kernel<DLE_F16, 1>), grid, block, 0, stream, a);
   else hipLaunchKernelGGL((bn_reduce_kernel<DLE_BF16, 1>), grid, block, 0, stream, a);
@@ -355,6 +367,7 @@ extern "C" int dle_bn_bwd_reduce(const void* dy, const void* y, const void* x, c
 template <int DT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* __restrict__ dy,
                                                            const unsigned short* __restrict__ y,
+                                                           const unsigned char* __restrict__ mask,
                                                            const unsigned short* __restrict__ x,
                                                            unsigned short* __restrict__ dx,
                                                            unsigned short* __restrict__ g_out,
@@ -379,14 +392,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
     }
   };
   load((int)(first % C8) * 8);
-  auto one = [&](long long i, ushort8_t gv, ushort8_t xv, ushort8_t yv) {
+  auto one = [&](long long i, ushort8_t gv, ushort8_t xv, ushort8_t yv, unsigned bits) {
     float gf[8], xf[8], yf[8], of[8];
     unpack8<DT>(gv, gf);
     unpack8<DT>(xv, xf);
     if (y) unpack8<DT>(yv, yf);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      if (y && !(yf[k] > 0.f)) gf[k] = 0.f;
+      if (mask ? !((bits >> k) & 1u) : (y && !(yf[k] > 0.f))) gf[k] = 0.f;
       const float xh = (xf[k] - kmu[k]) * krs[k];
       of[k] = ka[k] * (gf[k] - kb[k] - xh * kg[k]);
     }
@@ -397,25 +410,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
   if (invariant) {
     for (; i + 2 * stride < total8; i += 3 * stride) {        // 3 trips = 6-9 independent 16-byte loads in flight
       ushort8_t gv[3], xv[3], yv[3];
+      unsigned mb[3];
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         gv[u] = ((const ushort8_t*)dy)[i + u * stride];
         xv[u] = ((const ushort8_t*)x)[i + u * stride];
-        if (y) yv[u] = ((const ushort8_t*)y)[i + u * stride];
+        mb[u] = 0;
+        if (mask) mb[u] = mask[i + u * stride];
+        else if (y) yv[u] = ((const ushort8_t*)y)[i + u * stride];
       }
 #pragma unroll
-      for (int u = 0; u < 3; ++u) one(i + u * stride, gv[u], xv[u], yv[u]);
+      for (int u = 0; u < 3; ++u) one(i + u * stride, gv[u], xv[u], yv[u], mb[u]);
     }
   }
   for (; i < total8; i += stride) {
     if (!invariant) load((int)(i % C8) * 8);
     ushort8_t yv = {};
-    if (y) yv = ((const ushort8_t*)y)[i];
-    one(i, ((const ushort8_t*)dy)[i], ((const ushort8_t*)x)[i], yv);
+    unsigned mb = 0;
+    if (mask) mb = mask[i];
+    else if (y) yv = ((const ushort8_t*)y)[i];
+    one(i, ((const ushort8_t*)dy)[i], ((const ushort8_t*)x)[i], yv, mb);
   }
 }
 
-extern "C" int dle_bn_bwd_apply(const void* dy, const void* y, const void* x, void* dx, void* g_out, const float* mean,
+extern "C" int dle_bn_bwd_apply(const void* dy, const void* y, const void* relu_mask, const void* x, void* dx, void* g_out, const float* mean,
                                 const float* rstd, const float* gamma, const float* dgamma, const float* dbeta,
                                 int64_t M, int C, int dtype, hipStream_t stream) {
   DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "bn_bwd_apply: 16-bit activations only");
@@ -423,8 +441,8 @@ extern "C" int dle_bn_bwd_apply(const void* dy, const void* y, const void* x, vo
   DLE_CHECK_ARG(dy && x && dx && mean && rstd && gamma && dgamma && dbeta, "bn_bwd_apply: null pointer");
   const long long total8 = (long long)M * (C / 8);
   const int grid = cn_grid(total8, 256);
-  if (dtype == DLE_F16) hipLaunchKernelGGL(bn_bwd_apply_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned short*)y, (const unsigned short*)x, (unsigned short*)dx, (unsigned short*)g_out, mean, rstd, gamma, dgamma, dbeta, total8, C / 8, 1.0f / (float)M);
-  else hipLaunchKernelGGL(bn_bwd_apply_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned short*)y, (const unsigned short*)x, (unsigned short*)dx, (unsigned short*)g_out, mean, rstd, gamma, dgamma, dbeta, total8, C / 8, 1.0f / (float)M);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(bn_bwd_apply_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned short*)y, (const unsigned char*)relu_mask, (const unsigned short*)x, (unsigned short*)dx, (unsigned short*)g_out, mean, rstd, gamma, dgamma, dbeta, total8, C / 8, 1.0f / (float)M);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned short*)y, (const unsigned char*)relu_mask, (const unsigned short*)x, (unsigned short*)dx, (unsigned short*)g_out, mean, rstd, gamma, dgamma, dbeta, total8, C / 8, 1.0f / (float)M);
   DLE_LAUNCH_CHECK();
   return 0;
 }

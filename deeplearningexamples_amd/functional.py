@@ -412,8 +412,9 @@ def _bn_ws(x2d):
 
 
 def bn_fwd(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, residual=None, relu=True,
-           out=None):
-    """Training-mode BatchNorm over the leading dims of NHWC x (+ residual, + ReLU).  -> (y, mean, rstd)."""
+           out=None, want_mask=False):
+    """Training-mode BatchNorm over the leading dims of NHWC x (+ residual, + ReLU).  -> (y, mean, rstd) or, with
+    want_mask (and relu), (y, mean, rstd, relu_mask): the bit-packed y > 0 mask the backward pass reads instead of y."""
     C.require_cuda(x, gamma, beta, running_mean, running_var, residual, out)
     c = x.shape[-1]
     m = x.numel() // c
@@ -425,26 +426,36 @@ def bn_fwd(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, moment
     C.call("dle_bn_fwd_stats", C.ptr(x), m, c, eps, momentum, C.ptr(mean), C.ptr(rstd), C.ptr(running_mean),
            C.ptr(running_var), C.ptr(ws), ws.numel() * 4, C.dt(x), C.stream())
     y = torch.empty_like(x) if out is None else out
-    C.annotate(bytes=float(x.numel()) * 2 * (3 if residual is not None else 2), tag="M%dxC%d%s" % (x.numel() // c, c, "+res" if residual is not None else ""))
-    C.call("dle_bn_fwd_apply", C.ptr(x), C.ptr(residual), C.ptr(y), C.ptr(mean), C.ptr(rstd), C.ptr(gamma),
+    mask = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device) if (want_mask and relu) else None
+    C.annotate(bytes=float(x.numel()) * (2 * (3 if residual is not None else 2) + (0.125 if mask is not None else 0)),
+               tag="M%dxC%d%s" % (x.numel() // c, c, "+res" if residual is not None else ""))
+    C.call("dle_bn_fwd_apply", C.ptr(x), C.ptr(residual), C.ptr(y), C.ptr(mask), C.ptr(mean), C.ptr(rstd), C.ptr(gamma),
            C.ptr(beta), m, c, int(relu), C.dt(x), C.stream())
+    if want_mask:
+        return y, mean, rstd, mask
     return y, mean, rstd
 
 
-def bn_bwd(dy, y, x, mean, rstd, gamma, dgamma, dbeta, want_skip_grad=False, dx_out=None):
-    """-> (dx, g) ; y = saved post-ReLU output (None when the BN had no ReLU); g = dy*(y>0) if requested."""
-    C.require_cuda(dy, y, x, mean, rstd, gamma, dgamma, dbeta)
+def bn_bwd(dy, y, x, mean, rstd, gamma, dgamma, dbeta, want_skip_grad=False, dx_out=None, relu_mask=None):
+    """-> (dx, g) ; y = saved post-ReLU output or relu_mask = its bit-packed y > 0 mask (both None when the BN had no
+    ReLU); g = dy*(y>0) if requested."""
+    C.require_cuda(dy, y, x, mean, rstd, gamma, dgamma, dbeta, relu_mask)
     c = x.shape[-1]
     m = x.numel() // c
     ws = _bn_ws(x.reshape(m, c))
-    C.annotate(bytes=float(x.numel()) * 2 * (3 if y is not None else 2), tag="M%dxC%d%s" % (x.numel() // c, c, "+relu" if y is not None else ""))
-    C.call("dle_bn_bwd_reduce", C.ptr(dy), C.ptr(y), C.ptr(x), C.ptr(mean), C.ptr(rstd), C.ptr(dgamma), C.ptr(dbeta),
-           m, c, 0, C.ptr(ws), ws.numel() * 4, C.dt(x), C.stream())
+    if relu_mask is not None:
+        y = None
+    act_bytes = 0.125 if relu_mask is not None else (2.0 if y is not None else 0.0)
+    relu_tag = "+relu" if (y is not None or relu_mask is not None) else ""
+    C.annotate(bytes=float(x.numel()) * (4 + act_bytes), tag="M%dxC%d%s" % (x.numel() // c, c, relu_tag))
+    C.call("dle_bn_bwd_reduce", C.ptr(dy), C.ptr(y), C.ptr(relu_mask), C.ptr(x), C.ptr(mean), C.ptr(rstd), C.ptr(dgamma),
+           C.ptr(dbeta), m, c, 0, C.ptr(ws), ws.numel() * 4, C.dt(x), C.stream())
     dx = torch.empty_like(x) if dx_out is None else dx_out
     g = torch.empty_like(x) if want_skip_grad else None
-    C.annotate(bytes=float(x.numel()) * 2 * ((4 if y is not None else 3) + int(want_skip_grad)), tag="M%dxC%d%s%s" % (x.numel() // c, c, "+relu" if y is not None else "", "+skip" if want_skip_grad else ""))
-    C.call("dle_bn_bwd_apply", C.ptr(dy), C.ptr(y), C.ptr(x), C.ptr(dx), C.ptr(g), C.ptr(mean), C.ptr(rstd),
-           C.ptr(gamma), C.ptr(dgamma), C.ptr(dbeta), m, c, C.dt(x), C.stream())
+    C.annotate(bytes=float(x.numel()) * (6 + act_bytes + 2 * int(want_skip_grad)),
+               tag="M%dxC%d%s%s" % (x.numel() // c, c, relu_tag, "+skip" if want_skip_grad else ""))
+    C.call("dle_bn_bwd_apply", C.ptr(dy), C.ptr(y), C.ptr(relu_mask), C.ptr(x), C.ptr(dx), C.ptr(g), C.ptr(mean),
+           C.ptr(rstd), C.ptr(gamma), C.ptr(dgamma), C.ptr(dbeta), m, c, C.dt(x), C.stream())
     return dx, g
 
 

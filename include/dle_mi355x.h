@@ -192,18 +192,21 @@ int64_t dle_bn_workspace_bytes(int64_t M, int C);
 int dle_bn_fwd_stats(const void* x, int64_t M, int C, float eps, float momentum, float* mean, float* rstd,
                      float* running_mean, float* running_var, void* workspace, int64_t workspace_bytes,
                      int dtype, hipStream_t stream);
-/* y = act((x - mean) * rstd * gamma + beta (+ residual)), act = ReLU when relu != 0 */
-int dle_bn_fwd_apply(const void* x, const void* residual, void* y, const float* mean, const float* rstd,
-                     const float* gamma, const float* beta, int64_t M, int C, int relu, int dtype,
-                     hipStream_t stream);
-/* g = dy * (y > 0) (y == NULL: g = dy);  dgamma = sum g*xhat, dbeta = sum g */
-int dle_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
-                      float* dgamma, float* dbeta, int64_t M, int C, int accumulate, void* workspace,
-                      int64_t workspace_bytes, int dtype, hipStream_t stream);
+/* y = act((x - mean) * rstd * gamma + beta (+ residual)), act = ReLU when relu != 0.
+ * relu_mask (optional, M*C/8 bytes): bit k of byte i = (y[8 i + k] > 0) -- the backward pass then reads 1 bit per
+ * element instead of the 2-byte output to rebuild the ReLU mask.                                                */
+int dle_bn_fwd_apply(const void* x, const void* residual, void* y, void* relu_mask, const float* mean,
+                     const float* rstd, const float* gamma, const float* beta, int64_t M, int C, int relu,
+                     int dtype, hipStream_t stream);
+/* g = dy * relu'(y): from relu_mask when given, else from y > 0 (both NULL: g = dy);
+ * dgamma = sum g*xhat, dbeta = sum g */
+int dle_bn_bwd_reduce(const void* dy, const void* y, const void* relu_mask, const void* x, const float* mean,
+                      const float* rstd, float* dgamma, float* dbeta, int64_t M, int C, int accumulate,
+                      void* workspace, int64_t workspace_bytes, int dtype, hipStream_t stream);
 /* dx = gamma*rstd*(g - dbeta/M - xhat*dgamma/M); g_out (optional) = g, the skip-branch gradient */
-int dle_bn_bwd_apply(const void* dy, const void* y, const void* x, void* dx, void* g_out, const float* mean,
-                     const float* rstd, const float* gamma, const float* dgamma, const float* dbeta, int64_t M,
-                     int C, int dtype, hipStream_t stream);
+int dle_bn_bwd_apply(const void* dy, const void* y, const void* relu_mask, const void* x, void* dx, void* g_out,
+                     const float* mean, const float* rstd, const float* gamma, const float* dgamma,
+                     const float* dbeta, int64_t M, int C, int dtype, hipStream_t stream);
 /* argmax: uint8 [N,P,Q,C] window-scan index of the first maximum (ATen tie rule) */
 int dle_maxpool_fwd(const void* x, void* y, void* argmax, int N, int H, int W, int C, int ksize, int stride,
                     int pad, int dtype, hipStream_t stream);

@@ -52,6 +52,20 @@ def test_batchnorm_fwd_bwd(cuda, dtype, shape, relu, res):
     assert (dx.double().cpu() - ref_dx).abs().max() <= 6 * eps * max(1.0, float(ref_dx.abs().max()))
     if res:
         assert (gskip.double().cpu() - _nhwc(rr.grad)).abs().max() <= 2 * eps * float(rr.grad.abs().max())
+    if relu:
+        # the bit-packed ReLU mask path (1 bit / element instead of re-reading y) gives the same gradients bit for bit
+        run_m2, run_v2 = torch.zeros(c, device=cuda), torch.ones(c, device=cuda)
+        y2, mean2, rstd2, mask = F.bn_fwd(_nhwc(x).to(cuda), gamma.to(cuda), beta.to(cuda), run_m2, run_v2,
+                                          residual=_nhwc(r).to(cuda) if res else None, relu=True, want_mask=True)
+        assert torch.equal(y2, y)
+        bits = ((mask.to(torch.int32).unsqueeze(1) >> torch.arange(8, device=cuda, dtype=torch.int32)) & 1).reshape(y.shape)
+        assert torch.equal(bits.bool(), y > 0)
+        dgamma2, dbeta2 = torch.empty(c, device=cuda), torch.empty(c, device=cuda)
+        dx2, gskip2 = F.bn_bwd(_nhwc(dy).to(cuda), None, _nhwc(x).to(cuda), mean, rstd, gamma.to(cuda), dgamma2, dbeta2,
+                               want_skip_grad=res, relu_mask=mask)
+        assert torch.equal(dx2, dx) and torch.equal(dgamma2, dgamma) and torch.equal(dbeta2, dbeta)
+        if res:
+            assert torch.equal(gskip2, gskip)
 
 
 @pytest.mark.parametrize("dtype", DT)
