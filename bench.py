@@ -267,6 +267,15 @@ class BertWorkload:
 
 WORKLOADS = {"dlrm": DlrmWorkload, "rn50": Rn50Workload, "bert": BertWorkload}
 
+REFERENCE_PUBLISHED = {
+    "rn50": {"value": 2470, "unit": "img/s", "hardware": "1x A100 80GB, mixed precision, bs 256",
+             "source": "PyTorch/Classification/ConvNets/resnet50v1.5/README.md:598-599"},
+    "bert": {"value": 580, "unit": "seq/s", "hardware": "1x A100 80GB, fp16, phase 1 seq 128",
+             "source": "PyTorch/LanguageModeling/BERT/README.md:813-814"},
+    "dlrm": {"value": 4.02e6, "unit": "samples/s", "hardware": "1x A100 80GB, AMP + CUDA graphs, bs 64k",
+             "source": "PyTorch/Recommendation/DLRM/README.md:923-924"},
+}
+
 
 def lookup_traffic(kernel_key):
     """HBM-side bytes per launch of `kernel_key` from the committed PMC passes (profiles/traffic.json, written by
@@ -376,11 +385,14 @@ def main():
                "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
                "scaling": wl.scaling, "vs_baseline": None, "dtype": wl.dtype_name(), "data": "synthetic",
-               "config": wl.config(), "final_loss": loss, "roofline": roof, "kernel_breakdown": breakdown}
+               "config": wl.config(), "final_loss": loss, "roofline": roof, "kernel_breakdown": breakdown,
+               # context only (other hardware, so vs_baseline stays null): BASELINE.md's published 1-GPU numbers
+               "reference_published": REFERENCE_PUBLISHED.get(wl.name)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()                      # rank 0 is still replaying kernels / timing the CPU baseline
         dist.destroy_process_group()
 
 
