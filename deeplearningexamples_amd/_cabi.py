@@ -64,6 +64,7 @@ _SIGS = {
     "dle_maxpool_bwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "dle_avgpool_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
     "dle_avgpool_bwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
+    "dle_upsample_zero": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dle_softmax_xent": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64,
                                  c_i64, c_float, c_i64, c_int, c_void_p]),
     "dle_gemm_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_int, c_int,

@@ -225,7 +225,7 @@ static int bn_reduce_geometry(long long M, int C, int& lpr, int& gx, long long& 
   lpr = 1;
   while (lpr < cols_v && lpr < 256) lpr <<= 1;
   gx = (cols_v + lpr - 1) / lpr;
-  long long want = 512 / gx;
+  long long want = 1024 / gx;                             // ~4 workgroups per CU
   if (want < 1) want = 1;
   rpb = (M + want - 1) / want;
   const long long min_rows = 8LL * (256 / lpr);
@@ -443,6 +443,42 @@ extern "C" int dle_bn_bwd_apply(const void* dy, const void* y, const void* relu_
   const int grid = cn_grid(total8, 256);
   if (dtype == DLE_F16) hipLaunchKernelGGL(bn_bwd_apply_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned short*)y, (const unsigned char*)relu_mask, (const unsigned short*)x, (unsigned short*)dx, (unsigned short*)g_out, mean, rstd, gamma, dgamma, dbeta, total8, C / 8, 1.0f / (float)M);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned short*)y, (const unsigned char*)relu_mask, (const unsigned short*)x, (unsigned short*)dx, (unsigned short*)g_out, mean, rstd, gamma, dgamma, dbeta, total8, C / 8, 1.0f / (float)M);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- zero-stuffed upsampling (1x1 stride-s data gradient)
+// y[n, h, w, :] = x[n, h/s, w/s, :] when h, w are multiples of s (and in range), else 0.  The data gradient of a
+// 1x1 stride-s convolution (the ResNet downsample branches) is a plain GEMM on the P x Q grid followed by this pass --
+// the gather-form implicit GEMM spends 3/4 of its tiles on rows that are identically zero.
+template <int DT>
+__global__ __launch_bounds__(256) void upsample_zero_kernel(const unsigned short* __restrict__ x,
+                                                            unsigned short* __restrict__ y, long long total8, int H,
+                                                            int W, int P, int Q, int C8, int stride) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
+    const long long pix = i / C8;
+    const int c = (int)(i - pix * C8);
+    const int w = (int)(pix % W);
+    const long long t = pix / W;
+    const int h = (int)(t % H);
+    const long long n = t / H;
+    ushort8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int p = h / stride, q = w / stride;
+    if (p * stride == h && q * stride == w && p < P && q < Q) v = ((const ushort8_t*)x)[((n * P + p) * Q + q) * C8 + c];
+    ((ushort8_t*)y)[i] = v;
+  }
+}
+
+extern "C" int dle_upsample_zero(const void* x, void* y, int64_t N, int P, int Q, int H, int W, int C, int stride,
+                                 int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "upsample_zero: 16-bit activations only");
+  DLE_CHECK_ARG(N >= 0 && P > 0 && Q > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && stride >= 1, "upsample_zero: bad shape");
+  if (N == 0) return 0;
+  DLE_CHECK_ARG(x && y, "upsample_zero: null pointer");
+  const long long total8 = (long long)N * H * W * (C / 8);
+  const int grid = cn_grid(total8, 256, 4096);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(upsample_zero_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, total8, H, W, P, Q, C / 8, stride);
+  else hipLaunchKernelGGL(upsample_zero_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, total8, H, W, P, Q, C / 8, stride);
   DLE_LAUNCH_CHECK();
   return 0;
 }

@@ -363,6 +363,14 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, addend=None, out=None):
         out = torch.empty((n, h, wd, c), dtype=dy.dtype, device=dy.device)
     if addend is not None and (addend.shape != out.shape or not addend.is_contiguous() or addend.dtype != dy.dtype):
         raise ValueError("conv2d_dgrad: addend must match dx")
+    if r == 1 and s == 1 and pad == 0 and stride > 1 and addend is None and c % 8 == 0:
+        # 1x1 stride-s (downsample branch): plain GEMM on the P x Q grid, then zero-stuffing -- the gather form would
+        # run 1 - 1/s^2 of its tiles on rows that are identically zero
+        m = n * p * q
+        compact = gemm(dy.view(m, ko), w.view(ko, c), m, c, ko, True, False)
+        C.annotate(bytes=float(out.numel() + compact.numel()) * 2, tag="N%dx%dx%dxC%d s%d" % (n, h, wd, c, stride))
+        C.call("dle_upsample_zero", C.ptr(compact), C.ptr(out), n, p, q, h, wd, c, stride, C.dt(dy), C.stream())
+        return out
     C.annotate(flops=2.0 * n * p * q * ko * r * s * c, tag="dgrad %dx%dx%dx%d k%d %dx%d s%d" % (n, h, wd, c, ko, r, s, stride),
                bytes=float(dy.numel() + w.numel() + out.numel()) * 2)
     C.call("dle_conv2d_dgrad", C.ptr(dy), C.ptr(w), C.ptr(out), C.ptr(addend), n, h, wd, c, ko, r, s, stride, pad,

@@ -214,6 +214,10 @@ int dle_maxpool_bwd(const void* dy, const void* argmax, void* dx, int N, int H, 
                     int stride, int pad, int dtype, hipStream_t stream);
 int dle_avgpool_fwd(const void* x, void* y, int64_t N, int HW, int C, int dtype, hipStream_t stream);
 int dle_avgpool_bwd(const void* dy, void* dx, int64_t N, int HW, int C, int dtype, hipStream_t stream);
+/* y[n,h,w,:] = x[n,h/s,w/s,:] where h, w are multiples of s, else 0: with a plain GEMM on the P x Q grid this is the
+ * data gradient of a 1x1 stride-s convolution (ResNet downsample branches, models/resnet.py:150-158)           */
+int dle_upsample_zero(const void* x, void* y, int64_t N, int P, int Q, int H, int W, int C, int stride, int dtype,
+                      hipStream_t stream);
 /* loss_out[0] = mean over rows with target != ignore_index of (1-s)*nll + s*(lse - mean logits);
  * dlogits (optional, dlogits_dtype, row stride ld_out) = d loss / d logits * (*grad_scale_dev).
  * scratch: one int32 device word.                                                                           */

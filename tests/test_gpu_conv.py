@@ -11,7 +11,7 @@ GEOMS = [
     (2, 8, 8, 64, 64, 1, 1, 0), (2, 8, 8, 64, 256, 1, 1, 0), (3, 9, 7, 64, 64, 3, 1, 1),
     (2, 14, 14, 128, 128, 3, 2, 1), (2, 14, 14, 256, 512, 1, 2, 0), (1, 15, 15, 64, 96, 3, 2, 1),
     (2, 32, 32, 8, 64, 7, 2, 3), (4, 7, 7, 512, 512, 3, 1, 1), (2, 7, 7, 2048, 512, 1, 1, 0),
-    (5, 6, 10, 72, 40, 3, 1, 1),
+    (5, 6, 10, 72, 40, 3, 1, 1), (1, 15, 15, 64, 96, 1, 2, 0), (3, 8, 12, 128, 64, 1, 2, 0),
 ]
 
 
