@@ -186,7 +186,7 @@ struct Loader {
         }
       }
     }
-    tap_uniform = (MODE == 2 && (cg.C & 63) == 0) || (MODE == 4 && (cg.Ko & 63) == 0 && cg.stride == 1) ||
+    tap_uniform = (MODE == 2 && (cg.C & 63) == 0) || (MODE == 4 && (cg.Ko & 63) == 0) ||
                   (MODE == 5 && (cg.Ko & 63) == 0);
     if (MODE == 2 || MODE == 4 || MODE == 5) {
 #pragma unroll
@@ -222,7 +222,15 @@ struct Loader {
           ok = ok && h >= 0 && h < cg.H && w >= 0 && w < cg.W;
         } else if (MODE == 4) {
           const int hp = a0[j] - r, wp = a1[j] - s2;
-          ok = ok && hp >= 0 && wp >= 0 && hp < cg.P && wp < cg.Q;
+          if (cg.stride == 1) {
+            ok = ok && hp >= 0 && wp >= 0 && hp < cg.P && wp < cg.Q;
+          } else {                                   // strided forward conv: only every stride-th (h, w) has a source pixel
+            const int pp = fd_div(hp, cg.dStride), qq = fd_div(wp, cg.dStride);
+            ok = ok && hp >= 0 && wp >= 0 && pp * cg.stride == hp && qq * cg.stride == wp && pp < cg.P && qq < cg.Q;
+            const unsigned o2 = (unsigned)(((((int)off[j] * cg.P + pp) * cg.Q + qq) * cg.Ko + c0 + kin[j]) * 2);
+            dma16(rs, tile + (wave * NP + j) * 512, ok ? o2 : OOB_OFF);
+            continue;
+          }
         }
         dma16(rs, tile + (wave * NP + j) * 512, ok ? fo[j] + delta : OOB_OFF);
       }
