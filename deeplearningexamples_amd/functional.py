@@ -3,6 +3,8 @@
 Every function here launches hand-written HIP kernels from libdle_mi355x.so on the current
 torch stream; there is no eager fallback.  torch is used for memory, streams and autograd plumbing.
 """
+import os
+
 import torch
 
 from . import _cabi as C
@@ -272,6 +274,7 @@ def colsum(x, out=None, accumulate=False):
 def pick_splitk(m_out, n_out, k, target_blocks=512):
     """Split the contraction so that a skinny wgrad still fills 256 CUs (K tiles of 64)."""
     ktiles = (k + 63) // 64
+    target_blocks = int(os.environ.get("DLE_SPLITK_TARGET", target_blocks))      # tuning knob (tools/, not the product default)
     tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
     s = max(1, min(ktiles, target_blocks // max(tiles, 1)))
     return s
