@@ -152,3 +152,32 @@ def test_dropout_entry_points(cuda):
     assert torch.equal(m3, m)
     y0, m0 = F.dropout_fwd(x, 0.0, 7, 1)
     assert torch.equal(y0, x) and int(m0.min()) == 255
+
+
+def test_dropout_masks_bit_exact_vs_philox_oracle(cuda):
+    """The keep masks of all three dropout entry points equal the KAT-pinned CPU Philox restatement bit for bit
+    (integer work: bit-exact), including 64-bit seeds / offsets and the chunk numbering of the fused kernels."""
+    from deeplearningexamples_amd import functional as F
+    from oracle import philox_oracle as P
+    seed, off = 0x9E3779B97F4A7C15, (1 << 33) + 5
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(512, 256, generator=g).to(torch.bfloat16).to(cuda)
+    y, m = F.dropout_fwd(x, 0.1, seed, off)
+    keep = F.unpack_dropout_mask(m, x.shape).cpu().numpy()
+    ref = P.keep_mask(x.numel(), 0.1, seed, off).reshape(x.shape)
+    assert np.array_equal(keep, ref)
+    exp = torch.where(torch.from_numpy(ref).to(cuda), x.float() * float(P.inv_keep(0.1)), torch.zeros((), device=cuda))
+    assert torch.equal(y, exp.to(torch.bfloat16))
+    res = torch.randn(512, 256, generator=g).to(torch.bfloat16).to(cuda)
+    gamma, beta = torch.ones(256, device=cuda), torch.zeros(256, device=cuda)
+    _, z, _, _, m2 = F.dropout_add_layernorm_fwd(x, gamma, beta, res, 0.25, seed + 1, off + 1)
+    ref2 = P.keep_mask(x.numel(), 0.25, seed + 1, off + 1).reshape(x.shape)
+    assert np.array_equal(F.unpack_dropout_mask(m2, x.shape).cpu().numpy(), ref2)
+    zd = torch.where(torch.from_numpy(ref2).to(cuda), x.float() * float(P.inv_keep(0.25)), torch.zeros((), device=cuda))
+    assert torch.equal(z, (zd.to(torch.bfloat16).float() + res.float()).to(torch.bfloat16))
+    scores = torch.randn(6, 128, 128, generator=g).to(torch.bfloat16).to(cuda)
+    madd = torch.zeros(2, 128, device=cuda)
+    dropped, m3 = F.softmax_dropout_fwd_(scores, madd, 3 * 128, 0.125, 0.1, 11, 12)
+    ref3 = P.keep_mask(scores.numel(), 0.1, 11, 12).reshape(scores.shape)
+    assert np.array_equal(F.unpack_dropout_mask(m3, scores.shape).cpu().numpy(), ref3)
+    assert torch.equal(dropped != 0, torch.from_numpy(ref3).to(cuda) & (scores != 0))
