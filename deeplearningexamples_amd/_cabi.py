@@ -57,6 +57,9 @@ _SIGS = {
     "dle_bn_workspace_bytes": (c_i64, [c_i64, c_int]),
     "dle_bn_fwd_stats": (c_int, [c_void_p, c_i64, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_i64, c_int, c_void_p]),
+    "dle_conv2d_fwd_colstats": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_i64, c_void_p, c_void_p]),
+    "dle_bn_stats_from_partials": (c_int, [c_void_p, c_int, c_i64, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_i64, c_void_p]),
     "dle_bn_fwd_apply": (c_int, [c_void_p] * 8 + [c_i64, c_int, c_int, c_int, c_void_p]),
     "dle_bn_bwd_reduce": (c_int, [c_void_p] * 8 + [c_i64, c_int, c_int, c_void_p, c_i64, c_int, c_void_p]),
     "dle_bn_bwd_apply": (c_int, [c_void_p] * 11 + [c_i64, c_int, c_int, c_void_p]),

@@ -47,16 +47,12 @@ class ConvBN:
         self.saved = None
 
     def forward(self, x, residual=None):
-        n, h, w, c = x.shape
-        if self.k == 1 and self.stride == 1:
-            t = F.gemm(x.view(-1, c), self.w16.view(self.cout, c), n * h * w, self.cout, c, True, True)
-            t = t.view(n, h, w, self.cout)
-        else:
-            t = F.conv2d_fwd(x, self.w16, self.stride, self.pad)
-        # the backward pass rebuilds the ReLU mask from 1 bit per element instead of re-reading y twice
-        y, mean, rstd, mask = F.bn_fwd(t, self.bn.weight.data, self.bn.bias.data, self.bn.running_mean,
-                                       self.bn.running_var, eps=self.bn.eps, momentum=self.bn.momentum,
-                                       residual=residual, relu=self.relu, want_mask=True)
+        # conv + batch statistics in one pass over the activation (the statistics come out of the convolution
+        # epilogue), then normalise + residual + ReLU; the backward pass rebuilds the ReLU mask from 1 bit per element
+        t, mean, rstd = F.conv2d_fwd_bnstats(x, self.w16, self.stride, self.pad, self.bn.running_mean,
+                                             self.bn.running_var, eps=self.bn.eps, momentum=self.bn.momentum)
+        y, mask = F.bn_fwd_apply(t, mean, rstd, self.bn.weight.data, self.bn.bias.data, residual=residual,
+                                 relu=self.relu, want_mask=True)
         self.saved = (x, t, mask, mean, rstd)
         return y
 

@@ -220,6 +220,62 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float* __restr
   }
 }
 
+// level 1 of the statistics finish when the partials come from a convolution epilogue (one group per 128-row tile:
+// up to 25088 groups): 32 x (C/16) workgroups fold the groups g = y, y + 32, ... into out[y][2][C]; the existing
+// finishing kernel then folds those 32.  Fixed summation order: deterministic.
+__global__ __launch_bounds__(256) void bn_partial_fold_kernel(const float* __restrict__ partial, int groups, int C,
+                                                              float* __restrict__ out) {
+  __shared__ float red[2][256];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    int g = blockIdx.y + 32 * sl;
+    for (; g + 3 * 512 < groups; g += 4 * 512) {
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = partial[((long long)(g + 512 * u) * 2) * C + c];
+        b[u] = partial[((long long)(g + 512 * u) * 2 + 1) * C + c];
+      }
+      s0 += (a[0] + a[1]) + (a[2] + a[3]);
+      s1 += (b[0] + b[1]) + (b[2] + b[3]);
+    }
+    for (; g < groups; g += 512) { s0 += partial[((long long)g * 2) * C + c]; s1 += partial[((long long)g * 2 + 1) * C + c]; }
+  }
+  red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { t0 += red[0][q * 16 + cl]; t1 += red[1][q * 16 + cl]; }
+    out[((long long)blockIdx.y * 2) * C + c] = t0;
+    out[((long long)blockIdx.y * 2 + 1) * C + c] = t1;
+  }
+}
+
+// mean / rstd / running statistics from per-group column sums [groups][2][C] (dle_conv2d_fwd_colstats);
+// workspace: >= 32 * 2 * C floats.
+extern "C" int dle_bn_stats_from_partials(const float* partial, int groups, int64_t M, int C, float eps, float momentum,
+                                          float* mean, float* rstd, float* running_mean, float* running_var,
+                                          void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  DLE_CHECK_ARG(partial && mean && rstd && workspace && groups > 0 && M > 0 && C > 0, "bn_stats_from_partials: bad arguments");
+  DLE_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_stats_from_partials: running stats come in pairs");
+  DLE_CHECK_ARG(workspace_bytes >= 32LL * 2 * C * 4, "bn_stats_from_partials: workspace too small");
+  const float* src = partial;
+  int g = groups;
+  if (groups > 32) {
+    hipLaunchKernelGGL(bn_partial_fold_kernel, dim3((C + 15) / 16, 32), dim3(256), 0, stream, partial, groups, C, (float*)workspace);
+    DLE_LAUNCH_CHECK();
+    src = (const float*)workspace;
+    g = 32;
+  }
+  hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, src, g, C, (long long)M, eps, momentum,
+                     mean, rstd, running_mean, running_var);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
 static int bn_reduce_geometry(long long M, int C, int& lpr, int& gx, long long& rpb, long long& gy) {
   const int cols_v = C / 8;
   lpr = 1;

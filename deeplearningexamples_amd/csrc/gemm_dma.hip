@@ -90,6 +90,8 @@ struct Gemm2Args {
   // base + zo * stride_outer + zi * stride_inner (elements) -- e.g. (sequence, head) slices of a [T, 3H] buffer
   int batch_inner, batch_count;
   int debug_skip;        // reserved (profiling ablations)
+  float* stats;          // per-tile-row column sums of the ROUNDED output: [tiles_m][2][N] (sum, sum of squares); NULL: off
+  int force_small;       // keep the 128x128 tile (stats layout is indexed by 128-row tiles)
   long long sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
 };
 
@@ -619,6 +621,9 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
 #pragma unroll
     for (int r = 0; r < 4; ++r) { fbias[r] = b0[r]; fbias[4 + r] = b1[r]; }
   }
+  float st0[8], st1[8];                  // column sums / sums of squares over this thread's rows (p.stats only)
+#pragma unroll
+  for (int r = 0; r < 8; ++r) { st0[r] = 0.f; st1[r] = 0.f; }
   auto fast_pass = [&](auto ACTC, int half) __attribute__((always_inline)) {
     constexpr int act = decltype(ACTC)::value;
     constexpr bool needs_src = act == ACT_RELU_BWD || act == ACT_ADD || act == ACT_GELU_BWD || act == ACT_TANH_BWD;
@@ -667,7 +672,14 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
           }
         }
       }
-      *(ushort8_t*)(c + it * step) = pack8<DT>(v);
+      const ushort8_t ov = pack8<DT>(v);
+      *(ushort8_t*)(c + it * step) = ov;
+      if (!BIG && act == ACT_NONE && p.stats) {          // BatchNorm statistics of what the next pass will read
+        float vr[8];
+        unpack8<DT>(ov, vr);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { st0[r] += vr[r]; st1[r] += vr[r] * vr[r]; }
+      }
     }
   };
   __builtin_amdgcn_s_waitcnt(0x0F70);    // the zero-fill DMA issued under the last K tile has landed
@@ -737,6 +749,25 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
     epi_store8<DT>(p, v, m, n, nval, vec16, blockIdx.y);
   }
   }
+  if (!BIG && p.stats && fast) {
+    // the 16 threads that share a column group meet in LDS; one plain store per (tile row, statistic, column):
+    // deterministic, no atomics -- dle_bn_stats_from_partials sums the tile rows in a fixed order
+    lds_barrier();
+    float* red = epi;                                    // [2][RPI][TN]
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      red[(0 * RPI + f_ml0) * TN + f_nl + r] = st0[r];
+      red[(1 * RPI + f_ml0) * TN + f_nl + r] = st1[r];
+    }
+    lds_barrier();
+    for (int cidx = tid; cidx < 2 * TN; cidx += NT) {
+      const int which = cidx / TN, col = cidx - which * TN;
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < RPI; ++q) t += red[(which * RPI + q) * TN + col];
+      if (n0 + col < p.N) p.stats[((long long)tm * 2 + which) * p.N + n0 + col] = t;
+    }
+  }
 }
 
 // One launcher for every entry point.  modes: (A_MODE, B_MODE) in {(0,0),(0,1),(1,1),(2,0),(4,5),(1,3)}.
@@ -759,7 +790,7 @@ static int launch_gemm(const Gemm2Args& p_in, int in_dtype, int amode, int bmode
   const bool fits = amode <= 1 && bmode <= 1 && p.M >= 256 && p.N >= 256 &&
                     p.lda * 512 <= 0x7FFFFFFFLL && p.ldb * 512 <= 0x7FFFFFFFLL;
   // (split-K weight gradients stay on the 128x128 tile: measured faster there -- more, smaller slabs in flight)
-  const bool want = big_mode >= 1 || (big_mode != 0 && p.splitk == 1 && kt_per_item >= 4 && tiles_big * (batch > 0 ? batch : 1) >= 160);
+  const bool want = !p.force_small && (big_mode >= 1 || (big_mode != 0 && p.splitk == 1 && kt_per_item >= 4 && tiles_big * (batch > 0 ? batch : 1) >= 160));
   if (fits && want) {
     dim3 grid((unsigned)tiles_big, p.splitk, batch > 0 ? batch : 1), block(512);
     const size_t lds_big = 2 * (256 * BK + 256 * BK) * 2;
@@ -852,7 +883,7 @@ extern "C" int dle_gemm_dma_try(const void* A, const void* B, void* C, void* aux
   if (M < 1 || N < 8 || K < 8) return 0;
   // 32-bit byte offsets inside one operand tile panel
   if ((long long)lda * (a_kc ? BM : BK) * 2 > 0x7FFFFFFFLL || (long long)ldb * (b_kc ? BN : BK) * 2 > 0x7FFFFFFFLL) return 0;
-  Gemm2Args p;
+  Gemm2Args p = {};
   p.A = (const unsigned short*)A; p.B = (const unsigned short*)B; p.C = C; p.aux = aux; p.bias = bias;
   p.mask_src = (const unsigned short*)mask_src;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -918,6 +949,32 @@ extern "C" int dle_conv2d_fwd(const void* x, const void* w, void* y, const float
   p.out_dtype = out_dtype; p.act = act; p.splitk = 1; p.accumulate = 0; p.alpha = 1.f;
   p.cg = make_geom(H, W, C, P, Q, R, S, stride, pad, Ko);
   return conv_launch(p, dtype, 2, 0, stream);
+}
+
+// dle_conv2d_fwd (no bias / activation) that ALSO leaves, per 128-row tile of the [N*P*Q, Ko] output, the column sums
+// and sums of squares of the ROUNDED output in col_partial[tile_row][2][Ko] -- the BatchNorm that follows gets its
+// batch statistics without re-reading the activation (dle_bn_stats_from_partials).  1x1 stride-1 convolutions run as
+// plain matrices.  Returns the number of tile rows through *groups.
+extern "C" int dle_conv2d_fwd_colstats(const void* x, const void* w, void* y, int N, int H, int W, int C, int Ko, int R,
+                                       int S, int stride, int pad, int dtype, float* col_partial,
+                                       int64_t col_partial_bytes, int* groups, hipStream_t stream) {
+  const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+  if (int rc = conv_check("conv2d_fwd_colstats", N, H, W, C, Ko, R, S, stride, pad, P, Q, dtype)) return rc;
+  DLE_CHECK_ARG(x && w && y && col_partial && groups, "conv2d_fwd_colstats: null pointer");
+  DLE_CHECK_ARG((((uintptr_t)y) & 15) == 0, "conv2d_fwd_colstats: output must be 16-byte aligned");
+  const long long M = (long long)N * P * Q;
+  const int g = (int)((M + BM - 1) / BM);
+  DLE_CHECK_ARG(col_partial_bytes >= (long long)g * 2 * Ko * 4, "conv2d_fwd_colstats: partial buffer too small (%lld tile rows)", (long long)g);
+  *groups = g;
+  Gemm2Args p = {};
+  p.A = (const unsigned short*)x; p.B = (const unsigned short*)w; p.C = y;
+  p.M = (int)M; p.N = Ko; p.K = R * S * C; p.ldb = (long long)R * S * C; p.ldc = Ko;
+  p.out_dtype = dtype; p.act = ACT_NONE; p.splitk = 1; p.accumulate = 0; p.alpha = 1.f;
+  p.stats = col_partial; p.force_small = 1;
+  const bool plain = R == 1 && S == 1 && stride == 1 && pad == 0;
+  p.lda = plain ? C : 0;
+  p.cg = make_geom(H, W, C, P, Q, R, S, stride, pad, Ko);
+  return conv_launch(p, dtype, plain ? 0 : 2, 0, stream);
 }
 
 // dx[N,H,W,C] = conv_transpose(dy[N,P,Q,Ko], w[Ko,R,S,C]) (+ addend[N,H,W,C] when non-NULL)

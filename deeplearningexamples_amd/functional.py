@@ -447,6 +447,48 @@ def bn_fwd(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, moment
     return y, mean, rstd
 
 
+def conv2d_fwd_bnstats(x, w, stride=1, pad=0, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+    """conv (no bias / activation) + the training-mode BatchNorm statistics of its output in ONE pass over the
+    activation: the convolution epilogue leaves per-tile column sums, a tiny deterministic fold turns them into
+    mean / rstd / running stats.  x [N,H,W,C], w [Ko,R,S,C] -> (y [N,P,Q,Ko], mean [Ko], rstd [Ko])."""
+    C.require_cuda(x, w, running_mean, running_var)
+    n, h, wd, c = x.shape
+    ko, r, s, c2 = w.shape
+    if c2 != c or not x.is_contiguous() or not w.is_contiguous() or x.dtype != w.dtype:
+        raise ValueError("conv2d_fwd_bnstats: x must be NHWC-contiguous and w KRSC-contiguous with matching C/dtype")
+    p, q = _conv_out(h, wd, r, s, stride, pad)
+    m = n * p * q
+    y = torch.empty((n, p, q, ko), dtype=x.dtype, device=x.device)
+    groups = (m + 127) // 128
+    ws = splitk_workspace(x.device, (groups + 32) * 2 * ko * 4)
+    part, fold = ws[:groups * 2 * ko], ws[groups * 2 * ko:(groups + 32) * 2 * ko]
+    import ctypes
+    g_out = ctypes.c_int(0)
+    C.annotate(flops=2.0 * m * ko * r * s * c, tag="fwd+stats %dx%dx%dx%d k%d %dx%d s%d" % (n, h, wd, c, ko, r, s, stride),
+               bytes=float(x.numel() + w.numel() + y.numel()) * 2)
+    C.call("dle_conv2d_fwd_colstats", C.ptr(x), C.ptr(w), C.ptr(y), n, h, wd, c, ko, r, s, stride, pad, C.dt(x),
+           C.ptr(part), part.numel() * 4, ctypes.byref(g_out), C.stream())
+    mean = torch.empty(ko, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(ko, dtype=torch.float32, device=x.device)
+    C.call("dle_bn_stats_from_partials", C.ptr(part), g_out.value, m, ko, float(eps), float(momentum), C.ptr(mean),
+           C.ptr(rstd), C.ptr(running_mean), C.ptr(running_var), C.ptr(fold), fold.numel() * 4, C.stream())
+    return y, mean, rstd
+
+
+def bn_fwd_apply(x, mean, rstd, gamma, beta, residual=None, relu=True, want_mask=False):
+    """y = act((x - mean) * rstd * gamma + beta (+ residual)) with given statistics -> (y, relu_mask or None)."""
+    C.require_cuda(x, mean, rstd, gamma, beta, residual)
+    c = x.shape[-1]
+    m = x.numel() // c
+    y = torch.empty_like(x)
+    mask = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device) if (want_mask and relu) else None
+    C.annotate(bytes=float(x.numel()) * (2 * (3 if residual is not None else 2) + (0.125 if mask is not None else 0)),
+               tag="M%dxC%d%s" % (m, c, "+res" if residual is not None else ""))
+    C.call("dle_bn_fwd_apply", C.ptr(x), C.ptr(residual), C.ptr(y), C.ptr(mask), C.ptr(mean), C.ptr(rstd), C.ptr(gamma),
+           C.ptr(beta), m, c, int(relu), C.dt(x), C.stream())
+    return y, mask
+
+
 def bn_bwd(dy, y, x, mean, rstd, gamma, dgamma, dbeta, want_skip_grad=False, dx_out=None, relu_mask=None):
     """-> (dx, g) ; y = saved post-ReLU output or relu_mask = its bit-packed y > 0 mask (both None when the BN had no
     ReLU); g = dy*(y>0) if requested."""

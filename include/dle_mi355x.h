@@ -192,6 +192,16 @@ int64_t dle_bn_workspace_bytes(int64_t M, int C);
 int dle_bn_fwd_stats(const void* x, int64_t M, int C, float eps, float momentum, float* mean, float* rstd,
                      float* running_mean, float* running_var, void* workspace, int64_t workspace_bytes,
                      int dtype, hipStream_t stream);
+/* Batch statistics without re-reading the activation: dle_conv2d_fwd_colstats is dle_conv2d_fwd (no bias / act) whose
+ * epilogue also leaves per-128-row-tile column sums of the rounded output in col_partial[groups][2][Ko]
+ * (>= ceil(N*P*Q / 128) * 2 * Ko floats; *groups receives the count); dle_bn_stats_from_partials folds them (fixed
+ * order, deterministic) into mean / rstd / running stats exactly like dle_bn_fwd_stats.  workspace: >= 64*C floats. */
+int dle_conv2d_fwd_colstats(const void* x, const void* w, void* y, int N, int H, int W, int C, int Ko, int R, int S,
+                            int stride, int pad, int dtype, float* col_partial, int64_t col_partial_bytes,
+                            int* groups, hipStream_t stream);
+int dle_bn_stats_from_partials(const float* partial, int groups, int64_t M, int C, float eps, float momentum,
+                               float* mean, float* rstd, float* running_mean, float* running_var, void* workspace,
+                               int64_t workspace_bytes, hipStream_t stream);
 /* y = act((x - mean) * rstd * gamma + beta (+ residual)), act = ReLU when relu != 0.
  * relu_mask (optional, M*C/8 bytes): bit k of byte i = (y[8 i + k] > 0) -- the backward pass then reads 1 bit per
  * element instead of the 2-byte output to rebuild the ReLU mask.                                                */

@@ -38,6 +38,16 @@ def test_conv_fwd_dgrad_wgrad(cuda, geom, dtype):
 
     yh = F.conv2d_fwd(x_nhwc, w_krsc, stride, pad)
     close(yh.permute(0, 3, 1, 2), y.detach(), "fwd", float(y.abs().max()))
+    # conv + BatchNorm statistics from the convolution epilogue == conv, then the separate statistics pass
+    rm1, rv1 = torch.zeros(ko, device=cuda), torch.ones(ko, device=cuda)
+    rm2, rv2 = torch.zeros(ko, device=cuda), torch.ones(ko, device=cuda)
+    yf, mean_f, rstd_f = F.conv2d_fwd_bnstats(x_nhwc, w_krsc, stride, pad, rm1, rv1)
+    assert torch.equal(yf, yh)
+    _, mean_s, rstd_s = F.bn_fwd(yh, torch.ones(ko, device=cuda), torch.zeros(ko, device=cuda), rm2, rv2, relu=False)
+    np.testing.assert_allclose(mean_f.cpu().numpy(), mean_s.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rstd_f.cpu().numpy(), rstd_s.cpu().numpy(), rtol=1e-4)
+    np.testing.assert_allclose(rv1.cpu().numpy(), rv2.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(rm1.cpu().numpy(), rm2.cpu().numpy(), rtol=1e-4, atol=1e-6)
     dxh = F.conv2d_dgrad(dy_nhwc, w_krsc, (h, w), stride, pad)
     close(dxh.permute(0, 3, 1, 2), xd.grad, "dgrad", float(xd.grad.abs().max()) + 1e-3)
     add = (torch.randn(n, h, w, c, generator=g)).to(dtype).to(cuda)
