@@ -33,3 +33,37 @@ def test_product_path_fails_loudly_without_gpu_tensor():
     from deeplearningexamples_amd import functional as F
     with pytest.raises(RuntimeError):
         F.dot_interact_fwd(torch.zeros(2, 27, 128, dtype=torch.float16))
+
+
+def test_ctypes_signatures_match_header_types():
+    """Every ctypes signature in _cabi._SIGS has the arity and the per-argument type class of its declaration in
+    include/dle_mi355x.h (a mismatch is undefined behaviour at call time, not an exception)."""
+    import ctypes as ct
+    from deeplearningexamples_amd import _cabi
+    src = open(os.path.join(ROOT, "include", "dle_mi355x.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    decls = re.findall(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(dle_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src)
+    assert len(decls) >= 55
+
+    def klass(ctype_text):
+        t = ctype_text.strip()
+        t = re.sub(r"\b[A-Za-z_][A-Za-z0-9_]*$", "", t).strip() if not t.endswith("*") and " " in t else t
+        t = t.replace("const ", "").strip()
+        if t.endswith("*") or t == "hipStream_t":
+            return "ptr"
+        return {"int": "int", "int64_t": "i64", "uint64_t": "u64", "float": "float", "void": "void"}[t]
+
+    pyk = {ct.c_void_p: "ptr", ct.c_char_p: "ptr", ct.c_int: "int", ct.c_int64: "i64", ct.c_uint64: "u64",
+           ct.c_float: "float"}
+    checked = 0
+    for ret, name, params in decls:
+        restype, argtypes = _cabi._SIGS[name]
+        plist = [p for p in (x.strip() for x in params.replace("\n", " ").split(",")) if p and p != "void"]
+        got = [klass(p) for p in plist]
+        want = [pyk[a] for a in argtypes]
+        assert got == want, "%s: header %s vs ctypes %s" % (name, got, want)
+        rk = klass(ret + " x")
+        assert pyk.get(restype, "ptr") == rk, "%s: return type %s vs %s" % (name, rk, restype)
+        checked += 1
+    assert checked == len(_cabi._SIGS)
