@@ -28,6 +28,16 @@ from .model import BertForPreTraining
 NO_DECAY = ("bias", "gamma", "beta", "LayerNorm")      # run_pretraining.py:423
 
 
+def poly_warmup_lr(step_after, base_lr, warmup, total_steps, degree=0.5):
+    """PolyWarmUpScheduler.get_lr (LanguageModeling/BERT/schedulers.py:123-136) with last_epoch = step_after:
+    linear warm-up over the first `warmup` fraction of `total_steps`, then base_lr * (1 - progress) ** degree
+    (clamped at 0 past the end of the schedule instead of going complex)."""
+    progress = step_after / total_steps
+    if progress < warmup:
+        return base_lr * progress / warmup
+    return base_lr * (max(1.0 - progress, 0.0) ** degree)
+
+
 class BertTrainer:
     def __init__(self, model: BertForPreTraining, lr=6e-3, warmup=0.2843, total_steps=7038, weight_decay=0.01,
                  max_grad_norm=1.0, compute_dtype=torch.bfloat16, init_loss_scale=2.0 ** 20, world_size=1,
@@ -356,10 +366,7 @@ class BertTrainer:
 
     # ------------------------------------------------------------------ optimizer
     def current_lr(self):
-        progress = (self.opt_steps + 1) / self.total
-        if progress < self.warmup:
-            return self.base_lr * progress / self.warmup
-        return self.base_lr * (max(1.0 - progress, 0.0) ** 0.5)
+        return poly_warmup_lr(self.opt_steps + 1, self.base_lr, self.warmup, self.total)
 
     def optimizer_step(self):
         sc = self.scaler

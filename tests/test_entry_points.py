@@ -67,3 +67,34 @@ def test_entry_points_run_on_gpu(cuda, tmp_path):
              "--log_path", str(tmp_path / "dlrm.json"), "--print_freq", "2", "--synthetic_dataset_num_entries", "16384"])
     recs = [json.loads(l[5:]) for l in open(tmp_path / "dlrm.json")]
     assert "average_train_throughput" in recs[-1]["data"]
+
+
+def test_bert_lr_schedule_matches_reference_scheduler():
+    """bert.engine.poly_warmup_lr == the oracle's restatement == (when the reference tree is present) the reference's
+    own PolyWarmUpScheduler stepped on a dummy optimizer (LanguageModeling/BERT/schedulers.py:109-136)."""
+    import os
+    import sys
+    import torch
+    from deeplearningexamples_amd.bert.engine import poly_warmup_lr
+    from oracle import bert_oracle as BO
+    base, warm, total = 6e-3, 0.2843, 40
+    ours = [poly_warmup_lr(s, base, warm, total) for s in range(1, total)]
+    orc = [BO.poly_warmup_lr(s, base, warm, total) for s in range(1, total)]
+    assert max(abs(a - b) for a, b in zip(ours, orc)) < 1e-12
+    assert poly_warmup_lr(total + 5, base, warm, total) == 0.0
+    ref_dir = "/root/reference/PyTorch/LanguageModeling/BERT"
+    if os.path.isdir(ref_dir):
+        sys.path.insert(0, ref_dir)
+        try:
+            import schedulers as RS
+        finally:
+            sys.path.remove(ref_dir)
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=base)
+        sch = RS.PolyWarmUpScheduler(opt, warmup=warm, total_steps=total, base_lr=base, device="cpu")
+        got = []
+        for k in range(0, 11):            # FusedLAMBAMP keeps the completed-step count in param_group["step"]
+            opt.param_groups[0]["step"] = torch.tensor(float(k))
+            sch.step()                    # run_pretraining.py:529 steps the scheduler BEFORE the optimizer
+            got.append(float(opt.param_groups[0]["lr"]))
+        assert max(abs(a - b) for a, b in zip(got, ours[:11])) < 1e-9
