@@ -6,6 +6,8 @@ Produces deeplearningexamples_amd/lib/libdle_mi355x.so from csrc/*.hip.  hipcc c
 for gfx950 without a GPU present, so this also runs in the CPU-only build container.
 """
 import concurrent.futures as cf
+import hashlib
+import json
 import os
 import subprocess
 import sys
@@ -14,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libdle_mi355x.so")
+MANIFEST = os.path.join(HERE, "lib", "libdle_mi355x.manifest.json")   # content hashes of the sources the .so was built from
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-result", "-DNDEBUG"]
@@ -49,7 +52,26 @@ def _compile(src, force):
     return obj, True
 
 
+def _source_hashes():
+    out = {"flags": " ".join(FLAGS)}
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")):
+            out[f] = hashlib.sha256(open(os.path.join(CSRC, f), "rb").read()).hexdigest()
+    return out
+
+
 def build(force=False, verbose=True):
+    # The .so travels to the GPU box without its object files (and file times are not preserved there): decide
+    # "up to date" from CONTENT hashes recorded next to the library, not from mtimes of objects that are not there.
+    hashes = _source_hashes()
+    if not force and os.path.exists(LIB) and os.path.exists(MANIFEST):
+        try:
+            if json.load(open(MANIFEST)) == hashes:
+                if verbose:
+                    print("up to date:", LIB)
+                return LIB
+        except (OSError, ValueError):
+            pass
     os.makedirs(OBJ, exist_ok=True)
     srcs = sources()
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
@@ -64,6 +86,7 @@ def build(force=False, verbose=True):
             print("built", LIB, "(%d objects, %d recompiled)" % (len(objs), sum(c for _, c in res)))
     elif verbose:
         print("up to date:", LIB)
+    json.dump(hashes, open(MANIFEST, "w"), indent=0)
     return LIB
 
 
