@@ -80,3 +80,35 @@ def import_convnets():
     from image_classification import training, optimizers, smoothing
     return types.SimpleNamespace(models=models, training=training, optimizers=optimizers,
                                  smoothing=smoothing)
+
+
+def import_fused_lamb():
+    """The reference's FusedLAMBAMP class, unmodified, importable on CPU: `fused_lamb_CUDA` is bound to
+    oracle/lamb_cpu_ext.py, apex's multi_tensor_applier to its two-line Python (apex/multi_tensor_apply/
+    multi_tensor_apply.py: op(chunk_size, noop_flag, tensor_lists, *args), chunk 2048*32), amp_C to the same
+    functions, torch.cuda.current_device() to "cpu" (fused_lamb.py:23-24 builds lr/step on that device)."""
+    import torch
+    from oracle import lamb_cpu_ext
+    root = os.path.join(REF, "PyTorch/LanguageModeling/BERT/lamb_amp_opt")
+    if root not in sys.path:
+        sys.path.insert(0, root)
+
+    class _Applier:
+        available = True
+
+        def __init__(self, chunk_size):
+            self.chunk_size = chunk_size
+
+        def __call__(self, op, noop_flag_buffer, tensor_lists, *args):
+            return op(self.chunk_size, noop_flag_buffer, tensor_lists, *args)
+
+    mta = _stub("apex.multi_tensor_apply", multi_tensor_applier=_Applier(2048 * 32), MultiTensorApply=_Applier)
+    _stub("apex", multi_tensor_apply=mta)
+    _stub("amp_C", multi_tensor_l2norm=lamb_cpu_ext.multi_tensor_l2norm, multi_tensor_lamb=lamb_cpu_ext.multi_tensor_lamb)
+    _stub("fused_lamb_CUDA", multi_tensor_l2norm=lamb_cpu_ext.multi_tensor_l2norm,
+          multi_tensor_lamb=lamb_cpu_ext.multi_tensor_lamb)
+    torch.cuda.current_device = lambda: "cpu"
+    sys.modules.pop("fused_lamb", None)
+    sys.modules.pop("fused_lamb.fused_lamb", None)
+    from fused_lamb.fused_lamb import FusedLAMBAMP
+    return FusedLAMBAMP

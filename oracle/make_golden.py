@@ -189,6 +189,67 @@ def gen_rn50():
     print("rn50 losses", losses, "oracle", ol, "sensitivity to 1e-6 input noise", sens)
 
 
+def gen_lamb():
+    """The reference's UNMODIFIED FusedLAMBAMP + PolyWarmUpScheduler + torch GradScaler stepping on CPU
+    (fused_lamb_CUDA = oracle/lamb_cpu_ext.py): pins the optimizer's host sequence (run_pretraining.py:527-536)."""
+    from oracle import lamb_oracle as L
+    FusedLAMBAMP = R.import_fused_lamb()
+    sched = R.import_bert().schedulers
+    case = L.LAMB_GOLDEN_CASE
+    params0, grads = L.lamb_golden_inputs(case)
+    tp = {k: torch.nn.Parameter(torch.from_numpy(a.copy()).to(torch.float16 if half else torch.float32))
+          for k, (a, half) in params0.items()}
+    opt = FusedLAMBAMP([{"params": [tp[k] for k in names], "weight_decay": wd} for wd, names in case["groups"]],
+                       lr=case["lr"])
+    opt.setup_fp32_params()                                               # run_pretraining.py:477
+    lr_sched = sched.PolyWarmUpScheduler(opt, warmup=case["warmup"], total_steps=case["total_steps"],
+                                         base_lr=case["lr"], device="cpu")
+    scaler = torch.amp.GradScaler("cpu", init_scale=case["init_scale"], growth_interval=case["growth_interval"])
+    host = L.FusedLambHost(params0, case["groups"], case["lr"], case["warmup"], case["total_steps"],
+                           init_scale=case["init_scale"], growth_interval=case["growth_interval"])
+    rec = {"scale": [], "found_inf": [], "step": [], "lr": []}
+    for it, g in enumerate(grads):
+        scaler.scale(torch.zeros(1))        # what grad_scaler.scale(loss) does first: lazily create the scale tensor
+        scale = float(scaler.get_scale())
+        scaled = {}
+        for k, p in tp.items():
+            gs = (g[k] * np.float32(scale)).astype(np.float16 if p.dtype == torch.float16 else np.float32)
+            if it in case["overflow_at"] and k == "w_c":
+                gs = gs.copy(); gs.reshape(-1)[5] = np.inf
+            scaled[k] = gs
+            p.grad = torch.from_numpy(gs.copy())
+        lr_sched.step()                                                   # run_pretraining.py:528
+        scaler.step(opt)                                                  # :529
+        found = float(sum(v.item() for v in scaler._found_inf_per_device(opt).values()))
+        scaler.update()                                                   # :535
+        opt.zero_grad(set_to_none=True)
+        fo = host.optimizer_step(scaled)
+        assert bool(found) == bool(fo), (it, found, fo)
+        rec["scale"].append(scale); rec["found_inf"].append(found)
+        rec["step"].append(int(opt.param_groups[0]["step"].item())); rec["lr"].append(float(opt.param_groups[0]["lr"]))
+        assert host.step == rec["step"][-1] and np.float32(host.lr) == np.float32(rec["lr"][-1]), (it, host.step, host.lr, rec)
+    out = {k: np.asarray(v, np.float64) for k, v in rec.items()}
+    out["final_scale"] = np.float64(scaler.get_scale())
+    flat = [p for grp in opt.param_groups for p in grp["params"]]
+    flat32 = [p for grp in opt.param_groups_fp32 for p in grp["params"]]
+    names = [k for _, ns in case["groups"] for k in ns]
+    for k, p, p32 in zip(names, flat, flat32):
+        master = (p32 if p32 is not None else p).detach().numpy()
+        out["p_" + k] = master
+        out["m_" + k] = opt.state[p]["exp_avg"].numpy()
+        out["v_" + k] = opt.state[p]["exp_avg_sq"].numpy()
+        if p.dtype == torch.float16:
+            out["p16_" + k] = p.detach().numpy()
+        # the restated host sequence == the reference classes, bit for bit
+        assert np.array_equal(master, host.p[k]), k
+        assert np.array_equal(out["m_" + k], host.m[k]) and np.array_equal(out["v_" + k], host.v[k]), k
+        if p.dtype == torch.float16:
+            assert np.array_equal(out["p16_" + k], host.p16[k]), k
+    assert np.float32(out["final_scale"]) == host.scale
+    np.savez_compressed(os.path.join(GOLD, "lamb_ref_steps.npz"), **out)
+    print("lamb: steps", rec["step"], "scales", rec["scale"], "lr", rec["lr"])
+
+
 def gen_bert():
     """Per-step losses of the REFERENCE's BertForPreTraining (eager CPU, dropout 0) + the oracle's LAMB."""
     from oracle import bert_oracle as BO
