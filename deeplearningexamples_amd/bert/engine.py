@@ -22,7 +22,8 @@ from .. import _cabi as C
 from .. import functional as F
 from .. import multi_tensor as mt
 from ..dlrm.engine import GradScalerState
-from ..utils.buckets import allreduce_mean_
+from ..utils.buckets import GradBuckets
+from ..utils import comm
 from .model import BertForPreTraining
 
 NO_DECAY = ("bias", "gamma", "beta", "LayerNorm")      # run_pretraining.py:423
@@ -41,7 +42,8 @@ def poly_warmup_lr(step_after, base_lr, warmup, total_steps, degree=0.5):
 class BertTrainer:
     def __init__(self, model: BertForPreTraining, lr=6e-3, warmup=0.2843, total_steps=7038, weight_decay=0.01,
                  max_grad_norm=1.0, compute_dtype=torch.bfloat16, init_loss_scale=2.0 ** 20, world_size=1,
-                 process_group=None, hidden_dropout=None, attention_dropout=None, seed=42, rank=0):
+                 process_group=None, hidden_dropout=None, attention_dropout=None, seed=42, rank=0, static_batch=False,
+                 bucket_mb=64):
         self.model, self.cfg = model, model.config
         self.dev = model.bert.embeddings.word_embeddings.weight.device
         self.dtype = compute_dtype
@@ -57,7 +59,14 @@ class BertTrainer:
         self.scaler = GradScalerState(self.dev, enabled=compute_dtype == torch.float16, init_scale=init_loss_scale,
                                       growth_interval=2000)
         dev = self.dev
+        # static_batch: the caller promises that the SAME device tensors hold the same batch at every step (synthetic
+        # benchmark / graph-captured input buffers, run_pretraining.py:602-640) -- only then are the masked-row indices
+        # of a batch reused; by default they are rebuilt at every step (a loader may refill the same addresses)
+        self.static_batch = static_batch
         model.fuse_qkv_storage()
+        if world_size > 1:
+            # replicas start from rank 0's weights (torch DDP's constructor, run_pretraining.py:455-460)
+            comm.broadcast_parameters_(list(model.parameters()), 0, process_group)
         named = self._ordered_named_parameters(model)
         self.names = [n for n, _ in named]
         self.params = [p for _, p in named]
@@ -99,6 +108,13 @@ class BertTrainer:
         self.grad_divisor = 1          # gradient-accumulation micro-steps summed into the flat gradient
         self._batch_key, self._sel, self._idx0, self._mask_add, self._dense_labels = None, None, None, None, None
         self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
+        # gradient buckets over the flat buffer, all-reduced (mean) on the side stream while the backward pass is still
+        # running; the buffer follows named_parameters(), backward completes it from the end -> reverse buckets
+        self.buckets = GradBuckets(self.flat_grad, [(n, p.numel()) for n, p in zip(self.names, self.params)], bucket_mb,
+                                   process_group, self.comm_stream, reverse=True) if world_size > 1 else None
+        self._reduce_now = False       # set for the micro-step whose gradients are final (last accumulation step)
+        base_t = torch.tensor(float(lr), dtype=torch.float32, device=dev)
+        self._lr_consts = (base_t, torch.tensor(float(warmup), device=dev), torch.tensor(float(total_steps), device=dev))
 
     # ------------------------------------------------------------------ plumbing
     @staticmethod
@@ -158,7 +174,7 @@ class BertTrainer:
 
     def _prepare_batch(self, input_ids, attention_mask, labels):
         key = (input_ids.data_ptr(), labels.data_ptr(), attention_mask.data_ptr(), tuple(input_ids.shape))
-        if key == self._batch_key:
+        if self.static_batch and key == self._batch_key:
             return
         b, s = input_ids.shape
         flat = labels.reshape(-1)
@@ -303,6 +319,7 @@ class BertTrainer:
         self._bgrad("bert.pooler.dense_act.bias", dpool_pre, acc)
         dfirst = F.gemm(dpool_pre, self.w16["bert.pooler.dense_act.weight"], b, h, h, True, False)
         F.rows_scatter_(dseq, dfirst, self._idx0, accumulate=True)
+        self._grads_final(("cls.", "bert.pooler."))          # both heads are done (they sit at the END of the flat buffer)
         # ---- encoder
         dx = dseq
         scale = 1.0 / math.sqrt(d)
@@ -349,6 +366,7 @@ class BertTrainer:
             gbq = self.gview[pre + "attention.self.query.bias"]
             F.colsum(dqkv, out=torch.as_strided(gbq, (3 * h,), (1,)), accumulate=acc)
             dx = F.gemm(dqkv, layer.qkv16, t, h, 3 * h, True, False, act=C.ACT_ADD, mask_src=dz1)
+            self._grads_final((pre,))
         # ---- embeddings
         emb = m.bert.embeddings
         if sv["mask0"] is not None:
@@ -361,25 +379,44 @@ class BertTrainer:
             gpos[s:].zero_()
         F.colsum(dz0.view(b, s * h), out=gpos[:s].view(-1), accumulate=acc)
         F.rows_select_sum(dz0, sv["tt"], cfg["type_vocab"], self.gview["bert.embeddings.token_type_embeddings.weight"], acc)
+        self._grads_final(("bert.embeddings.",))
         self._last_sv = sv if getattr(self, "keep_activations", False) else None     # tests read the dropout masks
         self._sv = None
 
+    def _grads_final(self, prefixes):
+        """The gradients of every parameter whose name starts with one of `prefixes` are complete: launch the
+        all-reduce of the buckets they close (side stream, overlapped with the rest of the backward pass)."""
+        if self.buckets is None or not self._reduce_now:
+            return
+        for n in self.names:
+            if n.startswith(prefixes):
+                self.buckets.grad_ready(n)
+
     # ------------------------------------------------------------------ optimizer
     def current_lr(self):
+        """Host-side view of the schedule (logging); the step itself computes the rate on the device from the LAMB
+        step counter, which does not advance on a skipped (overflow) step -- PolyWarmUpScheduler.step reads
+        param_group['step'] + 1 (schedulers.py:123-131)."""
         return poly_warmup_lr(self.opt_steps + 1, self.base_lr, self.warmup, self.total)
+
+    def _device_lr(self):
+        base, warm, total = self._lr_consts
+        progress = (self.step_t.to(torch.float32) + 1.0) / total
+        lr = torch.where(progress < warm, base * progress / warm, base * torch.clamp(1.0 - progress, min=0.0) ** 0.5)
+        self.lr_t.copy_(lr.reshape(()))
 
     def optimizer_step(self):
         sc = self.scaler
         if self.grad_divisor != 1:
             # each micro-step's loss is divided by the accumulation count in the reference (run_pretraining.py:521)
             self.flat_grad.mul_(1.0 / self.grad_divisor)
-        if self.world > 1:
-            allreduce_mean_(self.flat_grad, self.pg)
+        if self.buckets is not None:
+            self.buckets.wait()          # every bucket was launched during the backward pass of the last micro-step
         self.noop.zero_()
         if sc.enabled:
             F.check_nonfinite_(self.flat_grad, sc.found_inf)
             self.noop.copy_(sc.found_inf.to(torch.int32))
-        self.lr_t.fill_(self.current_lr())
+        self._device_lr()                # from step_t BEFORE it advances (lr_scheduler.step() precedes optimizer.step())
         self.step_t += (1 - self.noop)
         gnorm, _ = mt.l2norm(self.t_all_grads, self.noop)
         scale = sc.scale if sc.enabled else self.one
@@ -398,6 +435,7 @@ class BertTrainer:
     def train_step(self, input_ids, token_type_ids, attention_mask, labels, next_sentence_labels):
         """One optimizer step on one micro-batch.  Returns the device-resident fp32 loss [1]."""
         loss, dlogits, dnsp = self.forward(input_ids, token_type_ids, attention_mask, labels, next_sentence_labels)
+        self._reduce_now = True
         self.backward(dlogits, dnsp)
         self.optimizer_step()
         return loss

@@ -89,7 +89,8 @@ def main(argv=None):
             b = next(it)
             loss, dlog, dnsp = trainer.forward(b["input_ids"], b["token_type_ids"], b["attention_mask"], b["labels"],
                                                b["next_sentence_labels"])
-            trainer.backward(dlog, dnsp, accumulate=micro_step > 0)       # no_sync on accumulation micro-steps
+            trainer._reduce_now = micro_step == acc - 1                   # no_sync on all but the last micro-step
+            trainer.backward(dlog, dnsp, accumulate=micro_step > 0)
             avg_loss += loss / acc
         trainer.grad_divisor = acc
         trainer.optimizer_step()

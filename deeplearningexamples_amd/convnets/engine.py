@@ -23,6 +23,7 @@ from .. import functional as F
 from .. import multi_tensor as mt
 from ..dlrm.engine import GradScalerState
 from ..utils.buckets import GradBuckets
+from ..utils import comm
 from .resnet import ResNet50
 
 
@@ -64,6 +65,11 @@ class ResNetTrainer:
         self.dtype = compute_dtype
         self.momentum, self.wd, self.nesterov, self.smoothing = momentum, weight_decay, nesterov, label_smoothing
         self.world, self.pg = world_size, process_group
+        self.bn_weight_decay = bn_weight_decay
+        if world_size > 1:
+            # data-parallel replicas start from rank 0's weights and BatchNorm buffers (torch DDP's constructor does
+            # this in the reference, training.py:78-84) -- whatever seed each rank built its model with
+            comm.broadcast_parameters_(list(model.parameters()) + list(model.buffers()), 0, process_group)
         self.stem, self.blocks = model.units()
         self.scaler = GradScalerState(self.dev, enabled=compute_dtype == torch.float16, init_scale=static_loss_scale,
                                       growth_interval=int(1e9))   # static scale, as configs.yml AMP (128)
@@ -136,7 +142,7 @@ class ResNetTrainer:
         for n, p in named.items():
             g, m, ph = self.gview[n], self.mview[n], self._phys(p)
             assert ph.data_ptr() == p.data_ptr(), "parameter %s is not dense in memory order" % n
-            if "bn" in n:                                              # optimizers.py:42-43 (name based)
+            if "bn" in n and not self.bn_weight_decay:                 # optimizers.py:42-43 (name based; --bn-weight-decay)
                 for lst, t in zip(nodecay, (g, ph, m)):
                     lst.append(t)
             elif n in self.w16 and self.w16[n].numel() == p.numel():
@@ -237,6 +243,12 @@ class ResNetTrainer:
         self.optimizer_step()
         sc.update()
         self.steps_done += 1          # BatchNorm.num_batches_tracked is materialised by sync_counters()
+        return loss
+
+    def reduced_loss(self, loss):
+        """Mean of the per-rank losses for logging (utils.py:117-123 reduce_tensor); not part of the step."""
+        if self.world > 1:
+            loss = comm.allreduce_mean_(loss.clone(), self.pg)
         return loss
 
     def sync_counters(self):

@@ -95,16 +95,23 @@ def main(argv=None):
     rank, world, local = init_from_env()
     device = torch.device("cuda", local)
     if args.seed is not None:
-        torch.manual_seed(args.seed)                       # same init on all ranks (DDP would broadcast rank 0's)
+        torch.manual_seed(args.seed)        # (replicas are synchronised by the trainer's broadcast from rank 0 either way)
     if is_main_process():
         dllogger.init([dllogger.JSONStreamBackend(dllogger.Verbosity.VERBOSE, args.workspace.rstrip("/") + "/" + args.raport_file),
                        dllogger.StdOutBackend(dllogger.Verbosity.DEFAULT)])
         dllogger.log(step="PARAMETER", data=vars(args))
+    if not args.amp:
+        raise SystemExit("this path computes in 16 bits with fp32 master weights: pass --amp (the reference's fp32 / TF32 "
+                         "recipes are not built)")
+    if args.optimizer_batch_size not in (-1, world * args.batch_size):
+        raise SystemExit("--optimizer-batch-size %d: gradient accumulation (main.py:413-432 batch_size_multiplier) is not "
+                         "built; use -1 or world * batch-size = %d" % (args.optimizer_batch_size, world * args.batch_size))
     model = ResNet50(num_classes=args.num_classes, device=device)
-    dtype = (torch.bfloat16 if args.amp_dtype == "bf16" else torch.float16) if args.amp else torch.bfloat16
+    dtype = torch.bfloat16 if args.amp_dtype == "bf16" else torch.float16
     trainer = ResNetTrainer(model, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay,
                             nesterov=args.nesterov, label_smoothing=args.label_smoothing, compute_dtype=dtype,
-                            static_loss_scale=args.static_loss_scale, world_size=world)
+                            static_loss_scale=args.static_loss_scale, world_size=world,
+                            bn_weight_decay=args.bn_weight_decay)
     iters, secs = train_loop(trainer, args, get_lr_policy(args), device, rank, world)
     if is_main_process():
         dllogger.log(step=tuple(), data={"train.total_ips": world * args.batch_size * iters / secs, "iterations": iters})

@@ -21,7 +21,8 @@ import torch.distributed as dist
 
 from .. import functional as F
 from .. import multi_tensor as mt
-from ..utils.buckets import allreduce_mean_
+from ..utils import comm
+from ..utils.comm import allreduce_mean_
 from .model import DistributedDlrm
 from .placement import ExchangePlan
 
@@ -91,6 +92,10 @@ class DlrmTrainer:
         bm = model.bottom_model.mlp
         self.bot_linears = bm.linears if bm is not None else []
         self.bot_grads = _FlatGrads(self.bot_linears, self.device) if bm is not None else None
+        if world_size > 1:
+            # the top MLP is the data-parallel part: every replica starts from rank 0's weights (the reference wraps it
+            # in torch DDP, dlrm/scripts/main.py:463-466); embeddings / bottom MLP are model parallel and stay local
+            comm.broadcast_parameters_(list(model.top_model.parameters()), 0, process_group)
         model.refresh_working_copies()
         self._tables = {}
         self._build_tables()
@@ -154,7 +159,7 @@ class DlrmTrainer:
         """[B_global, n_r, D] -> [B_r, n_total, D] (device feature order).  all_to_all_single over RCCL."""
         p = self.plan
         recv = torch.empty(sum(p.fwd_recv_splits), dtype=local_out.dtype, device=local_out.device)
-        dist.all_to_all_single(recv, local_out.view(-1), p.fwd_recv_splits, p.fwd_send_splits, group=self.pg)
+        comm.all_to_all_single(recv, local_out.view(-1), p.fwd_recv_splits, p.fwd_send_splits, group=self.pg)
         x = torch.empty((p.local_batch, p.n_total, p.dim), dtype=local_out.dtype, device=local_out.device)
         for s in range(p.world):
             if p.vectors[s] == 0:
@@ -177,7 +182,7 @@ class DlrmTrainer:
                                                        (p.recv_feature_base[s] + p.vectors[s]) * p.dim],
                         blk.view(p.local_batch, p.vectors[s] * p.dim))
         out = torch.empty((p.global_batch, p.n_local, p.dim), dtype=grad_x.dtype, device=grad_x.device)
-        dist.all_to_all_single(out.view(-1), send, p.fwd_send_splits, p.fwd_recv_splits, group=self.pg)
+        comm.all_to_all_single(out.view(-1), send, p.fwd_send_splits, p.fwd_recv_splits, group=self.pg)
         return out
 
     # ------------------------------------------------------------------ the step
@@ -201,6 +206,10 @@ class DlrmTrainer:
             grad_bottom = grad_x
         if sc.enabled:
             F.check_nonfinite_(grad_bottom, sc.found_inf)
+            if self.world > 1:
+                # grad_bottom is this rank's slice of a model-parallel gradient: ranks must agree on skipping the step
+                # (torch's GradScaler all-reduces found_inf across the process group in the same way)
+                comm.allreduce_max_(sc.found_inf, self.pg)
         m.bottom_model.backward(grad_bottom, self.lr_mp, inv_scale=sc.inv_scale if sc.enabled else None,
                                 skip_flag=sc.found_inf if sc.enabled else None,
                                 mlp_grads=self.bot_grads.views if self.bot_grads is not None else None,
@@ -211,6 +220,8 @@ class DlrmTrainer:
             F.check_nonfinite_(self.top_grads.flat, sc.found_inf)
             if self.bot_grads is not None:
                 F.check_nonfinite_(self.bot_grads.flat, sc.found_inf)
+            if self.world > 1:
+                comm.allreduce_max_(sc.found_inf, self.pg)
         if not self.freeze_mlps:
             self._dense_step()
         sc.update()

@@ -27,22 +27,27 @@ def cut_buckets(named_numels: Sequence[Tuple[str, int]], bucket_bytes: int) -> L
     return out
 
 
-def allreduce_mean_(t: torch.Tensor, group=None):
-    """In-place mean over the ranks.  NCCL/RCCL has a native AVG; gloo (CPU tests) sums and scales."""
-    if dist.get_backend(group) == "nccl":
-        dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
-    else:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        t.div_(dist.get_world_size(group))
-    return t
+from .comm import allreduce_mean_  # noqa: E402,F401  (re-exported: the engines import it from here)
 
 
 class GradBuckets:
-    def __init__(self, flat: torch.Tensor, named_numels, bucket_mb=25, group=None, comm_stream=None):
+    """`named_numels` lists the parameters in the order they lie in `flat`.  reverse=False: gradients complete in that
+    order (ResNet: the flat buffer is laid out in backward-completion order).  reverse=True: they complete from the
+    END of the buffer towards its start (BERT: the buffer follows named_parameters(), backward runs heads -> layer 23
+    -> ... -> embeddings), buckets are cut walking backwards and fire on the parameter with the LOWEST offset."""
+
+    def __init__(self, flat: torch.Tensor, named_numels, bucket_mb=25, group=None, comm_stream=None, reverse=False):
         self.flat, self.group, self.stream = flat, group, comm_stream
-        self.buckets = cut_buckets(named_numels, bucket_mb * (1 << 20))
+        if reverse:
+            total = sum(n for _, n in named_numels)
+            cut = cut_buckets(list(reversed(list(named_numels))), bucket_mb * (1 << 20))
+            self.buckets = [(total - e, total - s, name) for (s, e, name) in cut]
+            assert self.buckets[0][1] == flat.numel() and self.buckets[-1][0] == 0
+        else:
+            self.buckets = cut_buckets(named_numels, bucket_mb * (1 << 20))
+            assert self.buckets[-1][1] == flat.numel() and self.buckets[0][0] == 0
         self._by_last = {b[2]: i for i, b in enumerate(self.buckets)}
-        assert self.buckets[-1][1] == flat.numel() and self.buckets[0][0] == 0
+        self.fired = 0
 
     def grad_ready(self, name):
         """Call when the gradient of `name` has been written; fires the bucket that this parameter completes."""
@@ -50,6 +55,7 @@ class GradBuckets:
         if i is None:
             return False
         s, e, _ = self.buckets[i]
+        self.fired += 1
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
@@ -59,5 +65,8 @@ class GradBuckets:
         return True
 
     def wait(self):
+        """Make the compute stream wait for every bucket; all of them must have been launched by now."""
+        assert self.fired == len(self.buckets), "only %d of %d gradient buckets were reduced" % (self.fired, len(self.buckets))
+        self.fired = 0
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)

@@ -1,0 +1,84 @@
+"""Collectives of the train steps: one process per GPU, torch.distributed with backend "nccl" (= RCCL over xGMI).
+
+Replaces what the reference gets from torch DDP / torch.distributed over NCCL
+(Classification/ConvNets/image_classification/training.py:78-84, LanguageModeling/BERT/run_pretraining.py:455-475,
+Recommendation/DLRM/dlrm/model/distributed.py:68,95).  Every exchange of the engines goes through these helpers.
+
+The `gloo` branch exists for the tests only: the CPU suite (world_size 2, CPU tensors) and the two-process run on a
+ONE-GPU box (RCCL refuses two ranks on one device), where device tensors are staged through host memory around
+the gloo call.  It moves bytes; no arithmetic of the product path runs on the CPU.
+"""
+import torch
+import torch.distributed as dist
+
+
+def _staged(t, group):
+    return t.is_cuda and dist.get_backend(group) != "nccl"
+
+
+def allreduce_mean_(t: torch.Tensor, group=None):
+    """In-place mean over the ranks.  RCCL has a native AVG; gloo sums and scales."""
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+    elif t.is_cuda:
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h.div_(dist.get_world_size(group)))
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t.div_(dist.get_world_size(group))
+    return t
+
+
+def allreduce_max_(t: torch.Tensor, group=None):
+    """In-place maximum over the ranks (the found-inf flag of model-parallel parts)."""
+    if _staged(t, group):
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t
+
+
+def broadcast_(t: torch.Tensor, src=0, group=None):
+    if _staged(t, group):
+        h = t.detach().cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
+def all_to_all_single(out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits, group=None):
+    """torch.distributed.all_to_all_single with element split lists (DLRM bottom -> top exchange and its reverse)."""
+    if _staged(out, group):
+        world = dist.get_world_size(group)
+        ho, hi = torch.empty(out.shape, dtype=out.dtype), inp.detach().cpu()
+        # gloo has no all-to-all for every dtype: pairwise scatter of the send blocks does the same exchange
+        outs = list(ho.view(-1).split(list(out_splits)))
+        ins = [c.contiguous() for c in hi.view(-1).split(list(in_splits))]
+        rank = dist.get_rank(group)
+        for r in range(world):
+            # rank r scatters its blocks; every rank receives the block addressed to it
+            recv = torch.empty(outs[r].shape, dtype=ho.dtype)
+            if outs[r].dtype in (torch.float16, torch.bfloat16):
+                recv32 = torch.empty(outs[r].shape, dtype=torch.float32)
+                dist.scatter(recv32, [c.float() for c in ins] if rank == r else None, src=r, group=group)
+                recv = recv32.to(ho.dtype)
+            else:
+                dist.scatter(recv, ins if rank == r else None, src=r, group=group)
+            outs[r].copy_(recv)
+        out.copy_(ho)
+    else:
+        dist.all_to_all_single(out, inp, list(out_splits), list(in_splits), group=group)
+    return out
+
+
+def broadcast_parameters_(tensors, src=0, group=None):
+    """Make every data-parallel replica start from rank `src`'s values (what torch DDP does when it wraps a module:
+    ConvNets training.py:78-84, BERT run_pretraining.py:455-460, DLRM dlrm/scripts/main.py:463-466).  `tensors`:
+    parameters and buffers; integer buffers (num_batches_tracked) included."""
+    for t in tensors:
+        broadcast_(t.data if isinstance(t, torch.nn.Parameter) else t, src=src, group=group)

@@ -175,3 +175,9 @@ class BertOracle:
 BERT_TINY = dict(hidden=256, heads=4, layers=2, intermediate=1024, vocab=1024, real_vocab=1000, max_pos=512,
                  type_vocab=2, seq=128)
 BERT_STEP_CONFIG = dict(cfg=BERT_TINY, seed=21, batch=4, steps=5, lr=6e-3, warmup=0.2843, total_steps=20)
+
+# One encoder layer at BERT-LARGE width (hidden 1024, 16 heads of 64, FFN 4096, the padded 30528 vocabulary, S = 128):
+# the GEMM / attention / LayerNorm shapes of BASELINE.json configs[2], small enough for the CPU reference in seconds.
+BERT_LARGE_1L = dict(hidden=1024, heads=16, layers=1, intermediate=4096, vocab=30528, real_vocab=30522, max_pos=512,
+                     type_vocab=2, seq=128)
+BERT_STEP_CONFIG_LARGE = dict(cfg=BERT_LARGE_1L, seed=33, batch=4, steps=2, lr=6e-3, warmup=0.2843, total_steps=20)

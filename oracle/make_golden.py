@@ -150,11 +150,16 @@ def gen_dlrm_step():
         print("dlrm_step", name, "losses", arrs["losses"])
 
 
-def gen_rn50():
+def gen_rn50_224():
+    """BASELINE.json configs[0] shape (224x224, batch 32): the reference's module for 2 steps (minutes on 8 cores)."""
+    gen_rn50(cfg_name="RN50_STEP_CONFIG_224", out_name="rn50_step_224.npz")
+
+
+def gen_rn50(cfg_name="RN50_STEP_CONFIG", out_name="rn50_step.npz"):
     """Per-step losses of the REFERENCE's resnet50 + LabelSmoothing + get_sgd_optimizer on CPU (fp32)."""
     from oracle import resnet_oracle as RO
     ref = R.import_convnets()
-    c = RO.RN50_STEP_CONFIG
+    c = getattr(RO, cfg_name)
     model = ref.models.resnet50(pretrained=False)
     state0 = RO.seeded_state(c["seed"])
     sd = model.state_dict()
@@ -181,12 +186,20 @@ def gen_rn50():
     lp = [orc2.step(x * (1 + 1e-6), y) for _ in range(c["steps"])]
     sens = [abs(u - v) / abs(u) for u, v in zip(ol, lp)]
     fin = {k: v.detach().numpy() for k, v in model.state_dict().items()}
-    np.savez_compressed(os.path.join(GOLD, "rn50_step.npz"), losses=np.asarray(losses, np.float64),
+    # the precision floor of 16-bit STORAGE on this network, measured by the oracle itself: the same fp32 math with
+    # every tensor the AMP path keeps in 16 bits rounded where it is produced (oracle/resnet_oracle.py storage_dtype)
+    floors = {}
+    for nm, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        o16 = RO.ResNet50Oracle(state0, c["lr"], storage_dtype=dt)
+        floors[nm] = [o16.step(x, y) for _ in range(c["steps"])]
+    np.savez_compressed(os.path.join(GOLD, out_name), losses=np.asarray(losses, np.float64),
+                        losses_fp16_storage=np.asarray(floors["fp16"], np.float64),
+                        losses_bf16_storage=np.asarray(floors["bf16"], np.float64),
                         oracle_losses=np.asarray(ol, np.float64), sensitivity=np.asarray(sens, np.float64),
                         final_fc_bias=fin["fc.bias"], final_bn1_weight=fin["bn1.weight"],
                         final_bn1_running_mean=fin["bn1.running_mean"], final_bn1_running_var=fin["bn1.running_var"],
                         final_conv1_weight=fin["conv1.weight"])
-    print("rn50 losses", losses, "oracle", ol, "sensitivity to 1e-6 input noise", sens)
+    print(out_name, "losses", losses, "oracle", ol, "sensitivity to 1e-6 input noise", sens, "16-bit storage", floors)
 
 
 def gen_lamb():
@@ -250,11 +263,16 @@ def gen_lamb():
     print("lamb: steps", rec["step"], "scales", rec["scale"], "lr", rec["lr"])
 
 
-def gen_bert():
+def gen_bert_large():
+    """One encoder layer at BERT-Large width (BASELINE configs[2] shapes) through the reference's module."""
+    gen_bert(cfg_name="BERT_STEP_CONFIG_LARGE", out_name="bert_step_large1l.npz", last_layer=0)
+
+
+def gen_bert(cfg_name="BERT_STEP_CONFIG", out_name="bert_step.npz", last_layer=1):
     """Per-step losses of the REFERENCE's BertForPreTraining (eager CPU, dropout 0) + the oracle's LAMB."""
     from oracle import bert_oracle as BO
     ref = R.import_bert()
-    c = BO.BERT_STEP_CONFIG
+    c = getattr(BO, cfg_name)
     cfg = c["cfg"]
     conf = ref.modeling.BertConfig(cfg["vocab"], hidden_size=cfg["hidden"], num_hidden_layers=cfg["layers"],
                                    num_attention_heads=cfg["heads"], intermediate_size=cfg["intermediate"],
@@ -290,11 +308,11 @@ def gen_bert():
             assert torch.allclose(v.grad, orc.p[k].grad, rtol=2e-3, atol=2e-6), k
         orc.lamb_update({k: v.grad.numpy() for k, v in model.named_parameters()})
     assert np.allclose(ol, losses, rtol=1e-5), (ol, losses)
-    np.savez_compressed(os.path.join(GOLD, "bert_step.npz"), losses=np.asarray(losses, np.float64),
+    np.savez_compressed(os.path.join(GOLD, out_name), losses=np.asarray(losses, np.float64),
                         final_pooler_bias=orc.p["bert.pooler.dense_act.bias"].detach().numpy(),
-                        final_ln_weight=orc.p["bert.encoder.layer.1.output.LayerNorm.weight"].detach().numpy(),
+                        final_ln_weight=orc.p["bert.encoder.layer.%d.output.LayerNorm.weight" % last_layer].detach().numpy(),
                         final_query_row=orc.p["bert.encoder.layer.0.attention.self.query.weight"].detach().numpy()[:4])
-    print("bert losses", losses)
+    print(out_name, "losses", losses)
 
 
 if __name__ == "__main__":

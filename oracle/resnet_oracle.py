@@ -179,3 +179,7 @@ class ResNet50Oracle:
 # make_golden.gen_rn50 also stores `sensitivity`: the relative loss change under a 1e-6 input perturbation in
 # fp32 (a chaos check of the configuration itself; ~1e-7 with the damped init above).
 RN50_STEP_CONFIG = dict(seed=5, batch=32, size=64, lr=1e-3, steps=4, num_classes=1000)
+
+# BASELINE.json configs[0]: the reference's own CPU-runnable case -- synthetic 224x224, batch 32 (2 steps are pinned;
+# the full 100 iterations are ~1 h of host time and add nothing to parity).  Same seeded weights as above.
+RN50_STEP_CONFIG_224 = dict(seed=5, batch=32, size=224, lr=1e-3, steps=2, num_classes=1000)

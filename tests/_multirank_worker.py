@@ -1,0 +1,156 @@
+"""Worker of tests/test_gpu_multirank.py (NOT a test module): one rank of a 2-process run of a trainer.
+
+    python -m torch.distributed.run --nproc-per-node 2 ... tests/_multirank_worker.py <scenario> <backend> <out.json>
+
+backend nccl: one GPU per rank over RCCL (needs >= 2 GPUs).  backend gloo: both ranks on cuda:0 -- RCCL refuses two
+ranks on one device, so the collectives are staged through host memory (utils/comm.py); everything else (the
+engines' multi-rank code, every HIP kernel) is the production path.
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def run_bert(rank, world, dev, steps):
+    from oracle import bert_oracle as BO
+    from deeplearningexamples_amd.bert.model import BertForPreTraining
+    from deeplearningexamples_amd.bert.engine import BertTrainer
+    c = BO.BERT_STEP_CONFIG
+    torch.manual_seed(100 + rank)                           # replicas are built DIFFERENTLY; the trainer must sync them
+    model = BertForPreTraining(c["cfg"], device=dev)
+    if rank == 0:
+        model.load_state_dict({k: v.clone() for k, v in BO.seeded_state(c["cfg"], c["seed"]).items()}, strict=False)
+    tr = BertTrainer(model, lr=c["lr"], warmup=c["warmup"], total_steps=c["total_steps"], compute_dtype=torch.bfloat16,
+                     hidden_dropout=0.0, attention_dropout=0.0, world_size=world, rank=rank, bucket_mb=1)
+    full = BO.seeded_batch(c["cfg"], c["seed"] + 1, 8)
+    per = 8 // world
+    mine = [t[rank * per:(rank + 1) * per].contiguous().to(dev) for t in full]
+    losses = []
+    for _ in range(steps):
+        loss = tr.train_step(*mine)
+        if world > 1:
+            from deeplearningexamples_amd.utils import comm
+            loss = comm.allreduce_mean_(loss.clone())
+        losses.append(float(loss.item()))
+    named = dict(model.named_parameters())
+    probe = named["bert.encoder.layer.0.attention.self.query.weight"].detach().float().cpu().numpy()[:2].tolist()
+    return {"losses": losses, "probe": probe, "nbuckets": len(tr.buckets.buckets) if tr.buckets else 0}
+
+
+def run_rn50(rank, world, dev, steps):
+    from oracle import resnet_oracle as RO
+    from deeplearningexamples_amd.convnets.resnet import ResNet50
+    from deeplearningexamples_amd.convnets.engine import ResNetTrainer
+    c = RO.RN50_STEP_CONFIG
+    torch.manual_seed(200 + rank)
+    model = ResNet50(device=dev)
+    if rank == 0:
+        model.load_state_dict({k: v.clone() for k, v in RO.seeded_state(c["seed"]).items()}, strict=False)
+    tr = ResNetTrainer(model, lr=c["lr"], compute_dtype=torch.bfloat16, static_loss_scale=128.0, world_size=world,
+                       bucket_mb=4)
+    # the SAME batch on every rank: the mean of identical gradients is the single-rank gradient, BatchNorm statistics
+    # (per rank, as in the reference: no SyncBN) are identical too -> losses must equal the 1-rank run
+    x, y = RO.seeded_batch(c["seed"] + 100, 8, c["size"])
+    x, y = x.to(dev), y.to(dev)
+    losses = [float(tr.train_step(x, y).item()) for _ in range(steps)]
+    probe = model.fc.bias.detach().cpu().numpy()[:8].tolist()
+    return {"losses": losses, "probe": probe, "nbuckets": len(tr.buckets.buckets) if tr.buckets else 0}
+
+
+DLRM_MR = dict(num=13, sizes=[300, 50, 7, 2000, 11, 640], dim=128, bottom=[64, 128], top=[128, 64, 1], lr=0.5, batch=256,
+               seed=5)
+
+
+def dlrm_device_order(world):
+    from deeplearningexamples_amd.dlrm import placement as P
+    mapping = P.get_device_mapping(DLRM_MR["sizes"], world)
+    return mapping, [t for bucket in mapping["embedding"] for t in bucket]
+
+
+def run_dlrm(rank, world, dev, steps):
+    """world 2: tables placed by get_device_mapping.  world 1: ONE rank holding the tables in the 2-rank DEVICE order
+    (the interaction sees features in device order, dlrm/model/distributed.py:135-138), same weights, same batch."""
+    from oracle import dlrm_step_oracle as SO
+    from deeplearningexamples_amd.dlrm import placement as P
+    from deeplearningexamples_amd.dlrm.model import DistributedDlrm
+    from deeplearningexamples_amd.dlrm.engine import DlrmTrainer
+    c = DLRM_MR
+    mapping2, order = dlrm_device_order(2)
+    sizes_dev = [c["sizes"][t] for t in order]
+    state = SO.seeded_dlrm_state(sizes_dev, c["dim"], c["bottom"], c["top"], c["num"], c["seed"])
+    num, cat, click = SO.seeded_dlrm_batch(sizes_dev, c["num"], c["batch"], c["seed"] + 1)
+    off = np.concatenate([[0], np.cumsum(sizes_dev)])
+    if world == 1:
+        my = list(range(len(sizes_dev)))
+        has_bottom, vectors, batches = True, None, [c["batch"]]
+    else:
+        # position of this rank's tables inside the device-ordered list
+        start = sum(len(b) for b in mapping2["embedding"][:rank])
+        my = list(range(start, start + len(mapping2["embedding"][rank])))
+        has_bottom = rank == mapping2["bottom_mlp"]
+        vectors = mapping2["vectors_per_gpu"]
+        batches = P.get_gpu_batch_sizes(c["batch"], world)
+    torch.manual_seed(300 + rank)
+    model = DistributedDlrm(num_numerical_features=c["num"], categorical_feature_sizes=[sizes_dev[i] for i in my],
+                            bottom_mlp_sizes=c["bottom"] if has_bottom else None, top_mlp_sizes=c["top"],
+                            vectors_per_gpu=vectors, embedding_device_mapping=mapping2["embedding"] if world > 1 else None,
+                            world_num_categorical_features=len(sizes_dev), embedding_dim=c["dim"], device=dev,
+                            compute_dtype=torch.float16, world_size=world)
+    with torch.no_grad():
+        if has_bottom:
+            for i, l in enumerate(model.bottom_model.mlp.linears):
+                l.weight.copy_(state["bottom_mlp.%d.weight" % i]); l.bias.copy_(state["bottom_mlp.%d.bias" % i])
+        if rank == 0:                                        # the data-parallel top MLP: only rank 0 gets the seeded weights
+            for i, l in enumerate(model.top_model.mlp.linears):
+                l.weight.copy_(state["top_mlp.%d.weight" % i]); l.bias.copy_(state["top_mlp.%d.bias" % i])
+            model.top_model.out.weight.copy_(state["out.weight"]); model.top_model.out.bias.copy_(state["out.bias"])
+        if my:
+            rows = np.concatenate([np.arange(off[i], off[i + 1]) for i in my])
+            model.bottom_model.embeddings.weight.copy_(state["embedding"][torch.from_numpy(rows)])
+    model.refresh_working_copies()
+    tr = DlrmTrainer(model, lr=c["lr"], batch_sizes_per_gpu=batches, vectors_per_gpu=vectors, rank=rank,
+                     world_size=world, amp=True)
+    numd = num.to(dev) if has_bottom else None
+    catd = cat[:, my].contiguous().to(dev) if my else None
+    clickd = click.to(dev)
+    losses = []
+    for _ in range(steps):
+        loss = tr.train_step(numd, catd, clickd)
+        if world > 1:
+            from deeplearningexamples_amd.utils import comm
+            loss = comm.allreduce_mean_(loss.clone())        # equal per-rank batch sizes -> mean of means
+        losses.append(float(loss.item()))
+    probe = model.top_model.out.weight.detach().float().cpu().numpy().reshape(-1)[:8].tolist()
+    return {"losses": losses, "probe": probe}
+
+
+SCENARIOS = {"bert": run_bert, "rn50": run_rn50, "dlrm": run_dlrm}
+
+
+def main():
+    scenario, backend, out = sys.argv[1:4]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    kw = {"device_id": dev} if backend == "nccl" else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    res = SCENARIOS[scenario](rank, world, dev, 3)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, res)
+    if rank == 0:
+        json.dump(gathered, open(out, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

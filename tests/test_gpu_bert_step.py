@@ -23,17 +23,24 @@ def _build(cuda, dtype, c, state, p_hidden=0.0, p_attn=0.0):
     return model, tr
 
 
+CONFIGS = {"tiny": ("BERT_STEP_CONFIG", "bert_step.npz"),
+           # one encoder layer at BERT-LARGE width: hidden 1024, 16 heads, FFN 4096, vocabulary 30528, S = 128 -- the
+           # GEMM / attention / LayerNorm shapes of BASELINE.json configs[2]
+           "large1l": ("BERT_STEP_CONFIG_LARGE", "bert_step_large1l.npz")}
+
+
+@pytest.mark.parametrize("which", ["tiny", "large1l"])
 @pytest.mark.parametrize("dtype,bar", [(torch.float16, 1e-3), (torch.bfloat16, 3e-3)])
-def test_bert_losses_match_reference(cuda, golden_dir, dtype, bar):
-    c = BO.BERT_STEP_CONFIG
-    gold = np.load(os.path.join(golden_dir, "bert_step.npz"))
+def test_bert_losses_match_reference(cuda, golden_dir, dtype, bar, which):
+    c = getattr(BO, CONFIGS[which][0])
+    gold = np.load(os.path.join(golden_dir, CONFIGS[which][1]))
     state = BO.seeded_state(c["cfg"], c["seed"])
     model, tr = _build(cuda, dtype, c, state)
     batch = [t.to(cuda) for t in BO.seeded_batch(c["cfg"], c["seed"] + 1, c["batch"])]
     losses = [float(tr.train_step(*batch).item()) for _ in range(c["steps"])]
     print(dtype, "losses", losses, "reference", gold["losses"].tolist())
     np.testing.assert_allclose(losses, gold["losses"], rtol=bar)
-    assert losses[-1] < losses[0] - 0.2
+    assert losses[-1] < losses[0] - (0.2 if which == "tiny" else 0.0)
     named = dict(model.named_parameters())
     ref = gold["final_pooler_bias"]
     assert np.abs(named["bert.pooler.dense_act.bias"].detach().cpu().numpy() - ref).max() <= 0.05 * np.abs(ref).max() + 1e-4
@@ -42,9 +49,10 @@ def test_bert_losses_match_reference(cuda, golden_dir, dtype, bar):
     assert np.abs(got - ref).max() <= 0.05 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("which", ["tiny", "large1l"])
 @pytest.mark.parametrize("dtype,bar", [(torch.float16, 0.03), (torch.bfloat16, 0.12)])
-def test_bert_first_step_gradients_vs_oracle(cuda, dtype, bar):
-    c = BO.BERT_STEP_CONFIG
+def test_bert_first_step_gradients_vs_oracle(cuda, dtype, bar, which):
+    c = getattr(BO, CONFIGS[which][0])
     state = BO.seeded_state(c["cfg"], c["seed"])
     model, tr = _build(cuda, dtype, c, state)
     cpu_batch = BO.seeded_batch(c["cfg"], 99, 3)

@@ -35,7 +35,9 @@ def _scaled_grads(case, g, scale, it):
 
 def _check_against_gold(gold, case, p, m, v, p16):
     for k, (_, half) in case["shapes"].items():
-        np.testing.assert_allclose(p[k], gold["p_" + k], rtol=2e-5, atol=2e-6, err_msg=k)
+        # half parameters: the update is rounded to fp16 inside the gradient buffer (multi_tensor_lamb.cu:163), so an
+        # fp32-ulp difference upstream can flip one fp16 rounding of it: lr x trust ratio x 2^-11 |u| ~ 5e-6 absolute
+        np.testing.assert_allclose(p[k], gold["p_" + k], rtol=2e-5, atol=1e-5 if half else 2e-6, err_msg=k)
         np.testing.assert_allclose(m[k], gold["m_" + k], rtol=2e-5, atol=1e-7, err_msg=k)
         np.testing.assert_allclose(v[k], gold["v_" + k], rtol=2e-5, atol=1e-8, err_msg=k)
         if half:

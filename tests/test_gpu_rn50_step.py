@@ -4,7 +4,9 @@
 Configuration: batch 32, 64x64 synthetic images, seeded weights with damped residual branches (bn3 gamma in
 0.1..0.3 -- with gamma ~ 1 a random-init ResNet-50 amplifies 16-bit rounding ~20x and is chaotic from step to
 step, measured in oracle/resnet_oracle.py; the damped network is well conditioned: fixture `sensitivity` ~1e-7).
-Tolerances (relative, per-step loss): fp16 1e-3 (BASELINE north_star), bf16 4e-3 (3 fewer mantissa bits)."""
+Tolerance (relative, per-step loss): 1e-3 (BASELINE north_star) + the 16-bit STORAGE floor of this network for the
+dtype at that step, as the oracle measured it when the fixture was made (golden `losses_<dtype>_storage`: the same
+fp32 math with every tensor the AMP path keeps in 16 bits rounded where it is produced; fp16 <= 4e-5, bf16 <= 7.5e-4)."""
 import os
 
 import numpy as np
@@ -26,8 +28,8 @@ def _build(cuda, dtype, lr, state):
     return model, tr
 
 
-@pytest.mark.parametrize("dtype,bar", [(torch.float16, 1e-3), (torch.bfloat16, 4e-3)])
-def test_rn50_losses_match_reference(cuda, golden_dir, dtype, bar):
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_rn50_losses_match_reference(cuda, golden_dir, dtype):
     c = RO.RN50_STEP_CONFIG
     gold = np.load(os.path.join(golden_dir, "rn50_step.npz"))
     assert gold["sensitivity"].max() < 1e-5            # the configuration itself is not chaotic
@@ -36,8 +38,11 @@ def test_rn50_losses_match_reference(cuda, golden_dir, dtype, bar):
     x, y = RO.seeded_batch(c["seed"] + 100, c["batch"], c["size"])
     x, y = x.to(cuda), y.to(cuda)
     losses = [float(tr.train_step(x, y).item()) for _ in range(c["steps"])]
-    print(dtype, "losses", losses, "reference", gold["losses"].tolist())
-    np.testing.assert_allclose(losses, gold["losses"], rtol=bar)
+    ref = gold["losses"]
+    floor = np.abs(gold["losses_%s_storage" % ("fp16" if dtype == torch.float16 else "bf16")] - ref) / ref
+    rel = np.abs(np.asarray(losses) - ref) / ref
+    print(dtype, "losses", losses, "reference", ref.tolist(), "rel err", rel.tolist(), "storage floor", floor.tolist())
+    assert np.all(rel <= 1e-3 + floor), (rel, floor)
     assert losses[-1] < losses[0]
     tr.sync_counters()
     assert int(model.bn1.num_batches_tracked.item()) == c["steps"]
