@@ -63,6 +63,8 @@ class BertTrainer:
         # benchmark / graph-captured input buffers, run_pretraining.py:602-640) -- only then are the masked-row indices
         # of a batch reused; by default they are rebuilt at every step (a loader may refill the same addresses)
         self.static_batch = static_batch
+        self.fused_attention = True     # False: batched GEMMs + softmax kernels (also taken for shapes outside the fused envelope)
+        self.keep_activations = False   # tests: keep the dropout keep masks of the last step
         model.fuse_qkv_storage()
         if world_size > 1:
             # replicas start from rank 0's weights (torch DDP's constructor, run_pretraining.py:455-460)
@@ -207,22 +209,31 @@ class BertTrainer:
             x, mask0 = F.dropout_fwd(x, ph, seed, self._next_offset())
         sv = {"ids": ids, "tt": tts, "z0": z0, "ln0": (mean0, rstd0), "mask0": mask0, "layers": [], "b": b, "s": s}
         scale = 1.0 / math.sqrt(d)
+        fused_attn = self.fused_attention and F.attention_supported(s, d)
+        sv["fused_attn"] = fused_attn
         for l, layer in enumerate(m.bert.encoder.layer):
             pre = "bert.encoder.layer.%d." % l
             att = layer.attention
             qkv = F.gemm(x, layer.qkv16, t, 3 * h, h, True, True, bias=layer.qkv_bias)
-            probs = torch.empty((b * nh, s, s), dtype=dt, device=self.dev)
-            F.gemm_batched(qkv, qkv[:, h:], probs, s, s, d, 3 * h, 3 * h, s, True, True, b * nh, nh,
-                           (s * 3 * h, d), (s * 3 * h, d), (nh * s * s, s * s))
+            probs = pdrop = stats = None
             mask_a, mask_1, mask_2 = None, None, None
-            if pa > 0:
-                pdrop, mask_a = F.softmax_dropout_fwd_(probs, self._mask_add, nh * s, scale, pa, seed, self._next_offset())
+            off_a = self._next_offset() if pa > 0 else 0
+            if fused_attn:
+                # QK^T, scale + mask, softmax, dropout and P V in one kernel: no [B, heads, S, S] tensor in HBM
+                ctx, stats, mask_a = F.attention_fwd(qkv, self._mask_add, b, s, nh, scale, pa, seed, off_a,
+                                                     want_mask=self.keep_activations)
             else:
-                F.softmax_fwd_(probs, self._mask_add, nh * s, scale)
-                pdrop = probs
-            ctx = torch.empty((t, h), dtype=dt, device=self.dev)
-            F.gemm_batched(pdrop, qkv[:, 2 * h:], ctx, s, d, s, s, 3 * h, h, True, False, b * nh, nh,
-                           (nh * s * s, s * s), (s * 3 * h, d), (s * h, d))
+                probs = torch.empty((b * nh, s, s), dtype=dt, device=self.dev)
+                F.gemm_batched(qkv, qkv[:, h:], probs, s, s, d, 3 * h, 3 * h, s, True, True, b * nh, nh,
+                               (s * 3 * h, d), (s * 3 * h, d), (nh * s * s, s * s))
+                if pa > 0:
+                    pdrop, mask_a = F.softmax_dropout_fwd_(probs, self._mask_add, nh * s, scale, pa, seed, off_a)
+                else:
+                    F.softmax_fwd_(probs, self._mask_add, nh * s, scale)
+                    pdrop = probs
+                ctx = torch.empty((t, h), dtype=dt, device=self.dev)
+                F.gemm_batched(pdrop, qkv[:, 2 * h:], ctx, s, d, s, s, 3 * h, h, True, False, b * nh, nh,
+                               (nh * s * s, s * s), (s * 3 * h, d), (s * h, d))
             ao = F.gemm(ctx, self.w16[pre + "attention.output.dense.weight"], t, h, h, True, True,
                         bias=att.output.dense.bias.data)
             if ph > 0:
@@ -241,7 +252,7 @@ class BertTrainer:
                                                                       self._next_offset())
             else:
                 x2, z2, m2, r2 = F.layernorm_fwd(o2, layer.output.LayerNorm.weight.data, layer.output.LayerNorm.bias.data, residual=x1)
-            sv["layers"].append(dict(x=x, qkv=qkv, probs=probs, pdrop=pdrop, ctx=ctx, z1=z1, ln1=(m1, r1), x1=x1,
+            sv["layers"].append(dict(x=x, qkv=qkv, probs=probs, pdrop=pdrop, stats=stats, off_a=off_a, ctx=ctx, z1=z1, ln1=(m1, r1), x1=x1,
                                      pre=pre_act, it=it, z2=z2, ln2=(m2, r2), mask_a=mask_a, mask_1=mask_1, mask_2=mask_2))
             x = x2
         sv["seq"] = x
@@ -346,20 +357,24 @@ class BertTrainer:
             self._bgrad(pre + "attention.output.dense.bias", dao, acc)
             dctx = F.gemm(dao, self.w16[pre + "attention.output.dense.weight"], t, h, h, True, False)
             qkv, probs = a["qkv"], a["probs"]
-            dprobs = torch.empty_like(probs)
-            F.gemm_batched(dctx, qkv[:, 2 * h:], dprobs, s, s, d, h, 3 * h, s, True, True, b * nh, nh,
-                           (s * h, d), (s * 3 * h, d), (nh * s * s, s * s))
-            if a["mask_a"] is not None:
-                F.softmax_dropout_bwd_(probs, dprobs, a["mask_a"], scale, self.p_attn)
+            if sv["fused_attn"]:
+                dqkv = F.attention_bwd(qkv, dctx, self._mask_add, a["stats"], b, s, nh, scale, self.p_attn,
+                                       self.rng_seed, a["off_a"])
             else:
-                F.softmax_bwd_(probs, dprobs, scale)
-            dqkv = torch.empty((t, 3 * h), dtype=dt, device=self.dev)
-            F.gemm_batched(dprobs, qkv[:, h:], dqkv, s, d, s, s, 3 * h, 3 * h, True, False, b * nh, nh,
-                           (nh * s * s, s * s), (s * 3 * h, d), (s * 3 * h, d))                         # dQ = dS K
-            F.gemm_batched(dprobs, qkv, dqkv[:, h:], s, d, s, s, 3 * h, 3 * h, False, False, b * nh, nh,
-                           (nh * s * s, s * s), (s * 3 * h, d), (s * 3 * h, d))                         # dK = dS^T Q
-            F.gemm_batched(a["pdrop"], dctx, dqkv[:, 2 * h:], s, d, s, s, h, 3 * h, False, False, b * nh, nh,
-                           (nh * s * s, s * s), (s * h, d), (s * 3 * h, d))                             # dV = dropout(P)^T dO
+                dprobs = torch.empty_like(probs)
+                F.gemm_batched(dctx, qkv[:, 2 * h:], dprobs, s, s, d, h, 3 * h, s, True, True, b * nh, nh,
+                               (s * h, d), (s * 3 * h, d), (nh * s * s, s * s))
+                if a["mask_a"] is not None:
+                    F.softmax_dropout_bwd_(probs, dprobs, a["mask_a"], scale, self.p_attn)
+                else:
+                    F.softmax_bwd_(probs, dprobs, scale)
+                dqkv = torch.empty((t, 3 * h), dtype=dt, device=self.dev)
+                F.gemm_batched(dprobs, qkv[:, h:], dqkv, s, d, s, s, 3 * h, 3 * h, True, False, b * nh, nh,
+                               (nh * s * s, s * s), (s * 3 * h, d), (s * 3 * h, d))                         # dQ = dS K
+                F.gemm_batched(dprobs, qkv, dqkv[:, h:], s, d, s, s, 3 * h, 3 * h, False, False, b * nh, nh,
+                               (nh * s * s, s * s), (s * 3 * h, d), (s * 3 * h, d))                         # dK = dS^T Q
+                F.gemm_batched(a["pdrop"], dctx, dqkv[:, 2 * h:], s, d, s, s, h, 3 * h, False, False, b * nh, nh,
+                               (nh * s * s, s * s), (s * h, d), (s * 3 * h, d))                             # dV = dropout(P)^T dO
             gq = self.gview[pre + "attention.self.query.weight"]
             gqkv = torch.as_strided(gq, (3 * h, h), (h, 1))
             F.gemm(dqkv, a["x"], 3 * h, h, t, False, False, out=gqkv, splitk=F.pick_splitk(3 * h, h, t, 1024), accumulate=acc)
@@ -380,7 +395,7 @@ class BertTrainer:
         F.colsum(dz0.view(b, s * h), out=gpos[:s].view(-1), accumulate=acc)
         F.rows_select_sum(dz0, sv["tt"], cfg["type_vocab"], self.gview["bert.embeddings.token_type_embeddings.weight"], acc)
         self._grads_final(("bert.embeddings.",))
-        self._last_sv = sv if getattr(self, "keep_activations", False) else None     # tests read the dropout masks
+        self._last_sv = sv if self.keep_activations else None     # tests read the dropout masks
         self._sv = None
 
     def _grads_final(self, prefixes):

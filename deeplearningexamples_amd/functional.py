@@ -729,6 +729,49 @@ def softmax_dropout_bwd_(probs, dprobs, mask, scale, p):
     return dprobs
 
 
+def attention_supported(seq_len, head_dim):
+    """True when the fused attention kernels cover (seq_len, head_dim); otherwise use the batched-GEMM path."""
+    return bool(C.lib().dle_attention_supported(int(seq_len), int(head_dim)))
+
+
+def attention_fwd(qkv, mask_add, batch, seq_len, heads, scale, p=0.0, seed=0, offset=0, want_mask=False):
+    """context = dropout(softmax(q k^T * scale + mask_add)) v for every (sequence, head) of qkv [T, 3H] in ONE kernel
+    (BertSelfAttention.forward, modeling.py:340-384).  -> (ctx [T, H], stats [B*heads, S, 2] fp32, keep mask or None)."""
+    C.require_cuda(qkv, mask_add)
+    t, h3 = qkv.shape
+    h = h3 // 3
+    d = h // heads
+    if not qkv.is_contiguous() or t != batch * seq_len or heads * d * 3 != h3:
+        raise ValueError("attention_fwd: qkv must be a contiguous [batch * seq_len, 3 * heads * head_dim] tensor")
+    ctx = torch.empty((t, h), dtype=qkv.dtype, device=qkv.device)
+    stats = torch.empty((batch * heads, seq_len, 2), dtype=torch.float32, device=qkv.device)
+    mask = torch.empty(batch * heads * seq_len * seq_len // 8, dtype=torch.uint8, device=qkv.device) \
+        if (want_mask and p > 0) else None
+    bh = batch * heads
+    C.annotate(flops=4.0 * bh * seq_len * seq_len * d, bytes=float(t) * h * 2 * 4 + stats.numel() * 4,
+               tag="B%dxh%dxS%dxd%d" % (batch, heads, seq_len, d))
+    C.call("dle_attention_fwd", C.ptr(qkv), C.ptr(mask_add), C.ptr(ctx), C.ptr(stats), C.ptr(mask), batch, seq_len,
+           heads, d, float(scale), float(p), int(seed), int(offset), C.dt(qkv), C.stream())
+    return ctx, stats, mask
+
+
+def attention_bwd(qkv, dctx, mask_add, stats, batch, seq_len, heads, scale, p=0.0, seed=0, offset=0):
+    """dqkv [T, 3H] from dctx [T, H]: probabilities and dropout mask are recomputed from (qkv, stats, seed, offset)."""
+    C.require_cuda(qkv, dctx, mask_add, stats)
+    t, h3 = qkv.shape
+    h = h3 // 3
+    d = h // heads
+    if not qkv.is_contiguous() or not dctx.is_contiguous() or dctx.shape != (t, h):
+        raise ValueError("attention_bwd: qkv [T, 3H] and dctx [T, H] must be contiguous")
+    dqkv = torch.empty_like(qkv)
+    bh = batch * heads
+    C.annotate(flops=10.0 * bh * seq_len * seq_len * d, bytes=float(t) * h * 2 * 7 + stats.numel() * 4,
+               tag="B%dxh%dxS%dxd%d" % (batch, heads, seq_len, d))
+    C.call("dle_attention_bwd", C.ptr(qkv), C.ptr(dctx), C.ptr(mask_add), C.ptr(stats), C.ptr(dqkv), batch, seq_len,
+           heads, d, float(scale), float(p), int(seed), int(offset), C.dt(qkv), C.stream())
+    return dqkv
+
+
 def unpack_dropout_mask(mask, shape):
     """Bit-packed keep mask -> bool tensor of `shape` (bit k of byte i <-> flat element 8 i + k)."""
     bits = (mask.to(torch.int32).unsqueeze(1) >> torch.arange(8, device=mask.device, dtype=torch.int32)) & 1

@@ -51,26 +51,31 @@ def broadcast_(t: torch.Tensor, src=0, group=None):
     return t
 
 
+def _pairwise_exchange_host(ho, hi, out_splits, in_splits, group=None):
+    """The all-to-all on HOST tensors by pairwise send / recv of the raw bytes: gloo has no all-to-all for every dtype
+    and its scatter wants equal blocks (the blocks of a table-wise DLRM placement differ from rank to rank)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    outs = list(ho.view(-1).split(list(out_splits)))
+    ins = [c.contiguous() for c in hi.view(-1).split(list(in_splits))]
+    reqs = []
+    for r in range(world):
+        if r == rank:
+            outs[r].copy_(ins[r])
+            continue
+        if ins[r].numel():
+            reqs.append(dist.isend(ins[r].view(torch.uint8), dst=r, group=group))
+        if outs[r].numel():
+            reqs.append(dist.irecv(outs[r].view(torch.uint8), src=r, group=group))
+    for q in reqs:
+        q.wait()
+    return ho
+
+
 def all_to_all_single(out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits, group=None):
     """torch.distributed.all_to_all_single with element split lists (DLRM bottom -> top exchange and its reverse)."""
     if _staged(out, group):
-        world = dist.get_world_size(group)
-        ho, hi = torch.empty(out.shape, dtype=out.dtype), inp.detach().cpu()
-        # gloo has no all-to-all for every dtype: pairwise scatter of the send blocks does the same exchange
-        outs = list(ho.view(-1).split(list(out_splits)))
-        ins = [c.contiguous() for c in hi.view(-1).split(list(in_splits))]
-        rank = dist.get_rank(group)
-        for r in range(world):
-            # rank r scatters its blocks; every rank receives the block addressed to it
-            recv = torch.empty(outs[r].shape, dtype=ho.dtype)
-            if outs[r].dtype in (torch.float16, torch.bfloat16):
-                recv32 = torch.empty(outs[r].shape, dtype=torch.float32)
-                dist.scatter(recv32, [c.float() for c in ins] if rank == r else None, src=r, group=group)
-                recv = recv32.to(ho.dtype)
-            else:
-                dist.scatter(recv, ins if rank == r else None, src=r, group=group)
-            outs[r].copy_(recv)
-        out.copy_(ho)
+        ho = torch.empty(out.shape, dtype=out.dtype)
+        out.copy_(_pairwise_exchange_host(ho, inp.detach().cpu(), out_splits, in_splits, group))
     else:
         dist.all_to_all_single(out, inp, list(out_splits), list(in_splits), group=group)
     return out

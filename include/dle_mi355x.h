@@ -290,6 +290,21 @@ int dle_softmax_dropout_fwd(void* scores, void* dropped, void* mask, const float
 int dle_softmax_dropout_bwd(const void* probs, void* dprobs, const void* mask, int64_t rows, int L, float scale,
                             float p, int dtype, hipStream_t stream);
 
+/* ---- fused self-attention (S = 128, 64-wide heads): replaces BertSelfAttention.forward between the QKV and the output
+ * projection, LanguageModeling/BERT/modeling.py:340-384 (torch.bmm + softmax + nn.Dropout + torch.bmm) and its autograd
+ * backward.  qkv [T = B*S, 3H] (q | k | v, head h at columns h*64 of each third), ctx / dctx [T, H], dqkv [T, 3H];
+ * mask_add fp32 [B, S] (0 / -10000) or NULL; stats fp32 [B*heads, S, 2] = (row max, 1 / row sum) saved for backward;
+ * keep_mask (optional, B*heads*S*S/8 bytes) = the dropout keep bits in the layout of dle_softmax_dropout_fwd.  The
+ * backward regenerates probabilities and mask from (qkv, stats, seed, offset): nothing of shape [B, heads, S, S] is
+ * stored.  dle_attention_supported: 1 when (S, head_dim) is inside the kernels' envelope. */
+int dle_attention_supported(int S, int head_dim);
+int dle_attention_fwd(const void* qkv, const float* mask_add, void* ctx, float* stats, void* keep_mask, int B, int S,
+                      int heads, int head_dim, float scale, float p, uint64_t seed, uint64_t offset, int dtype,
+                      hipStream_t stream);
+int dle_attention_bwd(const void* qkv, const void* dctx, const float* mask_add, const float* stats, void* dqkv, int B,
+                      int S, int heads, int head_dim, float scale, float p, uint64_t seed, uint64_t offset, int dtype,
+                      hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

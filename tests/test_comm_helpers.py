@@ -32,13 +32,17 @@ def _worker(rank, world, port, q):
     out = torch.empty(sum(recv_splits))
     comm.all_to_all_single(out, inp, recv_splits, send_splits)
     exp = torch.cat([torch.full((n,), 10.0 * s + rank) for s, n in enumerate(recv_splits)])
+    # the host-staged form used for device tensors on a gloo group (two ranks on one GPU): uneven blocks, 16-bit payload
+    out16 = comm._pairwise_exchange_host(torch.empty(sum(recv_splits), dtype=torch.bfloat16), inp.to(torch.bfloat16),
+                                         recv_splits, send_splits)
+    staged_ok = bool(torch.equal(out16, exp.to(torch.bfloat16)))
     # reverse buckets: parameters complete from the END of the flat buffer
     names = [("a", 300), ("b", 200), ("c", 500), ("d", 100)]
     g = torch.full((1100,), float(rank))
     b = GradBuckets(g, names, bucket_mb=0.001, reverse=True)
     fired = [n for n, _ in reversed(names) if b.grad_ready(n)]
     b.wait()
-    q.put((rank, ok_bcast, t.tolist(), f.item(), bool(torch.equal(out, exp)), fired, bool(torch.all(g == 0.5)),
+    q.put((rank, ok_bcast, t.tolist(), f.item(), bool(torch.equal(out, exp)) and staged_ok, fired, bool(torch.all(g == 0.5)),
            [(s, e) for s, e, _ in b.buckets]))
     dist.barrier()
     dist.destroy_process_group()

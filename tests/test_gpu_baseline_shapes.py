@@ -100,17 +100,18 @@ def test_dlrm_embeddings_full_criteo_row_ranges(cuda):
     off = np.concatenate([[0], np.cumsum(SIZES)]).astype(np.int64)
     total = int(off[-1])
     # table content = a cheap closed form of (row, column), so any row can be re-derived on the host without a
-    # 16.7 GB copy: w[r, j] = ((r * 131 + j * 7) mod 8191) / 8191 - 0.5
+    # 16.7 GB copy: w[r, j] = ((r * 131 + j * 7) mod 8191) / 8192 - 0.5 (a power-of-two divisor: exact in fp32 on
+    # both sides; torch's GPU division by 8191 is not correctly rounded)
     rows = torch.arange(total, device=cuda, dtype=torch.int64)
     wtab = torch.empty((total, d), dtype=torch.float32, device=cuda)
     cols = torch.arange(d, device=cuda, dtype=torch.int64)[None, :] * 7
     chunk = 1 << 22
     for s in range(0, total, chunk):
         e = min(s + chunk, total)
-        wtab[s:e] = ((rows[s:e, None] * 131 + cols) % 8191).to(torch.float32) / 8191.0 - 0.5
+        wtab[s:e] = ((rows[s:e, None] * 131 + cols) % 8191).to(torch.float32) / 8192.0 - 0.5
 
     def host_rows(r):
-        return (((r[:, None] * 131 + np.arange(d)[None, :] * 7) % 8191).astype(np.float32) / np.float32(8191.0)
+        return (((r[:, None] * 131 + np.arange(d)[None, :] * 7) % 8191).astype(np.float32) / np.float32(8192.0)
                 - np.float32(0.5)).astype(np.float32)
 
     g = torch.Generator().manual_seed(7)

@@ -11,6 +11,6 @@ for w in "${@:-rn50 bert dlrm}"; do
     (cd $R && rocprofv3 --kernel-trace --stats -d $out -o x -- python bench.py --workload $ww --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-timer > $R/gpurun_out/prof_${tag}_$ww.json 2> $R/gpurun_out/prof_${tag}_$ww.err)
     db=$(find $out -name '*.db' | head -1)
     python $R/tools/rocpd_stats.py $db > $R/gpurun_out/${tag}_${ww}_kernel_stats.txt 2>&1
-    find $out -name '*.db' -size +40M -delete
+    rm -rf $out     # raw traces stay on the box: gpurun_out/ is capped at 64 MiB
   done
 done
