@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdle_mi355x.so")
 
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_ADD, ACT_GELU_BWD, ACT_TANH, ACT_TANH_BWD = 0, 1, 2, 3, 4, 5, 6, 7
+ACT_ADD_MASKED, ACT_MUL, ACT_GELU_DAUX = 8, 9, 10
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 

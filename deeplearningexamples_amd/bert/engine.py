@@ -242,9 +242,10 @@ class BertTrainer:
                                                                       self._next_offset())
             else:
                 x1, z1, m1, r1 = F.layernorm_fwd(ao, att.output.LayerNorm.weight.data, att.output.LayerNorm.bias.data, residual=x)
+            # the epilogue leaves gelu'(pre-activation) behind (not the pre-activation): the backward GEMM multiplies
             pre_act = torch.empty((t, inter), dtype=dt, device=self.dev)
             it = F.gemm(x1, self.w16[pre + "intermediate.dense_act.weight"], t, inter, h, True, True,
-                        bias=layer.intermediate.dense_act.bias.data, act=C.ACT_GELU, aux=pre_act)
+                        bias=layer.intermediate.dense_act.bias.data, act=C.ACT_GELU_DAUX, aux=pre_act)
             o2 = F.gemm(it, self.w16[pre + "output.dense.weight"], t, h, inter, True, True, bias=layer.output.dense.bias.data)
             if ph > 0:
                 x2, z2, m2, r2, mask_2 = F.dropout_add_layernorm_fwd(o2, layer.output.LayerNorm.weight.data,
@@ -343,7 +344,7 @@ class BertTrainer:
             do2 = F.dropout_bwd(dz2, a["mask_2"], self.p_hidden) if a["mask_2"] is not None else dz2
             self._wgrad(pre + "output.dense.weight", do2, a["it"], acc)
             self._bgrad(pre + "output.dense.bias", do2, acc)
-            dpre = F.gemm(do2, self.w16[pre + "output.dense.weight"], t, inter, h, True, False, act=C.ACT_GELU_BWD,
+            dpre = F.gemm(do2, self.w16[pre + "output.dense.weight"], t, inter, h, True, False, act=C.ACT_MUL,
                           mask_src=a["pre"])
             self._wgrad(pre + "intermediate.dense_act.weight", dpre, a["x1"], acc)
             self._bgrad(pre + "intermediate.dense_act.bias", dpre, acc)

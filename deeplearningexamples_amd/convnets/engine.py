@@ -193,14 +193,19 @@ class ResNetTrainer:
         gp = F.gemm(dlogits, fcw, n, fcw.shape[1], fcw.shape[0], True, False)
         g = F.avgpool_bwd(gp, self._feat_hw)
         for (u1, u2, u3, ud) in reversed(self.blocks):
-            g3, gskip = u3.backward(g, want_skip_grad=True)
+            # the block ends in relu(bn3(conv3) + shortcut): g * (out > 0) flows into BOTH branches.  It is never written:
+            # bn3's backward applies the mask on load, the shortcut side gets (g, mask) and applies it where it is consumed
+            mask3 = u3.relu_mask()
+            g3 = u3.backward(g)
             self._done(u3)
             if ud is not None:
-                gskip, _ = ud.backward(gskip)
+                gskip = ud.backward(g, dy_mask=mask3)
                 self._done(ud)
-            g2, _ = u2.backward(g3)
+            else:
+                gskip = (g, mask3)
+            g2 = u2.backward(g3)
             self._done(u2)
-            g, _ = u1.backward(g2, dx_addend=gskip)
+            g = u1.backward(g2, dx_addend=gskip)
             self._done(u1)
         g = F.maxpool_bwd(g, self._amax, self._pool_in_hw)
         self.stem.backward(g, need_dx=False)

@@ -56,13 +56,17 @@ class ConvBN:
         self.saved = (x, t, mask, mean, rstd)
         return y
 
-    def backward(self, dy, need_dx=True, dx_addend=None, want_skip_grad=False):
-        """dy: gradient w.r.t. the unit's output.  Returns (dx or None, skip-branch gradient or None)."""
+    def backward(self, dy, need_dx=True, dx_addend=None, dy_mask=None):
+        """dy: gradient w.r.t. the unit's output; dy_mask (optional): bit-packed keep bits to apply to dy first (the
+        ReLU that follows the residual add sits on the OTHER branch's unit: its mask gates this branch's gradient too).
+        dx_addend: a tensor, or (tensor, keep bits) = the residual-branch gradient dy * (y > 0) that is never
+        materialised: the data-gradient GEMM adds it under the mask in its epilogue.  Returns dx or None."""
         x, t, mask, mean, rstd = self.saved
         self.saved = None
-        gt, gskip = F.bn_bwd(dy, None, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta,
-                             want_skip_grad=want_skip_grad, relu_mask=mask if self.relu else None)
+        rmask = mask if self.relu else dy_mask
+        gt, _ = F.bn_bwd(dy, None, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta, relu_mask=rmask)
         n, h, w, c = x.shape
+        masked = isinstance(dx_addend, tuple)
         if self.k == 1 and self.stride == 1:
             m = n * h * w
             g2, x2 = gt.view(m, self.cout), x.view(m, c)
@@ -70,13 +74,22 @@ class ConvBN:
                    splitk=F.pick_splitk(self.cout, c, m, target_blocks=1024))
             dx = None
             if need_dx:
-                dx = F.gemm(g2, self.w16.view(self.cout, c), m, c, self.cout, True, False,
-                            act=C.ACT_ADD if dx_addend is not None else C.ACT_NONE,
-                            mask_src=dx_addend.view(m, c) if dx_addend is not None else None).view(n, h, w, c)
+                if masked:
+                    dx = F.gemm(g2, self.w16.view(self.cout, c), m, c, self.cout, True, False, act=C.ACT_ADD_MASKED,
+                                mask_src=dx_addend[0].view(m, c), aux=dx_addend[1]).view(n, h, w, c)
+                else:
+                    dx = F.gemm(g2, self.w16.view(self.cout, c), m, c, self.cout, True, False,
+                                act=C.ACT_ADD if dx_addend is not None else C.ACT_NONE,
+                                mask_src=dx_addend.view(m, c) if dx_addend is not None else None).view(n, h, w, c)
         else:
+            assert not masked, "masked residual gradients enter through the 1x1 convolution of a bottleneck"
             F.conv2d_wgrad(gt, x, (self.k, self.k), self.stride, self.pad, out=self.gw)
             dx = F.conv2d_dgrad(gt, self.w16, (h, w), self.stride, self.pad, addend=dx_addend) if need_dx else None
-        return dx, gskip
+        return dx
+
+    def relu_mask(self):
+        """Keep bits of this unit's output ReLU (valid between forward and backward)."""
+        return self.saved[2]
 
 
 class Bottleneck(nn.Module):

@@ -15,6 +15,12 @@
 template <int DT> __device__ __forceinline__ float up16(unsigned short u) { return Elem<DT>::to_f32(u); }
 template <int DT> __device__ __forceinline__ unsigned short dn16(float f) { return Elem<DT>::from_f32(f); }
 
+// Streaming reads on this chip peak with FEW loads in flight per lane once ~1000 workgroups are resident (a read-only
+// sweep: 6.4 TB/s with 1-2 loads per lane, 4.8-5.3 with 8: tools/probes/read_bw.hip); tools/kbench/bn_bench on the
+// batch-256 ResNet-50 shapes: forward apply 2.83 -> 2.58 ms / step, backward apply 3.84 -> 3.62 with one trip, 1024 workgroups.
+static int g_bn_apply_trips = 1;       // grid-stride trips in flight of the apply kernels (1 / 2 / 4 forward, 1 / 2 / 3 backward)
+static int g_bn_apply_cap = 1024;      // workgroup cap of the apply kernels
+
 static int cn_grid(long long items, int per_block, int cap = 2048) {
   long long g = (items + per_block - 1) / per_block;
   if (g > cap) g = cap;
@@ -72,7 +78,7 @@ struct BnRedArgs {
   int lpr;                      // lanes per row = pow2 >= C/8 (<= 256)
 };
 
-template <int DT, int MODE>
+template <int DT, int MODE, int UU = 0>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(BnRedArgs a) {
   __shared__ float red[2][256 * 8];
   const int cl = threadIdx.x % a.lpr, rl = threadIdx.x / a.lpr, rstep = 256 / a.lpr;
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(BnRedArgs a) {
         }
       }
     };
-    constexpr int U = MODE == 0 ? 8 : 4;          // rows in flight per lane (8 / 12 independent 16-byte loads)
+    constexpr int U = UU ? UU : (MODE == 0 ? 8 : 4);   // rows in flight per lane (U x 1..3 independent 16-byte loads)
     long long r = r0 + rl;
     for (; r + (long long)(U - 1) * rstep < r1; r += (long long)U * rstep) {
       ushort8_t xv[U], gv[U], yv[U];
@@ -191,32 +197,34 @@ __global__ __launch_bounds__(256) void bn_stats_finish_kernel(const float* __res
   }
 }
 
-// finish of MODE 1: dgamma = sum g xhat, dbeta = sum g
+// finish of MODE 1: dgamma = sum g xhat, dbeta = sum g.  A latency chain, not a bandwidth problem (<= 1024 groups x 2 x C
+// floats): 8 columns x 32 group slices per workgroup, 8 loads per stream in flight -> <= 4 dependent batches.
 __global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float* __restrict__ partial, int groups, int C,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int accumulate) {
   __shared__ double red[2][256];
-  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
   double s0 = 0.0, s1 = 0.0;
   if (c < C) {
     int g = sl;
-    for (; g + 28 < groups; g += 32) {          // 8 independent loads per stream in flight
+    for (; g + 7 * 32 < groups; g += 8 * 32) {
       float a[8], b[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { a[u] = partial[((long long)(g + 4 * u) * 2) * C + c]; b[u] = partial[((long long)(g + 4 * u) * 2 + 1) * C + c]; }
+      for (int u = 0; u < 8; ++u) { a[u] = partial[((long long)(g + 32 * u) * 2) * C + c]; b[u] = partial[((long long)(g + 32 * u) * 2 + 1) * C + c]; }
 #pragma unroll
       for (int u = 0; u < 8; ++u) { s0 += a[u]; s1 += b[u]; }
     }
-    for (; g < groups; g += 4) { s0 += partial[((long long)g * 2) * C + c]; s1 += partial[((long long)g * 2 + 1) * C + c]; }
+    for (; g < groups; g += 32) { s0 += partial[((long long)g * 2) * C + c]; s1 += partial[((long long)g * 2 + 1) * C + c]; }
   }
   red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
   __syncthreads();
   if (sl == 0 && c < C) {
-    const float t0 = (float)(red[0][cl] + red[0][64 + cl] + red[0][128 + cl] + red[0][192 + cl]);
-    const float t1 = (float)(red[1][cl] + red[1][64 + cl] + red[1][128 + cl] + red[1][192 + cl]);
-    dbeta[c] = accumulate ? dbeta[c] + t0 : t0;
-    dgamma[c] = accumulate ? dgamma[c] + t1 : t1;
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) { t0 += red[0][q * 8 + cl]; t1 += red[1][q * 8 + cl]; }
+    dbeta[c] = accumulate ? dbeta[c] + (float)t0 : (float)t0;
+    dgamma[c] = accumulate ? dgamma[c] + (float)t1 : (float)t1;
   }
 }
 
@@ -276,12 +284,33 @@ extern "C" int dle_bn_stats_from_partials(const float* partial, int groups, int6
   return 0;
 }
 
+static int g_bn_want_blocks = 1024;    // ~4 workgroups per CU
+static int g_bn_bwd_u = 2;             // rows in flight per lane of the backward reduction (2 / 4 / 8); measured on the
+                                       // batch-256 ResNet-50 shapes (tools/kbench/bn_bench): 2 -> 2.5 ms / step, 4 -> 3.1, 8 -> 5.5
+static int g_bn_lpr_cap = 32;          // lanes per row: wide layers split their columns over blockIdx.x instead of
+                                       // multiplying the row groups (the partials are groups x 2 x C floats)
+
+// Tuning knobs for A/B measurements (tools/kbench/bn_bench): target workgroup count and loads in flight of the
+// reduction kernels; values <= 0 keep the current setting.
+extern "C" int dle_bn_tune_apply(int trips, int grid_cap) {
+  if (trips > 0) g_bn_apply_trips = trips;
+  if (grid_cap > 0) g_bn_apply_cap = grid_cap;
+  return 0;
+}
+
+extern "C" int dle_bn_tune(int want_blocks, int bwd_rows_in_flight) {
+  if (want_blocks >= 100000) { g_bn_lpr_cap = want_blocks / 100000; want_blocks %= 100000; }   // cap * 100000 + blocks
+  if (want_blocks > 0) g_bn_want_blocks = want_blocks;
+  if (bwd_rows_in_flight == 2 || bwd_rows_in_flight == 4 || bwd_rows_in_flight == 8) g_bn_bwd_u = bwd_rows_in_flight;
+  return 0;
+}
+
 static int bn_reduce_geometry(long long M, int C, int& lpr, int& gx, long long& rpb, long long& gy) {
   const int cols_v = C / 8;
   lpr = 1;
-  while (lpr < cols_v && lpr < 256) lpr <<= 1;
+  while (lpr < cols_v && lpr < g_bn_lpr_cap) lpr <<= 1;
   gx = (cols_v + lpr - 1) / lpr;
-  long long want = 1024 / gx;                             // ~4 workgroups per CU
+  long long want = g_bn_want_blocks / gx;
   if (want < 1) want = 1;
   rpb = (M + want - 1) / want;
   const long long min_rows = 8LL * (256 / lpr);
@@ -322,7 +351,7 @@ extern "C" int dle_bn_fwd_stats(const void* x, int64_t M, int C, float eps, floa
 // y = act( (x - mean) * rstd * gamma + beta (+ residual) ),  act = ReLU when relu != 0
 // The grid stride (gridDim * 256 lanes) is a multiple of C/8 (a power of two <= 256 ... or any divisor of the
 // stride), so a lane keeps the SAME 8 channels for its whole sweep: scale/shift live in registers.
-template <int DT>
+template <int DT, int TR>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __restrict__ x,
                                                        const unsigned short* __restrict__ res,
                                                        unsigned short* __restrict__ y, const float* __restrict__ mean,
@@ -358,15 +387,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
   long long i = first;
   if (invariant) {
     // 4 trips in flight per lane (4-8 independent 16-byte loads): a lane alone does not cover the HBM latency
-    for (; i + 3 * stride < total8; i += 4 * stride) {
-      ushort8_t xv[4], rv[4];
+    for (; i + (TR - 1) * stride < total8; i += TR * stride) {
+      ushort8_t xv[TR], rv[TR];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < TR; ++u) {
         xv[u] = ((const ushort8_t*)x)[i + u * stride];
         if (res) rv[u] = ((const ushort8_t*)res)[i + u * stride];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) one(i + u * stride, xv[u], rv[u]);
+      for (int u = 0; u < TR; ++u) one(i + u * stride, xv[u], rv[u]);
     }
   }
   for (; i < total8; i += stride) {
@@ -389,9 +418,12 @@ extern "C" int dle_bn_fwd_apply(const void* x, const void* residual, void* y, vo
   if (M == 0) return 0;
   DLE_CHECK_ARG(x && y && mean && rstd && gamma && beta, "bn_fwd_apply: null pointer");
   const long long total8 = (long long)M * (C / 8);
-  const int grid = cn_grid(total8, 256);
-  if (dtype == DLE_F16) hipLaunchKernelGGL(bn_apply_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)residual, (unsigned short*)y, mean, rstd, gamma, beta, total8, C / 8, relu, (unsigned char*)relu_mask);
-  else hipLaunchKernelGGL(bn_apply_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)residual, (unsigned short*)y, mean, rstd, gamma, beta, total8, C / 8, relu, (unsigned char*)relu_mask);
+  const int grid = cn_grid(total8, 256, g_bn_apply_cap);
+#define BN_APP(DT, TR) hipLaunchKernelGGL((bn_apply_kernel<DT, TR>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)residual, (unsigned short*)y, mean, rstd, gamma, beta, total8, C / 8, relu, (unsigned char*)relu_mask)
+#define BN_APP_T(DT) do { if (g_bn_apply_trips == 1) BN_APP(DT, 1); else if (g_bn_apply_trips == 2) BN_APP(DT, 2); else BN_APP(DT, 4); } while (0)
+  if (dtype == DLE_F16) BN_APP_T(DLE_F16); else BN_APP_T(DLE_BF16);
+#undef BN_APP
+#undef BN_APP_T
   DLE_LAUNCH_CHECK();
   return 0;
 }
@@ -409,10 +441,13 @@ extern "C" int dle_bn_bwd_reduce(const void* dy, const void* y, const void* relu
   BnRedArgs a = {(const unsigned short*)x, (const unsigned short*)dy, (const unsigned short*)y,
                  (const unsigned char*)relu_mask, mean, rstd, (float*)workspace, (long long)M, C, rpb, lpr};
   dim3 grid(gx, (unsigned)gy), block(256);
-  if (dtype == DLE_F16) hipLaunchKernelGGL((bn_reduce_kernel<DLE_F16, 1>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((bn_reduce_kernel<DLE_BF16, 1>), grid, block, 0, stream, a);
+#define BN_RED(DT) do { if (g_bn_bwd_u == 2) hipLaunchKernelGGL((bn_reduce_kernel<DT, 1, 2>), grid, block, 0, stream, a); \
+    else if (g_bn_bwd_u == 8) hipLaunchKernelGGL((bn_reduce_kernel<DT, 1, 8>), grid, block, 0, stream, a); \
+    else hipLaunchKernelGGL((bn_reduce_kernel<DT, 1, 4>), grid, block, 0, stream, a); } while (0)
+  if (dtype == DLE_F16) BN_RED(DLE_F16); else BN_RED(DLE_BF16);
+#undef BN_RED
   DLE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, (const float*)workspace, (int)gy, C,
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, (const float*)workspace, (int)gy, C,
                      dgamma, dbeta, accumulate);
   DLE_LAUNCH_CHECK();
   return 0;
@@ -420,7 +455,7 @@ extern "C" int dle_bn_bwd_reduce(const void* dy, const void* y, const void* relu
 
 // backward pass 2: dx = gamma * rstd * (g - dbeta/M - xhat * dgamma/M), g = dy * (y > 0);
 // g_out (optional) receives g: the gradient that flows into the residual branch.
-template <int DT>
+template <int DT, int TR>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* __restrict__ dy,
                                                            const unsigned short* __restrict__ y,
                                                            const unsigned char* __restrict__ mask,
@@ -464,11 +499,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
   };
   long long i = first;
   if (invariant) {
-    for (; i + 2 * stride < total8; i += 3 * stride) {        // 3 trips = 6-9 independent 16-byte loads in flight
-      ushort8_t gv[3], xv[3], yv[3];
-      unsigned mb[3];
+    for (; i + (TR - 1) * stride < total8; i += TR * stride) {        // TR trips = 2-3 TR independent 16-byte loads in flight
+      ushort8_t gv[TR], xv[TR], yv[TR];
+      unsigned mb[TR];
 #pragma unroll
-      for (int u = 0; u < 3; ++u) {
+      for (int u = 0; u < TR; ++u) {
         gv[u] = ((const ushort8_t*)dy)[i + u * stride];
         xv[u] = ((const ushort8_t*)x)[i + u * stride];
         mb[u] = 0;
@@ -476,7 +511,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
         else if (y) yv[u] = ((const ushort8_t*)y)[i + u * stride];
       }
 #pragma unroll
-      for (int u = 0; u < 3; ++u) one(i + u * stride, gv[u], xv[u], yv[u], mb[u]);
+      for (int u = 0; u < TR; ++u) one(i + u * stride, gv[u], xv[u], yv[u], mb[u]);
     }
   }
   for (; i < total8; i += stride) {
@@ -496,9 +531,12 @@ extern "C" int dle_bn_bwd_apply(const void* dy, const void* y, const void* relu_
   DLE_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0, "bn_bwd_apply: bad shape");
   DLE_CHECK_ARG(dy && x && dx && mean && rstd && gamma && dgamma && dbeta, "bn_bwd_apply: null pointer");
   const long long total8 = (long long)M * (C / 8);
-  const int grid = cn_grid(total8, 256);
-  if (dtype == DLE_F16) hipLaunchKernelGGL(bn_bwd_apply_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned short*)y, (const unsigned char*)relu_mask, (const unsigned short*)x, (unsigned short*)dx, (unsigned short*)g_out, mean, rstd, gamma, dgamma, dbeta, total8, C / 8, 1.0f / (float)M);
-  else hipLaunchKernelGGL(bn_bwd_apply_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned short*)y, (const unsigned char*)relu_mask, (const unsigned short*)x, (unsigned short*)dx, (unsigned short*)g_out, mean, rstd, gamma, dgamma, dbeta, total8, C / 8, 1.0f / (float)M);
+  const int grid = cn_grid(total8, 256, g_bn_apply_cap);
+#define BN_BAPP(DT, TR) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, TR>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned short*)y, (const unsigned char*)relu_mask, (const unsigned short*)x, (unsigned short*)dx, (unsigned short*)g_out, mean, rstd, gamma, dgamma, dbeta, total8, C / 8, 1.0f / (float)M)
+#define BN_BAPP_T(DT) do { if (g_bn_apply_trips == 1) BN_BAPP(DT, 1); else if (g_bn_apply_trips == 2) BN_BAPP(DT, 2); else BN_BAPP(DT, 3); } while (0)
+  if (dtype == DLE_F16) BN_BAPP_T(DLE_F16); else BN_BAPP_T(DLE_BF16);
+#undef BN_BAPP
+#undef BN_BAPP_T
   DLE_LAUNCH_CHECK();
   return 0;
 }

@@ -453,9 +453,11 @@ extern "C" int dle_gemm(const void* A, const void* B, void* C, void* aux, const 
   DLE_CHECK_ARG(in_dtype == DLE_F16 || in_dtype == DLE_BF16, "gemm: inputs must be f16/bf16 (got %d)", in_dtype);
   DLE_CHECK_ARG(out_dtype == DLE_F32 || out_dtype == DLE_F16 || out_dtype == DLE_BF16, "gemm: bad out dtype");
   DLE_CHECK_ARG(!(a_kc == 0 && b_kc != 0), "gemm: (A m-contiguous, B k-contiguous) is not a hot-path layout");
-  const bool needs_src = act == ACT_RELU_BWD || act == 4 || act == 5 || act == 7;   // RELU_BWD, ADD, GELU_BWD, TANH_BWD
-  DLE_CHECK_ARG(act >= 0 && act <= 7, "gemm: unknown epilogue %d", act);
+  const bool needs_src = act == ACT_RELU_BWD || act == 4 || act == 5 || act == 7 || act == 8 || act == 9;   // RELU_BWD, ADD, GELU_BWD, TANH_BWD, ADD_MASKED, MUL
+  DLE_CHECK_ARG(act >= 0 && act <= 10, "gemm: unknown epilogue %d", act);
   DLE_CHECK_ARG(!needs_src || mask_src, "gemm: this epilogue needs mask_src");
+  DLE_CHECK_ARG(act != 8 || (aux && (ldc & 7) == 0), "gemm: the masked add reads its keep bits through aux (ldc a multiple of 8)");
+  DLE_CHECK_ARG(act != 10 || aux, "gemm: DLE_ACT_GELU_DAUX writes the derivative to aux");
   DLE_CHECK_ARG(!needs_src || out_dtype == in_dtype, "gemm: mask_src dtype = in dtype = out dtype");
   if (splitk < 1) splitk = 1;
   {

@@ -31,7 +31,10 @@
 #define GEMM2_LDS_BYTES (2 * (BM * BK + BN * BK) * 2)
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_ADD = 4, ACT_GELU_BWD = 5, ACT_TANH = 6,
-       ACT_TANH_BWD = 7 };
+       ACT_TANH_BWD = 7,
+       ACT_ADD_MASKED = 8,   // C = acc + (bit ? mask_src : 0); aux = bit-packed keep bits of the addend (INPUT, 1 bit / element)
+       ACT_MUL = 9,          // C = acc * mask_src (e.g. the GELU derivative the forward GEMM left behind)
+       ACT_GELU_DAUX = 10 }; // C = gelu(v), aux = gelu'(v) (instead of the pre-activation): the backward is a plain multiply
 
 struct Gemm2Args {
   const unsigned short* A;
@@ -59,6 +62,15 @@ __device__ __forceinline__ float gelu_tanh2(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
   const float u = k0 * (x + k1 * x * x * x);
   return 0.5f * x * (1.0f + fast_tanh(u));
+}
+// gelu(x) and d gelu / dx from one tanh
+__device__ __forceinline__ float gelu_tanh2_d(float x, float& d) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  const float x2 = x * x;
+  const float th = fast_tanh(k0 * (x + k1 * x2 * x));
+  const float hp = 0.5f * (1.0f + th);
+  d = hp + 0.5f * x * (1.f - th * th) * k0 * (1.f + 3.f * k1 * x2);
+  return x * hp;
 }
 
 // Epilogue of 8 consecutive output columns of row m (v = alpha * accumulators): split-K partials, or bias /
@@ -99,7 +111,11 @@ __device__ __forceinline__ void epi_store8(const Gemm2Args& p, float* v, int m, 
   } else if (p.act == ACT_TANH) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = fast_tanh(v[r]);
-  } else if (p.act == ACT_RELU_BWD || p.act == ACT_ADD || p.act == ACT_GELU_BWD || p.act == ACT_TANH_BWD) {
+  } else if (p.act == ACT_GELU_DAUX) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = gelu_tanh2_d(v[r], pre[r]);
+  } else if (p.act == ACT_RELU_BWD || p.act == ACT_ADD || p.act == ACT_GELU_BWD || p.act == ACT_TANH_BWD ||
+             p.act == ACT_ADD_MASKED || p.act == ACT_MUL) {
     ushort8_t sv = {0, 0, 0, 0, 0, 0, 0, 0};
     if (full) sv = *(const ushort8_t*)(p.mask_src + off);
     else
@@ -111,6 +127,11 @@ __device__ __forceinline__ void epi_store8(const Gemm2Args& p, float* v, int m, 
       const float y = yv[r];
       if (p.act == ACT_RELU_BWD) v[r] = y > 0.f ? v[r] : 0.f;
       else if (p.act == ACT_ADD) v[r] += y;
+      else if (p.act == ACT_MUL) v[r] *= y;
+      else if (p.act == ACT_ADD_MASKED) {
+        const long long e = off + r;                                     // bit index = element index of the addend
+        if (r < nval && ((((const unsigned char*)p.aux)[e >> 3] >> (e & 7)) & 1u)) v[r] += y;
+      }
       else if (p.act == ACT_TANH_BWD) v[r] *= (1.f - y * y);           // y = tanh output of the forward
       else {                                                            // y = GELU pre-activation
         const float k0 = 0.7978845608028654f, k1 = 0.044715f;
@@ -129,19 +150,20 @@ __device__ __forceinline__ void epi_store8(const Gemm2Args& p, float* v, int m, 
     } else {
       for (int r = 0; r < nval; ++r) c[r] = v[r];
     }
-    if (p.aux) {
+    if (p.aux && p.act != ACT_ADD_MASKED) {
       float* a = (float*)p.aux + off;
       for (int r = 0; r < nval; ++r) a[r] = pre[r];
     }
   } else {
     const ushort8_t o = p.out_dtype == DLE_F16 ? pack8<DLE_F16>(v) : pack8<DLE_BF16>(v);
     ushort8_t po = o;
-    if (p.aux) po = p.out_dtype == DLE_F16 ? pack8<DLE_F16>(pre) : pack8<DLE_BF16>(pre);
+    const bool side = p.aux && p.act != ACT_ADD_MASKED;
+    if (side) po = p.out_dtype == DLE_F16 ? pack8<DLE_F16>(pre) : pack8<DLE_BF16>(pre);
     unsigned short* c = (unsigned short*)p.C + off;
     if (full) *(ushort8_t*)c = o;
     else
       for (int r = 0; r < nval; ++r) c[r] = o[r];
-    if (p.aux) {
+    if (side) {
       unsigned short* a = (unsigned short*)p.aux + off;
       if (full) *(ushort8_t*)a = po;
       else
@@ -375,15 +397,17 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
   for (int r = 0; r < 8; ++r) { st0[r] = 0.f; st1[r] = 0.f; }
   auto fast_pass = [&](auto ACTC, int half) __attribute__((always_inline)) {
     constexpr int act = decltype(ACTC)::value;
-    constexpr bool needs_src = act == ACT_RELU_BWD || act == ACT_ADD || act == ACT_GELU_BWD || act == ACT_TANH_BWD;
+    constexpr bool needs_src = act == ACT_RELU_BWD || act == ACT_ADD || act == ACT_GELU_BWD || act == ACT_TANH_BWD ||
+                               act == ACT_ADD_MASKED || act == ACT_MUL;
     const float* e0 = epi + f_ml0 * TN;
     const int c4 = f_nl >> 2;
     const int olo = (c4 ^ f_ml0) << 2, ohi = ((c4 + 1) ^ f_ml0) << 2;
     const long long off0 = (long long)(m0 + half * (TM / 2) + f_ml0) * p.ldc + n0 + f_nl;
     const long long step = (long long)RPI * p.ldc;
     unsigned short* c = (unsigned short*)p.C + off0;
-    unsigned short* ax = p.aux ? (unsigned short*)p.aux + off0 : nullptr;
+    unsigned short* ax = (p.aux && act != ACT_ADD_MASKED) ? (unsigned short*)p.aux + off0 : nullptr;
     const unsigned short* ms = needs_src ? p.mask_src + off0 : nullptr;
+    const unsigned char* bits = act == ACT_ADD_MASKED ? (const unsigned char*)p.aux + (off0 >> 3) : nullptr;   // off0 % 8 == 0 (vec16)
     const int rows_left = p.M - (m0 + half * (TM / 2) + f_ml0);      // trips with it * RPI < rows_left are inside
     if (!f_col_ok) return;
 #pragma unroll
@@ -395,7 +419,14 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
       float v[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { v[r] = lo[r] + fbias[r]; v[4 + r] = hi[r] + fbias[4 + r]; }
-      if (ax) *(ushort8_t*)(ax + it * step) = pack8<DT>(v);      // pre-activation side output
+      if constexpr (act == ACT_GELU_DAUX) {
+        float dv[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = gelu_tanh2_d(v[r], dv[r]);
+        if (ax) *(ushort8_t*)(ax + it * step) = pack8<DT>(dv);   // derivative side output
+      } else if (ax) {
+        *(ushort8_t*)(ax + it * step) = pack8<DT>(v);            // pre-activation side output
+      }
       if constexpr (act == ACT_RELU) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
@@ -408,11 +439,15 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
       } else if constexpr (needs_src) {
         float yv[8];
         unpack8<DT>(*(const ushort8_t*)(ms + it * step), yv);
+        unsigned mbits = 0;
+        if constexpr (act == ACT_ADD_MASKED) mbits = bits[(it * step) >> 3];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           const float y = yv[r];
           if constexpr (act == ACT_RELU_BWD) v[r] = y > 0.f ? v[r] : 0.f;
           else if constexpr (act == ACT_ADD) v[r] += y;
+          else if constexpr (act == ACT_MUL) v[r] *= y;
+          else if constexpr (act == ACT_ADD_MASKED) { if ((mbits >> r) & 1u) v[r] += y; }
           else if constexpr (act == ACT_TANH_BWD) v[r] *= (1.f - y * y);
           else {
             const float k0 = 0.7978845608028654f, k1 = 0.044715f;
@@ -476,6 +511,9 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
       case ACT_ADD: fast_pass(std::integral_constant<int, ACT_ADD>(), half); break;
       case ACT_GELU_BWD: fast_pass(std::integral_constant<int, ACT_GELU_BWD>(), half); break;
       case ACT_TANH: fast_pass(std::integral_constant<int, ACT_TANH>(), half); break;
+      case ACT_ADD_MASKED: fast_pass(std::integral_constant<int, ACT_ADD_MASKED>(), half); break;
+      case ACT_MUL: fast_pass(std::integral_constant<int, ACT_MUL>(), half); break;
+      case ACT_GELU_DAUX: fast_pass(std::integral_constant<int, ACT_GELU_DAUX>(), half); break;
       default: fast_pass(std::integral_constant<int, ACT_TANH_BWD>(), half); break;
     }
     continue;

@@ -232,7 +232,7 @@ def gemm(a, b, m, n, k, a_kc, b_kc, out=None, out_dtype=None, bias=None, act=C.A
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != n):
         raise ValueError("gemm bias must be fp32 [n]")
     extra = (float(m * n) * mask_src.element_size() if mask_src is not None else 0.0) + \
-            (float(m * n) * aux.element_size() if aux is not None else 0.0)
+            (float(aux.numel()) * aux.element_size() if aux is not None else 0.0)
     C.annotate(flops=2.0 * m * n * k,
                bytes=float(m * k + n * k) * a.element_size() + float(m * n) * out.element_size() + extra,
                tag="%dx%dx%d%s%s" % (m, n, k, "+src" if mask_src is not None else "", "+aux" if aux is not None else ""))

@@ -23,7 +23,12 @@ typedef struct ihipStream_t* hipStream_t;
 
 enum { DLE_F32 = 0, DLE_F16 = 1, DLE_BF16 = 2 };
 enum { DLE_ACT_NONE = 0, DLE_ACT_RELU = 1, DLE_ACT_GELU = 2, DLE_ACT_RELU_BWD = 3, DLE_ACT_ADD = 4,
-       DLE_ACT_GELU_BWD = 5, DLE_ACT_TANH = 6, DLE_ACT_TANH_BWD = 7 };
+       DLE_ACT_GELU_BWD = 5, DLE_ACT_TANH = 6, DLE_ACT_TANH_BWD = 7,
+       DLE_ACT_ADD_MASKED = 8, /* C = acc + (bit ? mask_src : 0): aux is an INPUT here, the bit-packed keep bits of the
+                                  addend (bit k of byte i <-> element 8 i + k of the [M, ldc] addend): the residual-branch
+                                  gradient dy * (y > 0) of a ResNet block without materialising it */
+       DLE_ACT_MUL = 9,        /* C = acc * mask_src */
+       DLE_ACT_GELU_DAUX = 10  /* C = gelu(v), aux = gelu'(v): the backward GEMM then multiplies (DLE_ACT_MUL) */ };
 
 /* ---- library plumbing ---------------------------------------------------------------------- */
 const char* dle_last_error(void);

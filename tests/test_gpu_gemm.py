@@ -126,3 +126,32 @@ def test_gemm_big_tile(cuda, mnk, dtype):
     at = a.T.contiguous()
     chk(F.gemm(at, bt, m, n, k, False, False, out_dtype=torch.float32, splitk=sk), "mc/nc")
     chk(F.gemm(at, bt, m, n, k, False, False, out_dtype=torch.float32, splitk=max(sk, 2)), "mc/nc splitk")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(200, 136, 96), (4096, 2560, 256)])
+def test_gemm_masked_add_mul_and_gelu_derivative_epilogues(cuda, dtype, shape):
+    """DLE_ACT_ADD_MASKED (residual-branch gradient dy * (y > 0) added under its bit mask, never materialised),
+    DLE_ACT_MUL and DLE_ACT_GELU_DAUX (the forward GEMM leaves gelu'(v) behind) on the 128x128 and the 256x256 tile."""
+    F, C = _F()
+    m, n, k = shape
+    gen = torch.Generator().manual_seed(17)
+    a, b = _mk((m, k), dtype, gen, 0.5), _mk((n, k), dtype, gen, 0.5)
+    tol = dict(rtol=2e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=3e-3, atol=4e-3)
+    prod = a.double() @ b.double().T
+    add = _mk((m, n), dtype, gen)
+    keep = torch.rand(m, n, generator=gen) > 0.4
+    bits = (keep.reshape(-1, 8).to(torch.int32) << torch.arange(8, dtype=torch.int32)).sum(1).to(torch.uint8)
+    y = F.gemm(a.to(cuda), b.to(cuda), m, n, k, True, True, act=C.ACT_ADD_MASKED, mask_src=add.to(cuda), aux=bits.to(cuda))
+    ref = prod + torch.where(keep, add.double(), torch.zeros((), dtype=torch.float64))
+    np.testing.assert_allclose(y.cpu().double().numpy(), ref.numpy(), **tol)
+    y = F.gemm(a.to(cuda), b.to(cuda), m, n, k, True, True, act=C.ACT_MUL, mask_src=add.to(cuda))
+    np.testing.assert_allclose(y.cpu().double().numpy(), (prod * add.double()).numpy(), **tol)
+    bias = torch.randn(n, generator=gen)
+    daux = torch.empty((m, n), dtype=dtype, device=cuda)
+    y = F.gemm(a.to(cuda), b.to(cuda), m, n, k, True, True, bias=bias.to(cuda), act=C.ACT_GELU_DAUX, aux=daux)
+    pre = (prod + bias.double()).requires_grad_(True)
+    g = torch.nn.functional.gelu(pre, approximate="tanh")
+    g.sum().backward()
+    np.testing.assert_allclose(y.cpu().double().numpy(), g.detach().numpy(), **tol)
+    np.testing.assert_allclose(daux.cpu().double().numpy(), pre.grad.numpy(), **tol)
