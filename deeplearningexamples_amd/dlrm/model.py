@@ -65,6 +65,13 @@ class Mlp(nn.Module):
     def biases(self):
         return [m.bias for m in self.linears]
 
+    def load_state(self, weights, biases):
+        """AbstractMlp.load_state (dlrm/nn/mlps.py:69-75): take over checkpointed fp32 weights / biases.  The 16-bit
+        working copies are rebuilt by refresh_working_copies() (the checkpoint loader calls it on the whole model)."""
+        for new_w, w, new_b, b in zip(weights, self.weights, biases, self.biases):
+            w.data.copy_(new_w.data.to(w.device))
+            b.data.copy_(new_b.data.to(b.device))
+
     # ---- 16-bit working copies ---------------------------------------------------------------
     def k_padded(self, i):
         return _ceil_to(self.linears[i].in_features, 8)
