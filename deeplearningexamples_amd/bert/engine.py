@@ -43,6 +43,7 @@ class BertTrainer:
     def __init__(self, model: BertForPreTraining, lr=6e-3, warmup=0.2843, total_steps=7038, weight_decay=0.01,
                  max_grad_norm=1.0, compute_dtype=torch.bfloat16, init_loss_scale=2.0 ** 20, world_size=1,
                  process_group=None, hidden_dropout=None, attention_dropout=None, seed=42, rank=0, static_batch=False,
+                 max_predictions_per_seq=None,
                  bucket_mb=64):
         self.model, self.cfg = model, model.config
         self.dev = model.bert.embeddings.word_embeddings.weight.device
@@ -56,6 +57,7 @@ class BertTrainer:
         self.p_hidden = model.config.get("hidden_dropout", 0.1) if hidden_dropout is None else hidden_dropout
         self.p_attn = model.config.get("attention_dropout", 0.1) if attention_dropout is None else attention_dropout
         self.rng_seed, self._rng_offset = int(seed) + int(rank), 0
+        self._rng_base = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.scaler = GradScalerState(self.dev, enabled=compute_dtype == torch.float16, init_scale=init_loss_scale,
                                       growth_interval=2000)
         dev = self.dev
@@ -63,6 +65,11 @@ class BertTrainer:
         # benchmark / graph-captured input buffers, run_pretraining.py:602-640) -- only then are the masked-row indices
         # of a batch reused; by default they are rebuilt at every step (a loader may refill the same addresses)
         self.static_batch = static_batch
+        # max_predictions_per_seq (run_pretraining.py --max_predictions_per_seq): the dense MLM head then works on
+        # EXACTLY that many rows per sequence, chosen on the device (masked positions first, unmasked ones -- label -1,
+        # ignored by the criterion, zero gradient -- as padding): no host synchronisation, a static shape, HIP-graph
+        # capturable.  None: the masked rows are counted on the host like the reference's index_select (modeling.py:590).
+        self.max_pred = max_predictions_per_seq
         self.fused_attention = True     # False: batched GEMMs + softmax kernels (also taken for shapes outside the fused envelope)
         self.keep_activations = False   # tests: keep the dropout keep masks of the last step
         model.fuse_qkv_storage()
@@ -180,13 +187,21 @@ class BertTrainer:
             return
         b, s = input_ids.shape
         flat = labels.reshape(-1)
-        self._sel = torch.nonzero(flat != -1).squeeze(1)            # data-dependent size: one host sync per new batch,
+        if self.max_pred is not None:
+            # stable sort of (label == -1): masked positions first, in sequence order; the first max_pred columns
+            order = torch.sort((labels == -1).to(torch.int8), dim=1, stable=True).indices[:, :self.max_pred]
+            self._sel = (order + torch.arange(b, device=labels.device, dtype=torch.int64)[:, None] * s).reshape(-1)
+        else:
+            self._sel = torch.nonzero(flat != -1).squeeze(1)        # data-dependent size: one host sync per new batch,
         self._dense_labels = flat[self._sel].contiguous()          # like the reference's index_select (modeling.py:590)
         self._idx0 = torch.arange(b, device=self.dev, dtype=torch.int64) * s
         self._mask_add = ((1.0 - attention_mask.to(torch.float32)) * -10000.0).contiguous()
         self._batch_key = key
 
     def _next_offset(self):
+        """Index of the next dropout call INSIDE the current step.  The per-step advance lives in the device word
+        self._rng_base, which the kernels add to this index (and which backward() bumps on the device): a HIP-graph
+        captured step therefore draws fresh masks at every replay, like torch's graph-safe Philox state."""
         self._rng_offset += 1
         return self._rng_offset
 
@@ -198,6 +213,7 @@ class BertTrainer:
         b, s = input_ids.shape
         t = b * s
         self._prepare_batch(input_ids, attention_mask, labels)
+        self._rng_offset = 0
         emb = m.bert.embeddings
         ids, tts = input_ids.reshape(-1).contiguous(), token_type_ids.reshape(-1).contiguous()
         z0 = F.embed_sum(emb.word_embeddings.weight.data, emb.position_embeddings.weight.data,
@@ -206,7 +222,7 @@ class BertTrainer:
         ph, pa, seed = self.p_hidden, self.p_attn, self.rng_seed
         mask0 = None
         if ph > 0:
-            x, mask0 = F.dropout_fwd(x, ph, seed, self._next_offset())
+            x, mask0 = F.dropout_fwd(x, ph, seed, self._next_offset(), offset_base=self._rng_base)
         sv = {"ids": ids, "tt": tts, "z0": z0, "ln0": (mean0, rstd0), "mask0": mask0, "layers": [], "b": b, "s": s}
         scale = 1.0 / math.sqrt(d)
         fused_attn = self.fused_attention and F.attention_supported(s, d)
@@ -221,13 +237,14 @@ class BertTrainer:
             if fused_attn:
                 # QK^T, scale + mask, softmax, dropout and P V in one kernel: no [B, heads, S, S] tensor in HBM
                 ctx, stats, mask_a = F.attention_fwd(qkv, self._mask_add, b, s, nh, scale, pa, seed, off_a,
-                                                     want_mask=self.keep_activations)
+                                                     want_mask=self.keep_activations, offset_base=self._rng_base)
             else:
                 probs = torch.empty((b * nh, s, s), dtype=dt, device=self.dev)
                 F.gemm_batched(qkv, qkv[:, h:], probs, s, s, d, 3 * h, 3 * h, s, True, True, b * nh, nh,
                                (s * 3 * h, d), (s * 3 * h, d), (nh * s * s, s * s))
                 if pa > 0:
-                    pdrop, mask_a = F.softmax_dropout_fwd_(probs, self._mask_add, nh * s, scale, pa, seed, off_a)
+                    pdrop, mask_a = F.softmax_dropout_fwd_(probs, self._mask_add, nh * s, scale, pa, seed, off_a,
+                                                           offset_base=self._rng_base)
                 else:
                     F.softmax_fwd_(probs, self._mask_add, nh * s, scale)
                     pdrop = probs
@@ -239,7 +256,7 @@ class BertTrainer:
             if ph > 0:
                 x1, z1, m1, r1, mask_1 = F.dropout_add_layernorm_fwd(ao, att.output.LayerNorm.weight.data,
                                                                       att.output.LayerNorm.bias.data, x, ph, seed,
-                                                                      self._next_offset())
+                                                                      self._next_offset(), offset_base=self._rng_base)
             else:
                 x1, z1, m1, r1 = F.layernorm_fwd(ao, att.output.LayerNorm.weight.data, att.output.LayerNorm.bias.data, residual=x)
             # the epilogue leaves gelu'(pre-activation) behind (not the pre-activation): the backward GEMM multiplies
@@ -250,7 +267,7 @@ class BertTrainer:
             if ph > 0:
                 x2, z2, m2, r2, mask_2 = F.dropout_add_layernorm_fwd(o2, layer.output.LayerNorm.weight.data,
                                                                       layer.output.LayerNorm.bias.data, x1, ph, seed,
-                                                                      self._next_offset())
+                                                                      self._next_offset(), offset_base=self._rng_base)
             else:
                 x2, z2, m2, r2 = F.layernorm_fwd(o2, layer.output.LayerNorm.weight.data, layer.output.LayerNorm.bias.data, residual=x1)
             sv["layers"].append(dict(x=x, qkv=qkv, probs=probs, pdrop=pdrop, stats=stats, off_a=off_a, ctx=ctx, z1=z1, ln1=(m1, r1), x1=x1,
@@ -360,7 +377,7 @@ class BertTrainer:
             qkv, probs = a["qkv"], a["probs"]
             if sv["fused_attn"]:
                 dqkv = F.attention_bwd(qkv, dctx, self._mask_add, a["stats"], b, s, nh, scale, self.p_attn,
-                                       self.rng_seed, a["off_a"])
+                                       self.rng_seed, a["off_a"], offset_base=self._rng_base)
             else:
                 dprobs = torch.empty_like(probs)
                 F.gemm_batched(dctx, qkv[:, 2 * h:], dprobs, s, s, d, h, 3 * h, s, True, True, b * nh, nh,
@@ -398,6 +415,8 @@ class BertTrainer:
         self._grads_final(("bert.embeddings.",))
         self._last_sv = sv if self.keep_activations else None     # tests read the dropout masks
         self._sv = None
+        if self._rng_offset:
+            self._rng_base += self._rng_offset     # on the device: the next step (or graph replay) draws new masks
 
     def _grads_final(self, prefixes):
         """The gradients of every parameter whose name starts with one of `prefixes` are complete: launch the

@@ -14,6 +14,7 @@ import time
 import torch
 
 from ..utils import dllogger
+from ..utils.graph import GraphedStep
 from ..utils.dist import init_from_env, is_main_process
 from .engine import BertTrainer
 from .model import LARGE, BertForPreTraining, config_from_json
@@ -38,6 +39,8 @@ def parse_arguments(argv=None):
     p.add_argument("--json-summary", type=str, default="dllogger.json")
     p.add_argument("--disable_progress_bar", action="store_true")
     p.add_argument("--skip_checkpoint", action="store_true")
+    p.add_argument("--cuda_graphs", action="store_true",
+                   help="capture the micro-step and the optimizer step in HIP graphs (run_pretraining.py:310,602-640)")
     args = p.parse_args(argv)
     if args.steps_this_run < 0:
         args.steps_this_run = int(args.max_steps)
@@ -78,22 +81,40 @@ def main(argv=None):
     dtype = torch.float16 if args.fp16 else torch.bfloat16
     trainer = BertTrainer(model, lr=args.learning_rate, warmup=args.warmup_proportion, total_steps=int(args.max_steps),
                           compute_dtype=dtype, init_loss_scale=float(args.init_loss_scale), world_size=world,
-                          seed=args.seed, rank=rank)
+                          seed=args.seed, rank=rank,
+                          max_predictions_per_seq=args.max_predictions_per_seq if args.cuda_graphs else None)
     acc = args.gradient_accumulation_steps
     micro = args.train_batch_size // acc
     it = synthetic_batches(cfg, micro, args.max_seq_length, args.max_predictions_per_seq, device, args.seed + rank)
     avg_loss = torch.zeros(1, device=device)
     t0 = time.time()
+    # run_pretraining.py:602-640 keeps two graphs: micro-step + optimizer step, and the micro-step alone (accumulation).
+    # Here the optimizer step is its own captured callable, so one micro-step graph per accumulate flag serves both.
+    use_graphs = args.cuda_graphs and world == 1
+
+    def micro_first(*b):
+        loss, dlog, dnsp = trainer.forward(*b)
+        trainer.backward(dlog, dnsp, accumulate=False)
+        return loss
+
+    def micro_acc(*b):
+        loss, dlog, dnsp = trainer.forward(*b)
+        trainer.backward(dlog, dnsp, accumulate=True)
+        return loss
+
+    def opt_step():
+        trainer.optimizer_step()
+        return trainer.lr_t
+    g_first, g_acc, g_opt = (GraphedStep(f, enabled=use_graphs) for f in (micro_first, micro_acc, opt_step))
+    trainer.grad_divisor = acc
     for step in range(args.steps_this_run):
         for micro_step in range(acc):
             b = next(it)
-            loss, dlog, dnsp = trainer.forward(b["input_ids"], b["token_type_ids"], b["attention_mask"], b["labels"],
-                                               b["next_sentence_labels"])
             trainer._reduce_now = micro_step == acc - 1                   # no_sync on all but the last micro-step
-            trainer.backward(dlog, dnsp, accumulate=micro_step > 0)
+            loss = (g_first if micro_step == 0 else g_acc)(b["input_ids"], b["token_type_ids"], b["attention_mask"],
+                                                           b["labels"], b["next_sentence_labels"])
             avg_loss += loss / acc
-        trainer.grad_divisor = acc
-        trainer.optimizer_step()
+        g_opt()
         if (step + 1) % max(int(args.log_freq), 1) == 0 and is_main_process():
             dllogger.log(step=(0, step + 1), data={"average_loss": float(avg_loss.item()) / max(int(args.log_freq), 1),
                                                    "learning_rate": trainer.current_lr()})

@@ -189,6 +189,7 @@ __device__ __forceinline__ void at_softmax(float16_t* s, const float* mrow, floa
 
 template <int DT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
+  drop_resolve(p.drop);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned short* Qt = (unsigned short*)smem_raw;
   unsigned short* Kt = Qt + AT_TILE;
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 
 template <int DT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
+  drop_resolve(p.drop);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned short* Qt = (unsigned short*)smem_raw;
   unsigned short* Ot = Qt + AT_TILE;
@@ -429,14 +431,14 @@ extern "C" int dle_attention_supported(int S, int head_dim) { return S == AT_S &
 // (optional, B*heads*S*S/8 bytes) receives the dropout keep bits in the layout of dle_softmax_dropout_fwd.
 extern "C" int dle_attention_fwd(const void* qkv, const float* mask_add, void* ctx, float* stats, void* keep_mask, int B,
                                  int S, int heads, int head_dim, float scale, float p, uint64_t seed, uint64_t offset,
-                                 int dtype, hipStream_t stream) {
+                                 const uint64_t* offset_base, int dtype, hipStream_t stream) {
   if (int rc = attn_check("attention_fwd", B, S, heads, head_dim, dtype, p)) return rc;
   DLE_CHECK_ARG(qkv && ctx && stats, "attention_fwd: null pointer");
   DLE_CHECK_ARG(((((uintptr_t)qkv) | ((uintptr_t)ctx)) & 15) == 0, "attention_fwd: tensors must be 16-byte aligned");
   AttnArgs a = {};
   a.qkv = (const unsigned short*)qkv; a.mask_add = mask_add; a.ctx = (unsigned short*)ctx; a.stats = stats;
   a.mask_out = (unsigned char*)keep_mask; a.B = B; a.nh = heads; a.H = heads * head_dim; a.scale = scale;
-  a.drop = make_drop(nullptr, p, seed, offset);
+  a.drop = make_drop(nullptr, p, seed, offset, offset_base);
   const size_t lds = 3 * AT_TILE * 2;
   if (dtype == DLE_F16) hipLaunchKernelGGL(attn_fwd_kernel<DLE_F16>, dim3(B * heads), dim3(256), lds, stream, a);
   else hipLaunchKernelGGL(attn_fwd_kernel<DLE_BF16>, dim3(B * heads), dim3(256), lds, stream, a);
@@ -448,14 +450,14 @@ extern "C" int dle_attention_fwd(const void* qkv, const float* mask_add, void* c
 // (seed, offset) -- the same values dle_attention_fwd was called with.
 extern "C" int dle_attention_bwd(const void* qkv, const void* dctx, const float* mask_add, const float* stats, void* dqkv,
                                  int B, int S, int heads, int head_dim, float scale, float p, uint64_t seed,
-                                 uint64_t offset, int dtype, hipStream_t stream) {
+                                 uint64_t offset, const uint64_t* offset_base, int dtype, hipStream_t stream) {
   if (int rc = attn_check("attention_bwd", B, S, heads, head_dim, dtype, p)) return rc;
   DLE_CHECK_ARG(qkv && dctx && stats && dqkv, "attention_bwd: null pointer");
   DLE_CHECK_ARG(((((uintptr_t)qkv) | ((uintptr_t)dctx) | ((uintptr_t)dqkv)) & 15) == 0, "attention_bwd: tensors must be 16-byte aligned");
   AttnArgs a = {};
   a.qkv = (const unsigned short*)qkv; a.dctx = (const unsigned short*)dctx; a.mask_add = mask_add;
   a.stats = (float*)stats; a.dqkv = (unsigned short*)dqkv; a.B = B; a.nh = heads; a.H = heads * head_dim; a.scale = scale;
-  a.drop = make_drop(nullptr, p, seed, offset);
+  a.drop = make_drop(nullptr, p, seed, offset, offset_base);
   const size_t lds = 4 * AT_TILE * 2;
   static bool attr_set = false;
   if (!attr_set) {

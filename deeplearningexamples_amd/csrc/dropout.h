@@ -14,6 +14,7 @@ struct DropArgs {
   unsigned thr;
   float inv_keep;
   unsigned seed_lo, seed_hi, off_lo, off_hi;
+  const unsigned long long* off_dev;   // optional DEVICE word added to the call offset (graph-safe RNG advance)
 };
 
 __device__ __forceinline__ uint4_t philox4x32_10(uint4_t c, unsigned k0, unsigned k1) {
@@ -41,7 +42,18 @@ __device__ __forceinline__ unsigned drop_bits(const DropArgs& d, long long chunk
   return bits;
 }
 
-static inline DropArgs make_drop(void* mask, float p, unsigned long long seed, unsigned long long offset) {
+// The call offset a captured HIP graph would freeze in its kernel arguments: with off_dev the kernels add a counter that
+// lives in device memory (the captured step advances it itself), the way torch's graph-safe Philox state does.
+__device__ __forceinline__ void drop_resolve(DropArgs& d) {
+  if (d.off_dev) {
+    const unsigned long long o = (((unsigned long long)d.off_hi << 32) | d.off_lo) + *d.off_dev;
+    d.off_lo = (unsigned)o;
+    d.off_hi = (unsigned)(o >> 32);
+  }
+}
+
+static inline DropArgs make_drop(void* mask, float p, unsigned long long seed, unsigned long long offset,
+                                 const void* offset_base = nullptr) {
   DropArgs d;
   d.mask = (unsigned char*)mask;
   long long thr = (long long)(p * 65536.0f + 0.5f);
@@ -51,6 +63,7 @@ static inline DropArgs make_drop(void* mask, float p, unsigned long long seed, u
   d.inv_keep = 65536.0f / (float)(65536 - thr);
   d.seed_lo = (unsigned)seed; d.seed_hi = (unsigned)(seed >> 32);
   d.off_lo = (unsigned)offset; d.off_hi = (unsigned)(offset >> 32);
+  d.off_dev = (const unsigned long long*)offset_base;
   return d;
 }
 

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ mean, float* __restrict__ rstd, long long rows,
                                                      int H, float eps, DropArgs drop) {
+  drop_resolve(drop);
   const int lane = threadIdx.x & 63;
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
   const int nch = H >> 3;                              // 16-byte chunks per row
@@ -127,13 +128,14 @@ extern "C" int dle_layernorm_fwd(const void* x, const void* residual, void* z_ou
 extern "C" int dle_dropout_add_layernorm_fwd(const void* x, const void* residual, void* z_out, void* y, void* mask,
                                              const float* gamma, const float* beta, float* mean, float* rstd,
                                              int64_t rows, int H, float eps, float p, uint64_t seed, uint64_t offset,
+                                             const uint64_t* offset_base,
                                              int dtype, hipStream_t stream) {
   DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "dropout_add_layernorm_fwd: 16-bit activations only");
   DLE_CHECK_ARG(H > 0 && H % 8 == 0 && H <= 64 * LN_MAX_CHUNKS * 8, "dropout_add_layernorm_fwd: H must be a multiple of 8, <= 4096");
   DLE_CHECK_ARG(p >= 0.f && p < 1.f, "dropout_add_layernorm_fwd: p must be in [0, 1)");
   if (rows == 0) return 0;
   DLE_CHECK_ARG(x && y && gamma && beta && mean && rstd && mask, "dropout_add_layernorm_fwd: null pointer");
-  return ln_fwd_launch(x, residual, z_out, y, gamma, beta, mean, rstd, rows, H, eps, make_drop(mask, p, seed, offset), dtype, stream);
+  return ln_fwd_launch(x, residual, z_out, y, gamma, beta, mean, rstd, rows, H, eps, make_drop(mask, p, seed, offset, offset_base), dtype, stream);
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
@@ -462,6 +464,7 @@ template <int DT>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(unsigned short* __restrict__ s, const float* __restrict__ mask_add,
                                                           long long rows, int L, int rows_per_batch, float scale,
                                                           unsigned short* __restrict__ dropped, DropArgs drop) {
+  drop_resolve(drop);
   const int lpr = L >> 3;
   const int rpw = 64 / lpr;
   const int lane = threadIdx.x & 63, sub = lane / lpr, cl = lane % lpr;
@@ -561,6 +564,7 @@ extern "C" int dle_softmax_fwd(void* scores, const float* mask_add, int64_t rows
 // (modeling.py:366-370: attention_probs = self.dropout(self.softmax(attention_scores)))
 extern "C" int dle_softmax_dropout_fwd(void* scores, void* dropped, void* mask, const float* mask_add, int64_t rows, int L,
                                        int rows_per_batch, float scale, float p, uint64_t seed, uint64_t offset,
+                                       const uint64_t* offset_base,
                                        int dtype, hipStream_t stream) {
   DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "softmax_dropout_fwd: 16-bit scores only");
   DLE_CHECK_ARG(softmax_len_ok(L), "softmax_dropout_fwd: row length %d must be a power of two in [8, 512]", L);
@@ -568,7 +572,7 @@ extern "C" int dle_softmax_dropout_fwd(void* scores, void* dropped, void* mask, 
   if (rows == 0) return 0;
   DLE_CHECK_ARG(scores && dropped && mask && rows_per_batch > 0, "softmax_dropout_fwd: bad arguments");
   const int grid = tf_grid(rows, 4 * (64 / (L / 8)), 4096);
-  const DropArgs d = make_drop(mask, p, seed, offset);
+  const DropArgs d = make_drop(mask, p, seed, offset, offset_base);
   if (dtype == DLE_F16) hipLaunchKernelGGL(softmax_fwd_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (unsigned short*)scores, mask_add, (long long)rows, L, rows_per_batch, scale, (unsigned short*)dropped, d);
   else hipLaunchKernelGGL(softmax_fwd_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (unsigned short*)scores, mask_add, (long long)rows, L, rows_per_batch, scale, (unsigned short*)dropped, d);
   DLE_LAUNCH_CHECK();
@@ -608,6 +612,7 @@ extern "C" int dle_softmax_dropout_bwd(const void* probs, void* dprobs, const vo
 template <int DT, bool BWD>
 __global__ __launch_bounds__(256) void dropout_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
                                                       unsigned char* __restrict__ mask, long long chunks, DropArgs drop) {
+  drop_resolve(drop);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (long long)gridDim.x * blockDim.x) {
     float v[8];
     unpack8<DT>(((const ushort8_t*)x)[i], v);
@@ -622,13 +627,14 @@ __global__ __launch_bounds__(256) void dropout_kernel(const unsigned short* __re
 
 // y = dropout(x): n elements (multiple of 8), mask n / 8 bytes.  x == y is allowed.
 extern "C" int dle_dropout_fwd(const void* x, void* y, void* mask, int64_t n, float p, uint64_t seed, uint64_t offset,
+                               const uint64_t* offset_base,
                                int dtype, hipStream_t stream) {
   DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "dropout_fwd: 16-bit tensors only");
   DLE_CHECK_ARG(n >= 0 && n % 8 == 0, "dropout_fwd: n must be a multiple of 8");
   DLE_CHECK_ARG(p >= 0.f && p < 1.f, "dropout_fwd: p must be in [0, 1)");
   if (n == 0) return 0;
   DLE_CHECK_ARG(x && y && mask, "dropout_fwd: null pointer");
-  const DropArgs d = make_drop(mask, p, seed, offset);
+  const DropArgs d = make_drop(mask, p, seed, offset, offset_base);
   const int grid = tf_grid(n / 8, 256);
   if (dtype == DLE_F16) hipLaunchKernelGGL((dropout_kernel<DLE_F16, false>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, (unsigned char*)mask, (long long)(n / 8), d);
   else hipLaunchKernelGGL((dropout_kernel<DLE_BF16, false>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, (unsigned char*)mask, (long long)(n / 8), d);

@@ -11,6 +11,7 @@ import time
 import torch
 
 from ..utils import dllogger
+from ..utils.graph import GraphedStep
 from ..utils.dist import init_from_env, is_main_process
 from . import placement as P
 from .engine import DlrmTrainer
@@ -55,7 +56,7 @@ def parse_flags(argv=None):
     p.add_argument("--print_freq", type=int, default=200)
     p.add_argument("--benchmark_warmup_steps", type=int, default=0)
     p.add_argument("--amp", action="store_true")
-    p.add_argument("--cuda_graphs", action="store_true", help="accepted for CLI compatibility")
+    p.add_argument("--cuda_graphs", action="store_true", help="capture the train step in a HIP graph (main.py:120,194-274)")
     p.add_argument("--optimized_mlp", action="store_true", default=True)
     p.add_argument("--bottom_features_ordered", action="store_true")
     p.add_argument("--freeze_mlps", action="store_true")
@@ -98,6 +99,8 @@ def main(argv=None):
     num = num.to(device) if rank == mapping["bottom_mlp"] else None
     cat = cat[:, mine].contiguous().to(device) if mine else None
     steps_per_epoch = max(flags.synthetic_dataset_num_entries // flags.batch_size - 1, 1)
+    # CudaGraphWrapper (main.py:610-611): eager warm-up steps, one capture, then copy-in + replay per step
+    step_fn = GraphedStep(trainer.train_step, enabled=flags.cuda_graphs and world == 1)
     timer, times, moving_loss = StepTimer(), [], torch.zeros(1, device=device)
     step = 0
     for epoch in range(flags.epochs):
@@ -106,7 +109,7 @@ def main(argv=None):
             if flags.max_steps and step > flags.max_steps:
                 break
             trainer.set_lr_factor(sched.step())
-            moving_loss += trainer.train_step(num, cat, click)
+            moving_loss += step_fn(num, cat, click)
             step += 1
             if timer.measured is not None and step > flags.benchmark_warmup_steps:
                 times.append(timer.measured)

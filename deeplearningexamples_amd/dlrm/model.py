@@ -77,8 +77,13 @@ class Mlp(nn.Module):
         return _ceil_to(self.linears[i].in_features, 8)
 
     def refresh_working_copies(self):
-        """(Re)build the 16-bit weights from the fp32 masters (after init / checkpoint load)."""
-        self._w16 = []
+        """(Re)build the 16-bit weights from the fp32 masters (after init / checkpoint load).  Existing copies are
+        refreshed IN PLACE: the trainer's multi-tensor SGD tables hold their addresses (it rewrites them in the pass that
+        updates the masters), so handing out new tensors would leave the forward pass reading stale weights."""
+        if self._w16:
+            for i, lin in enumerate(self.linears):
+                F.cast_rows(lin.weight.data, self.compute_dtype, cols_out=self.k_padded(i), out=self._w16[i])
+            return self._w16
         for i, lin in enumerate(self.linears):
             self._w16.append(F.cast_rows(lin.weight.data, self.compute_dtype, cols_out=self.k_padded(i)))
         return self._w16
@@ -292,8 +297,10 @@ class DlrmTop(nn.Module):
 
     def refresh_working_copies(self):
         self.mlp.refresh_working_copies()
-        self._out_w16 = None
-        self.out_working_copy()
+        if self._out_w16 is not None:                       # in place: the optimizer table holds this buffer's address
+            F.cast_rows(self.out.weight.data, self.compute_dtype, out=self._out_w16)
+        else:
+            self.out_working_copy()
 
     def forward(self, bottom_output, bottom_mlp_output=None):
         z = self.interaction.interact(bottom_output, bottom_mlp_output)

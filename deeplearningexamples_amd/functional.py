@@ -670,14 +670,17 @@ def act_bwd(g, src, act):
 
 
 # ------------------------------------------------------------------ dropout (BERT training mode)
-def dropout_fwd(x, p, seed, offset):
-    """y = dropout(x) with the C-ABI's counter-based RNG.  Returns (y, mask) -- mask is bit-packed uint8 [numel/8]."""
+def dropout_fwd(x, p, seed, offset, offset_base=None):
+    """y = dropout(x) with the C-ABI's counter-based RNG.  Returns (y, mask) -- mask is bit-packed uint8 [numel/8].
+    offset_base (all dropout wrappers): optional int64 DEVICE tensor [1] added to `offset` by the kernel -- the RNG
+    advance of a HIP-graph-captured step lives in device memory."""
     C.require_cuda(x)
     n = x.numel()
     y = torch.empty_like(x)
     mask = torch.empty(n // 8, dtype=torch.uint8, device=x.device)
     C.annotate(bytes=float(n) * 2 * 2 + n / 8, tag="N%d" % n)
-    C.call("dle_dropout_fwd", C.ptr(x), C.ptr(y), C.ptr(mask), n, float(p), int(seed), int(offset), C.dt(x), C.stream())
+    C.call("dle_dropout_fwd", C.ptr(x), C.ptr(y), C.ptr(mask), n, float(p), int(seed), int(offset), C.ptr(offset_base),
+           C.dt(x), C.stream())
     return y, mask
 
 
@@ -690,7 +693,7 @@ def dropout_bwd(dy, mask, p):
     return dx
 
 
-def dropout_add_layernorm_fwd(x, gamma, beta, residual, p, seed, offset, eps=1e-12):
+def dropout_add_layernorm_fwd(x, gamma, beta, residual, p, seed, offset, eps=1e-12, offset_base=None):
     """y = LayerNorm(dropout(x) + residual).  Returns (y, z, mean, rstd, mask)."""
     C.require_cuda(x, gamma, beta, residual)
     rows, h = x.shape
@@ -701,12 +704,12 @@ def dropout_add_layernorm_fwd(x, gamma, beta, residual, p, seed, offset, eps=1e-
     mask = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device)
     C.annotate(bytes=float(x.numel()) * 2 * 4 + x.numel() / 8, tag="R%dxH%d+drop" % (rows, h))
     C.call("dle_dropout_add_layernorm_fwd", C.ptr(x), C.ptr(residual), C.ptr(z), C.ptr(y), C.ptr(mask), C.ptr(gamma),
-           C.ptr(beta), C.ptr(mean), C.ptr(rstd), rows, h, float(eps), float(p), int(seed), int(offset), C.dt(x),
-           C.stream())
+           C.ptr(beta), C.ptr(mean), C.ptr(rstd), rows, h, float(eps), float(p), int(seed), int(offset),
+           C.ptr(offset_base), C.dt(x), C.stream())
     return y, z, mean, rstd, mask
 
 
-def softmax_dropout_fwd_(scores, mask_add, rows_per_batch, scale, p, seed, offset):
+def softmax_dropout_fwd_(scores, mask_add, rows_per_batch, scale, p, seed, offset, offset_base=None):
     """scores -> probs in place; returns (dropped = dropout(probs), mask)."""
     C.require_cuda(scores, mask_add)
     l = scores.shape[-1]
@@ -715,7 +718,7 @@ def softmax_dropout_fwd_(scores, mask_add, rows_per_batch, scale, p, seed, offse
     mask = torch.empty(scores.numel() // 8, dtype=torch.uint8, device=scores.device)
     C.annotate(bytes=float(scores.numel()) * 6 + scores.numel() / 8, tag="R%dxL%d+drop" % (rows, l))
     C.call("dle_softmax_dropout_fwd", C.ptr(scores), C.ptr(dropped), C.ptr(mask), C.ptr(mask_add), rows, l,
-           rows_per_batch, float(scale), float(p), int(seed), int(offset), C.dt(scores), C.stream())
+           rows_per_batch, float(scale), float(p), int(seed), int(offset), C.ptr(offset_base), C.dt(scores), C.stream())
     return dropped, mask
 
 
@@ -734,7 +737,8 @@ def attention_supported(seq_len, head_dim):
     return bool(C.lib().dle_attention_supported(int(seq_len), int(head_dim)))
 
 
-def attention_fwd(qkv, mask_add, batch, seq_len, heads, scale, p=0.0, seed=0, offset=0, want_mask=False):
+def attention_fwd(qkv, mask_add, batch, seq_len, heads, scale, p=0.0, seed=0, offset=0, want_mask=False,
+                  offset_base=None):
     """context = dropout(softmax(q k^T * scale + mask_add)) v for every (sequence, head) of qkv [T, 3H] in ONE kernel
     (BertSelfAttention.forward, modeling.py:340-384).  -> (ctx [T, H], stats [B*heads, S, 2] fp32, keep mask or None)."""
     C.require_cuda(qkv, mask_add)
@@ -751,11 +755,11 @@ def attention_fwd(qkv, mask_add, batch, seq_len, heads, scale, p=0.0, seed=0, of
     C.annotate(flops=4.0 * bh * seq_len * seq_len * d, bytes=float(t) * h * 2 * 4 + stats.numel() * 4,
                tag="B%dxh%dxS%dxd%d" % (batch, heads, seq_len, d))
     C.call("dle_attention_fwd", C.ptr(qkv), C.ptr(mask_add), C.ptr(ctx), C.ptr(stats), C.ptr(mask), batch, seq_len,
-           heads, d, float(scale), float(p), int(seed), int(offset), C.dt(qkv), C.stream())
+           heads, d, float(scale), float(p), int(seed), int(offset), C.ptr(offset_base), C.dt(qkv), C.stream())
     return ctx, stats, mask
 
 
-def attention_bwd(qkv, dctx, mask_add, stats, batch, seq_len, heads, scale, p=0.0, seed=0, offset=0):
+def attention_bwd(qkv, dctx, mask_add, stats, batch, seq_len, heads, scale, p=0.0, seed=0, offset=0, offset_base=None):
     """dqkv [T, 3H] from dctx [T, H]: probabilities and dropout mask are recomputed from (qkv, stats, seed, offset)."""
     C.require_cuda(qkv, dctx, mask_add, stats)
     t, h3 = qkv.shape
@@ -768,7 +772,7 @@ def attention_bwd(qkv, dctx, mask_add, stats, batch, seq_len, heads, scale, p=0.
     C.annotate(flops=10.0 * bh * seq_len * seq_len * d, bytes=float(t) * h * 2 * 7 + stats.numel() * 4,
                tag="B%dxh%dxS%dxd%d" % (batch, heads, seq_len, d))
     C.call("dle_attention_bwd", C.ptr(qkv), C.ptr(dctx), C.ptr(mask_add), C.ptr(stats), C.ptr(dqkv), batch, seq_len,
-           heads, d, float(scale), float(p), int(seed), int(offset), C.dt(qkv), C.stream())
+           heads, d, float(scale), float(p), int(seed), int(offset), C.ptr(offset_base), C.dt(qkv), C.stream())
     return dqkv
 
 

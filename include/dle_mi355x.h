@@ -280,16 +280,19 @@ int dle_softmax_bwd(const void* probs, void* dprobs, int64_t rows, int L, float 
  * The reference draws from torch's CUDA Philox stream, so masks are NOT bit-identical to the reference's; parity of
  * the step is checked against the oracle under the masks these entry points produce.                            */
 int dle_dropout_fwd(const void* x, void* y, void* mask, int64_t n, float p, uint64_t seed, uint64_t offset,
+                    const uint64_t* offset_base,
                     int dtype, hipStream_t stream);
 int dle_dropout_bwd(const void* dy, const void* mask, void* dx, int64_t n, float p, int dtype, hipStream_t stream);
 /* y = LayerNorm(dropout(x) + residual); z_out = dropout(x) + residual (16-bit, for the backward pass) */
 int dle_dropout_add_layernorm_fwd(const void* x, const void* residual, void* z_out, void* y, void* mask,
                                   const float* gamma, const float* beta, float* mean, float* rstd, int64_t rows,
-                                  int H, float eps, float p, uint64_t seed, uint64_t offset, int dtype,
+                                  int H, float eps, float p, uint64_t seed, uint64_t offset,
+                                  const uint64_t* offset_base, int dtype,
                                   hipStream_t stream);
 /* scores -> probs in place; dropped = dropout(probs) is the operand of the P V contraction */
 int dle_softmax_dropout_fwd(void* scores, void* dropped, void* mask, const float* mask_add, int64_t rows, int L,
-                            int rows_per_batch, float scale, float p, uint64_t seed, uint64_t offset, int dtype,
+                            int rows_per_batch, float scale, float p, uint64_t seed, uint64_t offset,
+                            const uint64_t* offset_base, int dtype,
                             hipStream_t stream);
 /* in place over dprobs: g = dP * mask / (1 - p); dS = P * (g - sum(g * P)) * scale */
 int dle_softmax_dropout_bwd(const void* probs, void* dprobs, const void* mask, int64_t rows, int L, float scale,
@@ -304,10 +307,12 @@ int dle_softmax_dropout_bwd(const void* probs, void* dprobs, const void* mask, i
  * stored.  dle_attention_supported: 1 when (S, head_dim) is inside the kernels' envelope. */
 int dle_attention_supported(int S, int head_dim);
 int dle_attention_fwd(const void* qkv, const float* mask_add, void* ctx, float* stats, void* keep_mask, int B, int S,
-                      int heads, int head_dim, float scale, float p, uint64_t seed, uint64_t offset, int dtype,
+                      int heads, int head_dim, float scale, float p, uint64_t seed, uint64_t offset,
+                      const uint64_t* offset_base, int dtype,
                       hipStream_t stream);
 int dle_attention_bwd(const void* qkv, const void* dctx, const float* mask_add, const float* stats, void* dqkv, int B,
-                      int S, int heads, int head_dim, float scale, float p, uint64_t seed, uint64_t offset, int dtype,
+                      int S, int heads, int head_dim, float scale, float p, uint64_t seed, uint64_t offset,
+                      const uint64_t* offset_base, int dtype,
                       hipStream_t stream);
 
 #ifdef __cplusplus

@@ -16,6 +16,23 @@ from deeplearningexamples_amd.utils import checkpoint as CK  # noqa: E402
 needs_ref = pytest.mark.skipif(not R.have_reference(), reason="reference tree not mounted")
 
 
+@pytest.fixture(autouse=True)
+def _restore_import_state():
+    """oracle/_ref_import stubs third-party modules (apex, dllogger, absl, dlrm.cuda_ext ...) and patches three torch
+    attributes to run the reference on CPU: undo all of it so that later test modules see the real shims."""
+    mods, path = dict(sys.modules), list(sys.path)
+    saved = (torch.cuda.current_device, torch.Tensor.cuda, torch.cuda.synchronize)
+    yield
+    torch.cuda.current_device, torch.Tensor.cuda, torch.cuda.synchronize = saved
+    for k in list(sys.modules):
+        if k not in mods and not k.startswith(("torch", "numpy", "scipy", "_pytest", "pytest")):
+            del sys.modules[k]          # stubs and reference modules; torch's own lazily imported parts stay
+    for k, v in mods.items():
+        if sys.modules.get(k) is not v:
+            sys.modules[k] = v
+    sys.path[:] = path
+
+
 @needs_ref
 def test_rn50_checkpoint_loads_into_reference_and_back(tmp_path):
     from deeplearningexamples_amd.convnets.resnet import ResNet50

