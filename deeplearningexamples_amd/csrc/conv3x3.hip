@@ -116,17 +116,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(C3Args p) {
         const int slot = wave * 64 + i * 32 + fr + tapoff;
         abase[i] = slot * 64 + ((fh ^ swz_kc(slot)) << 3);
       }
+      if constexpr (!DGRAD) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        ushort8_t fa[2], fb[WTN];
+        for (int ks = 0; ks < 4; ++ks) {
+          ushort8_t fa[2], fb[WTN];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i] = *(const ushort8_t*)(patch + (abase[i] ^ (ks << 4)));
+          for (int i = 0; i < 2; ++i) fa[i] = *(const ushort8_t*)(patch + (abase[i] ^ (ks << 4)));
 #pragma unroll
-        for (int j = 0; j < WTN; ++j) fb[j] = read_frag<DGRAD, NT>(tb, j * 32, ks, lane);
+          for (int j = 0; j < WTN; ++j) fb[j] = frag_issue<false, NT>(tb, j * 32, ks, lane);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < WTN; ++j) acc[i][j] = Mfma32x16<DT>::run(fb[j], fa[i], acc[i][j]);
+            for (int j = 0; j < WTN; ++j) acc[i][j] = Mfma32x16<DT>::run(fb[j], fa[i], acc[i][j]);
+        }
+      } else {
+        // weights through asm-issued transpose reads (gemm_tiles.h): requested one k-step ahead, one explicit wait each
+        TrPair fb[2][WTN];
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) fb[0][j] = frag_issue<true, NT>(tb, j * 32, 0, lane);
+        static_for<0, 4>([&](auto KS) __attribute__((always_inline)) {
+          constexpr int ks = decltype(KS)::value, cur = ks & 1, nxt = cur ^ 1;
+          ushort8_t fa[2], vb[WTN];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) fa[i] = *(const ushort8_t*)(patch + (abase[i] ^ (ks << 4)));
+          frag_wait<true>();
+          if constexpr (ks < 3) {
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) fb[nxt][j] = frag_issue<true, NT>(tb, j * 32, ks + 1, lane);
+          }
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) vb[j] = frag_value(fb[cur][j]);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) acc[i][j] = Mfma32x16<DT>::run(vb[j], fa[i], acc[i][j]);
+        });
       }
       stage ^= 1;
       if (++tapcol == 3) { tapcol = 0; tapoff += p.Wp - 2; } else ++tapoff;

@@ -284,17 +284,47 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
       if (NSTAGE == 2 && kt + 1 < kt1) issue_all(kt + 1, stage ^ 1);
       const unsigned short* ta = lds + stage * STAGE;
       const unsigned short* tb = ta + TM * BK;
+      if constexpr (!(RCA || RCB)) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {      // 4 k-steps of 16
-        ushort8_t fa[WTM], fb[WTN];
+        for (int ks = 0; ks < 4; ++ks) {      // 4 k-steps of 16
+          ushort8_t fa[WTM], fb[WTN];
 #pragma unroll
-        for (int i = 0; i < WTM; ++i) fa[i] = read_frag<RCA, TM>(ta, wm * (WTM * 32) + i * 32, ks, lane);
+          for (int i = 0; i < WTM; ++i) fa[i] = frag_issue<false, TM>(ta, wm * (WTM * 32) + i * 32, ks, lane);
 #pragma unroll
-        for (int j = 0; j < WTN; ++j) fb[j] = read_frag<RCB, TN>(tb, wn * (WTN * 32) + j * 32, ks, lane);
+          for (int j = 0; j < WTN; ++j) fb[j] = frag_issue<false, TN>(tb, wn * (WTN * 32) + j * 32, ks, lane);
 #pragma unroll
-        for (int i = 0; i < WTM; ++i)
+          for (int i = 0; i < WTM; ++i)
 #pragma unroll
-          for (int j = 0; j < WTN; ++j) acc[i][j] = Mfma32x16<DT>::run(fb[j], fa[i], acc[i][j]);
+            for (int j = 0; j < WTN; ++j) acc[i][j] = Mfma32x16<DT>::run(fb[j], fa[i], acc[i][j]);
+        }
+      } else {
+        // transpose-read operands are issued by inline asm (gemm_tiles.h): software pipeline by hand -- the fragments of
+        // k-step ks + 1 are requested before the MFMAs of k-step ks, one explicit wait per k-step
+        typename FragT<RCA>::type fa[2][WTM];
+        typename FragT<RCB>::type fb[2][WTN];
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) fa[0][i] = frag_issue<RCA, TM>(ta, wm * (WTM * 32) + i * 32, 0, lane);
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) fb[0][j] = frag_issue<RCB, TN>(tb, wn * (WTN * 32) + j * 32, 0, lane);
+        static_for<0, 4>([&](auto KS) __attribute__((always_inline)) {
+          constexpr int ks = decltype(KS)::value, cur = ks & 1, nxt = cur ^ 1;
+          frag_wait<true>();
+          if constexpr (ks < 3) {
+#pragma unroll
+            for (int i = 0; i < WTM; ++i) fa[nxt][i] = frag_issue<RCA, TM>(ta, wm * (WTM * 32) + i * 32, ks + 1, lane);
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) fb[nxt][j] = frag_issue<RCB, TN>(tb, wn * (WTN * 32) + j * 32, ks + 1, lane);
+          }
+          ushort8_t va[WTM], vb[WTN];
+#pragma unroll
+          for (int i = 0; i < WTM; ++i) va[i] = frag_value(fa[cur][i]);
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) vb[j] = frag_value(fb[cur][j]);
+#pragma unroll
+          for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) acc[i][j] = Mfma32x16<DT>::run(vb[j], va[i], acc[i][j]);
+        });
       }
     }
   } else {
@@ -310,19 +340,26 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
     //    and k-step 0 of the current one (a piece costs ~60-180 issue cycles during which this wave issues nothing
     //    else -- never in a burst), which leaves them two k-steps to land before the barrier.  Past the last K
     //    tile every piece is out of range and zero-fills the idle stage (no branch in the loop).
-    ushort8_t fa[2][WTM], fb[2][WTN];
+    typename FragT<RCA>::type fa[2][WTM];
+    typename FragT<RCB>::type fb[2][WTN];
     auto kstep = [&](auto CUR, const unsigned short* ra, const unsigned short* rb, auto RKS, int dkt, int dstage,
                      auto HALF) {
       constexpr int cur = decltype(CUR)::value, nxt = cur ^ 1, rks = decltype(RKS)::value, half = decltype(HALF)::value;
+      frag_wait<RCA || RCB>();             // asm-issued transpose reads of the previous k-step (no-op for k-contiguous operands)
+      ushort8_t va[WTM], vb[WTN];
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) va[i] = frag_value(fa[cur][i]);
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) vb[j] = frag_value(fb[cur][j]);
       static_for<0, NM>([&](auto MI) {
         constexpr int m = decltype(MI)::value;
         constexpr int i = m / WTN, j = m % WTN;
-        acc[i][j] = Mfma32x16<DT>::run(fb[cur][j], fa[cur][i], acc[i][j]);
+        acc[i][j] = Mfma32x16<DT>::run(vb[j], va[i], acc[i][j]);
         static_for<0, NR>([&](auto U) {
           constexpr int u = decltype(U)::value;
           if constexpr ((u * (NM / 2)) / NR == m) {
-            if constexpr (u < WTM) fa[nxt][u] = read_frag<RCA, TM>(ra, wm * (WTM * 32) + u * 32, rks, lane);
-            else fb[nxt][u - WTM] = read_frag<RCB, TN>(rb, wn * (WTN * 32) + (u - WTM) * 32, rks, lane);
+            if constexpr (u < WTM) fa[nxt][u] = frag_issue<RCA, TM>(ra, wm * (WTM * 32) + u * 32, rks, lane);
+            else fb[nxt][u - WTM] = frag_issue<RCB, TN>(rb, wn * (WTN * 32) + (u - WTM) * 32, rks, lane);
           }
         });
         if constexpr (half >= 0) {
@@ -345,9 +382,9 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < WTM; ++i) fa[0][i] = read_frag<RCA, TM>(lds, wm * (WTM * 32) + i * 32, 0, lane);
+    for (int i = 0; i < WTM; ++i) fa[0][i] = frag_issue<RCA, TM>(lds, wm * (WTM * 32) + i * 32, 0, lane);
 #pragma unroll
-    for (int j = 0; j < WTN; ++j) fb[0][j] = read_frag<RCB, TN>(lds + TM * BK, wn * (WTN * 32) + j * 32, 0, lane);
+    for (int j = 0; j < WTN; ++j) fb[0][j] = frag_issue<RCB, TN>(lds + TM * BK, wn * (WTN * 32) + j * 32, 0, lane);
     static_for<0, 2>([&](auto J) { issue_a(kt0 + 1, 1, J); issue_b(kt0 + 1, 1, J); });
     __builtin_amdgcn_sched_barrier(0);
     for (int kt = kt0; kt < kt1; ++kt) {
@@ -576,8 +613,12 @@ static int launch_gemm(const Gemm2Args& p_in, int in_dtype, int amode, int bmode
   const long long tiles_big = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   const bool fits = amode <= 1 && bmode <= 1 && p.M >= 256 && p.N >= 256 &&
                     p.lda * 512 <= 0x7FFFFFFFLL && p.ldb * 512 <= 0x7FFFFFFFLL;
-  // (split-K weight gradients stay on the 128x128 tile: measured faster there -- more, smaller slabs in flight)
-  const bool want = !p.force_small && (big_mode >= 1 || (big_mode != 0 && p.splitk == 1 && kt_per_item >= 4 && tiles_big * (batch > 0 ? batch : 1) >= 160));
+  // Split-K weight gradients (fp32 slabs) take the big tile too once their slices cover half the chip: the 128x128 tile
+  // issues 8 LDS-DMA pieces per wave per 16 MFMAs and is bound by that issue cost (~590 TFLOP/s); the 256x256 tile
+  // halves it.  (It measured SLOWER before the transpose reads went to inline asm: every one of them drained the DMA queue.)
+  const long long work_big = tiles_big * (batch > 0 ? batch : 1) * (SLAB_MODE(p) ? p.splitk : 1);
+  const bool want = !p.force_small && (big_mode >= 1 || (big_mode != 0 && (p.splitk == 1 || SLAB_MODE(p)) && kt_per_item >= 4 &&
+                                                         work_big >= (p.splitk == 1 ? 160 : 128)));
   if (fits && want) {
     dim3 grid((unsigned)tiles_big, p.splitk, batch > 0 ? batch : 1), block(512);
     const size_t lds_big = 2 * (256 * BK + 256 * BK) * 2;

@@ -221,9 +221,28 @@ struct Loader {
 };
 
 // One MFMA operand fragment (32 rows x 16 k, 8 halves per lane) out of a TILE x 64 LDS image.
+//
+// Row-contiguous images are read with the LDS transpose read.  It is issued through INLINE ASM on purpose: hipcc (ROCm
+// 7.2) treats the ds_read_tr builtin as a possible alias of every LDS-DMA in flight and puts `s_waitcnt vmcnt(0)` in front
+// of it -- in a DMA-pipelined K loop that drains the prefetch of the NEXT tile before the current one is computed (the
+// weight-gradient GEMMs ran with no DMA / MFMA overlap inside a workgroup, the data-gradient GEMMs drained twice per K
+// tile).  The price: the compiler does not track an asm DS operation, so the caller waits for it explicitly
+// (frag_wait()) before the first use; compiler-generated lgkmcnt waits for its own reads stay correct (the counter is
+// in order, foreign entries only make them conservative).
+struct TrPair { short4_t lo, hi; };                 // the two 64-bit transpose reads of one fragment, as issued
+template <bool RC> struct FragT { typedef ushort8_t type; };
+template <> struct FragT<true> { typedef TrPair type; };
+
+__device__ __forceinline__ short4_t ds_read_tr16_asm(const unsigned short* p) {
+  short4_t v;
+  const unsigned addr = (unsigned)(unsigned long)(__attribute__((address_space(3))) const unsigned short*)p;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
 template <bool RC, int TILE>
-__device__ __forceinline__ ushort8_t read_frag(const unsigned short* t, int rbase32, int ks, int lane) {
-  if (!RC) {
+__device__ __forceinline__ typename FragT<RC>::type frag_issue(const unsigned short* t, int rbase32, int ks, int lane) {
+  if constexpr (!RC) {
     const int row = rbase32 + (lane & 31);
     return *(const ushort8_t*)(t + row * BK + (((ks * 2 + (lane >> 5)) ^ swz_kc(row)) << 3));
   } else {
@@ -232,17 +251,32 @@ __device__ __forceinline__ ushort8_t read_frag(const unsigned short* t, int rbas
     const int rbase = rbase32 + ((tg & 1) << 4);
     const int kb = ks * 16 + (tg >> 1) * 8 + (ti >> 2);
     const int chunk = (rbase >> 3) + ((ti & 3) >> 1);
-    ushort8_t f;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int k = kb + h * 4;
+    TrPair f;
+    {
+      const int cpos = (((chunk >> 1) ^ swz_rc<TILE>(kb)) << 1) | (chunk & 1);
+      f.lo = ds_read_tr16_asm(t + kb * TILE + cpos * 8 + ((ti & 1) << 2));
+    }
+    {
+      const int k = kb + 4;
       const int cpos = (((chunk >> 1) ^ swz_rc<TILE>(k)) << 1) | (chunk & 1);
-      const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) short4_t*)(t + k * TILE + cpos * 8 + ((ti & 1) << 2)));
-#pragma unroll
-      for (int e = 0; e < 4; ++e) f[h * 4 + e] = (unsigned short)v[e];
+      f.hi = ds_read_tr16_asm(t + k * TILE + cpos * 8 + ((ti & 1) << 2));
     }
     return f;
+  }
+}
+__device__ __forceinline__ ushort8_t frag_value(const ushort8_t& f) { return f; }
+__device__ __forceinline__ ushort8_t frag_value(const TrPair& f) {
+  ushort8_t r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = (unsigned short)f.lo[e]; r[4 + e] = (unsigned short)f.hi[e]; }
+  return r;
+}
+// every asm-issued fragment read of this wave has landed (call before the first frag_value() of a batch)
+template <bool ANY_RC>
+__device__ __forceinline__ void frag_wait() {
+  if constexpr (ANY_RC) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);        // hipcc hoists register-only MFMAs over an asm wait otherwise
   }
 }
 

@@ -74,3 +74,49 @@ class StepTimer:
         self._new = time.time()
         if self._previous is not None:
             self.measured = self._new - self._previous
+
+
+def roc_auc_score(y_true: torch.Tensor, y_score: torch.Tensor) -> float:
+    """Area under the ROC curve, the validation metric of the reference (dlrm/scripts/utils.py:289-320, sklearn's
+    definition): thresholds at the distinct score values, trapezoid rule over (fpr, tpr).  Runs on the tensors' device
+    (sort + prefix sum); float64 accumulation so that 10^8 validation samples keep their last digits."""
+    y_true, y_score = y_true.reshape(-1), y_score.reshape(-1)
+    if y_true.shape != y_score.shape:
+        raise TypeError("Shape of y_true and y_score must match. Got %s and %s." % (tuple(y_true.shape), tuple(y_score.shape)))
+    order = torch.argsort(y_score, descending=True)
+    s, t = y_score[order], y_true[order].to(torch.float64)
+    n = t.numel()
+    last = torch.ones(n, dtype=torch.bool, device=s.device)          # last element of every run of equal scores
+    last[:-1] = s[1:] != s[:-1]
+    idx = torch.nonzero(last).reshape(-1)
+    tps = torch.cumsum(t, 0)[idx]
+    fps = (idx + 1).to(torch.float64) - tps
+    zero = torch.zeros(1, dtype=torch.float64, device=s.device)
+    tps, fps = torch.cat([zero, tps]), torch.cat([zero, fps])
+    if float(tps[-1]) == 0.0 or float(fps[-1]) == 0.0:
+        return float("nan")                                          # one class only: the curve is undefined
+    return float(torch.trapz(tps / tps[-1], fps / fps[-1]).item())
+
+
+@torch.no_grad()
+def evaluate(model, batches, world_size=1, rank=0, batch_sizes_per_gpu=None, process_group=None, exchange=None):
+    """Validation pass (dlrm/scripts/main.py:733-835 dist_evaluate): forward only, every rank's logits gathered, AUC and
+    BCE loss over the whole validation set.  batches: iterable of (numerical or None, categorical or None, click).
+    exchange: the trainer's bottom -> top all-to-all (DlrmTrainer._bottom_to_top) when world_size > 1.
+    Returns (auc, loss)."""
+    import torch.distributed as dist
+    y_true, y_score = [], []
+    for num, cat, click in batches:
+        x = model.bottom_model(num, cat)
+        if world_size > 1:
+            x = exchange(x)
+        out = model.top_model(x).reshape(-1).float()
+        if world_size > 1:
+            parts = [torch.empty(b, dtype=out.dtype, device=out.device) for b in batch_sizes_per_gpu]
+            dist.all_gather(parts, out, group=process_group)
+            out = torch.cat(parts)
+        y_true.append(click.reshape(-1).float())
+        y_score.append(out)
+    y_true, y_score = torch.cat(y_true), torch.cat(y_score)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(y_score, y_true)
+    return roc_auc_score(y_true, y_score), float(loss.item())

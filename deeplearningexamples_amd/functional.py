@@ -272,8 +272,17 @@ def colsum(x, out=None, accumulate=False):
 
 
 def pick_splitk(m_out, n_out, k, target_blocks=512):
-    """Split the contraction so that a skinny wgrad still fills 256 CUs (K tiles of 64)."""
+    """Split the contraction so that a skinny wgrad still fills 256 CUs (K tiles of 64).  Outputs of at least 256x256
+    run on the 256x256 tile (gemm_dma.hip launch_gemm): ONE slice per CU (256 // tiles, each >= 4 K tiles deep) -- the big
+    tile issues half the LDS-DMA pieces per MFMA of the 128x128 one, which is what bounds the split weight gradients."""
     ktiles = (k + 63) // 64
+    if m_out >= 256 and n_out >= 256 and "DLE_SPLITK_TARGET" not in os.environ:
+        tiles_big = ((m_out + 255) // 256) * ((n_out + 255) // 256)
+        if tiles_big >= 160:
+            return 1
+        s = min(ktiles // 4, max(256 // tiles_big, 1))
+        if s >= 2 and tiles_big * s >= 128:
+            return s
     target_blocks = int(os.environ.get("DLE_SPLITK_TARGET", target_blocks))      # tuning knob (tools/, not the product default)
     tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
     s = max(1, min(ktiles, target_blocks // max(tiles, 1)))

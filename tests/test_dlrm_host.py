@@ -91,3 +91,32 @@ def test_all_to_all_layout_two_ranks_gloo():
         ret = mgr.dict()
         mp.spawn(_a2a_worker, args=(2, port, ret), nprocs=2, join=True)
         assert ret[0] and ret[1]
+
+
+def test_roc_auc_matches_sklearn_and_reference():
+    """dlrm/utils.roc_auc_score vs sklearn (the definition the reference restates) and, when the tree is mounted, vs the
+    reference's own function (dlrm/scripts/utils.py:289-320): ties, skewed classes, one-class input."""
+    import numpy as np
+    import torch
+    from sklearn.metrics import roc_auc_score as sk_auc
+    from deeplearningexamples_amd.dlrm.utils import roc_auc_score
+    g = torch.Generator().manual_seed(0)
+    cases = []
+    y = (torch.rand(5000, generator=g) < 0.3).float()
+    cases.append((y, torch.randn(5000, generator=g) + y))                                  # informative scores
+    cases.append((y, torch.randint(0, 7, (5000,), generator=g).float()))                   # heavy ties
+    cases.append(((torch.rand(4000, generator=g) < 0.01).float(), torch.rand(4000, generator=g)))
+    for yt, ys in cases:
+        assert abs(roc_auc_score(yt, ys) - sk_auc(yt.numpy(), ys.numpy())) < 1e-9
+    assert np.isnan(roc_auc_score(torch.ones(10), torch.rand(10, generator=g)))
+    from oracle import _ref_import as R
+    if R.have_reference():
+        import importlib.util, os
+        spec = importlib.util.spec_from_file_location("ref_dlrm_utils_auc", os.path.join(
+            R.REF, "PyTorch/Recommendation/DLRM/dlrm/scripts/utils.py"))
+        src = open(spec.origin).read()
+        ns = {"torch": torch}
+        start = src.index("def roc_auc_score")
+        exec(compile(src[start:], spec.origin, "exec"), ns)                                # the function alone (the module imports dllogger)
+        for yt, ys in cases[:2]:
+            assert abs(roc_auc_score(yt, ys) - ns["roc_auc_score"](yt.clone(), ys.clone())) < 1e-6

@@ -189,3 +189,34 @@ def test_dropout_masks_bit_exact_vs_philox_oracle(cuda):
     ref3 = P.keep_mask(scores.numel(), 0.1, 11, 12).reshape(scores.shape)
     assert np.array_equal(F.unpack_dropout_mask(m3, scores.shape).cpu().numpy(), ref3)
     assert torch.equal(dropped != 0, torch.from_numpy(ref3).to(cuda) & (scores != 0))
+
+
+def test_bert_phase2_seq512_vs_oracle(cuda):
+    """Phase 2 of the reference's recipe (run_pretraining.py --phase2: sequence length 512, 80 predictions): S = 512 is
+    outside the fused attention kernels' envelope, the step runs on the batched-GEMM + softmax path.  Loss and every
+    gradient of the first step vs the CPU oracle."""
+    c = BO.BERT_STEP_CONFIG
+    cfg = dict(c["cfg"], seq=512)
+    state = BO.seeded_state(cfg, c["seed"])
+    model, tr = _build(cuda, torch.float16, dict(c, cfg=cfg), state)
+    cpu_batch = BO.seeded_batch(cfg, 7, 2)
+    assert cpu_batch[0].shape == (2, 512)
+    orc = BO.BertOracle(cfg, state)
+    lo = orc.loss(*cpu_batch)
+    lo.backward()
+    loss, dlog, dnsp = tr.forward(*[t.to(cuda) for t in cpu_batch])
+    assert not tr._sv["fused_attn"]
+    assert abs(loss.item() - float(lo)) <= 1e-3 * float(lo)
+    tr.backward(dlog, dnsp)
+    torch.cuda.synchronize()
+    scale = float(tr.scaler.scale.item())
+    bad = []
+    for n, p in orc.p.items():
+        g = tr.gview[n].reshape(-1).cpu().double() / scale
+        r = p.grad.reshape(-1).double()
+        if float(r.norm()) < 1e-6:
+            continue
+        rel = float((g - r).norm() / (r.norm() + 1e-12))
+        if rel > 0.03:
+            bad.append((n, round(rel, 4)))
+    assert not bad, bad[:12]

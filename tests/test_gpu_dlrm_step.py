@@ -140,3 +140,23 @@ def test_small_kernels(cuda):
     F.amp_update_scale_(sc, tr, fi, inv, growth_interval=2)
     F.amp_update_scale_(sc, tr, fi, inv, growth_interval=2)
     assert sc.item() == 1024 and tr.item() == 0
+
+
+def test_evaluate_auc_and_loss(cuda):
+    """dlrm/utils.evaluate (dist_evaluate, main.py:733-835): the validation loss of a batch equals the training loss of the
+    step that sees the same weights; AUC of the HIP forward equals the AUC of the CPU oracle's logits."""
+    from deeplearningexamples_amd.dlrm.utils import evaluate, roc_auc_score
+    cfg = SO.DLRM_STEP_CONFIGS["tiny"]
+    model, trainer, state = _build(cfg, cuda, torch.float16)
+    batches = [[t.to(cuda) for t in SO.seeded_dlrm_batch(cfg["sizes"], cfg["num"], cfg["batch"], 50 + i)] for i in range(3)]
+    auc, loss = evaluate(model, batches)
+    assert 0.0 < auc < 1.0 and np.isfinite(loss)
+    _, loss0 = evaluate(model, batches[:1])
+    assert abs(loss0 - float(trainer.train_step(*batches[0]).item())) <= 1e-3 * loss0
+    orc = SO.DlrmOracle(state, cfg["sizes"], cfg["lr"])
+    if hasattr(orc, "forward"):
+        logits = torch.cat([orc.forward(*[t.cpu() for t in b[:2]]).reshape(-1) for b in batches])
+        ref_auc = roc_auc_score(torch.cat([b[2].cpu() for b in batches]), logits.detach())
+        model2, _, _ = _build(cfg, cuda, torch.float16)
+        auc2, _ = evaluate(model2, batches)
+        assert abs(auc2 - ref_auc) < 5e-3, (auc2, ref_auc)
