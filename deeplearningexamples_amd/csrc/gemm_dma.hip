@@ -55,6 +55,7 @@ struct Gemm2Args {
   int debug_skip;        // reserved (profiling ablations)
   float* stats;          // per-tile-row column sums of the ROUNDED output: [tiles_m][2][N] (sum, sum of squares); NULL: off
   int force_small;       // keep the 128x128 tile (stats layout is indexed by 128-row tiles)
+  int persist;           // 128x128 tile only: the grid is smaller than the tile list, a workgroup walks tiles bid, bid + grid, ...
   long long sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
 };
 
@@ -207,25 +208,30 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
 
   const int tiles_m = (p.M + TM - 1) / TM, tiles_n = (p.N + TN - 1) / TN;
   const int ntiles = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
   // Each XCD (private L2) works through a contiguous chunk of the tile list; the list is ordered in groups of GM tile
   // rows walked column by column, so the ~32-64 tiles an XCD runs at once form a GM x (32..64/GM) block: per K step
   // they pull GM A tiles + a few B tiles through L2 instead of 1 + 32 (a 1 x 32 strip re-reads the whole B matrix
   // once per tile row: 4 GB of L2 fills for an 8192^3 GEMM).
   constexpr int GM = 8;
-  int tm, tn;
-  {
+  auto tile_coords = [&](int bid, int& tm_, int& tn_) __attribute__((always_inline)) {
+    const int q = ntiles >> 3, r8 = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
     const int per_group = GM * tiles_n;
     const int g = bid / per_group, r = bid - g * per_group;
     const int rows = (tiles_m - g * GM) < GM ? (tiles_m - g * GM) : GM;
-    tm = g * GM + r % rows;
-    tn = r / rows;
-  }
-  const int m0 = tm * TM, n0 = tn * TN;
+    tm_ = g * GM + r % rows;
+    tn_ = r / rows;
+  };
+  // Persistent walk (128x128 tile, no split-K): the workgroup's NEXT tile is prefetched (its first K tile, into the
+  // stage the last K tile of the current one does not occupy) before the current tile's epilogue, so the DMA latency
+  // at the head of a tile and the store drain at its tail overlap -- the K <= 256 layers of ResNet-50 (1-4 K tiles per
+  // tile) ran at half the HBM rate with two one-shot workgroups per CU.
+  const int vstep = (int)gridDim.x;
+  int vbid = blockIdx.x;
+  int tm, tn;
+  tile_coords(vbid, tm, tn);
+  int m0 = tm * TM, n0 = tn * TN;          // current tile (epilogue)
+  int lm0 = m0, ln0 = n0;                  // the tile the loaders address (runs one tile ahead at tile boundaries)
 
   // balanced K slices: slice z owns k tiles [z*T/S, (z+1)*T/S) -- non-empty for every z when S <= T
   const int ktiles = (p.K + BK - 1) / BK;
@@ -236,20 +242,20 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
 
   LA la;
   LB lb;
-  la.init(wave, lane, m0, p.M, p.lda, p.cg);
-  lb.init(wave, lane, n0, p.N, p.ldb, p.cg);
+  la.init(wave, lane, lm0, p.M, p.lda, p.cg);
+  lb.init(wave, lane, ln0, p.N, p.ldb, p.cg);
 
   // DMA piece J of operand A / B of K tile kt into `stage` (one wave instruction each)
   auto issue_a = [&](int kt, int stage, auto J) __attribute__((always_inline)) {
     const int k0 = kt * BK;
-    const unsigned short* ba = A_MODE == 0 ? p.A + (long long)m0 * p.lda + k0
-                             : A_MODE == 1 ? p.A + (long long)k0 * p.lda + m0 : p.A;
+    const unsigned short* ba = A_MODE == 0 ? p.A + (long long)lm0 * p.lda + k0
+                             : A_MODE == 1 ? p.A + (long long)k0 * p.lda + lm0 : p.A;
     la.template issue<decltype(J)::value, decltype(J)::value + 1>(ba, lds + stage * STAGE, wave, kend - k0, k0, p.cg);
   };
   auto issue_b = [&](int kt, int stage, auto J) __attribute__((always_inline)) {
     const int k0 = kt * BK;
-    const unsigned short* bb = B_MODE == 0 ? p.B + (long long)n0 * p.ldb + k0
-                             : B_MODE == 1 ? p.B + (long long)k0 * p.ldb + n0 : p.B;
+    const unsigned short* bb = B_MODE == 0 ? p.B + (long long)ln0 * p.ldb + k0
+                             : B_MODE == 1 ? p.B + (long long)k0 * p.ldb + ln0 : p.B;
     lb.template issue<decltype(J)::value, decltype(J)::value + 1>(bb, lds + stage * STAGE + TM * BK, wave, kend - k0, k0, p.cg);
   };
   auto issue_all = [&](int kt, int stage) __attribute__((always_inline)) {
@@ -258,14 +264,22 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
   };
 
   float16_t acc[WTM][WTN];
+  if (kt0 < kt1) issue_all(kt0, 0);
+  int s0 = 0;                              // stage of this tile's first K tile (128x128 tile)
+  int stage_last = 0;
+  for (;;) {                               // tiles of this workgroup (one trip unless p.persist)
+  constexpr bool CAN_PERSIST = !BIG && A_MODE <= 1 && B_MODE <= 1;      // (the convolution loaders are too register-heavy)
+  const bool has_next = CAN_PERSIST && p.persist && vbid + vstep < ntiles;
+  if (CAN_PERSIST && vbid != (int)blockIdx.x) {   // (re-derived here, not kept alive across the epilogue: registers)
+    la.init(wave, lane, lm0, p.M, p.lda, p.cg);
+    lb.init(wave, lane, ln0, p.N, p.ldb, p.cg);
+  }
 #pragma unroll
   for (int i = 0; i < WTM; ++i)
 #pragma unroll
     for (int j = 0; j < WTN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  if (kt0 < kt1) issue_all(kt0, 0);
 
   const int fr = lane & 31, fh = lane >> 5;          // 32x32x16 fragment: row fr, k group fh (8 elements)
   constexpr bool RCA = LA::RC, RCB = LB::RC;
@@ -274,7 +288,8 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
     // 128x128 tile: DMA of the next K tile at the top, then 4 k-steps; hipcc schedules the body (2-4 workgroups
     // per CU overlap each other's bubbles)
     for (int kt = kt0; kt < kt1; ++kt) {
-      const int stage = NSTAGE == 1 ? 0 : (kt - kt0) & 1;
+      const int stage = NSTAGE == 1 ? 0 : s0 ^ ((kt - kt0) & 1);
+      stage_last = stage;
       if (NSTAGE == 1 && kt > kt0) {
         __syncthreads();                    // everyone is done reading the single stage
         issue_all(kt, 0);
@@ -282,6 +297,14 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA pieces of tile kt have landed
       __syncthreads();                      // ... and everybody's; everyone is done reading the other stage
       if (NSTAGE == 2 && kt + 1 < kt1) issue_all(kt + 1, stage ^ 1);
+      else if (CAN_PERSIST && NSTAGE == 2 && has_next) {   // last K tile: the loaders move on to the next tile of this workgroup
+        int ntm, ntn;
+        tile_coords(vbid + vstep, ntm, ntn);
+        lm0 = ntm * TM; ln0 = ntn * TN;
+        la.init(wave, lane, lm0, p.M, p.lda, p.cg);
+        lb.init(wave, lane, ln0, p.N, p.ldb, p.cg);
+        issue_all(kt0, stage ^ 1);
+      }
       const unsigned short* ta = lds + stage * STAGE;
       const unsigned short* tb = ta + TM * BK;
       if constexpr (!(RCA || RCB)) {
@@ -409,7 +432,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
   // contiguous row segments per 16 lanes.  Two passes of TM/2 rows (the wm = 0 waves, then the wm = 1 waves);
   // 16-byte slots XOR-swizzled by the row keep the staging tile at exactly the size of the operand stages
   // (32 KiB / 128 KiB) with conflict-free ds_write_b128 / ds_read_b128.
-  float* epi = (float*)smem_raw;
+  float* epi = (float*)smem_raw + (BIG ? 0 : stage_last * (STAGE / 2));   // (the other stage may hold the prefetched next tile)
   const bool vec16 = (p.ldc & 7) == 0 && ((((uintptr_t)p.C) | ((uintptr_t)p.aux) | ((uintptr_t)p.mask_src)) & 15) == 0;
   // Fast path (interior tile, 16-bit output of the input type, 16-byte aligned rows, no split-K): everything that does
   // not depend on the row -- the lane's 8 columns, its bias values, the swizzled LDS slots, the activation kind -- is
@@ -503,7 +526,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
       }
     }
   };
-  __builtin_amdgcn_s_waitcnt(0x0F70);    // the zero-fill DMA issued under the last K tile has landed
+  if (BIG) __builtin_amdgcn_s_waitcnt(0x0F70);    // the zero-fill DMA issued under the last K tile has landed
   for (int half = 0; half < 2; ++half) {
   lds_barrier();                         // operand stages (half 0) / previous half's tile are no longer read
   if (wm == half) {
@@ -592,6 +615,12 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
       if (n0 + col < p.N) p.stats[((long long)tm * 2 + which) * p.N + n0 + col] = t;
     }
   }
+  if (!CAN_PERSIST || !has_next) break;
+  vbid += vstep;
+  tile_coords(vbid, tm, tn);
+  m0 = tm * TM; n0 = tn * TN;
+  s0 = stage_last ^ 1;
+  }
 }
 
 // One launcher for every entry point.  modes: (A_MODE, B_MODE) in {(0,0),(0,1),(1,1),(2,0),(4,5),(1,3)}.
@@ -632,7 +661,11 @@ static int launch_gemm(const Gemm2Args& p_in, int in_dtype, int amode, int bmode
   } else {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const size_t lds = GEMM2_LDS_BYTES;
-    dim3 grid(tiles, p.splitk, batch > 0 ? batch : 1), block(256);
+    // persistent walk: two resident workgroups per CU, each prefetching its next tile under the current epilogue
+    static const int persist_mode = getenv("DLE_GEMM_PERSIST") ? atoi(getenv("DLE_GEMM_PERSIST")) : 1;
+    const int resident = 2 * 256;
+    p.persist = persist_mode && amode <= 1 && bmode <= 1 && p.splitk == 1 && batch <= 0 && tiles > resident;
+    dim3 grid(p.persist ? resident : tiles, p.splitk, batch > 0 ? batch : 1), block(256);
     // (a single-stage, 4-workgroups-per-CU variant for K <= 128 existed; with the hoisted epilogue it measured 2x
     //  SLOWER than this one -- 802816x256x64: 295 vs 144 us -- its 128-VGPR budget spilled; removed)
 #define GO(DT, AM, BMODE) hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE, 2, 0>), grid, block, lds, stream, p)
