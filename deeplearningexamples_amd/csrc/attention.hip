@@ -107,16 +107,30 @@ __device__ __forceinline__ ushort8_t at_img_frag_cols(const unsigned short* t, i
   return f;
 }
 
-// keep bits of this lane's 4 elements (columns 8 c + 4 hf + 0..3) of chunk `chunk`: bit j <-> element 4 hf + j
-__device__ __forceinline__ unsigned at_keep4(const DropArgs& d, unsigned chunk, int hf) {
-  const uint4_t r = philox4x32_10((uint4_t){chunk, 0u, d.off_lo, d.off_hi}, d.seed_lo, d.seed_hi);
-  const unsigned w0 = hf ? r[2] : r[0], w1 = hf ? r[3] : r[1];
-  unsigned bits = 0;
-  bits |= ((w0 & 0xffffu) >= d.thr ? 1u : 0u);
-  bits |= ((w0 >> 16) >= d.thr ? 1u : 0u) << 1;
-  bits |= ((w1 & 0xffffu) >= d.thr ? 1u : 0u) << 2;
-  bits |= ((w1 >> 16) >= d.thr ? 1u : 0u) << 3;
-  return bits;
+// Keep bits of this lane's 64 elements of query row chunk0 / 16: keepw[kb] bit (4 rq + j) <-> key kb*32 + 8 rq + 4 hf + j,
+// i.e. element 4 hf + j of chunk chunk0 + 4 kb + rq.  One Philox call yields the 8 decisions of a chunk and the two lanes
+// of a row (hf = 0 / 1) need 4 each: a lane runs the generator for the chunks c with c % 2 == hf only and trades the other
+// half of its words with lane ^ 32 -- the kernels were bound by the 32-bit multiplies of 16 calls per lane.
+__device__ __forceinline__ unsigned at_bits4(unsigned w0, unsigned w1, unsigned thr) {
+  return ((w0 & 0xffffu) >= thr ? 1u : 0u) | ((w0 >> 16) >= thr ? 2u : 0u) | ((w1 & 0xffffu) >= thr ? 4u : 0u) |
+         ((w1 >> 16) >= thr ? 8u : 0u);
+}
+__device__ __forceinline__ void at_keep_row(const DropArgs& d, unsigned chunk0, int hf, unsigned* keepw) {
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {                       // chunk pair (rq = 2 pr, 2 pr + 1) of this key block
+      const int rq_mine = 2 * pr + hf, rq_other = 2 * pr + (hf ^ 1);
+      const uint4_t r = philox4x32_10((uint4_t){chunk0 + (unsigned)(kb * 4 + rq_mine), 0u, d.off_lo, d.off_hi}, d.seed_lo, d.seed_hi);
+      const unsigned mine0 = hf ? r[2] : r[0], mine1 = hf ? r[3] : r[1];          // elements 4 hf .. + 3 of my chunk
+      const unsigned give0 = hf ? r[0] : r[2], give1 = hf ? r[1] : r[3];          // the partner's elements of my chunk
+      const unsigned got0 = (unsigned)__shfl_xor((int)give0, 32, 64), got1 = (unsigned)__shfl_xor((int)give1, 32, 64);
+      bits |= at_bits4(mine0, mine1, d.thr) << (4 * rq_mine);
+      bits |= at_bits4(got0, got1, d.thr) << (4 * rq_other);
+    }
+    keepw[kb] = bits;
+  }
 }
 
 // Accumulator block [32 values of the register-indexed dimension x 32 lanes] -> 8-byte LDS writes of a wave-private
@@ -228,20 +242,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   ushort8_t pd[8];
   const bool drop = p.drop.thr != 0;
   const unsigned chunk0 = ((unsigned)bh * AT_S + (unsigned)q) * 16u;
+  unsigned keepw[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+  if (drop) at_keep_row(p.drop, chunk0, hf, keepw);
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
-    unsigned mbits = 0;
+    if (drop) {
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      if (drop) {
-        const unsigned keep = at_keep4(p.drop, chunk0 + kb * 4 + rq, hf);
-        mbits |= keep << (8 * rq);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s[kb][rq * 4 + j] = ((keep >> j) & 1u) ? s[kb][rq * 4 + j] * p.drop.inv_keep : 0.f;
-      }
+      for (int r = 0; r < 16; ++r) s[kb][r] = ((keepw[kb] >> r) & 1u) ? s[kb][r] * p.drop.inv_keep : 0.f;
     }
     if (p.mask_out && drop) {
-      const unsigned other = __shfl_xor(mbits, 32, 64);          // this half holds elements 4 hf .. + 3 of each chunk
+      // byte of chunk (kb, rq): elements 0-3 from the hf = 0 lane, 4-7 from the hf = 1 lane
+      unsigned mbits = 0;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) mbits |= ((keepw[kb] >> (4 * rq)) & 0xFu) << (8 * rq);
+      const unsigned other = __shfl_xor(mbits, 32, 64);
       if (hf == 0) *(unsigned*)(p.mask_out + chunk0 + kb * 4) = mbits | (other << 4);
     }
     float v[16];
@@ -320,15 +334,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   const bool drop = p.drop.thr != 0;
   const unsigned chunk0 = ((unsigned)bh * AT_S + (unsigned)q) * 16u;
   unsigned keepw[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  if (drop) at_keep_row(p.drop, chunk0, hf, keepw);
   float delta = 0.f;
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
-    if (drop) {
-      unsigned mbits = 0;
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) mbits |= at_keep4(p.drop, chunk0 + kb * 4 + rq, hf) << (4 * rq);
-      keepw[kb] = mbits;
-    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float dp = ((keepw[kb] >> r) & 1u) ? g[kb][r] * p.drop.inv_keep : 0.f;
