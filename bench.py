@@ -289,7 +289,7 @@ REFERENCE_PUBLISHED = {
 #                            sparse gradient 13.3 KB + SGD row read-modify-write 26.6 KB, minus cache hits -> HBM)
 WORK_PER_SAMPLE = {"rn50": ("mfma", 24.54e9), "bert": ("mfma", 240.6e9), "dlrm": ("hbm", 53.0e3)}
 # entry points whose launches are matrix-core kernels (gemm2_kernel / gemm_kernel / conv3x3_kernel instantiations)
-MFMA_FAMILIES = ("dle_gemm", "dle_gemm_batched", "dle_attention_fwd", "dle_attention_bwd", "dle_conv2d_fwd", "dle_conv2d_fwd_colstats", "dle_conv2d_dgrad",
+MFMA_FAMILIES = ("dle_gemm", "dle_gemm_batched", "dle_attention_fwd", "dle_attention_bwd", "dle_conv2d_fwd", "dle_conv2d_fwd_colstats", "dle_conv2d_dgrad", "dle_conv2d_dgrad_s2",
                  "dle_conv2d_wgrad", "dle_attention_fwd", "dle_attention_bwd")
 
 

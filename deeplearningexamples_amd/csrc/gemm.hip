@@ -314,13 +314,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
   if (c0 < N) {
     long long r = r0 + rl;
     if (vec && DT != DLE_F32) {
-      // 8 independent 16-byte loads in flight per lane
-      for (; r + 7LL * rstep < r1; r += 8LL * rstep) {
-        ushort8_t v[8];
+      // 2 independent 16-byte loads in flight per lane: a read-only sweep peaks with FEW loads per lane once ~1000
+      // workgroups are resident (tools/probes/read_bw.hip: 6.4 TB/s with 1-2, 4.8-5.3 with 8)
+      constexpr int U = 2;
+      for (; r + (long long)(U - 1) * rstep < r1; r += (long long)U * rstep) {
+        ushort8_t v[U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *(const ushort8_t*)((const unsigned short*)x + (r + (long long)u * rstep) * ld + c0);
+        for (int u = 0; u < U; ++u) v[u] = *(const ushort8_t*)((const unsigned short*)x + (r + (long long)u * rstep) * ld + c0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < U; ++u) {
           float f[8];
           unpack8<DT == DLE_F32 ? DLE_BF16 : DT>(v[u], f);
 #pragma unroll
@@ -403,9 +405,10 @@ extern "C" int dle_colsum(const void* x, float* out, int64_t M, int N, int64_t l
   const int V = dtype == DLE_F32 ? 4 : 8;
   const int cols_v = (N + V - 1) / V;
   int lpr = 1;
-  while (lpr < cols_v && lpr < 256) lpr <<= 1;           // lanes per row (power of two, <= 256)
+  while (lpr < cols_v && lpr < 32) lpr <<= 1;            // lanes per row (power of two, <= 32: wide matrices split their
+                                                         // columns over blockIdx.x -- fewer row groups, smaller partials)
   const int gx = (cols_v + lpr - 1) / lpr;
-  long long want = 512 / gx;                               // ~2 workgroups per CU in total
+  long long want = 1024 / gx;                              // ~4 workgroups per CU in total (as the BatchNorm reductions)
   if (want < 1) want = 1;
   long long rpb = (M + want - 1) / want;
   const long long min_rows = 8LL * (256 / lpr);

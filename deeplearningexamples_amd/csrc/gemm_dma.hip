@@ -55,6 +55,8 @@ struct Gemm2Args {
   int debug_skip;        // reserved (profiling ablations)
   float* stats;          // per-tile-row column sums of the ROUNDED output: [tiles_m][2][N] (sum, sum of squares); NULL: off
   int force_small;       // keep the 128x128 tile (stats layout is indexed by 128-row tiles)
+  long long row_extra;   // output row m lives at m * ldc + (m / row_div.d) * row_extra (+ column): rows of a strided sub-grid
+  FastDiv row_div;
   int persist;           // 128x128 tile only: the grid is smaller than the tile list, a workgroup walks tiles bid, bid + grid, ...
   long long sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
 };
@@ -78,7 +80,7 @@ __device__ __forceinline__ float gelu_tanh2_d(float x, float& d) {
 // activation / mask / addend math and the 16-byte stores of C (+ the pre-activation side output).
 template <int DT>
 __device__ __forceinline__ void epi_store8(const Gemm2Args& p, float* v, int m, int n, int nval, bool vec16, int ky) {
-  const long long off = (long long)m * p.ldc + n;
+  const long long off = (long long)m * p.ldc + n + (p.row_extra ? (long long)fd_div(m, p.row_div) * p.row_extra : 0LL);
   if (p.splitk > 1) {
     if (p.ws) {
       float* c = p.ws + ((long long)ky * p.M + m) * p.N + n;
@@ -462,8 +464,10 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
     const float* e0 = epi + f_ml0 * TN;
     const int c4 = f_nl >> 2;
     const int olo = (c4 ^ f_ml0) << 2, ohi = ((c4 + 1) ^ f_ml0) << 2;
-    const long long off0 = (long long)(m0 + half * (TM / 2) + f_ml0) * p.ldc + n0 + f_nl;
+    const int mrow0 = m0 + half * (TM / 2) + f_ml0;
+    const long long off0 = (long long)mrow0 * p.ldc + n0 + f_nl;
     const long long step = (long long)RPI * p.ldc;
+    const bool remap = p.row_extra != 0;                     // strided sub-grid output (stride-2 data gradient classes)
     unsigned short* c = (unsigned short*)p.C + off0;
     unsigned short* ax = (p.aux && act != ACT_ADD_MASKED) ? (unsigned short*)p.aux + off0 : nullptr;
     const unsigned short* ms = needs_src ? p.mask_src + off0 : nullptr;
@@ -517,7 +521,8 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
         }
       }
       const ushort8_t ov = pack8<DT>(v);
-      *(ushort8_t*)(c + it * step) = ov;
+      if (remap) *(ushort8_t*)(c + it * step + (long long)fd_div(mrow0 + it * RPI, p.row_div) * p.row_extra) = ov;
+      else *(ushort8_t*)(c + it * step) = ov;
       if (!BIG && act == ACT_NONE && p.stats) {          // BatchNorm statistics of what the next pass will read
         float vr[8];
         unpack8<DT>(ov, vr);
@@ -904,6 +909,69 @@ extern "C" int dle_conv2d_wgrad(const void* dy, const void* x, float* dw, int N,
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { dle_set_error("splitk_reduce launch failed: %s", hipGetErrorString(e)); return (int)e; }
   }
+  return 0;
+}
+
+
+// ---- 3x3 / stride 2 / pad 1 data gradient without zero work -------------------------------------------------------
+// dx[n, h, w, :] receives dy[n, p, q, :] w[:, r, s, :] for the taps with 2p - 1 + r = h, 2q - 1 + s = w: an even h sees only
+// r = 1, an odd h sees r = 0 and r = 2 (likewise in w).  The gather form above walks all 9 taps for every pixel and
+// multiplies 3/4 zeros; here the four parity classes (h & 1, w & 1) are four stride-1 correlations of dy on the P x Q
+// grid with 1, 2, 2 and 4 taps, each written straight into its strided sub-grid of dx (row_extra / row_div in the
+// epilogue).  The tap-restricted weights of a class are a [C][taps * Ko] k-contiguous matrix packed into the workspace.
+template <int DT>
+__global__ __launch_bounds__(256) void dgrad_s2_pack_kernel(const unsigned short* __restrict__ w, unsigned short* __restrict__ out,
+                                                            int Ko, int C) {
+  // out: class (a, b) at element offset C * Ko * {0, 1, 3, 5}[2a + b]; layout [c][r'][s'][ko]; r' = 0 <-> dy row i, 1 <-> i + 1
+  const long long total = 9LL * Ko * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long t = i / C;
+    const int rs = (int)(t % 9), ko = (int)(t / 9);
+    const int r = rs / 3, sx = rs - r * 3;
+    const int a = r == 1 ? 0 : 1, b = sx == 1 ? 0 : 1;            // parity class of the dx pixels this tap feeds
+    const int rp = r == 0 ? 1 : 0, sp = sx == 0 ? 1 : 0;          // tap position inside the class kernel
+    const int Sp = b ? 2 : 1, taps = (a ? 2 : 1) * Sp;
+    const long long base = (long long)C * Ko * (a == 0 ? (b == 0 ? 0 : 1) : (b == 0 ? 3 : 5));
+    out[base + ((long long)c * taps + rp * Sp + sp) * Ko + ko] = w[i];
+  }
+}
+
+// dx [N,H,W,C] = conv_transpose(dy [N,H/2,W/2,Ko], w [Ko,3,3,C]) for stride 2, pad 1 (H, W even, Ko a multiple of 64).
+// workspace: >= 9 * Ko * C * 2 bytes (the packed class weights).
+extern "C" int dle_conv2d_dgrad_s2(const void* dy, const void* w, void* dx, int N, int H, int W, int C, int Ko,
+                                   void* workspace, int64_t workspace_bytes, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "conv2d_dgrad_s2: 16-bit dtypes only");
+  DLE_CHECK_ARG(dy && w && dx && workspace, "conv2d_dgrad_s2: null pointer");
+  DLE_CHECK_ARG(N > 0 && H > 0 && W > 0 && (H & 1) == 0 && (W & 1) == 0, "conv2d_dgrad_s2: H, W must be even");
+  DLE_CHECK_ARG(C % 8 == 0 && Ko % 64 == 0, "conv2d_dgrad_s2: C a multiple of 8, Ko a multiple of 64 (got %d, %d)", C, Ko);
+  DLE_CHECK_ARG(workspace_bytes >= 9LL * Ko * C * 2 && (((uintptr_t)workspace) & 15) == 0, "conv2d_dgrad_s2: workspace too small");
+  DLE_CHECK_ARG((long long)N * H * W * C * 2 < 0xFFFFFFE0LL, "conv2d_dgrad_s2: tensors above 4 GiB are not addressable");
+  const int P = H / 2, Q = W / 2;
+  {
+    long long g = (9LL * Ko * C + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (dtype == DLE_F16) hipLaunchKernelGGL(dgrad_s2_pack_kernel<DLE_F16>, dim3((unsigned)g), dim3(256), 0, stream, (const unsigned short*)w, (unsigned short*)workspace, Ko, C);
+    else hipLaunchKernelGGL(dgrad_s2_pack_kernel<DLE_BF16>, dim3((unsigned)g), dim3(256), 0, stream, (const unsigned short*)w, (unsigned short*)workspace, Ko, C);
+    DLE_LAUNCH_CHECK();
+  }
+  static const int cls_off[4] = {0, 1, 3, 5};
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      const int Rp = a ? 2 : 1, Sp = b ? 2 : 1;
+      Gemm2Args p = {};
+      p.A = (const unsigned short*)dy;
+      p.B = (const unsigned short*)workspace + (long long)C * Ko * cls_off[2 * a + b];
+      p.C = (unsigned short*)dx + ((long long)a * W + b) * C;          // pixel (a, b) of image 0
+      p.M = N * P * Q; p.N = C; p.K = Rp * Sp * Ko; p.lda = 0; p.ldb = (long long)Rp * Sp * Ko;
+      p.ldc = 2LL * C;                                                  // next j: two pixels further
+      p.row_extra = (long long)W * C;                                   // next i: one skipped image row more
+      p.row_div = make_fastdiv(Q);
+      p.out_dtype = dtype; p.act = ACT_NONE; p.splitk = 1; p.accumulate = 0; p.alpha = 1.f;
+      // the class correlation reads dy rows i + r', columns j + s' (no padding; past the edge reads zero)
+      p.cg = make_geom(P, Q, Ko, P, Q, Rp, Sp, 1, 0, C);
+      if (int rc = launch_gemm(p, dtype, 2, 0, 0, stream)) return rc;
+    }
   return 0;
 }
 

@@ -385,6 +385,13 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, addend=None, out=None):
         return out
     C.annotate(flops=2.0 * n * p * q * ko * r * s * c, tag="dgrad %dx%dx%dx%d k%d %dx%d s%d" % (n, h, wd, c, ko, r, s, stride),
                bytes=float(dy.numel() + w.numel() + out.numel()) * 2)
+    if (r == 3 and s == 3 and stride == 2 and pad == 1 and addend is None and h % 2 == 0 and wd % 2 == 0
+            and ko % 64 == 0 and c % 8 == 0):
+        # four parity-class correlations with 1 + 2 + 2 + 4 taps instead of 9 taps over 3/4 zeros
+        ws = splitk_workspace(dy.device, 9 * ko * c * 2)
+        C.call("dle_conv2d_dgrad_s2", C.ptr(dy), C.ptr(w), C.ptr(out), n, h, wd, c, ko, C.ptr(ws), ws.numel() * 4,
+               C.dt(dy), C.stream())
+        return out
     C.call("dle_conv2d_dgrad", C.ptr(dy), C.ptr(w), C.ptr(out), C.ptr(addend), n, h, wd, c, ko, r, s, stride, pad,
            C.dt(dy), C.stream())
     return out

@@ -298,6 +298,13 @@ int dle_softmax_dropout_fwd(void* scores, void* dropped, void* mask, const float
 int dle_softmax_dropout_bwd(const void* probs, void* dprobs, const void* mask, int64_t rows, int L, float scale,
                             float p, int dtype, hipStream_t stream);
 
+/* 3x3 / stride 2 / pad 1 data gradient as four parity-class correlations (1 + 2 + 2 + 4 taps: no zero work), each written
+ * into its strided sub-grid of dx -- cuDNN's bwd-data behind the strided 3x3 convolutions of the ResNet bottleneck
+ * (Classification/ConvNets/image_classification/models/resnet.py:126,148-175).  H, W even; Ko % 64 == 0; workspace:
+ * >= 9 * Ko * C * 2 bytes (tap-restricted weight matrices, rebuilt by every call). */
+int dle_conv2d_dgrad_s2(const void* dy, const void* w, void* dx, int N, int H, int W, int C, int Ko, void* workspace,
+                        int64_t workspace_bytes, int dtype, hipStream_t stream);
+
 /* ---- fused self-attention (S = 128, 64-wide heads): replaces BertSelfAttention.forward between the QKV and the output
  * projection, LanguageModeling/BERT/modeling.py:340-384 (torch.bmm + softmax + nn.Dropout + torch.bmm) and its autograd
  * backward.  qkv [T = B*S, 3H] (q | k | v, head h at columns h*64 of each third), ctx / dctx [T, H], dqkv [T, 3H];

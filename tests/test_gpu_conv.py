@@ -12,6 +12,7 @@ GEOMS = [
     (2, 14, 14, 128, 128, 3, 2, 1), (2, 14, 14, 256, 512, 1, 2, 0), (1, 15, 15, 64, 96, 3, 2, 1),
     (2, 32, 32, 8, 64, 7, 2, 3), (4, 7, 7, 512, 512, 3, 1, 1), (2, 7, 7, 2048, 512, 1, 1, 0),
     (5, 6, 10, 72, 40, 3, 1, 1), (1, 15, 15, 64, 96, 1, 2, 0), (3, 8, 12, 128, 64, 1, 2, 0),
+    (3, 12, 20, 72, 128, 3, 2, 1), (1, 28, 28, 256, 256, 3, 2, 1),      # stride-2 3x3: the parity-class data gradient
 ]
 
 
