@@ -167,7 +167,14 @@ class ResNetTrainer:
     # ------------------------------------------------------------------ the step
     def forward(self, images):
         """images fp32 NCHW (as produced by the reference's loaders) -> fp32 logits [N, classes]."""
-        x = F.nchw_to_nhwc(images, self.dtype, 8)
+        if images.dtype == torch.uint8:
+            # decoded images straight from the loader: normalisation fused with the layout change (dataloaders.py:354-384)
+            if getattr(self, "_mean_std", None) is None:
+                from .dataloaders import IMAGENET_MEAN, IMAGENET_STD
+                self._mean_std = (torch.tensor(IMAGENET_MEAN, device=self.dev) * 255.0, torch.tensor(IMAGENET_STD, device=self.dev) * 255.0)
+            x = F.u8_nchw_normalize_nhwc(images, self._mean_std[0], self._mean_std[1], self.dtype, 8)
+        else:
+            x = F.nchw_to_nhwc(images, self.dtype, 8)
         a0 = self.stem.forward(x)
         m0, self._amax = F.maxpool_fwd(a0)
         self._pool_in_hw = a0.shape[1:3]

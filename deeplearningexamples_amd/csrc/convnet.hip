@@ -61,6 +61,42 @@ extern "C" int dle_nchw_to_nhwc(const float* x, void* y, int64_t N, int C, int64
   return 0;
 }
 
+// uint8 NCHW (the decoded images a torch DataLoader collates) -> (x - mean[c]) / std[c] as 16-bit NHWC, padding channels
+// zero: PrefetchedWrapper's `input.float().sub_(mean).div_(std)` (image_classification/dataloaders.py:354-384) fused with
+// the layout change the step needs.
+template <int DT>
+__global__ __launch_bounds__(256) void u8_nchw_norm_nhwc_kernel(const unsigned char* __restrict__ x, unsigned short* __restrict__ y,
+                                                                long long N, int C, long long HW, int Cp,
+                                                                const float* __restrict__ mean, const float* __restrict__ std) {
+  const long long total = N * HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / HW, hw = i - n * HW;
+    for (int c8 = 0; c8 < Cp; c8 += 8) {
+      ushort8_t o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = c8 + k;
+        o[k] = c < C ? dn16<DT>(((float)x[(n * C + c) * HW + hw] - mean[c]) / std[c]) : (unsigned short)0;
+      }
+      *(ushort8_t*)(y + i * Cp + c8) = o;
+    }
+  }
+}
+
+extern "C" int dle_u8_nchw_normalize_nhwc(const void* x, void* y, const float* mean, const float* std, int64_t N, int C,
+                                          int64_t HW, int C_padded, int out_dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(out_dtype == DLE_F16 || out_dtype == DLE_BF16, "u8_nchw_normalize_nhwc: 16-bit output only");
+  DLE_CHECK_ARG(C > 0 && C_padded >= C && C_padded % 8 == 0, "u8_nchw_normalize_nhwc: padded channel count must be a multiple of 8");
+  if (N * HW == 0) return 0;
+  DLE_CHECK_ARG(x && y && mean && std, "u8_nchw_normalize_nhwc: null pointer");
+  const int grid = cn_grid(N * HW, 256);
+  if (out_dtype == DLE_F16) hipLaunchKernelGGL(u8_nchw_norm_nhwc_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned char*)x, (unsigned short*)y, (long long)N, C, (long long)HW, C_padded, mean, std);
+  else hipLaunchKernelGGL(u8_nchw_norm_nhwc_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned char*)x, (unsigned short*)y, (long long)N, C, (long long)HW, C_padded, mean, std);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------- column reductions over [M][C]
 // MODE 0: s0 = sum x, s1 = sum x^2                                  (BN forward statistics)
 // MODE 1: g = dy * (y > 0 if y) ; s0 = sum g, s1 = sum g * xhat     (BN backward reductions)

@@ -6,6 +6,7 @@ Mirrors Recommendation/DLRM/dlrm/scripts/main.py:43-143 (flags; argparse here, a
         --dataset_type synthetic_gpu --amp --batch_size 65536 --max_steps 200
 """
 import argparse
+import os
 import time
 
 import torch
@@ -14,6 +15,7 @@ from ..utils import dllogger
 from ..utils.graph import GraphedStep
 from ..utils.dist import init_from_env, is_main_process
 from . import placement as P
+from .data import FeatureSpec, ParametricDataset, prefetcher
 from .engine import DlrmTrainer
 from .model import DistributedDlrm
 from .utils import LearningRateScheduler, StepTimer
@@ -46,7 +48,10 @@ def parse_flags(argv=None):
     p.add_argument("--top_mlp_sizes", type=_int_list, default=[1024, 1024, 512, 256, 1])
     p.add_argument("--bottom_mlp_sizes", type=_int_list, default=[512, 256, 128])
     p.add_argument("--interaction_op", default="cuda_dot", choices=["cuda_dot", "dot"])
-    p.add_argument("--dataset_type", default="synthetic_gpu", choices=["synthetic_gpu"])
+    p.add_argument("--dataset_type", default="synthetic_gpu", choices=["synthetic_gpu", "parametric"],
+                   help="parametric: the split-binary files a feature_spec.yaml describes (dlrm/data/datasets.py:64-223)")
+    p.add_argument("--dataset", default=None, help="directory holding feature_spec.yaml and the train/ test/ files")
+    p.add_argument("--feature_spec", default="feature_spec.yaml")
     p.add_argument("--synthetic_dataset_num_entries", type=int, default=int(2 ** 15 * 1024))
     p.add_argument("--synthetic_dataset_table_sizes", type=_int_list, default=CRITEO_F15)
     p.add_argument("--synthetic_dataset_numerical_features", type=int, default=13)
@@ -70,6 +75,8 @@ def main(argv=None):
     device = torch.device("cuda", local)
     torch.manual_seed(flags.seed)
     sizes = list(flags.synthetic_dataset_table_sizes)
+    if flags.dataset_type == "parametric":
+        sizes = FeatureSpec.from_yaml(os.path.join(flags.dataset, flags.feature_spec)).get_categorical_sizes()
     if flags.max_table_size:
         sizes = [min(s, flags.max_table_size) for s in sizes]
     mapping = P.get_device_mapping(sizes, num_gpus=world)
@@ -92,19 +99,32 @@ def main(argv=None):
                           freeze_embeddings=flags.freeze_embeddings)
     sched = LearningRateScheduler(flags.warmup_steps, flags.warmup_factor, flags.decay_steps, flags.decay_start_step,
                                   flags.decay_power, flags.decay_end_lr / flags.lr)
-    g = torch.Generator(device="cpu").manual_seed(flags.seed)                 # same global batch on every rank
-    num = torch.rand((flags.batch_size, flags.synthetic_dataset_numerical_features), generator=g)
-    cat = torch.cat([torch.randint(0, s, (flags.batch_size, 1), generator=g) for s in sizes], dim=1)
-    click = torch.randint(0, 2, (flags.batch_size,), generator=g).float().to(device)
-    num = num.to(device) if rank == mapping["bottom_mlp"] else None
-    cat = cat[:, mine].contiguous().to(device) if mine else None
-    steps_per_epoch = max(flags.synthetic_dataset_num_entries // flags.batch_size - 1, 1)
+    loader = None
+    if flags.dataset_type == "parametric":
+        # every rank reads the numerical features only if it owns the bottom MLP and the categorical files of ITS tables
+        spec = FeatureSpec.from_yaml(os.path.join(flags.dataset, flags.feature_spec))
+        names = spec.get_categorical_feature_names()
+        loader = ParametricDataset(spec, "train", batch_size=flags.batch_size, numerical_features_enabled=rank == mapping["bottom_mlp"],
+                                   categorical_features_to_read=[names[t] for t in mine], drop_last_batch=True)
+        num = cat = click = None
+    else:
+        g = torch.Generator(device="cpu").manual_seed(flags.seed)                 # same global batch on every rank
+        num = torch.rand((flags.batch_size, flags.synthetic_dataset_numerical_features), generator=g)
+        cat = torch.cat([torch.randint(0, s, (flags.batch_size, 1), generator=g) for s in sizes], dim=1)
+        click = torch.randint(0, 2, (flags.batch_size,), generator=g).float().to(device)
+        num = num.to(device) if rank == mapping["bottom_mlp"] else None
+        cat = cat[:, mine].contiguous().to(device) if mine else None
+    steps_per_epoch = len(loader) if loader is not None else max(flags.synthetic_dataset_num_entries // flags.batch_size - 1, 1)
     # CudaGraphWrapper (main.py:610-611): eager warm-up steps, one capture, then copy-in + replay per step
     step_fn = GraphedStep(trainer.train_step, enabled=flags.cuda_graphs and world == 1)
     timer, times, moving_loss = StepTimer(), [], torch.zeros(1, device=device)
     step = 0
     for epoch in range(flags.epochs):
+        batches = prefetcher(iter(loader), device) if loader is not None else None
         for i in range(steps_per_epoch):
+            if batches is not None:
+                num, cat, click = next(batches)
+                num = num.float() if num is not None else None
             timer.click(synchronize=True)
             if flags.max_steps and step > flags.max_steps:
                 break

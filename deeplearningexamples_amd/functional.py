@@ -432,6 +432,18 @@ def nchw_to_nhwc(x, out_dtype, c_padded=None):
     return y
 
 
+def u8_nchw_normalize_nhwc(x, mean, std, out_dtype, c_padded=None):
+    """uint8 [N,C,H,W] -> ((x - mean[c]) / std[c]) as 16-bit [N,H,W,Cp] (PrefetchedWrapper's normalisation + layout)."""
+    C.require_cuda(x, mean, std)
+    if x.dtype != torch.uint8 or x.dim() != 4 or not x.is_contiguous():
+        raise ValueError("u8_nchw_normalize_nhwc expects a contiguous uint8 NCHW tensor")
+    n, c, h, w = x.shape
+    cp = c_padded or (c + 7) // 8 * 8
+    y = torch.empty((n, h, w, cp), dtype=out_dtype, device=x.device)
+    C.call("dle_u8_nchw_normalize_nhwc", C.ptr(x), C.ptr(y), C.ptr(mean), C.ptr(std), n, c, h * w, cp, C.dt(y), C.stream())
+    return y
+
+
 def _bn_ws(x2d):
     m, c = x2d.shape
     nbytes = C.lib().dle_bn_workspace_bytes(m, c)

@@ -298,6 +298,12 @@ int dle_softmax_dropout_fwd(void* scores, void* dropped, void* mask, const float
 int dle_softmax_dropout_bwd(const void* probs, void* dprobs, const void* mask, int64_t rows, int L, float scale,
                             float p, int dtype, hipStream_t stream);
 
+/* uint8 NCHW images -> (x - mean[c]) / std[c] as 16-bit NHWC (channels zero-padded to C_padded): the normalisation of
+ * PrefetchedWrapper.prefetched_loader (Classification/ConvNets/image_classification/dataloaders.py:354-384) fused with the
+ * layout change of the step's first kernel. */
+int dle_u8_nchw_normalize_nhwc(const void* x, void* y, const float* mean, const float* std, int64_t N, int C, int64_t HW,
+                               int C_padded, int out_dtype, hipStream_t stream);
+
 /* 3x3 / stride 2 / pad 1 data gradient as four parity-class correlations (1 + 2 + 2 + 4 taps: no zero work), each written
  * into its strided sub-grid of dx -- cuDNN's bwd-data behind the strided 3x3 convolutions of the ResNet bottleneck
  * (Classification/ConvNets/image_classification/models/resnet.py:126,148-175).  H, W even; Ko % 64 == 0; workspace:
