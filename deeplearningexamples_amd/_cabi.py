@@ -84,6 +84,7 @@ _SIGS = {
     "dle_rows_scatter": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
     "dle_softmax_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_float, c_int, c_void_p]),
     "dle_softmax_bwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_float, c_int, c_void_p]),
+    "dle_dropout_add_layernorm_bwd": (c_int, [c_void_p] * 6 + [c_float] + [c_void_p] * 5 + [c_i64, c_int, c_int, c_void_p, c_i64, c_int, c_void_p]),
     "dle_dropout_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_float, c_u64, c_u64, c_void_p, c_int, c_void_p]),
     "dle_dropout_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_float, c_int, c_void_p]),
     "dle_dropout_add_layernorm_fwd": (c_int, [c_void_p] * 9 + [c_i64, c_int, c_float, c_float, c_u64, c_u64, c_void_p, c_int, c_void_p]),
@@ -93,7 +94,7 @@ _SIGS = {
     "dle_conv2d_dgrad_s2": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_i64, c_int, c_void_p]),
     "dle_attention_supported": (c_int, [c_int, c_int]),
     "dle_attention_fwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_float, c_float, c_u64, c_u64, c_void_p, c_int, c_void_p]),
-    "dle_attention_bwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_float, c_float, c_u64, c_u64, c_void_p, c_int, c_void_p]),
+    "dle_attention_bwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_float, c_float, c_u64, c_u64, c_void_p, c_int, c_void_p]),
     "dle_colsum": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p, c_i64, c_void_p]),
     "dle_mt_table_len": (c_i64, [c_int, c_int]),
     "dle_mt_table_fill": (c_i64, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]),

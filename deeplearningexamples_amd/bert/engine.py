@@ -355,29 +355,44 @@ class BertTrainer:
         for l in range(cfg["layers"] - 1, -1, -1):
             layer, a = m.bert.encoder.layer[l], sv["layers"][l]
             pre = "bert.encoder.layer.%d." % l
-            dz2 = F.layernorm_bwd(dx, a["z2"], a["ln2"][0], a["ln2"][1], layer.output.LayerNorm.weight.data,
-                                  self.gview[pre + "output.LayerNorm.weight"], self.gview[pre + "output.LayerNorm.bias"], acc)
-            # dz2 flows unchanged into the residual branch; the dense branch sees it through the dropout mask
-            do2 = F.dropout_bwd(dz2, a["mask_2"], self.p_hidden) if a["mask_2"] is not None else dz2
+            # dz2 flows unchanged into the residual branch; the dense branch sees it through the dropout mask.  With
+            # dropout the LayerNorm backward writes both and the dense bias gradient (no dropout / column-sum passes)
+            if a["mask_2"] is not None:
+                dz2, do2 = F.dropout_add_layernorm_bwd(dx, a["z2"], a["ln2"][0], a["ln2"][1], layer.output.LayerNorm.weight.data,
+                                                       a["mask_2"], self.p_hidden, self.gview[pre + "output.LayerNorm.weight"],
+                                                       self.gview[pre + "output.LayerNorm.bias"],
+                                                       dbias=self.gview[pre + "output.dense.bias"], accumulate=acc)
+            else:
+                dz2 = F.layernorm_bwd(dx, a["z2"], a["ln2"][0], a["ln2"][1], layer.output.LayerNorm.weight.data,
+                                      self.gview[pre + "output.LayerNorm.weight"], self.gview[pre + "output.LayerNorm.bias"], acc)
+                do2 = dz2
+                self._bgrad(pre + "output.dense.bias", do2, acc)
             self._wgrad(pre + "output.dense.weight", do2, a["it"], acc)
-            self._bgrad(pre + "output.dense.bias", do2, acc)
             dpre = F.gemm(do2, self.w16[pre + "output.dense.weight"], t, inter, h, True, False, act=C.ACT_MUL,
                           mask_src=a["pre"])
             self._wgrad(pre + "intermediate.dense_act.weight", dpre, a["x1"], acc)
             self._bgrad(pre + "intermediate.dense_act.bias", dpre, acc)
             dx1 = F.gemm(dpre, self.w16[pre + "intermediate.dense_act.weight"], t, h, inter, True, False, act=C.ACT_ADD,
                          mask_src=dz2)
-            dz1 = F.layernorm_bwd(dx1, a["z1"], a["ln1"][0], a["ln1"][1], layer.attention.output.LayerNorm.weight.data,
-                                  self.gview[pre + "attention.output.LayerNorm.weight"],
-                                  self.gview[pre + "attention.output.LayerNorm.bias"], acc)
-            dao = F.dropout_bwd(dz1, a["mask_1"], self.p_hidden) if a["mask_1"] is not None else dz1
+            if a["mask_1"] is not None:
+                dz1, dao = F.dropout_add_layernorm_bwd(dx1, a["z1"], a["ln1"][0], a["ln1"][1],
+                                                       layer.attention.output.LayerNorm.weight.data, a["mask_1"], self.p_hidden,
+                                                       self.gview[pre + "attention.output.LayerNorm.weight"],
+                                                       self.gview[pre + "attention.output.LayerNorm.bias"],
+                                                       dbias=self.gview[pre + "attention.output.dense.bias"], accumulate=acc)
+            else:
+                dz1 = F.layernorm_bwd(dx1, a["z1"], a["ln1"][0], a["ln1"][1], layer.attention.output.LayerNorm.weight.data,
+                                      self.gview[pre + "attention.output.LayerNorm.weight"],
+                                      self.gview[pre + "attention.output.LayerNorm.bias"], acc)
+                dao = dz1
+                self._bgrad(pre + "attention.output.dense.bias", dao, acc)
             self._wgrad(pre + "attention.output.dense.weight", dao, a["ctx"], acc)
-            self._bgrad(pre + "attention.output.dense.bias", dao, acc)
             dctx = F.gemm(dao, self.w16[pre + "attention.output.dense.weight"], t, h, h, True, False)
             qkv, probs = a["qkv"], a["probs"]
             if sv["fused_attn"]:
+                cs = torch.empty((b, 3 * h), dtype=torch.float32, device=self.dev)
                 dqkv = F.attention_bwd(qkv, dctx, self._mask_add, a["stats"], b, s, nh, scale, self.p_attn,
-                                       self.rng_seed, a["off_a"], offset_base=self._rng_base)
+                                       self.rng_seed, a["off_a"], offset_base=self._rng_base, colsum_partial=cs)
             else:
                 dprobs = torch.empty_like(probs)
                 F.gemm_batched(dctx, qkv[:, 2 * h:], dprobs, s, s, d, h, 3 * h, s, True, True, b * nh, nh,
@@ -397,7 +412,8 @@ class BertTrainer:
             gqkv = torch.as_strided(gq, (3 * h, h), (h, 1))
             F.gemm(dqkv, a["x"], 3 * h, h, t, False, False, out=gqkv, splitk=F.pick_splitk(3 * h, h, t, 1024), accumulate=acc)
             gbq = self.gview[pre + "attention.self.query.bias"]
-            F.colsum(dqkv, out=torch.as_strided(gbq, (3 * h,), (1,)), accumulate=acc)
+            # fused path: the attention backward left per-sequence column sums [B, 3H]; fold those B rows instead of T
+            F.colsum(cs if sv["fused_attn"] else dqkv, out=torch.as_strided(gbq, (3 * h,), (1,)), accumulate=acc)
             dx = F.gemm(dqkv, layer.qkv16, t, h, 3 * h, True, False, act=C.ACT_ADD, mask_src=dz1)
             self._grads_final((pre,))
         # ---- embeddings

@@ -38,6 +38,7 @@ struct AttnArgs {
   unsigned short* dqkv;         // [T, 3H]  (backward out)
   float* stats;                 // [B * heads, S, 2]: row max of the scaled+masked scores, 1 / sum of exp
   unsigned char* mask_out;      // optional bit-packed keep mask [B * heads * S * S / 8] (tests), forward only
+  float* colsum;                // optional (backward): [B, 3H] column sums of this sequence's rows of dqkv (QKV bias gradient partials)
   int B, nh, H;
   float scale;
   DropArgs drop;                // thr == 0: no dropout
@@ -421,6 +422,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   at_store_rows(stg, out, 3LL * p.H, lane);
   at_store_rows(stg + 32 * AT_D, out + p.H, 3LL * p.H, lane);
   at_store_rows(stg + 64 * AT_D, out + 2 * p.H, 3LL * p.H, lane);
+  if (p.colsum) {
+    // bias gradient of the QKV projection = column sums of dqkv: the 128 rows of this (sequence, head) are summed here from
+    // the ROUNDED staged values (what a column-sum pass over dqkv would read); the host folds the B per-sequence rows
+    float cs[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      const unsigned short* t = stg + o * 32 * AT_D;
+      float a = 0.f;
+#pragma unroll 8
+      for (int row = 0; row < 32; ++row)
+        a += Elem<DT>::to_f32(t[row * AT_D + ((((lane >> 3) ^ (row & 7)) << 3) | (lane & 7))]);
+      cs[o] = a;
+    }
+    __syncthreads();                                           // every wave is done reading its staging tiles
+    float* red = (float*)smem_raw;                             // [4 waves][3][64]
+#pragma unroll
+    for (int o = 0; o < 3; ++o) red[(wave * 3 + o) * AT_D + lane] = cs[o];
+    __syncthreads();
+    if (tid < 3 * AT_D) {
+      const int o = tid / AT_D, c = tid - o * AT_D;
+      const float v = (red[(0 * 3 + o) * AT_D + c] + red[(1 * 3 + o) * AT_D + c]) + (red[(2 * 3 + o) * AT_D + c] + red[(3 * 3 + o) * AT_D + c]);
+      p.colsum[(long long)b * 3 * p.H + o * p.H + h * AT_D + c] = v;
+    }
+  }
 }
 
 static int attn_check(const char* what, int B, int S, int heads, int head_dim, int dtype, float p) {
@@ -456,16 +481,17 @@ extern "C" int dle_attention_fwd(const void* qkv, const float* mask_add, void* c
 }
 
 // dqkv[T, 3H] (dq | dk | dv) from dctx[T, H]; recomputes the probabilities from qkv + stats and the dropout mask from
-// (seed, offset) -- the same values dle_attention_fwd was called with.
+// (seed, offset) -- the same values dle_attention_fwd was called with.  colsum_partial (optional, fp32 [B, 3H]): per-sequence
+// column sums of dqkv; their sum over B is the bias gradient of the QKV projection (no column-sum pass over dqkv).
 extern "C" int dle_attention_bwd(const void* qkv, const void* dctx, const float* mask_add, const float* stats, void* dqkv,
-                                 int B, int S, int heads, int head_dim, float scale, float p, uint64_t seed,
-                                 uint64_t offset, const uint64_t* offset_base, int dtype, hipStream_t stream) {
+                                 float* colsum_partial, int B, int S, int heads, int head_dim, float scale, float p,
+                                 uint64_t seed, uint64_t offset, const uint64_t* offset_base, int dtype, hipStream_t stream) {
   if (int rc = attn_check("attention_bwd", B, S, heads, head_dim, dtype, p)) return rc;
   DLE_CHECK_ARG(qkv && dctx && stats && dqkv, "attention_bwd: null pointer");
   DLE_CHECK_ARG(((((uintptr_t)qkv) | ((uintptr_t)dctx) | ((uintptr_t)dqkv)) & 15) == 0, "attention_bwd: tensors must be 16-byte aligned");
   AttnArgs a = {};
   a.qkv = (const unsigned short*)qkv; a.dctx = (const unsigned short*)dctx; a.mask_add = mask_add;
-  a.stats = (float*)stats; a.dqkv = (unsigned short*)dqkv; a.B = B; a.nh = heads; a.H = heads * head_dim; a.scale = scale;
+  a.stats = (float*)stats; a.dqkv = (unsigned short*)dqkv; a.colsum = colsum_partial; a.B = B; a.nh = heads; a.H = heads * head_dim; a.scale = scale;
   a.drop = make_drop(nullptr, p, seed, offset, offset_base);
   const size_t lds = 4 * AT_TILE * 2;
   static bool attr_set = false;

@@ -294,16 +294,42 @@ __global__ __launch_bounds__(256) void emb_sgd_small(float* __restrict__ weight,
   const long long b0 = sl * per;
   long long b1 = b0 + per;
   if (b1 > batch) b1 = batch;
-  const int hw = threadIdx.x >> 5, l = threadIdx.x & 31;   // 8 half-waves, one sample each per trip
-  for (long long b = b0 + hw; b < b1; b += 8) {
-    const long long r = rows[b * T + t] - base;
-    const long long goff = b * g_bstride4 + (long long)t * D4;
+  const int hw = threadIdx.x >> 5, l = threadIdx.x & 31;   // 8 half-waves, UB samples each per trip
+  // the row ids and the gradient rows of UB samples are requested BEFORE the first LDS add: with one sample in flight per
+  // half-wave (24 per CU) the pass was bound by the two dependent global loads of every trip (0.38 TB/s)
+  constexpr int UB = 4;
+  long long b = b0 + (long long)hw * UB;
+  if (D4 <= 32) {
+    for (; b + UB <= b1; b += 8 * UB) {
+      long long r[UB];
+      typename In4<IDT>::V gv[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        r[u] = rows[(b + u) * T + t] - base;
+        if (l < D4) gv[u] = grad[(b + u) * g_bstride4 + (long long)t * D4 + l];
+      }
+      if (l < D4) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const float4_t g = In4<IDT>::up(gv[u]);
+          float* a = acc + r[u] * D + l * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) atomicAdd(a + j, g[j]);   // ds_add_f32
+        }
+      }
+    }
+  }
+  // tail of the slice (and rows wider than 32 float4 chunks): one sample per half-wave trip
+  for (long long bb = (D4 <= 32 ? b : b0 + (long long)hw * UB), e = bb + UB; bb < b1; ) {
+    const long long r = rows[bb * T + t] - base;
+    const long long goff = bb * g_bstride4 + (long long)t * D4;
     for (int c = l; c < D4; c += 32) {
       const float4_t g = In4<IDT>::up(grad[goff + c]);
       float* a = acc + r * D + c * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) atomicAdd(a + j, g[j]);   // ds_add_f32
     }
+    if (++bb == e) { bb += 7 * UB; e = bb + UB; }            // this half-wave's next group of UB samples
   }
   __syncthreads();
   const float lr = lr_dev ? *lr_dev : lr_host;

@@ -142,29 +142,39 @@ extern "C" int dle_dropout_add_layernorm_fwd(const void* x, const void* residual
 // xhat = (z - mean) * rstd;  dz = rstd * (dy*gamma - mean_H(dy*gamma) - xhat * mean_H(dy*gamma*xhat));
 // partial[block][0][c] = sum_rows dy (dbeta), partial[block][1][c] = sum_rows dy * xhat (dgamma).
 // ZT = dtype of z (16-bit) or fp32 reconstruction is done by the embedding variant below.
-template <int DT, int CH>
+// DROP: the LayerNorm input was dense(x) -> dropout -> + residual (modeling.py:394-398, 430-434): the kernel also writes
+// dzd = dz * keep / (1 - p), the gradient of the dense output (the separate dropout-backward pass is gone), and a third
+// column sum, sum_rows dzd = the dense layer's bias gradient (the separate column-sum pass is gone).
+template <int DT, int CH, bool DROP>
 __global__ __launch_bounds__(512) void ln_bwd_kernel(const unsigned short* __restrict__ dy,
                                                      const unsigned short* __restrict__ z,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, unsigned short* __restrict__ dz,
-                                                     float* __restrict__ partial, long long rows, int H) {
+                                                     float* __restrict__ partial, long long rows, int H,
+                                                     const unsigned char* __restrict__ keep, float inv_keep,
+                                                     unsigned short* __restrict__ dzd) {
+  constexpr int NS = DROP ? 3 : 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* red = (float*)smem_raw;                       // [waves][2][H]
+  float* red = (float*)smem_raw;                       // [waves][H]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nwv = blockDim.x >> 6;
   const long long wave = (long long)blockIdx.x * nwv + w, nwaves = (long long)gridDim.x * nwv;
   const int nch = H >> 3;
-  float ag[CH][8], ab[CH][8];
+  float ag[CH][8], ab[CH][8], ad[DROP ? CH : 1][8];
 #pragma unroll
   for (int i = 0; i < CH; ++i)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { ag[i][k] = 0.f; ab[i][k] = 0.f; }
+    for (int k = 0; k < 8; ++k) { ag[i][k] = 0.f; ab[i][k] = 0.f; if (DROP) ad[i][k] = 0.f; }
   for (long long r = wave; r < rows; r += nwaves) {
     const float mu = mean[r], rs = rstd[r];
     float g[CH][8], xh[CH][8];
+    unsigned kb[CH];                  // keep bits, requested WITH the row's other loads: fetched after the row reductions
+                                      // they exposed a second memory latency per row (the fused pass ran at 3.2 TB/s)
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = lane + i * 64;
+      kb[i] = 0;
+      if (DROP && c < nch) kb[i] = keep[r * nch + c];
       if (c < nch) {
         float df[8], zf[8];
         unpack8<DT>(*(const ushort8_t*)(dy + r * H + c * 8), df);
@@ -193,27 +203,62 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const unsigned short* __res
         float of[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) of[k] = rs * (g[i][k] - s1 - xh[i][k] * s2);
-        *(ushort8_t*)(dz + r * H + c * 8) = pack8<DT>(of);
+        const ushort8_t ov = pack8<DT>(of);
+        *(ushort8_t*)(dz + r * H + c * 8) = ov;
+        if (DROP) {
+          // what dle_dropout_bwd computed from the ROUNDED dz: dz16 * keep / (1 - p), rounded; its column sum = bias gradient
+          const unsigned bits = kb[i];
+          float rf[8], df[8];
+          unpack8<DT>(ov, rf);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) df[k] = ((bits >> k) & 1u) ? rf[k] * inv_keep : 0.f;
+          const ushort8_t dv = pack8<DT>(df);
+          *(ushort8_t*)(dzd + r * H + c * 8) = dv;
+          unpack8<DT>(dv, df);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) ad[i][k] += df[k];
+        }
       }
     }
   }
-  // column partials: waves of the block meet in LDS
+  // column partials: waves of the block meet in LDS, one statistic at a time ([waves][H] fp32: 32 KiB at H = 1024 -- a
+  // buffer for all statistics at once halved the resident workgroups and the kernel fell from 5.1 to 3.2 TB/s)
 #pragma unroll
-  for (int i = 0; i < CH; ++i) {
-    const int c = lane + i * 64;
-    if (c < nch)
+  for (int which = 0; which < NS; ++which) {
+    if (which) __syncthreads();
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        red[(w * 2 + 0) * H + c * 8 + k] = ab[i][k];
-        red[(w * 2 + 1) * H + c * 8 + k] = ag[i][k];
-      }
+    for (int i = 0; i < CH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch)
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          red[w * H + c * 8 + k] = which == 0 ? ab[i][k] : which == 1 ? ag[i][k] : ad[DROP ? i : 0][k];
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < H; col += blockDim.x) {
+      float t = 0.f;
+      for (int q = 0; q < nwv; ++q) t += red[q * H + col];
+      partial[((long long)blockIdx.x * NS + which) * H + col] = t;
+    }
   }
+}
+
+// third column of the DROP variant: out[c] (+)= sum over blocks of partial[block][2][c]
+__global__ __launch_bounds__(256) void colthird_finish_kernel(const float* __restrict__ partial, int groups, int C,
+                                                              float* __restrict__ out, int accumulate) {
+  __shared__ double red[256];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double s0 = 0.0;
+  if (c < C)
+    for (int g = sl; g < groups; g += 16) s0 += partial[((long long)g * 3 + 2) * C + c];
+  red[threadIdx.x] = s0;
   __syncthreads();
-  for (int c = threadIdx.x; c < 2 * H; c += blockDim.x) {
-    const int which = c / H, col = c - which * H;
-    float t = 0.f;
-    for (int q = 0; q < nwv; ++q) t += red[(q * 2 + which) * H + col];
-    partial[((long long)blockIdx.x * 2 + which) * H + col] = t;
+  if (sl == 0 && c < C) {
+    double t0 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t0 += red[q * 16 + cl];
+    out[c] = accumulate ? out[c] + (float)t0 : (float)t0;
   }
 }
 
@@ -221,7 +266,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const unsigned short* __res
 // workgroup: the pass is latency-bound, so it is spread over C/16 workgroups with 4 loads in flight per lane.
 __global__ __launch_bounds__(256) void colpair_finish_kernel(const float* __restrict__ partial, int groups, int C,
                                                              float* __restrict__ out1, float* __restrict__ out0,
-                                                             int accumulate) {
+                                                             int accumulate, int NS = 2) {
   __shared__ double red[2][256];
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
@@ -232,13 +277,13 @@ __global__ __launch_bounds__(256) void colpair_finish_kernel(const float* __rest
       float a[4], b[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        a[u] = partial[((long long)(g + 16 * u) * 2) * C + c];
-        b[u] = partial[((long long)(g + 16 * u) * 2 + 1) * C + c];
+        a[u] = partial[((long long)(g + 16 * u) * NS) * C + c];
+        b[u] = partial[((long long)(g + 16 * u) * NS + 1) * C + c];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) { s0 += a[u]; s1 += b[u]; }
     }
-    for (; g < groups; g += 16) { s0 += partial[((long long)g * 2) * C + c]; s1 += partial[((long long)g * 2 + 1) * C + c]; }
+    for (; g < groups; g += 16) { s0 += partial[((long long)g * NS) * C + c]; s1 += partial[((long long)g * NS + 1) * C + c]; }
   }
   red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
   __syncthreads();
@@ -252,7 +297,39 @@ __global__ __launch_bounds__(256) void colpair_finish_kernel(const float* __rest
 }
 
 #define LN_BWD_BLOCKS 512
-extern "C" int64_t dle_layernorm_workspace_bytes(int H) { return (int64_t)LN_BWD_BLOCKS * 2 * H * 4; }
+extern "C" int64_t dle_layernorm_workspace_bytes(int H) { return (int64_t)LN_BWD_BLOCKS * 3 * H * 4; }
+
+static int ln_bwd_launch(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma, void* dz,
+                         float* dgamma, float* dbeta, int64_t rows, int H, int accumulate, void* workspace,
+                         int64_t workspace_bytes, const void* keep, float p, void* dzd, float* dbias, int dtype,
+                         hipStream_t stream) {
+  const bool drop = keep != nullptr;
+  const int ns = drop ? 3 : 2;
+  const int nwv = H <= 1024 ? 8 : H <= 2048 ? 4 : 2;          // waves per workgroup: [waves][H] fp32 <= 32 KiB of LDS
+  // (4-wave workgroups for more resident waves measured SLOWER: 4.2 -> 4.8 ms / step)
+  int blocks = (int)((rows + nwv - 1) / nwv);
+  if (blocks > LN_BWD_BLOCKS) blocks = LN_BWD_BLOCKS;
+  DLE_CHECK_ARG(workspace_bytes >= (long long)blocks * ns * H * 4, "layernorm_bwd: workspace too small");
+  const size_t lds = (size_t)nwv * H * 4;
+  const int ch = (H / 8 + 63) / 64;
+  const DropArgs d = make_drop(nullptr, p, 0, 0);
+#define GO(DT, CH, DR) hipLaunchKernelGGL((ln_bwd_kernel<DT, CH, DR>), dim3(blocks), dim3(64 * nwv), lds, stream, (const unsigned short*)dy, (const unsigned short*)z, mean, rstd, gamma, (unsigned short*)dz, (float*)workspace, (long long)rows, H, (const unsigned char*)keep, d.inv_keep, (unsigned short*)dzd)
+#define PICK(DT, DR) do { if (ch <= 1) GO(DT, 1, DR); else if (ch <= 2) GO(DT, 2, DR); else if (ch <= 4) GO(DT, 4, DR); else GO(DT, 8, DR); } while (0)
+  if (drop) { if (dtype == DLE_F16) PICK(DLE_F16, true); else PICK(DLE_BF16, true); }
+  else { if (dtype == DLE_F16) PICK(DLE_F16, false); else PICK(DLE_BF16, false); }
+#undef GO
+#undef PICK
+  DLE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colpair_finish_kernel, dim3((H + 15) / 16), dim3(256), 0, stream, (const float*)workspace, blocks, H,
+                     dgamma, dbeta, accumulate, ns);
+  DLE_LAUNCH_CHECK();
+  if (drop && dbias) {
+    hipLaunchKernelGGL(colthird_finish_kernel, dim3((H + 15) / 16), dim3(256), 0, stream, (const float*)workspace, blocks, H,
+                       dbias, accumulate);
+    DLE_LAUNCH_CHECK();
+  }
+  return 0;
+}
 
 extern "C" int dle_layernorm_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                                  void* dz, float* dgamma, float* dbeta, int64_t rows, int H, int accumulate,
@@ -260,22 +337,25 @@ extern "C" int dle_layernorm_bwd(const void* dy, const void* z, const float* mea
   DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "layernorm_bwd: 16-bit activations only");
   DLE_CHECK_ARG(H > 0 && H % 8 == 0 && H <= 64 * LN_MAX_CHUNKS * 8, "layernorm_bwd: H must be a multiple of 8, <= 4096");
   DLE_CHECK_ARG(rows > 0 && dy && z && mean && rstd && gamma && dz && dgamma && dbeta && workspace, "layernorm_bwd: null pointer / empty");
-  const int nwv = H <= 1024 ? 8 : H <= 2048 ? 4 : 2;          // waves per workgroup: [waves][2][H] fp32 fits 64 KiB of LDS
-  int blocks = (int)((rows + nwv - 1) / nwv);
-  if (blocks > LN_BWD_BLOCKS) blocks = LN_BWD_BLOCKS;
-  DLE_CHECK_ARG(workspace_bytes >= (long long)blocks * 2 * H * 4, "layernorm_bwd: workspace too small");
-  const size_t lds = (size_t)nwv * 2 * H * 4;
-  const int ch = (H / 8 + 63) / 64;
-#define GO(DT, CH) hipLaunchKernelGGL((ln_bwd_kernel<DT, CH>), dim3(blocks), dim3(64 * nwv), lds, stream, (const unsigned short*)dy, (const unsigned short*)z, mean, rstd, gamma, (unsigned short*)dz, (float*)workspace, (long long)rows, H)
-#define PICK(DT) do { if (ch <= 1) GO(DT, 1); else if (ch <= 2) GO(DT, 2); else if (ch <= 4) GO(DT, 4); else GO(DT, 8); } while (0)
-  if (dtype == DLE_F16) PICK(DLE_F16); else PICK(DLE_BF16);
-#undef GO
-#undef PICK
-  DLE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colpair_finish_kernel, dim3((H + 15) / 16), dim3(256), 0, stream, (const float*)workspace, blocks, H,
-                     dgamma, dbeta, accumulate);
-  DLE_LAUNCH_CHECK();
-  return 0;
+  return ln_bwd_launch(dy, z, mean, rstd, gamma, dz, dgamma, dbeta, rows, H, accumulate, workspace, workspace_bytes, nullptr,
+                       0.f, nullptr, nullptr, dtype, stream);
+}
+
+// Backward of y = LayerNorm(dropout(x) + residual) (dle_dropout_add_layernorm_fwd): dz (the gradient of the residual
+// branch), dx = dz * keep / (1 - p) (the gradient of the dense layer's output) and, when dbias != NULL, dbias (+)= column
+// sums of dx -- the dropout-backward pass and the bias-gradient pass of the dense layer folded into this one.
+extern "C" int dle_dropout_add_layernorm_bwd(const void* dy, const void* z, const float* mean, const float* rstd,
+                                             const float* gamma, const void* keep_mask, float p, void* dz, void* dx,
+                                             float* dgamma, float* dbeta, float* dbias, int64_t rows, int H,
+                                             int accumulate, void* workspace, int64_t workspace_bytes, int dtype,
+                                             hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "dropout_add_layernorm_bwd: 16-bit activations only");
+  DLE_CHECK_ARG(H > 0 && H % 8 == 0 && H <= 64 * LN_MAX_CHUNKS * 8, "dropout_add_layernorm_bwd: H must be a multiple of 8, <= 4096");
+  DLE_CHECK_ARG(rows > 0 && dy && z && mean && rstd && gamma && keep_mask && dz && dx && dgamma && dbeta && workspace,
+                "dropout_add_layernorm_bwd: null pointer / empty");
+  DLE_CHECK_ARG(p >= 0.f && p < 1.f, "dropout_add_layernorm_bwd: p must be in [0, 1)");
+  return ln_bwd_launch(dy, z, mean, rstd, gamma, dz, dgamma, dbeta, rows, H, accumulate, workspace, workspace_bytes, keep_mask,
+                       p, dx, dbias, dtype, stream);
 }
 
 // ------------------------------------------------------------------ embeddings: gather-sum (fp32) -> 16-bit z

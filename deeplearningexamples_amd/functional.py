@@ -632,6 +632,20 @@ def layernorm_bwd(dy, z, mean, rstd, gamma, dgamma, dbeta, accumulate=False):
     return dz
 
 
+def dropout_add_layernorm_bwd(dy, z, mean, rstd, gamma, mask, p, dgamma, dbeta, dbias=None, accumulate=False):
+    """Backward of dropout_add_layernorm_fwd in one pass -> (dz, dx): dz feeds the residual branch, dx = dz * keep / (1 - p)
+    the dense layer; dbias (+)= column sums of dx."""
+    C.require_cuda(dy, z, mean, rstd, gamma, mask, dgamma, dbeta, dbias)
+    rows, h = z.shape
+    dz, dx = torch.empty_like(z), torch.empty_like(z)
+    ws = splitk_workspace(z.device, C.lib().dle_layernorm_workspace_bytes(h))
+    C.annotate(bytes=float(z.numel()) * 2 * 4 + z.numel() / 8, tag="R%dxH%d+drop" % (rows, h))
+    C.call("dle_dropout_add_layernorm_bwd", C.ptr(dy), C.ptr(z), C.ptr(mean), C.ptr(rstd), C.ptr(gamma), C.ptr(mask), float(p),
+           C.ptr(dz), C.ptr(dx), C.ptr(dgamma), C.ptr(dbeta), C.ptr(dbias), rows, h, int(accumulate), C.ptr(ws),
+           ws.numel() * 4, C.dt(z), C.stream())
+    return dz, dx
+
+
 def embed_sum(word, pos, typ, ids, token_type, seq_len, out_dtype):
     C.require_cuda(word, pos, typ, ids, token_type)
     t = ids.numel()
@@ -787,8 +801,10 @@ def attention_fwd(qkv, mask_add, batch, seq_len, heads, scale, p=0.0, seed=0, of
     return ctx, stats, mask
 
 
-def attention_bwd(qkv, dctx, mask_add, stats, batch, seq_len, heads, scale, p=0.0, seed=0, offset=0, offset_base=None):
-    """dqkv [T, 3H] from dctx [T, H]: probabilities and dropout mask are recomputed from (qkv, stats, seed, offset)."""
+def attention_bwd(qkv, dctx, mask_add, stats, batch, seq_len, heads, scale, p=0.0, seed=0, offset=0, offset_base=None,
+                  colsum_partial=None):
+    """dqkv [T, 3H] from dctx [T, H]: probabilities and dropout mask are recomputed from (qkv, stats, seed, offset).
+    colsum_partial (optional fp32 [batch, 3H]) receives the per-sequence column sums of dqkv (QKV bias gradient partials)."""
     C.require_cuda(qkv, dctx, mask_add, stats)
     t, h3 = qkv.shape
     h = h3 // 3
@@ -799,7 +815,9 @@ def attention_bwd(qkv, dctx, mask_add, stats, batch, seq_len, heads, scale, p=0.
     bh = batch * heads
     C.annotate(flops=10.0 * bh * seq_len * seq_len * d, bytes=float(t) * h * 2 * 7 + stats.numel() * 4,
                tag="B%dxh%dxS%dxd%d" % (batch, heads, seq_len, d))
-    C.call("dle_attention_bwd", C.ptr(qkv), C.ptr(dctx), C.ptr(mask_add), C.ptr(stats), C.ptr(dqkv), batch, seq_len,
+    C.require_cuda(colsum_partial)
+    C.call("dle_attention_bwd", C.ptr(qkv), C.ptr(dctx), C.ptr(mask_add), C.ptr(stats), C.ptr(dqkv), C.ptr(colsum_partial),
+           batch, seq_len,
            heads, d, float(scale), float(p), int(seed), int(offset), C.ptr(offset_base), C.dt(qkv), C.stream())
     return dqkv
 

@@ -279,6 +279,13 @@ int dle_softmax_bwd(const void* probs, void* dprobs, int64_t rows, int L, float 
  * the drop probability is quantised to round(p * 65536) / 65536 and kept values are scaled by its complement.
  * The reference draws from torch's CUDA Philox stream, so masks are NOT bit-identical to the reference's; parity of
  * the step is checked against the oracle under the masks these entry points produce.                            */
+/* backward of dle_dropout_add_layernorm_fwd in ONE pass: dz (residual branch), dx = dz * keep / (1 - p) (dense branch),
+ * dgamma / dbeta, and dbias (+)= column sums of dx when non-NULL -- the dropout-backward pass and the dense layer's bias
+ * gradient pass (autograd of modeling.py:394-398,430-434) folded into the LayerNorm backward. */
+int dle_dropout_add_layernorm_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                                  const void* keep_mask, float p, void* dz, void* dx, float* dgamma, float* dbeta,
+                                  float* dbias, int64_t rows, int H, int accumulate, void* workspace,
+                                  int64_t workspace_bytes, int dtype, hipStream_t stream);
 int dle_dropout_fwd(const void* x, void* y, void* mask, int64_t n, float p, uint64_t seed, uint64_t offset,
                     const uint64_t* offset_base,
                     int dtype, hipStream_t stream);
@@ -317,16 +324,16 @@ int dle_conv2d_dgrad_s2(const void* dy, const void* w, void* dx, int N, int H, i
  * mask_add fp32 [B, S] (0 / -10000) or NULL; stats fp32 [B*heads, S, 2] = (row max, 1 / row sum) saved for backward;
  * keep_mask (optional, B*heads*S*S/8 bytes) = the dropout keep bits in the layout of dle_softmax_dropout_fwd.  The
  * backward regenerates probabilities and mask from (qkv, stats, seed, offset): nothing of shape [B, heads, S, S] is
- * stored.  dle_attention_supported: 1 when (S, head_dim) is inside the kernels' envelope. */
+ * stored.  colsum_partial (optional, fp32 [B, 3H]): per-sequence column sums of dqkv -- their sum over B is the bias gradient of
+ * the QKV projection.  dle_attention_supported: 1 when (S, head_dim) is inside the kernels' envelope. */
 int dle_attention_supported(int S, int head_dim);
 int dle_attention_fwd(const void* qkv, const float* mask_add, void* ctx, float* stats, void* keep_mask, int B, int S,
                       int heads, int head_dim, float scale, float p, uint64_t seed, uint64_t offset,
                       const uint64_t* offset_base, int dtype,
                       hipStream_t stream);
-int dle_attention_bwd(const void* qkv, const void* dctx, const float* mask_add, const float* stats, void* dqkv, int B,
-                      int S, int heads, int head_dim, float scale, float p, uint64_t seed, uint64_t offset,
-                      const uint64_t* offset_base, int dtype,
-                      hipStream_t stream);
+int dle_attention_bwd(const void* qkv, const void* dctx, const float* mask_add, const float* stats, void* dqkv,
+                      float* colsum_partial, int B, int S, int heads, int head_dim, float scale, float p, uint64_t seed,
+                      uint64_t offset, const uint64_t* offset_base, int dtype, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,12 @@ def test_attention_fwd_bwd_vs_fp64(cuda, dtype, bar_f, bar_b, p):
     assert float((st[..., 0] - mx).abs().max()) < 1e-4 * (1 + float(mx.abs().max()))
     inv = 1.0 / torch.exp(sc - mx[..., None]).sum(-1)
     assert float(((st[..., 1] - inv) / inv).abs().max()) < 1e-4
+    # per-sequence column sums of dqkv (the QKV bias gradient partials), from the rounded values the kernel stored
+    cs = torch.empty((b, 3 * h), dtype=torch.float32, device=cuda)
+    dqkv_c = F.attention_bwd(qkv, dctx, mask_add, stats, b, s, nh, scale, p, seed, off, colsum_partial=cs)
+    assert torch.equal(dqkv_c, dqkv)
+    ref_cs = dqkv.float().view(b, s, 3 * h).sum(1)
+    assert float((cs - ref_cs).abs().max()) <= 1e-4 * (1.0 + float(ref_cs.abs().max()))
     # determinism: the same call gives the same bits
     ctx2, stats2, _ = F.attention_fwd(qkv, mask_add, b, s, nh, scale, p, seed, off)
     dqkv2 = F.attention_bwd(qkv, dctx, mask_add, stats2, b, s, nh, scale, p, seed, off)

@@ -220,3 +220,29 @@ def test_bert_phase2_seq512_vs_oracle(cuda):
         if rel > 0.03:
             bad.append((n, round(rel, 4)))
     assert not bad, bad[:12]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_dropout_add_layernorm_bwd_equals_the_three_passes(cuda, dtype):
+    """dle_dropout_add_layernorm_bwd = LayerNorm backward + dropout backward + bias column sums in one pass: the same bits
+    for dz / dx / dgamma / dbeta as the separate kernels, the same bias gradient up to fp32 summation order."""
+    from deeplearningexamples_amd import functional as F
+    g = torch.Generator().manual_seed(2)
+    rows, h, p = 1000, 1024, 0.1
+    x = torch.randn(rows, h, generator=g).to(dtype).to(cuda)
+    res = torch.randn(rows, h, generator=g).to(dtype).to(cuda)
+    dy = torch.randn(rows, h, generator=g).to(dtype).to(cuda)
+    gamma = (1 + 0.1 * torch.randn(h, generator=g)).to(cuda)
+    beta = torch.zeros(h, device=cuda)
+    y, z, mean, rstd, mask = F.dropout_add_layernorm_fwd(x, gamma, beta, res, p, 5, 6)
+    dg1, db1 = torch.zeros(h, device=cuda), torch.zeros(h, device=cuda)
+    dz1 = F.layernorm_bwd(dy, z, mean, rstd, gamma, dg1, db1)
+    dx1 = F.dropout_bwd(dz1, mask, p)
+    bias1 = F.colsum(dx1)
+    dg2, db2, bias2 = torch.zeros(h, device=cuda), torch.zeros(h, device=cuda), torch.full((h,), 3.0, device=cuda)
+    dz2, dx2 = F.dropout_add_layernorm_bwd(dy, z, mean, rstd, gamma, mask, p, dg2, db2, dbias=bias2, accumulate=False)
+    assert torch.equal(dz1, dz2) and torch.equal(dx1, dx2)
+    assert torch.allclose(dg1, dg2, rtol=1e-5, atol=1e-4) and torch.allclose(db1, db2, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(bias1, bias2, rtol=1e-5, atol=1e-3)
+    F.dropout_add_layernorm_bwd(dy, z, mean, rstd, gamma, mask, p, dg2, db2, dbias=bias2, accumulate=True)
+    assert torch.allclose(bias2, 2 * bias1, rtol=1e-5, atol=2e-3)

@@ -1,7 +1,7 @@
 """Replay one recorded C-ABI launch of a bench workload many times (target of rocprofv3 --pmc passes).
 
     python tools/replay_kernel.py --workload rn50 [--key "dle_gemm[802816x256x64]"] [--iters 50]
-Without --key the dominant entry point of the step (bench.py's roofline kernel) is replayed.  Prints the key."""
+Without --key the heaviest launch of the dominant kernel family (bench.py's roofline.heaviest_shape) is replayed.  Prints the key."""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,8 +25,9 @@ torch.cuda.synchronize()
 _cabi.set_timer(None)
 key = a.key
 if key is None:
-    roof, _ = bench.roofline_from(timer, 1)
-    key = roof["kernel"]
+    spp = {"rn50": 256, "bert": 256, "dlrm": 65536}[a.workload]
+    roof, _ = bench.roofline_from(timer, 1, a.workload, spp, 1.0)
+    key = roof["heaviest_shape"]
 name, tag = (key[:key.index("[")], key[key.index("[") + 1:-1]) if "[" in key else (key, None)
 fn, cargs = timer.last[(name, tag)]
 for _ in range(a.iters):
