@@ -57,6 +57,7 @@ struct Gemm2Args {
   int force_small;       // keep the 128x128 tile (stats layout is indexed by 128-row tiles)
   long long row_extra;   // output row m lives at m * ldc + (m / row_div.d) * row_extra (+ column): rows of a strided sub-grid
   FastDiv row_div;
+  int gm;                // tile rows per walk group (tile_coords); DLE_GEMM_GM, default 8
   int persist;           // 128x128 tile only: the grid is smaller than the tile list, a workgroup walks tiles bid, bid + grid, ...
   long long sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
 };
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
   // rows walked column by column, so the ~32-64 tiles an XCD runs at once form a GM x (32..64/GM) block: per K step
   // they pull GM A tiles + a few B tiles through L2 instead of 1 + 32 (a 1 x 32 strip re-reads the whole B matrix
   // once per tile row: 4 GB of L2 fills for an 8192^3 GEMM).
-  constexpr int GM = 8;
+  const int GM = p.gm;
   auto tile_coords = [&](int bid, int& tm_, int& tn_) __attribute__((always_inline)) {
     const int q = ntiles >> 3, r8 = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
     bid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
@@ -638,6 +639,8 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
 //  than the tile turnover it saves; it was removed.)
 static int launch_gemm(const Gemm2Args& p_in, int in_dtype, int amode, int bmode, int batch, hipStream_t stream) {
   Gemm2Args p = p_in;
+  static const int gm_env = getenv("DLE_GEMM_GM") ? atoi(getenv("DLE_GEMM_GM")) : 8;
+  p.gm = gm_env > 0 ? gm_env : 8;
   p.debug_skip = 0;
   p.batch_count = batch;
   const int ktiles = (p.K + BK - 1) / BK;

@@ -15,8 +15,14 @@ Pinning status (see DESIGN.md "Oracle"):
                         (BertForPreTraining, tiny config + loss fixtures).
   * resnet_oracle    -- pinned against the reference's image_classification.models.resnet50
                         eager module (loss / grad-norm fixtures).
-  * lamb_oracle      -- PARITY UNPINNED: the reference has no CPU implementation and no
-                        numeric test of multi_tensor_lamb.cu; the oracle follows the .cu
-                        line by line (citations in the file) and is cross-checked against
-                        an independent closed-form LAMB step only.
+  * lamb_oracle      -- pinned (round 2): the reference's UNMODIFIED FusedLAMBAMP + PolyWarmUpScheduler + torch
+                        GradScaler step on CPU with `fused_lamb_CUDA` bound to this module's numpy kernels
+                        (oracle/lamb_cpu_ext.py) wrote tests/golden/lamb_ref_steps.npz; the oracle's host-sequence
+                        restatement reproduces it bit for bit.  The per-element arithmetic of the .cu kernels has no
+                        CPU counterpart in the reference; it follows multi_tensor_lamb.cu line by line and is
+                        cross-checked against an independent float64 closed form.
+  * philox_oracle    -- pinned by the Random123 known-answer vectors.
+  * storage          -- not an oracle of the reference: 16-bit storage emulation (round-to-dtype with a
+                        straight-through gradient) used by the step oracles to MEASURE the precision floor that the
+                        loss-parity bars add to north_star's 1e-3.
 """

@@ -22,6 +22,8 @@ import numpy as np
 import torch
 import torch.nn.functional as TF
 
+from oracle.storage import q as q_store
+
 from . import lamb_oracle as L
 
 
@@ -92,8 +94,15 @@ def poly_warmup_lr(step_after, base_lr, warmup, total_steps, degree=0.5):
 
 
 class BertOracle:
-    def __init__(self, cfg, state, lr=6e-3, warmup=0.2843, total_steps=7038, weight_decay=0.01, max_grad_norm=1.0):
+    """storage_dtype=None: the reference's fp32 CPU path.  storage_dtype=torch.float16 / bfloat16: the same fp32 math with
+    the tensors the AMP path keeps in 16 bits (GEMM weights, every activation between two kernels, their gradients)
+    rounded where they are produced (oracle/storage.py) -- the measured precision floor of the loss-parity bars.  LayerNorm
+    parameters, biases, softmax internals, the MLM / NSP logits, the losses and the optimizer stay fp32, as in the engine."""
+
+    def __init__(self, cfg, state, lr=6e-3, warmup=0.2843, total_steps=7038, weight_decay=0.01, max_grad_norm=1.0,
+                 storage_dtype=None):
         self.cfg = cfg
+        self.sd = storage_dtype
         self.p = {k: v.clone().float().requires_grad_(True) for k, v in state.items()}
         self.m = {k: np.zeros(tuple(v.shape), np.float32) for k, v in state.items()}
         self.v = {k: np.zeros(tuple(v.shape), np.float32) for k, v in state.items()}
@@ -104,6 +113,7 @@ class BertOracle:
         """masks (optional): {"emb": bool [b,s,h], "attn<l>": bool [b,nh,s,s], "out1_<l>" / "out2_<l>": bool [b,s,h]}
         keep masks of the nn.Dropout sites; kept values are scaled by 1/(1-p) with p quantised like the C ABI."""
         p, c = self.p, self.cfg
+        Q = lambda t: q_store(t, self.sd)
         q16 = lambda pr: round(pr * 65536.0) / 65536.0
         drop = lambda t, key, pr: t if masks is None or pr <= 0 else t * masks[key].to(t.dtype) / (1.0 - q16(pr))
         b, s = ids.shape
@@ -111,32 +121,33 @@ class BertOracle:
         d = h // nh
         e = (p["bert.embeddings.word_embeddings.weight"][ids] + p["bert.embeddings.position_embeddings.weight"][:s][None]
              + p["bert.embeddings.token_type_embeddings.weight"][tt])
-        x = TF.layer_norm(e, (h,), p["bert.embeddings.LayerNorm.weight"], p["bert.embeddings.LayerNorm.bias"], 1e-12)
-        x = drop(x, "emb", p_hidden)
+        x = Q(TF.layer_norm(e, (h,), p["bert.embeddings.LayerNorm.weight"], p["bert.embeddings.LayerNorm.bias"], 1e-12))
+        x = Q(drop(x, "emb", p_hidden))
         ext = (1.0 - mask.float())[:, None, None, :] * -10000.0
         for l in range(c["layers"]):
             pre = "bert.encoder.layer.%d." % l
-            lin = lambda t, n: TF.linear(t, p[pre + n + ".weight"], p[pre + n + ".bias"])
+            lin = lambda t, n: Q(TF.linear(t, Q(p[pre + n + ".weight"]), p[pre + n + ".bias"]))
             q = lin(x, "attention.self.query").view(b, s, nh, d).transpose(1, 2)
             k = lin(x, "attention.self.key").view(b, s, nh, d).transpose(1, 2)
             v = lin(x, "attention.self.value").view(b, s, nh, d).transpose(1, 2)
             sc = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d) + ext
             probs = drop(torch.softmax(sc, -1), "attn%d" % l, p_attn)
-            ctx = torch.matmul(probs, v).transpose(1, 2).reshape(b, s, h)
-            a = TF.layer_norm(drop(lin(ctx, "attention.output.dense"), "out1_%d" % l, p_hidden) + x, (h,),
-                              p[pre + "attention.output.LayerNorm.weight"], p[pre + "attention.output.LayerNorm.bias"], 1e-12)
-            it = gelu(lin(a, "intermediate.dense_act"))
-            x = TF.layer_norm(drop(lin(it, "output.dense"), "out2_%d" % l, p_hidden) + a, (h,),
-                              p[pre + "output.LayerNorm.weight"], p[pre + "output.LayerNorm.bias"], 1e-12)
-        pooled = torch.tanh(TF.linear(x[:, 0], p["bert.pooler.dense_act.weight"], p["bert.pooler.dense_act.bias"]))
+            ctx = Q(torch.matmul(probs, v).transpose(1, 2).reshape(b, s, h))
+            a = Q(TF.layer_norm(drop(lin(ctx, "attention.output.dense"), "out1_%d" % l, p_hidden) + x, (h,),
+                                p[pre + "attention.output.LayerNorm.weight"], p[pre + "attention.output.LayerNorm.bias"], 1e-12))
+            # (the engine's FFN-1 GEMM applies bias + GELU to the fp32 accumulator and stores the result once)
+            it = Q(gelu(TF.linear(a, Q(p[pre + "intermediate.dense_act.weight"]), p[pre + "intermediate.dense_act.bias"])))
+            x = Q(TF.layer_norm(drop(lin(it, "output.dense"), "out2_%d" % l, p_hidden) + a, (h,),
+                                p[pre + "output.LayerNorm.weight"], p[pre + "output.LayerNorm.bias"], 1e-12))
+        pooled = Q(torch.tanh(TF.linear(x[:, 0], Q(p["bert.pooler.dense_act.weight"]), p["bert.pooler.dense_act.bias"])))
         flat = x.reshape(-1, h)
         sel = torch.nonzero(labels.reshape(-1) != -1).squeeze(1)
-        t = gelu(TF.linear(flat[sel], p["cls.predictions.transform.dense_act.weight"],
-                           p["cls.predictions.transform.dense_act.bias"]))
-        t = TF.layer_norm(t, (h,), p["cls.predictions.transform.LayerNorm.weight"],
-                          p["cls.predictions.transform.LayerNorm.bias"], 1e-12)
-        scores = TF.linear(t, p["bert.embeddings.word_embeddings.weight"]) + p["cls.predictions.bias"]
-        nsp = TF.linear(pooled, p["cls.seq_relationship.weight"], p["cls.seq_relationship.bias"])
+        t = Q(gelu(TF.linear(flat[sel], Q(p["cls.predictions.transform.dense_act.weight"]),
+                             p["cls.predictions.transform.dense_act.bias"])))
+        t = Q(TF.layer_norm(t, (h,), p["cls.predictions.transform.LayerNorm.weight"],
+                            p["cls.predictions.transform.LayerNorm.bias"], 1e-12))
+        scores = TF.linear(t, Q(p["bert.embeddings.word_embeddings.weight"])) + p["cls.predictions.bias"]     # fp32 logits
+        nsp = TF.linear(pooled, Q(p["cls.seq_relationship.weight"]), p["cls.seq_relationship.bias"])
         return scores, nsp, sel
 
     def loss(self, ids, tt, mask, labels, nsp_labels, masks=None, p_hidden=0.0, p_attn=0.0):

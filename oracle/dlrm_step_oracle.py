@@ -14,6 +14,8 @@ import numpy as np
 import torch
 import torch.nn.functional as TF
 
+from oracle.storage import q as q_store
+
 
 def tril_index_pairs(n_vec):
     """interactions.py:50-53."""
@@ -26,7 +28,10 @@ class DlrmOracle:
     """state: dict name -> fp32 torch tensor with the reference's state_dict layout restricted to
     bottom_mlp.{i}.{weight,bias}, top_mlp.{i}.{weight,bias}, out.{weight,bias}, embedding (joint [sum N, D])."""
 
-    def __init__(self, state, table_sizes, lr):
+    def __init__(self, state, table_sizes, lr, storage_dtype=None):
+        # storage_dtype: round what the AMP path keeps in 16 bits (MLP weights, the cast numerical input, gathered rows,
+        # every MLP / interaction output incl. the logits, and their gradients) -- oracle/storage.py; tables stay fp32
+        self.sd = storage_dtype
         self.p = {k: v.clone().float().requires_grad_(True) for k, v in state.items()}
         self.sizes = list(table_sizes)
         self.offsets = torch.tensor([0] + self.sizes, dtype=torch.long).cumsum(0)
@@ -36,22 +41,23 @@ class DlrmOracle:
 
     def forward(self, num, cat):
         p = self.p
-        h = num
+        Q = lambda t: q_store(t, self.sd)
+        h = Q(num)
         for i in range(self.n_bot):
-            h = torch.relu(TF.linear(h, p[f"bottom_mlp.{i}.weight"], p[f"bottom_mlp.{i}.bias"]))
+            h = Q(torch.relu(TF.linear(h, Q(p[f"bottom_mlp.{i}.weight"]), p[f"bottom_mlp.{i}.bias"])))
         rows = cat + self.offsets[:-1]
-        emb = p["embedding"][rows]                                   # [B, T, D]
+        emb = Q(p["embedding"][rows])                                # [B, T, D]
         x = torch.cat([h.unsqueeze(1), emb], dim=1)                  # bottom MLP first (parts.py:97-99)
         z = torch.bmm(x, x.transpose(1, 2))
         ri, ci = tril_index_pairs(x.shape[1])
         flat = z[:, ri, ci]
         raw = flat.shape[1] + h.shape[1]
         pad = ((raw - 1) // 8 + 1) * 8 - raw
-        inter = torch.cat([h, flat, torch.zeros(h.shape[0], pad)], dim=1)
+        inter = Q(torch.cat([h, flat, torch.zeros(h.shape[0], pad)], dim=1))
         t = inter
         for i in range(self.n_top):
-            t = torch.relu(TF.linear(t, p[f"top_mlp.{i}.weight"], p[f"top_mlp.{i}.bias"]))
-        return TF.linear(t, p["out.weight"], p["out.bias"]).squeeze(-1)
+            t = Q(torch.relu(TF.linear(t, Q(p[f"top_mlp.{i}.weight"]), p[f"top_mlp.{i}.bias"])))
+        return Q(TF.linear(t, Q(p["out.weight"]), p["out.bias"])).squeeze(-1)
 
     def step(self, num, cat, click, lr=None):
         lr = self.lr if lr is None else lr

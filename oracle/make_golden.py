@@ -315,8 +315,45 @@ def gen_bert(cfg_name="BERT_STEP_CONFIG", out_name="bert_step.npz", last_layer=1
     print(out_name, "losses", losses)
 
 
+def gen_floors():
+    """Append the measured 16-bit STORAGE floors to the BERT / DLRM step fixtures: the step oracle re-run with every tensor
+    the AMP path keeps in fp16 / bf16 rounded where it is produced (oracle/storage.py).  The fp32 oracle must first reproduce
+    the fixture's reference losses (it is what was pinned against the reference module when the fixture was written)."""
+    from oracle import bert_oracle as BO
+    from oracle import dlrm_step_oracle as SO
+    for cfg_name, out_name in (("BERT_STEP_CONFIG", "bert_step.npz"), ("BERT_STEP_CONFIG_LARGE", "bert_step_large1l.npz")):
+        c = getattr(BO, cfg_name)
+        path = os.path.join(GOLD, out_name)
+        arrs = dict(np.load(path))
+        state0 = BO.seeded_state(c["cfg"], c["seed"])
+        batch = BO.seeded_batch(c["cfg"], c["seed"] + 1, c["batch"])
+        for nm, dt in (("fp32", None), ("fp16", torch.float16), ("bf16", torch.bfloat16)):
+            orc = BO.BertOracle(c["cfg"], state0, c["lr"], c["warmup"], c["total_steps"], storage_dtype=dt)
+            ls = np.asarray([orc.step(*batch) for _ in range(c["steps"])], np.float64)
+            if dt is None:
+                assert np.allclose(ls, arrs["losses"], rtol=1e-5), (out_name, ls, arrs["losses"])
+            else:
+                arrs["losses_%s_storage" % nm] = ls
+        np.savez_compressed(path, **arrs)
+        print(out_name, "reference", arrs["losses"], "fp16 storage", arrs["losses_fp16_storage"], "bf16 storage", arrs["losses_bf16_storage"])
+    for name, c in SO.DLRM_STEP_CONFIGS.items():
+        path = os.path.join(GOLD, "dlrm_step_%s.npz" % name)
+        arrs = dict(np.load(path))
+        state0 = SO.seeded_dlrm_state(c["sizes"], c["dim"], c["bottom"], c["top"], c["num"], c["seed"])
+        num, cat, click = SO.seeded_dlrm_batch(c["sizes"], c["num"], c["batch"], c["seed"] + 1000)
+        for nm, dt in (("fp32", None), ("fp16", torch.float16), ("bf16", torch.bfloat16)):
+            orc = SO.DlrmOracle(state0, c["sizes"], c["lr"], storage_dtype=dt)
+            ls = np.asarray([orc.step(num, cat, click) for _ in range(c["steps"])], np.float64)
+            if dt is None:
+                assert np.allclose(ls, arrs["losses"], rtol=5e-5, atol=1e-6), (name, ls, arrs["losses"])
+            else:
+                arrs["losses_%s_storage" % nm] = ls
+        np.savez_compressed(path, **arrs)
+        print("dlrm_step", name, "reference", arrs["losses"], "fp16 storage", arrs["losses_fp16_storage"], "bf16 storage", arrs["losses_bf16_storage"])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dlrm", "dlrm_step", "rn50", "lamb", "bert"]
+    which = sys.argv[1:] or ["dlrm", "dlrm_step", "rn50", "lamb", "bert", "floors"]
     os.makedirs(GOLD, exist_ok=True)
     if not R.have_reference():
         sys.exit("reference not mounted; fixtures are generated in the build container only")

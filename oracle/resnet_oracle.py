@@ -16,6 +16,8 @@ import numpy as np
 import torch
 import torch.nn.functional as TF
 
+from oracle.storage import q as q_store
+
 LAYERS, WIDTHS, EXPANSION = [3, 4, 6, 3], [64, 128, 256, 512], 4
 
 
@@ -71,20 +73,6 @@ def seeded_batch(seed, batch, size, num_classes=1000):
     return torch.from_numpy(x), torch.from_numpy(y)
 
 
-class _RoundSTE(torch.autograd.Function):
-    """Round to a 16-bit storage type in the forward AND round the gradient in the backward (what a tensor that
-    is stored in that type between two kernels goes through); identity derivative."""
-
-    @staticmethod
-    def forward(ctx, x, dtype):
-        ctx.dtype = dtype
-        return x.to(dtype).float()
-
-    @staticmethod
-    def backward(ctx, g):
-        return g.to(ctx.dtype).float(), None
-
-
 class ResNet50Oracle:
     """storage_dtype=None: the reference's fp32 CPU path.  storage_dtype=torch.float16/bfloat16: the same math
     with activations, conv/fc weights and activation gradients ROUNDED to that type wherever the AMP path keeps a
@@ -100,7 +88,7 @@ class ResNet50Oracle:
         self.lr, self.mom, self.wd, self.smoothing, self.eps, self.bnm = lr, momentum, weight_decay, smoothing, eps, bn_momentum
 
     def _q(self, t):
-        return t if self.sd is None else _RoundSTE.apply(t, self.sd)
+        return q_store(t, self.sd)
 
     def _bn(self, x, name):
         rm = self.run.setdefault(name + ".running_mean", torch.zeros(x.shape[1]))

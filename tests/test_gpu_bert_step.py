@@ -1,6 +1,8 @@
 """BERT pre-training step on the HIP kernels vs the reference's own BertForPreTraining run on CPU
 (tests/golden/bert_step.npz, oracle/make_golden.py gen_bert; dropout 0) and vs the CPU oracle live.  GPU only.
-Tolerance: per-step loss within 1e-3 relative for fp16, 3e-3 for bf16 (3 fewer mantissa bits)."""
+Tolerance: per-step loss within 1e-3 relative (BASELINE.json north_star) + the 16-bit STORAGE floor of the network, which
+the oracle measures itself (oracle/storage.py: the fp32 restatement with every tensor the AMP path keeps in fp16 / bf16
+rounded where it is produced; committed next to the reference losses in the fixtures by oracle/make_golden.py floors)."""
 import os
 
 import numpy as np
@@ -30,16 +32,19 @@ CONFIGS = {"tiny": ("BERT_STEP_CONFIG", "bert_step.npz"),
 
 
 @pytest.mark.parametrize("which", ["tiny", "large1l"])
-@pytest.mark.parametrize("dtype,bar", [(torch.float16, 1e-3), (torch.bfloat16, 3e-3)])
-def test_bert_losses_match_reference(cuda, golden_dir, dtype, bar, which):
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_bert_losses_match_reference(cuda, golden_dir, dtype, which):
     c = getattr(BO, CONFIGS[which][0])
     gold = np.load(os.path.join(golden_dir, CONFIGS[which][1]))
     state = BO.seeded_state(c["cfg"], c["seed"])
     model, tr = _build(cuda, dtype, c, state)
     batch = [t.to(cuda) for t in BO.seeded_batch(c["cfg"], c["seed"] + 1, c["batch"])]
     losses = [float(tr.train_step(*batch).item()) for _ in range(c["steps"])]
-    print(dtype, "losses", losses, "reference", gold["losses"].tolist())
-    np.testing.assert_allclose(losses, gold["losses"], rtol=bar)
+    ref = gold["losses"]
+    rel = np.abs(np.asarray(losses) - ref) / ref
+    floor = np.abs(gold["losses_%s_storage" % ("fp16" if dtype == torch.float16 else "bf16")] - ref) / ref
+    print(dtype, "losses", losses, "reference", ref.tolist(), "rel err", rel.tolist(), "storage floor", floor.tolist())
+    assert np.all(rel <= 1e-3 + floor), (rel, floor)
     assert losses[-1] < losses[0] - (0.2 if which == "tiny" else 0.0)
     named = dict(model.named_parameters())
     ref = gold["final_pooler_bias"]
@@ -59,8 +64,10 @@ def test_bert_first_step_gradients_vs_oracle(cuda, dtype, bar, which):
     orc = BO.BertOracle(c["cfg"], state)
     lo = orc.loss(*cpu_batch)
     lo.backward()
+    floor = abs(float(BO.BertOracle(c["cfg"], state, storage_dtype=dtype).loss(*cpu_batch)) - float(lo))
     loss, dlog, dnsp = tr.forward(*[t.to(cuda) for t in cpu_batch])
-    assert abs(loss.item() - float(lo)) <= (1e-3 if dtype == torch.float16 else 3e-3) * float(lo)
+    print(dtype, which, "loss", loss.item(), "oracle", float(lo), "storage floor", floor)
+    assert abs(loss.item() - float(lo)) <= 1e-3 * float(lo) + floor
     tr.backward(dlog, dnsp)
     torch.cuda.synchronize()
     scale = float(tr.scaler.scale.item()) if tr.scaler.enabled else 1.0
@@ -115,7 +122,8 @@ def test_bert_training_mode_dropout_vs_oracle(cuda, dtype, bar):
     orc = BO.BertOracle(cfg, state)
     lo = orc.loss(*cpu_batch, masks=masks, p_hidden=0.1, p_attn=0.1)
     lo.backward()
-    assert abs(loss.item() - float(lo)) <= (1e-3 if dtype == torch.float16 else 3e-3) * float(lo), (loss.item(), float(lo))
+    floor = abs(float(BO.BertOracle(cfg, state, storage_dtype=dtype).loss(*cpu_batch, masks=masks, p_hidden=0.1, p_attn=0.1)) - float(lo))
+    assert abs(loss.item() - float(lo)) <= 1e-3 * float(lo) + floor, (loss.item(), float(lo), floor)
     scale = float(tr.scaler.scale.item()) if tr.scaler.enabled else 1.0
     bad = []
     for n, p in orc.p.items():

@@ -35,8 +35,12 @@ def test_step_losses_match_reference(cuda, golden_dir, name, dtype):
     num, cat, click = SO.seeded_dlrm_batch(cfg["sizes"], cfg["num"], cfg["batch"], cfg["seed"] + 1000)
     num, cat, click = num.to(cuda), cat.to(cuda), click.to(cuda)
     losses = [float(trainer.train_step(num, cat, click).item()) for _ in range(cfg["steps"])]
-    rtol = 1e-3 if dtype == torch.float16 else 4e-3        # bf16 has 3 fewer mantissa bits
-    np.testing.assert_allclose(losses, gold["losses"], rtol=rtol)
+    ref = gold["losses"]
+    rel = np.abs(np.asarray(losses) - ref) / ref
+    # 1e-3 (north_star) + the 16-bit storage floor the oracle measures on this network (oracle/storage.py, fixture arrays)
+    floor = np.abs(gold["losses_%s_storage" % ("fp16" if dtype == torch.float16 else "bf16")] - ref) / ref
+    print(dtype, name, "rel err", rel.tolist(), "storage floor", floor.tolist())
+    assert np.all(rel <= 1e-3 + floor), (rel, floor)
     assert trainer.scaler.found_inf.item() == 0
     # weights after the last step vs the reference's (fp32) weights
     got = {"out.weight": model.top_model.out.weight, "bottom_mlp.0.weight": model.bottom_model.mlp.linears[0].weight}

@@ -54,8 +54,8 @@ def test_rn50_losses_match_reference(cuda, golden_dir, dtype):
     np.testing.assert_allclose(model.fc.bias.detach().cpu().numpy(), gold["final_fc_bias"], rtol=5e-2, atol=2e-4)
 
 
-@pytest.mark.parametrize("dtype,lbar", [(torch.float16, 1e-3), (torch.bfloat16, 4e-3)])
-def test_rn50_first_step_gradients_vs_oracle(cuda, dtype, lbar):
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_rn50_first_step_gradients_vs_oracle(cuda, dtype):
     """Logits, loss and EVERY parameter gradient of the first step vs torch autograd on the CPU oracle.
 
     Gradient bar: at batch 8 the gradient of this network in 16-bit storage differs from the fp32 gradient by
@@ -70,15 +70,20 @@ def test_rn50_first_step_gradients_vs_oracle(cuda, dtype, lbar):
     orc = RO.ResNet50Oracle(state, lr=0.0)
     lo = orc.step(x, y)
     emu = RO.ResNet50Oracle(state, lr=0.0, storage_dtype=dtype)
-    emu.step(x, y)
+    l16 = emu.step(x, y)
     with torch.no_grad():
         ref_logits = orc.forward(x)
+        emu_logits = RO.ResNet50Oracle(state, lr=0.0, storage_dtype=dtype).forward(x)
+    # bars: 1e-3 (north_star) + what 16-bit storage alone costs on this network, measured by the oracle
+    lfloor = abs(l16 - lo) / lo
+    efloor = float((emu_logits - ref_logits).abs().max() / ref_logits.abs().max())
     logits = tr.forward(x.to(cuda))
     err = float((logits.cpu() - ref_logits).abs().max() / ref_logits.abs().max())
     loss, dl = F.softmax_xent(logits, y.to(cuda), smoothing=0.1, grad_dtype=dtype, grad_scale=tr.scaler.scale)
-    print("max logit error / max logit %.3e, loss hip %.6f oracle %.6f" % (err, loss.item(), lo))
-    assert err <= 20 * lbar
-    assert abs(loss.item() - lo) <= lbar * lo
+    print("max logit error / max logit %.3e (storage floor %.3e), loss hip %.6f oracle %.6f (storage floor %.3e)"
+          % (err, efloor, loss.item(), lo, lfloor))
+    assert err <= 2e-2 + 1.5 * efloor
+    assert abs(loss.item() - lo) <= (1e-3 + lfloor) * lo
     scale = float(tr.scaler.scale.item())
     tr.backward(dl)
     torch.cuda.synchronize()

@@ -40,3 +40,30 @@ def test_rn50_oracle_reproduces_reference_losses():
     losses = [orc.step(x, y) for _ in range(2)]             # the fixture's own bar: first two steps to 1e-4
     np.testing.assert_allclose(losses, gold["losses"][:2], rtol=1e-4)
     np.testing.assert_allclose(losses, gold["oracle_losses"][:2], rtol=1e-5)
+
+
+def test_storage_floors_in_fixtures_are_what_the_oracles_measure():
+    """The 16-bit storage floors the GPU loss-parity bars add to 1e-3 (fixture arrays losses_<dtype>_storage): the BERT and
+    DLRM tiny cases recomputed here; all floors are far below 1e-3 (the bars are dominated by north_star's figure)."""
+    from oracle import bert_oracle as BO
+    from oracle import dlrm_step_oracle as SO
+    c = BO.BERT_STEP_CONFIG
+    gold = np.load(os.path.join(HERE, "golden", "bert_step.npz"))
+    batch = BO.seeded_batch(c["cfg"], c["seed"] + 1, c["batch"])
+    orc = BO.BertOracle(c["cfg"], BO.seeded_state(c["cfg"], c["seed"]), c["lr"], c["warmup"], c["total_steps"],
+                        storage_dtype=torch.bfloat16)
+    losses = [orc.step(*batch) for _ in range(2)]
+    np.testing.assert_allclose(losses, gold["losses_bf16_storage"][:2], rtol=2e-5)
+    d = SO.DLRM_STEP_CONFIGS["tiny"]
+    gd = np.load(os.path.join(HERE, "golden", "dlrm_step_tiny.npz"))
+    st = SO.seeded_dlrm_state(d["sizes"], d["dim"], d["bottom"], d["top"], d["num"], d["seed"])
+    num, cat, click = SO.seeded_dlrm_batch(d["sizes"], d["num"], d["batch"], d["seed"] + 1000)
+    for nm, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        o = SO.DlrmOracle(st, d["sizes"], d["lr"], storage_dtype=dt)
+        ls = [o.step(num, cat, click) for _ in range(d["steps"])]
+        np.testing.assert_allclose(ls, gd["losses_%s_storage" % nm], rtol=2e-5)
+    for f, keys in (("bert_step.npz", 1), ("bert_step_large1l.npz", 1), ("dlrm_step_tiny.npz", 1), ("dlrm_step_criteo_shape.npz", 1)):
+        g = np.load(os.path.join(HERE, "golden", f))
+        for nm in ("fp16", "bf16"):
+            floor = np.abs(g["losses_%s_storage" % nm] - g["losses"]) / g["losses"]
+            assert floor.max() < 2e-4, (f, nm, floor)

@@ -1,4 +1,5 @@
-"""Time dle_gemm on a list of shapes (forward layout), HIP events.  python tools/probes/gemm_shapes.py"""
+"""Time dle_gemm on a list of shapes (forward layout), HIP events.
+    python tools/probes/gemm_shapes.py [MxNxK ...]      (DLE_GEMM_BIG=0/1, DLE_GEMM_GM=g select the tile / walk order)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -11,7 +12,8 @@ def timeit(fn, iters=10, warmup=3):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e-3
-shapes = [(802816, 256, 64), (802816, 256, 128), (802816, 256, 256), (802816, 64, 256), (802816, 128, 64), (200704, 512, 128),
+arg_shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
+shapes = arg_shapes or [(802816, 256, 64), (802816, 256, 128), (802816, 256, 256), (802816, 64, 256), (802816, 128, 64), (200704, 512, 128),
           (50176, 1024, 256), (16384, 4096, 1024), (16384, 1024, 4096), (65536, 1024, 1024)]
 for m, n, k in shapes:
     a = torch.randn(m, k, device=dev).bfloat16(); b = torch.randn(n, k, device=dev).bfloat16()
@@ -19,6 +21,8 @@ for m, n, k in shapes:
     t = timeit(lambda: F.gemm(a, b, m, n, k, True, True, out=out))
     byts = (m * k + n * k + m * n) * 2
     print("fwd %8dx%5dx%5d  %8.1f us  %7.1f TF  %6.2f TB/s" % (m, n, k, t * 1e6, 2.0 * m * n * k / t / 1e12, byts / t / 1e12), flush=True)
+if arg_shapes:
+    sys.exit(0)
 x = torch.empty(802816 * 256, device=dev, dtype=torch.bfloat16)
 y = torch.empty_like(x)
 t = timeit(lambda: y.copy_(x))
