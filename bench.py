@@ -337,16 +337,24 @@ def roofline_from(timer, steps, wl_name, samples_per_step_per_gpu, ms_per_step):
     fams = sorted(fam.values(), key=lambda f: -f["ms"])
     top = fams[0]
     bound_step, work = WORK_PER_SAMPLE[wl_name]
-    is_mfma = top["name"] in MFMA_FAMILIES and top["flops"] > 0
+    # The family's bound is the side of the roofline its ALGORITHMIC arithmetic intensity puts it on: flops / byte below the
+    # ridge (peak flops / peak bytes = 312) -> HBM, above -> MFMA.  (ResNet-50's GEMM launches are mostly K <= 256 1x1
+    # convolutions at ~100 flop/B: no schedule can run them faster than their bytes at 8 TB/s.)  Both fractions are kept.
     t_s = top["ms"] * 1e-3
-    if is_mfma:
-        ach = top["flops"] / t_s / 1e12
-        r = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-             "frac": round(ach / MFMA_PEAK_TFLOPS, 4)}
+    is_mfma_kernel = top["name"] in MFMA_FAMILIES and top["flops"] > 0
+    ach_f = top["flops"] / t_s / 1e12 if top["flops"] else 0.0
+    ach_b = top["bytes"] / t_s / 1e9 if top["bytes"] else 0.0
+    ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    ai = top["flops"] / top["bytes"] if (top["flops"] and top["bytes"]) else None
+    if is_mfma_kernel and (ai is None or ai >= ridge):
+        r = {"bound": "mfma", "achieved": round(ach_f, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": round(ach_f / MFMA_PEAK_TFLOPS, 4)}
     else:
-        ach = top["bytes"] / t_s / 1e9
-        r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": round(ach / HBM_PEAK_GBS, 4)}
+        r = {"bound": "hbm", "achieved": round(ach_b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(ach_b / HBM_PEAK_GBS, 4)}
+    r.update({"arithmetic_intensity": round(ai, 1) if ai else None, "ridge": round(ridge, 1),
+              "frac_mfma": round(ach_f / MFMA_PEAK_TFLOPS, 4) if is_mfma_kernel else None,
+              "frac_hbm": round(ach_b / HBM_PEAK_GBS, 4) if top["bytes"] else None})
     big = max(top["shapes"], key=lambda a: a["avg_ms"] * a["calls"])
     bigname = big["name"] + ("[" + big["tag"] + "]" if big["tag"] else "")
     step_rate = work * samples_per_step_per_gpu / (ms_per_step * 1e-3)

@@ -187,15 +187,21 @@ __device__ __forceinline__ void epi_store8(const Gemm2Args& p, float* v, int m, 
 // NSTAGE = 1 (BIG = 0 only): one stage (32 KiB) and a 128-VGPR budget -> 4 workgroups per CU.  For K <= 128 a tile is
 // one or two K tiles: its lifetime is dominated by the DMA latency at the start and the store drain at the end, so the
 // bytes in flight per CU (= resident workgroups) set the throughput, not the overlap inside one workgroup.
-template <int DT, int A_MODE, int B_MODE, int NSTAGE, int BIG>
+// PLAIN = 1: the epilogue is the fast path with no bias, activation, addend or side output (stores and BatchNorm partials
+// only), decided by the launcher.  Such an instantiation issues NO load the compiler knows about inside the persistent tile
+// loop (its LDS-DMA goes through inline asm), so hipcc's wait-count pass has nothing to drain: with the general epilogue in
+// the same code it inserts s_waitcnt vmcnt(0) at the head of every tile (a bias / addend load of some path might still be
+// in flight when a register is reused), which waits for the previous tile's STORES before the next DMA can be issued.
+template <int DT, int A_MODE, int B_MODE, int NSTAGE, int BIG, int PLAIN = 0>
 __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) void gemm2_kernel(Gemm2Args p) {
   constexpr int WGN = BIG ? 4 : 2;                     // wave grid 2 x WGN
   constexpr int NW = 2 * WGN, NT = 64 * NW;
   constexpr int WTM = BIG ? 4 : 2, WTN = 2;            // 32x32 MFMA blocks per wave (rows, columns)
   constexpr int TM = 2 * WTM * 32, TN = WGN * WTN * 32;   // workgroup tile: 128x128 / 256x256
   constexpr int STAGE = (TM + TN) * BK;                // halves per stage (A tile | B tile)
-  typedef Loader<A_MODE, TM, NW> LA;
-  typedef Loader<B_MODE, TN, NW> LB;
+  constexpr bool RAW_DMA = !BIG && A_MODE <= 1 && B_MODE <= 1;     // the persistent-walk kernels (counted waits, below)
+  typedef Loader<A_MODE, TM, NW, RAW_DMA> LA;
+  typedef Loader<B_MODE, TN, NW, RAW_DMA> LB;
   static_assert(LA::NP == 4 && LB::NP == 4, "4 DMA pieces per wave per operand per K tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned short* lds = (unsigned short*)smem_raw;   // [stages][A tile | B tile]
@@ -270,6 +276,12 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
   if (kt0 < kt1) issue_all(kt0, 0);
   int s0 = 0;                              // stage of this tile's first K tile (128x128 tile)
   int stage_last = 0;
+  // vmcnt retires IN ORDER and counts stores: waiting with vmcnt(0) for the next tile's first K tile (whose DMA was issued
+  // BEFORE the epilogue) would also wait for every store of that epilogue to be acknowledged -- several microseconds per
+  // tile under a write-heavy load, with nothing of this workgroup in flight meanwhile (K <= 256 layers ran at ~3 TB/s).
+  // After an interior tile on the fast epilogue every wave has issued at least 2 * ITERS = 8 memory instructions behind
+  // that DMA, so vmcnt(8) proves the DMA has landed and leaves the youngest 8 (stores) in flight.
+  bool counted_wait = false;
   for (;;) {                               // tiles of this workgroup (one trip unless p.persist)
   constexpr bool CAN_PERSIST = !BIG && A_MODE <= 1 && B_MODE <= 1;      // (the convolution loaders are too register-heavy)
   const bool has_next = CAN_PERSIST && p.persist && vbid + vstep < ntiles;
@@ -290,6 +302,9 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
   if constexpr (!BIG) {
     // 128x128 tile: DMA of the next K tile at the top, then 4 k-steps; hipcc schedules the body (2-4 workgroups
     // per CU overlap each other's bubbles)
+    // this wave's DMA pieces of the first K tile have landed (issued by the prologue, or under the previous tile)
+    if (CAN_PERSIST && counted_wait) __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8), see counted_wait
+    else __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0)
     for (int kt = kt0; kt < kt1; ++kt) {
       const int stage = NSTAGE == 1 ? 0 : s0 ^ ((kt - kt0) & 1);
       stage_last = stage;
@@ -297,8 +312,9 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
         __syncthreads();                    // everyone is done reading the single stage
         issue_all(kt, 0);
       }
-      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA pieces of tile kt have landed
-      __syncthreads();                      // ... and everybody's; everyone is done reading the other stage
+      if (kt > kt0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA pieces of tile kt have landed
+      lds_barrier();                        // ... and everybody's; everyone is done reading the other stage (no global
+                                            // fence: __syncthreads() would wait for the previous tile's stores again)
       if (NSTAGE == 2 && kt + 1 < kt1) issue_all(kt + 1, stage ^ 1);
       else if (CAN_PERSIST && NSTAGE == 2 && has_next) {   // last K tile: the loaders move on to the next tile of this workgroup
         int ntm, ntn;
@@ -442,15 +458,15 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
   // hoisted out of the store loop, which is then ~30 VALU instructions per 16-byte store instead of ~100 VALU + 60
   // SALU (the generic loop below re-decides every runtime flag per store; a K <= 256 GEMM was instruction-bound in it).
   // (edge tiles included: N % 8 == 0 makes every 8-column group entirely inside or outside, rows are checked per trip)
-  const bool fast = p.splitk == 1 && p.out_dtype == DT && vec16 && (p.N & 7) == 0;
-  const bool fast_slab = p.splitk > 1 && p.ws != nullptr && (p.N & 7) == 0;
+  const bool fast = PLAIN || (p.splitk == 1 && p.out_dtype == DT && vec16 && (p.N & 7) == 0);
+  const bool fast_slab = !PLAIN && p.splitk > 1 && p.ws != nullptr && (p.N & 7) == 0;
   constexpr int RPI = NT / (TN / 8), ITERS = (TM / 2) / RPI;      // rows per store-loop trip (16), trips per half
   const int f_ml0 = tid / (TN / 8), f_nl = (tid % (TN / 8)) << 3;
   float fbias[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) fbias[r] = 0.f;
   const bool f_col_ok = n0 + f_nl < p.N;
-  if (fast && p.bias && f_col_ok) {
+  if (!PLAIN && fast && p.bias && f_col_ok) {
     const float4_t b0 = *(const float4_t*)(p.bias + n0 + f_nl), b1 = *(const float4_t*)(p.bias + n0 + f_nl + 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { fbias[r] = b0[r]; fbias[4 + r] = b1[r]; }
@@ -468,9 +484,9 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
     const int mrow0 = m0 + half * (TM / 2) + f_ml0;
     const long long off0 = (long long)mrow0 * p.ldc + n0 + f_nl;
     const long long step = (long long)RPI * p.ldc;
-    const bool remap = p.row_extra != 0;                     // strided sub-grid output (stride-2 data gradient classes)
+    const bool remap = !PLAIN && p.row_extra != 0;           // strided sub-grid output (stride-2 data gradient classes)
     unsigned short* c = (unsigned short*)p.C + off0;
-    unsigned short* ax = (p.aux && act != ACT_ADD_MASKED) ? (unsigned short*)p.aux + off0 : nullptr;
+    unsigned short* ax = (!PLAIN && p.aux && act != ACT_ADD_MASKED) ? (unsigned short*)p.aux + off0 : nullptr;
     const unsigned short* ms = needs_src ? p.mask_src + off0 : nullptr;
     const unsigned char* bits = act == ACT_ADD_MASKED ? (const unsigned char*)p.aux + (off0 >> 3) : nullptr;   // off0 % 8 == 0 (vec16)
     const int rows_left = p.M - (m0 + half * (TM / 2) + f_ml0);      // trips with it * RPI < rows_left are inside
@@ -568,6 +584,10 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
     }
     continue;
   }
+  if constexpr (PLAIN) {
+    fast_pass(std::integral_constant<int, ACT_NONE>(), half);
+    continue;
+  }
   if (fast) {
     switch (p.act) {
       case ACT_NONE: fast_pass(std::integral_constant<int, ACT_NONE>(), half); break;
@@ -622,6 +642,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
     }
   }
   if (!CAN_PERSIST || !has_next) break;
+  counted_wait = fast && m0 + TM <= p.M && n0 + TN <= p.N && 2 * ITERS >= 8;
   vbid += vstep;
   tile_coords(vbid, tm, tn);
   m0 = tm * TM; n0 = tn * TN;
@@ -676,11 +697,19 @@ static int launch_gemm(const Gemm2Args& p_in, int in_dtype, int amode, int bmode
     dim3 grid(p.persist ? resident : tiles, p.splitk, batch > 0 ? batch : 1), block(256);
     // (a single-stage, 4-workgroups-per-CU variant for K <= 128 existed; with the hoisted epilogue it measured 2x
     //  SLOWER than this one -- 802816x256x64: 295 vs 144 us -- its 128-VGPR budget spilled; removed)
+    // store-only epilogue (see PLAIN at the kernel): no bias / activation / addend / side output, 16-bit output of the input
+    // type on the 16-byte fast path
+    const bool plain = amode <= 1 && bmode <= 1 && p.splitk == 1 && batch <= 0 && p.act == ACT_NONE && !p.bias && !p.aux &&
+                       !p.mask_src && p.out_dtype == in_dtype && p.row_extra == 0 && (p.N & 7) == 0 && (p.ldc & 7) == 0 &&
+                       (((uintptr_t)p.C) & 15) == 0;
 #define GO(DT, AM, BMODE) hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE, 2, 0>), grid, block, lds, stream, p)
-#define PICK(DT) do { if (amode == 0 && bmode == 0) GO(DT, 0, 0); else if (amode == 0) GO(DT, 0, 1); else if (amode == 1 && bmode == 1) GO(DT, 1, 1); \
+#define GOP(DT, AM, BMODE) hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE, 2, 0, 1>), grid, block, lds, stream, p)
+#define PICK(DT) do { if (plain) { if (amode == 0 && bmode == 0) GOP(DT, 0, 0); else if (amode == 0) GOP(DT, 0, 1); else GOP(DT, 1, 1); } \
+      else if (amode == 0 && bmode == 0) GO(DT, 0, 0); else if (amode == 0) GO(DT, 0, 1); else if (amode == 1 && bmode == 1) GO(DT, 1, 1); \
       else if (amode == 2) GO(DT, 2, 0); else if (amode == 4) GO(DT, 4, 5); else GO(DT, 1, 3); } while (0)
     if (in_dtype == DLE_F16) PICK(DLE_F16); else PICK(DLE_BF16);
 #undef GO
+#undef GOP
 #undef PICK
   }
   hipError_t e = hipGetLastError();

@@ -70,6 +70,27 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned short*
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_wave_base, 16, voff, 0, 0, 0);
 }
 
+// The same instruction issued through inline asm, for kernels whose EVERY LDS-DMA goes this way (M0 is set here, behind the
+// compiler's back).  hipcc's wait-count pass treats a builtin DMA as pending until it has seen a wait that provably covers it
+// and then drains the whole queue -- s_waitcnt vmcnt(0) -- before the first overwrite of one of its address registers; a
+// counted wait that leaves younger STORES in flight (the persistent tile walk of gemm_dma.hip) cannot be expressed to it.
+// Hidden from that pass, every wait is the explicit one in the source.  (vmcnt retires in order, so the waits the compiler
+// inserts for its own loads only become more conservative when instructions it does not know about are in the queue.)
+typedef int int4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int4v_t rsrc_words(const void* base) {
+  const unsigned long long b = (unsigned long long)base;
+  int4v_t r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+  r.z = (int)0xFFFFFFE0u;
+  r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void dma16_raw(int4v_t rs, unsigned short* lds_wave_base, unsigned voff) {
+  const int m0v = __builtin_amdgcn_readfirstlane((int)(unsigned)(__UINTPTR_TYPE__)(lds_void*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(m0v), "v"(voff), "s"(rs) : "memory");
+}
+
 // ---- per-operand tile loader state: 4 DMA instructions per wave per K tile --------------------------
 // k-contiguous images  [128 rows][8 chunks]: instr j of wave w covers rows (4w+j)*8 .. +7     (modes 0, 2, 4)
 // row-contiguous images [64 k][16 chunks]:   instr j of wave w covers k rows (4w+j)*4 .. +3   (modes 1, 3, 5)
@@ -78,7 +99,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned short*
 //   4  im2col, data grad: A(m=(n,h,w), k=(r,s,ko)) = dY[n, (h+pad-r)/st, (w+pad-s)/st, ko]   (0 unless divisible)
 //   3  im2col, weight grad B operand: B(n'=(r,s,c), k=pixel(n,p,q)) = X[n, p*st-pad+r, q*st-pad+s, c]
 //   5  KRSC weights as the data-grad B operand: B(c, k=(r,s,ko)) = W[ko][r][s][c]
-template <int MODE, int TILE, int NW>
+template <int MODE, int TILE, int NW, bool RAW = false>
 struct Loader {
   // the operand tile has TILE rows (128 or 256) x 64 k = TILE/8 DMA pieces of 1 KiB; NW waves own NP pieces each
   static constexpr bool RC = (MODE == 1 || MODE == 3 || MODE == 5);
@@ -215,7 +236,8 @@ struct Loader {
         const int tap = fd_div(k, cg.dKo), ko = k - tap * cg.Ko;
         o += (unsigned)((((long long)ko * cg.R * cg.S + tap) * cg.C) * 2);
       }
-      dma16(rs, tile + (wave * NP + j) * 512, ok ? o : OOB_OFF);
+      if constexpr (RAW) dma16_raw(rsrc_words(base), tile + (wave * NP + j) * 512, ok ? o : OOB_OFF);
+      else dma16(rs, tile + (wave * NP + j) * 512, ok ? o : OOB_OFF);
     }
   }
 };

@@ -155,3 +155,43 @@ def test_gemm_masked_add_mul_and_gelu_derivative_epilogues(cuda, dtype, shape):
     g.sum().backward()
     np.testing.assert_allclose(y.cpu().double().numpy(), g.detach().numpy(), **tol)
     np.testing.assert_allclose(daux.cpu().double().numpy(), pre.grad.numpy(), **tol)
+
+
+WALK_CASES = [(131072, 256, 64), (70005, 192, 64), (66000, 128, 200)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("mnk", WALK_CASES)
+def test_gemm_persistent_tile_walk(cuda, mnk, dtype):
+    """More 128x128 tiles than resident workgroups (2 per CU): every workgroup walks several tiles, the next tile's first
+    K tile is prefetched under the current epilogue and waited for with a COUNTED vmcnt that leaves the epilogue's stores in
+    flight.  Store-only epilogue (the PLAIN instantiation) and the general one, all three operand layouts, interior tiles,
+    ragged M / N edges and a ragged K; every output element against fp64."""
+    F, C = _F()
+    m, n, k = mnk
+    gen = torch.Generator(device=cuda).manual_seed(m + n + k)
+    a = (torch.randn(m, k, generator=gen, device=cuda) * 0.5).to(dtype)
+    b = (torch.randn(n, k, generator=gen, device=cuda) * 0.5).to(dtype)
+    ref = a.double() @ b.double().T
+    tol = (2e-3 if dtype == torch.float16 else 1.6e-2) * np.sqrt(k)
+
+    def chk(out, what, r=ref):
+        err = (out.double() - r).abs().max().item()
+        assert err <= tol, "%s: max err %g (m,n,k=%s)" % (what, err, mnk)
+
+    bt, at = b.T.contiguous(), a.T.contiguous()
+    for rep in range(2):                                     # back to back: tiles of one launch still draining under the next
+        chk(F.gemm(a, b, m, n, k, True, True), "kc/kc store-only")
+        chk(F.gemm(a, bt, m, n, k, True, False), "kc/nc store-only")
+        chk(F.gemm(at, bt, m, n, k, False, False), "mc/nc store-only")
+    bias = torch.randn(n, generator=gen, device=cuda)
+    chk(F.gemm(a, b, m, n, k, True, True, bias=bias, act=C.ACT_RELU), "bias relu", (ref + bias.double()).clamp(min=0))
+    add = (torch.randn(m, n, generator=gen, device=cuda)).to(dtype)
+    chk(F.gemm(a, bt, m, n, k, True, False, act=C.ACT_ADD, mask_src=add), "kc/nc + addend", ref + add.double())
+    if (m * n) % 8 == 0:
+        keep = torch.rand(m, n, generator=gen, device=cuda) > 0.4
+        bits = (keep.reshape(-1, 8).to(torch.int32) << torch.arange(8, dtype=torch.int32, device=cuda)).sum(1).to(torch.uint8)
+        y = F.gemm(a, bt, m, n, k, True, False, act=C.ACT_ADD_MASKED, mask_src=add, aux=bits)
+        chk(y, "masked addend", ref + torch.where(keep, add.double(), torch.zeros((), dtype=torch.float64, device=cuda)))
+    # the fp32-output path is not store-only (different output type): general epilogue on the same walk
+    chk(F.gemm(a, b, m, n, k, True, True, out_dtype=torch.float32), "f32 out")

@@ -12,15 +12,24 @@ def timeit(fn, iters=10, warmup=3):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e-3
-arg_shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
+from deeplearningexamples_amd import _cabi as C
+# MxNxK[:flags]  flags: d = B stored [K][N] (data-gradient layout), s = + 16-bit addend (ACT_ADD), m = + addend under a 1-bit mask
+arg_specs = [(a.split(":") + [""])[:2] for a in sys.argv[1:]]
+arg_shapes = [tuple(int(v) for v in a.split("x")) + (f,) for a, f in arg_specs]
 shapes = arg_shapes or [(802816, 256, 64), (802816, 256, 128), (802816, 256, 256), (802816, 64, 256), (802816, 128, 64), (200704, 512, 128),
           (50176, 1024, 256), (16384, 4096, 1024), (16384, 1024, 4096), (65536, 1024, 1024)]
-for m, n, k in shapes:
-    a = torch.randn(m, k, device=dev).bfloat16(); b = torch.randn(n, k, device=dev).bfloat16()
+for spec in shapes:
+    m, n, k = spec[:3]
+    fl = spec[3] if len(spec) > 3 else ""
+    a = torch.randn(m, k, device=dev).bfloat16()
+    b = (torch.randn(k, n, device=dev) if "d" in fl else torch.randn(n, k, device=dev)).bfloat16()
     out = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
-    t = timeit(lambda: F.gemm(a, b, m, n, k, True, True, out=out))
-    byts = (m * k + n * k + m * n) * 2
-    print("fwd %8dx%5dx%5d  %8.1f us  %7.1f TF  %6.2f TB/s" % (m, n, k, t * 1e6, 2.0 * m * n * k / t / 1e12, byts / t / 1e12), flush=True)
+    src = torch.randn(m, n, device=dev).bfloat16() if ("s" in fl or "m" in fl) else None
+    bits = torch.randint(0, 255, (m * n // 8,), device=dev, dtype=torch.uint8) if "m" in fl else None
+    act = C.ACT_ADD_MASKED if "m" in fl else C.ACT_ADD if "s" in fl else C.ACT_NONE
+    t = timeit(lambda: F.gemm(a, b, m, n, k, True, "d" not in fl, out=out, act=act, mask_src=src, aux=bits))
+    byts = (m * k + n * k + m * n) * 2 + (m * n * 2 if src is not None else 0) + (m * n // 8 if bits is not None else 0)
+    print("%-3s %8dx%5dx%5d  %8.1f us  %7.1f TF  %6.2f TB/s" % (fl or "fwd", m, n, k, t * 1e6, 2.0 * m * n * k / t / 1e12, byts / t / 1e12), flush=True)
 if arg_shapes:
     sys.exit(0)
 x = torch.empty(802816 * 256, device=dev, dtype=torch.bfloat16)
