@@ -40,15 +40,29 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _sha(paths, extra=""):
+    h = hashlib.sha256(extra.encode())
+    for q in paths:
+        h.update(open(q, "rb").read())
+    return h.hexdigest()
+
+
 def _compile(src, force):
+    """One object per source.  Up to date = the CONTENT hash of (flags, the source, every header of csrc/ and include/)
+    recorded next to the object matches -- file times are not preserved everywhere this tree travels."""
     obj = os.path.join(OBJ, src[:-4] + ".o")
-    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
-    if not force and not _stale(obj, [os.path.join(CSRC, src)] + headers):
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    headers = sorted(os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h"))
+    headers += sorted(os.path.join(inc, h) for h in os.listdir(inc) if h.endswith(".h")) if os.path.isdir(inc) else []
+    want = _sha([os.path.join(CSRC, src)] + headers, " ".join(FLAGS))
+    stamp = obj + ".sha256"
+    if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return obj, False
     cmd = [hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout[-4000:], r.stderr[-8000:]))
+    open(stamp, "w").write(want)
     return obj, True
 
 
@@ -77,7 +91,7 @@ def build(force=False, verbose=True):
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         res = list(ex.map(lambda s: _compile(s, force), srcs))
     objs = [o for o, _ in res]
-    if any(c for _, c in res) or _stale(LIB, objs):
+    if any(c for _, c in res) or not os.path.exists(LIB) or _stale(LIB, objs):
         cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", LIB]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -86,7 +100,7 @@ def build(force=False, verbose=True):
             print("built", LIB, "(%d objects, %d recompiled)" % (len(objs), sum(c for _, c in res)))
     elif verbose:
         print("up to date:", LIB)
-    json.dump(hashes, open(MANIFEST, "w"), indent=0)
+    json.dump(hashes, open(MANIFEST, "w"), indent=0)          # only after a successful link of objects that match `hashes`
     return LIB
 
 
