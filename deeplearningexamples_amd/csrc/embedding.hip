@@ -340,6 +340,129 @@ __global__ __launch_bounds__(256) void emb_sgd_small(float* __restrict__ weight,
   }
 }
 
+// Tiny tables, second form (<= 128 rows, dim <= 128): the per-row sums of a batch slice are accumulated in REGISTERS.
+// A wavefront takes one sample at a time (lane = 2 consecutive dims of the 128-wide gradient row: one coalesced 256-byte
+// load per sample), so the row id is wave-uniform and selects the accumulator pair by register index (v_movrel) -- no LDS
+// read-modify-write per lookup, no same-address serialisation (a 4-row table takes every lookup of the batch on 4 rows).
+// 16 wavefronts per workgroup; tables with more than 32 / 64 rows split their rows over 2 / 4 wavefront groups, each
+// wavefront scans 64 row ids at a time (one per lane), ballots the samples whose row it owns and requests only those
+// gradient rows, DLE_EMB_TINY_U at a time -- every load in flight is a useful one.  The 16 register images meet in LDS once
+// per workgroup; one fp32 atomic per (slice, row, dim) reaches the table (32 slices: 1.4 M adds for the eight tiny tables of
+// criteo_f15, where the LDS form issued 67 M ds_add_f32 on a handful of rows and 5.4 M global adds: 341 us per step).
+#define DLE_EMB_TINY_U 16
+template <int IDT> struct In2;
+template <> struct In2<DLE_F32> {
+  typedef float2_t V;
+  static __device__ __forceinline__ void up(V v, float& a, float& b) { a = v[0]; b = v[1]; }
+};
+template <> struct In2<DLE_F16> {
+  typedef unsigned V;
+  static __device__ __forceinline__ void up(V v, float& a, float& b) {
+    a = Elem<DLE_F16>::to_f32((unsigned short)(v & 0xFFFFu)); b = Elem<DLE_F16>::to_f32((unsigned short)(v >> 16));
+  }
+};
+template <> struct In2<DLE_BF16> {
+  typedef unsigned V;
+  static __device__ __forceinline__ void up(V v, float& a, float& b) {
+    a = __builtin_bit_cast(float, v << 16); b = __builtin_bit_cast(float, v & 0xFFFF0000u);
+  }
+};
+
+template <int IDT>
+__global__ __launch_bounds__(1024) void emb_sgd_tiny(float* __restrict__ weight, const long long* __restrict__ rows,
+                                                     const void* __restrict__ grad_v,
+                                                     const float* __restrict__ lr_dev, float lr_host,
+                                                     const float* __restrict__ scale,
+                                                     const float* __restrict__ skip_flag, SmallTables st,
+                                                     long long batch, int T, int D, long long g_bstride, int slices) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (skip_flag && *skip_flag != 0.0f) return;
+  typedef typename In2<IDT>::V V2;
+  const V2* __restrict__ grad = (const V2*)grad_v;                 // pairs of elements
+  float* sum = (float*)smem_raw;                                   // [nrows][D]
+  const int k = blockIdx.x / slices, sl = blockIdx.x - k * slices;
+  const int t = st.t[k], nrows = st.rows[k];
+  const long long base = st.base[k];
+  for (int q = threadIdx.x; q < nrows * D; q += 1024) sum[q] = 0.f;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;        // 16 wavefronts
+  const int split = nrows <= 32 ? 1 : (nrows <= 64 ? 2 : 4);
+  const int nrw = (nrows + split - 1) / split;                     // rows per wavefront group (<= 32)
+  const int r0 = (w % split) * nrw;
+  const int phase = w / split, nphase = 16 / split;
+  const bool active = 2 * lane < D;
+  const long long per = (batch + slices - 1) / slices;
+  const long long b0 = sl * per;
+  long long b1 = b0 + per;
+  if (b1 > batch) b1 = batch;
+  typedef float f32x32_t __attribute__((ext_vector_type(32)));
+  f32x32_t acc0 = 0.f, acc1 = 0.f;                                 // [row of this wavefront's group]: even / odd dim of the lane
+  const long long half_stride = g_bstride >> 1;                    // gradient row stride in element pairs
+  const long long toff = ((long long)t * D) >> 1;
+  // the row ids of the NEXT chunk are requested before this chunk's gradient rows (one dependent round trip less per chunk)
+  long long rid_next = -1;
+  {
+    const long long bl = b0 + (long long)phase * 64 + lane;
+    if (bl < b1) rid_next = rows[bl * T + t];
+  }
+  for (long long bb = b0 + (long long)phase * 64; bb < b1; bb += (long long)nphase * 64) {
+    const long long rid_raw = rid_next;
+    {
+      const long long bl = bb + (long long)nphase * 64 + lane;
+      rid_next = -1;
+      if (bl < b1) rid_next = rows[bl * T + t];
+    }
+    int rid = -1;
+    if (bb + lane < b1) rid = (int)(rid_raw - base) - r0;
+    unsigned long long mask = __ballot(rid >= 0 && rid < nrw);
+    while (mask) {
+      int ri[DLE_EMB_TINY_U];
+      V2 gv[DLE_EMB_TINY_U];
+#pragma unroll
+      for (int u = 0; u < DLE_EMB_TINY_U; ++u) {
+        ri[u] = -1;
+        if (mask) {
+          const int sidx = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          ri[u] = __builtin_amdgcn_readlane(rid, sidx);
+          if (active) gv[u] = grad[(bb + sidx) * half_stride + toff + lane];
+        }
+      }
+      // (not unrolled: one indexed read-modify-write site; the loaded pair of trip u is picked by a uniform select)
+#pragma nounroll
+      for (int u = 0; u < DLE_EMB_TINY_U; ++u) {
+        int r = ri[0];
+        V2 g = gv[0];
+#pragma unroll
+        for (int q = 1; q < DLE_EMB_TINY_U; ++q)
+          if (u == q) { r = ri[q]; g = gv[q]; }
+        if (r < 0) break;
+        float g0 = 0.f, g1 = 0.f;
+        if (active) In2<IDT>::up(g, g0, g1);
+        acc0[r] += g0;                     // r is wave-uniform (v_readlane): register-indexed, no LDS, no branch
+        acc1[r] += g1;
+      }
+    }
+  }
+  __syncthreads();                                                 // sum[] is zeroed
+  if (active) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const int r = r0 + c;
+      if (c < nrw && r < nrows) {
+        if (acc0[c] != 0.f) atomicAdd(sum + r * D + 2 * lane, acc0[c]);            // ds_add_f32, once per workgroup
+        if (acc1[c] != 0.f) atomicAdd(sum + r * D + 2 * lane + 1, acc1[c]);
+      }
+    }
+  }
+  __syncthreads();
+  const float lr = lr_dev ? *lr_dev : lr_host;
+  const float alpha = -lr * (scale ? *scale : 1.0f);
+  for (int q = threadIdx.x; q < nrows * D; q += 1024) {
+    const float v = sum[q];
+    if (v != 0.f) unsafeAtomicAdd(weight + base * D + q, alpha * v);
+  }
+}
+
 // pass 1: thread every lookup of a "large" table into its row's list
 __global__ __launch_bounds__(256) void emb_link(const long long* __restrict__ rows, int* __restrict__ head,
                                                 int* __restrict__ next, const unsigned char* __restrict__ is_small,
@@ -447,23 +570,49 @@ extern "C" int dle_emb_sgd_dedup(float* weight, const int64_t* rows, const void*
   const long long n = (long long)batch * tables;
   SmallTables st;
   st.n = 0;
-  int max_rows = 0, n_large = 0;
+  int n_large = 0;
   for (int t = 0; t < tables; ++t) {
     const long long r = table_offsets_host[t + 1] - table_offsets_host[t];
     if (r * dim * 4 <= DLE_EMB_SMALL_LDS_BYTES && st.n < 64) {
       st.t[st.n] = t; st.base[st.n] = table_offsets_host[t]; st.rows[st.n] = (int)r;
-      if ((int)r > max_rows) max_rows = (int)r;
       ++st.n;
     } else {
       ++n_large;
     }
   }
-  if (st.n > 0) {
+  // tiny tables (<= 128 rows, dim <= 128, 16-bit gradients, even element-pair strides): register form; the other "small" ones: LDS form
+  SmallTables tiny, lds_t;
+  tiny.n = 0; lds_t.n = 0;
+  int max_rows = 0, max_rows_tiny = 0;
+  static const int tiny_mode = getenv("DLE_EMB_TINY") ? atoi(getenv("DLE_EMB_TINY")) : 1;
+  for (int i = 0; i < st.n; ++i) {
+    const bool is_tiny = tiny_mode && grad_dtype != DLE_F32 && st.rows[i] <= 128 && dim <= 128 && (dim & 1) == 0 &&
+                         (grad_batch_stride & 1) == 0;        // (fp32 gradients: the LDS form -- not the train step's path)
+    SmallTables& dst = is_tiny ? tiny : lds_t;
+    dst.t[dst.n] = st.t[i]; dst.base[dst.n] = st.base[i]; dst.rows[dst.n] = st.rows[i];
+    ++dst.n;
+    if (is_tiny) { if (st.rows[i] > max_rows_tiny) max_rows_tiny = st.rows[i]; }
+    else if (st.rows[i] > max_rows) max_rows = st.rows[i];
+  }
+  if (tiny.n > 0) {
+    // one 16-wavefront workgroup per CU and table slice; >= 2048 samples per workgroup
+    int slices = (int)((256 + tiny.n - 1) / tiny.n);
+    const long long max_slices = (batch + 2047) / 2048;
+    if (slices > max_slices) slices = (int)max_slices;
+    if (slices < 1) slices = 1;
+    const size_t lds = (size_t)max_rows_tiny * dim * 4;
+#define GO(IDT) hipLaunchKernelGGL(emb_sgd_tiny<IDT>, dim3(tiny.n * slices), dim3(1024), lds, stream, weight, (const long long*)rows, grad, lr_dev, lr_host, scale_dev, skip_flag_dev, tiny, (long long)batch, tables, dim, (long long)grad_batch_stride, slices)
+    if (grad_dtype == DLE_F16) GO(DLE_F16);
+    else GO(DLE_BF16);
+#undef GO
+    DLE_LAUNCH_CHECK();
+  }
+  if (lds_t.n > 0) {
     int slices = (int)((batch + 511) / 512);
     if (slices > 128) slices = 128;
     if (slices < 1) slices = 1;
     const size_t lds = (size_t)max_rows * dim * 4;
-#define GO(IDT, VT) hipLaunchKernelGGL(emb_sgd_small<IDT>, dim3(st.n * slices), dim3(256), lds, stream, weight, (const long long*)rows, (const VT*)grad, lr_dev, lr_host, scale_dev, skip_flag_dev, st, (long long)batch, tables, D4, gs4, slices)
+#define GO(IDT, VT) hipLaunchKernelGGL(emb_sgd_small<IDT>, dim3(lds_t.n * slices), dim3(256), lds, stream, weight, (const long long*)rows, (const VT*)grad, lr_dev, lr_host, scale_dev, skip_flag_dev, lds_t, (long long)batch, tables, D4, gs4, slices)
     if (grad_dtype == DLE_F32) GO(DLE_F32, float4_t);
     else if (grad_dtype == DLE_F16) GO(DLE_F16, ushort4_t);
     else GO(DLE_BF16, ushort4_t);

@@ -148,6 +148,16 @@ def test_dlrm_embeddings_full_criteo_row_ranges(cuda):
         where = np.nonzero(flat == r_)[0]
         exp = host_rows(np.asarray([r_]))[0] - np.float32(lr) * gflat[where].astype(np.float64).sum(0)
         np.testing.assert_allclose(wtab[int(r_)].cpu().numpy(), exp, rtol=1e-5, atol=1e-6)
+    # the tiny tables (4 .. 104 rows: every sample of the batch lands on a handful of rows -- the register-accumulating
+    # kernel): EVERY row against the float64 sum of its ~b / rows gradients
+    for t, s_ in enumerate(SIZES):
+        if s_ > 128:
+            continue
+        for r_ in range(s_):
+            row = int(off[t]) + r_
+            where = np.nonzero(flat == row)[0]
+            exp = host_rows(np.asarray([row]))[0].astype(np.float64) - lr * gflat[where].astype(np.float64).sum(0)
+            np.testing.assert_allclose(wtab[row].cpu().numpy(), exp, rtol=2e-5, atol=2e-5 * max(1.0, len(where) ** 0.5))
     # untouched rows keep their bits
     probe = np.setdiff1d(np.random.default_rng(2).integers(0, total, 5000), uniq)
     assert np.array_equal(wtab[torch.from_numpy(probe).to(cuda)].cpu().numpy(), host_rows(probe))
