@@ -31,6 +31,8 @@ _SIGS = {
     "dle_dot_interact_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dle_dot_interact_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                      c_int, c_void_p]),
+    "dle_dot_interact_bwd_checked": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                             c_int, c_void_p, c_void_p]),
     "dle_emb_gather_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int,
                                    c_int, c_i64, c_void_p]),
     "dle_emb_offset_indices": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),

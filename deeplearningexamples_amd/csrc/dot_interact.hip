@@ -97,10 +97,11 @@ __global__ __launch_bounds__(256) void dot_bwd_mfma(const unsigned short* __rest
                                                     const unsigned short* __restrict__ ug,
                                                     unsigned short* __restrict__ grad,
                                                     unsigned short* __restrict__ mlp_grad, int B,
-                                                    int R, int C, int OW) {
+                                                    int R, int C, int OW, float* __restrict__ found_inf) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + wave;
+  unsigned bad = 0;                                      // OR of the exponent-all-ones tests of the 16-bit values written
   const int XS = C + 8;                                  // halves per staged X row
   const size_t per_wave = (size_t)32 * XS + 32 * DOT_BWD_USTRIDE;
   unsigned short* xs = (unsigned short*)smem_raw + wave * per_wave;
@@ -193,7 +194,11 @@ __global__ __launch_bounds__(256) void dot_bwd_mfma(const unsigned short* __rest
           }
           ushort4_t o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = Elem<DT>::from_f32(v[e]);
+          for (int e = 0; e < 4; ++e) {
+            o[e] = Elem<DT>::from_f32(v[e]);
+            constexpr unsigned EXPM = DT == DLE_F16 ? 0x7C00u : 0x7F80u;
+            bad |= ((unsigned)o[e] & EXPM) == EXPM;
+          }
           *(ushort4_t*)(xs + row * XS + n) = o;
         }
       }
@@ -208,6 +213,9 @@ __global__ __launch_bounds__(256) void dot_bwd_mfma(const unsigned short* __rest
       *(ushort8_t*)(gb + (size_t)rr * C + cc * 8) = *(const ushort8_t*)(xs + rr * XS + cc * 8);
     }
   }
+  // GradScaler's inf / nan test on the gradient this kernel just produced (the values as stored, like a pass over the
+  // tensor would see them): the train step's separate 450 MB sweep of the embedding gradient goes away
+  if (found_inf && bad) *found_inf = 1.0f;
 }
 
 // ------------------------------------------------------------------ generic path (any R, C, dtype)
@@ -337,9 +345,11 @@ extern "C" int dle_dot_interact_fwd(const void* x, void* out, int batch, int row
   return 0;
 }
 
-extern "C" int dle_dot_interact_bwd(const void* x, const void* upstream, void* grad, void* mlp_grad,
-                                    int batch, int rows, int cols, int dtype, int force_generic,
-                                    hipStream_t stream) {
+extern "C" int dle_check_nonfinite(const void* x, float* found_inf, int64_t n, int dtype, hipStream_t stream);
+
+extern "C" int dle_dot_interact_bwd_checked(const void* x, const void* upstream, void* grad, void* mlp_grad,
+                                            int batch, int rows, int cols, int dtype, int force_generic,
+                                            float* found_inf, hipStream_t stream) {
   DLE_CHECK_ARG(batch >= 0 && rows >= 1 && cols >= 1, "dot_interact_bwd: bad shape %d %d %d", batch, rows, cols);
   DLE_CHECK_ARG(dtype == DLE_F32 || dtype == DLE_F16 || dtype == DLE_BF16, "dot_interact_bwd: bad dtype %d", dtype);
   if (batch == 0) return 0;
@@ -351,7 +361,7 @@ extern "C" int dle_dot_interact_bwd(const void* x, const void* upstream, void* g
     const size_t lds = (size_t)4 * (32 * (cols + 8) + 32 * DOT_BWD_USTRIDE) * 2;
     dim3 grid((batch + 3) / 4), block(256);
 #define GO(DT, NB) hipLaunchKernelGGL((dot_bwd_mfma<DT, NB>), grid, block, lds, stream, (const unsigned short*)x, \
-                         (const unsigned short*)upstream, (unsigned short*)grad, (unsigned short*)mlp_grad, batch, rows, cols, OW)
+                         (const unsigned short*)upstream, (unsigned short*)grad, (unsigned short*)mlp_grad, batch, rows, cols, OW, found_inf)
 #define PICK(DT) do { if (cols <= 32) GO(DT, 1); else if (cols <= 64) GO(DT, 2); else if (cols <= 128) GO(DT, 4); else GO(DT, 8); } while (0)
     if (dtype == DLE_F16) PICK(DLE_F16); else PICK(DLE_BF16);
 #undef GO
@@ -368,5 +378,13 @@ extern "C" int dle_dot_interact_bwd(const void* x, const void* upstream, void* g
       hipLaunchKernelGGL(dot_bwd_generic<DLE_BF16>, grid, block, lds, stream, (const unsigned short*)x, (const unsigned short*)upstream, (unsigned short*)grad, (unsigned short*)mlp_grad, batch, rows, cols, OW);
   }
   DLE_LAUNCH_CHECK();
+  if (!fast && found_inf)                       // generic path: the plain sweep (values as stored)
+    return dle_check_nonfinite(grad, found_inf, (int64_t)batch * rows * cols, dtype, stream);
   return 0;
+}
+
+extern "C" int dle_dot_interact_bwd(const void* x, const void* upstream, void* grad, void* mlp_grad,
+                                    int batch, int rows, int cols, int dtype, int force_generic,
+                                    hipStream_t stream) {
+  return dle_dot_interact_bwd_checked(x, upstream, grad, mlp_grad, batch, rows, cols, dtype, force_generic, nullptr, stream);
 }

@@ -118,8 +118,8 @@ class DlrmTrainer:
             padded = [i for i in range(len(linears)) if i not in same]
             gp = [grads.views[i][0] for i in padded]
             pp = [linears[i].weight.data for i in padded]
-            return (mt.TensorTable([g, p, c]) if g else None,
-                    mt.TensorTable([gb + gp, pb + pp]), padded)
+            return (mt.TensorTable([g, p, c], mt.streaming_chunk([g])) if g else None,
+                    mt.TensorTable([gb + gp, pb + pp], mt.streaming_chunk([gb + gp])), padded)
         self.t_top_w, self.t_top_b, self.top_padded = split(self.top_linears, self.top_grads, w16)
         if self.bot_grads is not None:
             bw16 = self.model.bottom_model.mlp.working_copies()
@@ -194,8 +194,10 @@ class DlrmTrainer:
         logits = m.top_model(x)
         labels = click[p.batch_start[self.rank]:p.batch_start[self.rank + 1]] if self.world > 1 else click
         loss, dlogits = F.bce_with_logits(logits, labels, grad_scale=sc.scale if sc.enabled else None)
+        # one rank: the interaction backward itself reports inf / nan in the gradient it writes (no sweep over 450 MB)
+        fused_check = sc.enabled and self.world == 1
         grad_x = m.top_model.backward(dlogits.view(-1, 1), grads=self.top_grads.views[:-1],
-                                      out_grads=self.top_grads.views[-1])
+                                      out_grads=self.top_grads.views[-1], found_inf=sc.found_inf if fused_check else None)
         if self.world > 1:
             # data-parallel mean of the top-MLP gradients, overlapped with the bottom backward
             self.comm_stream.wait_stream(torch.cuda.current_stream())
@@ -205,7 +207,8 @@ class DlrmTrainer:
         else:
             grad_bottom = grad_x
         if sc.enabled:
-            F.check_nonfinite_(grad_bottom, sc.found_inf)
+            if not fused_check:
+                F.check_nonfinite_(grad_bottom, sc.found_inf)
             if self.world > 1:
                 # grad_bottom is this rank's slice of a model-parallel gradient: ranks must agree on skipping the step
                 # (torch's GradScaler all-reduces found_inf across the process group in the same way)

@@ -219,9 +219,9 @@ class DotInteraction(nn.Module):
         self._x = bottom_output
         return F.dot_interact_fwd(bottom_output)
 
-    def backward(self, upstream, grad_out=None):
-        """-> grad [B, R, D] with the bottom-MLP slice already folded into row 0."""
-        g, _ = F.dot_interact_bwd(self._x, upstream, fuse_mlp_grad=True, grad_out=grad_out)
+    def backward(self, upstream, grad_out=None, found_inf=None):
+        """-> grad [B, R, D] with the bottom-MLP slice already folded into row 0 (found_inf: see F.dot_interact_bwd)."""
+        g, _ = F.dot_interact_bwd(self._x, upstream, fuse_mlp_grad=True, grad_out=grad_out, found_inf=found_inf)
         return g
 
 
@@ -310,8 +310,9 @@ class DlrmTop(nn.Module):
         return F.gemm(h, w, h.shape[0], w.shape[0], w.shape[1], True, True, out_dtype=self.compute_dtype,
                       bias=self.out.bias.data)
 
-    def backward(self, dlogits, grads=None, out_grads=None, grad_x_out=None):
-        """dlogits [B, 1] 16-bit -> gradient of the interaction input [B, R, D]."""
+    def backward(self, dlogits, grads=None, out_grads=None, grad_x_out=None, found_inf=None):
+        """dlogits [B, 1] 16-bit -> gradient of the interaction input [B, R, D]; found_inf (optional fp32 [1]) is set by the
+        interaction backward when that gradient holds an inf / nan."""
         h, w = self._h, self.out_working_copy()
         m, n, k = h.shape[0], w.shape[0], w.shape[1]
         gw, gb = out_grads if out_grads is not None else (_grad_buf(self.out.weight), _grad_buf(self.out.bias))
@@ -320,7 +321,7 @@ class DlrmTop(nn.Module):
         gh = F.gemm(dlogits, w, m, k, n, True, False, out_dtype=self.compute_dtype, act=C.ACT_RELU_BWD,
                     mask_src=h)
         gz = self.mlp.backward(gh, need_input_grad=True, grads=grads, masked=True)
-        return self.interaction.backward(gz, grad_out=grad_x_out)
+        return self.interaction.backward(gz, grad_out=grad_x_out, found_inf=found_inf)
 
 
 class DistributedDlrm(nn.Module):

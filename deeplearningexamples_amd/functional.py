@@ -28,9 +28,10 @@ def dot_interact_fwd(x, force_generic=False):
     return out
 
 
-def dot_interact_bwd(x, upstream, force_generic=False, fuse_mlp_grad=False, grad_out=None):
+def dot_interact_bwd(x, upstream, force_generic=False, fuse_mlp_grad=False, grad_out=None, found_inf=None):
     """-> (grad [B,R,C], mlp_grad [B,C])  (dotBasedInteractBwd).  fuse_mlp_grad: mlp_grad is added onto
-    grad[:,0,:] in the kernel and None is returned in its place."""
+    grad[:,0,:] in the kernel and None is returned in its place.  found_inf (fp32 [1], optional): set to 1 by the kernel
+    when the gradient it stores holds an inf / nan (GradScaler's check without a pass over the tensor)."""
     C.require_cuda(x, upstream)
     x = x.contiguous()
     b, r, c = x.shape
@@ -41,8 +42,13 @@ def dot_interact_bwd(x, upstream, force_generic=False, fuse_mlp_grad=False, grad
     grad = torch.empty_like(x) if grad_out is None else grad_out
     mlp_grad = None if fuse_mlp_grad else torch.empty((b, c), dtype=x.dtype, device=x.device)
     C.annotate(bytes=float(b) * (2 * r * c + ow + (0 if fuse_mlp_grad else c)) * x.element_size())
-    C.call("dle_dot_interact_bwd", C.ptr(x), C.ptr(upstream), C.ptr(grad), C.ptr(mlp_grad), b, r, c,
-           C.dt(x), int(force_generic), C.stream())
+    if found_inf is not None:
+        C.require_cuda(found_inf)
+        C.call("dle_dot_interact_bwd_checked", C.ptr(x), C.ptr(upstream), C.ptr(grad), C.ptr(mlp_grad), b, r, c,
+               C.dt(x), int(force_generic), C.ptr(found_inf), C.stream())
+    else:
+        C.call("dle_dot_interact_bwd", C.ptr(x), C.ptr(upstream), C.ptr(grad), C.ptr(mlp_grad), b, r, c,
+               C.dt(x), int(force_generic), C.stream())
     return grad, mlp_grad
 
 

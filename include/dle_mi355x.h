@@ -49,6 +49,11 @@ int dle_dot_interact_fwd(const void* x, void* out, int batch, int rows, int cols
 int dle_dot_interact_bwd(const void* x, const void* upstream, void* grad, void* mlp_grad,
                          int batch, int rows, int cols, int dtype, int force_generic,
                          hipStream_t stream);
+/* The same, and *found_inf = 1 when any element of grad as stored is inf / nan (left untouched otherwise): the check
+ * torch's GradScaler.unscale_ makes on this gradient (dlrm/scripts/main.py:585-608 scaler.step), without a pass over it. */
+int dle_dot_interact_bwd_checked(const void* x, const void* upstream, void* grad, void* mlp_grad,
+                                 int batch, int rows, int cols, int dtype, int force_generic,
+                                 float* found_inf, hipStream_t stream);
 
 /* ---- DLRM embeddings --------------------------------------------------------------------------
  * replaces dlrm.cuda_ext.fused_embedding.gather_gpu_fused_fwd / _bwd

@@ -186,3 +186,33 @@ def test_cuda_ext_autograd_functions_match_torch(cuda):
     o2 = emb(idx)
     o2.sum().backward()
     assert emb.weights.grad.is_sparse and o2.shape == (9, 3, 16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_dot_interact_bwd_reports_nonfinite(cuda, dtype, force_generic):
+    """dle_dot_interact_bwd_checked: the flag GradScaler.unscale_ would raise on this gradient, set by the kernel that writes
+    it (MFMA path) or by the plain sweep (generic path); same gradient bits as the unchecked entry point; untouched when finite."""
+    from deeplearningexamples_amd import functional as F
+    g = torch.Generator().manual_seed(3)
+    b, r, c = 37, 27, 128
+    x = (torch.randn(b, r, c, generator=g) * 0.5).to(dtype).to(cuda)
+    up = (torch.randn(b, F.dot_interact_out_width(r, c), generator=g) * 0.1).to(dtype).to(cuda)
+    flag = torch.zeros(1, device=cuda)
+    g0, _ = F.dot_interact_bwd(x, up, force_generic=force_generic, fuse_mlp_grad=True)
+    g1, _ = F.dot_interact_bwd(x, up, force_generic=force_generic, fuse_mlp_grad=True, found_inf=flag)
+    assert torch.equal(g0, g1) and flag.item() == 0.0
+    flag.fill_(0.25)                                            # left untouched (not cleared) when everything is finite
+    F.dot_interact_bwd(x, up, force_generic=force_generic, fuse_mlp_grad=True, found_inf=flag)
+    assert flag.item() == 0.25
+    for bad in (float("inf"), float("nan")):
+        up2 = up.clone()
+        up2[b - 1, c + 5] = bad                                 # one pairwise-product gradient of the LAST sample
+        flag.zero_()
+        g2, _ = F.dot_interact_bwd(x, up2, force_generic=force_generic, fuse_mlp_grad=True, found_inf=flag)
+        assert flag.item() == 1.0 and not bool(torch.isfinite(g2.float()).all())
+    if dtype == torch.float16:                                  # overflow of the 16-bit conversion alone
+        flag.zero_()
+        F.dot_interact_bwd(x * 200, up * 200, force_generic=force_generic, fuse_mlp_grad=True, found_inf=flag)
+        big, _ = F.dot_interact_bwd(x * 200, up * 200, force_generic=force_generic, fuse_mlp_grad=True)
+        assert flag.item() == (0.0 if bool(torch.isfinite(big.float()).all()) else 1.0)
