@@ -109,19 +109,41 @@ __global__ __launch_bounds__(256) void dot_bwd_mfma(const unsigned short* __rest
   const int row = lane & 31, h = lane >> 5;
   const bool act = b < B;
   const int ntril = R * (R - 1) / 2;
+  // Prologue.  Every global load of the sample -- the 2 * NB 16-byte pieces of X per lane and the <= 8 pairwise-gradient
+  // values per lane -- is requested up front from UNCONDITIONAL (clamped) addresses and masked afterwards: written as
+  // "if (row < R) v = load; store to LDS" in a counted loop, hipcc kept one load in flight per lane (load, wait, ds_write)
+  // and the kernel was bound by ~14 dependent memory round trips per sample (2.4 TB/s).
+  const int cpr = C >> 3;                                // 16-byte chunks per row
+  ushort8_t xv[2 * NB];
+  unsigned short tv[8];
   if (act) {
-    // stage X (coalesced 16 B per lane), zero the pad rows R..31, zero U
     const unsigned short* xb = x + (size_t)b * R * C;
-    const int cpr = C >> 3;                              // 16-byte chunks per row
-    for (int q = lane; q < 32 * cpr; q += 64) {
+#pragma unroll
+    for (int it = 0; it < 2 * NB; ++it) {
+      const int q = lane + 64 * it;
       const int rr = q / cpr, cc = q - rr * cpr;
-      ushort8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (rr < R) v = *(const ushort8_t*)(xb + (size_t)rr * C + cc * 8);
-      *(ushort8_t*)(xs + rr * XS + cc * 8) = v;
+      const bool ok = q < 32 * cpr && rr < R;
+      xv[it] = *(const ushort8_t*)(xb + (ok ? (size_t)rr * C + cc * 8 : 0));
+      if (!ok) xv[it] = ushort8_t{0, 0, 0, 0, 0, 0, 0, 0};
     }
+    const unsigned short* ut = ug + (size_t)b * OW + C;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int t = lane + 64 * it;
+      tv[it] = ut[t < ntril ? t : 0];
+    }
+    // zero U, stage X (pad rows R..31 are zeros)
     for (int q = lane; q < 32 * DOT_BWD_USTRIDE / 8; q += 64) {
       ushort8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
       *(ushort8_t*)(us + q * 8) = z;
+    }
+#pragma unroll
+    for (int it = 0; it < 2 * NB; ++it) {
+      const int q = lane + 64 * it;
+      if (q < 32 * cpr) {
+        const int rr = q / cpr, cc = q - rr * cpr;
+        *(ushort8_t*)(xs + rr * XS + cc * 8) = xv[it];
+      }
     }
     // bottom-MLP gradient = first C entries of the upstream gradient
     const unsigned short* ub = ug + (size_t)b * OW;
@@ -132,13 +154,15 @@ __global__ __launch_bounds__(256) void dot_bwd_mfma(const unsigned short* __rest
   }
   __syncthreads();
   if (act) {
-    const unsigned short* ub = ug + (size_t)b * OW + C;
-    for (int t = lane; t < ntril; t += 64) {
-      int i, j;
-      tril_unrank(t, i, j);
-      const unsigned short v = ub[t];
-      us[i * DOT_BWD_USTRIDE + j] = v;
-      us[j * DOT_BWD_USTRIDE + i] = v;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int t = lane + 64 * it;
+      if (t < ntril) {
+        int i, j;
+        tril_unrank(t, i, j);
+        us[i * DOT_BWD_USTRIDE + j] = tv[it];
+        us[j * DOT_BWD_USTRIDE + i] = tv[it];
+      }
     }
   }
   __syncthreads();

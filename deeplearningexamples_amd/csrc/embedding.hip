@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void emb_sgd_small(float* __restrict__ weight,
 // 16 wavefronts per workgroup; tables with more than 32 / 64 rows split their rows over 2 / 4 wavefront groups, each
 // wavefront scans 64 row ids at a time (one per lane), ballots the samples whose row it owns and requests only those
 // gradient rows, DLE_EMB_TINY_U at a time -- every load in flight is a useful one.  The 16 register images meet in LDS once
-// per workgroup; one fp32 atomic per (slice, row, dim) reaches the table (32 slices: 1.4 M adds for the eight tiny tables of
+// per workgroup (plain read-modify-writes in turns, see below); one fp32 atomic per (slice, row, dim) reaches the table (32 slices: 1.4 M adds for the eight tiny tables of
 // criteo_f15, where the LDS form issued 67 M ds_add_f32 on a handful of rows and 5.4 M global adds: 341 us per step).
 #define DLE_EMB_TINY_U 16
 template <int IDT> struct In2;
@@ -398,7 +398,10 @@ __global__ __launch_bounds__(1024) void emb_sgd_tiny(float* __restrict__ weight,
   f32x32_t acc0 = 0.f, acc1 = 0.f;                                 // [row of this wavefront's group]: even / odd dim of the lane
   const long long half_stride = g_bstride >> 1;                    // gradient row stride in element pairs
   const long long toff = ((long long)t * D) >> 1;
-  // the row ids of the NEXT chunk are requested before this chunk's gradient rows (one dependent round trip less per chunk)
+  // The row ids of the NEXT chunk are requested together with this chunk's first gradient rows.  The explicit vmcnt(0) at the
+  // head of every batch costs nothing (the previous batch has been consumed) and is there for the COMPILER: without it hipcc
+  // assumes a load of an earlier batch may still target gv[u] (a batch can end early) and puts s_waitcnt vmcnt(0) in front of
+  // EVERY load of the batch -- one gradient row in flight per wavefront (221 us for the eight tiny tables).
   long long rid_next = -1;
   {
     const long long bl = b0 + (long long)phase * 64 + lane;
@@ -406,16 +409,18 @@ __global__ __launch_bounds__(1024) void emb_sgd_tiny(float* __restrict__ weight,
   }
   for (long long bb = b0 + (long long)phase * 64; bb < b1; bb += (long long)nphase * 64) {
     const long long rid_raw = rid_next;
+    int rid = -1;
+    if (bb + lane < b1) rid = (int)(rid_raw - base) - r0;
+    unsigned long long mask = __ballot(rid >= 0 && rid < nrw);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     {
       const long long bl = bb + (long long)nphase * 64 + lane;
       rid_next = -1;
       if (bl < b1) rid_next = rows[bl * T + t];
     }
-    int rid = -1;
-    if (bb + lane < b1) rid = (int)(rid_raw - base) - r0;
-    unsigned long long mask = __ballot(rid >= 0 && rid < nrw);
     while (mask) {
       int ri[DLE_EMB_TINY_U];
+      __builtin_amdgcn_s_waitcnt(0x0F70);      // (see above; rid_next may be waited for here: it was issued a batch ago)
       V2 gv[DLE_EMB_TINY_U];
 #pragma unroll
       for (int u = 0; u < DLE_EMB_TINY_U; ++u) {
@@ -443,14 +448,22 @@ __global__ __launch_bounds__(1024) void emb_sgd_tiny(float* __restrict__ weight,
       }
     }
   }
-  __syncthreads();                                                 // sum[] is zeroed
-  if (active) {
+  // The 16 register images meet in LDS WITHOUT float atomics: ds_add_f32 retires about one lane per clock per CU on this part
+  // (PMC: 336 stall cycles per LDS instruction; the 65 K lane-adds of this merge were ~85 % of the kernel's 190 us, and the 67 M
+  // of the LDS form its 341 us).  Wavefronts that share rows take turns: in turn `ph` the wavefronts of sample phase ph -- one
+  // per row group, disjoint rows -- add their pairs with a plain 8-byte read-modify-write.
+  for (int ph = 0; ph < nphase; ++ph) {
+    __syncthreads();                                               // sum[] is zeroed / the previous turn is done
+    if (phase == ph && active) {
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
-      const int r = r0 + c;
-      if (c < nrw && r < nrows) {
-        if (acc0[c] != 0.f) atomicAdd(sum + r * D + 2 * lane, acc0[c]);            // ds_add_f32, once per workgroup
-        if (acc1[c] != 0.f) atomicAdd(sum + r * D + 2 * lane + 1, acc1[c]);
+      for (int c = 0; c < 32; ++c) {
+        const int r = r0 + c;
+        if (c < nrw && r < nrows) {
+          float2_t* dst = (float2_t*)(sum + r * D + 2 * lane);
+          float2_t v = *dst;
+          v[0] += acc0[c]; v[1] += acc1[c];
+          *dst = v;
+        }
       }
     }
   }

@@ -145,7 +145,9 @@ extern "C" int dle_dropout_add_layernorm_fwd(const void* x, const void* residual
 // DROP: the LayerNorm input was dense(x) -> dropout -> + residual (modeling.py:394-398, 430-434): the kernel also writes
 // dzd = dz * keep / (1 - p), the gradient of the dense output (the separate dropout-backward pass is gone), and a third
 // column sum, sum_rows dzd = the dense layer's bias gradient (the separate column-sum pass is gone).
-template <int DT, int CH, bool DROP>
+// FULL: H == CH * 512, every chunk of every lane is inside the row -- no conditional stores, so the compiler can COUNT the
+// stores issued after the prefetch and wait for the prefetched row alone (vmcnt(n), not vmcnt(0)).
+template <int DT, int CH, bool DROP, bool FULL = false>
 __global__ __launch_bounds__(512) void ln_bwd_kernel(const unsigned short* __restrict__ dy,
                                                      const unsigned short* __restrict__ z,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -164,59 +166,161 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const unsigned short* __res
   for (int i = 0; i < CH; ++i)
 #pragma unroll
     for (int k = 0; k < 8; ++k) { ag[i][k] = 0.f; ab[i][k] = 0.f; if (DROP) ad[i][k] = 0.f; }
-  for (long long r = wave; r < rows; r += nwaves) {
-    const float mu = mean[r], rs = rstd[r];
-    float g[CH][8], xh[CH][8];
-    unsigned kb[CH];                  // keep bits, requested WITH the row's other loads: fetched after the row reductions
-                                      // they exposed a second memory latency per row (the fused pass ran at 3.2 TB/s)
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
+  if constexpr (CH <= 2) {
+    // Every load of a row is issued UNCONDITIONALLY (out-of-range chunks / the row past the end read a clamped, valid address and
+    // are masked where they are used) and one row AHEAD of its use: with the loads inside `if (c < nch)` blocks hipcc issued
+    // chunk i + 1's loads only after chunk i had been reduced, and the first wait of a row also waited for the previous row's
+    // stores to be acknowledged (vmcnt retires in order) -- two to three exposed memory round trips per 4 KB row, 3.2 TB/s.
+    constexpr bool HOIST = CH <= 2;                 // gamma in registers for the whole sweep (16 VGPRs at H = 1024)
+    int cc[CH];
+    bool valid[CH];
+  #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = lane + i * 64;
-      kb[i] = 0;
-      if (DROP && c < nch) kb[i] = keep[r * nch + c];
-      if (c < nch) {
-        float df[8], zf[8];
-        unpack8<DT>(*(const ushort8_t*)(dy + r * H + c * 8), df);
-        unpack8<DT>(*(const ushort8_t*)(z + r * H + c * 8), zf);
-        const float4_t g0 = *(const float4_t*)(gamma + c * 8), g1 = *(const float4_t*)(gamma + c * 8 + 4);
-#pragma unroll
+      valid[i] = FULL || c < nch;
+      cc[i] = valid[i] ? c : nch - 1;
+    }
+    float gmh[HOIST ? CH : 1][8];
+    if (HOIST) {
+  #pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const float4_t g0 = *(const float4_t*)(gamma + cc[i] * 8), g1 = *(const float4_t*)(gamma + cc[i] * 8 + 4);
+  #pragma unroll
+        for (int k = 0; k < 4; ++k) { gmh[HOIST ? i : 0][k] = g0[k]; gmh[HOIST ? i : 0][4 + k] = g1[k]; }
+      }
+    }
+    ushort8_t dyv[CH], zv[CH], dyn[CH], zn[CH];
+    unsigned kb[CH], kbn[CH];
+    float mu, rs, mun, rsn;
+    auto load_row = [&](long long r, ushort8_t (&a)[CH], ushort8_t (&b)[CH], unsigned (&kk)[CH], float& m_, float& r_)
+        __attribute__((always_inline)) {
+      const long long rr = r < rows ? r : rows - 1;
+      m_ = mean[rr]; r_ = rstd[rr];
+  #pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        a[i] = *(const ushort8_t*)(dy + rr * H + cc[i] * 8);
+        b[i] = *(const ushort8_t*)(z + rr * H + cc[i] * 8);
+        kk[i] = DROP ? (unsigned)keep[rr * nch + cc[i]] : 0u;
+      }
+    };
+    if (wave < rows) load_row(wave, dyv, zv, kb, mu, rs);
+    for (long long r = wave; r < rows; r += nwaves) {
+      load_row(r + nwaves, dyn, zn, kbn, mun, rsn);          // the next row of this wave (clamped at the end of the sweep)
+      __builtin_amdgcn_sched_barrier(0);                     // (the loads stay AHEAD of this row's stores: in-order vmcnt)
+      float g[CH][8], xh[CH][8];
+      float s1 = 0.f, s2 = 0.f;
+  #pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        float df[8], zf[8], gm[8];
+        unpack8<DT>(dyv[i], df);
+        unpack8<DT>(zv[i], zf);
+        if (HOIST) {
+  #pragma unroll
+          for (int k = 0; k < 8; ++k) gm[k] = gmh[HOIST ? i : 0][k];
+        } else {
+          const float4_t g0 = *(const float4_t*)(gamma + cc[i] * 8), g1 = *(const float4_t*)(gamma + cc[i] * 8 + 4);
+  #pragma unroll
+          for (int k = 0; k < 4; ++k) { gm[k] = g0[k]; gm[4 + k] = g1[k]; }
+        }
+        const float vm = valid[i] ? 1.f : 0.f;
+  #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const float d = df[k];
+          const float d = df[k] * vm;
           const float xx = (zf[k] - mu) * rs;
-          const float gm = k < 4 ? g0[k & 3] : g1[k & 3];
           ab[i][k] += d;
           ag[i][k] += d * xx;
-          g[i][k] = d * gm;
+          g[i][k] = d * gm[k];
           xh[i][k] = xx;
           s1 += g[i][k];
           s2 += g[i][k] * xx;
         }
       }
+      s1 = wave_sum(s1) / (float)H;
+      s2 = wave_sum(s2) / (float)H;
+  #pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        if (valid[i]) {
+          const int c = lane + i * 64;
+          float of[8];
+  #pragma unroll
+          for (int k = 0; k < 8; ++k) of[k] = rs * (g[i][k] - s1 - xh[i][k] * s2);
+          const ushort8_t ov = pack8<DT>(of);
+          *(ushort8_t*)(dz + r * H + c * 8) = ov;
+          if (DROP) {
+            // what dle_dropout_bwd computed from the ROUNDED dz: dz16 * keep / (1 - p), rounded; its column sum = bias gradient
+            const unsigned bits = kb[i];
+            float rf[8], df[8];
+            unpack8<DT>(ov, rf);
+  #pragma unroll
+            for (int k = 0; k < 8; ++k) df[k] = ((bits >> k) & 1u) ? rf[k] * inv_keep : 0.f;
+            const ushort8_t dv = pack8<DT>(df);
+            *(ushort8_t*)(dzd + r * H + c * 8) = dv;
+            unpack8<DT>(dv, df);
+  #pragma unroll
+            for (int k = 0; k < 8; ++k) ad[i][k] += df[k];
+          }
+        }
+      }
+      mu = mun; rs = rsn;
+  #pragma unroll
+      for (int i = 0; i < CH; ++i) { dyv[i] = dyn[i]; zv[i] = zn[i]; kb[i] = kbn[i]; }
     }
-    s1 = wave_sum(s1) / (float)H;
-    s2 = wave_sum(s2) / (float)H;
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int c = lane + i * 64;
-      if (c < nch) {
-        float of[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) of[k] = rs * (g[i][k] - s1 - xh[i][k] * s2);
-        const ushort8_t ov = pack8<DT>(of);
-        *(ushort8_t*)(dz + r * H + c * 8) = ov;
-        if (DROP) {
-          // what dle_dropout_bwd computed from the ROUNDED dz: dz16 * keep / (1 - p), rounded; its column sum = bias gradient
-          const unsigned bits = kb[i];
-          float rf[8], df[8];
-          unpack8<DT>(ov, rf);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) df[k] = ((bits >> k) & 1u) ? rf[k] * inv_keep : 0.f;
-          const ushort8_t dv = pack8<DT>(df);
-          *(ushort8_t*)(dzd + r * H + c * 8) = dv;
-          unpack8<DT>(dv, df);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) ad[i][k] += df[k];
+  } else {
+  // wide rows (H > 1024): one row at a time (the prefetched form needs 2 x CH x 9 more registers and spills)
+    for (long long r = wave; r < rows; r += nwaves) {
+      const float mu = mean[r], rs = rstd[r];
+      float g[CH][8], xh[CH][8];
+      unsigned kb[CH];                  // keep bits, requested WITH the row's other loads: fetched after the row reductions
+                                        // they exposed a second memory latency per row (the fused pass ran at 3.2 TB/s)
+      float s1 = 0.f, s2 = 0.f;
+  #pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int c = lane + i * 64;
+        kb[i] = 0;
+        if (DROP && c < nch) kb[i] = keep[r * nch + c];
+        if (c < nch) {
+          float df[8], zf[8];
+          unpack8<DT>(*(const ushort8_t*)(dy + r * H + c * 8), df);
+          unpack8<DT>(*(const ushort8_t*)(z + r * H + c * 8), zf);
+          const float4_t g0 = *(const float4_t*)(gamma + c * 8), g1 = *(const float4_t*)(gamma + c * 8 + 4);
+  #pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float d = df[k];
+            const float xx = (zf[k] - mu) * rs;
+            const float gm = k < 4 ? g0[k & 3] : g1[k & 3];
+            ab[i][k] += d;
+            ag[i][k] += d * xx;
+            g[i][k] = d * gm;
+            xh[i][k] = xx;
+            s1 += g[i][k];
+            s2 += g[i][k] * xx;
+          }
+        }
+      }
+      s1 = wave_sum(s1) / (float)H;
+      s2 = wave_sum(s2) / (float)H;
+  #pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+          float of[8];
+  #pragma unroll
+          for (int k = 0; k < 8; ++k) of[k] = rs * (g[i][k] - s1 - xh[i][k] * s2);
+          const ushort8_t ov = pack8<DT>(of);
+          *(ushort8_t*)(dz + r * H + c * 8) = ov;
+          if (DROP) {
+            // what dle_dropout_bwd computed from the ROUNDED dz: dz16 * keep / (1 - p), rounded; its column sum = bias gradient
+            const unsigned bits = kb[i];
+            float rf[8], df[8];
+            unpack8<DT>(ov, rf);
+  #pragma unroll
+            for (int k = 0; k < 8; ++k) df[k] = ((bits >> k) & 1u) ? rf[k] * inv_keep : 0.f;
+            const ushort8_t dv = pack8<DT>(df);
+            *(ushort8_t*)(dzd + r * H + c * 8) = dv;
+            unpack8<DT>(dv, df);
+  #pragma unroll
+            for (int k = 0; k < 8; ++k) ad[i][k] += df[k];
+          }
         }
       }
     }
@@ -313,8 +417,9 @@ static int ln_bwd_launch(const void* dy, const void* z, const float* mean, const
   const size_t lds = (size_t)nwv * H * 4;
   const int ch = (H / 8 + 63) / 64;
   const DropArgs d = make_drop(nullptr, p, 0, 0);
-#define GO(DT, CH, DR) hipLaunchKernelGGL((ln_bwd_kernel<DT, CH, DR>), dim3(blocks), dim3(64 * nwv), lds, stream, (const unsigned short*)dy, (const unsigned short*)z, mean, rstd, gamma, (unsigned short*)dz, (float*)workspace, (long long)rows, H, (const unsigned char*)keep, d.inv_keep, (unsigned short*)dzd)
-#define PICK(DT, DR) do { if (ch <= 1) GO(DT, 1, DR); else if (ch <= 2) GO(DT, 2, DR); else if (ch <= 4) GO(DT, 4, DR); else GO(DT, 8, DR); } while (0)
+#define GO(DT, CH, DR, FL) hipLaunchKernelGGL((ln_bwd_kernel<DT, CH, DR, FL>), dim3(blocks), dim3(64 * nwv), lds, stream, (const unsigned short*)dy, (const unsigned short*)z, mean, rstd, gamma, (unsigned short*)dz, (float*)workspace, (long long)rows, H, (const unsigned char*)keep, d.inv_keep, (unsigned short*)dzd)
+#define PICK(DT, DR) do { if (H == 1024) GO(DT, 2, DR, true); else if (H == 512) GO(DT, 1, DR, true); else if (ch <= 1) GO(DT, 1, DR, false); \
+    else if (ch <= 2) GO(DT, 2, DR, false); else if (ch <= 4) GO(DT, 4, DR, false); else GO(DT, 8, DR, false); } while (0)
   if (drop) { if (dtype == DLE_F16) PICK(DLE_F16, true); else PICK(DLE_BF16, true); }
   else { if (dtype == DLE_F16) PICK(DLE_F16, false); else PICK(DLE_BF16, false); }
 #undef GO
