@@ -432,17 +432,14 @@ __global__ __launch_bounds__(1024) void emb_sgd_tiny(float* __restrict__ weight,
           if (active) gv[u] = grad[(bb + sidx) * half_stride + toff + lane];
         }
       }
-      // (not unrolled: one indexed read-modify-write site; the loaded pair of trip u is picked by a uniform select)
-#pragma nounroll
-      for (int u = 0; u < DLE_EMB_TINY_U; ++u) {
-        int r = ri[0];
-        V2 g = gv[0];
+      // (unrolled: with register-indexed accumulators a copy is ~15 instructions; a uniform select of (ri[u], gv[u]) by a
+      //  run-time u cost 15 compares + selects per sample -- 90 scalar instructions per sample in the PMC counts)
 #pragma unroll
-        for (int q = 1; q < DLE_EMB_TINY_U; ++q)
-          if (u == q) { r = ri[q]; g = gv[q]; }
+      for (int u = 0; u < DLE_EMB_TINY_U; ++u) {
+        const int r = ri[u];
         if (r < 0) break;
         float g0 = 0.f, g1 = 0.f;
-        if (active) In2<IDT>::up(g, g0, g1);
+        if (active) In2<IDT>::up(gv[u], g0, g1);
         acc0[r] += g0;                     // r is wave-uniform (v_readlane): register-indexed, no LDS, no branch
         acc1[r] += g1;
       }
