@@ -114,7 +114,11 @@ struct BnRedArgs {
   int lpr;                      // lanes per row = pow2 >= C/8 (<= 256)
 };
 
-template <int DT, int MODE, int UU = 0>
+// MM (MODE 1): 0 = no ReLU mask, 1 = bit mask (a.mask), 2 = saved output (a.y), -1 = decided at run time (legacy form).
+// With the mask kind a run-time pointer test, the loads of the U rows sat in conditional blocks and hipcc put s_waitcnt
+// vmcnt(0) between them (a possibly-pending load into the same registers on another path): ONE row in flight per lane.
+// The compile-time forms issue all loads of a batch back to back and request the next batch before reducing the current.
+template <int DT, int MODE, int UU = 0, int MM = -1>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(BnRedArgs a) {
   __shared__ float red[2][256 * 8];
   const int cl = threadIdx.x % a.lpr, rl = threadIdx.x / a.lpr, rstep = 256 / a.lpr;
@@ -151,6 +155,50 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(BnRedArgs a) {
     };
     constexpr int U = UU ? UU : (MODE == 0 ? 8 : 4);   // rows in flight per lane (U x 1..3 independent 16-byte loads)
     long long r = r0 + rl;
+    if constexpr (MODE == 1 && MM >= 0) {
+      auto load_batch = [&](long long rb, ushort8_t (&xv)[U], ushort8_t (&gv)[U], ushort8_t (&yv)[U], unsigned (&mb)[U])
+          __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long long o = (rb + (long long)u * rstep) * a.C + c0;
+          xv[u] = *(const ushort8_t*)(a.x + o);
+          gv[u] = *(const ushort8_t*)(a.dy + o);
+          mb[u] = 0;
+          if constexpr (MM == 1) mb[u] = a.mask[o >> 3];
+          if constexpr (MM == 2) yv[u] = *(const ushort8_t*)(a.y + o);
+        }
+      };
+      auto accum_mm = [&](ushort8_t xv, ushort8_t gv, ushort8_t yv, unsigned bits) __attribute__((always_inline)) {
+        float xf[8], gf[8], yf[8];
+        unpack8<DT>(xv, xf);
+        unpack8<DT>(gv, gf);
+        if constexpr (MM == 2) unpack8<DT>(yv, yf);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float g = gf[k];
+          if constexpr (MM == 1) { if (!((bits >> k) & 1u)) g = 0.f; }
+          if constexpr (MM == 2) { if (!(yf[k] > 0.f)) g = 0.f; }
+          s0[k] += g;
+          s1[k] += g * (xf[k] - mu[k]) * rs[k];
+        }
+      };
+      const long long bstep = (long long)U * rstep;
+      if (r + (long long)(U - 1) * rstep < r1) {
+        ushort8_t xv[U], gv[U], yv[U], xn[U], gn[U], yn[U];
+        unsigned mb[U], mn[U];
+        load_batch(r, xv, gv, yv, mb);
+        for (; r + bstep + (long long)(U - 1) * rstep < r1; r += bstep) {
+          load_batch(r + bstep, xn, gn, yn, mn);
+#pragma unroll
+          for (int u = 0; u < U; ++u) accum_mm(xv[u], gv[u], yv[u], mb[u]);
+#pragma unroll
+          for (int u = 0; u < U; ++u) { xv[u] = xn[u]; gv[u] = gn[u]; yv[u] = yn[u]; mb[u] = mn[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) accum_mm(xv[u], gv[u], yv[u], mb[u]);
+        r += bstep;
+      }
+    } else {
     for (; r + (long long)(U - 1) * rstep < r1; r += (long long)U * rstep) {
       ushort8_t xv[U], gv[U], yv[U];
       unsigned mb[U];
@@ -167,6 +215,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(BnRedArgs a) {
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) accum(xv[u], gv[u], yv[u], mb[u]);
+    }
     }
     for (; r < r1; r += rstep) {
       const long long o = r * a.C + c0;
@@ -320,6 +369,7 @@ extern "C" int dle_bn_stats_from_partials(const float* partial, int groups, int6
   return 0;
 }
 
+static const int g_bn_pf = getenv("DLE_BN_PF") ? atoi(getenv("DLE_BN_PF")) : 1;   // prefetched / compile-time-mode streaming kernels
 static int g_bn_want_blocks = 1024;    // ~4 workgroups per CU
 static int g_bn_bwd_u = 2;             // rows in flight per lane of the backward reduction (2 / 4 / 8); measured on the
                                        // batch-256 ResNet-50 shapes (tools/kbench/bn_bench): 2 -> 2.5 ms / step, 4 -> 3.1, 8 -> 5.5
@@ -446,6 +496,63 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
   }
 }
 
+// The same pass with the NEXT trip's loads requested before the current trip's stores (vmcnt retires in order: a load issued
+// after a store cannot be consumed before that store is acknowledged), the residual / mask choices compile-time (no loads
+// inside run-time conditionals) and the grid stride a multiple of C/8 (the launcher checks it).
+template <int DT, bool HAS_RES, int ACT>      // ACT: 0 = none, 1 = ReLU, 2 = ReLU + bit mask
+__global__ __launch_bounds__(256) void bn_apply_pf_kernel(const unsigned short* __restrict__ x,
+                                                          const unsigned short* __restrict__ res,
+                                                          unsigned short* __restrict__ y, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, long long total8, int C8,
+                                                          unsigned char* __restrict__ mask_out) {
+  const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  if (first >= total8) return;
+  float sc[8], sh[8];
+  const int c0 = (int)(first % C8) * 8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sc[k] = rstd[c0 + k] * gamma[c0 + k]; sh[k] = beta[c0 + k] - mean[c0 + k] * sc[k]; }
+  auto one = [&](long long i, ushort8_t xv, ushort8_t rv) __attribute__((always_inline)) {
+    float xf[8], rf[8], of[8];
+    unpack8<DT>(xv, xf);
+    if constexpr (HAS_RES) unpack8<DT>(rv, rf);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float v = xf[k] * sc[k] + sh[k];
+      if constexpr (HAS_RES) v += rf[k];
+      if constexpr (ACT >= 1) v = v > 0.f ? v : 0.f;
+      of[k] = v;
+    }
+    ((ushort8_t*)y)[i] = pack8<DT>(of);
+    if constexpr (ACT == 2) {
+      unsigned bits = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) bits |= (of[k] > 0.f ? 1u : 0u) << k;
+      mask_out[i] = (unsigned char)bits;
+    }
+  };
+  long long i = first;
+  ushort8_t xc = ((const ushort8_t*)x)[i], rc = {};
+  if constexpr (HAS_RES) rc = ((const ushort8_t*)res)[i];
+  // (first trip peeled: at the head of the loop the pending queue then has the same shape on both incoming edges -- next
+  //  trip's loads, then this trip's stores -- and the compiler can wait with vmcnt(#stores) instead of vmcnt(0))
+  auto trip = [&]() __attribute__((always_inline)) {
+    const ushort8_t xn = ((const ushort8_t*)x)[i + stride];
+    ushort8_t rn = {};
+    if constexpr (HAS_RES) rn = ((const ushort8_t*)res)[i + stride];
+    __builtin_amdgcn_sched_barrier(0);
+    one(i, xc, rc);
+    xc = xn; rc = rn;
+    i += stride;
+  };
+  if (i + stride < total8) {
+    trip();
+    while (i + stride < total8) trip();
+  }
+  one(i, xc, rc);
+}
+
 extern "C" int dle_bn_fwd_apply(const void* x, const void* residual, void* y, void* relu_mask, const float* mean, const float* rstd,
                                 const float* gamma, const float* beta, int64_t M, int C, int relu, int dtype,
                                 hipStream_t stream) {
@@ -457,7 +564,18 @@ extern "C" int dle_bn_fwd_apply(const void* x, const void* residual, void* y, vo
   const int grid = cn_grid(total8, 256, g_bn_apply_cap);
 #define BN_APP(DT, TR) hipLaunchKernelGGL((bn_apply_kernel<DT, TR>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)residual, (unsigned short*)y, mean, rstd, gamma, beta, total8, C / 8, relu, (unsigned char*)relu_mask)
 #define BN_APP_T(DT) do { if (g_bn_apply_trips == 1) BN_APP(DT, 1); else if (g_bn_apply_trips == 2) BN_APP(DT, 2); else BN_APP(DT, 4); } while (0)
-  if (dtype == DLE_F16) BN_APP_T(DLE_F16); else BN_APP_T(DLE_BF16);
+  if (g_bn_pf && ((long long)grid * 256) % (C / 8) == 0) {
+    const int act = !relu ? 0 : (relu_mask ? 2 : 1);
+#define BN_PF(DT, HR, ACT) hipLaunchKernelGGL((bn_apply_pf_kernel<DT, HR, ACT>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)residual, (unsigned short*)y, mean, rstd, gamma, beta, total8, C / 8, (unsigned char*)relu_mask)
+#define BN_PF_A(DT, HR) do { if (act == 0) BN_PF(DT, HR, 0); else if (act == 1) BN_PF(DT, HR, 1); else BN_PF(DT, HR, 2); } while (0)
+#define BN_PF_R(DT) do { if (residual) BN_PF_A(DT, true); else BN_PF_A(DT, false); } while (0)
+    if (dtype == DLE_F16) BN_PF_R(DLE_F16); else BN_PF_R(DLE_BF16);
+#undef BN_PF
+#undef BN_PF_A
+#undef BN_PF_R
+  } else {
+    if (dtype == DLE_F16) BN_APP_T(DLE_F16); else BN_APP_T(DLE_BF16);
+  }
 #undef BN_APP
 #undef BN_APP_T
   DLE_LAUNCH_CHECK();
@@ -477,7 +595,11 @@ extern "C" int dle_bn_bwd_reduce(const void* dy, const void* y, const void* relu
   BnRedArgs a = {(const unsigned short*)x, (const unsigned short*)dy, (const unsigned short*)y,
                  (const unsigned char*)relu_mask, mean, rstd, (float*)workspace, (long long)M, C, rpb, lpr};
   dim3 grid(gx, (unsigned)gy), block(256);
-#define BN_RED(DT) do { if (g_bn_bwd_u == 2) hipLaunchKernelGGL((bn_reduce_kernel<DT, 1, 2>), grid, block, 0, stream, a); \
+  const int mm = g_bn_pf ? (relu_mask ? 1 : (y ? 2 : 0)) : -1;
+#define BN_RED(DT) do { if (mm == 1) hipLaunchKernelGGL((bn_reduce_kernel<DT, 1, 2, 1>), grid, block, 0, stream, a); \
+    else if (mm == 0) hipLaunchKernelGGL((bn_reduce_kernel<DT, 1, 2, 0>), grid, block, 0, stream, a); \
+    else if (mm == 2) hipLaunchKernelGGL((bn_reduce_kernel<DT, 1, 2, 2>), grid, block, 0, stream, a); \
+    else if (g_bn_bwd_u == 2) hipLaunchKernelGGL((bn_reduce_kernel<DT, 1, 2>), grid, block, 0, stream, a); \
     else if (g_bn_bwd_u == 8) hipLaunchKernelGGL((bn_reduce_kernel<DT, 1, 8>), grid, block, 0, stream, a); \
     else hipLaunchKernelGGL((bn_reduce_kernel<DT, 1, 4>), grid, block, 0, stream, a); } while (0)
   if (dtype == DLE_F16) BN_RED(DLE_F16); else BN_RED(DLE_BF16);
@@ -560,6 +682,71 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
   }
 }
 
+// Prefetched form of the pass above (see bn_apply_pf_kernel): MM = 0 no ReLU mask, 1 bit mask, 2 saved output.
+template <int DT, int MM, bool HAS_GOUT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pf_kernel(const unsigned short* __restrict__ dy,
+                                                              const unsigned short* __restrict__ y,
+                                                              const unsigned char* __restrict__ mask,
+                                                              const unsigned short* __restrict__ x,
+                                                              unsigned short* __restrict__ dx,
+                                                              unsigned short* __restrict__ g_out,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                                              const float* __restrict__ dbeta, long long total8, int C8,
+                                                              float inv_m) {
+  const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  if (first >= total8) return;
+  float ka[8], kmu[8], krs[8], kb[8], kg[8];
+  const int c0 = (int)(first % C8) * 8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    krs[k] = rstd[c0 + k];
+    kmu[k] = mean[c0 + k];
+    ka[k] = gamma[c0 + k] * krs[k];
+    kb[k] = dbeta[c0 + k] * inv_m;
+    kg[k] = dgamma[c0 + k] * inv_m;
+  }
+  auto one = [&](long long i, ushort8_t gv, ushort8_t xv, ushort8_t yv, unsigned bits) __attribute__((always_inline)) {
+    float gf[8], xf[8], yf[8], of[8];
+    unpack8<DT>(gv, gf);
+    unpack8<DT>(xv, xf);
+    if constexpr (MM == 2) unpack8<DT>(yv, yf);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if constexpr (MM == 1) { if (!((bits >> k) & 1u)) gf[k] = 0.f; }
+      if constexpr (MM == 2) { if (!(yf[k] > 0.f)) gf[k] = 0.f; }
+      const float xh = (xf[k] - kmu[k]) * krs[k];
+      of[k] = ka[k] * (gf[k] - kb[k] - xh * kg[k]);
+    }
+    ((ushort8_t*)dx)[i] = pack8<DT>(of);
+    if constexpr (HAS_GOUT) ((ushort8_t*)g_out)[i] = pack8<DT>(gf);
+  };
+  auto load = [&](long long i, ushort8_t& gv, ushort8_t& xv, ushort8_t& yv, unsigned& mb) __attribute__((always_inline)) {
+    gv = ((const ushort8_t*)dy)[i];
+    xv = ((const ushort8_t*)x)[i];
+    mb = 0;
+    if constexpr (MM == 1) mb = mask[i];
+    if constexpr (MM == 2) yv = ((const ushort8_t*)y)[i];
+  };
+  long long i = first;
+  ushort8_t gc, xc, yc = {}, gn, xn, yn = {};
+  unsigned mc, mn;
+  load(i, gc, xc, yc, mc);
+  auto trip = [&]() __attribute__((always_inline)) {      // (first trip peeled, see bn_apply_pf_kernel)
+    load(i + stride, gn, xn, yn, mn);
+    __builtin_amdgcn_sched_barrier(0);
+    one(i, gc, xc, yc, mc);
+    gc = gn; xc = xn; yc = yn; mc = mn;
+    i += stride;
+  };
+  if (i + stride < total8) {
+    trip();
+    while (i + stride < total8) trip();
+  }
+  one(i, gc, xc, yc, mc);
+}
+
 extern "C" int dle_bn_bwd_apply(const void* dy, const void* y, const void* relu_mask, const void* x, void* dx, void* g_out, const float* mean,
                                 const float* rstd, const float* gamma, const float* dgamma, const float* dbeta,
                                 int64_t M, int C, int dtype, hipStream_t stream) {
@@ -570,7 +757,18 @@ extern "C" int dle_bn_bwd_apply(const void* dy, const void* y, const void* relu_
   const int grid = cn_grid(total8, 256, g_bn_apply_cap);
 #define BN_BAPP(DT, TR) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, TR>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned short*)y, (const unsigned char*)relu_mask, (const unsigned short*)x, (unsigned short*)dx, (unsigned short*)g_out, mean, rstd, gamma, dgamma, dbeta, total8, C / 8, 1.0f / (float)M)
 #define BN_BAPP_T(DT) do { if (g_bn_apply_trips == 1) BN_BAPP(DT, 1); else if (g_bn_apply_trips == 2) BN_BAPP(DT, 2); else BN_BAPP(DT, 3); } while (0)
-  if (dtype == DLE_F16) BN_BAPP_T(DLE_F16); else BN_BAPP_T(DLE_BF16);
+  if (g_bn_pf && ((long long)grid * 256) % (C / 8) == 0) {
+    const int mm = relu_mask ? 1 : (y ? 2 : 0);
+#define BN_PF(DT, MMV, GO) hipLaunchKernelGGL((bn_bwd_apply_pf_kernel<DT, MMV, GO>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned short*)y, (const unsigned char*)relu_mask, (const unsigned short*)x, (unsigned short*)dx, (unsigned short*)g_out, mean, rstd, gamma, dgamma, dbeta, total8, C / 8, 1.0f / (float)M)
+#define BN_PF_M(DT, GO) do { if (mm == 0) BN_PF(DT, 0, GO); else if (mm == 1) BN_PF(DT, 1, GO); else BN_PF(DT, 2, GO); } while (0)
+#define BN_PF_G(DT) do { if (g_out) BN_PF_M(DT, true); else BN_PF_M(DT, false); } while (0)
+    if (dtype == DLE_F16) BN_PF_G(DLE_F16); else BN_PF_G(DLE_BF16);
+#undef BN_PF
+#undef BN_PF_M
+#undef BN_PF_G
+  } else {
+    if (dtype == DLE_F16) BN_BAPP_T(DLE_F16); else BN_BAPP_T(DLE_BF16);
+  }
 #undef BN_BAPP
 #undef BN_BAPP_T
   DLE_LAUNCH_CHECK();
