@@ -44,7 +44,7 @@ class BertTrainer:
                  max_grad_norm=1.0, compute_dtype=torch.bfloat16, init_loss_scale=2.0 ** 20, world_size=1,
                  process_group=None, hidden_dropout=None, attention_dropout=None, seed=42, rank=0, static_batch=False,
                  max_predictions_per_seq=None,
-                 bucket_mb=64):
+                 bucket_mb=64, allreduce_dtype=None):
         self.model, self.cfg = model, model.config
         self.dev = model.bert.embeddings.word_embeddings.weight.device
         self.dtype = compute_dtype
@@ -120,7 +120,7 @@ class BertTrainer:
         # gradient buckets over the flat buffer, all-reduced (mean) on the side stream while the backward pass is still
         # running; the buffer follows named_parameters(), backward completes it from the end -> reverse buckets
         self.buckets = GradBuckets(self.flat_grad, [(n, p.numel()) for n, p in zip(self.names, self.params)], bucket_mb,
-                                   process_group, self.comm_stream, reverse=True) if world_size > 1 else None
+                                   process_group, self.comm_stream, reverse=True, wire_dtype=allreduce_dtype) if world_size > 1 else None
         self._reduce_now = False       # set for the micro-step whose gradients are final (last accumulation step)
         base_t = torch.tensor(float(lr), dtype=torch.float32, device=dev)
         self._lr_consts = (base_t, torch.tensor(float(warmup), device=dev), torch.tensor(float(total_steps), device=dev))

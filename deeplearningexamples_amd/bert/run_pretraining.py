@@ -39,6 +39,10 @@ def parse_arguments(argv=None):
     p.add_argument("--json-summary", type=str, default="dllogger.json")
     p.add_argument("--disable_progress_bar", action="store_true")
     p.add_argument("--skip_checkpoint", action="store_true")
+    p.add_argument("--allreduce_post_accumulation", action="store_true",
+                   help="accepted: gradients are always reduced once per optimizer step, on the last micro-batch")
+    p.add_argument("--allreduce_post_accumulation_fp16", action="store_true",
+                   help="16-bit wire format for the gradient buckets (run_pretraining.py:261,416-417): the compute dtype")
     p.add_argument("--cuda_graphs", action="store_true",
                    help="capture the micro-step and the optimizer step in HIP graphs (run_pretraining.py:310,602-640)")
     args = p.parse_args(argv)
@@ -81,7 +85,7 @@ def main(argv=None):
     dtype = torch.float16 if args.fp16 else torch.bfloat16
     trainer = BertTrainer(model, lr=args.learning_rate, warmup=args.warmup_proportion, total_steps=int(args.max_steps),
                           compute_dtype=dtype, init_loss_scale=float(args.init_loss_scale), world_size=world,
-                          seed=args.seed, rank=rank,
+                          seed=args.seed, rank=rank, allreduce_dtype=dtype if args.allreduce_post_accumulation_fp16 else None,
                           max_predictions_per_seq=args.max_predictions_per_seq if args.cuda_graphs else None)
     acc = args.gradient_accumulation_steps
     micro = args.train_batch_size // acc

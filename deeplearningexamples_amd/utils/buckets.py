@@ -27,7 +27,7 @@ def cut_buckets(named_numels: Sequence[Tuple[str, int]], bucket_bytes: int) -> L
     return out
 
 
-from .comm import allreduce_mean_  # noqa: E402,F401  (re-exported: the engines import it from here)
+from .comm import allreduce_mean_, allreduce_sum_  # noqa: E402,F401  (re-exported: the engines import it from here)
 
 
 class GradBuckets:
@@ -36,8 +36,15 @@ class GradBuckets:
     END of the buffer towards its start (BERT: the buffer follows named_parameters(), backward runs heads -> layer 23
     -> ... -> embeddings), buckets are cut walking backwards and fire on the parameter with the LOWEST offset."""
 
-    def __init__(self, flat: torch.Tensor, named_numels, bucket_mb=25, group=None, comm_stream=None, reverse=False):
+    def __init__(self, flat: torch.Tensor, named_numels, bucket_mb=25, group=None, comm_stream=None, reverse=False,
+                 wire_dtype=None):
+        """wire_dtype (torch.float16 / torch.bfloat16, optional): the buckets travel in 16 bits -- each rank pre-divides its
+        fp32 gradients by the world size, rounds them into a 16-bit staging buffer, the SUM all-reduce runs on that buffer and
+        the result is widened back into the flat fp32 buffer (half the bytes over xGMI; what the reference gets from
+        --allreduce_post_accumulation_fp16 with an fp16 model, run_pretraining.py:416-417,461-475)."""
         self.flat, self.group, self.stream = flat, group, comm_stream
+        self.wire_dtype = wire_dtype
+        self._wire = None
         if reverse:
             total = sum(n for _, n in named_numels)
             cut = cut_buckets(list(reversed(list(named_numels))), bucket_mb * (1 << 20))
@@ -59,10 +66,23 @@ class GradBuckets:
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
-                allreduce_mean_(self.flat[s:e], self.group)
+                self._reduce(s, e)
         else:
-            allreduce_mean_(self.flat[s:e], self.group)
+            self._reduce(s, e)
         return True
+
+    def _reduce(self, s, e):
+        if self.wire_dtype is None:
+            allreduce_mean_(self.flat[s:e], self.group)
+            return
+        if self._wire is None:          # one staging buffer of the largest bucket (buckets are reduced one after the other
+            n = max(b[1] - b[0] for b in self.buckets)                                    # on the communication stream)
+            self._wire = torch.empty(n, dtype=self.wire_dtype, device=self.flat.device)
+        w = self._wire[:e - s]
+        torch.div(self.flat[s:e], float(dist.get_world_size(self.group)), out=self.flat[s:e])
+        w.copy_(self.flat[s:e])
+        allreduce_sum_(w, self.group)
+        self.flat[s:e].copy_(w)
 
     def wait(self):
         """Make the compute stream wait for every bucket; all of them must have been launched by now."""

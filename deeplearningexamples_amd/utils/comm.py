@@ -30,6 +30,17 @@ def allreduce_mean_(t: torch.Tensor, group=None):
     return t
 
 
+def allreduce_sum_(t: torch.Tensor, group=None):
+    """In-place sum over the ranks (16-bit wire buffers of the gradient buckets: pre-divided by the world size)."""
+    if _staged(t, group):
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def allreduce_max_(t: torch.Tensor, group=None):
     """In-place maximum over the ranks (the found-inf flag of model-parallel parts)."""
     if _staged(t, group):

@@ -38,6 +38,40 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
+def _worker_wire(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        named = [("w1", 500), ("b2", 30), ("w2", 3000), ("b3", 10), ("w3", 1000)]     # named_parameters() order
+        total = sum(n for _, n in named)
+        g = torch.Generator().manual_seed(5)
+        base = torch.randn(total, generator=g)
+        flat = base * (rank + 1) * 0.25
+        # BERT layout: backward completes the buffer from its END; 16-bit wire format (fp16: gloo has no bf16 reduction)
+        gb = GradBuckets(flat, named, bucket_mb=0, reverse=True, wire_dtype=torch.float16)
+        gb.buckets = [(total - e, total - s, nm) for (s, e, nm) in cut_buckets(list(reversed(named)), 2000 * 4)]
+        gb._by_last = {b[2]: i for i, b in enumerate(gb.buckets)}
+        fired = [gb.grad_ready(n) for n, _ in reversed(named)]
+        gb.wait()
+        exact = base * (1 + 2) * 0.25 / 2                      # the fp32 mean
+        # what the wire format computes: each rank's share rounded to fp16, summed in fp16
+        exp = ((base * 0.25 / 2).half() + (base * 0.5 / 2).half()).float()
+        ret[rank] = (bool(torch.equal(flat, exp)) and float((flat - exact).abs().max()) < 2e-3 and sum(fired) == len(gb.buckets)
+                     and len(gb.buckets) >= 2)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_16bit_wire_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    port = 31600 + os.getpid() % 2000
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_wire, args=(2, port, ret), nprocs=2, join=True)
+        assert ret[0] and ret[1]
+
+
 def test_bucketed_mean_allreduce_two_ranks_gloo():
     import torch.multiprocessing as mp
     port = 29600 + os.getpid() % 2000
