@@ -57,6 +57,7 @@ struct Gemm2Args {
   int force_small;       // keep the 128x128 tile (stats layout is indexed by 128-row tiles)
   long long row_extra;   // output row m lives at m * ldc + (m / row_div.d) * row_extra (+ column): rows of a strided sub-grid
   FastDiv row_div;
+  int lds_src;           // 256x256 tile: 32 KiB of LDS beyond the two stages are available for epilogue source rows
   int gm;                // tile rows per walk group (tile_coords); DLE_GEMM_GM, default 8
   int persist;           // 128x128 tile only: the grid is smaller than the tile list, a workgroup walks tiles bid, bid + grid, ...
   long long sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
@@ -548,6 +549,105 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
       }
     }
   };
+  // ---- 256x256 tile, epilogues that read a 16-bit source tensor (addend, activation derivative, ReLU source), interior tile.
+  // Loaded per trip from global memory, each source row sat behind the previous trip's store in the in-order vmcnt queue and
+  // one 16-byte load per lane was in flight: 32768x4096x1024 ran 443 us against 276 us without a source.  A register window
+  // spills in this kernel (128 accumulators live until staged).  Here the source arrives through the 32 KiB of LDS the two
+  // operand stages leave free: 32-row chunks (16 KiB, two LDS-DMA pieces per wavefront) double-buffered, chunk g + 1 requested
+  // BEFORE the stores of chunk g and waited for with vmcnt(2) = the two store instructions issued behind it; the trips read
+  // their source rows with ds_read_b128.  No global load the compiler knows about remains in the epilogue.
+  bool epilogue_done = false;
+  if constexpr (BIG && !PLAIN) {
+    const bool src_act = p.act == ACT_RELU_BWD || p.act == ACT_ADD || p.act == ACT_GELU_BWD || p.act == ACT_TANH_BWD ||
+                         p.act == ACT_MUL;
+    if (p.lds_src && fast && src_act && p.mask_src != nullptr && p.row_extra == 0 && m0 + TM <= p.M && n0 + TN <= p.N) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);        // the zero-fill DMA issued under the last K tile has landed
+      unsigned short* srcbuf = (unsigned short*)smem_raw + 65536;       // halves: behind the 128 KiB of the two stages
+      const int4v_t rs_src = rsrc_words(p.mask_src);
+      auto issue_src = [&](int g) __attribute__((always_inline)) {      // chunk g = rows m0 + 32 g .. + 31
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int piece = wave * 2 + j;                                // 16 pieces of 2 rows x 512 B
+          const int row = m0 + g * 32 + piece * 2 + (lane >> 5);
+          const unsigned voff = (unsigned)(((long long)row * p.ldc + n0 + (lane & 31) * 8) * 2);
+          dma16_raw(rs_src, srcbuf + (g & 1) * 8192 + piece * 512, voff);
+        }
+      };
+      auto src_pass = [&](auto ACTC) __attribute__((always_inline)) {
+        constexpr int act = decltype(ACTC)::value;
+        const float* e0 = epi + f_ml0 * TN;
+        const int c4 = f_nl >> 2;
+        const int olo = (c4 ^ f_ml0) << 2, ohi = ((c4 + 1) ^ f_ml0) << 2;
+        const float alpha_s = p.alpha;
+        issue_src(0);
+        // (alpha is applied when a trip reads the staged tile: `acc * alpha` in the staging loop is hoisted by hipcc out of the
+        //  half loop as a second 128-register copy of the accumulators and spilled)
+        for (int half = 0; half < 2; ++half) {
+          lds_barrier();                         // operand stages (half 0) / previous half's tile are no longer read
+          if (wm == half) {
+#pragma unroll
+            for (int i = 0; i < WTM; ++i)
+#pragma unroll
+              for (int j = 0; j < WTN; ++j)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                  float4_t v = {acc[i][j][qd * 4 + 0], acc[i][j][qd * 4 + 1], acc[i][j][qd * 4 + 2], acc[i][j][qd * 4 + 3]};
+                  const int row = i * 32 + fr, cq = (wn * (WTN * 32) + j * 32 + qd * 8 + fh * 4) >> 2;
+                  *(float4_t*)(epi + row * TN + ((cq ^ (row & 31)) << 2)) = v;
+                }
+          }
+          const long long off0 = (long long)(m0 + half * (TM / 2) + f_ml0) * p.ldc + n0 + f_nl;
+          const long long step = (long long)RPI * p.ldc;
+          unsigned short* c = (unsigned short*)p.C + off0;
+          unsigned short* ax = p.aux ? (unsigned short*)p.aux + off0 : nullptr;
+#pragma unroll
+          for (int ch = 0; ch < ITERS / 2; ++ch) {
+            const int g = half * (ITERS / 2) + ch;
+            if (g == 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // chunk 0: nothing of this workgroup is behind it
+            else __builtin_amdgcn_s_waitcnt(0x0F72);          // vmcnt(2): the >= 2 stores of chunk g - 1 stay in flight
+            lds_barrier();                        // everybody's pieces of chunk g landed; chunk g - 1 (and, at ch == 0, the
+                                                  // staging writes of this half) are visible / no longer read
+            if (g + 1 < ITERS) issue_src(g + 1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const int it = ch * 2 + t;
+              const float* e = e0 + it * RPI * TN;
+              const int x = (it & 1) << 6;
+              const float4_t lo = *(const float4_t*)(e + (olo ^ x)), hi = *(const float4_t*)(e + (ohi ^ x));
+              float v[8], yv[8];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { v[r] = lo[r] * alpha_s + fbias[r]; v[4 + r] = hi[r] * alpha_s + fbias[4 + r]; }
+              if (ax) *(ushort8_t*)(ax + it * step) = pack8<DT>(v);            // pre-activation side output
+              unpack8<DT>(*(const ushort8_t*)(srcbuf + (g & 1) * 8192 + (f_ml0 + RPI * t) * TN + f_nl), yv);
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {
+                const float y = yv[r];
+                if constexpr (act == ACT_RELU_BWD) v[r] = y > 0.f ? v[r] : 0.f;
+                else if constexpr (act == ACT_ADD) v[r] += y;
+                else if constexpr (act == ACT_MUL) v[r] *= y;
+                else if constexpr (act == ACT_TANH_BWD) v[r] *= (1.f - y * y);
+                else {
+                  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+                  const float th = fast_tanh(k0 * (y + k1 * y * y * y));
+                  v[r] *= 0.5f * (1.f + th) + 0.5f * y * (1.f - th * th) * k0 * (1.f + 3.f * k1 * y * y);
+                }
+              }
+              *(ushort8_t*)(c + it * step) = pack8<DT>(v);
+            }
+          }
+        }
+      };
+      switch (p.act) {
+        case ACT_RELU_BWD: src_pass(std::integral_constant<int, ACT_RELU_BWD>()); break;
+        case ACT_ADD: src_pass(std::integral_constant<int, ACT_ADD>()); break;
+        case ACT_MUL: src_pass(std::integral_constant<int, ACT_MUL>()); break;
+        case ACT_TANH_BWD: src_pass(std::integral_constant<int, ACT_TANH_BWD>()); break;
+        default: src_pass(std::integral_constant<int, ACT_GELU_BWD>()); break;
+      }
+      epilogue_done = true;
+    }
+  }
+  if (!epilogue_done) {
   if (BIG) __builtin_amdgcn_s_waitcnt(0x0F70);    // the zero-fill DMA issued under the last K tile has landed
   for (int half = 0; half < 2; ++half) {
   lds_barrier();                         // operand stages (half 0) / previous half's tile are no longer read
@@ -641,6 +741,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
       if (n0 + col < p.N) p.stats[((long long)tm * 2 + which) * p.N + n0 + col] = t;
     }
   }
+  }   // !epilogue_done
   if (!CAN_PERSIST || !has_next) break;
   counted_wait = fast && m0 + TM <= p.M && n0 + TN <= p.N && 2 * ITERS >= 8;
   vbid += vstep;
@@ -679,7 +780,13 @@ static int launch_gemm(const Gemm2Args& p_in, int in_dtype, int amode, int bmode
                                                          work_big >= (p.splitk == 1 ? 160 : 128)));
   if (fits && want) {
     dim3 grid((unsigned)tiles_big, p.splitk, batch > 0 ? batch : 1), block(512);
-    const size_t lds_big = 2 * (256 * BK + 256 * BK) * 2;
+    // 128 KiB of operand stages + (when the device grants a workgroup the whole 160 KiB) 32 KiB for epilogue source rows
+    static const int lds_max = [] { int dev = 0, v = 0; hipGetDevice(&dev);
+                                    hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev); return v; }();
+    static const int lds_src_mode = getenv("DLE_GEMM_LDS_SRC") ? atoi(getenv("DLE_GEMM_LDS_SRC")) : 1;
+    const size_t lds_stages = 2 * (256 * BK + 256 * BK) * 2;
+    p.lds_src = lds_src_mode && lds_max >= (int)(lds_stages + 32768) && (long long)p.M * p.ldc * 2 < 0xFFFFFFE0LL;
+    const size_t lds_big = lds_stages + (lds_max >= (int)(lds_stages + 32768) ? 32768 : 0);
 #define GOBIG(DT, AM, BMODE) do { static bool attr_set = false; \
       if (!attr_set) { hipFuncSetAttribute((const void*)gemm2_kernel<DT, AM, BMODE, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big); attr_set = true; } \
       hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE, 2, 1>), grid, block, lds_big, stream, p); } while (0)
