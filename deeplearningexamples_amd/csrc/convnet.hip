@@ -1040,6 +1040,87 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
   }
 }
 
+// Wide rows (the MLM head: 30522 classes, 122 KB of fp32 logits per row): ONE workgroup per row, 16-byte loads, four of them
+// in flight per lane from unconditional (clamped) addresses, max and sum of exponentials in ONE pass (running maximum with
+// rescaling), the gradient pass re-reads the row from L2.  The wave-per-row form above reads a row three times with 4-byte
+// loads, one dependent load at a time: 774 us for the 5120 x 30528 logits of a BERT-Large batch (0.8 TB/s).
+template <int ODT>
+__global__ __launch_bounds__(256) void softmax_xent_wide_kernel(const float* __restrict__ logits,
+                                                                const long long* __restrict__ target,
+                                                                float* __restrict__ loss_sum, void* __restrict__ dlogits,
+                                                                const float* __restrict__ grad_scale,
+                                                                const int* __restrict__ n_valid_dev, long long rows,
+                                                                int classes, long long ld, long long ld_out, float smoothing,
+                                                                long long ignore_index) {
+  __shared__ float red[3][4];
+  const long long row = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float4_t* x4 = (const float4_t*)(logits + row * ld);
+  const int n4 = (classes + 3) >> 2;
+  const long long t = target[row];
+  const bool valid = t != ignore_index;
+  float m = -INFINITY, se = 0.f, sx = 0.f;
+  for (int base = tid; base < n4; base += 1024) {
+    float4_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = base + 256 * u; v[u] = x4[i < n4 ? i : n4 - 1]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + 256 * u;
+      if (i < n4) {
+        float xv[4];
+        float mx = m;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { xv[k] = (4 * i + k < classes) ? v[u][k] : -INFINITY; mx = fmaxf(mx, xv[k]); }
+        se *= __expf(m - mx);              // (m = -inf, se = 0 on the first group: exp(-inf) = 0)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { se += __expf(xv[k] - mx); sx += (4 * i + k < classes) ? xv[k] : 0.f; }
+        m = mx;
+      }
+    }
+  }
+  const float wm = wave_max(m);
+  se = wave_sum(se * __expf(m - wm));
+  sx = wave_sum(sx);
+  if (lane == 0) { red[0][w] = wm; red[1][w] = se; red[2][w] = sx; }
+  __syncthreads();
+  const float mx = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+  float tot = 0.f, totx = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { tot += red[1][q] * __expf(red[0][q] - mx); totx += red[2][q]; }
+  const float lse = mx + __logf(tot);
+  if (tid == 0 && valid) {
+    const float nll = lse - logits[row * ld + t];
+    const float smooth = lse - totx / (float)classes;
+    unsafeAtomicAdd(loss_sum, (1.f - smoothing) * nll + smoothing * smooth);
+  }
+  if (dlogits) {
+    const float nv = (float)(*n_valid_dev > 0 ? *n_valid_dev : 1);
+    const float gs = valid ? (grad_scale ? *grad_scale : 1.0f) / nv : 0.f;
+    const float inv_se = 1.0f / tot, sm = smoothing / (float)classes;
+    const int n4o = (int)(ld_out >> 2);
+    for (int i = tid; i < n4o; i += 256) {
+      const float4_t v = x4[i < n4 ? i : n4 - 1];
+      float g[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = 4 * i + k;
+        g[k] = c < classes ? (__expf(v[k] - mx) * inv_se - (c == t ? 1.f - smoothing : 0.f) - sm) * gs : 0.f;
+      }
+      if (ODT == DLE_F32) {
+        const float4_t o = {g[0], g[1], g[2], g[3]};
+        *(float4_t*)((float*)dlogits + row * ld_out + 4 * i) = o;
+      } else {
+        typedef __attribute__((ext_vector_type(4))) unsigned short ushort4v_t;
+        ushort4v_t o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = ODT == DLE_F16 ? Elem<DLE_F16>::from_f32(g[k]) : Elem<DLE_BF16>::from_f32(g[k]);
+        *(ushort4v_t*)((unsigned short*)dlogits + row * ld_out + 4 * i) = o;
+      }
+    }
+  }
+}
+
 __global__ void count_valid_kernel(const long long* __restrict__ target, long long rows, long long ignore_index,
                                    int* __restrict__ n_valid) {
   __shared__ float red[16];
@@ -1069,8 +1150,12 @@ extern "C" int dle_softmax_xent(const float* logits, const int64_t* target, floa
   hipLaunchKernelGGL(count_valid_kernel, dim3(cn_grid(rows, 256, 256)), dim3(256), 0, stream, (const long long*)target,
                      (long long)rows, (long long)ignore_index, scratch);
   DLE_LAUNCH_CHECK();
-  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define GO(ODT) hipLaunchKernelGGL(softmax_xent_kernel<ODT>, grid, block, 0, stream, logits, (const long long*)target, loss_out, dlogits, grad_scale_dev, (const int*)scratch, (long long)rows, classes, (long long)ld, (long long)ld_out, smoothing, (long long)ignore_index)
+  // wide rows: a workgroup per row with 16-byte accesses (rows, output rows and bases 16-byte aligned)
+  const bool wide = classes >= 4096 && (ld & 3) == 0 && (((uintptr_t)logits) & 15) == 0 &&
+                    (!dlogits || ((ld_out & 3) == 0 && (((uintptr_t)dlogits) & 15) == 0));
+  dim3 grid(wide ? (unsigned)rows : (unsigned)((rows + 3) / 4)), block(256);
+#define GO(ODT) do { if (wide) hipLaunchKernelGGL(softmax_xent_wide_kernel<ODT>, grid, block, 0, stream, logits, (const long long*)target, loss_out, dlogits, grad_scale_dev, (const int*)scratch, (long long)rows, classes, (long long)ld, (long long)ld_out, smoothing, (long long)ignore_index); \
+  else hipLaunchKernelGGL(softmax_xent_kernel<ODT>, grid, block, 0, stream, logits, (const long long*)target, loss_out, dlogits, grad_scale_dev, (const int*)scratch, (long long)rows, classes, (long long)ld, (long long)ld_out, smoothing, (long long)ignore_index); } while (0)
   if (dlogits_dtype == DLE_F32) GO(DLE_F32);
   else if (dlogits_dtype == DLE_F16) GO(DLE_F16);
   else if (dlogits_dtype == DLE_BF16) GO(DLE_BF16);

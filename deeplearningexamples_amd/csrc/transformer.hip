@@ -347,56 +347,46 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const unsigned short* __res
   }
 }
 
-// third column of the DROP variant: out[c] (+)= sum over blocks of partial[block][2][c]
-__global__ __launch_bounds__(256) void colthird_finish_kernel(const float* __restrict__ partial, int groups, int C,
-                                                              float* __restrict__ out, int accumulate) {
-  __shared__ double red[256];
-  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
-  double s0 = 0.0;
-  if (c < C)
-    for (int g = sl; g < groups; g += 16) s0 += partial[((long long)g * 3 + 2) * C + c];
-  red[threadIdx.x] = s0;
-  __syncthreads();
-  if (sl == 0 && c < C) {
-    double t0 = 0.0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) t0 += red[q * 16 + cl];
-    out[c] = accumulate ? out[c] + (float)t0 : (float)t0;
-  }
-}
-
 // dgamma / dbeta = sum over blocks of the partials (fp64 accumulation).  16 columns x 16 group slices per
 // workgroup: the pass is latency-bound, so it is spread over C/16 workgroups with 4 loads in flight per lane.
 __global__ __launch_bounds__(256) void colpair_finish_kernel(const float* __restrict__ partial, int groups, int C,
                                                              float* __restrict__ out1, float* __restrict__ out0,
-                                                             int accumulate, int NS = 2) {
-  __shared__ double red[2][256];
+                                                             int accumulate, int NS = 2, float* __restrict__ out2 = nullptr) {
+  // out2 (NS == 3): the third statistic of the fused dropout + LayerNorm backward (the dense layer's bias gradient) in the
+  // same launch -- its own finishing kernel was 48 launches x 12 us per BERT step
+  __shared__ double red[3][256];
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
-  double s0 = 0.0, s1 = 0.0;
+  const bool third = out2 != nullptr && NS == 3;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   if (c < C) {
     int g = sl;
     for (; g + 48 < groups; g += 64) {
-      float a[4], b[4];
+      float a[4], b[4], d[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         a[u] = partial[((long long)(g + 16 * u) * NS) * C + c];
         b[u] = partial[((long long)(g + 16 * u) * NS + 1) * C + c];
+        d[u] = partial[((long long)(g + 16 * u) * NS + (third ? 2 : 0)) * C + c];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { s0 += a[u]; s1 += b[u]; }
+      for (int u = 0; u < 4; ++u) { s0 += a[u]; s1 += b[u]; s2 += d[u]; }
     }
-    for (; g < groups; g += 16) { s0 += partial[((long long)g * NS) * C + c]; s1 += partial[((long long)g * NS + 1) * C + c]; }
+    for (; g < groups; g += 16) {
+      s0 += partial[((long long)g * NS) * C + c];
+      s1 += partial[((long long)g * NS + 1) * C + c];
+      s2 += partial[((long long)g * NS + (third ? 2 : 0)) * C + c];
+    }
   }
-  red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+  red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
   __syncthreads();
   if (sl == 0 && c < C) {
-    double t0 = 0.0, t1 = 0.0;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { t0 += red[0][q * 16 + cl]; t1 += red[1][q * 16 + cl]; }
+    for (int q = 0; q < 16; ++q) { t0 += red[0][q * 16 + cl]; t1 += red[1][q * 16 + cl]; t2 += red[2][q * 16 + cl]; }
     out0[c] = accumulate ? out0[c] + (float)t0 : (float)t0;
     out1[c] = accumulate ? out1[c] + (float)t1 : (float)t1;
+    if (third) out2[c] = accumulate ? out2[c] + (float)t2 : (float)t2;
   }
 }
 
@@ -426,13 +416,8 @@ static int ln_bwd_launch(const void* dy, const void* z, const float* mean, const
 #undef PICK
   DLE_LAUNCH_CHECK();
   hipLaunchKernelGGL(colpair_finish_kernel, dim3((H + 15) / 16), dim3(256), 0, stream, (const float*)workspace, blocks, H,
-                     dgamma, dbeta, accumulate, ns);
+                     dgamma, dbeta, accumulate, ns, (drop && dbias) ? dbias : (float*)nullptr);
   DLE_LAUNCH_CHECK();
-  if (drop && dbias) {
-    hipLaunchKernelGGL(colthird_finish_kernel, dim3((H + 15) / 16), dim3(256), 0, stream, (const float*)workspace, blocks, H,
-                       dbias, accumulate);
-    DLE_LAUNCH_CHECK();
-  }
   return 0;
 }
 

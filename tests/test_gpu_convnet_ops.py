@@ -112,3 +112,34 @@ def test_softmax_xent(cuda, smoothing, ignore):
                               grad_dtype=torch.float32)
     assert abs(loss.item() - loss_r.item()) < 1e-5 * max(1, abs(loss_r.item()))
     np.testing.assert_allclose(dl.cpu().numpy(), (xr.grad * 4).float().numpy(), rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("gdtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_softmax_xent_wide_rows_mlm_head(cuda, gdtype):
+    """The MLM-head shape: 30522 classes inside rows padded to 30528 (logits AND gradient), ignore_index -1, loss-scaled
+    gradient -- the workgroup-per-row kernel (online max / sum, 16-byte accesses); padded gradient columns are zero."""
+    from deeplearningexamples_amd import functional as F
+    g = torch.Generator().manual_seed(12)
+    rows, classes, ld = 45, 30522, 30528
+    buf = torch.randn(rows, ld, generator=g) * 4
+    buf[:, classes:] = 1e4                                   # garbage in the padding must not enter the softmax
+    buf[3, 17] = 60.0                                        # a dominant logit late in the running-maximum order
+    buf[4, classes - 1] = 55.0                               # ... and in the ragged last group of four
+    t = torch.randint(0, classes, (rows,), generator=g)
+    t[::4] = -1
+    t[4] = classes - 1
+    x = buf[:, :classes]
+    xr = x.double().requires_grad_()
+    lp = torch.log_softmax(xr, -1)
+    valid = t != -1
+    loss_r = (-lp[valid].gather(1, t[valid, None]).squeeze(1)).mean()
+    loss_r.backward()
+    xd = buf.to(cuda)[:, :classes]                           # row stride 30528, 30522 classes
+    loss, dl = F.softmax_xent(xd, t.to(cuda), 0.0, -1, grad_scale=torch.tensor([128.0], device=cuda), grad_dtype=gdtype,
+                              ld_out=ld)
+    assert abs(loss.item() - loss_r.item()) < 2e-5 * max(1, abs(loss_r.item()))
+    ref = (xr.grad * 128).float().numpy()
+    got = dl.float().cpu().numpy()
+    tol = dict(rtol=1e-4, atol=1e-6) if gdtype == torch.float32 else dict(rtol=1e-2, atol=1e-5)
+    np.testing.assert_allclose(got[:, :classes], ref, **tol)
+    assert not got[:, classes:].any()
