@@ -914,6 +914,61 @@ extern "C" int dle_maxpool_fwd(const void* x, void* y, void* argmax, int N, int 
   return 0;
 }
 
+// MaxPool2d(3, 2, 1) -- the ResNet stem: an input pixel lies in ONE window per axis when its coordinate is even (tap 1) and in
+// two when it is odd (taps 0 and 2): at most four candidate windows, requested up front from unconditional (clamped)
+// addresses and masked.  The generic gather above walks 3 x 3 taps through `continue`s (loads inside conditionals: one in
+// flight per lane) with 64-bit div / mod per element: 303 us for the 205 MB gradient of a batch-256 stem.
+template <int DT>
+__global__ __launch_bounds__(256) void maxpool_bwd_k3s2_kernel(const unsigned short* __restrict__ dy,
+                                                               const unsigned char* __restrict__ amax,
+                                                               unsigned short* __restrict__ dx, int N, int H, int W, int C8,
+                                                               int P, int Q) {
+  const unsigned total = (unsigned)N * H * W * C8;                 // (the launcher checks < 2^31)
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned c8 = i % (unsigned)C8;
+    unsigned t = i / (unsigned)C8;
+    const int w = (int)(t % (unsigned)W); t /= (unsigned)W;
+    const int h = (int)(t % (unsigned)H);
+    const int n = (int)(t / (unsigned)H);
+    // candidate windows per axis: (index, tap); the second exists only for odd coordinates
+    const int p0 = (h + 1) >> 1, r0 = (h & 1) ? 0 : 1, p1 = (h - 1) >> 1;      // p1: tap 2, odd h only
+    const int q0 = (w + 1) >> 1, s0 = (w & 1) ? 0 : 1, q1 = (w - 1) >> 1;
+    const bool vp[2] = {p0 < P, (h & 1) != 0};
+    const bool vq[2] = {q0 < Q, (w & 1) != 0};
+    const int pp[2] = {p0 < P ? p0 : P - 1, (h & 1) ? p1 : 0}, rr[2] = {r0, 2};
+    const int qq[2] = {q0 < Q ? q0 : Q - 1, (w & 1) ? q1 : 0}, ss[2] = {s0, 2};
+    ushort8_t g[4];
+    uint2_t am[4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const unsigned o = (((unsigned)n * P + pp[a]) * Q + qq[b]) * C8 + c8;
+        g[a * 2 + b] = ((const ushort8_t*)dy)[o];
+        am[a * 2 + b] = ((const uint2_t*)amax)[o];
+      }
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const bool ok = vp[a] && vq[b];
+        const unsigned want = ok ? (unsigned)(rr[a] * 3 + ss[b]) : 0xFFu;       // argmax codes are < 9
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const unsigned code = (am[a * 2 + b][k >> 2] >> ((k & 3) * 8)) & 0xffu;
+          if (code == want) acc[k] += up16<DT>(g[a * 2 + b][k]);
+        }
+      }
+    ushort8_t o8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o8[k] = dn16<DT>(acc[k]);
+    ((ushort8_t*)dx)[i] = o8;
+  }
+}
+
 extern "C" int dle_maxpool_bwd(const void* dy, const void* argmax, void* dx, int N, int H, int W, int C, int ksize,
                                int stride, int pad, int dtype, hipStream_t stream) {
   DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "maxpool_bwd: 16-bit activations only");
@@ -922,6 +977,12 @@ extern "C" int dle_maxpool_bwd(const void* dy, const void* argmax, void* dx, int
   DLE_CHECK_ARG(dy && dx && argmax, "maxpool_bwd: null pointer");
   const int P = (H + 2 * pad - ksize) / stride + 1, Q = (W + 2 * pad - ksize) / stride + 1;
   const int grid = cn_grid((long long)N * H * W * (C / 8), 256, 8192);
+  if (ksize == 3 && stride == 2 && pad == 1 && (long long)N * H * W * (C / 8) < 0x7FFFFFFFLL && P >= 1 && Q >= 1) {
+    if (dtype == DLE_F16) hipLaunchKernelGGL(maxpool_bwd_k3s2_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned char*)argmax, (unsigned short*)dx, N, H, W, C / 8, P, Q);
+    else hipLaunchKernelGGL(maxpool_bwd_k3s2_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned char*)argmax, (unsigned short*)dx, N, H, W, C / 8, P, Q);
+    DLE_LAUNCH_CHECK();
+    return 0;
+  }
   if (dtype == DLE_F16) hipLaunchKernelGGL(maxpool_bwd_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned char*)argmax, (unsigned short*)dx, N, H, W, C / 8, P, Q, ksize, stride, pad);
   else hipLaunchKernelGGL(maxpool_bwd_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned char*)argmax, (unsigned short*)dx, N, H, W, C / 8, P, Q, ksize, stride, pad);
   DLE_LAUNCH_CHECK();

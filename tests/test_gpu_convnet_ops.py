@@ -81,6 +81,16 @@ def test_pools_and_layout(cuda, dtype):
     assert torch.equal(y.cpu(), _nhwc(yr.detach()).to(dtype))
     dx = F.maxpool_bwd(_nhwc(dy).to(cuda), am, (13, 11))
     np.testing.assert_allclose(dx.float().cpu().numpy(), _nhwc(xr.grad).to(dtype).float().numpy(), rtol=1e-2, atol=1e-2)
+    for hw in ((8, 10), (2, 2), (1, 5)):                     # even sizes (the 112 x 112 stem), degenerate ones
+        x2 = torch.relu(torch.randn(2, 8, *hw, generator=g)).to(dtype)
+        x2r = x2.float().requires_grad_()
+        y2r = torch.nn.functional.max_pool2d(x2r, 3, 2, 1)
+        dy2 = torch.randn(y2r.shape, generator=g).to(dtype)
+        y2r.backward(dy2.float())
+        y2, am2 = F.maxpool_fwd(_nhwc(x2).to(cuda))
+        assert torch.equal(y2.cpu(), _nhwc(y2r.detach()).to(dtype))
+        dx2 = F.maxpool_bwd(_nhwc(dy2).to(cuda), am2, hw)
+        np.testing.assert_allclose(dx2.float().cpu().numpy(), _nhwc(x2r.grad).to(dtype).float().numpy(), rtol=1e-2, atol=1e-2)
     a = torch.randn(5, 64, 7, 7, generator=g).to(dtype)
     p = F.avgpool_fwd(_nhwc(a).to(cuda))
     np.testing.assert_allclose(p.float().cpu().numpy(), a.float().mean((2, 3)).to(dtype).float().numpy(), rtol=1e-2, atol=1e-2)
