@@ -48,6 +48,7 @@ _SIGS = {
     "dle_amp_update_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int,
                                      c_void_p]),
     "dle_check_nonfinite": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+    "dle_axpby_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_i64, c_void_p]),
     "dle_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p]),
     "dle_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_i64, c_int, c_void_p]),
     "dle_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

@@ -59,8 +59,13 @@ def lr_linear_policy(base_lr, warmup_length, epochs):
 class ResNetTrainer:
     def __init__(self, model: ResNet50, lr: float, momentum=0.875, weight_decay=3.0517578125e-05, nesterov=False,
                  label_smoothing=0.1, compute_dtype=torch.bfloat16, bn_weight_decay=False, static_loss_scale=1.0,
-                 world_size=1, process_group=None, bucket_mb=25):
+                 world_size=1, process_group=None, bucket_mb=25, grad_acc_steps=1):
         self.model = model
+        # gradient accumulation (main.py:405-416 batch_size_multiplier -> training.py divide_loss / grad_acc_steps): the optimizer
+        # steps every grad_acc_steps calls of train_step on the sum of the micro-batch gradients, each divided by grad_acc_steps
+        self.grad_acc_steps = max(1, int(grad_acc_steps))
+        self.steps_since_update = 0
+        self.flat_acc = None
         self.dev = model.fc.weight.device
         self.dtype = compute_dtype
         self.momentum, self.wd, self.nesterov, self.smoothing = momentum, weight_decay, nesterov, label_smoothing
@@ -161,7 +166,7 @@ class ResNetTrainer:
     # ------------------------------------------------------------------ communication
     def _maybe_reduce(self, finished_param_name):
         """Launch the all-reduce of a gradient bucket once its last gradient has been produced."""
-        if self.buckets is not None:
+        if self.buckets is not None and getattr(self, "_reduce_now", True):
             self.buckets.grad_ready(finished_param_name)
 
     # ------------------------------------------------------------------ the step
@@ -242,18 +247,39 @@ class ResNetTrainer:
         self.first_step = False
 
     def train_step(self, images, target):
-        """One optimisation step.  Returns the device-resident fp32 loss [1] (no host sync)."""
+        """One call of the reference's Trainer.train_step (training.py:167-186): forward + backward of one (micro-)batch and,
+        every grad_acc_steps calls, the optimizer step.  Returns the device-resident fp32 loss [1] (no host sync), divided by
+        grad_acc_steps like the reference's `loss /= divide_loss`."""
         sc = self.scaler
+        acc = self.grad_acc_steps
+        self.steps_since_update += 1
+        last = self.steps_since_update == acc
         logits = self.forward(images)
         loss, dlogits = F.softmax_xent(logits, target, smoothing=self.smoothing,
                                        grad_scale=sc.scale if sc.enabled else None, grad_dtype=self.dtype)
+        self._reduce_now = acc == 1                 # buckets fire during backward only without accumulation
         self.backward(dlogits)
-        if self.buckets is not None:
+        if acc > 1:
+            # micro-batch gradients meet in a second flat buffer: flat_acc = sum_k flat_grad_k / acc (the backward kernels
+            # overwrite flat_grad, and BatchNorm's backward needs the per-micro-batch dgamma / dbeta it has just written)
+            if self.flat_acc is None:
+                self.flat_acc = torch.empty_like(self.flat_grad)
+            first = self.steps_since_update == 1
+            dst = self.flat_grad if last else self.flat_acc
+            F.axpby_(self.flat_grad, None if first else self.flat_acc, dst, 1.0 / acc, 0.0 if first else 1.0)
+            loss = loss / acc
+            if not last:
+                self.steps_done += 1
+                return loss
+            if self.world > 1:
+                comm.allreduce_mean_(self.flat_grad, self.pg)          # one reduction per optimizer step
+        elif self.buckets is not None:
             self.buckets.wait()
         if sc.enabled:
             F.check_nonfinite_(self.flat_grad, sc.found_inf)
         self.optimizer_step()
         sc.update()
+        self.steps_since_update = 0
         self.steps_done += 1          # BatchNorm.num_batches_tracked is materialised by sync_counters()
         return loss
 

@@ -103,15 +103,19 @@ def main(argv=None):
     if not args.amp:
         raise SystemExit("this path computes in 16 bits with fp32 master weights: pass --amp (the reference's fp32 / TF32 "
                          "recipes are not built)")
-    if args.optimizer_batch_size not in (-1, world * args.batch_size):
-        raise SystemExit("--optimizer-batch-size %d: gradient accumulation (main.py:413-432 batch_size_multiplier) is not "
-                         "built; use -1 or world * batch-size = %d" % (args.optimizer_batch_size, world * args.batch_size))
+    # main.py:405-416: the optimizer steps on optimizer-batch-size samples = batch_size_multiplier micro-batches per rank
+    bsm = 1
+    if args.optimizer_batch_size >= 0:
+        tbs = world * args.batch_size
+        if args.optimizer_batch_size % tbs != 0:
+            raise SystemExit("--optimizer-batch-size %d is not a multiple of world x batch-size = %d" % (args.optimizer_batch_size, tbs))
+        bsm = args.optimizer_batch_size // tbs
     model = ResNet50(num_classes=args.num_classes, device=device)
     dtype = torch.bfloat16 if args.amp_dtype == "bf16" else torch.float16
     trainer = ResNetTrainer(model, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay,
                             nesterov=args.nesterov, label_smoothing=args.label_smoothing, compute_dtype=dtype,
                             static_loss_scale=args.static_loss_scale, world_size=world,
-                            bn_weight_decay=args.bn_weight_decay)
+                            bn_weight_decay=args.bn_weight_decay, grad_acc_steps=bsm)
     iters, secs = train_loop(trainer, args, get_lr_policy(args), device, rank, world)
     if is_main_process():
         dllogger.log(step=tuple(), data={"train.total_ips": world * args.batch_size * iters / secs, "iterations": iters})

@@ -320,3 +320,29 @@ extern "C" int dle_act_bwd(const void* g, const void* src, void* out, int64_t n,
   DLE_LAUNCH_CHECK();
   return 0;
 }
+
+// out = a * x + b * y on flat fp32 arrays (out may alias x or y).  Gradient accumulation over micro-batches:
+// Classification/ConvNets/main.py:405-416 (batch_size_multiplier), image_classification/training.py:86-96,167-186 -- autograd's
+// += into .grad with the loss pre-divided by the number of micro-batches; apex's amp_C.multi_tensor_axpby is the same pass.
+__global__ __launch_bounds__(256) void axpby_f32_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                        float* __restrict__ out, float a, float b, long long n) {
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4_t xv = ((const float4_t*)x)[i];
+    float4_t o = xv * a;
+    if (b != 0.f) o += ((const float4_t*)y)[i] * b;      // (b == 0: y is not read -- it may be uninitialised)
+    ((float4_t*)out)[i] = o;
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = a * x[i] + (b != 0.f ? b * y[i] : 0.f);
+}
+
+extern "C" int dle_axpby_f32(const float* x, const float* y, float* out, float a, float b, int64_t n, hipStream_t stream) {
+  if (n == 0) return 0;
+  DLE_CHECK_ARG(x && out && (y || b == 0.f), "axpby_f32: null pointer");
+  DLE_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)out) | ((uintptr_t)y)) & 15) == 0, "axpby_f32: arrays must be 16-byte aligned");
+  hipLaunchKernelGGL(axpby_f32_kernel, dim3(ew_grid(n / 4 + 1, 256)), dim3(256), 0, stream, x, y ? y : x, out, a, b, (long long)n);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}

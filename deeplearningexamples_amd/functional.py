@@ -212,6 +212,17 @@ def amp_update_scale_(scale, growth_tracker, found_inf, inv_scale=None, growth_f
            float(growth_factor), float(backoff_factor), int(growth_interval), int(clear_found_inf), C.stream())
 
 
+def axpby_(x, y, out, a=1.0, b=1.0):
+    """out = a * x + b * y on flat fp32 tensors (out may be x or y; y may be None when b == 0)."""
+    C.require_cuda(x, y, out)
+    if x.dtype != torch.float32 or out.dtype != torch.float32 or not (x.is_contiguous() and out.is_contiguous()):
+        raise ValueError("axpby_ expects contiguous fp32 tensors")
+    if out.numel() != x.numel() or (y is not None and y.numel() != x.numel()):
+        raise ValueError("axpby_: size mismatch")
+    C.call("dle_axpby_f32", C.ptr(x), C.ptr(y), C.ptr(out), float(a), float(b if y is not None else 0.0), x.numel(), C.stream())
+    return out
+
+
 def check_nonfinite_(x, found_inf):
     C.require_cuda(x, found_inf)
     C.call("dle_check_nonfinite", C.ptr(x), C.ptr(found_inf), x.numel(), C.dt(x), C.stream())

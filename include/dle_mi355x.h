@@ -183,6 +183,10 @@ int dle_amp_update_scale(float* scale, int* growth_tracker, float* found_inf, fl
                          float growth_factor, float backoff_factor, int growth_interval,
                          int clear_found_inf, hipStream_t stream);
 int dle_check_nonfinite(const void* x, float* found_inf, int64_t n, int dtype, hipStream_t stream);
+/* out = a * x + b * y on flat fp32 arrays (16-byte aligned; out may alias x or y; y is not read when b == 0): the
+ * accumulation of micro-batch gradients behind --optimizer-batch-size (Classification/ConvNets/main.py:405-416,
+ * image_classification/training.py:86-96,167-186: loss / divide_loss, autograd's += into .grad; apex amp_C.multi_tensor_axpby). */
+int dle_axpby_f32(const float* x, const float* y, float* out, float a, float b, int64_t n, hipStream_t stream);
 /* out = g * act'(src) on flat 16-bit arrays; act = DLE_ACT_GELU_BWD (src = pre-activation) or DLE_ACT_TANH_BWD */
 int dle_act_bwd(const void* g, const void* src, void* out, int64_t n, int act, int dtype, hipStream_t stream);
 /* out[r,c] = y[r,c] > 0 ? g[r,c] : 0 on 16-bit strided views (nn.ReLU backward, dlrm/nn/mlps.py:85-87) */

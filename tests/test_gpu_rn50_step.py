@@ -100,3 +100,49 @@ def test_rn50_first_step_gradients_vs_oracle(cuda, dtype):
     print("(name, hip-vs-fp32, 16-bit-storage-floor) every 9th:", report[::9])
     assert not bad, bad[:10]
     assert report[-2][1] < (0.01 if dtype == torch.float16 else 0.04)    # fc.weight: one GEMM away from the loss
+
+
+def test_rn50_gradient_accumulation(cuda):
+    """--optimizer-batch-size = 2 x batch (main.py:405-416, training.py:86-96,167-186): two train_step calls, ONE optimizer
+    step on (g(mb1) + g(mb2)) / 2, the loss of each call divided by 2; BatchNorm statistics per micro-batch.  Checked against
+    the same engine run without accumulation: its two micro-batch gradients, averaged on the host, and its own SGD step."""
+    from deeplearningexamples_amd import functional as F
+    c = RO.RN50_STEP_CONFIG
+    state = RO.seeded_state(c["seed"])
+    xa, ya = RO.seeded_batch(5, 8, c["size"])
+    xb, yb = RO.seeded_batch(6, 8, c["size"])
+    xa, ya, xb, yb = xa.to(cuda), ya.to(cuda), xb.to(cuda), yb.to(cuda)
+    from deeplearningexamples_amd.convnets.resnet import ResNet50
+    from deeplearningexamples_amd.convnets.engine import ResNetTrainer
+
+    def make(acc):
+        model = ResNet50(device=cuda)
+        model.load_state_dict({k: v.clone() for k, v in state.items()}, strict=False)
+        return model, ResNetTrainer(model, lr=0.05, compute_dtype=torch.bfloat16, grad_acc_steps=acc)
+
+    m1, t1 = make(1)
+    grads, losses = [], []
+    for x, y in ((xa, ya), (xb, yb)):
+        logits = t1.forward(x)
+        loss, dl = F.softmax_xent(logits, y, smoothing=0.1, grad_dtype=torch.bfloat16)
+        t1.backward(dl)
+        grads.append(t1.flat_grad.clone())
+        losses.append(loss.item())
+    w_before = m1.fc.weight.detach().clone()
+    t1.flat_grad.copy_((grads[0] + grads[1]) / 2)
+    t1.optimizer_step()
+    m2, t2 = make(2)
+    la = t2.train_step(xa, ya)
+    assert torch.equal(m2.fc.weight, w_before), "the optimizer must not step on the first micro-batch"
+    lb = t2.train_step(xb, yb)
+    assert abs(la.item() - losses[0] / 2) < 1e-6 and abs(lb.item() - losses[1] / 2) < 1e-6
+    ref = (grads[0] + grads[1]) / 2
+    err = float((t2.flat_grad - ref).abs().max() / ref.abs().max())
+    assert err < 1e-6, err
+    for (n, p), (_, q) in zip(m2.named_parameters(), m1.named_parameters()):
+        assert torch.allclose(p, q, rtol=1e-6, atol=1e-7), n
+    assert not torch.equal(m2.fc.weight, w_before)
+    np.testing.assert_allclose(m2.bn1.running_mean.cpu().numpy(), m1.bn1.running_mean.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    # the third call starts the next accumulation window
+    t2.train_step(xa, ya)
+    assert t2.steps_since_update == 1
