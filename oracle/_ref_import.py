@@ -112,3 +112,18 @@ def import_fused_lamb():
     sys.modules.pop("fused_lamb.fused_lamb", None)
     from fused_lamb.fused_lamb import FusedLAMBAMP
     return FusedLAMBAMP
+
+
+def import_waveglow():
+    """PyTorch/SpeechSynthesis/Tacotron2/waveglow/{model,loss_function}.py, loaded by file path: the
+    package directory shares its name (`waveglow`) with nothing in this repo, but its parent also holds `tacotron2` / `common`
+    packages that are not needed here."""
+    import importlib.util
+    base = os.path.join(REF, "PyTorch", "SpeechSynthesis", "Tacotron2", "waveglow")
+    out = {}
+    for nm in ("model", "loss_function"):
+        spec = importlib.util.spec_from_file_location("_ref_waveglow_" + nm, os.path.join(base, nm + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        out[nm] = mod
+    return types.SimpleNamespace(**out)

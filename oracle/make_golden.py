@@ -352,8 +352,39 @@ def gen_floors():
         print("dlrm_step", name, "reference", arrs["losses"], "fp16 storage", arrs["losses_fp16_storage"], "bf16 storage", arrs["losses_bf16_storage"])
 
 
+def gen_waveglow():
+    """Loss and every parameter gradient of the REFERENCE's WaveGlow + WaveGlowLoss on CPU (small flow / WN sizes, full mel and
+    grouping geometry): pins oracle/waveglow_oracle.py -- groundwork for SURVEY.md 8 row f1, no product path yet."""
+    from oracle import waveglow_oracle as WO
+    ref = R.import_waveglow()
+    c = WO.WAVEGLOW_CASE
+    model = ref.model.WaveGlow(**c["cfg"])
+    state = WO.seeded_state(c["cfg"], c["seed"])
+    ref_shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert ref_shapes == WO.param_shapes(c["cfg"]), set(ref_shapes.items()) ^ set(WO.param_shapes(c["cfg"]).items())
+    model.load_state_dict(state)
+    model.train()
+    mel, audio = WO.seeded_inputs(c)
+    crit = ref.loss_function.WaveGlowLoss(sigma=c["sigma"])
+    loss = crit(model((mel, audio)), audio)
+    loss.backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    lo = WO.waveglow_loss(p, c["cfg"], mel, audio, c["sigma"])
+    lo.backward()
+    assert abs(float(lo) - float(loss)) <= 1e-6 * abs(float(loss)), (float(lo), float(loss))
+    arrs = {"loss": np.asarray([float(loss)], np.float64)}
+    for k, v in model.named_parameters():
+        g, go = v.grad, p[k].grad
+        assert torch.allclose(g, go, rtol=2e-4, atol=1e-7), (k, float((g - go).abs().max()))
+        arrs["gnorm." + k] = np.asarray([float(g.norm())], np.float64)
+    for k in ("upsample.weight", "convinv.1.conv.weight", "WN.2.in_layers.1.weight_g", "WN.3.end.bias"):
+        arrs["grad." + k] = dict(model.named_parameters())[k].grad.numpy().reshape(-1)[:64]
+    np.savez_compressed(os.path.join(GOLD, "waveglow_loss.npz"), **arrs)
+    print("waveglow_loss.npz loss", float(loss), "params", len(list(model.named_parameters())))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dlrm", "dlrm_step", "rn50", "lamb", "bert", "floors"]
+    which = sys.argv[1:] or ["dlrm", "dlrm_step", "rn50", "lamb", "bert", "floors", "waveglow"]
     os.makedirs(GOLD, exist_ok=True)
     if not R.have_reference():
         sys.exit("reference not mounted; fixtures are generated in the build container only")
