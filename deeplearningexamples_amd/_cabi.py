@@ -110,6 +110,25 @@ _SIGS = {
                                    c_void_p, c_float, c_int, c_void_p]),
     "dle_mt_sgd": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float,
                            c_float, c_float, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "dle_mt_adam": (c_int, [c_void_p, c_int, c_i64, c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
+                            c_float, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
+    "dle_wg_taps": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "dle_wg_taps_bwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_i64, c_i64, c_int, c_void_p]),
+    "dle_wg_gate_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p]),
+    "dle_wg_gate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_int, c_void_p]),
+    "dle_wg_invconv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p]),
+    "dle_wg_invconv_bwd_partials": (c_int, [c_i64]),
+    "dle_wg_invconv_bwd": (c_int, [c_void_p] * 8 + [c_float, c_void_p, c_i64, c_int, c_void_p]),
+    "dle_wg_logdet_inv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dle_wg_coupling_partials": (c_int, [c_i64]),
+    "dle_wg_coupling_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+    "dle_wg_coupling_bwd": (c_int, [c_void_p] * 6 + [c_float, c_i64, c_int, c_int, c_void_p]),
+    "dle_wg_loss": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_i64, c_void_p, c_void_p, c_void_p]),
+    "dle_wg_dz_init": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_i64, c_void_p]),
+    "dle_wg_weight_norm_fwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "dle_wg_weight_norm_bwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    "dle_wg_upsample_weight": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "dle_wg_upsample_weight_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
 _lib = None

@@ -362,6 +362,52 @@ __global__ __launch_bounds__(MT_BLOCK) void mt_sgd(const long long* __restrict__
   }
 }
 
+// -------------------------------------------------------------------- Adam (torch.optim.Adam, fp32 state)
+// SpeechSynthesis/Tacotron2/train.py:400-401,487-497: GradScaler.unscale_ + clip_grad_norm_ + Adam.step in one pass.
+// lists: g (fp32, scaled by the loss scale), p, exp_avg, exp_avg_sq.  grad = g * inv_scale * clip,
+// clip = min(1, max_norm / (||g|| * inv_scale + 1e-6)) (torch.nn.utils.clip_grad_norm_), then torch's Adam:
+//   grad += wd * p;  m = b1 m + (1 - b1) grad;  v = b2 v + (1 - b2) grad^2;
+//   p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps),  t = *step (already advanced by the caller).
+__global__ __launch_bounds__(MT_BLOCK) void mt_adam(const long long* __restrict__ table, int n, int chunk,
+                                                    const float* __restrict__ skip_flag, const float* __restrict__ lr_ptr,
+                                                    float lr_host, float beta1, float beta2, float eps, float wd,
+                                                    const int* __restrict__ step_ptr, const float* __restrict__ inv_scale,
+                                                    const float* __restrict__ gnorm, float max_norm) {
+  if (skip_flag && *skip_flag != 0.f) return;   // GradScaler found_inf -> the step is skipped
+  const MtTable t = mt_view(table, n);
+  const long long c = blockIdx.x;
+  const int ti = mt_find(t, c);
+  const long long off = (c - t.chunk_start[ti]) * chunk;
+  long long len = t.size[ti] - off;
+  if (len > chunk) len = chunk;
+  const float lr = lr_ptr ? *lr_ptr : lr_host;
+  const float is = inv_scale ? *inv_scale : 1.0f;
+  float gs = is;
+  if (gnorm && max_norm > 0.f) {
+    const float coef = max_norm / (*gnorm * is + 1e-6f);
+    if (coef < 1.0f) gs = is * coef;
+  }
+  const int step = *step_ptr;
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+  const float step_size = lr / bc1;
+  const float rsq_bc2 = 1.0f / sqrtf(bc2);
+  const float* g = (const float*)t.ptr[0 * n + ti] + off;
+  float* p = (float*)t.ptr[1 * n + ti] + off;
+  float* m = (float*)t.ptr[2 * n + ti] + off;
+  float* v = (float*)t.ptr[3 * n + ti] + off;
+  for (long long i = threadIdx.x; i < len; i += MT_BLOCK) {
+    float gr = g[i] * gs;
+    const float pi = p[i];
+    gr += wd * pi;
+    const float mi = beta1 * m[i] + (1.f - beta1) * gr;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gr * gr;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - step_size * mi / (sqrtf(vi) * rsq_bc2 + eps);
+  }
+}
+
 // -------------------------------------------------------------------- C ABI
 extern "C" int64_t dle_mt_table_len(int n_tensors, int n_lists) {
   return (int64_t)n_tensors + (n_tensors + 1) + (int64_t)n_lists * n_tensors;
@@ -460,6 +506,19 @@ extern "C" int dle_mt_sgd(const int64_t* table_dev, int n_tensors, int64_t total
   else { dle_set_error("mt_sgd: bad dtype %d", grad_dtype); return -1; }
 #undef GO
 #undef GO3
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dle_mt_adam(const int64_t* table_dev, int n_tensors, int64_t total_chunks, int chunk,
+                           const float* skip_flag_dev, const float* lr_dev, float lr_host, float beta1, float beta2,
+                           float eps, float weight_decay, const int* step_dev, const float* inv_scale_dev,
+                           const float* grad_norm_dev, float max_grad_norm, hipStream_t stream) {
+  DLE_CHECK_ARG(table_dev && step_dev, "mt_adam: null table / step");
+  if (n_tensors == 0 || total_chunks == 0) return 0;
+  hipLaunchKernelGGL(mt_adam, dim3((unsigned)total_chunks), dim3(MT_BLOCK), 0, stream, (const long long*)table_dev, n_tensors,
+                     chunk, skip_flag_dev, lr_dev, lr_host, beta1, beta2, eps, weight_decay, step_dev, inv_scale_dev,
+                     grad_norm_dev, max_grad_norm);
   DLE_LAUNCH_CHECK();
   return 0;
 }

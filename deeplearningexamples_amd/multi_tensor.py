@@ -111,3 +111,15 @@ def sgd(table, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False
            int(has_momentum), C.ptr(skip_flag), C.ptr(lr_dev), 0.0 if lr_dev is not None else float(lr),
            momentum, dampening, weight_decay, int(nesterov), int(first_step), C.ptr(inv_scale), copy_dt,
            C.stream())
+
+
+def adam(table, lr, beta1, beta2, eps, weight_decay, step, skip_flag=None, inv_scale=None, grad_norm=None,
+         max_grad_norm=0.0):
+    """lists: g, p, exp_avg, exp_avg_sq (fp32).  GradScaler.unscale_ + clip_grad_norm_ + torch.optim.Adam.step in one pass
+    (SpeechSynthesis/Tacotron2/train.py:400-401,487-497); `step` = int32 device word holding THIS update's step number."""
+    if table.n_lists != 4 or any(d != torch.float32 for d in table.dtypes):
+        raise ValueError("adam expects four fp32 lists: g, p, exp_avg, exp_avg_sq")
+    lr_dev = lr if isinstance(lr, torch.Tensor) else None
+    C.call("dle_mt_adam", C.ptr(table.table), table.n, table.total_chunks, table.chunk, C.ptr(skip_flag), C.ptr(lr_dev),
+           0.0 if lr_dev is not None else float(lr), beta1, beta2, eps, weight_decay, C.ptr(step), C.ptr(inv_scale),
+           C.ptr(grad_norm), float(max_grad_norm if grad_norm is not None else 0.0), C.stream())

@@ -1,0 +1,285 @@
+"""WaveGlow train step on the gfx950 library: the AMP + data-parallel iteration of
+SpeechSynthesis/Tacotron2/train.py:474-500 for `-m WaveGlow` -- model forward (waveglow/model.py:188-231), WaveGlowLoss
+(waveglow/loss_function.py:30-48), scaled backward, GradScaler.unscale_ + clip_grad_norm_, torch.optim.Adam, GradScaler.update
+-- as a fixed sequence of C-ABI launches on one HIP stream with an explicit backward (no autograd tape).  No CPU path.
+
+Layout (see csrc/waveglow.hip): a series [B, C, T] of the reference is the matrix [B*T, C]; M = B * T / 8 rows of grouped
+audio.  Every Conv1d is a dle_gemm over rows:
+  * ConvTranspose1d(80, 80, 1024, stride 256): ONE GEMM [B*Fq, 4*80] x [256*80, 4*80]^T whose output, time-major [B, T, 80],
+    read as [M, 640] IS the grouped spectrogram with its channels in (g, mel) order -- the cond weights are laid out to match;
+  * the 8 cond_layers of ALL 12 flows: one GEMM spect [M, 640] -> [M, 12*8*2nc]; its backward is one data-gradient GEMM with
+    K = 12*8*2nc and one weight-gradient GEMM, so the spectrogram gradient is accumulated in fp32 inside the contraction;
+  * dilated in_layers: row gather (dle_wg_taps) + GEMM with K = 3 nc, the cond slice added in the epilogue (DLE_ACT_ADD);
+  * res_skip_layers: two GEMMs (residual half + skip half), the running sums added in the epilogue;
+  * start / end (n_half <= 4 channels): GEMMs with the narrow side zero-padded to 8.
+The flow state stays fp32 ([M, 8]); 16-bit tensors are the GEMM operands and WN activations, as under autocast.
+"""
+import torch
+
+from .. import _cabi as C
+from .. import functional as F
+from .. import multi_tensor as mt
+from ..dlrm.engine import GradScalerState
+from ..utils.buckets import GradBuckets
+from . import ops
+from .model import UPSAMPLE_KERNEL, UPSAMPLE_STRIDE, FlatViews, WaveGlow, flow_channels
+
+
+class _Flow:
+    """Per-flow 16-bit weight operands (rebuilt from the fp32 masters every step) and saved forward tensors."""
+    __slots__ = ("c", "nh", "w_start", "w_in", "w_rs", "w_end", "winv_t", "state", "y", "a0", "xs", "acts", "out", "o")
+
+
+class WaveGlowTrainer:
+    def __init__(self, model: WaveGlow, lr=1e-4, weight_decay=0.0, grad_clip_thresh=65504.0, sigma=1.0,
+                 compute_dtype=torch.float16, amp=True, init_loss_scale=65536.0, growth_interval=2000, world_size=1,
+                 process_group=None, bucket_mb=25):
+        self.model, self.cfg = model, model.cfg
+        self.dev = model.store.flat.device
+        self.dtype = compute_dtype
+        self.lr, self.wd, self.clip, self.sigma = float(lr), float(weight_decay), float(grad_clip_thresh), float(sigma)
+        self.world, self.pg = world_size, process_group
+        wn = self.cfg["WN_config"]
+        self.nc, self.nl, self.ks = wn["n_channels"], wn["n_layers"], wn["kernel_size"]
+        self.mel, self.ng, self.nf = self.cfg["n_mel_channels"], self.cfg["n_group"], self.cfg["n_flows"]
+        if self.nc % 8 or self.mel % 8 or self.ks % 2 == 0:
+            raise ValueError("n_channels and n_mel_channels must be multiples of 8, kernel_size odd")
+        self.chans = flow_channels(self.cfg)
+        self.p = model.store                                             # fp32 masters (views of one flat buffer)
+        self.g = FlatViews(model.layout, self.dev)                       # fp32 gradients, same offsets
+        self.m = FlatViews(model.layout, self.dev)                       # Adam exp_avg
+        self.v = FlatViews(model.layout, self.dev)                       # Adam exp_avg_sq
+        self.scaler = GradScalerState(self.dev, enabled=amp, init_scale=init_loss_scale, growth_interval=growth_interval)
+        self.step_t = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.noop = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.lr_t = torch.full((1,), self.lr, dtype=torch.float32, device=self.dev)
+        self._tables = mt.TableCache()
+        self.cond_cols = self.nf * self.nl * 2 * self.nc                 # columns of the all-flows cond / pre-activation matrices
+        self.w_cond = torch.zeros((self.cond_cols, self.mel * self.ng), dtype=self.dtype, device=self.dev)
+        self.flows = []
+        for (c, nh) in self.chans:
+            f = _Flow()
+            f.c, f.nh = c, nh
+            f.w_start = torch.zeros((self.nc, 8), dtype=self.dtype, device=self.dev)
+            f.w_in = [torch.zeros((2 * self.nc, self.ks * self.nc), dtype=self.dtype, device=self.dev) for _ in range(self.nl)]
+            f.w_rs = [torch.zeros((2 * self.nc if i < self.nl - 1 else self.nc, self.nc), dtype=self.dtype, device=self.dev)
+                      for i in range(self.nl)]
+            f.w_end = torch.zeros((8, self.nc), dtype=self.dtype, device=self.dev)      # rows >= 2 nh stay zero
+            self.flows.append(f)
+        self.logdets = torch.zeros(self.nf, dtype=torch.float32, device=self.dev)
+        self.signs = torch.ones(self.nf, dtype=torch.float32, device=self.dev)
+        self.buckets = None
+        if world_size > 1:
+            # the flat gradient follows the forward order, backward completes it from the end: reverse buckets (like BERT)
+            named = [(n, s) for n, _, s in model.layout]
+            self.comm_stream = torch.cuda.Stream() if self.dev.type == "cuda" else None
+            self.buckets = GradBuckets(self.g.flat, named, bucket_mb=bucket_mb, group=process_group,
+                                       comm_stream=self.comm_stream, reverse=True)
+            from ..utils.comm import broadcast_
+            broadcast_(self.p.flat, 0, process_group)                    # DDP broadcasts rank 0's weights at wrap time
+
+    # ------------------------------------------------------------------ weights: fp32 masters -> 16-bit GEMM operands
+    def _prepare_weights(self):
+        p, nc, nl = self.p, self.nc, self.nl
+        self.w_up, self.b_up = ops.upsample_weight(p["upsample.weight"], p["upsample.bias"], self.dtype, UPSAMPLE_STRIDE)
+        for k, f in enumerate(self.flows):
+            pre = "WN.%d." % k
+            ops.weight_norm_fwd(p[pre + "start.weight_v"], p[pre + "start.weight_g"], f.w_start, cip=8)
+            ops.weight_norm_fwd(p[pre + "end.weight"], None, f.w_end)
+            for i in range(nl):
+                ops.weight_norm_fwd(p[pre + "in_layers.%d.weight_v" % i], p[pre + "in_layers.%d.weight_g" % i], f.w_in[i])
+                r0 = (k * nl + i) * 2 * nc
+                # the reference's grouped spectrogram has channel = mel * 8 + g, the time-major rows here g * 80 + mel: the
+                # [2nc, 640, 1] weight read as [2nc, 80 "channels", 8 "taps"] lands in exactly that order (tap-major operand)
+                ops.weight_norm_fwd(p[pre + "cond_layers.%d.weight_v" % i].view(2 * nc, self.mel, self.ng),
+                                    p[pre + "cond_layers.%d.weight_g" % i], self.w_cond[r0:r0 + 2 * nc])
+                ops.weight_norm_fwd(p[pre + "res_skip_layers.%d.weight_v" % i], p[pre + "res_skip_layers.%d.weight_g" % i],
+                                    f.w_rs[i])
+            f.winv_t = ops.logdet_inv(p["convinv.%d.conv.weight" % k], f.c, self.logdets[k:k + 1], self.signs[k:k + 1])
+
+    def _cond_bias(self):
+        """The cond-layer biases of all flows: contiguous in the flat parameter buffer (model.param_layout), (flow, layer) major
+        like the rows of w_cond."""
+        off, _ = self.p.offsets["WN.0.cond_layers.0.bias"]
+        return self.p.flat[off:off + self.cond_cols]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, mel, audio):
+        """mel fp32 [B, 80, frames], audio fp32 [B, T] -> loss fp32 [1]; keeps what backward needs."""
+        C.require_cuda(mel, audio)
+        nc, nl, ng = self.nc, self.nl, self.ng
+        b, t = audio.shape
+        if t % ng or mel.dtype != torch.float32 or audio.dtype != torch.float32:
+            raise ValueError("audio length must be a multiple of n_group; inputs are fp32")
+        fq = (t + UPSAMPLE_STRIDE - 1) // UPSAMPLE_STRIDE
+        if mel.shape[0] != b or mel.shape[1] != self.mel or mel.shape[2] < fq:
+            # waveglow/model.py:198 asserts spect.size(2) >= audio.size(1); frames past the segment never reach it
+            raise ValueError("mel must be [B, %d, >= %d frames]" % (self.mel, fq))
+        self._prepare_weights()
+        self.b, self.t, self.fq, self.tg = b, t, fq, t // ng
+        m = b * self.tg
+        self.M = m
+        ntap = UPSAMPLE_KERNEL // UPSAMPLE_STRIDE
+        mel_cl = F.nchw_to_nhwc(mel[:, :, :fq].contiguous().view(b, self.mel, fq, 1), self.dtype, c_padded=self.mel)
+        self.col_mel = ops.taps(mel_cl.view(b * fq, self.mel), b, fq, ntap, -1, 0)
+        up = F.gemm(self.col_mel, self.w_up, b * fq, UPSAMPLE_STRIDE * self.mel, ntap * self.mel, True, True, bias=self.b_up)
+        if fq * UPSAMPLE_STRIDE == t:
+            spect = up.view(m, self.mel * ng)
+        else:                                                            # drop the tail of the last frame block (model.py:199-200)
+            spect = torch.empty((b, t * self.mel), dtype=self.dtype, device=self.dev)
+            F.copy_rows(up.view(b, fq * UPSAMPLE_STRIDE * self.mel)[:, :t * self.mel], spect)
+            spect = spect.view(m, self.mel * ng)
+        self.spect = spect
+        # every cond_layer of every flow in one contraction
+        self.cond = F.gemm(spect, self.w_cond, m, self.cond_cols, self.mel * ng, True, True, bias=self._cond_bias())
+        self.s_all = torch.empty((m, self.cond_cols), dtype=self.dtype, device=self.dev)
+        state = audio.contiguous().view(m, ng)
+        parts = ops.coupling_partials(m)
+        self.logs_partial = torch.zeros((self.nf, parts), dtype=torch.float32, device=self.dev)
+        for k, f in enumerate(self.flows):
+            pre = "WN.%d." % k
+            f.state = state
+            f.y, f.a0 = ops.invconv_fwd(state, self.p["convinv.%d.conv.weight" % k], f.c, self.dtype)
+            x = F.gemm(f.a0, f.w_start, m, nc, 8, True, True, bias=self.p[pre + "start.bias"])
+            f.xs, f.acts = [], []
+            out = None
+            for i in range(nl):
+                d = 2 ** i
+                c0 = (k * nl + i) * 2 * nc
+                col = ops.taps(x, b, self.tg, self.ks, d, self.ks // 2)
+                s_i = self.s_all[:, c0:c0 + 2 * nc]
+                F.gemm(col, f.w_in[i], m, 2 * nc, self.ks * nc, True, True, out=s_i, bias=self.p[pre + "in_layers.%d.bias" % i],
+                       act=C.ACT_ADD, mask_src=self.cond[:, c0:c0 + 2 * nc])
+                acts = ops.gate_fwd(s_i, nc)
+                f.xs.append(x)
+                f.acts.append(acts)
+                b_rs = self.p[pre + "res_skip_layers.%d.bias" % i]
+                if i < nl - 1:
+                    x = F.gemm(acts, f.w_rs[i][:nc], m, nc, nc, True, True, bias=b_rs[:nc], act=C.ACT_ADD, mask_src=x)
+                    w_skip, b_skip = f.w_rs[i][nc:], b_rs[nc:]
+                else:
+                    w_skip, b_skip = f.w_rs[i], b_rs
+                out = F.gemm(acts, w_skip, m, nc, nc, True, True, bias=b_skip, act=C.ACT_ADD if out is not None else C.ACT_NONE,
+                             mask_src=out)
+            f.out = out
+            f.o = F.gemm(out, f.w_end, m, 8, nc, True, True, bias=self.p.slot(pre + "end.bias"), out_dtype=torch.float32)
+            state = ops.coupling_fwd(f.y, f.o, f.c, self.logs_partial[k])
+        self.z = state
+        self.loss = ops.loss(state, self.logs_partial.view(-1), self.logdets, self.sigma)
+        return self.loss
+
+    # ------------------------------------------------------------------ backward (gradients scaled by the loss scale)
+    def backward(self):
+        nc, nl, m, b = self.nc, self.nl, self.M, self.b
+        p, g, scale = self.p, self.g, self.scaler.scale
+        count = float(m * self.ng)
+        dz = ops.dz_init(self.z, scale, 1.0 / (self.sigma * self.sigma * count))
+        ds_all = torch.empty((m, self.cond_cols), dtype=self.dtype, device=self.dev)
+        d_rs = torch.empty((m, 2 * nc), dtype=self.dtype, device=self.dev)
+        dw_tmp = torch.empty(2 * nc * self.ks * nc, dtype=torch.float32, device=self.dev)       # largest GEMM-layout weight gradient
+        for k in range(self.nf - 1, -1, -1):
+            f = self.flows[k]
+            pre = "WN.%d." % k
+            dy, d_o = ops.coupling_bwd(dz, f.y, f.o, scale, 1.0 / count, f.c, self.dtype)
+            # end: data gradient straight into the skip half of d_rs, weight / bias gradients into their 8-wide slots
+            F.gemm(d_o, f.w_end, m, nc, 8, True, False, out=d_rs[:, nc:])
+            F.gemm(d_o, f.out, 8, nc, m, False, False, out=g.slot(pre + "end.weight").view(8, nc), splitk=F.pick_splitk(8, nc, m))
+            F.colsum(d_o, out=g.slot(pre + "end.bias"))
+            d_x0 = None
+            for i in range(nl - 1, -1, -1):
+                last = i == nl - 1
+                c0 = (k * nl + i) * 2 * nc
+                g_rs = d_rs[:, nc:] if last else d_rs                    # last layer: res_skip has the skip half only
+                rs = nc if last else 2 * nc
+                d_acts = F.gemm(g_rs, f.w_rs[i], m, nc, rs, True, False)
+                dw = dw_tmp[:rs * nc].view(rs, nc)
+                F.gemm(g_rs, f.acts[i], rs, nc, m, False, False, out=dw, splitk=F.pick_splitk(rs, nc, m))
+                self._wn_bwd(pre + "res_skip_layers.%d" % i, dw)
+                F.colsum(g_rs, out=g[pre + "res_skip_layers.%d.bias" % i])
+                ds_i = ops.gate_bwd(d_acts, self.s_all[:, c0:c0 + 2 * nc], ds_all[:, c0:c0 + 2 * nc])
+                gb = g[pre + "in_layers.%d.bias" % i]
+                F.colsum(ds_i, out=gb)
+                g[pre + "cond_layers.%d.bias" % i].copy_(gb)              # s = in_layer + cond_layer: the same column sums
+                col = ops.taps(f.xs[i], b, self.tg, self.ks, 2 ** i, self.ks // 2)
+                dw = dw_tmp[:2 * nc * self.ks * nc].view(2 * nc, self.ks * nc)
+                F.gemm(ds_i, col, 2 * nc, self.ks * nc, m, False, False, out=dw, splitk=F.pick_splitk(2 * nc, self.ks * nc, m))
+                self._wn_bwd(pre + "in_layers.%d" % i, dw)
+                dcol = F.gemm(ds_i, f.w_in[i], m, self.ks * nc, 2 * nc, True, False)
+                add = None if last else d_rs[:, :nc]                     # + the residual path's gradient (audio = res + audio)
+                if i > 0:
+                    ops.taps_bwd(dcol, b, self.tg, nc, self.ks, 2 ** i, self.ks // 2, out=d_rs[:, :nc], addend=add)
+                else:
+                    d_x0 = torch.empty((m, nc), dtype=self.dtype, device=self.dev)
+                    ops.taps_bwd(dcol, b, self.tg, nc, self.ks, 1, self.ks // 2, out=d_x0, addend=add)
+            # start
+            da0 = F.gemm(d_x0, f.w_start, m, 8, nc, True, False, out_dtype=torch.float32)
+            dw = dw_tmp[:nc * 8].view(nc, 8)
+            F.gemm(d_x0, f.a0, nc, 8, m, False, False, out=dw, splitk=F.pick_splitk(nc, 8, m))
+            self._wn_bwd(pre + "start", dw, cip=8)
+            F.colsum(d_x0, out=g[pre + "start.bias"])
+            dz = ops.invconv_bwd(dy, da0, f.state, p["convinv.%d.conv.weight" % k], f.winv_t,
+                                 g["convinv.%d.conv.weight" % k], scale, 1.0 / self.ng, f.c)
+        # cond layers of all flows: one weight-gradient GEMM, one data-gradient GEMM (K = all cond columns)
+        kc = self.mel * self.ng
+        dw_cond = torch.empty((self.cond_cols, kc), dtype=torch.float32, device=self.dev)
+        F.gemm(ds_all, self.spect, self.cond_cols, kc, m, False, False, out=dw_cond, splitk=F.pick_splitk(self.cond_cols, kc, m))
+        for k in range(self.nf):
+            for i in range(nl):
+                r0 = (k * nl + i) * 2 * nc
+                self._wn_bwd("WN.%d.cond_layers.%d" % (k, i), dw_cond[r0:r0 + 2 * nc], as_shape=(2 * nc, self.mel, self.ng))
+        d_spect = F.gemm(ds_all, self.w_cond, m, kc, self.cond_cols, True, False)
+        # upsampling
+        fq, t = self.fq, self.t
+        cols = UPSAMPLE_STRIDE * self.mel
+        if fq * UPSAMPLE_STRIDE == t:
+            d_up = d_spect.view(b * fq, cols)
+        else:
+            d_up = torch.zeros((b, fq * cols), dtype=self.dtype, device=self.dev)
+            F.copy_rows(d_spect.view(b, t * self.mel), d_up[:, :t * self.mel])
+            d_up = d_up.view(b * fq, cols)
+        kk = self.col_mel.shape[1]
+        db = torch.empty((cols, kk), dtype=torch.float32, device=self.dev)
+        F.gemm(d_up, self.col_mel, cols, kk, b * fq, False, False, out=db, splitk=F.pick_splitk(cols, kk, b * fq))
+        ops.upsample_weight_bwd(db, g["upsample.weight"], UPSAMPLE_STRIDE)
+        F.colsum(d_up.view(b * fq * UPSAMPLE_STRIDE, self.mel), out=g["upsample.bias"])
+        if self.buckets is not None:
+            # The cond-layer gradients of every flow exist only now (one GEMM for all flows), so the buckets go out after the
+            # backward pass: ~1 GB of fp32 gradients at the reference's size = 2 x 7/8 x 1 GB over 7 x ~153 GB/s ~ 1.7 ms at N = 8.
+            for _, _, name in self.buckets.buckets:
+                self.buckets.grad_ready(name)
+
+    def _wn_bwd(self, name, dw, cip=None, as_shape=None):
+        v, dv = self.p[name + ".weight_v"], self.g[name + ".weight_v"]
+        if as_shape is not None:
+            v, dv = v.view(as_shape), dv.view(as_shape)
+        ops.weight_norm_bwd(dw, v, self.p[name + ".weight_g"], dv, self.g[name + ".weight_g"], cip=cip)
+
+    # ------------------------------------------------------------------ optimizer (train.py:487-497)
+    def optimizer_step(self):
+        sc = self.scaler
+        if self.buckets is not None:
+            self.buckets.wait()
+        t_g = self._tables.get("g", [[self.g.flat]])
+        if sc.enabled:
+            F.check_nonfinite_(self.g.flat, sc.found_inf)
+        self.noop.copy_(sc.found_inf.to(torch.int32))
+        self.step_t += (1 - self.noop)                                   # Adam's state step advances only when the step is taken
+        gnorm, _ = mt.l2norm(t_g)
+        self.grad_norm = gnorm
+        t_adam = self._tables.get("adam", [[self.g.flat], [self.p.flat], [self.m.flat], [self.v.flat]],
+                                  chunk=mt.streaming_chunk([[self.g.flat]]))
+        mt.adam(t_adam, self.lr_t, 0.9, 0.999, 1e-8, self.wd, self.step_t, skip_flag=sc.found_inf if sc.enabled else None,
+                inv_scale=sc.inv_scale if sc.enabled else None, grad_norm=gnorm, max_grad_norm=self.clip)
+        sc.update()
+
+    def set_lr(self, lr):
+        """adjust_learning_rate (train.py:324-342) computes the value on the host once per iteration."""
+        if lr != self.lr:
+            self.lr = float(lr)
+            self.lr_t.fill_(self.lr)
+
+    def train_step(self, mel, audio):
+        loss = self.forward(mel, audio)
+        self.backward()
+        self.optimizer_step()
+        return loss

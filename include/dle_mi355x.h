@@ -344,6 +344,58 @@ int dle_attention_bwd(const void* qkv, const void* dctx, const float* mask_add, 
                       float* colsum_partial, int B, int S, int heads, int head_dim, float scale, float p, uint64_t seed,
                       uint64_t offset, const uint64_t* offset_base, int dtype, hipStream_t stream);
 
+/* ---- torch.optim.Adam over a tensor table (csrc/multi_tensor.hip): GradScaler.unscale_ + clip_grad_norm_ + Adam.step of
+ * SpeechSynthesis/Tacotron2/train.py:400-401,487-497 in one pass.  lists: g, p, exp_avg, exp_avg_sq (all fp32).
+ * step_dev: int32 device word = the step number t of THIS update (the caller advances it when the step is not skipped);
+ * grad_norm_dev: L2 norm of the (still scaled) gradients from dle_mt_l2norm, max_grad_norm <= 0 disables clipping. */
+int dle_mt_adam(const int64_t* table_dev, int n_tensors, int64_t total_chunks, int chunk, const float* skip_flag_dev,
+                const float* lr_dev, float lr_host, float beta1, float beta2, float eps, float weight_decay,
+                const int* step_dev, const float* inv_scale_dev, const float* grad_norm_dev, float max_grad_norm,
+                hipStream_t stream);
+
+/* ---- WaveGlow training step (csrc/waveglow.hip): SpeechSynthesis/Tacotron2/waveglow/model.py + loss_function.py -------
+ * Channels-last: a series [B, C, T] of the reference is the matrix [B*T, C]; Conv1d = dle_gemm over rows.  The flow state
+ * is fp32 [M, 8] (M = B*T/8 groups of n_group = 8 samples); a flow with c remaining channels works on columns [8-c, 8).
+ * dle_wg_taps: row gather of a k-tap dilated Conv1d, col[b,t,k*C+ch] = x[b, t+(k-left)*dilation, ch] (0 outside [0,T));
+ *   WN in_layers (model.py:112-118, left = 1) and ConvTranspose1d(1024, stride 256) (model.py:165-167; dilation -1, left 0).
+ * dle_wg_taps_bwd: its transpose, dx[b,t,ch] = sum_k dcol[b, t-(k-left)*dilation, k*C+ch] (+ addend; dx may alias addend).
+ * dle_wg_gate_fwd/bwd: fused_add_tanh_sigmoid_multiply (model.py:34-41) on the summed pre-activation s [M, 2nc] (row stride ld).
+ * dle_wg_invconv_fwd/bwd: Invertible1x1Conv.forward (model.py:62-85) on the active channels, and its backward incl. the
+ *   d/dW of the log-determinant term; dle_wg_logdet_inv: log|det W|, sign and W^-T of the c x c matrix (torch.logdet).
+ * dle_wg_coupling_fwd/bwd: audio_1 = exp(log_s) * audio_1 + b (model.py:217-222); o fp32 [M, 8] = (b | log_s | 0).
+ * dle_wg_loss / dle_wg_dz_init: WaveGlowLoss.forward (loss_function.py:30-48) and its gradient wrt z.
+ * dle_wg_weight_norm_fwd/bwd: torch.nn.utils.weight_norm(dim 0) of Conv1d weights (model.py:95-136) -> 16-bit GEMM operand
+ *   w16[co, tap*Cip + ci]; g NULL = plain weight.  dle_wg_upsample_weight(_bwd): ConvTranspose1d weight [Cm, Cm, ksize] <->
+ *   GEMM operand b16[(r*Cm+co), (j*Cm+ci)] = w[ci, co, r + stride*j] and the bias repeated per phase r. */
+int dle_wg_taps(const void* x, void* col, int B, int T, int C, int ntaps, int dilation, int left, int dtype,
+                hipStream_t stream);
+int dle_wg_taps_bwd(const void* dcol, const void* addend, void* dx, int B, int T, int C, int ntaps, int dilation, int left,
+                    int64_t ld_add, int64_t ld_dx, int dtype, hipStream_t stream);
+int dle_wg_gate_fwd(const void* s, void* acts, int64_t M, int nc, int64_t ld_s, int dtype, hipStream_t stream);
+int dle_wg_gate_bwd(const void* dacts, const void* s, void* ds, int64_t M, int nc, int64_t ld_s, int64_t ld_ds, int dtype,
+                    hipStream_t stream);
+int dle_wg_invconv_fwd(const float* x, const float* W, float* y, void* a0_16, int64_t M, int c, int dtype,
+                       hipStream_t stream);
+int dle_wg_invconv_bwd_partials(int64_t M);
+int dle_wg_invconv_bwd(const float* dy, const float* da0, const float* x, const float* W, const float* WinvT, float* dx,
+                       float* dW, const float* scale_dev, float logdet_coef, float* workspace, int64_t M, int c,
+                       hipStream_t stream);
+int dle_wg_logdet_inv(const float* W, float* logdet, float* WinvT, float* sign, int c, hipStream_t stream);
+int dle_wg_coupling_partials(int64_t M);
+int dle_wg_coupling_fwd(const float* y, const float* o, float* z, float* logs_partial, int64_t M, int c, hipStream_t stream);
+int dle_wg_coupling_bwd(const float* dz, const float* y, const float* o, float* dy, void* d_o16, const float* scale_dev,
+                        float logs_coef, int64_t M, int c, int dtype, hipStream_t stream);
+int dle_wg_loss(const float* z, const float* logs_partial, int n_logs, const float* logdets, int n_flows, float sigma,
+                int64_t M, float* loss_out, float* workspace, hipStream_t stream);
+int dle_wg_dz_init(const float* z, float* dz, const float* scale_dev, float coef, int64_t M, hipStream_t stream);
+int dle_wg_weight_norm_fwd(const float* v, const float* g, void* w16, int Co, int Ci, int Kt, int Cip, int dtype,
+                           hipStream_t stream);
+int dle_wg_weight_norm_bwd(const float* dw, const float* v, const float* g, float* dv, float* dg, int Co, int Ci, int Kt,
+                           int Cip, hipStream_t stream);
+int dle_wg_upsample_weight(const float* w, const float* bias, void* b16, float* bias_rep, int Cm, int ksize, int stride,
+                           int dtype, hipStream_t stream);
+int dle_wg_upsample_weight_bwd(const float* db, float* dw, int Cm, int ksize, int stride, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
