@@ -297,14 +297,24 @@ class WaveGlowWorkload:
         self.samples_per_step = self.batch * self.segment * world
         self.scaling = "weak"
         self.loss = None
+        # ~2,500 launches of ~15 us per step: the step is captured in a HIP graph (utils/graph.py, the reference's
+        # CudaGraphWrapper idea) unless DLE_WG_GRAPH=0; multi-rank runs stay eager (the bucket all-reduce is not captured)
+        from deeplearningexamples_amd.utils.graph import GraphedStep
+        self.graphed = world == 1 and os.environ.get("DLE_WG_GRAPH", "1") != "0"
+        self._step = GraphedStep(self.trainer.train_step, enabled=self.graphed, warmup_steps=2)
 
     def step(self):
-        self.loss = self.trainer.train_step(self.mel, self.audio)
+        from deeplearningexamples_amd import _cabi
+        if self.graphed and _cabi._timer is not None:      # the per-launch event pass of bench.py needs real launches
+            self.loss = self.trainer.train_step(self.mel, self.audio)
+        else:
+            self.loss = self._step(self.mel, self.audio)
 
     def config(self):
         return {"workload": "WaveGlow training (PyTorch/SpeechSynthesis/Tacotron2 -m WaveGlow), 12 flows x 8 layers x 512 "
                             "channels, synthetic LJSpeech-shaped mel / audio segments (BASELINE.json configs[4], WaveGlow half)",
                 "batch_per_gpu": self.batch, "segment_length": self.segment, "unit_note": "audio samples / s",
+                "hip_graph": bool(self.graphed),
                 "parallelism": "single GPU" if self.world == 1 else "dp%d" % self.world}
 
     def dtype_name(self):
