@@ -129,6 +129,9 @@ _SIGS = {
     "dle_wg_weight_norm_bwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "dle_wg_upsample_weight": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "dle_wg_upsample_weight_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dle_wg_weight_norm_fwd_batched": (c_int, [c_void_p, c_int, c_i64, c_int, c_void_p]),
+    "dle_wg_weight_norm_bwd_batched": (c_int, [c_void_p, c_int, c_i64, c_void_p]),
+    "dle_wg_logdet_inv_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
 }
 
 _lib = None

@@ -258,9 +258,8 @@ __global__ void wg_invconv_wfinish_kernel(const float* __restrict__ partial, int
 
 // log |det W| and W^{-T} of one c x c matrix (c <= 8), Gauss-Jordan with partial pivoting in fp64 on one lane.
 // (torch.logdet(W) returns nan for det < 0; the sign is reported so the host side can refuse such a matrix.)
-__global__ void wg_logdet_inv_kernel(const float* __restrict__ W, float* __restrict__ logdet, float* __restrict__ WinvT,
-                                     float* __restrict__ sign_out, int c) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void wg_logdet_inv_one(const float* __restrict__ W, float* __restrict__ logdet,
+                                                  float* __restrict__ WinvT, float* __restrict__ sign_out, int c) {
   double a[8][16];
   for (int i = 0; i < c; ++i)
     for (int j = 0; j < c; ++j) { a[i][j] = (double)W[i * c + j]; a[i][c + j] = (i == j) ? 1.0 : 0.0; }
@@ -289,6 +288,22 @@ __global__ void wg_logdet_inv_kernel(const float* __restrict__ W, float* __restr
   if (sign_out) *sign_out = (float)sign;
   for (int i = 0; i < c; ++i)
     for (int j = 0; j < c; ++j) WinvT[i * c + j] = (float)a[j][c + i];     // (W^-1)^T [i, j] = W^-1 [j, i]
+}
+
+__global__ void wg_logdet_inv_kernel(const float* __restrict__ W, float* __restrict__ logdet, float* __restrict__ WinvT,
+                                     float* __restrict__ sign_out, int c) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  wg_logdet_inv_one(W, logdet, WinvT, sign_out, c);
+}
+
+// every flow of the network in one launch: workgroup f handles the matrix at base + table[2f] (c = table[2f + 1]),
+// WinvT slot f = 64 floats
+__global__ void wg_logdet_inv_batched_kernel(const float* __restrict__ base, const long long* __restrict__ table,
+                                             float* __restrict__ logdets, float* __restrict__ WinvT,
+                                             float* __restrict__ signs) {
+  if (threadIdx.x != 0) return;
+  const int f = blockIdx.x;
+  wg_logdet_inv_one(base + table[2 * f], logdets + f, WinvT + (long long)f * 64, signs ? signs + f : nullptr, (int)table[2 * f + 1]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -409,10 +424,8 @@ __global__ __launch_bounds__(WG_BLOCK) void wg_dz_init_kernel(const float* __res
 // the 16-bit GEMM operand w16[co, tap * Cip + ci] (Cip >= Ci: zero-padded input channels).  g == NULL: plain weight.
 // One wavefront per output channel.
 template <int DT>
-__global__ __launch_bounds__(64) void wg_weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
-                                                                unsigned short* __restrict__ w16, int Co, int Ci, int Kt,
-                                                                int Cip) {
-  const int co = blockIdx.x;
+__device__ __forceinline__ void wg_weight_norm_fwd_row(const float* __restrict__ v, const float* __restrict__ g,
+                                                       unsigned short* __restrict__ w16, int co, int Ci, int Kt, int Cip) {
   const int n = Ci * Kt;
   const float* vr = v + (long long)co * n;
   float f = 1.0f;
@@ -430,12 +443,18 @@ __global__ __launch_bounds__(64) void wg_weight_norm_fwd_kernel(const float* __r
   }
 }
 
+template <int DT>
+__global__ __launch_bounds__(64) void wg_weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                                unsigned short* __restrict__ w16, int Co, int Ci, int Kt,
+                                                                int Cip) {
+  wg_weight_norm_fwd_row<DT>(v, g, w16, blockIdx.x, Ci, Kt, Cip);
+}
+
 // dw fp32 [Co, Kt * Cip] (the wgrad GEMM's layout) -> dv [Co, Ci, Kt], dg [Co]:
 //   dg = <dw, v> / ||v||;  dv = (g / ||v||) * (dw - v * <dw, v> / ||v||^2).   g == NULL: dv = dw (re-laid out).
-__global__ __launch_bounds__(64) void wg_weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
-                                                                const float* __restrict__ g, float* __restrict__ dv,
-                                                                float* __restrict__ dg, int Co, int Ci, int Kt, int Cip) {
-  const int co = blockIdx.x;
+__device__ __forceinline__ void wg_weight_norm_bwd_row(const float* __restrict__ dw, const float* __restrict__ v,
+                                                       const float* __restrict__ g, float* __restrict__ dv,
+                                                       float* __restrict__ dg, int co, int Ci, int Kt, int Cip) {
   const int n = Ci * Kt;
   const float* vr = v + (long long)co * n;
   const float* dr = dw + (long long)co * Kt * Cip;
@@ -463,6 +482,41 @@ __global__ __launch_bounds__(64) void wg_weight_norm_bwd_kernel(const float* __r
     const int ci = i / Kt, tap = i - ci * Kt;
     dvr[i] = gg * inv * (dr[tap * Cip + ci] - vr[i] * d * inv * inv);
   }
+}
+
+__global__ __launch_bounds__(64) void wg_weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
+                                                                const float* __restrict__ g, float* __restrict__ dv,
+                                                                float* __restrict__ dg, int Co, int Ci, int Kt, int Cip) {
+  wg_weight_norm_bwd_row(dw, v, g, dv, dg, blockIdx.x, Ci, Kt, Cip);
+}
+
+// Every weight of the network in ONE launch (the per-tensor form is ~600 launches of ~10 us per step at the reference's
+// size): a device table of WG_WN_FIELDS int64 per tensor
+//   { row_start, Co, Ci, Kt, Cip, v, g (0: plain), w16, dw, dv, dg }
+// sorted by row_start; workgroup r (one wavefront) finds its tensor by binary search and handles row r - row_start.
+#define WG_WN_FIELDS 11
+__device__ __forceinline__ int wg_wn_find(const long long* __restrict__ table, int n, long long row) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[(long long)mid * WG_WN_FIELDS] <= row) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+template <int DT>
+__global__ __launch_bounds__(64) void wg_weight_norm_fwd_batched_kernel(const long long* __restrict__ table, int n) {
+  const long long row = blockIdx.x;
+  const long long* e = table + (long long)wg_wn_find(table, n, row) * WG_WN_FIELDS;
+  wg_weight_norm_fwd_row<DT>((const float*)e[5], (const float*)e[6], (unsigned short*)e[7], (int)(row - e[0]), (int)e[2],
+                             (int)e[3], (int)e[4]);
+}
+
+__global__ __launch_bounds__(64) void wg_weight_norm_bwd_batched_kernel(const long long* __restrict__ table, int n) {
+  const long long row = blockIdx.x;
+  const long long* e = table + (long long)wg_wn_find(table, n, row) * WG_WN_FIELDS;
+  wg_weight_norm_bwd_row((const float*)e[8], (const float*)e[5], (const float*)e[6], (float*)e[9], (float*)e[10],
+                         (int)(row - e[0]), (int)e[2], (int)e[3], (int)e[4]);
 }
 
 // ConvTranspose1d(Cm, Cm, ksize, stride) with ksize = ntap * stride as ONE GEMM (model.py:165-167, 197):
@@ -713,6 +767,40 @@ extern "C" int dle_wg_upsample_weight_bwd(const float* db, float* dw, int Cm, in
   DLE_CHECK_ARG(db && dw && Cm > 0 && stride > 0 && ksize > 0 && ksize % stride == 0, "wg_upsample_weight_bwd: bad args");
   const long long total = (long long)ksize * Cm * Cm;
   hipLaunchKernelGGL(wg_upsample_weight_bwd_kernel, dim3(wg_grid(total)), dim3(WG_BLOCK), 0, stream, db, dw, Cm, ksize, stride);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// Table-driven forms (one launch for the whole network).  table_dev: n_entries x 11 int64 = { row_start, Co, Ci, Kt, Cip,
+// v, g (0: plain weight), w16, dw, dv, dg } (device pointers as integers), sorted by row_start, total_rows = sum of Co.
+extern "C" int dle_wg_weight_norm_fwd_batched(const int64_t* table_dev, int n_entries, int64_t total_rows, int dtype,
+                                              hipStream_t stream) {
+  DLE_CHECK_ARG(table_dev && n_entries > 0 && total_rows > 0 && total_rows < 0x7fffffffLL, "wg_weight_norm_fwd_batched: bad args");
+  WG_DT_CHECK("wg_weight_norm_fwd_batched");
+  if (dtype == DLE_F16)
+    hipLaunchKernelGGL(wg_weight_norm_fwd_batched_kernel<DLE_F16>, dim3((unsigned)total_rows), dim3(64), 0, stream,
+                       (const long long*)table_dev, n_entries);
+  else
+    hipLaunchKernelGGL(wg_weight_norm_fwd_batched_kernel<DLE_BF16>, dim3((unsigned)total_rows), dim3(64), 0, stream,
+                       (const long long*)table_dev, n_entries);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dle_wg_weight_norm_bwd_batched(const int64_t* table_dev, int n_entries, int64_t total_rows, hipStream_t stream) {
+  DLE_CHECK_ARG(table_dev && n_entries > 0 && total_rows > 0 && total_rows < 0x7fffffffLL, "wg_weight_norm_bwd_batched: bad args");
+  hipLaunchKernelGGL(wg_weight_norm_bwd_batched_kernel, dim3((unsigned)total_rows), dim3(64), 0, stream,
+                     (const long long*)table_dev, n_entries);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// table_dev: n_flows x 2 int64 = { element offset of the c x c matrix from `base`, c }; WinvT: n_flows x 64 floats.
+extern "C" int dle_wg_logdet_inv_batched(const float* base, const int64_t* table_dev, float* logdets, float* WinvT,
+                                         float* signs, int n_flows, hipStream_t stream) {
+  DLE_CHECK_ARG(base && table_dev && logdets && WinvT && n_flows > 0, "wg_logdet_inv_batched: bad args");
+  hipLaunchKernelGGL(wg_logdet_inv_batched_kernel, dim3(n_flows), dim3(64), 0, stream, base, (const long long*)table_dev,
+                     logdets, WinvT, signs);
   DLE_LAUNCH_CHECK();
   return 0;
 }

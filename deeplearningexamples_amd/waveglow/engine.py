@@ -9,10 +9,14 @@ audio.  Every Conv1d is a dle_gemm over rows:
     read as [M, 640] IS the grouped spectrogram with its channels in (g, mel) order -- the cond weights are laid out to match;
   * the 8 cond_layers of ALL 12 flows: one GEMM spect [M, 640] -> [M, 12*8*2nc]; its backward is one data-gradient GEMM with
     K = 12*8*2nc and one weight-gradient GEMM, so the spectrogram gradient is accumulated in fp32 inside the contraction;
-  * dilated in_layers: row gather (dle_wg_taps) + GEMM with K = 3 nc, the cond slice added in the epilogue (DLE_ACT_ADD);
+  * dilated in_layers: row gather (dle_wg_taps) + GEMM with K = 3 nc, the cond slice added in the epilogue (DLE_ACT_ADD); the
+    gathered rows of every (flow, layer) are kept, and ALL in_layer weight gradients are one batched GEMM after the backward
+    sweep (96 slices of 1024 x 1536 x M fill the chip; one by one they needed split-K slabs + a reduction each);
   * res_skip_layers: two GEMMs (residual half + skip half), the running sums added in the epilogue;
   * start / end (n_half <= 4 channels): GEMMs with the narrow side zero-padded to 8.
-The flow state stays fp32 ([M, 8]); 16-bit tensors are the GEMM operands and WN activations, as under autocast.
+Weight normalisation (fp32 masters -> 16-bit operands, GEMM-layout gradients -> dv, dg) and the 12 log-determinants run as ONE
+table-driven launch each.  The flow state stays fp32 ([M, 8]); 16-bit tensors are the GEMM operands and WN activations, as
+under autocast.
 """
 import torch
 
@@ -27,7 +31,7 @@ from .model import UPSAMPLE_KERNEL, UPSAMPLE_STRIDE, FlatViews, WaveGlow, flow_c
 
 class _Flow:
     """Per-flow 16-bit weight operands (rebuilt from the fp32 masters every step) and saved forward tensors."""
-    __slots__ = ("c", "nh", "w_start", "w_in", "w_rs", "w_end", "winv_t", "state", "y", "a0", "xs", "acts", "out", "o")
+    __slots__ = ("c", "nh", "w_start", "w_in", "w_rs", "w_end", "dw_start", "dw_rs", "winv_t", "state", "y", "a0", "out", "o")
 
 
 class WaveGlowTrainer:
@@ -35,79 +39,97 @@ class WaveGlowTrainer:
                  compute_dtype=torch.float16, amp=True, init_loss_scale=65536.0, growth_interval=2000, world_size=1,
                  process_group=None, bucket_mb=25):
         self.model, self.cfg = model, model.cfg
-        self.dev = model.store.flat.device
-        self.dtype = compute_dtype
+        self.dev = dev = model.store.flat.device
+        self.dtype = dt = compute_dtype
         self.lr, self.wd, self.clip, self.sigma = float(lr), float(weight_decay), float(grad_clip_thresh), float(sigma)
         self.world, self.pg = world_size, process_group
         wn = self.cfg["WN_config"]
-        self.nc, self.nl, self.ks = wn["n_channels"], wn["n_layers"], wn["kernel_size"]
+        self.nc, self.nl, self.ks = nc, nl, ks = wn["n_channels"], wn["n_layers"], wn["kernel_size"]
         self.mel, self.ng, self.nf = self.cfg["n_mel_channels"], self.cfg["n_group"], self.cfg["n_flows"]
-        if self.nc % 8 or self.mel % 8 or self.ks % 2 == 0:
+        if nc % 8 or self.mel % 8 or ks % 2 == 0:
             raise ValueError("n_channels and n_mel_channels must be multiples of 8, kernel_size odd")
         self.chans = flow_channels(self.cfg)
-        self.p = model.store                                             # fp32 masters (views of one flat buffer)
-        self.g = FlatViews(model.layout, self.dev)                       # fp32 gradients, same offsets
-        self.m = FlatViews(model.layout, self.dev)                       # Adam exp_avg
-        self.v = FlatViews(model.layout, self.dev)                       # Adam exp_avg_sq
-        self.scaler = GradScalerState(self.dev, enabled=amp, init_scale=init_loss_scale, growth_interval=growth_interval)
-        self.step_t = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        self.noop = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        self.lr_t = torch.full((1,), self.lr, dtype=torch.float32, device=self.dev)
+        self.p = p = model.store                                         # fp32 masters (views of one flat buffer)
+        self.g = g = FlatViews(model.layout, dev)                        # fp32 gradients, same offsets
+        self.m = FlatViews(model.layout, dev)                            # Adam exp_avg
+        self.v = FlatViews(model.layout, dev)                            # Adam exp_avg_sq
+        self.scaler = GradScalerState(dev, enabled=amp, init_scale=init_loss_scale, growth_interval=growth_interval)
+        self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.noop = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.lr_t = torch.full((1,), self.lr, dtype=torch.float32, device=dev)
         self._tables = mt.TableCache()
-        self.cond_cols = self.nf * self.nl * 2 * self.nc                 # columns of the all-flows cond / pre-activation matrices
-        self.w_cond = torch.zeros((self.cond_cols, self.mel * self.ng), dtype=self.dtype, device=self.dev)
-        self.flows = []
-        for (c, nh) in self.chans:
+        self.cond_cols = self.nf * nl * 2 * nc                           # columns of the all-flows cond / pre-activation matrices
+        kc = self.mel * self.ng
+        # 16-bit GEMM operands and fp32 GEMM-layout weight gradients: persistent, so that ONE table drives each direction
+        self.w_cond = torch.zeros((self.cond_cols, kc), dtype=dt, device=dev)
+        self.dw_cond = torch.zeros((self.cond_cols, kc), dtype=torch.float32, device=dev)
+        self.w_in = torch.zeros((self.nf * nl, 2 * nc, ks * nc), dtype=dt, device=dev)
+        self.dw_in = torch.zeros((self.nf * nl, 2 * nc, ks * nc), dtype=torch.float32, device=dev)
+        self.flows, fwd, bwd, ld = [], [], [], []
+        for k, (c, nh) in enumerate(self.chans):
             f = _Flow()
             f.c, f.nh = c, nh
-            f.w_start = torch.zeros((self.nc, 8), dtype=self.dtype, device=self.dev)
-            f.w_in = [torch.zeros((2 * self.nc, self.ks * self.nc), dtype=self.dtype, device=self.dev) for _ in range(self.nl)]
-            f.w_rs = [torch.zeros((2 * self.nc if i < self.nl - 1 else self.nc, self.nc), dtype=self.dtype, device=self.dev)
-                      for i in range(self.nl)]
-            f.w_end = torch.zeros((8, self.nc), dtype=self.dtype, device=self.dev)      # rows >= 2 nh stay zero
+            pre = "WN.%d." % k
+            f.w_start = torch.zeros((nc, 8), dtype=dt, device=dev)
+            f.dw_start = torch.zeros((nc, 8), dtype=torch.float32, device=dev)
+            f.w_end = torch.zeros((8, nc), dtype=dt, device=dev)         # rows >= 2 nh stay zero
+            f.w_in = [self.w_in[k * nl + i] for i in range(nl)]
+            f.w_rs = [torch.zeros((2 * nc if i < nl - 1 else nc, nc), dtype=dt, device=dev) for i in range(nl)]
+            f.dw_rs = [torch.zeros((2 * nc if i < nl - 1 else nc, nc), dtype=torch.float32, device=dev) for i in range(nl)]
+
+            def normed(name, w16, dw, cip=None, as_shape=None):
+                v, dv = p[name + ".weight_v"], g[name + ".weight_v"]
+                if as_shape is not None:
+                    v, dv = v.view(as_shape), dv.view(as_shape)
+                e = dict(v=v, g=p[name + ".weight_g"], w16=w16, dw=dw, dv=dv, dg=g[name + ".weight_g"], cip=cip)
+                fwd.append(e)
+                bwd.append(e)
+            normed(pre + "start", f.w_start, f.dw_start, cip=8)
+            fwd.append(dict(v=p[pre + "end.weight"], g=None, w16=f.w_end))       # plain weight; its gradient goes to its slot directly
+            for i in range(nl):
+                z = k * nl + i
+                normed(pre + "in_layers.%d" % i, self.w_in[z], self.dw_in[z])
+                # the reference's grouped spectrogram has channel = mel * 8 + g, the time-major rows here g * 80 + mel: the
+                # [2nc, 640, 1] weight read as [2nc, 80 "channels", 8 "taps"] lands in exactly that order (tap-major operand)
+                normed(pre + "cond_layers.%d" % i, self.w_cond[z * 2 * nc:(z + 1) * 2 * nc], self.dw_cond[z * 2 * nc:(z + 1) * 2 * nc],
+                       as_shape=(2 * nc, self.mel, self.ng))
+                normed(pre + "res_skip_layers.%d" % i, f.w_rs[i], f.dw_rs[i])
+            ld.append((p.offsets["convinv.%d.conv.weight" % k][0], c))
             self.flows.append(f)
-        self.logdets = torch.zeros(self.nf, dtype=torch.float32, device=self.dev)
-        self.signs = torch.ones(self.nf, dtype=torch.float32, device=self.dev)
+        self.wn_fwd = ops.WeightNormTable(fwd, dev)
+        self.wn_bwd = ops.WeightNormTable(bwd, dev)
+        self.ld_table = ops.LogdetTable(ld, dev)
+        self.logdets = torch.zeros(self.nf, dtype=torch.float32, device=dev)
+        self.signs = torch.ones(self.nf, dtype=torch.float32, device=dev)
+        self.winv_t = torch.zeros((self.nf, 64), dtype=torch.float32, device=dev)
+        for k, f in enumerate(self.flows):
+            f.winv_t = self.winv_t[k, :f.c * f.c]
         self.buckets = None
         if world_size > 1:
-            # the flat gradient follows the forward order, backward completes it from the end: reverse buckets (like BERT)
             named = [(n, s) for n, _, s in model.layout]
-            self.comm_stream = torch.cuda.Stream() if self.dev.type == "cuda" else None
-            self.buckets = GradBuckets(self.g.flat, named, bucket_mb=bucket_mb, group=process_group,
-                                       comm_stream=self.comm_stream, reverse=True)
+            self.comm_stream = torch.cuda.Stream() if dev.type == "cuda" else None
+            self.buckets = GradBuckets(g.flat, named, bucket_mb=bucket_mb, group=process_group, comm_stream=self.comm_stream,
+                                       reverse=True)
             from ..utils.comm import broadcast_
-            broadcast_(self.p.flat, 0, process_group)                    # DDP broadcasts rank 0's weights at wrap time
+            broadcast_(p.flat, 0, process_group)                         # DDP broadcasts rank 0's weights at wrap time
 
     # ------------------------------------------------------------------ weights: fp32 masters -> 16-bit GEMM operands
     def _prepare_weights(self):
-        p, nc, nl = self.p, self.nc, self.nl
+        p = self.p
         self.w_up, self.b_up = ops.upsample_weight(p["upsample.weight"], p["upsample.bias"], self.dtype, UPSAMPLE_STRIDE)
-        for k, f in enumerate(self.flows):
-            pre = "WN.%d." % k
-            ops.weight_norm_fwd(p[pre + "start.weight_v"], p[pre + "start.weight_g"], f.w_start, cip=8)
-            ops.weight_norm_fwd(p[pre + "end.weight"], None, f.w_end)
-            for i in range(nl):
-                ops.weight_norm_fwd(p[pre + "in_layers.%d.weight_v" % i], p[pre + "in_layers.%d.weight_g" % i], f.w_in[i])
-                r0 = (k * nl + i) * 2 * nc
-                # the reference's grouped spectrogram has channel = mel * 8 + g, the time-major rows here g * 80 + mel: the
-                # [2nc, 640, 1] weight read as [2nc, 80 "channels", 8 "taps"] lands in exactly that order (tap-major operand)
-                ops.weight_norm_fwd(p[pre + "cond_layers.%d.weight_v" % i].view(2 * nc, self.mel, self.ng),
-                                    p[pre + "cond_layers.%d.weight_g" % i], self.w_cond[r0:r0 + 2 * nc])
-                ops.weight_norm_fwd(p[pre + "res_skip_layers.%d.weight_v" % i], p[pre + "res_skip_layers.%d.weight_g" % i],
-                                    f.w_rs[i])
-            f.winv_t = ops.logdet_inv(p["convinv.%d.conv.weight" % k], f.c, self.logdets[k:k + 1], self.signs[k:k + 1])
+        ops.weight_norm_fwd_batched(self.wn_fwd, self.dtype)
+        ops.logdet_inv_batched(p.flat, self.ld_table, self.logdets, self.winv_t, self.signs)
 
-    def _cond_bias(self):
-        """The cond-layer biases of all flows: contiguous in the flat parameter buffer (model.param_layout), (flow, layer) major
-        like the rows of w_cond."""
-        off, _ = self.p.offsets["WN.0.cond_layers.0.bias"]
-        return self.p.flat[off:off + self.cond_cols]
+    def _bias_block(self, store, first):
+        """A (flow, layer)-major block of 2nc-wide biases that is contiguous in the flat buffers (model.param_layout)."""
+        off, _ = store.offsets[first]
+        return store.flat[off:off + self.cond_cols]
 
     # ------------------------------------------------------------------ forward
     def forward(self, mel, audio):
         """mel fp32 [B, 80, frames], audio fp32 [B, T] -> loss fp32 [1]; keeps what backward needs."""
         C.require_cuda(mel, audio)
-        nc, nl, ng = self.nc, self.nl, self.ng
+        nc, nl, ng, ks = self.nc, self.nl, self.ng, self.ks
         b, t = audio.shape
         if t % ng or mel.dtype != torch.float32 or audio.dtype != torch.float32:
             raise ValueError("audio length must be a multiple of n_group; inputs are fp32")
@@ -131,8 +153,11 @@ class WaveGlowTrainer:
             spect = spect.view(m, self.mel * ng)
         self.spect = spect
         # every cond_layer of every flow in one contraction
-        self.cond = F.gemm(spect, self.w_cond, m, self.cond_cols, self.mel * ng, True, True, bias=self._cond_bias())
+        self.cond = F.gemm(spect, self.w_cond, m, self.cond_cols, self.mel * ng, True, True,
+                           bias=self._bias_block(self.p, "WN.0.cond_layers.0.bias"))
         self.s_all = torch.empty((m, self.cond_cols), dtype=self.dtype, device=self.dev)
+        self.col_all = torch.empty((self.nf * nl, m, ks * nc), dtype=self.dtype, device=self.dev)     # gathered in_layer inputs
+        self.acts_all = torch.empty((self.nf * nl, m, nc), dtype=self.dtype, device=self.dev)
         state = audio.contiguous().view(m, ng)
         parts = ops.coupling_partials(m)
         self.logs_partial = torch.zeros((self.nf, parts), dtype=torch.float32, device=self.dev)
@@ -141,18 +166,15 @@ class WaveGlowTrainer:
             f.state = state
             f.y, f.a0 = ops.invconv_fwd(state, self.p["convinv.%d.conv.weight" % k], f.c, self.dtype)
             x = F.gemm(f.a0, f.w_start, m, nc, 8, True, True, bias=self.p[pre + "start.bias"])
-            f.xs, f.acts = [], []
             out = None
             for i in range(nl):
-                d = 2 ** i
-                c0 = (k * nl + i) * 2 * nc
-                col = ops.taps(x, b, self.tg, self.ks, d, self.ks // 2)
+                z = k * nl + i
+                c0 = z * 2 * nc
+                col = ops.taps(x, b, self.tg, ks, 2 ** i, ks // 2, out=self.col_all[z])
                 s_i = self.s_all[:, c0:c0 + 2 * nc]
-                F.gemm(col, f.w_in[i], m, 2 * nc, self.ks * nc, True, True, out=s_i, bias=self.p[pre + "in_layers.%d.bias" % i],
+                F.gemm(col, f.w_in[i], m, 2 * nc, ks * nc, True, True, out=s_i, bias=self.p[pre + "in_layers.%d.bias" % i],
                        act=C.ACT_ADD, mask_src=self.cond[:, c0:c0 + 2 * nc])
-                acts = ops.gate_fwd(s_i, nc)
-                f.xs.append(x)
-                f.acts.append(acts)
+                acts = ops.gate_fwd(s_i, nc, out=self.acts_all[z])
                 b_rs = self.p[pre + "res_skip_layers.%d.bias" % i]
                 if i < nl - 1:
                     x = F.gemm(acts, f.w_rs[i][:nc], m, nc, nc, True, True, bias=b_rs[:nc], act=C.ACT_ADD, mask_src=x)
@@ -170,13 +192,12 @@ class WaveGlowTrainer:
 
     # ------------------------------------------------------------------ backward (gradients scaled by the loss scale)
     def backward(self):
-        nc, nl, m, b = self.nc, self.nl, self.M, self.b
+        nc, nl, m, b, ks = self.nc, self.nl, self.M, self.b, self.ks
         p, g, scale = self.p, self.g, self.scaler.scale
         count = float(m * self.ng)
         dz = ops.dz_init(self.z, scale, 1.0 / (self.sigma * self.sigma * count))
         ds_all = torch.empty((m, self.cond_cols), dtype=self.dtype, device=self.dev)
         d_rs = torch.empty((m, 2 * nc), dtype=self.dtype, device=self.dev)
-        dw_tmp = torch.empty(2 * nc * self.ks * nc, dtype=torch.float32, device=self.dev)       # largest GEMM-layout weight gradient
         for k in range(self.nf - 1, -1, -1):
             f = self.flows[k]
             pre = "WN.%d." % k
@@ -188,45 +209,40 @@ class WaveGlowTrainer:
             d_x0 = None
             for i in range(nl - 1, -1, -1):
                 last = i == nl - 1
-                c0 = (k * nl + i) * 2 * nc
+                z = k * nl + i
+                c0 = z * 2 * nc
                 g_rs = d_rs[:, nc:] if last else d_rs                    # last layer: res_skip has the skip half only
                 rs = nc if last else 2 * nc
                 d_acts = F.gemm(g_rs, f.w_rs[i], m, nc, rs, True, False)
-                dw = dw_tmp[:rs * nc].view(rs, nc)
-                F.gemm(g_rs, f.acts[i], rs, nc, m, False, False, out=dw, splitk=F.pick_splitk(rs, nc, m))
-                self._wn_bwd(pre + "res_skip_layers.%d" % i, dw)
+                F.gemm(g_rs, self.acts_all[z], rs, nc, m, False, False, out=f.dw_rs[i], splitk=F.pick_splitk(rs, nc, m))
                 F.colsum(g_rs, out=g[pre + "res_skip_layers.%d.bias" % i])
                 ds_i = ops.gate_bwd(d_acts, self.s_all[:, c0:c0 + 2 * nc], ds_all[:, c0:c0 + 2 * nc])
-                gb = g[pre + "in_layers.%d.bias" % i]
-                F.colsum(ds_i, out=gb)
-                g[pre + "cond_layers.%d.bias" % i].copy_(gb)              # s = in_layer + cond_layer: the same column sums
-                col = ops.taps(f.xs[i], b, self.tg, self.ks, 2 ** i, self.ks // 2)
-                dw = dw_tmp[:2 * nc * self.ks * nc].view(2 * nc, self.ks * nc)
-                F.gemm(ds_i, col, 2 * nc, self.ks * nc, m, False, False, out=dw, splitk=F.pick_splitk(2 * nc, self.ks * nc, m))
-                self._wn_bwd(pre + "in_layers.%d" % i, dw)
-                dcol = F.gemm(ds_i, f.w_in[i], m, self.ks * nc, 2 * nc, True, False)
+                dcol = F.gemm(ds_i, f.w_in[i], m, ks * nc, 2 * nc, True, False)
                 add = None if last else d_rs[:, :nc]                     # + the residual path's gradient (audio = res + audio)
                 if i > 0:
-                    ops.taps_bwd(dcol, b, self.tg, nc, self.ks, 2 ** i, self.ks // 2, out=d_rs[:, :nc], addend=add)
+                    ops.taps_bwd(dcol, b, self.tg, nc, ks, 2 ** i, ks // 2, out=d_rs[:, :nc], addend=add)
                 else:
                     d_x0 = torch.empty((m, nc), dtype=self.dtype, device=self.dev)
-                    ops.taps_bwd(dcol, b, self.tg, nc, self.ks, 1, self.ks // 2, out=d_x0, addend=add)
+                    ops.taps_bwd(dcol, b, self.tg, nc, ks, 1, ks // 2, out=d_x0, addend=add)
             # start
             da0 = F.gemm(d_x0, f.w_start, m, 8, nc, True, False, out_dtype=torch.float32)
-            dw = dw_tmp[:nc * 8].view(nc, 8)
-            F.gemm(d_x0, f.a0, nc, 8, m, False, False, out=dw, splitk=F.pick_splitk(nc, 8, m))
-            self._wn_bwd(pre + "start", dw, cip=8)
+            F.gemm(d_x0, f.a0, nc, 8, m, False, False, out=f.dw_start, splitk=F.pick_splitk(nc, 8, m))
             F.colsum(d_x0, out=g[pre + "start.bias"])
             dz = ops.invconv_bwd(dy, da0, f.state, p["convinv.%d.conv.weight" % k], f.winv_t,
                                  g["convinv.%d.conv.weight" % k], scale, 1.0 / self.ng, f.c)
-        # cond layers of all flows: one weight-gradient GEMM, one data-gradient GEMM (K = all cond columns)
+        # ---- everything that spans the flows, once
         kc = self.mel * self.ng
-        dw_cond = torch.empty((self.cond_cols, kc), dtype=torch.float32, device=self.dev)
-        F.gemm(ds_all, self.spect, self.cond_cols, kc, m, False, False, out=dw_cond, splitk=F.pick_splitk(self.cond_cols, kc, m))
-        for k in range(self.nf):
-            for i in range(nl):
-                r0 = (k * nl + i) * 2 * nc
-                self._wn_bwd("WN.%d.cond_layers.%d" % (k, i), dw_cond[r0:r0 + 2 * nc], as_shape=(2 * nc, self.mel, self.ng))
+        nz = self.nf * nl
+        # in_layer weight gradients of every (flow, layer): slice z = ds_all[:, z*2nc:(z+1)*2nc]^T x col_all[z]
+        F.gemm_batched(ds_all, self.col_all, self.dw_in, 2 * nc, ks * nc, m, self.cond_cols, ks * nc, ks * nc, False, False,
+                       nz, 1, (2 * nc, 0), (m * ks * nc, 0), (2 * nc * ks * nc, 0))
+        # cond layers: one weight-gradient GEMM, one data-gradient GEMM (K = all cond columns)
+        F.gemm(ds_all, self.spect, self.cond_cols, kc, m, False, False, out=self.dw_cond, splitk=F.pick_splitk(self.cond_cols, kc, m))
+        # s = in_layer + cond_layer: both bias gradients are the column sums of ds, contiguous blocks in (flow, layer) order
+        gb = self._bias_block(g, "WN.0.cond_layers.0.bias")
+        F.colsum(ds_all, out=gb)
+        self._bias_block(g, "WN.0.in_layers.0.bias").copy_(gb)
+        ops.weight_norm_bwd_batched(self.wn_bwd)                         # every dv, dg from the GEMM-layout gradients
         d_spect = F.gemm(ds_all, self.w_cond, m, kc, self.cond_cols, True, False)
         # upsampling
         fq, t = self.fq, self.t
@@ -243,16 +259,10 @@ class WaveGlowTrainer:
         ops.upsample_weight_bwd(db, g["upsample.weight"], UPSAMPLE_STRIDE)
         F.colsum(d_up.view(b * fq * UPSAMPLE_STRIDE, self.mel), out=g["upsample.bias"])
         if self.buckets is not None:
-            # The cond-layer gradients of every flow exist only now (one GEMM for all flows), so the buckets go out after the
+            # The cond / in_layer gradients of every flow exist only now (one GEMM for all flows), so the buckets go out after the
             # backward pass: ~1 GB of fp32 gradients at the reference's size = 2 x 7/8 x 1 GB over 7 x ~153 GB/s ~ 1.7 ms at N = 8.
             for _, _, name in self.buckets.buckets:
                 self.buckets.grad_ready(name)
-
-    def _wn_bwd(self, name, dw, cip=None, as_shape=None):
-        v, dv = self.p[name + ".weight_v"], self.g[name + ".weight_v"]
-        if as_shape is not None:
-            v, dv = v.view(as_shape), dv.view(as_shape)
-        ops.weight_norm_bwd(dw, v, self.p[name + ".weight_g"], dv, self.g[name + ".weight_g"], cip=cip)
 
     # ------------------------------------------------------------------ optimizer (train.py:487-497)
     def optimizer_step(self):

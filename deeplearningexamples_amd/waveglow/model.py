@@ -6,7 +6,7 @@ initial distributions, so a checkpoint of one loads into the other.  This class 
 kernel sequence of waveglow/engine.py.
 
 Storage: every fp32 master parameter is a view into ONE flat buffer (`flat`), laid out so that the engine's GEMM-shaped reads
-are contiguous (the cond-layer biases of all flows follow each other; `end.weight` / `end.bias` own 8-row / 8-float slots whose
+are contiguous (the cond-layer biases of all flows follow each other, so do the in-layer biases; `end.weight` / `end.bias` own 8-row / 8-float slots whose
 tail stays zero, because the `end` GEMM runs 8 output channels wide).  Gradients and the Adam moments use the same offsets
 in their own flat buffers, so the data-parallel all-reduce, the norm and the optimizer see one tensor each.
 """
@@ -49,6 +49,9 @@ def param_layout(cfg):
     for k in range(cfg["n_flows"]):                                    # contiguous: ONE bias vector for the all-flows cond GEMM
         for i in range(nl):
             add("WN.%d.cond_layers.%d.bias" % (k, i), (2 * nc,))
+    for k in range(cfg["n_flows"]):                                    # contiguous, same order: their gradients are one copy of
+        for i in range(nl):                                            # the cond-bias gradients (s = in_layer + cond_layer)
+            add("WN.%d.in_layers.%d.bias" % (k, i), (2 * nc,))
     for k, (n_rem, n_half) in enumerate(flow_channels(cfg)):
         add("convinv.%d.conv.weight" % k, (n_rem, n_rem, 1))
         pre = "WN.%d." % k
@@ -58,7 +61,6 @@ def param_layout(cfg):
         add(pre + "end.weight", (2 * n_half, nc, 1), slot=8 * nc)
         add(pre + "end.bias", (2 * n_half,), slot=8)
         for i in range(nl):
-            add(pre + "in_layers.%d.bias" % i, (2 * nc,))
             add(pre + "in_layers.%d.weight_g" % i, (2 * nc, 1, 1))
             add(pre + "in_layers.%d.weight_v" % i, (2 * nc, nc, ks))
         for i in range(nl):

@@ -185,3 +185,48 @@ def upsample_weight_bwd(db, dw, stride):
     if not db.is_contiguous() or db.dtype != torch.float32:
         raise ValueError("upsample_weight_bwd: db must be contiguous fp32")
     C.call("dle_wg_upsample_weight_bwd", C.ptr(db), C.ptr(dw), cm, ks, stride, C.stream())
+
+
+class WeightNormTable:
+    """Device table for the one-launch forms (csrc/waveglow.hip WG_WN_FIELDS): entries = dicts with v [Co, Ci, Kt] fp32,
+    g (or None), w16, dw (fp32 GEMM-layout gradient or None), dv, dg (or None), cip."""
+    FIELDS = 11
+
+    def __init__(self, entries, device):
+        import numpy as np
+        self.entries = entries
+        rows, start = [], 0
+        for e in entries:
+            co, ci, kt = e["v"].shape
+            if not e["v"].is_contiguous():
+                raise ValueError("weight-norm table: v must be contiguous")
+            ptr = [0 if e.get(k) is None else e[k].data_ptr() for k in ("v", "g", "w16", "dw", "dv", "dg")]
+            rows.append([start, co, ci, kt, e.get("cip") or ci] + ptr)
+            start += co
+        self.n, self.total_rows = len(entries), start
+        self.table = torch.from_numpy(np.asarray(rows, dtype=np.int64).reshape(-1)).to(device)
+
+
+def weight_norm_fwd_batched(tab, dtype):
+    C.call("dle_wg_weight_norm_fwd_batched", C.ptr(tab.table), tab.n, tab.total_rows, C.dt(dtype), C.stream())
+
+
+def weight_norm_bwd_batched(tab):
+    C.call("dle_wg_weight_norm_bwd_batched", C.ptr(tab.table), tab.n, tab.total_rows, C.stream())
+
+
+class LogdetTable:
+    """(element offset from the flat parameter buffer, c) of every flow's invertible 1x1 convolution."""
+
+    def __init__(self, offsets_and_c, device):
+        import numpy as np
+        self.host = list(offsets_and_c)
+        self.n = len(self.host)
+        self.table = torch.from_numpy(np.asarray(self.host, dtype=np.int64).reshape(-1)).to(device)
+
+
+def logdet_inv_batched(flat, tab, logdets, winv_t_all, signs):
+    """logdets[f], signs[f], winv_t_all[f, :c*c] for every flow in one launch."""
+    C.require_cuda(flat, logdets, winv_t_all, signs)
+    C.call("dle_wg_logdet_inv_batched", C.ptr(flat), C.ptr(tab.table), C.ptr(logdets), C.ptr(winv_t_all), C.ptr(signs), tab.n,
+           C.stream())

@@ -395,6 +395,13 @@ int dle_wg_weight_norm_bwd(const float* dw, const float* v, const float* g, floa
 int dle_wg_upsample_weight(const float* w, const float* bias, void* b16, float* bias_rep, int Cm, int ksize, int stride,
                            int dtype, hipStream_t stream);
 int dle_wg_upsample_weight_bwd(const float* db, float* dw, int Cm, int ksize, int stride, hipStream_t stream);
+/* One launch for every tensor of the network.  Weight-norm table: n_entries x 11 int64 = { row_start, Co, Ci, Kt, Cip, v, g
+ * (0: plain weight), w16, dw, dv, dg } (device addresses), sorted by row_start, total_rows = sum of Co.  Log-determinant
+ * table: n_flows x 2 int64 = { element offset of the c x c matrix from base, c }; WinvT: n_flows x 64 floats. */
+int dle_wg_weight_norm_fwd_batched(const int64_t* table_dev, int n_entries, int64_t total_rows, int dtype, hipStream_t stream);
+int dle_wg_weight_norm_bwd_batched(const int64_t* table_dev, int n_entries, int64_t total_rows, hipStream_t stream);
+int dle_wg_logdet_inv_batched(const float* base, const int64_t* table_dev, float* logdets, float* WinvT, float* signs,
+                              int n_flows, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -150,7 +150,7 @@ def invconv_bwd(dy, da0, x, w, winv_t, dw_out, scale, logdet_coef, c):
     if da0 is not None:
         g[:, off:off + nh] += da0[:, :nh]
     dx = g @ _w8(w, c)
-    dw = (g[:, off:].double().t() @ x[:, off:].double()).float() - float(scale) * logdet_coef * winv_t
+    dw = (g[:, off:].double().t() @ x[:, off:].double()).float() - float(scale) * logdet_coef * winv_t.reshape(c, c)
     dw_out.view(-1)[:c * c].copy_(dw.reshape(-1))
     return dx
 
@@ -232,6 +232,38 @@ def upsample_weight_bwd(db, dw, stride):
     dw.copy_(db.view(stride, cm, nt, cm).permute(3, 1, 2, 0).reshape(cm, cm, ks))
 
 
+def weight_norm_fwd_batched(tab, dtype):
+    for e in tab.entries:
+        weight_norm_fwd(e["v"], e.get("g"), e["w16"], e.get("cip"))
+
+
+def weight_norm_bwd_batched(tab):
+    for e in tab.entries:
+        weight_norm_bwd(e["dw"], e["v"], e.get("g"), e["dv"], e.get("dg"), e.get("cip"))
+
+
+def logdet_inv_batched(flat, tab, logdets, winv_t_all, signs):
+    for f, (off, c) in enumerate(tab.host):
+        w = flat[off:off + c * c]
+        winv_t_all[f, :c * c] = logdet_inv(w, c, logdets[f:f + 1], signs[f:f + 1]).reshape(-1)
+
+
+def gemm_batched(a, b, c, m, n, k, lda, ldb, ldc, a_kc, b_kc, batch, batch_inner, sa, sb, sc, alpha=1.0):
+    """dle_gemm_batched on flat storage: slice z = (zo, zi) of X starts at X + zo * sx[0] + zi * sx[1] (elements)."""
+
+    def view(t, off, rows, cols, ld):
+        return torch.as_strided(t, (rows, cols), (ld, 1), t.storage_offset() + off)
+    for z in range(batch):
+        zo, zi = divmod(z, batch_inner)
+        am = view(a, zo * sa[0] + zi * sa[1], m if a_kc else k, k if a_kc else m, lda)
+        bm = view(b, zo * sb[0] + zi * sb[1], n if b_kc else k, k if b_kc else n, ldb)
+        cm = view(c, zo * sc[0] + zi * sc[1], m, n, ldc)
+        am = am if a_kc else am.t()
+        bm = bm if b_kc else bm.t()
+        cm.copy_((am.double() @ bm.double().t()).float() * alpha)
+    return c
+
+
 # ---------------------------------------------------------------- csrc/multi_tensor.hip (as the engine uses it)
 class _Table:
     def __init__(self, lists, chunk):
@@ -280,11 +312,11 @@ def install(monkeypatch):
     from deeplearningexamples_amd.waveglow import engine, ops
     me = globals()
     monkeypatch.setattr(C, "require_cuda", lambda *a: None)
-    for name in ("gemm", "colsum", "copy_rows", "nchw_to_nhwc", "check_nonfinite_", "amp_update_scale_"):
+    for name in ("gemm", "gemm_batched", "colsum", "copy_rows", "nchw_to_nhwc", "check_nonfinite_", "amp_update_scale_"):
         monkeypatch.setattr(F, name, me[name])
     for name in ("taps", "taps_bwd", "gate_fwd", "gate_bwd", "invconv_fwd", "logdet_inv", "invconv_bwd", "coupling_partials",
                  "coupling_fwd", "coupling_bwd", "loss", "dz_init", "weight_norm_fwd", "weight_norm_bwd", "upsample_weight",
-                 "upsample_weight_bwd"):
+                 "upsample_weight_bwd", "weight_norm_fwd_batched", "weight_norm_bwd_batched", "logdet_inv_batched"):
         monkeypatch.setattr(ops, name, me[name])
     fake_mt = types.SimpleNamespace(TableCache=TableCache, streaming_chunk=streaming_chunk, l2norm=l2norm, adam=adam)
     monkeypatch.setattr(engine, "mt", fake_mt)

@@ -299,6 +299,61 @@ def test_adam_with_unscale_clip_and_skip(cuda):
     _close(dev[1], ref_p, rtol=1e-4, atol=2e-6)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_table_driven_weight_norm_and_logdet(cuda, dtype):
+    """One launch for every tensor (dle_wg_weight_norm_{fwd,bwd}_batched, dle_wg_logdet_inv_batched) == the per-tensor statements."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    shapes = [(64, 4, 1, 8), (128, 64, 3, 64), (8, 64, 1, 64), (128, 80, 8, 80), (64, 64, 1, 64), (1024, 512, 3, 512), (6, 64, 1, 64)]
+    host, dev = [], []
+    for co, ci, kt, cip in shapes:
+        plain = co in (8, 6)                                  # `end`: no gain, no gradient entry
+        e = dict(v=torch.randn(co, ci, kt, generator=g) * 0.1, g=None if plain else 1 + 0.1 * torch.randn(co, 1, 1, generator=g),
+                 w16=torch.zeros(co, kt * cip, dtype=dtype), dw=torch.randn(co, kt * cip, generator=g), dv=torch.zeros(co, ci, kt),
+                 dg=None if plain else torch.zeros(co, 1, 1), cip=cip)
+        host.append(e)
+        dev.append({k: (v.to(cuda) if isinstance(v, torch.Tensor) else v) for k, v in e.items()})
+    ops.weight_norm_fwd_batched(ops.WeightNormTable(dev, cuda), dtype)
+    D.weight_norm_fwd_batched(ops.WeightNormTable(host, "cpu"), dtype)
+    for h, d in zip(host, dev):
+        _close(d["w16"], h["w16"], rtol=2e-3 if dtype == torch.float16 else 1e-2, atol=1e-6)
+    hn, dn = [e for e in host if e["g"] is not None], [e for e in dev if e["g"] is not None]
+    ops.weight_norm_bwd_batched(ops.WeightNormTable(dn, cuda))
+    D.weight_norm_bwd_batched(ops.WeightNormTable(hn, "cpu"))
+    for h, d in zip(hn, dn):
+        _close(d["dv"], h["dv"], rtol=1e-4, atol=1e-4)
+        _close(d["dg"], h["dg"], rtol=1e-4, atol=1e-4)
+    flat = torch.zeros(400)
+    entries = []
+    for off, c in ((8, 8), (96, 8), (200, 6), (264, 4), (320, 2)):
+        flat[off:off + c * c] = _rot(c, g).reshape(-1)
+        entries.append((off, c))
+    nf = len(entries)
+    ld, sg, wi = torch.zeros(nf, device=cuda), torch.zeros(nf, device=cuda), torch.zeros(nf, 64, device=cuda)
+    ops.logdet_inv_batched(flat.to(cuda), ops.LogdetTable(entries, cuda), ld, wi, sg)
+    ldr, sgr, wir = torch.zeros(nf), torch.zeros(nf), torch.zeros(nf, 64)
+    D.logdet_inv_batched(flat, ops.LogdetTable(entries, "cpu"), ldr, wir, sgr)
+    _close(ld, ldr, rtol=1e-5, atol=1e-6)
+    _close(wi, wir, rtol=1e-4, atol=1e-5)
+    assert torch.equal(sg.cpu(), sgr)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_all_in_layer_weight_gradients_as_one_batched_gemm(cuda, dtype):
+    """dw_in[z] = ds_all[:, z*2nc:(z+1)*2nc]^T x col_all[z]: column-sliced A (row stride = all columns), fp32 output."""
+    from deeplearningexamples_amd import functional as F
+    g = torch.Generator().manual_seed(31)
+    for m, nc, nz in ((1000, 64, 6), (512, 128, 3)):
+        ds = (torch.randn(m, nz * 2 * nc, generator=g) * 0.3).to(dtype)
+        col = (torch.randn(nz, m, 3 * nc, generator=g) * 0.3).to(dtype)
+        args = (2 * nc, 3 * nc, m, nz * 2 * nc, 3 * nc, 3 * nc, False, False, nz, 1, (2 * nc, 0), (m * 3 * nc, 0), (2 * nc * 3 * nc, 0))
+        got = F.gemm_batched(ds.to(cuda), col.to(cuda), torch.zeros(nz, 2 * nc, 3 * nc, device=cuda), *args)
+        ref = D.gemm_batched(ds, col, torch.zeros(nz, 2 * nc, 3 * nc), *args)
+        _close(got, ref, rtol=2e-3, atol=2e-2)
+        direct = torch.stack([ds[:, z * 2 * nc:(z + 1) * 2 * nc].float().t() @ col[z].float() for z in range(nz)])
+        _close(got, direct, rtol=2e-3, atol=2e-2)
+
+
 # ------------------------------------------------------------------------------------------------- the step
 def _trainer(cuda, dtype, cfg=None, seed=None, **kw):
     from oracle import waveglow_oracle as WO
