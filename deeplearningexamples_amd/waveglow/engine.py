@@ -234,8 +234,13 @@ class WaveGlowTrainer:
         kc = self.mel * self.ng
         nz = self.nf * nl
         # in_layer weight gradients of every (flow, layer): slice z = ds_all[:, z*2nc:(z+1)*2nc]^T x col_all[z]
-        F.gemm_batched(ds_all, self.col_all, self.dw_in, 2 * nc, ks * nc, m, self.cond_cols, ks * nc, ks * nc, False, False,
-                       nz, 1, (2 * nc, 0), (m * ks * nc, 0), (2 * nc * ks * nc, 0))
+        if m % 8 == 0:
+            F.gemm_batched(ds_all, self.col_all, self.dw_in, 2 * nc, ks * nc, m, self.cond_cols, ks * nc, ks * nc, False, False,
+                           nz, 1, (2 * nc, 0), (m * ks * nc, 0), (2 * nc * ks * nc, 0))
+        else:                          # the batched kernel wants the contraction (M rows) in 16-byte steps; any other batch x segment
+            for z in range(nz):        # goes slice by slice through dle_gemm (which has an unaligned path)
+                F.gemm(ds_all[:, z * 2 * nc:(z + 1) * 2 * nc], self.col_all[z], 2 * nc, ks * nc, m, False, False, out=self.dw_in[z],
+                       splitk=F.pick_splitk(2 * nc, ks * nc, m))
         # cond layers: one weight-gradient GEMM, one data-gradient GEMM (K = all cond columns)
         F.gemm(ds_all, self.spect, self.cond_cols, kc, m, False, False, out=self.dw_cond, splitk=F.pick_splitk(self.cond_cols, kc, m))
         # s = in_layer + cond_layer: both bias gradients are the column sums of ds, contiguous blocks in (flow, layer) order

@@ -131,7 +131,34 @@ def run_dlrm(rank, world, dev, steps):
     return {"losses": losses, "probe": probe}
 
 
-SCENARIOS = {"bert": run_bert, "rn50": run_rn50, "dlrm": run_dlrm}
+def run_waveglow(rank, world, dev, steps):
+    from oracle import waveglow_oracle as WO
+    from deeplearningexamples_amd.waveglow.engine import WaveGlowTrainer
+    from deeplearningexamples_amd.waveglow.model import WaveGlow
+    c = WO.WAVEGLOW_CASE
+    torch.manual_seed(300 + rank)                           # replicas are built DIFFERENTLY; the trainer must sync them
+    model = WaveGlow(**c["cfg"], device=dev)
+    if rank == 0:
+        model.load_reference_state(WO.seeded_state(c["cfg"], c["seed"]))
+    # lr: Adam moves every element by ~lr per step whatever the gradient size; small enough that an element whose 16-bit gradient
+    # changes sign between the 1-rank and the 2-rank evaluation stays inside the probe tolerance of the test
+    tr = WaveGlowTrainer(model, lr=2e-5, grad_clip_thresh=0.5, compute_dtype=torch.float16, init_loss_scale=1024.0,
+                         world_size=world, bucket_mb=1)
+    mel, audio = WO.seeded_inputs(dict(c, batch=4))
+    per = 4 // world                                        # equal halves: the mean of the rank losses is the full-batch loss
+    mine = [t[rank * per:(rank + 1) * per].contiguous().to(dev) for t in (mel, audio)]
+    losses = []
+    for _ in range(steps):
+        loss = tr.train_step(*mine)
+        if world > 1:
+            from deeplearningexamples_amd.utils import comm
+            loss = comm.allreduce_mean_(loss.clone())
+        losses.append(float(loss.item()))
+    probe = model.state_dict()["WN.1.in_layers.1.weight_v"].detach().float().cpu().numpy().reshape(-1)[:16].tolist()
+    return {"losses": losses, "probe": probe, "nbuckets": len(tr.buckets.buckets) if tr.buckets else 0}
+
+
+SCENARIOS = {"bert": run_bert, "rn50": run_rn50, "dlrm": run_dlrm, "waveglow": run_waveglow}
 
 
 def main():
