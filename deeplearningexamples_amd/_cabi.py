@@ -112,7 +112,7 @@ _SIGS = {
                            c_float, c_float, c_int, c_int, c_void_p, c_int, c_void_p]),
     "dle_mt_adam": (c_int, [c_void_p, c_int, c_i64, c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                             c_float, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
-    "dle_wg_taps": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "dle_wg_taps": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_i64, c_int, c_void_p]),
     "dle_wg_taps_bwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_i64, c_i64, c_int, c_void_p]),
     "dle_wg_gate_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p]),
     "dle_wg_gate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_int, c_void_p]),

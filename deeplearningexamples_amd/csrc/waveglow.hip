@@ -31,9 +31,9 @@ static int wg_grid(long long items, int per_block = WG_BLOCK) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Row gather for k-tap (dilated) 1-D convolutions: col[b, t, k*C + c] = x[b, t + (k - left) * dil, c], zero outside
-// [0, T).  16 bytes (8 channels) per lane; C % 8 == 0.
+// [0, T).  16 bytes (8 channels) per lane; C % 8 == 0; x may be a column slice of a wider matrix (row stride ld_x).
 __global__ __launch_bounds__(WG_BLOCK) void wg_taps_kernel(const uint4_t* __restrict__ x, uint4_t* __restrict__ col,
-                                                           int B, int T, int C8, int ntaps, int dil, int left) {
+                                                           int B, int T, int C8, int ntaps, int dil, int left, long long ldx8) {
   const long long total = (long long)B * T * ntaps * C8;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C8);
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(WG_BLOCK) void wg_taps_kernel(const uint4_t* __rest
     const long long b = r / T;
     const long long ts = (long long)t + (long long)(k - left) * dil;
     uint4_t v = {0u, 0u, 0u, 0u};
-    if (ts >= 0 && ts < T) v = x[(b * T + ts) * C8 + c];
+    if (ts >= 0 && ts < T) v = x[(b * T + ts) * ldx8 + c];
     col[i] = v;
   }
 }
@@ -561,13 +561,14 @@ __global__ __launch_bounds__(WG_BLOCK) void wg_upsample_weight_bwd_kernel(const 
 #define WG_AL16(p) ((((uintptr_t)(p)) & 15) == 0)
 
 extern "C" int dle_wg_taps(const void* x, void* col, int B, int T, int C, int ntaps, int dilation, int left,
-                           int dtype, hipStream_t stream) {
+                           int64_t ld_x, int dtype, hipStream_t stream) {
   DLE_CHECK_ARG(x && col && B > 0 && T > 0 && C > 0 && ntaps > 0, "wg_taps: bad args");
   WG_DT_CHECK("wg_taps");
-  DLE_CHECK_ARG(C % 8 == 0 && WG_AL16(x) && WG_AL16(col), "wg_taps: C %% 8 == 0 and 16-byte aligned tensors");
+  DLE_CHECK_ARG(C % 8 == 0 && ld_x % 8 == 0 && ld_x >= C && WG_AL16(x) && WG_AL16(col),
+                "wg_taps: C, ld_x %% 8 == 0, ld_x >= C and 16-byte aligned tensors");
   const long long total = (long long)B * T * ntaps * (C / 8);
   hipLaunchKernelGGL(wg_taps_kernel, dim3(wg_grid(total)), dim3(WG_BLOCK), 0, stream, (const uint4_t*)x, (uint4_t*)col, B, T,
-                     C / 8, ntaps, dilation, left);
+                     C / 8, ntaps, dilation, left, (long long)(ld_x / 8));
   DLE_LAUNCH_CHECK();
   return 0;
 }

@@ -12,7 +12,7 @@ audio.  Every Conv1d is a dle_gemm over rows:
   * dilated in_layers: row gather (dle_wg_taps) + GEMM with K = 3 nc, the cond slice added in the epilogue (DLE_ACT_ADD); the
     gathered rows of every (flow, layer) are kept, and ALL in_layer weight gradients are one batched GEMM after the backward
     sweep (96 slices of 1024 x 1536 x M fill the chip; one by one they needed split-K slabs + a reduction each);
-  * res_skip_layers: two GEMMs (residual half + skip half), the running sums added in the epilogue;
+  * res_skip_layers: one GEMM per layer over a two-halves buffer [audio | skip sum], the previous halves added in the epilogue;
   * start / end (n_half <= 4 channels): GEMMs with the narrow side zero-padded to 8.
 Weight normalisation (fp32 masters -> 16-bit operands, GEMM-layout gradients -> dv, dg) and the 12 log-determinants run as ONE
 table-driven launch each.  The flow state stays fp32 ([M, 8]); 16-bit tensors are the GEMM operands and WN activations, as
@@ -165,25 +165,28 @@ class WaveGlowTrainer:
             pre = "WN.%d." % k
             f.state = state
             f.y, f.a0 = ops.invconv_fwd(state, self.p["convinv.%d.conv.weight" % k], f.c, self.dtype)
-            x = F.gemm(f.a0, f.w_start, m, nc, 8, True, True, bias=self.p[pre + "start.bias"])
-            out = None
+            # xo = [audio | running skip sum], two [M, 2nc] buffers in turn: ONE res_skip GEMM per layer writes both halves and
+            # adds the previous layer's halves in its epilogue (model.py:150-156: audio = res + audio, output = output + skip)
+            xo = [torch.empty((m, 2 * nc), dtype=self.dtype, device=self.dev) for _ in range(2)]
+            F.gemm(f.a0, f.w_start, m, nc, 8, True, True, bias=self.p[pre + "start.bias"], out=xo[0][:, :nc])
+            xo[0][:, nc:].zero_()
+            cur = 0
             for i in range(nl):
                 z = k * nl + i
                 c0 = z * 2 * nc
-                col = ops.taps(x, b, self.tg, ks, 2 ** i, ks // 2, out=self.col_all[z])
+                col = ops.taps(xo[cur][:, :nc], b, self.tg, ks, 2 ** i, ks // 2, out=self.col_all[z])
                 s_i = self.s_all[:, c0:c0 + 2 * nc]
                 F.gemm(col, f.w_in[i], m, 2 * nc, ks * nc, True, True, out=s_i, bias=self.p[pre + "in_layers.%d.bias" % i],
                        act=C.ACT_ADD, mask_src=self.cond[:, c0:c0 + 2 * nc])
                 acts = ops.gate_fwd(s_i, nc, out=self.acts_all[z])
                 b_rs = self.p[pre + "res_skip_layers.%d.bias" % i]
                 if i < nl - 1:
-                    x = F.gemm(acts, f.w_rs[i][:nc], m, nc, nc, True, True, bias=b_rs[:nc], act=C.ACT_ADD, mask_src=x)
-                    w_skip, b_skip = f.w_rs[i][nc:], b_rs[nc:]
-                else:
-                    w_skip, b_skip = f.w_rs[i], b_rs
-                out = F.gemm(acts, w_skip, m, nc, nc, True, True, bias=b_skip, act=C.ACT_ADD if out is not None else C.ACT_NONE,
-                             mask_src=out)
-            f.out = out
+                    F.gemm(acts, f.w_rs[i], m, 2 * nc, nc, True, True, bias=b_rs, act=C.ACT_ADD, mask_src=xo[cur], out=xo[1 - cur])
+                else:                                                    # the last layer has the skip half only
+                    F.gemm(acts, f.w_rs[i], m, nc, nc, True, True, bias=b_rs, act=C.ACT_ADD, mask_src=xo[cur][:, nc:],
+                           out=xo[1 - cur][:, nc:])
+                cur = 1 - cur
+            f.out = out = xo[cur][:, nc:]
             f.o = F.gemm(out, f.w_end, m, 8, nc, True, True, bias=self.p.slot(pre + "end.bias"), out_dtype=torch.float32)
             state = ops.coupling_fwd(f.y, f.o, f.c, self.logs_partial[k])
         self.z = state

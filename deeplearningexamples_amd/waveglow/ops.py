@@ -16,15 +16,19 @@ def _row_view(t, what):
 
 
 def taps(x, batch, steps, ntaps, dilation, left, out=None):
-    """col[b*T+t, k*C+c] = x[b*T + t + (k-left)*dilation, c] inside a sample, 0 outside.  x [batch*steps, C] 16-bit contiguous."""
+    """col[b*T+t, k*C+c] = x[b*T + t + (k-left)*dilation, c] inside a sample, 0 outside.  x [batch*steps, C] 16-bit, possibly a
+    column slice of a wider matrix (row-strided view)."""
     C.require_cuda(x, out)
-    if x.dim() != 2 or not x.is_contiguous() or x.shape[0] != batch * steps:
-        raise ValueError("taps: x must be a contiguous [batch*steps, C] matrix")
+    ld_x = _row_view(x, "taps x")
+    if x.shape[0] != batch * steps:
+        raise ValueError("taps: x must have batch*steps rows")
     ch = x.shape[1]
     if out is None:
         out = torch.empty((batch * steps, ntaps * ch), dtype=x.dtype, device=x.device)
+    if not out.is_contiguous() or out.numel() != batch * steps * ntaps * ch:
+        raise ValueError("taps: out must be a contiguous [batch*steps, ntaps*C] matrix")
     C.annotate(bytes=float(x.numel() + out.numel()) * x.element_size(), tag="%dx%dx%d" % (batch * steps, ch, ntaps))
-    C.call("dle_wg_taps", C.ptr(x), C.ptr(out), batch, steps, ch, ntaps, dilation, left, C.dt(x), C.stream())
+    C.call("dle_wg_taps", C.ptr(x), C.ptr(out), batch, steps, ch, ntaps, dilation, left, ld_x, C.dt(x), C.stream())
     return out
 
 

@@ -356,7 +356,7 @@ int dle_mt_adam(const int64_t* table_dev, int n_tensors, int64_t total_chunks, i
 /* ---- WaveGlow training step (csrc/waveglow.hip): SpeechSynthesis/Tacotron2/waveglow/model.py + loss_function.py -------
  * Channels-last: a series [B, C, T] of the reference is the matrix [B*T, C]; Conv1d = dle_gemm over rows.  The flow state
  * is fp32 [M, 8] (M = B*T/8 groups of n_group = 8 samples); a flow with c remaining channels works on columns [8-c, 8).
- * dle_wg_taps: row gather of a k-tap dilated Conv1d, col[b,t,k*C+ch] = x[b, t+(k-left)*dilation, ch] (0 outside [0,T));
+ * dle_wg_taps: row gather of a k-tap dilated Conv1d, col[b,t,k*C+ch] = x[b, t+(k-left)*dilation, ch] (0 outside [0,T); x rows ld_x apart);
  *   WN in_layers (model.py:112-118, left = 1) and ConvTranspose1d(1024, stride 256) (model.py:165-167; dilation -1, left 0).
  * dle_wg_taps_bwd: its transpose, dx[b,t,ch] = sum_k dcol[b, t-(k-left)*dilation, k*C+ch] (+ addend; dx may alias addend).
  * dle_wg_gate_fwd/bwd: fused_add_tanh_sigmoid_multiply (model.py:34-41) on the summed pre-activation s [M, 2nc] (row stride ld).
@@ -367,7 +367,7 @@ int dle_mt_adam(const int64_t* table_dev, int n_tensors, int64_t total_chunks, i
  * dle_wg_weight_norm_fwd/bwd: torch.nn.utils.weight_norm(dim 0) of Conv1d weights (model.py:95-136) -> 16-bit GEMM operand
  *   w16[co, tap*Cip + ci]; g NULL = plain weight.  dle_wg_upsample_weight(_bwd): ConvTranspose1d weight [Cm, Cm, ksize] <->
  *   GEMM operand b16[(r*Cm+co), (j*Cm+ci)] = w[ci, co, r + stride*j] and the bias repeated per phase r. */
-int dle_wg_taps(const void* x, void* col, int B, int T, int C, int ntaps, int dilation, int left, int dtype,
+int dle_wg_taps(const void* x, void* col, int B, int T, int C, int ntaps, int dilation, int left, int64_t ld_x, int dtype,
                 hipStream_t stream);
 int dle_wg_taps_bwd(const void* dcol, const void* addend, void* dx, int B, int T, int C, int ntaps, int dilation, int left,
                     int64_t ld_add, int64_t ld_dx, int dtype, hipStream_t stream);

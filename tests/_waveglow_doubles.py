@@ -79,7 +79,7 @@ def amp_update_scale_(scale, growth_tracker, found_inf, inv_scale=None, growth_f
 # ---------------------------------------------------------------- csrc/waveglow.hip
 def taps(x, batch, steps, ntaps, dilation, left, out=None):
     ch = x.shape[1]
-    xb = x.view(batch, steps, ch)
+    xb = x.reshape(batch, steps, ch)
     col = torch.zeros((batch, steps, ntaps, ch), dtype=x.dtype, device=x.device)
     for k in range(ntaps):
         sh = (k - left) * dilation                       # col[:, t, k] = x[:, t + sh]

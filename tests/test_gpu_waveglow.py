@@ -40,6 +40,8 @@ def test_taps_and_transpose(cuda, dtype, b, t, ch, nt, dil, left):
     x = torch.randn(b * t, ch, generator=g).to(dtype)
     col = ops.taps(x.to(cuda), b, t, nt, dil, left)
     assert torch.equal(col.cpu(), D.taps(x, b, t, nt, dil, left))
+    wide = torch.randn(b * t, 2 * ch, generator=g).to(dtype)                 # x = the left half of a wider matrix (row stride 2 C)
+    assert torch.equal(ops.taps(wide.to(cuda)[:, :ch], b, t, nt, dil, left).cpu(), D.taps(wide[:, :ch], b, t, nt, dil, left))
     dcol = torch.randn(b * t, nt * ch, generator=g).to(dtype)
     add = torch.randn(b * t, 2 * ch, generator=g).to(dtype)
     for with_add in (False, True):
@@ -252,6 +254,19 @@ def test_gemm_shapes_this_path_adds(cuda, dtype):
     acts, wr, br, x = r(m, nc), r(2 * nc, nc), torch.randn(2 * nc, generator=g), r(m, nc)
     got, ref = both(lambda L, d: L.gemm(d(acts), d(wr)[nc:], m, nc, nc, True, True, bias=d(br)[nc:], act=C.ACT_ADD, mask_src=d(x)))
     _close(got, ref, **tol)
+    # one res_skip GEMM over the two-halves buffer [audio | skip sum]; last layer: the skip half only, in place in the right half
+    xo = r(m, 2 * nc)
+    got, ref = both(lambda L, d: L.gemm(d(acts), d(wr), m, 2 * nc, nc, True, True, bias=d(br), act=C.ACT_ADD, mask_src=d(xo),
+                                        out=d(torch.zeros(m, 2 * nc, dtype=dtype))))
+    _close(got, ref, **tol)
+    got, ref = both(lambda L, d: L.gemm(d(acts), d(wr)[:nc], m, nc, nc, True, True, bias=d(br)[:nc], act=C.ACT_ADD,
+                                        mask_src=d(xo)[:, nc:], out=d(torch.zeros(m, 2 * nc, dtype=dtype))[:, nc:]))
+    _close(got, ref, **tol)
+    got, ref = both(lambda L, d: L.gemm(d(xo)[:, nc:], d(we), m, 8, nc, True, True, bias=d(be), out_dtype=torch.float32))   # end from the half
+    _close(got, ref, rtol=1e-4, atol=1e-4)
+    got, ref = both(lambda L, d: L.gemm(d(d_o), d(xo)[:, nc:], 8, nc, m, False, False, out=d(torch.zeros(8, nc)),
+                                        splitk=F.pick_splitk(8, nc, m)))                                           # end wgrad, strided B
+    _close(got, ref, rtol=1e-3, atol=1e-3)
     # res_skip dgrad from the two-halves gradient buffer, last layer = right half only (row stride 2 nc)
     d_rs = r(m, 2 * nc)
     got, ref = both(lambda L, d: L.gemm(d(d_rs)[:, nc:], d(wr)[:nc], m, nc, nc, True, False))

@@ -125,3 +125,49 @@ def test_segment_that_is_not_a_multiple_of_the_hop(monkeypatch):
     tr.backward()
     for k in ("upsample.weight", "upsample.bias", "WN.0.cond_layers.1.weight_v", "convinv.3.conv.weight"):
         assert torch.allclose(tr.g[k], p[k].grad, rtol=3e-4, atol=2e-7), k
+
+
+def _dp_worker(rank, world, port, ret):
+    """One rank of a world-size-2 gloo run of the engine's data-parallel path (doubles for the kernels)."""
+    import pytest as _pytest
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import waveglow_oracle as WO
+        from tests import _waveglow_doubles as D
+        from deeplearningexamples_amd.waveglow.engine import WaveGlowTrainer
+        from deeplearningexamples_amd.waveglow.model import WaveGlow
+        D.install(_pytest.MonkeyPatch())
+        c = WO.WAVEGLOW_CASE
+        torch.manual_seed(50 + rank)                                  # different initial replicas: the trainer must broadcast
+        model = WaveGlow(**c["cfg"])
+        if rank == 0:
+            model.load_reference_state(WO.seeded_state(c["cfg"], c["seed"]))
+        tr = WaveGlowTrainer(model, compute_dtype=torch.float32, amp=True, init_loss_scale=256.0, world_size=world, bucket_mb=1)
+        mel, audio = WO.seeded_inputs(dict(c, batch=4))
+        per = 4 // world
+        tr.forward(mel[rank * per:(rank + 1) * per].contiguous(), audio[rank * per:(rank + 1) * per].contiguous())
+        tr.backward()
+        tr.buckets.wait()
+        ret[rank] = (tr.g.flat.clone(), tr.p.flat.clone(), len(tr.buckets.buckets))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_gradients_two_ranks_gloo(monkeypatch):
+    """Two ranks with the two halves of a batch: the bucketed mean all-reduce leaves the full-batch gradient on both; replicas
+    built from different seeds start from rank 0's weights (DDP semantics, train.py:402-407)."""
+    import torch.multiprocessing as mp
+    port = 30100 + os.getpid() % 2000
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_dp_worker, args=(2, port, ret), nprocs=2, join=True)
+        (g0, p0, nb), (g1, p1, _) = ret[0], ret[1]
+    assert nb > 1 and torch.equal(g0, g1) and torch.equal(p0, p1)
+    WO, c, model, state, tr = _trainer(monkeypatch, True, init_loss_scale=256.0)
+    mel, audio = WO.seeded_inputs(dict(c, batch=4))
+    tr.forward(mel, audio)
+    tr.backward()
+    assert torch.equal(p0, tr.p.flat)
+    assert float((g0 - tr.g.flat).norm()) <= 1e-4 * float(tr.g.flat.norm())
