@@ -13,6 +13,7 @@ audio.  Every Conv1d is a dle_gemm over rows:
     gathered rows of every (flow, layer) are kept, and ALL in_layer weight gradients are one batched GEMM after the backward
     sweep (96 slices of 1024 x 1536 x M fill the chip; one by one they needed split-K slabs + a reduction each);
   * res_skip_layers: one GEMM per layer over a two-halves buffer [audio | skip sum], the previous halves added in the epilogue;
+    their weight gradients: two batched GEMMs after the sweep over the kept per-layer output gradients;
   * start / end (n_half <= 4 channels): GEMMs with the narrow side zero-padded to 8.
 Weight normalisation (fp32 masters -> 16-bit operands, GEMM-layout gradients -> dv, dg) and the 12 log-determinants run as ONE
 table-driven launch each.  The flow state stays fp32 ([M, 8]); 16-bit tensors are the GEMM operands and WN activations, as
@@ -65,6 +66,7 @@ class WaveGlowTrainer:
         self.dw_cond = torch.zeros((self.cond_cols, kc), dtype=torch.float32, device=dev)
         self.w_in = torch.zeros((self.nf * nl, 2 * nc, ks * nc), dtype=dt, device=dev)
         self.dw_in = torch.zeros((self.nf * nl, 2 * nc, ks * nc), dtype=torch.float32, device=dev)
+        self.dw_rs = torch.zeros((self.nf, nl, 2 * nc, nc), dtype=torch.float32, device=dev)    # last layer: first nc rows (skip only)
         self.flows, fwd, bwd, ld = [], [], [], []
         for k, (c, nh) in enumerate(self.chans):
             f = _Flow()
@@ -75,7 +77,7 @@ class WaveGlowTrainer:
             f.w_end = torch.zeros((8, nc), dtype=dt, device=dev)         # rows >= 2 nh stay zero
             f.w_in = [self.w_in[k * nl + i] for i in range(nl)]
             f.w_rs = [torch.zeros((2 * nc if i < nl - 1 else nc, nc), dtype=dt, device=dev) for i in range(nl)]
-            f.dw_rs = [torch.zeros((2 * nc if i < nl - 1 else nc, nc), dtype=torch.float32, device=dev) for i in range(nl)]
+            f.dw_rs = [self.dw_rs[k, i, :(2 * nc if i < nl - 1 else nc)] for i in range(nl)]
 
             def normed(name, w16, dw, cip=None, as_shape=None):
                 v, dv = p[name + ".weight_v"], g[name + ".weight_v"]
@@ -200,13 +202,20 @@ class WaveGlowTrainer:
         count = float(m * self.ng)
         dz = ops.dz_init(self.z, scale, 1.0 / (self.sigma * self.sigma * count))
         ds_all = torch.empty((m, self.cond_cols), dtype=self.dtype, device=self.dev)
-        d_rs = torch.empty((m, 2 * nc), dtype=self.dtype, device=self.dev)
+        # gradient of every res_skip output, [d audio_{i+1} | d output] per (flow, layer): kept so that ALL res_skip weight
+        # gradients are two batched GEMMs after the sweep (one by one: 96 x (1024 x 512 x M split-K GEMM + slab reduction) = 6 ms)
+        d_rs_all = torch.empty((self.nf, nl, m, 2 * nc), dtype=self.dtype, device=self.dev)
+        batched = m % 8 == 0                 # the batched kernel wants the contraction (M rows) in 16-byte steps
         for k in range(self.nf - 1, -1, -1):
             f = self.flows[k]
             pre = "WN.%d." % k
             dy, d_o = ops.coupling_bwd(dz, f.y, f.o, scale, 1.0 / count, f.c, self.dtype)
-            # end: data gradient straight into the skip half of d_rs, weight / bias gradients into their 8-wide slots
-            F.gemm(d_o, f.w_end, m, nc, 8, True, False, out=d_rs[:, nc:])
+            # end: data gradient straight into the skip half of the last layer's buffer (copied to the other layers' skip halves:
+            # `output` is the plain sum of the skips), weight / bias gradients into their 8-wide slots
+            d_out = d_rs_all[k, nl - 1, :, nc:]
+            F.gemm(d_o, f.w_end, m, nc, 8, True, False, out=d_out)
+            for i in range(nl - 1):
+                F.copy_rows(d_out, d_rs_all[k, i, :, nc:])
             F.gemm(d_o, f.out, 8, nc, m, False, False, out=g.slot(pre + "end.weight").view(8, nc), splitk=F.pick_splitk(8, nc, m))
             F.colsum(d_o, out=g.slot(pre + "end.bias"))
             d_x0 = None
@@ -214,16 +223,17 @@ class WaveGlowTrainer:
                 last = i == nl - 1
                 z = k * nl + i
                 c0 = z * 2 * nc
-                g_rs = d_rs[:, nc:] if last else d_rs                    # last layer: res_skip has the skip half only
+                g_rs = d_out if last else d_rs_all[k, i]                 # last layer: res_skip has the skip half only
                 rs = nc if last else 2 * nc
                 d_acts = F.gemm(g_rs, f.w_rs[i], m, nc, rs, True, False)
-                F.gemm(g_rs, self.acts_all[z], rs, nc, m, False, False, out=f.dw_rs[i], splitk=F.pick_splitk(rs, nc, m))
+                if not batched:
+                    F.gemm(g_rs, self.acts_all[z], rs, nc, m, False, False, out=f.dw_rs[i], splitk=F.pick_splitk(rs, nc, m))
                 F.colsum(g_rs, out=g[pre + "res_skip_layers.%d.bias" % i])
                 ds_i = ops.gate_bwd(d_acts, self.s_all[:, c0:c0 + 2 * nc], ds_all[:, c0:c0 + 2 * nc])
                 dcol = F.gemm(ds_i, f.w_in[i], m, ks * nc, 2 * nc, True, False)
-                add = None if last else d_rs[:, :nc]                     # + the residual path's gradient (audio = res + audio)
+                add = None if last else d_rs_all[k, i, :, :nc]           # + the residual path's gradient (audio = res + audio)
                 if i > 0:
-                    ops.taps_bwd(dcol, b, self.tg, nc, ks, 2 ** i, ks // 2, out=d_rs[:, :nc], addend=add)
+                    ops.taps_bwd(dcol, b, self.tg, nc, ks, 2 ** i, ks // 2, out=d_rs_all[k, i - 1, :, :nc], addend=add)
                 else:
                     d_x0 = torch.empty((m, nc), dtype=self.dtype, device=self.dev)
                     ops.taps_bwd(dcol, b, self.tg, nc, ks, 1, ks // 2, out=d_x0, addend=add)
@@ -237,11 +247,18 @@ class WaveGlowTrainer:
         kc = self.mel * self.ng
         nz = self.nf * nl
         # in_layer weight gradients of every (flow, layer): slice z = ds_all[:, z*2nc:(z+1)*2nc]^T x col_all[z]
-        if m % 8 == 0:
+        if batched:
             F.gemm_batched(ds_all, self.col_all, self.dw_in, 2 * nc, ks * nc, m, self.cond_cols, ks * nc, ks * nc, False, False,
                            nz, 1, (2 * nc, 0), (m * ks * nc, 0), (2 * nc * ks * nc, 0))
-        else:                          # the batched kernel wants the contraction (M rows) in 16-byte steps; any other batch x segment
-            for z in range(nz):        # goes slice by slice through dle_gemm (which has an unaligned path)
+            # res_skip weight gradients: slice (k, i) = d_rs_all[k, i]^T x acts_all[k, i]; layers 0 .. nl-2 are 2nc x nc, the last
+            # layer of every flow nc x nc from the skip half only
+            if nl > 1:
+                F.gemm_batched(d_rs_all, self.acts_all, self.dw_rs, 2 * nc, nc, m, 2 * nc, nc, nc, False, False, self.nf * (nl - 1),
+                               nl - 1, (nl * m * 2 * nc, m * 2 * nc), (nl * m * nc, m * nc), (nl * 2 * nc * nc, 2 * nc * nc))
+            F.gemm_batched(d_rs_all[0, nl - 1, :, nc:], self.acts_all[nl - 1], self.dw_rs[0, nl - 1], nc, nc, m, 2 * nc, nc, nc,
+                           False, False, self.nf, 1, (nl * m * 2 * nc, 0), (nl * m * nc, 0), (nl * 2 * nc * nc, 0))
+        else:                          # any other batch x segment goes slice by slice through dle_gemm (which has an unaligned path)
+            for z in range(nz):
                 F.gemm(ds_all[:, z * 2 * nc:(z + 1) * 2 * nc], self.col_all[z], 2 * nc, ks * nc, m, False, False, out=self.dw_in[z],
                        splitk=F.pick_splitk(2 * nc, ks * nc, m))
         # cond layers: one weight-gradient GEMM, one data-gradient GEMM (K = all cond columns)

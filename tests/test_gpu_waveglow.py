@@ -369,6 +369,33 @@ def test_all_in_layer_weight_gradients_as_one_batched_gemm(cuda, dtype):
         _close(got, direct, rtol=2e-3, atol=2e-2)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_all_res_skip_weight_gradients_as_two_batched_gemms(cuda, dtype):
+    """Slices (flow, layer < L-1): d_rs[k, i]^T x acts[k, i] (2nc x nc, outer / inner strides skip the last layer's slot); the last
+    layers: the skip half of d_rs only (column-offset A with row stride 2nc), nc x nc."""
+    from deeplearningexamples_amd import functional as F
+    g = torch.Generator().manual_seed(41)
+    nf, nl, m, nc = 3, 4, 512, 64
+    d_rs = (torch.randn(nf, nl, m, 2 * nc, generator=g) * 0.3).to(dtype)
+    acts = (torch.randn(nf * nl, m, nc, generator=g) * 0.3).to(dtype)
+
+    def run(L, d):
+        a, b, c = d(d_rs), d(acts), d(torch.zeros(nf, nl, 2 * nc, nc))
+        L.gemm_batched(a, b, c, 2 * nc, nc, m, 2 * nc, nc, nc, False, False, nf * (nl - 1), nl - 1,
+                       (nl * m * 2 * nc, m * 2 * nc), (nl * m * nc, m * nc), (nl * 2 * nc * nc, 2 * nc * nc))
+        L.gemm_batched(a[0, nl - 1, :, nc:], b[nl - 1], c[0, nl - 1], nc, nc, m, 2 * nc, nc, nc, False, False, nf, 1,
+                       (nl * m * 2 * nc, 0), (nl * m * nc, 0), (nl * 2 * nc * nc, 0))
+        return c
+    got, ref = run(F, lambda t: t.to(cuda)), run(D, lambda t: t)
+    _close(got, ref, rtol=2e-3, atol=2e-2)
+    for k in range(nf):
+        for i in range(nl):
+            a = d_rs[k, i].float() if i < nl - 1 else d_rs[k, i, :, nc:].float()
+            want = a.t() @ acts[k * nl + i].float()
+            _close(got[k, i, :want.shape[0]], want, rtol=2e-3, atol=2e-2)
+    assert float(got[:, nl - 1, nc:].abs().max()) == 0                     # the unused half of the last layers' slots is untouched
+
+
 # ------------------------------------------------------------------------------------------------- the step
 def _trainer(cuda, dtype, cfg=None, seed=None, **kw):
     from oracle import waveglow_oracle as WO
