@@ -127,3 +127,22 @@ def import_waveglow():
         spec.loader.exec_module(mod)
         out[nm] = mod
     return types.SimpleNamespace(**out)
+
+
+def import_tacotron2():
+    """PyTorch/SpeechSynthesis/Tacotron2/tacotron2/{model,loss_function}.py (Tacotron2 half).  `librosa` (mel
+    filter bank / STFT helpers of tacotron2_common.layers, never touched by the model) is absent here: stubbed."""
+    import importlib.util
+    root = os.path.join(REF, "PyTorch", "SpeechSynthesis", "Tacotron2")
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    util = _stub("librosa.util", pad_center=None, tiny=None, normalize=None)
+    filt = _stub("librosa.filters", mel=None)
+    _stub("librosa", util=util, filters=filt)
+    out = {}
+    for nm in ("model", "loss_function"):
+        spec = importlib.util.spec_from_file_location("_ref_tacotron2_" + nm, os.path.join(root, "tacotron2", nm + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        out[nm] = mod
+    return types.SimpleNamespace(**out)

@@ -383,8 +383,54 @@ def gen_waveglow():
     print("waveglow_loss.npz loss", float(loss), "params", len(list(model.named_parameters())))
 
 
+def gen_tacotron2():
+    """Loss and every parameter gradient of the REFERENCE's Tacotron2 + Tacotron2Loss on CPU (training mode, small widths, the
+    full structure), with F.dropout bound to oracle.tacotron2_oracle.MaskStream so that reference and oracle draw the same masks:
+    pins oracle/tacotron2_oracle.py -- groundwork for the Tacotron2 half of SURVEY.md 8 row f1, no product path yet."""
+    import torch.nn.functional as TF
+    from oracle import tacotron2_oracle as TO
+    ref = R.import_tacotron2()
+    c = TO.TACOTRON2_CASE
+    cfg = c["cfg"]
+    model = ref.model.Tacotron2(mask_padding=False, max_decoder_steps=2000, gate_threshold=0.5, decoder_no_early_stopping=False, **cfg)
+    state = TO.seeded_state(cfg, c["seed"])
+    trainable = {k: tuple(v.shape) for k, v in model.named_parameters()}
+    assert trainable == TO.param_shapes(cfg), set(trainable.items()) ^ set(TO.param_shapes(cfg).items())
+    model.load_state_dict(state, strict=False)                       # BatchNorm running buffers keep their defaults
+    model.train()
+    text, tl, mel, gate, ml = TO.seeded_batch(c)
+    stream = TO.MaskStream(c["seed"] + 2)
+    real_dropout = TF.dropout
+    TF.dropout = lambda x, p=0.5, training=True, inplace=False: stream(x, p) if training else x
+    try:
+        out = model((text, tl, mel, int(tl.max()), ml))
+        loss = ref.loss_function.Tacotron2Loss()(out, (mel, gate))
+        loss.backward()
+    finally:
+        TF.dropout = real_dropout
+    p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    stream2 = TO.MaskStream(c["seed"] + 2)
+    lo, (mo, mp, go, al) = TO.tacotron2_loss(p, cfg, text, tl, mel, gate, stream2)
+    lo.backward()
+    assert stream.calls == stream2.calls, (stream.calls, stream2.calls)
+    assert abs(float(lo) - float(loss)) <= 2e-6 * abs(float(loss)), (float(lo), float(loss))
+    assert torch.allclose(al, out[3], atol=1e-6) and torch.allclose(mo, out[0], atol=2e-5)
+    arrs = {"loss": np.asarray([float(loss)], np.float64), "dropout_calls": np.asarray([stream.calls], np.int64),
+            "alignment_last": out[3][:, -1].detach().numpy()}
+    for k, v in model.named_parameters():
+        g, go_ = v.grad, p[k].grad
+        assert torch.allclose(g, go_, rtol=5e-4, atol=2e-7), (k, float((g - go_).abs().max()), float(g.abs().max()))
+        arrs["gnorm." + k] = np.asarray([float(g.norm())], np.float64)
+    for k in ("embedding.weight", "encoder.lstm.weight_hh_l0_reverse", "decoder.attention_rnn.weight_ih",
+              "decoder.attention_layer.location_layer.location_conv.conv.weight", "decoder.prenet.layers.0.linear_layer.weight",
+              "postnet.convolutions.2.0.conv.weight", "decoder.gate_layer.linear_layer.weight"):
+        arrs["grad." + k] = dict(model.named_parameters())[k].grad.numpy().reshape(-1)[:64]
+    np.savez_compressed(os.path.join(GOLD, "tacotron2_loss.npz"), **arrs)
+    print("tacotron2_loss.npz loss", float(loss), "params", len(trainable), "dropout calls", stream.calls)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dlrm", "dlrm_step", "rn50", "lamb", "bert", "floors", "waveglow"]
+    which = sys.argv[1:] or ["dlrm", "dlrm_step", "rn50", "lamb", "bert", "floors", "waveglow", "tacotron2"]
     os.makedirs(GOLD, exist_ok=True)
     if not R.have_reference():
         sys.exit("reference not mounted; fixtures are generated in the build container only")

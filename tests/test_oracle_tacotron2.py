@@ -1,0 +1,41 @@
+"""GROUNDWORK for the Tacotron2 half of SURVEY.md section 8 row f1 (no product path yet): the Tacotron2 loss oracle against the
+fixture the REFERENCE's own Tacotron2 + Tacotron2Loss produced on CPU in training mode with the same dropout masks
+(tests/golden/tacotron2_loss.npz, oracle/make_golden.py gen_tacotron2: loss, the gradient norm of all 60 parameters, gradient
+slices, the last alignment row).  CPU only."""
+import os
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_tacotron2_oracle_reproduces_reference_loss_and_gradients():
+    from oracle import tacotron2_oracle as TO
+    c = TO.TACOTRON2_CASE
+    gold = np.load(os.path.join(HERE, "golden", "tacotron2_loss.npz"))
+    p = {k: v.clone().requires_grad_(True) for k, v in TO.seeded_state(c["cfg"], c["seed"]).items()}
+    text, tl, mel, gate, ml = TO.seeded_batch(c)
+    stream = TO.MaskStream(c["seed"] + 2)
+    loss, (mel_out, mel_post, gate_out, align) = TO.tacotron2_loss(p, c["cfg"], text, tl, mel, gate, stream)
+    loss.backward()
+    assert stream.calls == int(gold["dropout_calls"][0]) == 3 + 2 + 2 * int(ml.max()) + 5
+    assert abs(float(loss.detach()) - float(gold["loss"][0])) <= 2e-6 * abs(float(gold["loss"][0]))
+    np.testing.assert_allclose(align[:, -1].detach().numpy(), gold["alignment_last"], atol=1e-6)
+    # attention never looks at padded text positions, rows sum to one
+    pad = torch.arange(text.shape[1])[None, :] >= tl[:, None]
+    assert float(align.detach()[pad[:, None, :].expand_as(align)].abs().max()) == 0
+    np.testing.assert_allclose(align.detach().sum(2).numpy(), 1.0, atol=1e-5)
+    names = [k[len("gnorm."):] for k in gold.files if k.startswith("gnorm.")]
+    assert sorted(names) == sorted(p) and len(names) == 60
+    for k in names:
+        ref = float(gold["gnorm." + k][0])
+        # (a convolution bias in front of a training-mode BatchNorm has a mathematically zero gradient: rounding noise ~1e-7)
+        assert abs(float(p[k].grad.norm()) - ref) <= 5e-4 * ref + 1e-6, k
+    for k in [f[len("grad."):] for f in gold.files if f.startswith("grad.")]:
+        np.testing.assert_allclose(p[k].grad.numpy().reshape(-1)[:64], gold["grad." + k], rtol=5e-4, atol=2e-7)
+    # the reference's default widths (tacotron2/arg_parser.py:40-107) are in the shape table too
+    sh = TO.param_shapes(TO.TACOTRON2_DEFAULT)
+    assert sh["decoder.attention_rnn.weight_ih"] == (4096, 768) and sh["decoder.decoder_rnn.weight_ih"] == (4096, 1536)
+    assert sh["decoder.linear_projection.linear_layer.weight"] == (80, 1536) and sh["encoder.lstm.weight_hh_l0_reverse"] == (1024, 256)
+    assert sum(int(np.prod(s)) for s in sh.values()) == 28193153                    # 28.2 M trainable parameters
