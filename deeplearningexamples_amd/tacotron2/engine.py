@@ -1,0 +1,462 @@
+"""Tacotron2 train step on the gfx950 library (second half): the AMP iteration of
+SpeechSynthesis/Tacotron2/train.py:474-500 for `-m Tacotron2` -- Tacotron2.forward (tacotron2/model.py:667-681: embedding,
+encoder, teacher-forced decoder, postnet), Tacotron2Loss (tacotron2/loss_function.py:31-46), scaled backward (BPTT through the
+decoder and the encoder LSTMs), GradScaler.unscale_ + clip_grad_norm_, torch.optim.Adam -- as a fixed sequence of C-ABI launches
+with an explicit backward.  No CPU path.
+
+Layout: channels-last matrices.  Text side rows are (b, t_in) batch-major ([B*Ti, C]: convolutions = dle_wg_taps + dle_gemm, BatchNorm
+over rows), decoder state is one row per sample.  What is NOT recurrent under teacher forcing runs once for all steps: the
+prenet, the prenet's share of the attention-LSTM gates, the mel / gate projection, and every weight gradient (per-step gate
+gradients and inputs are kept, so each weight gradient is ONE GEMM over To*B rows after the sweep).  Per decoder step, forward:
+gates GEMM (+ the precomputed prenet share in the epilogue) -> dle_t2_lstm_fwd (dropout inside) -> query GEMM -> location taps +
+GEMM (location conv and dense pre-multiplied into one [A, 31*2] matrix, the processed memory added in the epilogue) ->
+dle_t2_attention_fwd (energies, masked softmax, context, cumulative weights) -> gates GEMM -> dle_t2_lstm_fwd.
+Vectors that feed several consumers are written by the producing kernel straight into the consumers' operand buffers
+(X_a[t] = [context | attention_hidden], X_d[t] = [attention_hidden | context | decoder_hidden], HC[:, t] = [decoder_hidden | context]).
+Restrictions: n_frames_per_step = 1, mask_padding = False (the reference's defaults).
+"""
+import torch
+
+from .. import _cabi as C
+from .. import functional as F
+from .. import multi_tensor as mt
+from ..dlrm.engine import GradScalerState
+from ..utils.buckets import GradBuckets
+from ..waveglow import ops as wops
+from ..waveglow.model import FlatViews
+from . import ops
+from .model import Tacotron2, bn_names
+
+NPAD = 8          # the mel + gate projection runs (n_mel + 1) outputs wide, padded to a multiple of 8
+
+
+class Tacotron2Trainer:
+    def __init__(self, model: Tacotron2, lr=1e-3, weight_decay=1e-6, grad_clip_thresh=1.0, compute_dtype=torch.float16, amp=True,
+                 init_loss_scale=65536.0, growth_interval=2000, world_size=1, process_group=None, bucket_mb=25, seed=1234, rank=0):
+        self.model, self.cfg = model, model.cfg
+        self.dev = dev = model.store.flat.device
+        self.dtype = compute_dtype
+        self.lr, self.wd, self.clip = float(lr), float(weight_decay), float(grad_clip_thresh)
+        self.world, self.pg = world_size, process_group
+        c = self.cfg
+        self.E, self.A, self.Ha, self.Hd, self.P = (c["encoder_embedding_dim"], c["attention_dim"], c["attention_rnn_dim"],
+                                                    c["decoder_rnn_dim"], c["prenet_dim"])
+        self.NM, self.NF, self.KL = c["n_mel_channels"], c["attention_location_n_filters"], c["attention_location_kernel_size"]
+        self.h = self.E // 2
+        self.NO = (self.NM + 1 + NPAD - 1) // NPAD * NPAD
+        for v in (self.E, self.A, self.Ha, self.Hd, self.P, self.NM, self.NF, self.h, c["postnet_embedding_dim"]):
+            if v % 8:
+                raise ValueError("every layer width must be a multiple of 8")
+        self.p = model.store
+        self.g = FlatViews(model.layout, dev)
+        self.m = FlatViews(model.layout, dev)
+        self.v = FlatViews(model.layout, dev)
+        self.scaler = GradScalerState(dev, enabled=amp, init_scale=init_loss_scale, growth_interval=growth_interval)
+        self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.noop = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.lr_t = torch.full((1,), self.lr, dtype=torch.float32, device=dev)
+        self._tables = mt.TableCache()
+        self.rng_seed, self._rng_calls = int(seed) + int(rank), 0
+        self._buf = dict(model.named_buffers())
+        self.buckets = None
+        if world_size > 1:
+            self.comm_stream = torch.cuda.Stream() if dev.type == "cuda" else None
+            self.buckets = GradBuckets(self.g.flat, [(n, s) for n, _, s in model.layout], bucket_mb=bucket_mb, group=process_group,
+                                       comm_stream=self.comm_stream, reverse=True)
+            from ..utils.comm import broadcast_
+            broadcast_(self.p.flat, 0, process_group)
+
+    # ------------------------------------------------------------------ helpers
+    def _z(self, *shape, dtype=None):
+        return torch.zeros(shape, dtype=dtype or self.dtype, device=self.dev)
+
+    def _e(self, *shape, dtype=None):
+        return torch.empty(shape, dtype=dtype or self.dtype, device=self.dev)
+
+    def _drop(self, x, p):
+        self._rng_calls += 1
+        return F.dropout_fwd(x, p, self.rng_seed, self._rng_calls)
+
+    def _conv_w(self, name):
+        """Conv1d weight [Co, Ci, K] -> GEMM operand [Co, K * Ci] (tap-major), 16-bit."""
+        w = self.p[name]
+        w16 = self._e(w.shape[0], w.shape[2] * w.shape[1])
+        wops.weight_norm_fwd(w, None, w16)
+        return w16
+
+    def _cast(self, t):
+        return F.cast(t, self.dtype)
+
+    def _sum2(self, a, b):
+        out = torch.empty_like(a)
+        F.axpby_(a, b, out, 1.0, 1.0)
+        return out
+
+    def _prepare_weights(self):
+        p, dt = self.p, self.dtype
+        E, A, Ha, Hd, P, NM = self.E, self.A, self.Ha, self.Hd, self.P, self.NM
+        w = {}
+        w["emb"] = self._cast(p["embedding.weight"])
+        for i in range(self.cfg["encoder_n_convolutions"]):
+            w["enc%d" % i] = self._conv_w("encoder.convolutions.%d.0.conv.weight" % i)
+        for sfx in ("", "_reverse"):
+            w["eih" + sfx] = self._cast(p["encoder.lstm.weight_ih_l0" + sfx])
+            w["ehh" + sfx] = self._cast(p["encoder.lstm.weight_hh_l0" + sfx])
+            w["eb" + sfx] = self._sum2(p["encoder.lstm.bias_ih_l0" + sfx], p["encoder.lstm.bias_hh_l0" + sfx])
+        w["pre0"] = self._cast(p["decoder.prenet.layers.0.linear_layer.weight"])
+        w["pre1"] = self._cast(p["decoder.prenet.layers.1.linear_layer.weight"])
+        wih, whh = p["decoder.attention_rnn.weight_ih"], p["decoder.attention_rnn.weight_hh"]
+        w["a_pre"] = F.cast_rows(wih[:, :P], dt)                                      # the prenet's share of the gates
+        w["a_cat"] = self._e(4 * Ha, E + Ha)                                           # [context | attention_hidden] share
+        F.cast_rows(wih[:, P:], dt, out=w["a_cat"][:, :E])
+        F.cast_rows(whh, dt, out=w["a_cat"][:, E:])
+        w["a_b"] = self._sum2(p["decoder.attention_rnn.bias_ih"], p["decoder.attention_rnn.bias_hh"])
+        w["d_cat"] = self._e(4 * Hd, Ha + E + Hd)
+        F.cast_rows(p["decoder.decoder_rnn.weight_ih"], dt, out=w["d_cat"][:, :Ha + E])
+        F.cast_rows(p["decoder.decoder_rnn.weight_hh"], dt, out=w["d_cat"][:, Ha + E:])
+        w["d_b"] = self._sum2(p["decoder.decoder_rnn.bias_ih"], p["decoder.decoder_rnn.bias_hh"])
+        att = "decoder.attention_layer."
+        w["q"] = self._cast(p[att + "query_layer.linear_layer.weight"])
+        w["mem"] = self._cast(p[att + "memory_layer.linear_layer.weight"])
+        w["v"] = p[att + "v.linear_layer.weight"].view(-1)
+        # location conv [F, 2, KL] (tap-major, channels padded to 8) and dense [A, F] pre-multiplied: one [A, KL*8] operand
+        wc = p[att + "location_layer.location_conv.conv.weight"]
+        w["loc_c"] = self._z(self.NF, self.KL * 8)
+        wops.weight_norm_fwd(wc, None, w["loc_c"], cip=8)
+        w["loc_d"] = self._cast(p[att + "location_layer.location_dense.linear_layer.weight"])
+        w["loc"] = F.gemm(w["loc_d"], w["loc_c"], A, self.KL * 8, self.NF, True, False)
+        w["proj"] = self._z(self.NO, Hd + E)
+        F.cast_rows(p["decoder.linear_projection.linear_layer.weight"], dt, out=w["proj"][:NM])
+        F.cast_rows(p["decoder.gate_layer.linear_layer.weight"], dt, out=w["proj"][NM:NM + 1])
+        w["proj_b"] = self._z(self.NO, dtype=torch.float32)
+        w["proj_b"][:NM].copy_(p["decoder.linear_projection.linear_layer.bias"])
+        w["proj_b"][NM:NM + 1].copy_(p["decoder.gate_layer.linear_layer.bias"])
+        for i in range(self.cfg["postnet_n_convolutions"]):
+            w["post%d" % i] = self._conv_w("postnet.convolutions.%d.0.conv.weight" % i)
+        self.w = w
+
+    def _conv_bn(self, x, b, t, name, w16, act, p_drop):
+        """Conv1d(k, pad (k-1)/2) + BatchNorm1d(train) + act + dropout on rows (b, t).  -> (y, saved)."""
+        k = self.p[name + ".0.conv.weight"].shape[2]
+        cout = self.p[name + ".0.conv.weight"].shape[0]
+        col = wops.taps(x, b, t, k, 1, k // 2)
+        pre = F.gemm(col, w16, b * t, cout, col.shape[1], True, True, bias=self.p[name + ".0.conv.bias"])
+        bn = name + ".1"
+        y, mean, rstd = F.bn_fwd(pre, self.p[bn + ".weight"], self.p[bn + ".bias"], self._buf[bn + ".running_mean"],
+                                 self._buf[bn + ".running_var"], eps=1e-5, momentum=0.1, relu=(act == "relu"))
+        self._buf[bn + ".num_batches_tracked"] += 1
+        if act == "tanh":
+            y = ops.tanh_fwd(y)
+        yd, mask = self._drop(y, p_drop)
+        return yd, dict(col=col, pre=pre, mean=mean, rstd=rstd, y=y, mask=mask, act=act, k=k, cout=cout, name=name)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, text, text_lengths, mel, gate_target, output_lengths=None):
+        """text int64 [B, Ti] (sorted by length, descending, 0-padded), text_lengths int64 [B], mel fp32 [B, n_mel, To] zero padded,
+        gate_target fp32 [B, To] -> loss fp32 [1]."""
+        C.require_cuda(text, text_lengths, mel, gate_target)
+        E, A, Ha, Hd, P, NM, NO, h = self.E, self.A, self.Ha, self.Hd, self.P, self.NM, self.NO, self.h
+        dt, cfg = self.dtype, self.cfg
+        b, ti = text.shape
+        to = mel.shape[2]
+        self._prepare_weights()
+        w = self.w
+        sv = self.sv = dict(b=b, ti=ti, to=to, text=text.reshape(-1).contiguous(), lengths=text_lengths)
+        # ---- encoder: embedding, 3 x (conv + BN + ReLU + dropout), bi-LSTM over the packed batch
+        x = F.rows_gather(w["emb"], sv["text"])
+        sv["enc"] = []
+        for i in range(cfg["encoder_n_convolutions"]):
+            x_in = x
+            x, s = self._conv_bn(x, b, ti, "encoder.convolutions.%d" % i, w["enc%d" % i], "relu", 0.5)
+            s["x_in"] = x_in
+            sv["enc"].append(s)
+        sv["enc_out"] = x
+        memory = self._z(b * ti, E)                                      # [fwd | reverse] halves, zero at padded positions
+        mem3 = memory.view(b, ti, E)
+        steps = torch.arange(ti, device=self.dev)
+        live_all = (steps[:, None] < text_lengths[None, :]).to(torch.float32).contiguous()          # [Ti, B]
+        sv["live"] = live_all
+        sv["lstm"] = {}
+        for d, sfx in enumerate(("", "_reverse")):
+            gx = F.gemm(x, w["eih" + sfx], b * ti, 4 * h, E, True, True, bias=w["eb" + sfx]).view(b, ti, 4 * h)
+            gates = self._e(b, ti, 4 * h)                                # replaced by the gate activations step by step
+            hprev = self._z(b, ti, h)                                    # the state each step started from (rows (b, t))
+            c_all = self._z(ti + 1, b, h, dtype=torch.float32)          # cell state BEFORE the step processed k-th
+            hstate = self._z(b, h)
+            order = range(ti - 1, -1, -1) if d else range(ti)
+            for k, t in enumerate(order):
+                F.copy_rows(hstate, hprev[:, t])
+                F.gemm(hstate, w["ehh" + sfx], b, 4 * h, h, True, True, out=gates[:, t], act=C.ACT_ADD, mask_src=gx[:, t])
+                hnew = self._e(b, h)
+                ops.lstm_fwd(gates[:, t], c_all[k], c_all[k + 1], [hnew], live=live_all[t], h_prev=hstate,
+                             out_dst=mem3[:, t, d * h:(d + 1) * h])
+                hstate = hnew
+            sv["lstm"][sfx] = dict(gates=gates, hprev=hprev, c_all=c_all, order=list(order))
+        sv["memory"] = memory
+        pm = F.gemm(memory, w["mem"], b * ti, A, E, True, True)          # processed memory
+        sv["pm"] = pm
+        # ---- decoder, teacher forcing.  Prenet over the go frame + all target frames at once (model.py:473-476)
+        dec_in = self._z(to + 1, b, NM)
+        dec_in[1:].copy_(mel.permute(2, 0, 1))                           # input pipeline: time-major 16-bit copy of the targets
+        r_all = (to + 1) * b
+        l1 = F.gemm(dec_in.view(r_all, NM), w["pre0"], r_all, P, NM, True, True, act=C.ACT_RELU)
+        l1d, m1 = self._drop(l1, 0.5)
+        l2 = F.gemm(l1d, w["pre1"], r_all, P, P, True, True, act=C.ACT_RELU)
+        l2d, m2 = self._drop(l2, 0.5)
+        sv.update(dec_in=dec_in, l1=l1, l1d=l1d, m1=m1, l2=l2, l2d=l2d, m2=m2)
+        g_pre = F.gemm(l2d[:to * b], w["a_pre"], to * b, 4 * Ha, P, True, True, bias=w["a_b"]).view(to, b, 4 * Ha)
+        pa, pd = cfg["p_attention_dropout"], cfg["p_decoder_dropout"]
+        _, keep_a = self._drop(torch.ones(to * b * Ha, dtype=dt, device=self.dev), pa)
+        _, keep_d = self._drop(torch.ones(to * b * Hd, dtype=dt, device=self.dev), pd)
+        x_a = self._z(to + 1, b, E + Ha)                                 # [context_{t-1} | attention_hidden_{t-1}]
+        x_d = self._z(to + 1, b, Ha + E + Hd)                            # [attention_hidden_t | context_t | decoder_hidden_{t-1}]
+        hc = self._z(b, to, Hd + E)                                      # [decoder_hidden_t | context_t], rows (b, t)
+        ga = self._e(to, b, 4 * Ha)
+        gd = self._e(to, b, 4 * Hd)
+        ac = self._z(to + 1, b, Ha, dtype=torch.float32)
+        dc = self._z(to + 1, b, Hd, dtype=torch.float32)
+        awc = self._z(to + 1, b * ti, 8)                                 # (previous weights, cumulative weights, 0 x 6) per step
+        aw = self._e(to, b, ti, dtype=torch.float32)
+        tanh_all = self._e(to, b * ti, A)
+        q_all = self._e(to, b, A, dtype=torch.float32)
+        for t in range(to):
+            F.gemm(x_a[t], w["a_cat"], b, 4 * Ha, E + Ha, True, True, out=ga[t], act=C.ACT_ADD, mask_src=g_pre[t])
+            ops.lstm_fwd(ga[t], ac[t], ac[t + 1], [x_d[t][:, :Ha], x_a[t + 1][:, E:]], keep=keep_a, keep_index=t * b * Ha, p=pa)
+            F.gemm(x_d[t][:, :Ha], w["q"], b, A, Ha, True, True, out=q_all[t])
+            col = wops.taps(awc[t], b, ti, self.KL, 1, self.KL // 2)
+            pl = F.gemm(col, w["loc"], b * ti, A, self.KL * 8, True, True, act=C.ACT_ADD, mask_src=pm)
+            ops.attention_fwd(q_all[t], pl, w["v"], memory, text_lengths, awc[t], tanh_all[t], aw[t], awc[t + 1],
+                              [x_d[t][:, Ha:Ha + E], x_a[t + 1][:, :E], hc[:, t, Hd:]])
+            F.gemm(x_d[t], w["d_cat"], b, 4 * Hd, Ha + E + Hd, True, True, out=gd[t], bias=w["d_b"])
+            ops.lstm_fwd(gd[t], dc[t], dc[t + 1], [x_d[t + 1][:, Ha + E:], hc[:, t, :Hd]], keep=keep_d, keep_index=t * b * Hd, p=pd)
+        sv.update(g_pre=g_pre, keep_a=keep_a, keep_d=keep_d, x_a=x_a, x_d=x_d, hc=hc, ga=ga, gd=gd, ac=ac, dc=dc, awc=awc, aw=aw,
+                  tanh_all=tanh_all, q_all=q_all)
+        # ---- mel + gate projection of every step at once, postnet, loss
+        r = b * to
+        out_all = F.gemm(hc.view(r, Hd + E), w["proj"], r, NO, Hd + E, True, True, bias=w["proj_b"], out_dtype=torch.float32)
+        y = F.cast_rows(out_all[:, :NM], dt)
+        sv["post"] = []
+        npc = cfg["postnet_n_convolutions"]
+        for i in range(npc):
+            y_in = y
+            y, s = self._conv_bn(y, b, to, "postnet.convolutions.%d" % i, w["post%d" % i], "tanh" if i < npc - 1 else "none", 0.5)
+            s["x_in"] = y_in
+            sv["post"].append(s)
+        target = mel.permute(0, 2, 1).contiguous().view(r, NM)           # input pipeline: rows (b, t)
+        scale = self.scaler.scale
+        d_out = self._z(r, NO)
+        d_post = self._e(r, NM)
+        mel_l = ops.mel_loss(out_all, y, target, NM, scale, d_out, d_post)
+        gate_l, dgate = F.bce_with_logits(out_all[:, NM:], gate_target.reshape(-1).contiguous(), grad_scale=scale, ld_logits=NO)
+        d_out[:, NM].copy_(dgate)
+        self.loss = mel_l + gate_l
+        sv.update(out_all=out_all, d_out=d_out, d_post=d_post)
+        return self.loss
+
+    # ------------------------------------------------------------------ backward
+    def _conv_bn_bwd(self, dy, s, b, t, w16, want_dx=True):
+        """Backward of _conv_bn: dropout -> act -> BatchNorm -> conv.  Fills the parameter gradients, returns dx (16-bit)."""
+        name, k, cout, g = s["name"], s["k"], s["cout"], self.g
+        d = F.dropout_bwd(dy, s["mask"], 0.5)
+        if s["act"] == "tanh":
+            d = F.act_bwd(d, s["y"], C.ACT_TANH_BWD)
+        bn = name + ".1"
+        dpre, _ = F.bn_bwd(d, s["y"] if s["act"] == "relu" else None, s["pre"], s["mean"], s["rstd"], self.p[bn + ".weight"],
+                           g[bn + ".weight"], g[bn + ".bias"])
+        rows, kc = s["col"].shape
+        dw = torch.empty((cout, kc), dtype=torch.float32, device=self.dev)
+        F.gemm(dpre, s["col"], cout, kc, rows, False, False, out=dw, splitk=F.pick_splitk(cout, kc, rows))
+        wops.weight_norm_bwd(dw, self.p[name + ".0.conv.weight"], None, g[name + ".0.conv.weight"], None)
+        F.colsum(dpre, out=g[name + ".0.conv.bias"])
+        if not want_dx:
+            return None
+        cin = kc // k
+        dcol = F.gemm(dpre, w16, rows, kc, cout, True, False)
+        dx = self._e(rows, cin)
+        wops.taps_bwd(dcol, b, t, cin, k, 1, k // 2, out=dx)
+        return dx
+
+    def _wgrad(self, dy, x, out, rows):
+        """out (fp32 [N, K]) = dy[rows, N]^T x[rows, K]."""
+        n, k = out.shape
+        F.gemm(dy, x, n, k, rows, False, False, out=out, splitk=F.pick_splitk(n, k, rows))
+
+    def backward(self):
+        sv, w, g, p = self.sv, self.w, self.g, self.p
+        E, A, Ha, Hd, P, NM, NO, h = self.E, self.A, self.Ha, self.Hd, self.P, self.NM, self.NO, self.h
+        b, ti, to, dt, cfg = sv["b"], sv["ti"], sv["to"], self.dtype, self.cfg
+        f32 = torch.float32
+        r = b * to
+        # ---- postnet
+        npc = cfg["postnet_n_convolutions"]
+        dy = sv["d_post"]
+        for i in range(npc - 1, -1, -1):
+            dy = self._conv_bn_bwd(dy, sv["post"][i], b, to, w["post%d" % i])
+        d_out = sv["d_out"]
+        d_out[:, :NM].add_(dy)                                          # + the postnet branch (mel_post = mel_out + postnet(mel_out))
+        # ---- projection (all steps)
+        hc2 = sv["hc"].view(r, Hd + E)
+        dwp = torch.empty((NO, Hd + E), dtype=f32, device=self.dev)
+        self._wgrad(d_out, hc2, dwp, r)
+        g["decoder.linear_projection.linear_layer.weight"].copy_(dwp[:NM])
+        g["decoder.gate_layer.linear_layer.weight"].copy_(dwp[NM:NM + 1])
+        dbp = torch.empty(NO, dtype=f32, device=self.dev)
+        F.colsum(d_out, out=dbp)
+        g["decoder.linear_projection.linear_layer.bias"].copy_(dbp[:NM])
+        g["decoder.gate_layer.linear_layer.bias"].copy_(dbp[NM:NM + 1])
+        dhc = F.gemm(d_out, w["proj"], r, Hd + E, NO, True, False, out_dtype=f32).view(b, to, Hd + E)
+        # ---- decoder BPTT
+        memory, pm = sv["memory"], sv["pm"]
+        x_a, x_d, ga, gd, ac, dc, aw, awc = sv["x_a"], sv["x_d"], sv["ga"], sv["gd"], sv["ac"], sv["dc"], sv["aw"], sv["awc"]
+        d_memory = self._z(b * ti, E, dtype=f32)
+        d_pm = self._z(b * ti, A, dtype=f32)
+        dv = self._z(A, dtype=f32)
+        dw_loc = self._z(A, self.KL * 8, dtype=f32)
+        dq_all = self._e(to, b, A)
+        d_ah_rec = self._z(b, Ha, dtype=f32)                            # gradient wrt attention_hidden_t from step t+1's gates
+        d_ctx_rec = self._z(b, E, dtype=f32)                             # gradient wrt context_t from step t+1's gates
+        d_dh_rec = self._z(b, Hd, dtype=f32)
+        d_ac = self._z(b, Ha, dtype=f32)
+        d_dc = self._z(b, Hd, dtype=f32)
+        d_aw_loc = self._z(b, ti, dtype=f32)                             # wrt weights_t as "previous weights" of step t+1
+        d_cum = self._z(b, ti, dtype=f32)                                # wrt cumulative weights_t (all later steps)
+        for t in range(to - 1, -1, -1):
+            # decoder LSTM
+            dh = dhc[:, t, :Hd] + d_dh_rec
+            d_dc_prev = torch.empty_like(d_dc)
+            ops.lstm_bwd(dh, d_dc, gd[t], dc[t], gd[t], d_dc_prev, keep=sv["keep_d"], keep_index=t * b * Hd, p=cfg["p_decoder_dropout"])
+            d_dc = d_dc_prev
+            dxd = F.gemm(gd[t], w["d_cat"], b, Ha + E + Hd, 4 * Hd, True, False, out_dtype=f32)
+            d_dh_rec = dxd[:, Ha + E:]
+            # attention
+            d_ctx = dhc[:, t, Hd:] + dxd[:, Ha:Ha + E] + d_ctx_rec
+            d_cum_t = d_cum                                              # cumulative_t = cumulative_{t-1} + weights_t
+            d_pl = self._e(b * ti, A)
+            dq = self._e(b, A, dtype=f32)
+            ops.attention_bwd(d_ctx.contiguous(), (d_aw_loc + d_cum_t).contiguous(), aw[t], sv["tanh_all"][t], w["v"], memory, d_memory,
+                              d_pl, dq, dv, d_pm)
+            dq_all[t].copy_(dq)
+            # location term: pl = taps(awc[t]) x W_loc^T + pm
+            col = wops.taps(awc[t], b, ti, self.KL, 1, self.KL // 2)
+            F.gemm(d_pl, col, A, self.KL * 8, b * ti, False, False, out=dw_loc, accumulate=True,
+                   splitk=1)
+            dcol = F.gemm(d_pl, w["loc"], b * ti, self.KL * 8, A, True, False)
+            d_awc = self._e(b * ti, 8)
+            wops.taps_bwd(dcol, b, ti, 8, self.KL, 1, self.KL // 2, out=d_awc)
+            d_awc3 = d_awc.view(b, ti, 8).float()
+            d_aw_loc = d_awc3[:, :, 0].contiguous()                      # awc[t] = (weights_{t-1}, cumulative_{t-1})
+            d_cum = d_cum + d_awc3[:, :, 1]
+            # attention LSTM
+            d_ah = dxd[:, :Ha] + d_ah_rec + F.gemm(dq_all[t], w["q"], b, Ha, A, True, False, out_dtype=f32)
+            d_ac_prev = torch.empty_like(d_ac)
+            ops.lstm_bwd(d_ah, d_ac, ga[t], ac[t], ga[t], d_ac_prev, keep=sv["keep_a"], keep_index=t * b * Ha, p=cfg["p_attention_dropout"])
+            d_ac = d_ac_prev
+            dxa = F.gemm(ga[t], w["a_cat"], b, E + Ha, 4 * Ha, True, False, out_dtype=f32)
+            d_ctx_rec, d_ah_rec = dxa[:, :E], dxa[:, E:]
+        # ---- weight gradients of the decoder: one GEMM each over all steps
+        rt = to * b
+        ga2, gd2 = ga.view(rt, 4 * Ha), gd.view(rt, 4 * Hd)
+        dwa = torch.empty((4 * Ha, E + Ha), dtype=f32, device=self.dev)
+        self._wgrad(ga2, x_a.view(-1, E + Ha), dwa, rt)
+        dwa_pre = torch.empty((4 * Ha, P), dtype=f32, device=self.dev)
+        self._wgrad(ga2, sv["l2d"], dwa_pre, rt)
+        gih = g["decoder.attention_rnn.weight_ih"]
+        gih[:, :P].copy_(dwa_pre)
+        gih[:, P:].copy_(dwa[:, :E])
+        g["decoder.attention_rnn.weight_hh"].copy_(dwa[:, E:])
+        F.colsum(ga2, out=g["decoder.attention_rnn.bias_ih"])
+        g["decoder.attention_rnn.bias_hh"].copy_(g["decoder.attention_rnn.bias_ih"])
+        dwd = torch.empty((4 * Hd, Ha + E + Hd), dtype=f32, device=self.dev)
+        self._wgrad(gd2, x_d.view(-1, Ha + E + Hd), dwd, rt)
+        g["decoder.decoder_rnn.weight_ih"].copy_(dwd[:, :Ha + E])
+        g["decoder.decoder_rnn.weight_hh"].copy_(dwd[:, Ha + E:])
+        F.colsum(gd2, out=g["decoder.decoder_rnn.bias_ih"])
+        g["decoder.decoder_rnn.bias_hh"].copy_(g["decoder.decoder_rnn.bias_ih"])
+        att = "decoder.attention_layer."
+        self._wgrad(dq_all.view(rt, A), x_d.view(-1, Ha + E + Hd)[:, :Ha], g[att + "query_layer.linear_layer.weight"], rt)
+        g[att + "v.linear_layer.weight"].view(-1).copy_(dv)
+        dwl16 = self._cast(dw_loc)
+        F.gemm(dwl16, w["loc_c"], A, self.NF, self.KL * 8, True, True, out=g[att + "location_layer.location_dense.linear_layer.weight"])
+        dwc = torch.empty((self.NF, self.KL * 8), dtype=f32, device=self.dev)
+        F.gemm(w["loc_d"], dwl16, self.NF, self.KL * 8, A, False, False, out=dwc)
+        wops.weight_norm_bwd(dwc, p[att + "location_layer.location_conv.conv.weight"], None,
+                             g[att + "location_layer.location_conv.conv.weight"], None, cip=8)
+        d_pm16 = self._cast(d_pm)
+        self._wgrad(d_pm16, memory, g[att + "memory_layer.linear_layer.weight"], b * ti)
+        F.gemm(d_pm16, w["mem"], b * ti, E, A, True, False, out=d_memory, accumulate=True)
+        # ---- prenet
+        r_all = (to + 1) * b
+        d_l2d = self._z(r_all, P)
+        F.gemm(ga2, w["a_pre"], rt, P, 4 * Ha, True, False, out=d_l2d[:rt])
+        d_l2 = F.dropout_bwd(d_l2d, sv["m2"], 0.5)
+        d_pre2 = self._relu_mask(d_l2, sv["l2"])
+        self._wgrad(d_pre2, sv["l1d"], g["decoder.prenet.layers.1.linear_layer.weight"], r_all)
+        d_l1d = F.gemm(d_pre2, w["pre1"], r_all, P, P, True, False)
+        d_pre1 = self._relu_mask(F.dropout_bwd(d_l1d, sv["m1"], 0.5), sv["l1"])
+        self._wgrad(d_pre1, sv["dec_in"].view(r_all, NM), g["decoder.prenet.layers.0.linear_layer.weight"], r_all)
+        # ---- encoder: bi-LSTM BPTT, convolutions, embedding
+        dm3 = d_memory.view(b, ti, E)
+        x_enc = sv["enc_out"]
+        dx_enc = None
+        for d, sfx in enumerate(("", "_reverse")):
+            s = sv["lstm"][sfx]
+            gates, hprev, c_all, order = s["gates"], s["hprev"], s["c_all"], s["order"]
+            dh_rec = self._z(b, h, dtype=f32)
+            d_c = self._z(b, h, dtype=f32)
+            for k in range(ti - 1, -1, -1):
+                t = order[k]
+                dh = dm3[:, t, d * h:(d + 1) * h] + dh_rec
+                dh_prev = torch.empty_like(dh_rec)
+                d_c_prev = torch.empty_like(d_c)
+                ops.lstm_bwd(dh, d_c, gates[:, t], c_all[k], gates[:, t], d_c_prev, live=sv["live"][t], dh_prev=dh_prev)
+                d_c = d_c_prev
+                F.gemm(gates[:, t], w["ehh" + sfx], b, h, 4 * h, True, False, out=dh_prev, accumulate=True)
+                dh_rec = dh_prev
+            g2 = gates.view(b * ti, 4 * h)
+            self._wgrad(g2, x_enc, g["encoder.lstm.weight_ih_l0" + sfx], b * ti)
+            self._wgrad(g2, hprev.view(b * ti, h), g["encoder.lstm.weight_hh_l0" + sfx], b * ti)
+            F.colsum(g2, out=g["encoder.lstm.bias_ih_l0" + sfx])
+            g["encoder.lstm.bias_hh_l0" + sfx].copy_(g["encoder.lstm.bias_ih_l0" + sfx])
+            dx_d = F.gemm(g2, w["eih" + sfx], b * ti, E, 4 * h, True, False, out_dtype=f32)
+            dx_enc = dx_d if dx_enc is None else dx_enc + dx_d
+        dy = self._cast(dx_enc)
+        for i in range(cfg["encoder_n_convolutions"] - 1, -1, -1):
+            dy = self._conv_bn_bwd(dy, sv["enc"][i], b, ti, w["enc%d" % i])
+        g["embedding.weight"].zero_()
+        F.embed_scatter_add_(g["embedding.weight"], dy, sv["text"])
+        if self.buckets is not None:
+            for _, _, name in self.buckets.buckets:
+                self.buckets.grad_ready(name)
+
+    def _relu_mask(self, g, y):
+        out = torch.empty_like(g)
+        return F.relu_bwd(g, y, out)
+
+    # ------------------------------------------------------------------ optimizer (train.py:487-497)
+    def optimizer_step(self):
+        sc = self.scaler
+        if self.buckets is not None:
+            self.buckets.wait()
+        t_g = self._tables.get("g", [[self.g.flat]])
+        if sc.enabled:
+            F.check_nonfinite_(self.g.flat, sc.found_inf)
+        self.noop.copy_(sc.found_inf.to(torch.int32))
+        self.step_t += (1 - self.noop)
+        gnorm, _ = mt.l2norm(t_g)
+        self.grad_norm = gnorm
+        t_adam = self._tables.get("adam", [[self.g.flat], [self.p.flat], [self.m.flat], [self.v.flat]],
+                                  chunk=mt.streaming_chunk([[self.g.flat]]))
+        mt.adam(t_adam, self.lr_t, 0.9, 0.999, 1e-8, self.wd, self.step_t, skip_flag=sc.found_inf if sc.enabled else None,
+                inv_scale=sc.inv_scale if sc.enabled else None, grad_norm=gnorm, max_grad_norm=self.clip)
+        sc.update()
+
+    def set_lr(self, lr):
+        if lr != self.lr:
+            self.lr = float(lr)
+            self.lr_t.fill_(self.lr)
+
+    def train_step(self, text, text_lengths, mel, gate_target, output_lengths=None):
+        loss = self.forward(text, text_lengths, mel, gate_target, output_lengths)
+        self.backward()
+        self.optimizer_step()
+        return loss

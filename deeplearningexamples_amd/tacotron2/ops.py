@@ -1,0 +1,85 @@
+"""Tensor-level wrappers of the Tacotron2 entry points of the C ABI (include/dle_mi355x.h, csrc/tacotron2.hip): allocation and
+argument marshalling only; no CPU path.  Reference pieces they stand in for (SpeechSynthesis/Tacotron2/tacotron2/): the pointwise
+part of nn.LSTM / nn.LSTMCell with the dropout that follows it (model.py:205-214,425-444), the location-sensitive attention of one
+decoder step (model.py:79-121), the mel terms of Tacotron2Loss (loss_function.py:42-44), torch.tanh of the postnet (model.py:170).
+"""
+import torch
+
+from .. import _cabi as C
+
+
+def inv_keep(p):
+    """Scale of a kept element: the drop probability is quantised to 1/65536 (csrc/dropout.h make_drop)."""
+    thr = min(max(int(p * 65536.0 + 0.5), 0), 65535)
+    return 65536.0 / (65536 - thr)
+
+
+def _ld(t, what):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError("%s: expected a 2-D view with unit inner stride" % what)
+    return t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
+
+def tanh_fwd(x):
+    C.require_cuda(x)
+    if not x.is_contiguous():
+        raise ValueError("tanh_fwd: contiguous input")
+    y = torch.empty_like(x)
+    C.call("dle_t2_tanh_fwd", C.ptr(x), C.ptr(y), x.numel(), C.dt(x), C.stream())
+    return y
+
+
+def lstm_fwd(gates, c_prev, c_out, h_dsts, keep=None, keep_index=0, p=0.0, live=None, h_prev=None, out_dst=None):
+    """See tests/_tacotron2_doubles.py lstm_fwd for the statement.  gates: 16-bit [B, 4H] row-strided view, replaced by the gate
+    activations; h_dsts: up to three 16-bit [B, H] row-strided views."""
+    C.require_cuda(gates, c_prev, c_out, keep, live, h_prev, out_dst, *h_dsts)
+    b, h4 = gates.shape
+    hh = h4 // 4
+    if len(h_dsts) > 3:
+        raise ValueError("lstm_fwd: at most three destinations")
+    d = list(h_dsts) + [None] * (3 - len(h_dsts))
+    C.call("dle_t2_lstm_fwd", C.ptr(gates), _ld(gates, "gates"), C.ptr(c_prev), C.ptr(c_out), C.ptr(d[0]),
+           _ld(d[0], "h dst") if d[0] is not None else 0, C.ptr(d[1]), _ld(d[1], "h dst") if d[1] is not None else 0, C.ptr(d[2]),
+           _ld(d[2], "h dst") if d[2] is not None else 0, C.ptr(keep), int(keep_index), float(inv_keep(p) if keep is not None else 1.0),
+           C.ptr(live), C.ptr(h_prev), _ld(h_prev, "h_prev") if h_prev is not None else 0, C.ptr(out_dst),
+           _ld(out_dst, "out_dst") if out_dst is not None else 0, b, hh, C.dt(gates), C.stream())
+
+
+def lstm_bwd(dh, dc_next, act, c_prev, dgates, dc_prev, keep=None, keep_index=0, p=0.0, live=None, dh_prev=None):
+    C.require_cuda(dh, dc_next, act, c_prev, dgates, dc_prev, keep, live, dh_prev)
+    b, hh = dh.shape
+    C.call("dle_t2_lstm_bwd", C.ptr(dh), _ld(dh, "dh"), C.ptr(dc_next), C.ptr(act), _ld(act, "act"), C.ptr(c_prev), C.ptr(dgates),
+           _ld(dgates, "dgates"), C.ptr(dc_prev), C.ptr(keep), int(keep_index), float(inv_keep(p) if keep is not None else 1.0),
+           C.ptr(live), C.ptr(dh_prev), b, hh, C.dt(act), C.stream())
+
+
+def attention_fwd(q, pl, v, memory, lengths, awc_prev, tanh_out, aw_out, awc_next, ctx_dsts):
+    C.require_cuda(q, pl, v, memory, lengths, awc_prev, tanh_out, aw_out, awc_next, *ctx_dsts)
+    b, a = q.shape
+    ti = pl.shape[0] // b
+    e = memory.shape[1]
+    if len(ctx_dsts) > 3:
+        raise ValueError("attention_fwd: at most three destinations")
+    d = list(ctx_dsts) + [None] * (3 - len(ctx_dsts))
+    C.call("dle_t2_attention_fwd", C.ptr(q), C.ptr(pl), C.ptr(v), C.ptr(memory), C.ptr(lengths), C.ptr(awc_prev), C.ptr(tanh_out),
+           C.ptr(aw_out), C.ptr(awc_next), C.ptr(d[0]), _ld(d[0], "ctx dst") if d[0] is not None else 0, C.ptr(d[1]),
+           _ld(d[1], "ctx dst") if d[1] is not None else 0, C.ptr(d[2]), _ld(d[2], "ctx dst") if d[2] is not None else 0, b, ti, a, e,
+           C.dt(pl), C.stream())
+
+
+def attention_bwd(d_ctx, d_aw_in, aw, tanh_out, v, memory, d_memory, d_pl, dq, dv_acc, d_pm_acc):
+    C.require_cuda(d_ctx, d_aw_in, aw, tanh_out, v, memory, d_memory, d_pl, dq, dv_acc, d_pm_acc)
+    b, ti = aw.shape
+    C.call("dle_t2_attention_bwd", C.ptr(d_ctx), C.ptr(d_aw_in), C.ptr(aw), C.ptr(tanh_out), C.ptr(v), C.ptr(memory),
+           C.ptr(d_memory), C.ptr(d_pl), C.ptr(dq), C.ptr(dv_acc), C.ptr(d_pm_acc), b, ti, v.numel(), memory.shape[1],
+           C.dt(tanh_out), C.stream())
+
+
+def mel_loss(out_all, post, target, n_mel, scale, d_out, d_post):
+    C.require_cuda(out_all, post, target, scale, d_out, d_post)
+    r = out_all.shape[0]
+    loss = torch.empty(1, dtype=torch.float32, device=out_all.device)
+    ws = torch.empty(1024, dtype=torch.float32, device=out_all.device)
+    C.call("dle_t2_mel_loss", C.ptr(out_all), _ld(out_all, "out_all"), C.ptr(post), C.ptr(target), C.ptr(scale), C.ptr(d_out),
+           _ld(d_out, "d_out"), C.ptr(d_post), C.ptr(loss), C.ptr(ws), r, n_mel, C.dt(post), C.stream())
+    return loss
