@@ -132,6 +132,15 @@ _SIGS = {
     "dle_wg_weight_norm_fwd_batched": (c_int, [c_void_p, c_int, c_i64, c_int, c_void_p]),
     "dle_wg_weight_norm_bwd_batched": (c_int, [c_void_p, c_int, c_i64, c_void_p]),
     "dle_wg_logdet_inv_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dle_t2_tanh_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+    "dle_t2_lstm_fwd": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p,
+                                c_i64, c_float, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
+    "dle_t2_lstm_bwd": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64,
+                                c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dle_t2_attention_fwd": (c_int, [c_void_p] * 10 + [c_i64, c_void_p, c_i64, c_void_p, c_i64] + [c_int] * 5 + [c_void_p]),
+    "dle_t2_attention_bwd": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_void_p]),
+    "dle_t2_mel_loss": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64,
+                                c_int, c_int, c_void_p]),
 }
 
 _lib = None

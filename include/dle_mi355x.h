@@ -403,6 +403,35 @@ int dle_wg_weight_norm_bwd_batched(const int64_t* table_dev, int n_entries, int6
 int dle_wg_logdet_inv_batched(const float* base, const int64_t* table_dev, float* logdets, float* WinvT, float* signs,
                               int n_flows, hipStream_t stream);
 
+/* ---- Tacotron2 training step (csrc/tacotron2.hip): SpeechSynthesis/Tacotron2/tacotron2/model.py + loss_function.py -----------
+ * dle_t2_lstm_fwd/bwd: the pointwise part of nn.LSTM / nn.LSTMCell (model.py:205-214,425-444) on gates [B, 4H] (i, f, g, o, biases
+ *   included; replaced in place by the gate activations, which the backward reads) + the F.dropout on the hidden state (bit-packed
+ *   keep mask of dle_dropout_fwd, bit <-> element keep_index + b*H + j, scale inv_keep); h goes to up to three row-strided
+ *   destinations (the operand buffers of its consumers).  live (fp32 [B], optional): rows with 0 keep (h_prev, c_prev) and write 0
+ *   to out_dst -- pack_padded_sequence semantics of the encoder (model.py:205-214).
+ * dle_t2_attention_fwd/bwd: Attention.forward of one decoder step (model.py:79-121): energies v . tanh(q + pl) (pl = processed
+ *   memory + location term, [B*Ti, A]), softmax over the first lengths[b] text positions, context = weights x memory ([B*Ti, E]);
+ *   awc rows = (weights, cumulative weights, 0 x 6) 16-bit = the next step's location-convolution input.  Backward accumulates
+ *   d_memory / d_pm (fp32) and dv across steps, writes d_pl (16-bit) and dq.
+ * dle_t2_tanh_fwd: torch.tanh of the postnet (model.py:170).  dle_t2_mel_loss: MSE(mel_out) + MSE(mel_out + postnet) of
+ *   Tacotron2Loss (loss_function.py:42-44) and its gradients (scaled by *scale_dev); workspace >= 1024 floats. */
+int dle_t2_tanh_fwd(const void* x, void* y, int64_t n, int dtype, hipStream_t stream);
+int dle_t2_lstm_fwd(void* gates, int64_t ld_g, const float* c_prev, float* c_out, void* d0, int64_t ld0, void* d1, int64_t ld1,
+                    void* d2, int64_t ld2, const void* keep, int64_t keep_index, float inv_keep, const float* live,
+                    const void* h_prev, int64_t ld_hp, void* out_dst, int64_t ld_out, int B, int H, int dtype, hipStream_t stream);
+int dle_t2_lstm_bwd(const float* dh, int64_t ld_dh, const float* dc_next, const void* act, int64_t ld_act, const float* c_prev,
+                    void* dgates, int64_t ld_dg, float* dc_prev, const void* keep, int64_t keep_index, float inv_keep,
+                    const float* live, float* dh_prev, int B, int H, int dtype, hipStream_t stream);
+int dle_t2_attention_fwd(const float* q, const void* pl, const float* v, const void* memory, const int64_t* lengths,
+                         const void* awc_prev, void* tanh_out, float* aw_out, void* awc_next, void* d0, int64_t ld0, void* d1,
+                         int64_t ld1, void* d2, int64_t ld2, int B, int Ti, int A, int E, int dtype, hipStream_t stream);
+int dle_t2_attention_bwd(const float* d_ctx, const float* d_aw_in, const float* aw, const void* tanh_out, const float* v,
+                         const void* memory, float* d_memory, void* d_pl, float* dq, float* dv_acc, float* d_pm_acc, int B, int Ti,
+                         int A, int E, int dtype, hipStream_t stream);
+int dle_t2_mel_loss(const float* out_all, int64_t ld_out, const void* post, const float* target, const float* scale_dev,
+                    void* d_out, int64_t ld_dout, void* d_post, float* loss, float* workspace, int64_t R, int n_mel, int dtype,
+                    hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,202 @@
+"""Tacotron2 train step on the MI355X (second half): every kernel of csrc/tacotron2.hip against the plain-torch
+statement of the same entry point (tests/_tacotron2_doubles.py, evaluated on the CPU), and the whole step against the oracle
+that the reference's own Tacotron2 + Tacotron2Loss pins (tests/golden/tacotron2_loss.npz), evaluated under the dropout masks
+the HIP RNG drew.  Bars: loss 1e-3 relative (north_star); gradients inside the 16-bit STORAGE floor measured with the
+fp64-accumulating doubles at the same storage dtype (BPTT through ~30 decoder steps + the encoder: fp16 worst tensor 4 %, median
+0.3 %; bf16 worst 14 %, median 2 %) times a margin."""
+import numpy as np
+import pytest
+import torch
+
+from tests import _tacotron2_doubles as D
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float16, torch.bfloat16]
+
+
+def _tol(dtype):
+    return dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=1.6e-2, atol=1.6e-2)
+
+
+def _ops():
+    from deeplearningexamples_amd.tacotron2 import ops
+    return ops
+
+
+def _close(got, ref, **kw):
+    np.testing.assert_allclose(got.detach().float().cpu().numpy(), ref.detach().float().cpu().numpy(), **kw)
+
+
+def _keep_bits(n, p, g):
+    keep = torch.rand(n, generator=g) >= p
+    return keep, D._pack(keep)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,h,with_drop,with_live", [(3, 96, True, False), (48, 1024, True, False), (5, 32, False, True), (104, 256, False, True)])
+def test_lstm_cell_forward_backward(cuda, dtype, b, h, with_drop, with_live):
+    ops = _ops()
+    g = torch.Generator().manual_seed(b * 7 + h)
+    wide = (torch.randn(b, 3, 4 * h, generator=g) * 1.5).to(dtype)                 # gates = a [B, 4H] slice with row stride 12 H
+    c_prev = torch.randn(b, h, generator=g)
+    h_prev = torch.randn(b, h, generator=g).to(dtype)
+    keep, bits = _keep_bits(4 * b * h, 0.1, g) if with_drop else (None, None)
+    kidx = 2 * b * h if with_drop else 0
+    live = (torch.rand(b, generator=g) > 0.4).float() if with_live else None
+
+    def run(L, d):
+        gates = d(wide.clone())
+        c_out, dst0, dst1 = d(torch.zeros(b, h)), d(torch.zeros(b, 2 * h, dtype=dtype)), d(torch.zeros(b, h, dtype=dtype))
+        out_dst = d(torch.zeros(b, 3 * h, dtype=dtype)) if with_live else None
+        L.lstm_fwd(gates[:, 1], d(c_prev), c_out, [dst0[:, h:], dst1], keep=d(bits) if with_drop else None, keep_index=kidx, p=0.1,
+                   live=d(live) if with_live else None, h_prev=d(h_prev) if with_live else None,
+                   out_dst=out_dst[:, h:2 * h] if with_live else None)
+        return gates, c_out, dst0, dst1, out_dst
+    got, ref = run(ops, lambda t: t.to(cuda)), run(D, lambda t: t)
+    for a, r in zip(got, ref):
+        if a is not None:
+            _close(a, r, **_tol(dtype))
+    # backward from the activations the forward left behind
+    act = ref[0]
+    dh, dc_next = torch.randn(b, h, generator=g), torch.randn(b, h, generator=g)
+
+    def runb(L, d):
+        a = d(act.clone())
+        dcp, dhp = d(torch.zeros(b, h)), d(torch.zeros(b, h)) if with_live else None
+        L.lstm_bwd(d(dh), d(dc_next), a[:, 1], d(c_prev), a[:, 1], dcp, keep=d(bits) if with_drop else None, keep_index=kidx, p=0.1,
+                   live=d(live) if with_live else None, dh_prev=dhp)
+        return a, dcp, dhp
+    got, ref = runb(ops, lambda t: t.to(cuda)), runb(D, lambda t: t)
+    for a, r in zip(got, ref):
+        if a is not None:
+            _close(a, r, **_tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,ti,a,e", [(3, 23, 32, 64), (48, 150, 128, 512), (2, 300, 128, 512)])
+def test_attention_step_forward_backward(cuda, dtype, b, ti, a, e):
+    ops = _ops()
+    g = torch.Generator().manual_seed(b + ti)
+    q = torch.randn(b, a, generator=g)
+    pl = torch.randn(b * ti, a, generator=g).to(dtype)
+    v = torch.randn(a, generator=g) * 0.5
+    mem = torch.randn(b * ti, e, generator=g).to(dtype)
+    lengths = torch.randint(ti // 2, ti + 1, (b,), generator=g)
+    lengths[0] = ti
+    awc_prev = torch.zeros(b * ti, 8, dtype=dtype)
+    awc_prev[:, :2] = torch.rand(b * ti, 2, generator=g).to(dtype)
+
+    def run(L, d):
+        th, aw, nxt = d(torch.zeros(b * ti, a, dtype=dtype)), d(torch.zeros(b, ti)), d(torch.ones(b * ti, 8, dtype=dtype))
+        c0, c1 = d(torch.zeros(b, 2 * e, dtype=dtype)), d(torch.zeros(b, e, dtype=dtype))
+        L.attention_fwd(d(q), d(pl), d(v), d(mem), d(lengths), d(awc_prev), th, aw, nxt, [c0[:, e:], c1])
+        return th, aw, nxt, c0, c1
+    got, ref = run(ops, lambda t: t.to(cuda)), run(D, lambda t: t)
+    _close(got[0], ref[0], **_tol(dtype))
+    _close(got[1], ref[1], rtol=2e-2, atol=2e-4)                                  # the saved tanh is rounded to 16 bits in both
+    for k in (2, 3, 4):
+        _close(got[k], ref[k], **_tol(dtype))
+    pad = torch.arange(ti)[None, :] >= lengths[:, None]
+    assert float(got[1].cpu()[pad].abs().max() if pad.any() else 0.0) == 0.0      # no weight on padded text positions
+    # backward, from the CPU forward's saved tensors
+    th, aw = ref[0], ref[1]
+    d_ctx, d_aw_in = torch.randn(b, e, generator=g), torch.randn(b, ti, generator=g) * 0.1
+    base_mem, base_pm, base_dv = torch.randn(b * ti, e, generator=g), torch.randn(b * ti, a, generator=g), torch.randn(a, generator=g)
+
+    def runb(L, d):
+        dmem, dpm, dv = d(base_mem.clone()), d(base_pm.clone()), d(base_dv.clone())
+        dpl, dq = d(torch.zeros(b * ti, a, dtype=dtype)), d(torch.zeros(b, a))
+        L.attention_bwd(d(d_ctx), d(d_aw_in), d(aw), d(th), d(v), d(mem), dmem, dpl, dq, dv, dpm)
+        return dmem, dpl, dq, dv, dpm
+    got, ref = runb(ops, lambda t: t.to(cuda)), runb(D, lambda t: t)
+    _close(got[0], ref[0], rtol=1e-4, atol=1e-4)
+    _close(got[1], ref[1], **_tol(dtype))
+    _close(got[2], ref[2], rtol=2e-3, atol=2e-3)
+    _close(got[3], ref[3], rtol=2e-3, atol=5e-3)
+    _close(got[4], ref[4], rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_mel_loss_and_tanh(cuda, dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    r, nm, ld = 93, 80, 88
+    out_all = torch.randn(r, ld, generator=g)
+    post = torch.randn(r, nm, generator=g).to(dtype)
+    target = torch.randn(r, nm, generator=g) - 2
+    scale = torch.tensor([128.0])
+
+    def run(L, d):
+        d_out, d_post = d(torch.zeros(r, ld, dtype=dtype)), d(torch.zeros(r, nm, dtype=dtype))
+        loss = L.mel_loss(d(out_all), d(post), d(target), nm, d(scale), d_out, d_post)
+        return loss, d_out, d_post
+    got, ref = run(ops, lambda t: t.to(cuda)), run(D, lambda t: t)
+    _close(got[0], ref[0], rtol=1e-5)
+    _close(got[1], ref[1], **_tol(dtype))
+    _close(got[2], ref[2], **_tol(dtype))
+    x = (torch.randn(4097, generator=g) * 2).to(dtype)
+    _close(ops.tanh_fwd(x.to(cuda)), D.tanh_fwd(x), **_tol(dtype))
+
+
+def _engine_masks(tr, F):
+    """The keep masks the engine drew (HIP counter-based RNG), in the order tests/test_tacotron2_host.py _Replay expects."""
+    sv = tr.sv
+    b, ti, to = sv["b"], sv["ti"], sv["to"]
+    un = lambda m, shape: F.unpack_dropout_mask(m, shape).cpu()
+    log = [un(s["mask"], s["y"].shape) for s in sv["enc"]]
+    log += [un(sv["m1"], sv["l1"].shape), un(sv["m2"], sv["l2"].shape)]
+    log += [un(sv["keep_a"], (to * b * tr.Ha,)), un(sv["keep_d"], (to * b * tr.Hd,))]
+    log += [un(s["mask"], s["y"].shape) for s in sv["post"]]
+    return log
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_step_loss_and_gradients_vs_oracle_under_the_hip_masks(cuda, dtype):
+    from oracle import tacotron2_oracle as TO
+    from deeplearningexamples_amd import functional as F
+    from deeplearningexamples_amd.tacotron2.engine import Tacotron2Trainer
+    from deeplearningexamples_amd.tacotron2.model import Tacotron2
+    from tests.test_tacotron2_host import _Replay
+    c = TO.TACOTRON2_CASE
+    cfg = c["cfg"]
+    state = TO.seeded_state(cfg, c["seed"])
+    model = Tacotron2(device=cuda, **cfg)
+    model.load_reference_state(state)
+    tr = Tacotron2Trainer(model, compute_dtype=dtype, init_loss_scale=1024.0)
+    text, tl, mel, gate, ml = TO.seeded_batch(c)
+    loss = tr.forward(text.to(cuda), tl.to(cuda), mel.to(cuda), gate.to(cuda))
+    tr.backward()
+    assert bool(torch.isfinite(tr.g.flat).all())
+    replay = _Replay(_engine_masks(tr, F), mel.shape[2], text.shape[0], cfg["attention_rnn_dim"], cfg["decoder_rnn_dim"])
+    p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    lo, (_, _, _, align) = TO.tacotron2_loss(p, cfg, text, tl, mel, gate, replay)
+    lo.backward()
+    assert replay.calls == len(replay.sites)
+    assert abs(float(loss) - float(lo.detach())) <= 1e-3 * abs(float(lo.detach())), (float(loss), float(lo.detach()))
+    _close(tr.sv["aw"].permute(1, 0, 2), align, rtol=5e-2, atol=2e-3 if dtype == torch.float16 else 1e-2)
+    worst_bar, med_bar = (0.10, 1.5e-2) if dtype == torch.float16 else (0.35, 6e-2)
+    errs = {}
+    for k, v in p.items():
+        if float(v.grad.norm()) > 1e-5:                        # (conv biases in front of a BatchNorm have zero gradient)
+            errs[k] = float((tr.g[k].cpu() / 1024.0 - v.grad).norm() / v.grad.norm())
+    bad = {k: e for k, e in errs.items() if e > worst_bar}
+    assert not bad, bad
+    assert float(np.median(list(errs.values()))) <= med_bar
+    # keep rates of the drawn masks
+    log = _engine_masks(tr, F)
+    assert abs(float(log[0].float().mean()) - 0.5) < 0.03 and abs(float(log[5].float().mean()) - 0.9) < 0.03
+
+
+def test_three_steps_run_and_the_loss_falls(cuda):
+    from oracle import tacotron2_oracle as TO
+    from deeplearningexamples_amd.tacotron2.engine import Tacotron2Trainer
+    from deeplearningexamples_amd.tacotron2.model import Tacotron2
+    c = TO.TACOTRON2_CASE
+    model = Tacotron2(device=cuda, **c["cfg"])
+    model.load_reference_state(TO.seeded_state(c["cfg"], c["seed"]))
+    tr = Tacotron2Trainer(model, compute_dtype=torch.float16, lr=1e-3, init_loss_scale=1024.0)
+    batch = [t.to(cuda) for t in TO.seeded_batch(c)[:4]]
+    losses = [float(tr.train_step(*batch)) for _ in range(6)]
+    assert int(tr.step_t) == 6 and float(tr.scaler.found_inf) == 0 and all(np.isfinite(losses))
+    assert losses[-1] < losses[0], losses
+    assert int(model.state_dict()["postnet.convolutions.0.1.num_batches_tracked"]) == 6
