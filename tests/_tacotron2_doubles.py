@@ -260,7 +260,7 @@ def attention_bwd(d_ctx, d_aw_in, aw, tanh_out, v, memory, d_memory, d_pl, dq, d
     d_pre = d_e.unsqueeze(2) * v.view(1, 1, a) * (1 - th * th)
     d_pl.copy_(d_pre.view(b * ti, a))
     dq.copy_(d_pre.sum(1))
-    d_pm_acc.add_(d_pl.float())
+    d_pm_acc.add_(d_pre.view(b * ti, a))                               # the fp32 value, not its 16-bit rounding
 
 
 def mel_loss(out_all, post, target, n_mel, scale, d_out, d_post):

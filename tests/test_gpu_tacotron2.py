@@ -162,11 +162,13 @@ def test_step_loss_and_gradients_vs_oracle_under_the_hip_masks(cuda, dtype):
     state = TO.seeded_state(cfg, c["seed"])
     model = Tacotron2(device=cuda, **cfg)
     model.load_reference_state(state)
-    tr = Tacotron2Trainer(model, compute_dtype=dtype, init_loss_scale=1024.0)
+    scale = 65536.0                                            # GradScaler's default: small fp16 gradients stay out of the subnormals
+    tr = Tacotron2Trainer(model, compute_dtype=dtype, init_loss_scale=scale)
     text, tl, mel, gate, ml = TO.seeded_batch(c)
     loss = tr.forward(text.to(cuda), tl.to(cuda), mel.to(cuda), gate.to(cuda))
     tr.backward()
     assert bool(torch.isfinite(tr.g.flat).all())
+    print({k: round(float(tr.g[k].abs().max()), 1) for k in ("embedding.weight", "decoder.decoder_rnn.weight_ih")})
     replay = _Replay(_engine_masks(tr, F), mel.shape[2], text.shape[0], cfg["attention_rnn_dim"], cfg["decoder_rnn_dim"])
     p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
     lo, (_, _, _, align) = TO.tacotron2_loss(p, cfg, text, tl, mel, gate, replay)
@@ -174,11 +176,13 @@ def test_step_loss_and_gradients_vs_oracle_under_the_hip_masks(cuda, dtype):
     assert replay.calls == len(replay.sites)
     assert abs(float(loss) - float(lo.detach())) <= 1e-3 * abs(float(lo.detach())), (float(loss), float(lo.detach()))
     _close(tr.sv["aw"].permute(1, 0, 2), align, rtol=5e-2, atol=2e-3 if dtype == torch.float16 else 1e-2)
-    worst_bar, med_bar = (0.10, 1.5e-2) if dtype == torch.float16 else (0.35, 6e-2)
+    # floor of the worst tensor (always an encoder one: its gradient crosses the decoder sweep, the attention, the bi-LSTM sweep and
+    # three conv + BatchNorm layers) over six mask draws with the doubles: fp16 1 - 6 %, bf16 ~14 %; medians 0.3 % / 2 %
+    worst_bar, med_bar = (0.15, 1.5e-2) if dtype == torch.float16 else (0.35, 6e-2)
     errs = {}
     for k, v in p.items():
         if float(v.grad.norm()) > 1e-5:                        # (conv biases in front of a BatchNorm have zero gradient)
-            errs[k] = float((tr.g[k].cpu() / 1024.0 - v.grad).norm() / v.grad.norm())
+            errs[k] = float((tr.g[k].cpu() / scale - v.grad).norm() / v.grad.norm())
     bad = {k: e for k, e in errs.items() if e > worst_bar}
     assert not bad, bad
     assert float(np.median(list(errs.values()))) <= med_bar
