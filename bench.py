@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=os.environ.get("DLE_BENCH_WORKLOAD", "rn50"),
-                    choices=["dlrm", "rn50", "bert", "waveglow"])
+                    choices=["dlrm", "rn50", "bert", "waveglow", "tacotron2"])
     ap.add_argument("--batch", type=int, default=None, help="global batch (DLRM) / per-GPU batch (RN50, BERT)")
     ap.add_argument("--dtype", default=None, choices=[None, "fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -349,8 +349,75 @@ class WaveGlowWorkload:
                           "the reference's modules) + clip_grad_norm_ + torch.optim.Adam, 1 step of 1 x 2048 audio samples"}
 
 
-WORKLOADS = {"dlrm": DlrmWorkload, "rn50": Rn50Workload, "bert": BertWorkload, "waveglow": WaveGlowWorkload}
-NESTED_STEPS = {"rn50": (30, 8), "bert": (12, 3), "dlrm": (100, 20), "waveglow": (10, 3)}   # (timed steps, warm-up), nested records
+class Tacotron2Workload:
+    """BASELINE.json configs[4], the Tacotron2 half (a "next" row -- not part of the bar): the reference's default
+    network (tacotron2/arg_parser.py:40-107, 28.2 M parameters), fp16 AMP, batch 128 (platform/DGXA100_tacotron2_AMP_1NGPU_train.sh),
+    Adam lr 1e-3, weight decay 1e-6, grad-clip 1.0; synthetic LJSpeech-shaped batch from TextMelCollate's layout: text lengths
+    60..160 symbols sorted descending, mel lengths ~5.4 frames per symbol (320..860 frames), zero padded, teacher forcing.  Unit =
+    mel frames / s, the reference's `train_items_per_sec` (sum of output_lengths per iteration, tacotron2/data_function.py:139-151)."""
+
+    name = "tacotron2"
+
+    def __init__(self, args, rank, world, device):
+        from deeplearningexamples_amd.tacotron2.engine import Tacotron2Trainer
+        from deeplearningexamples_amd.tacotron2.model import Tacotron2
+        self.rank, self.world, self.device = rank, world, device
+        self.batch = args.batch or 128
+        self.dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+        torch.manual_seed(0)
+        self.model = Tacotron2(device=device)
+        self.trainer = Tacotron2Trainer(self.model, lr=1e-3, weight_decay=1e-6, grad_clip_thresh=1.0, compute_dtype=self.dtype,
+                                        world_size=world, rank=rank)
+        g = torch.Generator(device="cpu").manual_seed(700 + rank)
+        tl = torch.sort(torch.randint(60, 161, (self.batch,), generator=g), descending=True).values
+        ml = (tl.float() * (5.0 + 0.8 * torch.rand(self.batch, generator=g))).long()
+        text = torch.zeros(self.batch, int(tl.max()), dtype=torch.long)
+        mel = torch.zeros(self.batch, 80, int(ml.max()))
+        gate = torch.zeros(self.batch, int(ml.max()))
+        for i in range(self.batch):
+            text[i, :tl[i]] = torch.randint(1, 148, (int(tl[i]),), generator=g)
+            mel[i, :, :ml[i]] = torch.randn(80, int(ml[i]), generator=g) * 1.5 - 4.0
+            gate[i, ml[i] - 1:] = 1
+        self.data = [t.to(device) for t in (text, tl, mel, gate)]
+        self.samples_per_step = int(ml.sum()) * world
+        self.frames, self.text_len = int(ml.max()), int(tl.max())
+        self.scaling = "weak"
+        self.loss = None
+
+    def step(self):
+        self.loss = self.trainer.train_step(*self.data)
+
+    def config(self):
+        return {"workload": "Tacotron2 training (PyTorch/SpeechSynthesis/Tacotron2 -m Tacotron2), default network, teacher forcing, "
+                            "synthetic LJSpeech-shaped padded batch (BASELINE.json configs[4], Tacotron2 half)",
+                "batch_per_gpu": self.batch, "max_text_len": self.text_len, "max_mel_frames": self.frames,
+                "mel_frames_per_step": self.samples_per_step // self.world, "unit_note": "mel frames / s",
+                "parallelism": "single GPU" if self.world == 1 else "dp%d" % self.world}
+
+    def dtype_name(self):
+        return "fp16" if self.dtype == torch.float16 else "bf16"
+
+    def cpu_baseline(self):
+        from oracle import tacotron2_oracle as TO
+        cfg = TO.TACOTRON2_DEFAULT
+        case = dict(cfg=cfg, seed=5, text_lengths=[60, 50], mel_lengths=[120, 100])
+        p = {k: v.clone().requires_grad_(True) for k, v in TO.seeded_state(cfg, 5).items()}
+        text, tl, mel, gate, ml = TO.seeded_batch(case)
+        opt = torch.optim.Adam(list(p.values()), lr=1e-3, weight_decay=1e-6)
+        t0 = time.time()
+        opt.zero_grad()
+        TO.tacotron2_loss(p, cfg, text, tl, mel, gate, TO.MaskStream(1))[0].backward()
+        torch.nn.utils.clip_grad_norm_(list(p.values()), 1.0)
+        opt.step()
+        dt = time.time() - t0
+        return {"value": round(float(ml.sum()) / dt, 1), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": "oracle/tacotron2_oracle.py (fp32 torch-CPU restatement of Tacotron2 + Tacotron2Loss, pinned against the "
+                          "reference's modules under shared dropout masks) + clip_grad_norm_ + Adam, 1 step of 2 utterances, 220 mel frames"}
+
+
+WORKLOADS = {"dlrm": DlrmWorkload, "rn50": Rn50Workload, "bert": BertWorkload, "waveglow": WaveGlowWorkload,
+             "tacotron2": Tacotron2Workload}
+NESTED_STEPS = {"rn50": (30, 8), "bert": (12, 3), "dlrm": (100, 20), "waveglow": (10, 3), "tacotron2": (3, 1)}   # (timed steps, warm-up)
 
 REFERENCE_PUBLISHED = {
     "rn50": {"value": 2470, "unit": "img/s", "hardware": "1x A100 80GB, mixed precision, bs 256",
@@ -361,6 +428,8 @@ REFERENCE_PUBLISHED = {
              "source": "PyTorch/Recommendation/DLRM/README.md:923-924"},
     "waveglow": {"value": 149479, "unit": "audio samples/s", "hardware": "1x A100 40GB, AMP, bs 10",
                  "source": "PyTorch/SpeechSynthesis/Tacotron2/README.md:704-706"},
+    "tacotron2": {"value": 26484, "unit": "mel frames/s", "hardware": "1x A100 40GB, AMP, bs 128",
+                  "source": "PyTorch/SpeechSynthesis/Tacotron2/README.md:696-698"},
 }
 
 
@@ -370,8 +439,10 @@ REFERENCE_PUBLISHED = {
 #   DLRM Criteo-shape train  ~53 KB HBM / sample on the embedding path (gather read 13.3 KB + fp16 write 6.7 KB +
 #                            sparse gradient 13.3 KB + SGD row read-modify-write 26.6 KB, minus cache hits -> HBM)
 #   WaveGlow train           ~196 MFLOP / audio sample (WaveGlowWorkload.flops_per_audio_sample; GEMMs -> MFMA)
+#   Tacotron2 train          ~0.22 GFLOP / mel frame (3 x 2 x [attention LSTM 7.3 M + decoder LSTM 10.5 M + location / query / projection
+#                            0.3 M MAC per frame + the text-side work amortised]; latency-bound loop of small GEMMs -> priced on MFMA)
 WORK_PER_SAMPLE = {"rn50": ("mfma", 24.54e9), "bert": ("mfma", 240.6e9), "dlrm": ("hbm", 53.0e3),
-                   "waveglow": ("mfma", WaveGlowWorkload.flops_per_audio_sample())}
+                   "waveglow": ("mfma", WaveGlowWorkload.flops_per_audio_sample()), "tacotron2": ("mfma", 0.22e9)}
 # entry points whose launches are matrix-core kernels (gemm2_kernel / gemm_kernel / conv3x3_kernel instantiations)
 MFMA_FAMILIES = ("dle_gemm", "dle_gemm_batched", "dle_attention_fwd", "dle_attention_bwd", "dle_conv2d_fwd", "dle_conv2d_fwd_colstats", "dle_conv2d_dgrad", "dle_conv2d_dgrad_s2",
                  "dle_conv2d_wgrad", "dle_attention_fwd", "dle_attention_bwd")
@@ -547,8 +618,8 @@ def main():
     nested_names = []
     if world == 1 and not args.no_nested:
         nested_names = [w for w in ("rn50", "bert", "dlrm") if w != args.workload]
-        if args.workload != "waveglow" and os.environ.get("DLE_BENCH_WAVEGLOW", "1") != "0":
-            nested_names.append("waveglow")            # the "next" row (f1): reported beside the three workloads of the metric
+        if os.environ.get("DLE_BENCH_WAVEGLOW", "1") != "0":                 # the "next" row (f1), both halves: reported beside the
+            nested_names += [w for w in ("waveglow", "tacotron2") if w != args.workload]      # three workloads of the metric
     # ---- CPU leg first (rank 0, N = 1): the oracle on the host cores, bounded samples; the GPU legs then run back to
     # back to the end of the process
     cpu = {}

@@ -168,7 +168,6 @@ def test_step_loss_and_gradients_vs_oracle_under_the_hip_masks(cuda, dtype):
     loss = tr.forward(text.to(cuda), tl.to(cuda), mel.to(cuda), gate.to(cuda))
     tr.backward()
     assert bool(torch.isfinite(tr.g.flat).all())
-    print({k: round(float(tr.g[k].abs().max()), 1) for k in ("embedding.weight", "decoder.decoder_rnn.weight_ih")})
     replay = _Replay(_engine_masks(tr, F), mel.shape[2], text.shape[0], cfg["attention_rnn_dim"], cfg["decoder_rnn_dim"])
     p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
     lo, (_, _, _, align) = TO.tacotron2_loss(p, cfg, text, tl, mel, gate, replay)
