@@ -309,6 +309,12 @@ class Tacotron2Trainer:
         memory, pm = sv["memory"], sv["pm"]
         x_a, x_d, ga, gd, ac, dc, aw, awc = sv["x_a"], sv["x_d"], sv["ga"], sv["gd"], sv["ac"], sv["dc"], sv["aw"], sv["awc"]
         d_memory = self._z(b * ti, E, dtype=f32)
+        # context_t = weights_t x memory: d memory = sum_t weights_t (x) d_context_t.  When the shapes fit the batched kernel (Ti, E
+        # multiples of 8) the per-step gradients are kept (16-bit, steps padded to a multiple of 8) and the sum is ONE batched GEMM
+        # per sample after the sweep; otherwise the attention kernel accumulates it step by step.
+        hoist = ti % 8 == 0 and E % 8 == 0
+        to8 = (to + 7) // 8 * 8
+        dctx_all = self._z(to8, b, E) if hoist else None
         d_pm = self._z(b * ti, A, dtype=f32)
         dv = self._z(A, dtype=f32)
         dw_loc = self._z(A, self.KL * 8, dtype=f32)
@@ -333,13 +339,16 @@ class Tacotron2Trainer:
             d_cum_t = d_cum                                              # cumulative_t = cumulative_{t-1} + weights_t
             d_pl = self._e(b * ti, A)
             dq = self._e(b, A, dtype=f32)
-            ops.attention_bwd(d_ctx.contiguous(), (d_aw_loc + d_cum_t).contiguous(), aw[t], sv["tanh_all"][t], w["v"], memory, d_memory,
-                              d_pl, dq, dv, d_pm)
+            d_ctx = d_ctx.contiguous()
+            ops.attention_bwd(d_ctx, (d_aw_loc + d_cum_t).contiguous(), aw[t], sv["tanh_all"][t], w["v"], memory,
+                              None if hoist else d_memory, d_pl, dq, dv, d_pm)
+            if hoist:
+                dctx_all[t].copy_(d_ctx)
             dq_all[t].copy_(dq)
             # location term: pl = taps(awc[t]) x W_loc^T + pm
             col = wops.taps(awc[t], b, ti, self.KL, 1, self.KL // 2)
             F.gemm(d_pl, col, A, self.KL * 8, b * ti, False, False, out=dw_loc, accumulate=True,
-                   splitk=1)
+                   splitk=F.pick_splitk(A, self.KL * 8, b * ti))              # K = B * Ti rows over the chip, slabs summed onto dw_loc
             dcol = F.gemm(d_pl, w["loc"], b * ti, self.KL * 8, A, True, False)
             d_awc = self._e(b * ti, 8)
             wops.taps_bwd(dcol, b, ti, 8, self.KL, 1, self.KL // 2, out=d_awc)
@@ -381,6 +390,11 @@ class Tacotron2Trainer:
         F.gemm(w["loc_d"], dwl16, self.NF, self.KL * 8, A, False, False, out=dwc)
         wops.weight_norm_bwd(dwc, p[att + "location_layer.location_conv.conv.weight"], None,
                              g[att + "location_layer.location_conv.conv.weight"], None, cip=8)
+        if hoist:
+            aw16 = self._z(to8, b, ti)
+            F.cast(aw, dt, out=aw16[:to])
+            # sample b: d_memory[b] [Ti, E] = aw16[:, b, :]^T [Ti, To] x dctx_all[:, b, :] [To, E]
+            F.gemm_batched(aw16, dctx_all, d_memory, ti, E, to8, b * ti, b * E, E, False, False, b, 1, (ti, 0), (E, 0), (ti * E, 0))
         d_pm16 = self._cast(d_pm)
         self._wgrad(d_pm16, memory, g[att + "memory_layer.linear_layer.weight"], b * ti)
         F.gemm(d_pm16, w["mem"], b * ti, E, A, True, False, out=d_memory, accumulate=True)

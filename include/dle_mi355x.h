@@ -412,7 +412,8 @@ int dle_wg_logdet_inv_batched(const float* base, const int64_t* table_dev, float
  * dle_t2_attention_fwd/bwd: Attention.forward of one decoder step (model.py:79-121): energies v . tanh(q + pl) (pl = processed
  *   memory + location term, [B*Ti, A]), softmax over the first lengths[b] text positions, context = weights x memory ([B*Ti, E]);
  *   awc rows = (weights, cumulative weights, 0 x 6) 16-bit = the next step's location-convolution input.  Backward accumulates
- *   d_memory / d_pm (fp32) and dv across steps, writes d_pl (16-bit) and dq.
+ *   d_memory (fp32; NULL: the caller sums weights_t (x) d_ctx_t over the steps itself) / d_pm (fp32) and dv across steps, writes
+ *   d_pl (16-bit) and dq.
  * dle_t2_tanh_fwd: torch.tanh of the postnet (model.py:170).  dle_t2_mel_loss: MSE(mel_out) + MSE(mel_out + postnet) of
  *   Tacotron2Loss (loss_function.py:42-44) and its gradients (scaled by *scale_dev); workspace >= 1024 floats. */
 int dle_t2_tanh_fwd(const void* x, void* y, int64_t n, int dtype, hipStream_t stream);

@@ -252,7 +252,8 @@ def attention_bwd(d_ctx, d_aw_in, aw, tanh_out, v, memory, d_memory, d_pl, dq, d
     b, ti = aw.shape
     a = v.numel()
     mem = memory.float().view(b, ti, -1)
-    d_memory.add_((aw.unsqueeze(2) * d_ctx.unsqueeze(1)).reshape(b * ti, -1))
+    if d_memory is not None:
+        d_memory.add_((aw.unsqueeze(2) * d_ctx.unsqueeze(1)).reshape(b * ti, -1))
     d_aw = (mem * d_ctx.unsqueeze(1)).sum(2) + d_aw_in
     d_e = aw * (d_aw - (aw * d_aw).sum(1, keepdim=True))
     th = tanh_out.float().view(b, ti, a)
@@ -289,7 +290,7 @@ def install(monkeypatch):
     for name in ("gemm", "cast_rows", "cast", "bn_fwd", "bn_bwd", "dropout_fwd", "dropout_bwd", "rows_gather", "embed_scatter_add_",
                  "act_bwd", "bce_with_logits", "relu_bwd", "axpby_"):
         monkeypatch.setattr(F, name, me[name])
-    for name in ("colsum", "copy_rows", "check_nonfinite_", "amp_update_scale_"):
+    for name in ("colsum", "copy_rows", "check_nonfinite_", "amp_update_scale_", "gemm_batched"):
         monkeypatch.setattr(F, name, getattr(W, name))
     for name in ("taps", "taps_bwd", "weight_norm_fwd", "weight_norm_bwd"):
         monkeypatch.setattr(wops, name, getattr(W, name))

@@ -33,14 +33,14 @@ class _Replay:
         return x * keep.reshape(x.shape) * self.inv_keep(p)
 
 
-def _setup(monkeypatch, amp=True, **kw):
+def _setup(monkeypatch, amp=True, case=None, **kw):
     from oracle import tacotron2_oracle as TO
     from tests import _tacotron2_doubles as D
     from deeplearningexamples_amd.tacotron2.engine import Tacotron2Trainer
     from deeplearningexamples_amd.tacotron2.model import Tacotron2
     D.install(monkeypatch)
     D.Masks.reset(99)
-    c = TO.TACOTRON2_CASE
+    c = dict(TO.TACOTRON2_CASE, **(case or {}))
     torch.manual_seed(0)
     model = Tacotron2(**c["cfg"])
     state = TO.seeded_state(c["cfg"], c["seed"])
@@ -59,9 +59,11 @@ def test_state_dict_matches_the_oracle_shape_table():
     assert "postnet.convolutions.4.1.running_var" in sd and "encoder.convolutions.0.1.num_batches_tracked" in sd
 
 
-@pytest.mark.parametrize("amp", [False, True])
-def test_engine_sequence_reproduces_oracle_loss_and_gradients(monkeypatch, amp):
-    TO, D, c, model, state, tr = _setup(monkeypatch, amp, init_loss_scale=256.0)
+@pytest.mark.parametrize("amp,case", [(False, None), (True, None),
+                                      # 24 text positions: the context gradient of the memory goes through the batched GEMM
+                                      (True, dict(text_lengths=[24, 17, 9], mel_lengths=[20, 29, 13]))])
+def test_engine_sequence_reproduces_oracle_loss_and_gradients(monkeypatch, amp, case):
+    TO, D, c, model, state, tr = _setup(monkeypatch, amp, case=case, init_loss_scale=256.0)
     text, tl, mel, gate, ml = TO.seeded_batch(c)
     loss = tr.forward(text, tl, mel, gate)
     tr.backward()
