@@ -98,9 +98,10 @@ def reference_parameter_order(cfg):
     return names
 
 
-def optimizer_state_dict(trainer):
-    """The state_dict torch.optim.Adam(model.parameters(), lr, weight_decay) would hold after the trainer's steps."""
-    names = reference_parameter_order(trainer.cfg)
+def optimizer_state_dict(trainer, names=None):
+    """The state_dict torch.optim.Adam(model.parameters(), lr, weight_decay) would hold after the trainer's steps.  names: the
+    reference model's parameters() order (default: WaveGlow's)."""
+    names = names or reference_parameter_order(trainer.cfg)
     step = int(trainer.step_t.item())
     state = {}
     if step > 0:
@@ -113,8 +114,8 @@ def optimizer_state_dict(trainer):
     return {"state": state, "param_groups": [group]}
 
 
-def load_optimizer_state_dict(trainer, sd):
-    names = reference_parameter_order(trainer.cfg)
+def load_optimizer_state_dict(trainer, sd, names=None):
+    names = names or reference_parameter_order(trainer.cfg)
     steps = set()
     with torch.no_grad():
         for i, n in enumerate(names):
@@ -149,7 +150,7 @@ def load_scaler_state_dict(trainer, sd):
     sc.growth_factor, sc.backoff_factor, sc.growth_interval = sd["growth_factor"], sd["backoff_factor"], sd["growth_interval"]
 
 
-def save_checkpoint(trainer, epoch, config, output_dir, model_name, local_rank, world_size):
+def save_checkpoint(trainer, epoch, config, output_dir, model_name, local_rank, world_size, names=None):
     """train.py:185-226 (rank 0 writes; every rank's RNG state is recorded)."""
     rng = torch.random.get_rng_state()
     cuda_rng = torch.cuda.get_rng_state(local_rank) if torch.cuda.is_available() else torch.zeros(1, dtype=torch.uint8)
@@ -164,7 +165,7 @@ def save_checkpoint(trainer, epoch, config, output_dir, model_name, local_rank, 
         return None
     ckpt = {"epoch": epoch, "cuda_rng_state_all": torch.stack(cudas), "random_rng_states_all": torch.stack(rngs),
             "config": config, "state_dict": {k: v.detach().cpu().clone() for k, v in trainer.model.state_dict().items()},
-            "optimizer": optimizer_state_dict(trainer), "scaler": scaler_state_dict(trainer)}
+            "optimizer": optimizer_state_dict(trainer, names), "scaler": scaler_state_dict(trainer)}
     name = "checkpoint_{}_{}.pt".format(model_name, epoch)
     path = os.path.join(output_dir, name)
     torch.save(ckpt, path)
@@ -180,7 +181,7 @@ def get_last_checkpoint_filename(output_dir, model_name):
     return os.path.join(output_dir, os.readlink(link)) if os.path.exists(link) else ""
 
 
-def load_checkpoint(trainer, filepath, local_rank):
+def load_checkpoint(trainer, filepath, local_rank, names=None):
     """train.py:239-255 -> (config, first epoch to run)."""
     ckpt = torch.load(filepath, map_location="cpu", weights_only=False)
     if torch.cuda.is_available():
@@ -193,7 +194,7 @@ def load_checkpoint(trainer, filepath, local_rank):
     else:
         raise Exception("Model checkpoint must have either 'random_rng_state' or 'random_rng_states_all' key.")
     trainer.model.load_reference_state(ckpt["state_dict"])
-    load_optimizer_state_dict(trainer, ckpt["optimizer"])
+    load_optimizer_state_dict(trainer, ckpt["optimizer"], names)
     load_scaler_state_dict(trainer, ckpt["scaler"])
     return ckpt["config"], ckpt["epoch"] + 1
 

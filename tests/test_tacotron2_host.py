@@ -84,3 +84,59 @@ def test_engine_sequence_reproduces_oracle_loss_and_gradients(monkeypatch, amp, 
     sd = model.state_dict()
     assert int(sd["encoder.convolutions.0.1.num_batches_tracked"]) == 1
     assert float(sd["postnet.convolutions.0.1.running_mean"].abs().max()) > 0
+
+
+def test_overflow_skips_the_step(monkeypatch):
+    TO, D, c, model, state, tr = _setup(monkeypatch, True, init_loss_scale=1024.0)
+    batch = TO.seeded_batch(c)[:4]
+    before = tr.p.flat.clone()
+    tr.forward(*batch)
+    tr.backward()
+    tr.g.flat[11] = float("nan")
+    tr.optimizer_step()
+    assert torch.equal(tr.p.flat, before) and int(tr.step_t) == 0 and float(tr.scaler.scale) == 512.0
+    tr.train_step(*batch)
+    assert int(tr.step_t) == 1 and not torch.equal(tr.p.flat, before)
+
+
+def _dp_worker(rank, world, port, ret):
+    import pytest as _pytest
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import tacotron2_oracle as TO
+        from tests import _tacotron2_doubles as D
+        from deeplearningexamples_amd.tacotron2.engine import Tacotron2Trainer
+        from deeplearningexamples_amd.tacotron2.model import Tacotron2
+        D.install(_pytest.MonkeyPatch())
+        D.Masks.reset(7)                                              # the same masks on both ranks and in the 1-rank run
+        c = TO.TACOTRON2_CASE
+        torch.manual_seed(60 + rank)
+        model = Tacotron2(**c["cfg"])
+        if rank == 0:
+            model.load_reference_state(TO.seeded_state(c["cfg"], c["seed"]))
+        tr = Tacotron2Trainer(model, compute_dtype=torch.float32, amp=True, init_loss_scale=256.0, world_size=world, bucket_mb=1)
+        tr.forward(*TO.seeded_batch(c)[:4])                           # the SAME batch on both ranks: mean gradient = 1-rank gradient
+        tr.backward()
+        tr.buckets.wait()
+        ret[rank] = (tr.g.flat.clone(), tr.p.flat.clone(), len(tr.buckets.buckets))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_gradients_two_ranks_gloo(monkeypatch):
+    """Replicas built from different seeds start from rank 0's weights; the bucketed mean all-reduce of identical per-rank gradients
+    returns the one-rank gradient (DDP semantics, train.py:402-407)."""
+    import torch.multiprocessing as mp
+    port = 30700 + os.getpid() % 2000
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_dp_worker, args=(2, port, ret), nprocs=2, join=True)
+        (g0, p0, nb), (g1, p1, _) = ret[0], ret[1]
+    assert nb > 1 and torch.equal(g0, g1) and torch.equal(p0, p1)
+    TO, D, c, model, state, tr = _setup(monkeypatch, True, init_loss_scale=256.0)
+    D.Masks.reset(7)
+    tr.forward(*TO.seeded_batch(c)[:4])
+    tr.backward()
+    assert torch.equal(p0, tr.p.flat) and float((g0 - tr.g.flat).norm()) <= 1e-5 * float(tr.g.flat.norm())
