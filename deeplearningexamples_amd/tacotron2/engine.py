@@ -25,7 +25,7 @@ from ..utils.buckets import GradBuckets
 from ..waveglow import ops as wops
 from ..waveglow.model import FlatViews
 from . import ops
-from .model import Tacotron2, bn_names
+from .model import Tacotron2
 
 NPAD = 8          # the mel + gate projection runs (n_mel + 1) outputs wide, padded to a multiple of 8
 
