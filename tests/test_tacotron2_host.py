@@ -140,3 +140,23 @@ def test_data_parallel_gradients_two_ranks_gloo(monkeypatch):
     tr.forward(*TO.seeded_batch(c)[:4])
     tr.backward()
     assert torch.equal(p0, tr.p.flat) and float((g0 - tr.g.flat).norm()) <= 1e-5 * float(tr.g.flat.norm())
+
+
+def test_reference_widths_one_step(monkeypatch):
+    """The reference's default widths (tacotron2/arg_parser.py:40-107: 512-wide encoder, 1024-unit LSTM cells, attention 128 / 32 x 31,
+    prenet 256, 28.2 M parameters) on a two-utterance batch: the engine's sequence against the oracle's autograd."""
+    from oracle import tacotron2_oracle as TO
+    case = dict(cfg=TO.TACOTRON2_DEFAULT, text_lengths=[16, 11], mel_lengths=[12, 9])
+    TO, D, c, model, state, tr = _setup(monkeypatch, True, case=case, init_loss_scale=64.0)
+    text, tl, mel, gate, ml = TO.seeded_batch(c)
+    loss = tr.forward(text, tl, mel, gate)
+    tr.backward()
+    cfg = c["cfg"]
+    replay = _Replay(D.Masks.log, mel.shape[2], text.shape[0], cfg["attention_rnn_dim"], cfg["decoder_rnn_dim"])
+    p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    lo, _ = TO.tacotron2_loss(p, cfg, text, tl, mel, gate, replay)
+    lo.backward()
+    assert abs(float(loss) - float(lo.detach())) <= 5e-6 * abs(float(lo.detach()))
+    for k, v in p.items():
+        assert float((tr.g[k] / 64.0 - v.grad).norm()) <= 1e-3 * float(v.grad.norm()) + 2e-6, k
+    assert sum(v.numel() for v in p.values()) == 28193153
