@@ -22,9 +22,13 @@ Pinning status (see DESIGN.md "Oracle"):
                         CPU counterpart in the reference; it follows multi_tensor_lamb.cu line by line and is
                         cross-checked against an independent float64 closed form.
   * philox_oracle    -- pinned by the Random123 known-answer vectors.
-  * waveglow_oracle  -- GROUNDWORK for section 8 row f1 (no product path yet): the WaveGlow training loss, pinned against
-                        the reference's own WaveGlow + WaveGlowLoss on CPU (loss and every parameter gradient,
+  * waveglow_oracle  -- section 8 row f1 (product: deeplearningexamples_amd/waveglow): the WaveGlow training loss, pinned
+                        against the reference's own WaveGlow + WaveGlowLoss on CPU (loss and every parameter gradient,
                         tests/golden/waveglow_loss.npz).
+  * tacotron2_oracle -- section 8 row f1 (product: deeplearningexamples_amd/tacotron2): the Tacotron2 training loss with
+                        externally supplied dropout masks, pinned against the reference's own Tacotron2 + Tacotron2Loss in
+                        training mode under the same masks (loss, alignments, all 60 parameter gradients,
+                        tests/golden/tacotron2_loss.npz).
   * storage          -- not an oracle of the reference: 16-bit storage emulation (round-to-dtype with a
                         straight-through gradient) used by the step oracles to MEASURE the precision floor that the
                         loss-parity bars add to north_star's 1e-3.

@@ -354,7 +354,7 @@ def gen_floors():
 
 def gen_waveglow():
     """Loss and every parameter gradient of the REFERENCE's WaveGlow + WaveGlowLoss on CPU (small flow / WN sizes, full mel and
-    grouping geometry): pins oracle/waveglow_oracle.py -- groundwork for SURVEY.md 8 row f1, no product path yet."""
+    grouping geometry): pins oracle/waveglow_oracle.py."""
     from oracle import waveglow_oracle as WO
     ref = R.import_waveglow()
     c = WO.WAVEGLOW_CASE
@@ -386,7 +386,7 @@ def gen_waveglow():
 def gen_tacotron2():
     """Loss and every parameter gradient of the REFERENCE's Tacotron2 + Tacotron2Loss on CPU (training mode, small widths, the
     full structure), with F.dropout bound to oracle.tacotron2_oracle.MaskStream so that reference and oracle draw the same masks:
-    pins oracle/tacotron2_oracle.py -- groundwork for the Tacotron2 half of SURVEY.md 8 row f1, no product path yet."""
+    pins oracle/tacotron2_oracle.py (the Tacotron2 half of SURVEY.md 8 row f1)."""
     import torch.nn.functional as TF
     from oracle import tacotron2_oracle as TO
     ref = R.import_tacotron2()

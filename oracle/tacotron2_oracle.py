@@ -1,5 +1,5 @@
-"""CPU restatement of the Tacotron2 training loss (TEST INFRASTRUCTURE ONLY; GROUNDWORK for the Tacotron2 half of SURVEY.md
-section 8 row f1 -- there is no HIP path for this model yet, nothing in the product imports or mirrors it).
+"""CPU restatement of the Tacotron2 training loss (TEST INFRASTRUCTURE ONLY; the Tacotron2 half of SURVEY.md section 8 row f1 --
+the checker of the HIP path in deeplearningexamples_amd/tacotron2; nothing in the product imports it).
 
 Follows, in plain fp32 torch on the CPU (paths relative to /root/reference/PyTorch/SpeechSynthesis/Tacotron2/):
     tacotron2/model.py:604-620,667-681  Tacotron2.forward: embedding, encoder, teacher-forced decoder, postnet residual
@@ -12,7 +12,7 @@ Follows, in plain fp32 torch on the CPU (paths relative to /root/reference/PyTor
     tacotron2/model.py:138-174          Postnet: 4 x (Conv1d k5 + BN + tanh + dropout 0.5) + (Conv1d + BN + dropout 0.5)
     tacotron2/loss_function.py:31-46    MSE(mel) + MSE(mel_postnet) + BCEWithLogits(gate)   (mask_padding = False, the default)
 Dropout is EXTERNAL: every dropout site asks `drop(x, p)` for its mask in the reference's call order, so that the reference run
-(F.dropout patched to the same stream), this oracle and a future HIP path (counter-based masks) see identical masks.
+(F.dropout patched to the same stream), this oracle and the HIP path (counter-based masks, replayed site by site) see identical masks.
 BatchNorm uses batch statistics (training mode) and does not update running buffers here.  Parameter names are the reference's
 state_dict keys.  Pinned by tests/golden/tacotron2_loss.npz (oracle/make_golden.py gen_tacotron2: loss, every parameter gradient
 norm, gradient slices; the generator asserts oracle == reference).

@@ -1,5 +1,5 @@
-"""CPU restatement of the WaveGlow training loss (TEST INFRASTRUCTURE ONLY; GROUNDWORK for SURVEY.md section 8 row f1 --
-there is no HIP path for this model yet, nothing in the product imports or mirrors it).
+"""CPU restatement of the WaveGlow training loss (TEST INFRASTRUCTURE ONLY; SURVEY.md section 8 row f1 -- the checker of the HIP
+path in deeplearningexamples_amd/waveglow; nothing in the product imports it).
 
 Follows, in plain fp32 torch on the CPU (paths relative to /root/reference/PyTorch/SpeechSynthesis/Tacotron2/):
     waveglow/model.py:34-41     fused_add_tanh_sigmoid_multiply

@@ -1,4 +1,4 @@
-"""GROUNDWORK for the Tacotron2 half of SURVEY.md section 8 row f1 (no product path yet): the Tacotron2 loss oracle against the
+"""The Tacotron2 loss oracle (checker of deeplearningexamples_amd/tacotron2) against the
 fixture the REFERENCE's own Tacotron2 + Tacotron2Loss produced on CPU in training mode with the same dropout masks
 (tests/golden/tacotron2_loss.npz, oracle/make_golden.py gen_tacotron2: loss, the gradient norm of all 60 parameters, gradient
 slices, the last alignment row).  CPU only."""

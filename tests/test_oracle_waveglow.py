@@ -1,4 +1,4 @@
-"""GROUNDWORK for SURVEY.md section 8 row f1 (no product path yet): the WaveGlow loss oracle against the fixture the REFERENCE's
+"""The WaveGlow loss oracle (checker of deeplearningexamples_amd/waveglow) against the fixture the REFERENCE's
 own WaveGlow + WaveGlowLoss produced on CPU (tests/golden/waveglow_loss.npz, oracle/make_golden.py gen_waveglow: loss, the
 gradient norm of every parameter, gradient slices).  CPU only."""
 import os
