@@ -259,7 +259,9 @@ def main(argv=None):
                 from ..utils.comm import allreduce_mean_
                 loss = allreduce_mean_(loss.clone())
             loss_v = float(loss.item())                      # the reference reads the loss every iteration too (train.py:476-481)
-            if np.isnan(loss_v):
+            # torch.logdet of a matrix with a negative determinant is NaN in the reference (model.py:74); the kernels return
+            # log|det| and the sign, so the same condition is raised here instead of training on
+            if np.isnan(loss_v) or float(trainer.signs.min().item()) < 0:
                 raise Exception("loss is NaN")
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
