@@ -171,3 +171,28 @@ def test_data_parallel_gradients_two_ranks_gloo(monkeypatch):
     tr.backward()
     assert torch.equal(p0, tr.p.flat)
     assert float((g0 - tr.g.flat).norm()) <= 1e-4 * float(tr.g.flat.norm())
+
+
+def test_reference_size_network_host_sequence(monkeypatch):
+    """The reference's default network (12 flows x 8 layers x 512 channels, 268 M parameters; waveglow/arg_parser.py:38-64) on a
+    2 x 2048-sample batch: the engine's sequence (98,304-column cond / pre-activation matrices, 96-slice batched weight gradients,
+    table-driven weight norm) against the oracle's autograd."""
+    from oracle import waveglow_oracle as WO
+    from tests import _waveglow_doubles as D
+    from deeplearningexamples_amd.waveglow.engine import WaveGlowTrainer
+    from deeplearningexamples_amd.waveglow.model import DEFAULT_CONFIG, WaveGlow
+    D.install(monkeypatch)
+    state = WO.seeded_state(DEFAULT_CONFIG, 11)
+    model = WaveGlow(**DEFAULT_CONFIG)
+    model.load_reference_state(state)
+    tr = WaveGlowTrainer(model, compute_dtype=torch.float32, amp=True, init_loss_scale=64.0)
+    mel, audio = WO.seeded_inputs(dict(cfg=DEFAULT_CONFIG, seed=11, batch=2, segment=2048))
+    loss = tr.forward(mel, audio)
+    tr.backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    lo = WO.waveglow_loss(p, DEFAULT_CONFIG, mel, audio, 1.0)
+    lo.backward()
+    assert abs(float(loss) - float(lo.detach())) <= 5e-6 * abs(float(lo.detach()))
+    for k, v in p.items():
+        assert float((tr.g[k] / 64.0 - v.grad).norm()) <= 2e-3 * float(v.grad.norm()) + 1e-7, k
+    assert tr.p.flat.numel() >= 268e6
