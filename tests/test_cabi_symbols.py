@@ -67,3 +67,22 @@ def test_ctypes_signatures_match_header_types():
         assert pyk.get(restype, "ptr") == rk, "%s: return type %s vs %s" % (name, rk, restype)
         checked += 1
     assert checked == len(_cabi._SIGS)
+
+
+def test_product_never_imports_the_oracle_or_the_test_doubles():
+    """oracle/ and tests/ are checkers: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline legs may touch them."""
+    pkg = os.path.join(ROOT, "deeplearningexamples_amd")
+    pat = re.compile(r"^\s*(from|import)\s+(oracle|tests)\b", re.M)
+    bad = []
+    for base in (pkg, os.path.join(ROOT, "shims")):
+        for d, _, files in os.walk(base):
+            for f in files:
+                if f.endswith(".py") and pat.search(open(os.path.join(d, f)).read()):
+                    bad.append(os.path.join(d, f))
+    assert not bad, bad
+    # bench.py: every oracle import sits inside a cpu_baseline() body
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for m in re.finditer(r"^(\s*)from oracle import", src, re.M):
+        head = src[:m.start()]
+        last_def = head.rfind("\n    def ")
+        assert head[last_def:].lstrip().startswith("def cpu_baseline("), src[m.start():m.start() + 60]
