@@ -113,7 +113,6 @@ class BertTrainer:
         self.max_norm_t = torch.full((1,), max_grad_norm, dtype=torch.float32, device=dev)
         self.one = torch.ones(1, dtype=torch.float32, device=dev)
         self.noop = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.opt_steps = 0
         self.grad_divisor = 1          # gradient-accumulation micro-steps summed into the flat gradient
         self._batch_key, self._sel, self._idx0, self._mask_add, self._dense_labels = None, None, None, None, None
         self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
@@ -444,10 +443,17 @@ class BertTrainer:
                 self.buckets.grad_ready(n)
 
     # ------------------------------------------------------------------ optimizer
+    @property
+    def opt_steps(self):
+        """Optimizer steps APPLIED so far = the LAMB step word on the device (one .item(): call it at log / checkpoint time
+        only).  It does not advance on overflow-skipped steps and keeps advancing under HIP-graph replay, where host-side
+        counters inside the captured step would freeze."""
+        return int(self.step_t.item())
+
     def current_lr(self):
-        """Host-side view of the schedule (logging); the step itself computes the rate on the device from the LAMB
-        step counter, which does not advance on a skipped (overflow) step -- PolyWarmUpScheduler.step reads
-        param_group['step'] + 1 (schedulers.py:123-131)."""
+        """The rate the NEXT optimizer step will apply (logging): PolyWarmUpScheduler.step reads param_group['step'] + 1
+        (schedulers.py:123-131), evaluated from the device step word, so the logged value follows skipped steps and graph
+        replays exactly like the rate the kernels use (_device_lr)."""
         return poly_warmup_lr(self.opt_steps + 1, self.base_lr, self.warmup, self.total)
 
     def _device_lr(self):
@@ -458,11 +464,10 @@ class BertTrainer:
 
     def optimizer_step(self):
         sc = self.scaler
-        if self.grad_divisor != 1:
-            # each micro-step's loss is divided by the accumulation count in the reference (run_pretraining.py:521)
-            self.flat_grad.mul_(1.0 / self.grad_divisor)
         if self.buckets is not None:
-            self.buckets.wait()          # every bucket was launched during the backward pass of the last micro-step
+            # every bucket was launched during the backward pass of the last micro-step, on the communication stream, and
+            # reduces flat_grad IN PLACE: nothing on the compute stream may touch the buffer before this wait
+            self.buckets.wait()
         self.noop.zero_()
         if sc.enabled:
             F.check_nonfinite_(self.flat_grad, sc.found_inf)
@@ -472,6 +477,12 @@ class BertTrainer:
         gnorm, _ = mt.l2norm(self.t_all_grads, self.noop)
         scale = sc.scale if sc.enabled else self.one
         inv = sc.inv_scale if sc.enabled else self.one
+        if self.grad_divisor != 1:
+            # each micro-step's loss is divided by the accumulation count in the reference (run_pretraining.py:521); here the
+            # micro-steps are summed undivided and the count joins the loss scale (no pass over the 1.3 GB buffer): the
+            # gradients LAMB sees are flat_grad * inv_scale / count, the norm test compares against max_norm * scale * count
+            scale = scale * float(self.grad_divisor)
+            inv = inv * (1.0 / self.grad_divisor)
         max_norm = self.max_norm_t * scale
         for key, tb in self.tables.items():
             _, pn = mt.l2norm(tb["t_p"], self.noop, per_tensor=True)
@@ -481,7 +492,6 @@ class BertTrainer:
             mt.lamb_stage2(tb["t_s2"], self.noop, pn, un, self.lr_t, tb["wd"], False)
         self.nsp_bias8[:2].copy_(self.model.cls.seq_relationship.bias.data)
         sc.update()
-        self.opt_steps += 1
 
     def train_step(self, input_ids, token_type_ids, attention_mask, labels, next_sentence_labels):
         """One optimizer step on one micro-batch.  Returns the device-resident fp32 loss [1]."""

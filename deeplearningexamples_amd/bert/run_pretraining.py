@@ -109,7 +109,8 @@ def main(argv=None):
     def opt_step():
         trainer.optimizer_step()
         return trainer.lr_t
-    g_first, g_acc, g_opt = (GraphedStep(f, enabled=use_graphs) for f in (micro_first, micro_acc, opt_step))
+    side = torch.cuda.Stream() if use_graphs else None       # ONE side stream: the three captured callables depend on each other
+    g_first, g_acc, g_opt = (GraphedStep(f, enabled=use_graphs, stream=side) for f in (micro_first, micro_acc, opt_step))
     trainer.grad_divisor = acc
     for step in range(args.steps_this_run):
         for micro_step in range(acc):

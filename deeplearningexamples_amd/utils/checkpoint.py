@@ -89,7 +89,9 @@ class Checkpointer:
         return os.path.join(self.checkpoint_dir, filename)
 
     def cleanup(self):
-        drop = self.checkpoints[:-self.keep_last_n] if self.keep_last_n > 0 else list(self.checkpoints)
+        # the reference's slicing, as is (utils.py:40-46): keep_last_n = 0 (its default) -> checkpoints[:-0] is EMPTY, every
+        # numbered file stays; -1 ("all checkpoints" in its help text) drops only the oldest one, exactly as there
+        drop = self.checkpoints[:-self.keep_last_n]
         self.checkpoints = self.checkpoints[len(drop):]
         for f in drop:
             os.remove(self.get_full_path(f))
@@ -213,7 +215,10 @@ def bert_trainer_state(trainer, epoch=0):
                                               with_moments=trainer.opt_steps > 0),
             "grad_scaler": grad_scaler_state(sc.scale.item(), sc.growth_tracker.item(), sc.growth_factor,
                                              sc.backoff_factor, sc.growth_interval) if sc.enabled else {},
-            "epoch": epoch}
+            "epoch": epoch,
+            # not a reference key (its loaders ignore it): the position of the counter-based dropout stream, so that a resumed
+            # run continues the mask sequence instead of replaying it from 0
+            "dle_rng_base": int(trainer._rng_base.item())}
 
 
 def bert_trainer_load(trainer, checkpoint):
@@ -231,7 +236,7 @@ def bert_trainer_load(trainer, checkpoint):
             trainer.exp_avg[n].zero_()
             trainer.exp_avg_sq[n].zero_()
     trainer.step_t.fill_(step)
-    trainer.opt_steps = step
+    trainer._rng_base.fill_(int(checkpoint.get("dle_rng_base", 0)))
     gs = checkpoint.get("grad_scaler") or {}
     if trainer.scaler.enabled and "scale" in gs:
         trainer.scaler.scale.fill_(gs["scale"])

@@ -17,10 +17,12 @@ class GraphedStep:
     """step_fn(*tensors) -> loss tensor.  Call the wrapper like step_fn; the returned tensor is the graph's static
     output (valid until the next call)."""
 
-    def __init__(self, step_fn: Callable, enabled: bool = True, warmup_steps: int = 3):
+    def __init__(self, step_fn: Callable, enabled: bool = True, warmup_steps: int = 3, stream=None):
+        """stream: wrappers whose steps depend on each other (BERT: first micro-step / accumulating micro-step / optimizer
+        step) should share ONE side stream; every warm-up call is additionally ordered after the caller's current stream."""
         self._fn, self.enabled, self.warmup_steps = step_fn, enabled, warmup_steps
         self.graph: Optional[torch.cuda.CUDAGraph] = None
-        self.stream = torch.cuda.Stream() if enabled else None
+        self.stream = (stream or torch.cuda.Stream()) if enabled else None
         self.static_args: Optional[List] = None
         self.loss = None
         self.step = -1
@@ -44,9 +46,11 @@ class GraphedStep:
             self.loss = self._fn(*args)
             return self.loss
         if self.step == 0:
-            self.stream.wait_stream(torch.cuda.current_stream())
             self.static_args = [a.clone() if isinstance(a, torch.Tensor) else a for a in args]
         if self.step < self.warmup_steps:
+            # every warm-up step: the side stream starts after whatever the caller's stream has enqueued (the batch being
+            # produced, another wrapper's step -- e.g. the optimizer step that rewrites the weights this step reads)
+            self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
                 self._copy_inputs(args)
                 self.loss = self._fn(*self.static_args)

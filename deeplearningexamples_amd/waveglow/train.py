@@ -166,6 +166,10 @@ def save_checkpoint(trainer, epoch, config, output_dir, model_name, local_rank, 
     ckpt = {"epoch": epoch, "cuda_rng_state_all": torch.stack(cudas), "random_rng_states_all": torch.stack(rngs),
             "config": config, "state_dict": {k: v.detach().cpu().clone() for k, v in trainer.model.state_dict().items()},
             "optimizer": optimizer_state_dict(trainer, names), "scaler": scaler_state_dict(trainer)}
+    if hasattr(trainer, "_rng_calls"):
+        # not a reference key (its loader ignores it): the position of the trainer's counter-based dropout stream (Tacotron2),
+        # which torch's restored RNG state does not drive -- a resumed run continues the mask sequence
+        ckpt["dle_rng_calls"] = int(trainer._rng_calls)
     name = "checkpoint_{}_{}.pt".format(model_name, epoch)
     path = os.path.join(output_dir, name)
     torch.save(ckpt, path)
@@ -193,7 +197,10 @@ def load_checkpoint(trainer, filepath, local_rank, names=None):
         torch.random.set_rng_state(ckpt["random_rng_state"])
     else:
         raise Exception("Model checkpoint must have either 'random_rng_state' or 'random_rng_states_all' key.")
-    trainer.model.load_reference_state(ckpt["state_dict"])
+    # the reference wraps the model in DistributedDataParallel when distributed: its multi-GPU files carry "module." keys
+    trainer.model.load_reference_state({(k[7:] if k.startswith("module.") else k): v for k, v in ckpt["state_dict"].items()})
+    if hasattr(trainer, "_rng_calls"):
+        trainer._rng_calls = int(ckpt.get("dle_rng_calls", 0))
     load_optimizer_state_dict(trainer, ckpt["optimizer"], names)
     load_scaler_state_dict(trainer, ckpt["scaler"])
     return ckpt["config"], ckpt["epoch"] + 1

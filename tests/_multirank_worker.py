@@ -158,7 +158,65 @@ def run_waveglow(rank, world, dev, steps):
     return {"losses": losses, "probe": probe, "nbuckets": len(tr.buckets.buckets) if tr.buckets else 0}
 
 
-SCENARIOS = {"bert": run_bert, "rn50": run_rn50, "dlrm": run_dlrm, "waveglow": run_waveglow}
+def run_rccl_single_rank(rank, world, dev, steps):
+    """ONE rank, backend nccl: every `nccl` branch of utils/comm.py (AVG all-reduce, SUM / MAX, broadcast, all_to_all_single with
+    split lists, `device_id` initialisation) and the engines' bucket hooks on the communication stream execute on a real RCCL
+    communicator -- on a one-GPU box, where two ranks cannot share the device.  A one-rank collective is the identity, so a
+    trainer built with world_size = 2 over this group (its multi-rank code path: parameter broadcast, buckets fired during
+    backward on the side stream, bucket wait before the optimizer) must reproduce the world_size = 1 trainer (to the run-to-run noise of the step's few atomics)."""
+    from deeplearningexamples_amd.utils import comm
+    from deeplearningexamples_amd.utils.buckets import GradBuckets
+    assert dist.get_backend() == "nccl" and world == 1
+    out = {}
+    g = torch.Generator().manual_seed(1)
+    t = torch.randn(1 << 20, generator=g).to(dev)
+    ref = t.clone()
+    comm.allreduce_mean_(t); comm.allreduce_sum_(t); comm.allreduce_max_(t); comm.broadcast_(t, 0)
+    out["identity"] = bool(torch.equal(t, ref))
+    src = torch.randn(7 * 128, generator=g).to(dev).half()
+    dst = torch.zeros_like(src)
+    comm.all_to_all_single(dst, src, [7 * 128], [7 * 128])
+    out["a2a"] = bool(torch.equal(dst, src))
+    flat = torch.randn(3 << 20, generator=g).to(dev)
+    keep = flat.clone()
+    stream = torch.cuda.Stream()
+    for wire in (None, torch.bfloat16):
+        b = GradBuckets(flat, [("p%d" % i, 1 << 20) for i in range(3)], bucket_mb=2, comm_stream=stream, reverse=True, wire_dtype=wire)
+        for i in (2, 1, 0):
+            b.grad_ready("p%d" % i)
+        b.wait()
+        torch.cuda.synchronize()
+        tol = 0.0 if wire is None else 4e-3
+        out["buckets_%s" % ("fp32" if wire is None else "bf16wire")] = bool((flat - keep).abs().max() <= tol * keep.abs().max())
+        flat.copy_(keep)
+    # the trainers: world_size flag 2 over the one-rank RCCL group == world_size 1
+    for name, fn in (("rn50", run_rn50), ("bert", run_bert)):
+        a = fn(0, 1, dev, steps)
+        b2 = fn(0, 2, dev, steps) if name == "rn50" else _bert_flag2(dev, steps)
+        out[name] = {"one": a["losses"], "flag2": b2["losses"], "probe_one": a["probe"], "probe_flag2": b2["probe"],
+                     "nbuckets": b2["nbuckets"]}
+    return out
+
+
+def _bert_flag2(dev, steps):
+    """run_bert's one-rank batch (all 8 sequences) with the trainer in its multi-rank configuration."""
+    from oracle import bert_oracle as BO
+    from deeplearningexamples_amd.bert.model import BertForPreTraining
+    from deeplearningexamples_amd.bert.engine import BertTrainer
+    c = BO.BERT_STEP_CONFIG
+    torch.manual_seed(100)
+    model = BertForPreTraining(c["cfg"], device=dev)
+    model.load_state_dict({k: v.clone() for k, v in BO.seeded_state(c["cfg"], c["seed"]).items()}, strict=False)
+    tr = BertTrainer(model, lr=c["lr"], warmup=c["warmup"], total_steps=c["total_steps"], compute_dtype=torch.bfloat16,
+                     hidden_dropout=0.0, attention_dropout=0.0, world_size=2, rank=0, bucket_mb=1)
+    mine = [t.contiguous().to(dev) for t in BO.seeded_batch(c["cfg"], c["seed"] + 1, 8)]
+    losses = [float(tr.train_step(*mine).item()) for _ in range(steps)]
+    named = dict(model.named_parameters())
+    probe = named["bert.encoder.layer.0.attention.self.query.weight"].detach().float().cpu().numpy()[:2].tolist()
+    return {"losses": losses, "probe": probe, "nbuckets": len(tr.buckets.buckets)}
+
+
+SCENARIOS = {"bert": run_bert, "rn50": run_rn50, "dlrm": run_dlrm, "waveglow": run_waveglow, "rccl1": run_rccl_single_rank}
 
 
 def main():

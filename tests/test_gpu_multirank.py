@@ -57,3 +57,22 @@ def test_two_ranks_match_one_rank(cuda, tmp_path, scenario, rtol):
     np.testing.assert_allclose(np.asarray(two[0]["probe"]), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
     if scenario in ("bert", "rn50", "waveglow"):
         assert two[0]["nbuckets"] > 1          # several gradient buckets were reduced during the backward pass
+
+
+def test_rccl_branch_on_a_single_rank_communicator(cuda, tmp_path):
+    """the `nccl` branches of utils/comm.py and the engines' bucket hooks on a real RCCL communicator (one rank:
+    a one-GPU box cannot host two), see _multirank_worker.run_rccl_single_rank."""
+    out = str(tmp_path / "rccl1.json")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29950 + os.getpid() % 40))
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_multirank_worker.py"), "rccl1", "nccl", out], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, "single-rank RCCL run failed:\n%s\n%s" % (r.stdout[-3000:], r.stderr[-6000:])
+    res = json.load(open(out))[0]
+    print(res)
+    assert res["identity"] and res["a2a"] and res["buckets_fp32"] and res["buckets_bf16wire"]
+    for name in ("rn50", "bert"):
+        np.testing.assert_allclose(res[name]["flag2"], res[name]["one"], rtol=1e-4)
+        ref = np.asarray(res[name]["probe_one"])
+        np.testing.assert_allclose(np.asarray(res[name]["probe_flag2"]), ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+        assert res[name]["nbuckets"] > 1

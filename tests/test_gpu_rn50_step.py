@@ -146,3 +146,73 @@ def test_rn50_gradient_accumulation(cuda):
     # the third call starts the next accumulation window
     t2.train_step(xa, ya)
     assert t2.steps_since_update == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_rn50_unit_backward_teacher_forced_vs_fp32(cuda, dtype):
+    """The discriminating gradient bar (the end-to-end floor above is 14 % / 40 % of the fp32 gradient: BatchNorm's backward
+    cancels a common mode, so 16-bit rounding is amplified ~14x per layer and accumulates over 53 layers).  Here every conv +
+    BN (+ ReLU) (+ residual) unit of the step is checked ON ITS OWN: the gradient the HIP step handed to the unit (dy, the ReLU
+    bits, the residual-branch addend) and the tensors it saved in forward go through plain fp32 torch on the CPU
+    (models/resnet.py:148-175, models/common.py:31-128 backward = torch autograd's conv / batch_norm formulas), and the unit's
+    d gamma, d beta, dW and dx must agree.  One unit deep, the 16-bit floor is the rounding of ONE stored tensor (the
+    normalised-gradient operand: 2^-9 bf16, 2^-12 fp16 relative L2 per element, averaged down in the reductions):
+    bars 2 % (bf16) / 0.4 % (fp16) relative L2 -- < 5 % as a parity bar should be."""
+    import torch.nn.functional as TF
+    from deeplearningexamples_amd import functional as F
+    from deeplearningexamples_amd.convnets import resnet as R
+    c = dict(RO.RN50_STEP_CONFIG, batch=8)
+    state = RO.seeded_state(c["seed"])
+    model, tr = _build(cuda, dtype, 0.0, state)
+    x, y = RO.seeded_batch(77, c["batch"], c["size"])
+    records = []
+    orig = R.ConvBN.backward
+
+    def spy(self, dy, need_dx=True, dx_addend=None, dy_mask=None):
+        saved = self.saved
+        dx = orig(self, dy, need_dx=need_dx, dx_addend=dx_addend, dy_mask=dy_mask)
+        records.append((self, dy, dx_addend, dy_mask, saved, dx))
+        return dx
+    R.ConvBN.backward = spy
+    try:
+        logits = tr.forward(x.to(cuda))
+        loss, dl = F.softmax_xent(logits, y.to(cuda), smoothing=0.1, grad_dtype=dtype, grad_scale=tr.scaler.scale)
+        tr.backward(dl)
+        torch.cuda.synchronize()
+    finally:
+        R.ConvBN.backward = orig
+    assert len(records) == 53
+    bar = 4e-3 if dtype == torch.float16 else 2e-2
+    nchw = lambda t: t.detach().float().cpu().permute(0, 3, 1, 2).contiguous()
+    bits = lambda m, ref: F.unpack_dropout_mask(m, ref.shape).cpu().permute(0, 3, 1, 2).float()
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    worst = {}
+    for u, dy, addend, dy_mask, (xs, t, mask, mean, rstd), dx in records:
+        rmask = mask if u.relu else dy_mask
+        g = nchw(dy)
+        if rmask is not None:
+            g = g * bits(rmask, dy)
+        tt, mu, rs = nchw(t), mean.cpu().view(1, -1, 1, 1), rstd.cpu().view(1, -1, 1, 1)
+        gamma = u.bn.weight.detach().cpu().view(1, -1, 1, 1)
+        xhat = (tt - mu) * rs
+        m = float(tt.numel() // tt.shape[1])
+        dbeta, dgamma = g.sum(dim=(0, 2, 3)), (g * xhat).sum(dim=(0, 2, 3))
+        gt = gamma * rs * (g - dbeta.view(1, -1, 1, 1) / m - xhat * dgamma.view(1, -1, 1, 1) / m)
+        xin = nchw(xs)[:, :u.cin]
+        w16 = u.w16.detach().float().cpu().permute(0, 3, 1, 2)[:, :u.cin].contiguous()           # KRSC -> KCRS
+        dw = torch.nn.grad.conv2d_weight(xin, w16.shape, gt, stride=u.stride, padding=u.pad)
+        errs = {"dgamma": rel(u.ggamma.cpu(), dgamma), "dbeta": rel(u.gbeta.cpu(), dbeta),
+                "dW": rel(u.gw.detach().cpu().permute(0, 3, 1, 2)[:, :u.cin], dw)}
+        if dx is not None:
+            ref_dx = torch.nn.grad.conv2d_input(xin.shape, w16, gt, stride=u.stride, padding=u.pad)
+            if isinstance(addend, tuple):
+                ref_dx = ref_dx + nchw(addend[0]) * bits(addend[1], addend[0])
+            elif addend is not None:
+                ref_dx = ref_dx + nchw(addend)
+            errs["dx"] = rel(nchw(dx)[:, :u.cin], ref_dx)
+        for k, e in errs.items():
+            if e > worst.get(k, (0.0, ""))[0]:
+                worst[k] = (e, u.name_conv)
+        bad = {k: e for k, e in errs.items() if e > bar}
+        assert not bad, (u.name_conv, bad)
+    print(dtype, "worst per-unit relative L2 errors:", {k: (round(v[0], 5), v[1]) for k, v in worst.items()})

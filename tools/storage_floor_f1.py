@@ -41,7 +41,7 @@ def waveglow(cfg_name, cfg, seed, batch, segment, scale):
     mp.undo()
 
 
-def tacotron2(seeds):
+def tacotron2(seeds, case=None, label="small", scale=1024.0):
     from oracle import tacotron2_oracle as TO
     from tests import _tacotron2_doubles as D
     from tests.test_tacotron2_host import _Replay
@@ -49,7 +49,7 @@ def tacotron2(seeds):
     from deeplearningexamples_amd.tacotron2.model import Tacotron2
     mp = pytest.MonkeyPatch()
     D.install(mp)
-    c = TO.TACOTRON2_CASE
+    c = case or TO.TACOTRON2_CASE
     cfg = c["cfg"]
     text, tl, mel, gate, ml = TO.seeded_batch(c)
     for dt in (torch.float16, torch.bfloat16):
@@ -58,17 +58,17 @@ def tacotron2(seeds):
             state = TO.seeded_state(cfg, c["seed"])
             model = Tacotron2(**cfg)
             model.load_reference_state(state)
-            tr = Tacotron2Trainer(model, compute_dtype=dt, amp=True, init_loss_scale=1024.0)
+            tr = Tacotron2Trainer(model, compute_dtype=dt, amp=True, init_loss_scale=scale)
             loss = tr.forward(text, tl, mel, gate)
             tr.backward()
             replay = _Replay(D.Masks.log, mel.shape[2], text.shape[0], cfg["attention_rnn_dim"], cfg["decoder_rnn_dim"])
             p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
             lo, _ = TO.tacotron2_loss(p, cfg, text, tl, mel, gate, replay)
             lo.backward()
-            errs = {k: float((tr.g[k] / 1024 - p[k].grad).norm() / p[k].grad.norm()) for k in p if float(p[k].grad.norm()) > 1e-5}
+            errs = {k: float((tr.g[k] / scale - p[k].grad).norm() / p[k].grad.norm()) for k in p if float(p[k].grad.norm()) > 1e-5}
             worst = max(errs.items(), key=lambda kv: kv[1])
-            print("tacotron2 small  %-9s masks %d  loss rel %.2e   gradient rel L2: worst %.2e (%s)  median %.2e" %
-                  (str(dt).split(".")[1], seed, abs(float(loss) - float(lo.detach())) / abs(float(lo.detach())), worst[1], worst[0],
+            print("tacotron2 %-7s %-9s masks %d  loss rel %.2e   gradient rel L2: worst %.2e (%s)  median %.2e" %
+                  (label, str(dt).split(".")[1], seed, abs(float(loss) - float(lo.detach())) / abs(float(lo.detach())), worst[1], worst[0],
                    float(np.median(list(errs.values())))), flush=True)
     mp.undo()
 
@@ -78,6 +78,10 @@ if __name__ == "__main__":
     warnings.filterwarnings("ignore")
     from oracle import waveglow_oracle as WO
     from deeplearningexamples_amd.waveglow.model import DEFAULT_CONFIG
+    if "--t2-default" in sys.argv:       # the reference's widths, the case tests/test_gpu_tacotron2.py checks on the GPU
+        from oracle import tacotron2_oracle as TO
+        tacotron2([1, 2, 3], TO.TACOTRON2_DEFAULT_CASE, "default", 65536.0)
+        sys.exit(0)
     waveglow("small", WO.WAVEGLOW_SMALL, 7, 2, 2048, 65536.0)
     if "--full" in sys.argv:
         waveglow("default", DEFAULT_CONFIG, 11, 2, 2048, 4096.0)
