@@ -1,18 +1,23 @@
-"""BERT pre-training entry point on MI355X with the reference's CLI (subset that drives the train step).
+"""BERT pre-training entry point on MI355X with the reference's command line.
 
 Mirrors LanguageModeling/BERT/run_pretraining.py:140-321 (flags), :323-375 (setup_training), :377-486
-(prepare_model_and_optimizer), :658-736 (loop with gradient accumulation) and its dllogger keys
-(average_loss, learning_rate, training_sequences_per_second, e2e_train_time, final_loss, raw_train_time).
+(prepare_model_and_optimizer: --resume_from_checkpoint / --init_checkpoint / --resume_step / --phase2 / --resume_phase2),
+:489-515 (checkpoint_step: ckpt_{step}.pt every --num_steps_per_checkpoint optimizer steps and at the end, the three most
+recent files kept), :658-736 (loop with gradient accumulation) and its dllogger keys (average_loss, learning_rate,
+training_sequences_per_second, e2e_train_time, final_loss, raw_train_time).  Checkpoint files are the reference's
+(utils/checkpoint.py: they load into the reference's BertForPreTraining / FusedLAMBAMP / GradScaler and back).
 The lddl loader (un-vendored) is replaced by a synthetic loader with the same 5-key int64 batch
 (run_pretraining.py:603-609).
     python -m torch.distributed.run --nproc-per-node 8 -m deeplearningexamples_amd.bert.run_pretraining \
         --train_batch_size 256 --gradient_accumulation_steps 2 --max_steps 20 --bf16
 """
 import argparse
+import os
 import time
 
 import torch
 
+from ..utils import checkpoint as ckpt
 from ..utils import dllogger
 from ..utils.graph import GraphedStep
 from ..utils.dist import init_from_env, is_main_process
@@ -22,9 +27,32 @@ from .model import LARGE, BertForPreTraining, config_from_json
 
 def parse_arguments(argv=None):
     p = argparse.ArgumentParser()
+    p.add_argument("--input_dir", default=None, type=str, help="lddl parquet shards (external loader; synthetic batches here)")
     p.add_argument("--config_file", default=None, type=str, help="BERT model config json (default: BERT-Large)")
+    p.add_argument("--bert_model", default="bert-large-uncased", type=str)
+    p.add_argument("--output_dir", default=None, type=str, help="where ckpt_{step}.pt files are written / resumed from")
+    p.add_argument("--vocab_file", default=None, type=str)
+    p.add_argument("--init_checkpoint", default=None, type=str, help="start from this checkpoint's weights (step and LR reset)")
     p.add_argument("--max_seq_length", default=128, type=int)
     p.add_argument("--max_predictions_per_seq", default=20, type=int)
+    p.add_argument("--num_train_epochs", default=3.0, type=float)
+    p.add_argument("--local_rank", type=int, default=int(os.getenv("LOCAL_RANK", -1)))
+    p.add_argument("--amp", action="store_true", help="accepted: 16-bit compute is always on (--fp16 / --bf16 pick the type)")
+    p.add_argument("--loss_scale", type=float, default=0.0)
+    p.add_argument("--checkpoint_activations", action="store_true", help="accepted; activations fit in 288 GB and are kept")
+    p.add_argument("--resume_from_checkpoint", action="store_true")
+    p.add_argument("--resume_step", type=int, default=-1)
+    p.add_argument("--num_steps_per_checkpoint", type=int, default=100)
+    p.add_argument("--phase2", action="store_true", help="sequence length 512 phase: step / LR restart from a phase-1 checkpoint")
+    p.add_argument("--resume_phase2", action="store_true")
+    p.add_argument("--phase1_end_step", type=int, default=7038)
+    p.add_argument("--do_train", action="store_true")
+    p.add_argument("--use_env", action="store_true")
+    p.add_argument("--profile", action="store_true")
+    p.add_argument("--profile-start", default=0, type=int)
+    p.add_argument("--num_workers", type=int, default=4)
+    p.add_argument("--no_dense_sequence_output", action="store_true")
+    p.add_argument("--disable_jit_fusions", action="store_true", help="accepted: there is no TorchScript in this path")
     p.add_argument("--train_batch_size", default=32, type=int, help="per-GPU batch of one optimizer step")
     p.add_argument("--learning_rate", default=6e-3, type=float)
     p.add_argument("--max_steps", default=1000, type=float)
@@ -87,6 +115,52 @@ def main(argv=None):
                           compute_dtype=dtype, init_loss_scale=float(args.init_loss_scale), world_size=world,
                           seed=args.seed, rank=rank, allreduce_dtype=dtype if args.allreduce_post_accumulation_fp16 else None,
                           max_predictions_per_seq=args.max_predictions_per_seq if args.cuda_graphs else None)
+    # ---- resume (run_pretraining.py:388-452)
+    global_step = 0
+    if args.resume_from_checkpoint or args.init_checkpoint:
+        if args.init_checkpoint:
+            path = args.init_checkpoint
+        else:
+            if args.resume_step == -1:
+                names = [f for f in os.listdir(args.output_dir) if f.startswith("ckpt_") and f.endswith(".pt")]
+                if not names:
+                    raise SystemExit("--resume_from_checkpoint: no ckpt_<step>.pt in %s" % args.output_dir)
+                args.resume_step = max(int(f[:-3].split("_")[1]) for f in names)
+            global_step = args.resume_step
+            path = os.path.join(args.output_dir, "ckpt_%d.pt" % global_step)
+        state = torch.load(path, map_location=device, weights_only=False)
+        if (args.phase2 and not args.resume_phase2) or args.init_checkpoint:
+            # phase 2 from a phase-1 checkpoint / fine start from given weights: step count and learning rate restart, the
+            # saved loss scale is not taken over (run_pretraining.py:437-445)
+            for group in state["optimizer"]["param_groups"]:
+                group["step"] = torch.zeros_like(torch.as_tensor(group["step"]))
+                group["lr"] = torch.as_tensor(float(args.learning_rate))
+            state = dict(state, grad_scaler={})
+        ckpt.bert_trainer_load(trainer, state)
+        if args.phase2 and not args.init_checkpoint:
+            global_step -= args.phase1_end_step
+        if args.init_checkpoint:
+            args.resume_step, global_step = 0, 0
+        if is_main_process():
+            print("resume step from ", args.resume_step)
+    recent = []
+
+    def checkpoint_step(step):
+        """run_pretraining.py:489-515: ckpt_{step}.pt on the main process, the three most recent files stay."""
+        torch.cuda.synchronize()
+        if not is_main_process() or args.skip_checkpoint or not args.output_dir:
+            return
+        dllogger.log(step="PARAMETER", data={"checkpoint_step": step})
+        os.makedirs(args.output_dir, exist_ok=True)
+        shown = step if (args.resume_step < 0 or not args.phase2) else step + args.phase1_end_step
+        out = os.path.join(args.output_dir, "ckpt_%d.pt" % shown)
+        torch.save(ckpt.bert_trainer_state(trainer, epoch=0), out)
+        if out in recent:
+            recent.remove(out)
+        recent.append(out)
+        if len(recent) > 3:
+            os.remove(recent.pop(0))
+
     acc = args.gradient_accumulation_steps
     micro = args.train_batch_size // acc
     it = synthetic_batches(cfg, micro, args.max_seq_length, args.max_predictions_per_seq, device, args.seed + rank)
@@ -112,7 +186,9 @@ def main(argv=None):
     side = torch.cuda.Stream() if use_graphs else None       # ONE side stream: the three captured callables depend on each other
     g_first, g_acc, g_opt = (GraphedStep(f, enabled=use_graphs, stream=side) for f in (micro_first, micro_acc, opt_step))
     trainer.grad_divisor = acc
-    for step in range(args.steps_this_run):
+    loss = avg_loss
+    steps_run = 0
+    for step in range(global_step, args.steps_this_run):
         for micro_step in range(acc):
             b = next(it)
             trainer._reduce_now = micro_step == acc - 1                   # no_sync on all but the last micro-step
@@ -120,14 +196,21 @@ def main(argv=None):
                                                            b["labels"], b["next_sentence_labels"])
             avg_loss += loss / acc
         g_opt()
-        if (step + 1) % max(int(args.log_freq), 1) == 0 and is_main_process():
-            dllogger.log(step=(0, step + 1), data={"average_loss": float(avg_loss.item()) / max(int(args.log_freq), 1),
+        steps_run += 1
+        done = step + 1
+        if done % max(int(args.log_freq), 1) == 0:
+            if is_main_process():
+                dllogger.log(step=(0, done), data={"average_loss": float(avg_loss.item()) / max(int(args.log_freq), 1),
                                                    "learning_rate": trainer.current_lr()})
             avg_loss.zero_()
+            if done % args.num_steps_per_checkpoint == 0 and done < args.steps_this_run:
+                checkpoint_step(done)
+    if steps_run:
+        checkpoint_step(args.steps_this_run)
     torch.cuda.synchronize()
     secs = time.time() - t0
     if is_main_process():
-        seqs = args.train_batch_size * world * args.steps_this_run
+        seqs = args.train_batch_size * world * steps_run
         dllogger.log(step=tuple(), data={"e2e_train_time": secs, "training_sequences_per_second": seqs / secs,
                                          "final_loss": float(loss.item()), "raw_train_time": secs})
         dllogger.flush()

@@ -170,8 +170,39 @@ class ResNetTrainer:
             self.buckets.grad_ready(finished_param_name)
 
     # ------------------------------------------------------------------ the step
+    def _input(self, images):
+        if images.dim() == 4 and not images.is_contiguous():
+            images = images.contiguous()         # --memory-format nhwc loaders hand over channels_last tensors
+        return images
+
+    def infer(self, images):
+        """Evaluation-mode forward (Executor.forward under model.eval(), training.py:98-105): running BatchNorm statistics,
+        no state kept.  -> fp32 logits [N, classes]."""
+        images = self._input(images)
+        if images.dtype == torch.uint8:
+            if getattr(self, "_mean_std", None) is None:
+                from .dataloaders import IMAGENET_MEAN, IMAGENET_STD
+                self._mean_std = (torch.tensor(IMAGENET_MEAN, device=self.dev) * 255.0, torch.tensor(IMAGENET_STD, device=self.dev) * 255.0)
+            x = F.u8_nchw_normalize_nhwc(images, self._mean_std[0], self._mean_std[1], self.dtype, 8)
+        else:
+            x = F.nchw_to_nhwc(images, self.dtype, 8)
+        h, _ = F.maxpool_fwd(self.stem.forward_eval(x))
+        for (u1, u2, u3, ud) in self.blocks:
+            res = ud.forward_eval(h) if ud is not None else h
+            h = u3.forward_eval(u2.forward_eval(u1.forward_eval(h)), residual=res)
+        pooled = F.avgpool_fwd(h)
+        return F.gemm(pooled, self.fc_w16, pooled.shape[0], self.fc_w16.shape[0], self.fc_w16.shape[1], True, True,
+                      out_dtype=torch.float32, bias=self.model.fc.bias.data)
+
+    def eval_step(self, images, target):
+        """-> (loss [1] (plain cross entropy, as NLLMultiLabelSmooth / LabelSmoothing / CrossEntropyLoss evaluate), logits)."""
+        logits = self.infer(images)
+        loss, _ = F.softmax_xent(logits, target, smoothing=0.0)
+        return loss, logits
+
     def forward(self, images):
         """images fp32 NCHW (as produced by the reference's loaders) -> fp32 logits [N, classes]."""
+        images = self._input(images)
         if images.dtype == torch.uint8:
             # decoded images straight from the loader: normalisation fused with the layout change (dataloaders.py:354-384)
             if getattr(self, "_mean_std", None) is None:
@@ -255,8 +286,18 @@ class ResNetTrainer:
         self.steps_since_update += 1
         last = self.steps_since_update == acc
         logits = self.forward(images)
-        loss, dlogits = F.softmax_xent(logits, target, smoothing=self.smoothing,
-                                       grad_scale=sc.scale if sc.enabled else None, grad_dtype=self.dtype)
+        gs = sc.scale if sc.enabled else None
+        if isinstance(target, tuple):
+            # --mixup (mixup.py:19-69): targets c * onehot(y) + (1 - c) * onehot(y[perm]); NLLMultiLabelSmooth is linear in the
+            # target, so loss = c * L(y) + (1 - c) * L(y[perm]) with the label-smoothing loss L, and so is its gradient
+            ya, yb, lam = target
+            la, da = F.softmax_xent(logits, ya, smoothing=self.smoothing, grad_scale=gs, grad_dtype=torch.float32)
+            lb, db = F.softmax_xent(logits, yb, smoothing=self.smoothing, grad_scale=gs, grad_dtype=torch.float32)
+            loss = lam * la + (1.0 - lam) * lb
+            F.axpby_(da.view(-1), db.view(-1), da.view(-1), lam, 1.0 - lam)
+            dlogits = F.cast(da, self.dtype)
+        else:
+            loss, dlogits = F.softmax_xent(logits, target, smoothing=self.smoothing, grad_scale=gs, grad_dtype=self.dtype)
         self._reduce_now = acc == 1                 # buckets fire during backward only without accumulation
         self.backward(dlogits)
         if acc > 1:

@@ -56,6 +56,15 @@ class ConvBN:
         self.saved = (x, t, mask, mean, rstd)
         return y
 
+    def forward_eval(self, x, residual=None):
+        """Inference-mode unit (model.eval(): BatchNorm normalises with its running statistics, nothing is saved) -- the
+        validation pass of training.py:257-311."""
+        t = F.conv2d_fwd(x, self.w16, self.stride, self.pad)
+        rstd = torch.rsqrt(self.bn.running_var + self.bn.eps)
+        y, _ = F.bn_fwd_apply(t, self.bn.running_mean, rstd, self.bn.weight.data, self.bn.bias.data, residual=residual,
+                              relu=self.relu, want_mask=False)
+        return y
+
     def backward(self, dy, need_dx=True, dx_addend=None, dy_mask=None):
         """dy: gradient w.r.t. the unit's output; dy_mask (optional): bit-packed keep bits to apply to dy first (the
         ReLU that follows the residual add sits on the OTHER branch's unit: its mask gates this branch's gradient too).

@@ -155,9 +155,9 @@ class DlrmTrainer:
                 F.cast_rows(self.bot_linears[i].weight.data, c.dtype, cols_out=c.shape[1], out=c)
 
     # ------------------------------------------------------------------ hybrid-parallel exchange
-    def _bottom_to_top(self, local_out):
+    def _bottom_to_top(self, local_out, plan=None):
         """[B_global, n_r, D] -> [B_r, n_total, D] (device feature order).  all_to_all_single over RCCL."""
-        p = self.plan
+        p = plan or self.plan
         recv = torch.empty(sum(p.fwd_recv_splits), dtype=local_out.dtype, device=local_out.device)
         comm.all_to_all_single(recv, local_out.view(-1), p.fwd_recv_splits, p.fwd_send_splits, group=self.pg)
         x = torch.empty((p.local_batch, p.n_total, p.dim), dtype=local_out.dtype, device=local_out.device)
@@ -184,6 +184,49 @@ class DlrmTrainer:
         out = torch.empty((p.global_batch, p.n_local, p.dim), dtype=grad_x.dtype, device=grad_x.device)
         comm.all_to_all_single(out.view(-1), send, p.fwd_send_splits, p.fwd_recv_splits, group=self.pg)
         return out
+
+    # ------------------------------------------------------------------ validation (dlrm/scripts/main.py:733-835 dist_evaluate)
+    @torch.no_grad()
+    def evaluate(self, batches, batch_sizes_per_gpu=None):
+        """Forward only over `batches` = iterable of (numerical or None, categorical or None, click[, valid rows]); with several
+        ranks every rank's logits are gathered; AUC (utils.roc_auc_score) and the BCE loss over the whole set -> (auc, loss) on
+        the main process, (None, None) elsewhere.  Batches may use a different (static) size than the train step."""
+        from .utils import roc_auc_score
+        m = self.model
+        y_true, y_score = [], []
+        plan = None
+        for item in batches:
+            num, cat, click = item[:3]
+            valid = item[3] if len(item) > 3 else click.shape[0]
+            x = m.bottom_model(num, cat)
+            if self.world > 1:
+                if plan is None or plan.global_batch != x.shape[0]:
+                    sizes = list(batch_sizes_per_gpu) if batch_sizes_per_gpu and sum(batch_sizes_per_gpu) == x.shape[0] else \
+                        [x.shape[0] // self.world] * self.world
+                    plan = ExchangePlan(sizes, self.plan.vectors, self.plan.dim, self.rank)
+                x = self._bottom_to_top(x, plan)
+            out = m.top_model(x).reshape(-1).float()
+            if self.world > 1:
+                parts = [torch.empty(b, dtype=out.dtype, device=out.device) for b in plan.batch_sizes]
+                if dist.get_backend(self.pg) == "nccl":
+                    dist.all_gather(parts, out, group=self.pg)
+                else:                                   # one-GPU test rig: staged through the host (utils/comm.py)
+                    hp = [t.cpu() for t in parts]
+                    dist.all_gather(hp, out.cpu(), group=self.pg)
+                    parts = [t.to(out.device) for t in hp]
+                out = torch.cat(parts)
+            y_true.append(click.reshape(-1).float()[:valid])
+            y_score.append(out[:valid])
+        if self.rank != 0:
+            if self.world > 1:
+                dist.barrier(group=self.pg)
+            return None, None
+        y_true, y_score = torch.cat(y_true), torch.cat(y_score)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(y_score, y_true)
+        auc = roc_auc_score(y_true, torch.sigmoid(y_score))
+        if self.world > 1:
+            dist.barrier(group=self.pg)
+        return auc, float(loss.item())
 
     # ------------------------------------------------------------------ the step
     def train_step(self, numerical_features, categorical_features, click):

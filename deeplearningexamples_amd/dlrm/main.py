@@ -1,16 +1,20 @@
-"""DLRM training entry point on MI355X with the reference's flags (subset that drives the train step).
+"""DLRM training / evaluation entry point on MI355X with the reference's flags.
 
 Mirrors Recommendation/DLRM/dlrm/scripts/main.py:43-143 (flags; argparse here, absl in the reference), :387-611
-(setup: device mapping, per-rank model, LR compensation) and :621-717 (loop, average_train_throughput).
+(setup: device mapping, per-rank model, LR compensation, --load_checkpoint_path, --mode test), :621-717 (loop: --test_freq /
+--test_after validation passes with AUC, --auc_threshold stop, --save_checkpoint_path at the end, average_train_throughput)
+and :733-835 (dist_evaluate).  Checkpoints are the reference's directory format (utils/checkpoint.py).
     python -m torch.distributed.run --nproc-per-node 8 -m deeplearningexamples_amd.dlrm.main \
         --dataset_type synthetic_gpu --amp --batch_size 65536 --max_steps 200
 """
 import argparse
 import os
+import sys
 import time
 
 import torch
 
+from ..utils import checkpoint as ckpt
 from ..utils import dllogger
 from ..utils.graph import GraphedStep
 from ..utils.dist import init_from_env, is_main_process
@@ -18,7 +22,7 @@ from . import placement as P
 from .data import FeatureSpec, ParametricDataset, prefetcher
 from .engine import DlrmTrainer
 from .model import DistributedDlrm
-from .utils import LearningRateScheduler, StepTimer
+from .utils import LearningRateScheduler, StepTimer, SyntheticDataset, evaluate
 
 CRITEO_F15 = [7912889, 33823, 582469, 245828, 11, 2209, 10667, 104, 4, 968, 15, 8165896, 17139, 2675940, 7156453,
               302516, 12022, 97, 35, 7339, 20046, 4, 7105, 1382, 63, 5554114]
@@ -30,9 +34,10 @@ def _int_list(s):
 
 def parse_flags(argv=None):
     p = argparse.ArgumentParser()
-    p.add_argument("--mode", default="train", choices=["train"])
+    p.add_argument("--mode", default="train", choices=["train", "test", "inference_benchmark"])
     p.add_argument("--seed", type=int, default=12345)
     p.add_argument("--batch_size", type=int, default=65536)
+    p.add_argument("--test_batch_size", type=int, default=65536)
     p.add_argument("--lr", type=float, default=24)
     p.add_argument("--epochs", type=int, default=1)
     p.add_argument("--max_steps", type=int, default=None)
@@ -57,6 +62,20 @@ def parse_flags(argv=None):
     p.add_argument("--synthetic_dataset_numerical_features", type=int, default=13)
     p.add_argument("--max_table_size", type=int, default=None)
     p.add_argument("--hash_indices", action="store_true")
+    p.add_argument("--shuffle_batch_order", action="store_true")
+    p.add_argument("--synthetic_dataset_use_feature_spec", action="store_true")
+    p.add_argument("--load_checkpoint_path", default=None, help="directory written by --save_checkpoint_path (or by the reference)")
+    p.add_argument("--save_checkpoint_path", default=None)
+    p.add_argument("--test_freq", type=int, default=None, help="validation pass every N steps (default: once per epoch)")
+    p.add_argument("--test_after", type=float, default=0, help="no validation before this many epochs")
+    p.add_argument("--auc_threshold", type=float, default=None, help="stop as soon as the validation AUC reaches this value")
+    p.add_argument("--auc_device", default="GPU", choices=["GPU", "CPU"])
+    p.add_argument("--base_device", default="cuda", choices=["cuda"])
+    p.add_argument("--backend", default="nccl")
+    p.add_argument("--inference_benchmark_batch_sizes", type=_int_list, default=[1, 64, 4096])
+    p.add_argument("--inference_benchmark_steps", type=int, default=200)
+    p.add_argument("--Adam_embedding_optimizer", action="store_true")
+    p.add_argument("--Adam_MLP_optimizer", action="store_true")
     p.add_argument("--log_path", default="./log.json")
     p.add_argument("--print_freq", type=int, default=200)
     p.add_argument("--benchmark_warmup_steps", type=int, default=0)
@@ -66,7 +85,12 @@ def parse_flags(argv=None):
     p.add_argument("--bottom_features_ordered", action="store_true")
     p.add_argument("--freeze_mlps", action="store_true")
     p.add_argument("--freeze_embeddings", action="store_true")
-    return p.parse_args(argv)
+    f = p.parse_args(argv)
+    if f.mode == "inference_benchmark":
+        raise SystemExit("--mode inference_benchmark: inference is outside this path (the train step and its validation pass)")
+    if f.Adam_embedding_optimizer or f.Adam_MLP_optimizer:
+        raise SystemExit("--Adam_*_optimizer: the path implements the reference's default SGD recipe")
+    return f
 
 
 def main(argv=None):
@@ -99,26 +123,78 @@ def main(argv=None):
                           freeze_embeddings=flags.freeze_embeddings)
     sched = LearningRateScheduler(flags.warmup_steps, flags.warmup_factor, flags.decay_steps, flags.decay_start_step,
                                   flags.decay_power, flags.decay_end_lr / flags.lr)
-    loader = None
+    writer = ckpt.make_distributed_checkpoint_writer(mapping, rank, is_main_process(), dict(vars(flags)))
+    if flags.load_checkpoint_path:               # main.py:493-495
+        ckpt.make_distributed_checkpoint_loader(mapping, rank, device=device).load_checkpoint(model, flags.load_checkpoint_path)
+    loader = test_loader = None
+    test_bs = flags.test_batch_size // world * world
+    test_batches = P.get_gpu_batch_sizes(test_bs, num_gpus=world) if world > 1 else (test_bs,)
+    has_bottom = rank == mapping["bottom_mlp"]
     if flags.dataset_type == "parametric":
         # every rank reads the numerical features only if it owns the bottom MLP and the categorical files of ITS tables
         spec = FeatureSpec.from_yaml(os.path.join(flags.dataset, flags.feature_spec))
         names = spec.get_categorical_feature_names()
-        loader = ParametricDataset(spec, "train", batch_size=flags.batch_size, numerical_features_enabled=rank == mapping["bottom_mlp"],
-                                   categorical_features_to_read=[names[t] for t in mine], drop_last_batch=True)
+        kw = dict(numerical_features_enabled=has_bottom, categorical_features_to_read=[names[t] for t in mine])
+        loader = ParametricDataset(spec, "train", batch_size=flags.batch_size, drop_last_batch=True, **kw)
+        try:
+            test_loader = ParametricDataset(spec, "test", batch_size=test_bs, drop_last_batch=False, **kw)
+        except (KeyError, OSError, ValueError):
+            test_loader = None                   # a feature spec without a test mapping: training only
         num = cat = click = None
     else:
         g = torch.Generator(device="cpu").manual_seed(flags.seed)                 # same global batch on every rank
         num = torch.rand((flags.batch_size, flags.synthetic_dataset_numerical_features), generator=g)
         cat = torch.cat([torch.randint(0, s, (flags.batch_size, 1), generator=g) for s in sizes], dim=1)
         click = torch.randint(0, 2, (flags.batch_size,), generator=g).float().to(device)
-        num = num.to(device) if rank == mapping["bottom_mlp"] else None
+        num = num.to(device) if has_bottom else None
         cat = cat[:, mine].contiguous().to(device) if mine else None
+        # data/factories.py: the synthetic test set is another SyntheticDataset (one fixed batch, num_entries / batch of them)
+        gt = torch.Generator(device="cpu").manual_seed(flags.seed + 1)
+        tds = SyntheticDataset(min(flags.synthetic_dataset_num_entries, 4 * test_bs), device="cpu", batch_size=test_bs,
+                               numerical_features=flags.synthetic_dataset_numerical_features,
+                               categorical_feature_sizes=sizes, generator=gt)
+        tnum = tds._num_tensor.to(device) if has_bottom else None
+        tcat = tds._cat_tensor[:, mine].contiguous().to(device) if mine else None
+        tclick = tds._label_tensor.to(device)
+        test_loader = [(tnum, tcat, tclick)] * len(tds)
+
+    def run_test():
+        """dist_evaluate (main.py:733-835): forward only over the test set, logits of every rank gathered, AUC + BCE loss."""
+        if test_loader is None:
+            return None, None
+        if isinstance(test_loader, list):
+            batches = test_loader
+        else:
+            def batches_iter():
+                for tn, tc, tk in prefetcher(iter(test_loader), device):
+                    yield (tn.float() if tn is not None else None), tc, tk
+            batches = batches_iter()
+        plan_batches = test_batches
+
+        def gen():
+            for tn, tc, tk in batches:
+                n = tk.shape[0]
+                if n != test_bs:                 # last batch: padded to the static test batch, outputs cut back (main.py:782-797)
+                    pad = test_bs - n
+                    if tn is not None:
+                        tn = torch.cat([tn, torch.zeros((pad, tn.shape[1]), dtype=tn.dtype, device=tn.device)])
+                    if tc is not None:
+                        tc = torch.cat([tc, torch.zeros((pad, tc.shape[1]), dtype=tc.dtype, device=tc.device)])
+                yield tn, tc, tk, n
+        return trainer.evaluate(gen(), plan_batches)
+    if flags.mode == "test":                     # main.py:506-513
+        auc, vloss = run_test()
+        if is_main_process():
+            dllogger.log(step=tuple(), data={"best_auc": auc, "best_validation_loss": vloss})
+            dllogger.flush()
+        return trainer
     steps_per_epoch = len(loader) if loader is not None else max(flags.synthetic_dataset_num_entries // flags.batch_size - 1, 1)
     # CudaGraphWrapper (main.py:610-611): eager warm-up steps, one capture, then copy-in + replay per step
     step_fn = GraphedStep(trainer.train_step, enabled=flags.cuda_graphs and world == 1)
     timer, times, moving_loss = StepTimer(), [], torch.zeros(1, device=device)
     step = 0
+    test_freq = flags.test_freq if flags.test_freq is not None else steps_per_epoch - 1
+    best_auc, best_loss, best_epoch, t_start, hit = 0.0, 1e6, 0.0, time.time(), False
     for epoch in range(flags.epochs):
         batches = prefetcher(iter(loader), device) if loader is not None else None
         for i in range(steps_per_epoch):
@@ -137,10 +213,30 @@ def main(argv=None):
                 dllogger.log(step=(epoch, i), data={"loss": float(moving_loss.item()) / flags.print_freq,
                                                     "step_time": timer.measured, "lr": trainer.base_lr * trainer.lr_factor})
                 moving_loss.zero_()
+            gstep = steps_per_epoch * epoch + i                      # main.py:676-699
+            if test_freq > 0 and gstep % test_freq == 0 and gstep > 0 and gstep / steps_per_epoch >= flags.test_after:
+                auc, vloss = run_test()
+                if auc is not None:
+                    if is_main_process():
+                        print("Epoch %d step %d. auc %.6f" % (epoch, i, auc))
+                        dllogger.log(step=(epoch, i), data={"auc": auc, "validation_loss": vloss})
+                    if auc > best_auc:
+                        best_auc, best_epoch = auc, epoch + (i + 1) / steps_per_epoch
+                    best_loss = min(best_loss, vloss)
+                    if flags.auc_threshold and auc >= flags.auc_threshold:
+                        print("Hit target accuracy AUC %s at epoch %.2f in %ds. " %
+                              (flags.auc_threshold, gstep / steps_per_epoch, int(time.time() - t_start)))
+                        hit = True
+                        break
+        if hit:
+            break
     torch.cuda.synchronize()
+    if flags.save_checkpoint_path:               # main.py:706-707
+        writer.save_checkpoint(model, flags.save_checkpoint_path, epoch, step)
     if is_main_process():
         avg = flags.batch_size / (sum(times) / max(len(times), 1)) if times else 0.0
-        dllogger.log(step=tuple(), data={"average_train_throughput": avg, "training_loss": float(moving_loss.item())})
+        dllogger.log(step=tuple(), data={"best_auc": best_auc, "best_validation_loss": best_loss, "best_epoch": best_epoch,
+                                         "average_train_throughput": avg, "training_loss": float(moving_loss.item())})
         dllogger.flush()
     return trainer
 

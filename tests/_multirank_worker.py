@@ -44,6 +44,42 @@ def run_bert(rank, world, dev, steps):
     return {"losses": losses, "probe": probe, "nbuckets": len(tr.buckets.buckets) if tr.buckets else 0}
 
 
+def run_bert_acc(rank, world, dev, steps):
+    """Gradient accumulation (run_pretraining.py:679-681, --gradient_accumulation_steps): every rank runs 2 micro-batches per
+    optimizer step, only the last one communicates (buckets fired during ITS backward), the accumulation count joins the loss
+    scale.  world 1: the same four micro-batches on one rank (divisor 4) -> the mean over ranks of (gA + gB) / 2."""
+    from oracle import bert_oracle as BO
+    from deeplearningexamples_amd.bert.model import BertForPreTraining
+    from deeplearningexamples_amd.bert.engine import BertTrainer
+    c = BO.BERT_STEP_CONFIG
+    torch.manual_seed(100 + rank)
+    model = BertForPreTraining(c["cfg"], device=dev)
+    if rank == 0:
+        model.load_state_dict({k: v.clone() for k, v in BO.seeded_state(c["cfg"], c["seed"]).items()}, strict=False)
+    tr = BertTrainer(model, lr=c["lr"], warmup=c["warmup"], total_steps=c["total_steps"], compute_dtype=torch.bfloat16,
+                     hidden_dropout=0.0, attention_dropout=0.0, world_size=world, rank=rank, bucket_mb=1)
+    full = BO.seeded_batch(c["cfg"], c["seed"] + 1, 8)
+    quarters = [[t[q * 2:(q + 1) * 2].contiguous().to(dev) for t in full] for q in range(4)]
+    mine = quarters if world == 1 else quarters[rank * 2:(rank + 1) * 2]
+    tr.grad_divisor = len(mine)
+    losses = []
+    for _ in range(steps):
+        tot = 0.0
+        for i, mb in enumerate(mine):
+            tr._reduce_now = i == len(mine) - 1
+            loss, dlog, dnsp = tr.forward(*mb)
+            tr.backward(dlog, dnsp, accumulate=i > 0)
+            tot = tot + loss / len(mine)
+        tr.optimizer_step()
+        if world > 1:
+            from deeplearningexamples_amd.utils import comm
+            tot = comm.allreduce_mean_(tot.clone())
+        losses.append(float(tot.item()))
+    named = dict(model.named_parameters())
+    probe = named["bert.encoder.layer.0.attention.self.query.weight"].detach().float().cpu().numpy()[:2].tolist()
+    return {"losses": losses, "probe": probe, "nbuckets": len(tr.buckets.buckets) if tr.buckets else 0}
+
+
 def run_rn50(rank, world, dev, steps):
     from oracle import resnet_oracle as RO
     from deeplearningexamples_amd.convnets.resnet import ResNet50
@@ -216,7 +252,7 @@ def _bert_flag2(dev, steps):
     return {"losses": losses, "probe": probe, "nbuckets": len(tr.buckets.buckets)}
 
 
-SCENARIOS = {"bert": run_bert, "rn50": run_rn50, "dlrm": run_dlrm, "waveglow": run_waveglow, "rccl1": run_rccl_single_rank}
+SCENARIOS = {"bert_acc": run_bert_acc, "bert": run_bert, "rn50": run_rn50, "dlrm": run_dlrm, "waveglow": run_waveglow, "rccl1": run_rccl_single_rank}
 
 
 def main():

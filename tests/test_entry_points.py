@@ -47,6 +47,128 @@ def test_cli_parsers():
     assert f.top_mlp_sizes == [64, 32, 1] and f.synthetic_dataset_table_sizes == [100, 200] and f.amp
 
 
+def test_reference_command_lines_parse():
+    """The reference's own command lines (README / scripts) must not end in an argparse error: every flag of
+    ConvNets/main.py:89-356, run_pretraining.py:140-321 and dlrm/scripts/main.py:43-143 is known to the drop-in parsers."""
+    import argparse
+    import re
+    from deeplearningexamples_amd.convnets.main import add_parser_arguments
+    from deeplearningexamples_amd.bert.run_pretraining import parse_arguments
+    from deeplearningexamples_amd.dlrm.main import parse_flags
+    a = add_parser_arguments(argparse.ArgumentParser()).parse_args(
+        ["--arch", "resnet50", "-b", "256", "--amp", "--static-loss-scale", "128", "--label-smoothing", "0.1", "--mixup", "0.2",
+         "--lr", "2.048", "--lr-schedule", "cosine", "--warmup", "8", "--epochs", "250", "--momentum", "0.875", "--wd", "3.05e-5",
+         "--resume", "ck/checkpoint.pth.tar", "--checkpoint-filename", "c.pth.tar", "--gather-checkpoints", "3", "--evaluate",
+         "--data-backend", "pytorch", "--memory-format", "nhwc", "--workspace", "/tmp/w", "--raport-file", "r.json", "-j", "8",
+         "--run-epochs", "2", "--training-only", "--no-checkpoints", "--topk", "5", "--seed", "1", "/data/imagenet"])
+    assert a.data == "/data/imagenet" and a.resume and a.gather_checkpoints == 3 and not a.save_checkpoints
+    b = parse_arguments(["--input_dir", "/d", "--output_dir", "/o", "--config_file", "bert_config.json", "--bert_model",
+                         "bert-large-uncased", "--train_batch_size", "8192", "--max_seq_length", "512",
+                         "--max_predictions_per_seq", "80", "--max_steps", "1563", "--warmup_proportion", "0.128",
+                         "--num_steps_per_checkpoint", "200", "--learning_rate", "4e-3", "--seed", "42", "--fp16",
+                         "--gradient_accumulation_steps", "256", "--allreduce_post_accumulation",
+                         "--allreduce_post_accumulation_fp16", "--do_train", "--phase2", "--resume_from_checkpoint",
+                         "--phase1_end_step", "7038", "--json-summary", "j.json", "--disable_progress_bar", "--num_workers", "4",
+                         "--init_checkpoint", "x.pt", "--resume_step", "7038", "--cuda_graphs", "--use_env"])
+    assert b.phase2 and b.resume_from_checkpoint and b.num_steps_per_checkpoint == 200 and b.output_dir == "/o"
+    f = parse_flags(["--dataset", "/data", "--seed", "1", "--epochs", "1", "--amp", "--cuda_graphs", "--save_checkpoint_path",
+                     "/ck", "--load_checkpoint_path", "/ck", "--test_freq", "100", "--test_after", "0.5", "--auc_threshold",
+                     "0.8025", "--test_batch_size", "131072", "--mode", "test", "--dataset_type", "parametric"])
+    assert f.auc_threshold == 0.8025 and f.test_freq == 100 and f.save_checkpoint_path == "/ck" and f.mode == "test"
+    ref = "/root/reference/PyTorch"
+    if os.path.isdir(ref):          # every flag the reference defines is accepted here (flag NAMES; semantics: the GPU test below)
+        ours = {"rn50": add_parser_arguments(argparse.ArgumentParser())}
+        src = open(ref + "/Classification/ConvNets/main.py").read()
+        known = {o for act in ours["rn50"]._actions for o in act.option_strings}
+        missing = [x for x in set(re.findall(r'"(--[a-zA-Z0-9_-]+)"', src[src.index("def add_parser_arguments"):src.index("def prepare_for_training")])) if x not in known]
+        assert not missing, missing
+        src = open(ref + "/LanguageModeling/BERT/run_pretraining.py").read()
+        flags = set(re.findall(r"""add_argument\(\s*['"](--[a-zA-Z0-9_-]+)['"]""", src))
+        import deeplearningexamples_amd.bert.run_pretraining as bp
+        psrc = open(bp.__file__).read()
+        missing = [x for x in flags if '"%s"' % x not in psrc]
+        assert not missing, missing
+        src = open(ref + "/Recommendation/DLRM/dlrm/scripts/main.py").read()
+        flags = set(re.findall(r'DEFINE_[a-z]+\(\s*"([a-zA-Z0-9_]+)"', src))
+        import deeplearningexamples_amd.dlrm.main as dm
+        psrc = open(dm.__file__).read()
+        missing = [x for x in flags if '"--%s"' % x not in psrc]
+        assert not missing, missing
+
+
+@pytest.mark.gpu
+def test_entry_points_save_and_resume_on_gpu(cuda, tmp_path):
+    """f2 / f4 through the drop-in command lines: each CLI trains, writes the reference's checkpoint file(s), a SECOND process-
+    equivalent call resumes from them and continues; the ResNet CLI evaluates (--evaluate), the DLRM CLI logs an AUC."""
+    import torch
+    from deeplearningexamples_amd.convnets import main as rn
+    from deeplearningexamples_amd.bert import run_pretraining as bp
+    from deeplearningexamples_amd.dlrm import main as dl
+    # ---- ResNet-50: 2 epochs of 3 iterations with validation and checkpoints, then resume for a third epoch, then --evaluate
+    ws = tmp_path / "rn"
+    common = ["--batch-size", "8", "--image-size", "64", "--prof", "3", "--amp", "--label-smoothing", "0.1", "--lr", "0.01",
+              "--lr-schedule", "cosine", "--warmup", "1", "--workspace", str(ws), "--print-freq", "1", "--steps-per-epoch", "3",
+              "--num-classes", "16", "--seed", "3"]
+    rn.main(common + ["--epochs", "3", "--run-epochs", "2"])
+    assert {"checkpoint.pth.tar", "checkpoint_0000.pth.tar", "checkpoint_0001.pth.tar"} <= set(os.listdir(ws))
+    ck = torch.load(ws / "checkpoint.pth.tar", map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 2 and set(ck) >= {"state_dict", "optimizer", "best_prec1"}
+    t = rn.main(common + ["--epochs", "3", "--resume", str(ws / "checkpoint.pth.tar")])
+    assert (ws / "checkpoint_0002.pth.tar").exists() and t.steps_done == 9          # 6 restored + 3 new iterations
+    recs = [json.loads(l[5:]) for l in open(ws / "experiment_raport.json")]
+    assert any("val.top1" in r.get("data", {}) for r in recs)
+    rn.main(common + ["--epochs", "3", "--resume", str(ws / "checkpoint_0001.pth.tar"), "--evaluate"])
+    # mixup + nhwc loader batches run through the same CLI
+    rn.main(common + ["--epochs", "1", "--mixup", "0.2", "--memory-format", "nhwc", "--no-checkpoints", "--training-only",
+                      "--workspace", str(tmp_path / "rn2")])
+    # ---- ResNet-50, --data-backend pytorch over a folder of pre-decoded images (uint8 -> normalised NHWC in the first kernel)
+    rng = np.random.default_rng(0)
+    for split in ("train", "val"):
+        for c in range(2):
+            d = tmp_path / "imgs" / split / ("class%d" % c)
+            os.makedirs(d)
+            for i in range(8):
+                np.save(d / ("%d.npy" % i), rng.integers(0, 256, (80, 96, 3), dtype=np.uint8))
+    rn.main(["--batch-size", "4", "--image-size", "64", "--epochs", "1", "--amp", "--lr", "0.01", "--workspace",
+             str(tmp_path / "rn3"), "--data-backend", "pytorch", "--num-classes", "2", "-j", "0", "--print-freq", "1",
+             str(tmp_path / "imgs")])
+    recs = [json.loads(l[5:]) for l in open(tmp_path / "rn3" / "experiment_raport.json")]
+    assert any("val.top1" in r.get("data", {}) for r in recs) and any("train.loss" in r.get("data", {}) for r in recs)
+    # ---- BERT: 4 steps with a checkpoint every 2, "killed" after 4; resume to 6; phase-2 restart from the phase-1 file
+    cfg = tmp_path / "tiny.json"
+    cfg.write_text(json.dumps(dict(vocab_size=1000, hidden_size=256, num_attention_heads=4, num_hidden_layers=2,
+                                   intermediate_size=1024, max_position_embeddings=512, type_vocab_size=2)))
+    out = tmp_path / "bert_out"
+    base = ["--config_file", str(cfg), "--train_batch_size", "8", "--gradient_accumulation_steps", "2", "--max_steps", "6",
+            "--json-summary", str(tmp_path / "bert.json"), "--bf16", "--output_dir", str(out), "--num_steps_per_checkpoint", "2",
+            "--do_train"]
+    t = bp.main(base + ["--steps_this_run", "4"])
+    assert sorted(os.listdir(out)) == ["ckpt_2.pt", "ckpt_4.pt"] and t.opt_steps == 4
+    w4 = t.model.state_dict()["bert.pooler.dense_act.weight"].clone()
+    t2 = bp.main(base + ["--resume_from_checkpoint"])
+    assert t2.opt_steps == 6 and sorted(os.listdir(out)) == ["ckpt_2.pt", "ckpt_4.pt", "ckpt_6.pt"]
+    ck = torch.load(out / "ckpt_4.pt", map_location="cpu", weights_only=False)
+    assert torch.equal(ck["model"]["bert.pooler.dense_act.weight"].cpu(), w4.cpu()) and int(ck["optimizer"]["param_groups"][0]["step"]) == 4
+    t3 = bp.main(base[:-5] + ["--output_dir", str(tmp_path / "bert_p2"), "--init_checkpoint", str(out / "ckpt_6.pt"), "--phase2",
+                              "--max_seq_length", "256", "--max_predictions_per_seq", "40", "--steps_this_run", "2"])
+    assert t3.opt_steps == 2                       # step and LR restart (run_pretraining.py:437-445)
+    # ---- DLRM: train with validation passes + save; test mode from the saved directory; resume training from it
+    ckd = tmp_path / "dlrm_ck"
+    dbase = ["--batch_size", "2048", "--synthetic_dataset_table_sizes", "1000,50,7,20000", "--amp", "--print_freq", "2",
+             "--synthetic_dataset_num_entries", "16384", "--test_batch_size", "4096"]
+    dl.main(dbase + ["--max_steps", "6", "--log_path", str(tmp_path / "dlrm.json"), "--test_freq", "3",
+                     "--save_checkpoint_path", str(ckd)])
+    recs = [json.loads(l[5:]) for l in open(tmp_path / "dlrm.json")]
+    aucs = [r["data"]["auc"] for r in recs if "auc" in r.get("data", {})]
+    assert aucs and all(0.0 <= a <= 1.0 for a in aucs) and "best_auc" in recs[-1]["data"]
+    assert os.path.exists(ckd / "metadata.pt") and os.path.exists(ckd / "bottom_model.embeddings.0.bin")
+    dl.main(dbase + ["--mode", "test", "--load_checkpoint_path", str(ckd), "--log_path", str(tmp_path / "dlrm_test.json")])
+    rt = [json.loads(l[5:]) for l in open(tmp_path / "dlrm_test.json")]
+    assert rt[-1]["data"]["best_auc"] == pytest.approx(aucs[-1], abs=0.05)     # same weights up to the steps after the last test
+    t = dl.main(dbase + ["--max_steps", "3", "--load_checkpoint_path", str(ckd), "--log_path", str(tmp_path / "dlrm2.json")])
+    assert t is not None
+
+
 @pytest.mark.gpu
 def test_entry_points_run_on_gpu(cuda, tmp_path):
     from deeplearningexamples_amd.convnets import main as rn
