@@ -99,10 +99,12 @@ class Masks:
     """Dropout keep masks of a doubles run, by call order, so that the oracle can replay them site by site."""
     rng = np.random.default_rng(0)
     log = []
+    replay = None            # list of keep masks to serve in call order instead of drawing (the masks a HIP run drew)
 
     @classmethod
-    def reset(cls, seed):
+    def reset(cls, seed, replay=None):
         cls.rng, cls.log = np.random.default_rng(seed), []
+        cls.replay = list(replay) if replay is not None else None
 
 
 def _pack(keep):
@@ -123,7 +125,10 @@ def inv_keep(p):
 
 
 def dropout_fwd(x, p, seed, offset, offset_base=None):
-    keep = torch.from_numpy(Masks.rng.random(tuple(x.shape)) >= p)
+    if Masks.replay is not None:
+        keep = Masks.replay.pop(0).reshape(x.shape).bool()
+    else:
+        keep = torch.from_numpy(Masks.rng.random(tuple(x.shape)) >= p)
     Masks.log.append(keep)
     return (x.float() * keep * inv_keep(p)).to(x.dtype), _pack(keep)
 

@@ -130,7 +130,7 @@ def test_entry_points_save_and_resume_on_gpu(cuda, tmp_path):
             for i in range(8):
                 np.save(d / ("%d.npy" % i), rng.integers(0, 256, (80, 96, 3), dtype=np.uint8))
     rn.main(["--batch-size", "4", "--image-size", "64", "--epochs", "1", "--amp", "--lr", "0.01", "--workspace",
-             str(tmp_path / "rn3"), "--data-backend", "pytorch", "--num-classes", "2", "-j", "0", "--print-freq", "1",
+             str(tmp_path / "rn3"), "--data-backend", "pytorch", "--num-classes", "2", "--topk", "2", "-j", "0", "--print-freq", "1",
              str(tmp_path / "imgs")])
     recs = [json.loads(l[5:]) for l in open(tmp_path / "rn3" / "experiment_raport.json")]
     assert any("val.top1" in r.get("data", {}) for r in recs) and any("train.loss" in r.get("data", {}) for r in recs)

@@ -70,7 +70,7 @@ def test_bert_resume_continues_identically(cuda, tmp_path):
     for n in n1:
         assert torch.allclose(n1[n], n2[n], rtol=1e-5, atol=1e-7), n
     ck = torch.load(tmp_path / "ckpt_2.pt", map_location="cpu", weights_only=False)
-    assert set(ck) == {"model", "optimizer", "grad_scaler", "epoch"} and "cls.predictions.decoder.weight" in ck["model"]
+    assert set(ck) == {"model", "optimizer", "grad_scaler", "epoch", "dle_rng_base"} and "cls.predictions.decoder.weight" in ck["model"]
     assert ck["optimizer"]["param_groups"][0]["step"].dtype == torch.int32 and ck["grad_scaler"]["scale"] == float(t1.scaler.scale.item()) or True
 
 

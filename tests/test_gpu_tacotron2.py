@@ -202,17 +202,14 @@ def _oracle_under_engine_masks(TO, F, tr, p, cfg, batch):
     return lo, outs
 
 
-# 16-bit storage floors of THIS case (tools/storage_floor_f1.py --t2-default, profiles/r03_t2_default_storage_floor.txt: the product
-# engine on the CPU over fp64-accumulating doubles with 16-bit storage, three mask draws): worst tensor / median of the per-tensor
-# relative L2 gradient error.  Bars = 1.3 x the worst of the three draws.
-T2_DEFAULT_FLOOR = {torch.float16: (1.96e-2, 2.71e-3), torch.bfloat16: (1.02e-1, 2.09e-2)}
-
-
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_default_widths_step_vs_oracle_under_the_hip_masks(cuda, dtype):
+def test_default_widths_step_vs_oracle_under_the_hip_masks(cuda, dtype, monkeypatch):
     """The network bench.py times (tacotron2/arg_parser.py:40-107: 512-wide encoder, 1024-unit LSTM cells, attention 128 / 32 x 31,
     prenet 256; 28.2 M parameters) on 4 utterances, 40 text positions, 60 decoder steps: loss 1e-3, alignments, every parameter
-    gradient inside 1.3 x the 16-bit storage floor measured at this size (tacotron2/model.py:405-519, loss_function.py:31-46)."""
+    gradient (tacotron2/model.py:405-519, loss_function.py:31-46).  Gradient bars = 1.3 x the 16-bit STORAGE floor of this case
+    UNDER THE SAME MASKS: the product engine re-run on the CPU over the fp64-accumulating doubles with 16-bit storage
+    (tools/storage_floor_f1.py's measurement; over mask draws the worst-tensor floor moves between 1.9 and 3 % in fp16, 8 - 10 %
+    in bf16 -- profiles/r03_t2_default_storage_floor.txt -- so it is taken for the draw at hand, not from a table)."""
     from oracle import tacotron2_oracle as TO
     from deeplearningexamples_amd import functional as F
     from deeplearningexamples_amd.tacotron2.engine import Tacotron2Trainer
@@ -228,19 +225,30 @@ def test_default_widths_step_vs_oracle_under_the_hip_masks(cuda, dtype):
     loss = tr.forward(text.to(cuda), tl.to(cuda), mel.to(cuda), gate.to(cuda))
     tr.backward()
     assert bool(torch.isfinite(tr.g.flat).all())
+    masks = _engine_masks(tr, F)
     p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
     lo, (_, _, _, align) = _oracle_under_engine_masks(TO, F, tr, p, cfg, (text, tl, mel, gate))
     lo.backward()
     assert abs(float(loss) - float(lo.detach())) <= 1e-3 * abs(float(lo.detach())), (float(loss), float(lo.detach()))
     _close(tr.sv["aw"].permute(1, 0, 2), align, rtol=5e-2, atol=2e-3 if dtype == torch.float16 else 1e-2)
-    worst_floor, med_floor = T2_DEFAULT_FLOOR[dtype]
-    errs = {}
-    for k, v in p.items():
-        if float(v.grad.norm()) > 1e-5:
-            errs[k] = float((tr.g[k].cpu() / scale - v.grad).norm() / v.grad.norm())
-    bad = {k: e for k, e in errs.items() if e > 1.3 * worst_floor}
+    live = [k for k, v in p.items() if float(v.grad.norm()) > 1e-5]
+    errs = {k: float((tr.g[k].cpu() / scale - p[k].grad).norm() / p[k].grad.norm()) for k in live}
+    # the floor: same engine, same masks, same storage dtype, fp64-accumulating plain-torch doubles on the CPU
+    D.install(monkeypatch)
+    D.Masks.reset(0, replay=masks)
+    cpu_model = Tacotron2(**cfg)
+    cpu_model.load_reference_state(state)
+    ftr = Tacotron2Trainer(cpu_model, compute_dtype=dtype, amp=True, init_loss_scale=scale)
+    ftr.forward(text, tl, mel, gate)
+    ftr.backward()
+    floor = {k: float((ftr.g[k] / scale - p[k].grad).norm() / p[k].grad.norm()) for k in live}
+    worst_floor, med_floor = max(floor.values()), float(np.median(list(floor.values())))
+    print(dtype, "worst / median relative L2 gradient error: HIP %.3e / %.3e, 16-bit storage floor under the same masks %.3e / %.3e"
+          % (max(errs.values()), float(np.median(list(errs.values()))), worst_floor, med_floor))
+    assert worst_floor < (0.05 if dtype == torch.float16 else 0.2)                     # the floor itself is a usable bar
+    bad = {k: (e, floor[k]) for k, e in errs.items() if e > 1.3 * worst_floor}
     assert not bad, bad
-    assert float(np.median(list(errs.values()))) <= 1.3 * med_floor, float(np.median(list(errs.values())))
+    assert float(np.median(list(errs.values()))) <= 1.3 * med_floor
 
 
 @pytest.mark.parametrize("case_name", ["small", "default"])
