@@ -346,3 +346,45 @@ extern "C" int dle_axpby_f32(const float* x, const float* y, float* out, float a
   DLE_LAUNCH_CHECK();
   return 0;
 }
+
+// y[c][r] = (16-bit) x[r][c] of a row-major [rows, cols] matrix (fp32, or the output's own 16-bit type); row strides ld_x / ld_y.
+// The recurrent steps read their weights as the k-contiguous operand of BOTH the forward and the data-gradient product
+// (gemm_smallm.hip streams [N, K] rows): the transposed working copy is made once per iteration next to the plain one, the way
+// autocast's per-forward weight casts are (torch.nn.LSTMCell / cuDNN keep transposed packed weights for the same reason).
+template <int DT, bool SRC_F32>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const void* __restrict__ x, unsigned short* __restrict__ y, int rows,
+                                                             int cols, long long ld_x, long long ld_y) {
+  __shared__ unsigned short tile[64][66];
+  const int tiles_c = (cols + 63) / 64;
+  const int tr = blockIdx.x / tiles_c, tc = blockIdx.x - tr * tiles_c;
+  const int r0 = tr * 64, c0 = tc * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    unsigned short v = 0;
+    if (r < rows && c < cols)
+      v = SRC_F32 ? Elem<DT>::from_f32(((const float*)x)[(long long)r * ld_x + c]) : ((const unsigned short*)x)[(long long)r * ld_x + c];
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) y[(long long)c * ld_y + r] = tile[tx][i];
+  }
+}
+
+extern "C" int dle_transpose_cast(const void* x, void* y, int rows, int cols, int64_t ld_x, int64_t ld_y, int in_dtype, int out_dtype,
+                                  hipStream_t stream) {
+  DLE_CHECK_ARG(x && y && rows > 0 && cols > 0 && ld_x >= cols && ld_y >= rows, "transpose_cast: bad args");
+  DLE_CHECK_ARG((out_dtype == DLE_F16 || out_dtype == DLE_BF16) && (in_dtype == DLE_F32 || in_dtype == out_dtype),
+                "transpose_cast: 16-bit output from fp32 or from the same 16-bit type");
+  const int grid = ((rows + 63) / 64) * ((cols + 63) / 64);
+#define GO(DT, F) hipLaunchKernelGGL((transpose_cast_kernel<DT, F>), dim3(grid), dim3(256), 0, stream, x, (unsigned short*)y, rows, cols, (long long)ld_x, (long long)ld_y)
+  if (out_dtype == DLE_F16) { if (in_dtype == DLE_F32) GO(DLE_F16, true); else GO(DLE_F16, false); }
+  else { if (in_dtype == DLE_F32) GO(DLE_BF16, true); else GO(DLE_BF16, false); }
+#undef GO
+  DLE_LAUNCH_CHECK();
+  return 0;
+}

@@ -445,6 +445,10 @@ extern "C" int dle_gemm_dma_try(const void* A, const void* B, void* C, void* aux
                                 int accumulate, float alpha, void* workspace, int64_t workspace_bytes,
                                 hipStream_t stream);
 
+extern "C" int dle_gemm_smallm_try(const void* A, const void* B, void* C, const float* bias, const void* src, int M, int N, int K,
+                                   int64_t lda, int64_t ldb, int64_t ldc, int in_dtype, int out_dtype, int act_add, int accumulate,
+                                   float alpha, hipStream_t stream);     // gemm_smallm.hip
+
 // C ABI.  a_kc / b_kc: operand stored with the contraction dimension contiguous (see header).
 extern "C" int dle_gemm(const void* A, const void* B, void* C, void* aux, const float* bias,
                         const void* mask_src, int M, int N, int K, int64_t lda, int64_t ldb,
@@ -475,6 +479,15 @@ extern "C" int dle_gemm(const void* A, const void* B, void* C, void* aux, const 
   {
     // fast path: LDS-DMA fed kernel (gemm_dma.hip); DLE_GEMM_LEGACY=1 pins the register-staged kernel
     static const bool legacy = getenv("DLE_GEMM_LEGACY") != nullptr && getenv("DLE_GEMM_LEGACY")[0] == '1';
+    // few rows (recurrent steps, heads): the weight-streaming kernel of gemm_smallm.hip -- N / 16..32 workgroups instead of a
+    // dozen 128x128 tiles
+    if (!legacy && K > 0 && M <= 256 && a_kc && b_kc && splitk == 1 && !aux && (act == ACT_NONE || act == 4) &&
+        (!accumulate || out_dtype == DLE_F32)) {
+      const int r = dle_gemm_smallm_try(A, B, C, bias, mask_src, M, N, K, lda, ldb, ldc, in_dtype, out_dtype, act == 4, accumulate,
+                                        alpha, stream);
+      if (r == 1) return 0;
+      if (r != 0) return r;
+    }
     if (!legacy && K > 0) {
       const int r = dle_gemm_dma_try(A, B, C, aux, bias, mask_src, M, N, K, lda, ldb, ldc, a_kc, b_kc, in_dtype,
                                      out_dtype, act, splitk, accumulate, alpha, workspace, workspace_bytes, stream);

@@ -1,0 +1,207 @@
+// Few-row GEMM for gfx950: C[M <= 256, N] = epilogue(alpha * A[M, K] B[N, K]^T), both operands k-contiguous.
+//
+// The recurrent loops of the path (Tacotron2's attention / decoder LSTMCells and their data gradients,
+// SpeechSynthesis/Tacotron2/tacotron2/model.py:405-455, one row per sample: M = batch = 128; the encoder LSTM steps; the
+// pooler / NSP heads of BERT) multiply a handful of rows by a wide weight matrix once per time step.  On the 128x128 tile of
+// gemm_dma.hip such a product is 12-32 workgroups on 256 CUs, each walking the whole K range alone: 28-54 us per launch,
+// 64 TFLOP/s, and ~9,000 of them per Tacotron2 iteration.  These products are bound by how fast the WEIGHTS (12-21 MB per
+// launch, L2 / Infinity-Cache resident across steps) reach the CUs, so the tile is chosen for bytes per workgroup, not for MFMA
+// reuse: 64 rows x TN (32 | 16) columns x the full K range per workgroup -> ceil(M / 64) x N / TN workgroups (256 for a
+// 128 x 4096 gate matrix), K * 2 * (64 + TN) bytes each.
+//  * operands stream HBM/L2 -> LDS by LDS-DMA (buffer_load ... lds, 16 B / lane, 1 KiB per wave instruction) in K chunks of
+//    128 elements (256-byte rows, full cache lines), FOUR stages: three chunks in flight per workgroup while one is multiplied;
+//    counted vmcnt (never 0 inside the loop), LDS-only barriers; every DMA goes through inline asm (gemm_tiles.h) so hipcc's
+//    wait-count pass inserts nothing;
+//  * the LDS image of a DMA is lane-linear, so bank conflicts are removed on the SOURCE address: slot s of row r holds the
+//    16-byte chunk s ^ (r & 15); a fragment read (16 rows x one k chunk per 16-lane group) then touches 16 distinct slots of
+//    the 256-byte bank window;
+//  * v_mfma_f32_16x16x32 with the WEIGHT rows as the first operand: a lane ends up with 4 consecutive output columns of one row
+//    (8 / 16-byte stores); 4 wavefronts, one 16-row block each, TN / 16 column blocks.
+// Epilogue: alpha, bias[n], 16-bit addend (DLE_ACT_ADD), fp32 accumulate, fp32 or 16-bit output.
+#include "gemm_tiles.h"
+
+#define SM_BKE 128                     // K elements per chunk
+#define SM_TS 64                       // rows of A per workgroup
+#define SM_STAGES 4
+
+struct SmallMArgs {
+  const unsigned short* A;
+  const unsigned short* B;
+  void* C;
+  const float* bias;
+  const unsigned short* src;
+  int M, N, K;
+  long long lda, ldb, ldc;
+  int out_dtype, act_add, accumulate;
+  float alpha;
+};
+
+template <int DT> struct Mfma16x32;
+template <> struct Mfma16x32<DLE_F16> {
+  static __device__ __forceinline__ float4_t run(ushort8_t a, ushort8_t b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma16x32<DLE_BF16> {
+  static __device__ __forceinline__ float4_t run(ushort8_t a, ushort8_t b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+// One K chunk of the workgroup's (SM_TS + TN)-row operand panel into `stage`.  NPW pieces per wavefront; piece q covers rows
+// 4q .. 4q + 3 (A rows first); lane l -> row 4q + (l >> 4), LDS slot l & 15, source chunk slot ^ (row & 15).
+template <int TN>
+struct SmallMLoader {
+  static constexpr int R = SM_TS + TN, NPW = R / 16;
+  unsigned off[NPW];        // byte offset of (row, chunk) inside its operand, k0 = 0
+  int kin[NPW];             // first k element of the lane's chunk
+  bool ok[NPW];
+  __device__ __forceinline__ void init(const SmallMArgs& p, int wave, int lane, int m0, int n0) {
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+      const int q = wave + 4 * j, row = 4 * q + (lane >> 4), chunk = (lane & 15) ^ (row & 15);
+      const bool is_a = row < SM_TS;
+      const int g = is_a ? m0 + row : n0 + row - SM_TS;
+      ok[j] = is_a ? g < p.M : g < p.N;
+      kin[j] = chunk * 8;
+      off[j] = (unsigned)(((long long)g * (is_a ? p.lda : p.ldb) + chunk * 8) * 2);
+    }
+  }
+  __device__ __forceinline__ void issue(const SmallMArgs& p, unsigned short* stage, int wave, int k0) {
+    const int4v_t ra = rsrc_words(p.A), rb = rsrc_words(p.B);
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+      const int q = wave + 4 * j;
+      const bool valid = ok[j] && k0 + kin[j] < p.K;
+      dma16_raw(4 * q < SM_TS ? ra : rb, stage + q * 512, valid ? off[j] + (unsigned)k0 * 2u : OOB_OFF);
+    }
+  }
+};
+
+template <int N> __device__ __forceinline__ void sm_wait_vm() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
+template <int DT, int TN>
+__global__ __launch_bounds__(256) void gemm_smallm_kernel(SmallMArgs p) {
+  typedef SmallMLoader<TN> L;
+  constexpr int R = L::R, NB = TN / 16, STAGE = R * SM_BKE;      // halves per stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* lds = (unsigned short*)smem_raw;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tiles_n = (p.N + TN - 1) / TN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int m0 = tm * SM_TS, n0 = tn * TN;
+  L ld;
+  ld.init(p, wave, lane, m0, n0);
+  const int nk = (p.K + SM_BKE - 1) / SM_BKE;
+#pragma unroll
+  for (int s = 0; s < SM_STAGES - 1; ++s)
+    if (s < nk) ld.issue(p, lds + s * STAGE, wave, s * SM_BKE);
+  float4_t acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) acc[b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, kg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    // this wave's pieces of chunk kt have landed; the (at most two) younger chunks stay in flight
+    if (kt + 2 < nk) sm_wait_vm<2 * L::NPW>();
+    else if (kt + 1 < nk) sm_wait_vm<L::NPW>();
+    else sm_wait_vm<0>();
+    lds_barrier();                           // ... and everybody's; the stage chunk kt + 3 will overwrite is no longer read
+    if (kt + SM_STAGES - 1 < nk) ld.issue(p, lds + ((kt + SM_STAGES - 1) % SM_STAGES) * STAGE, wave, (kt + SM_STAGES - 1) * SM_BKE);
+    const unsigned short* st = lds + (kt % SM_STAGES) * STAGE;
+    const unsigned short* xa = st + (wave * 16 + fr) * SM_BKE;
+#pragma unroll
+    for (int ks = 0; ks < SM_BKE / 32; ++ks) {
+      const int slot = (ks * 4 + kg) ^ fr;
+      const ushort8_t fx = *(const ushort8_t*)(xa + slot * 8);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const ushort8_t fw = *(const ushort8_t*)(st + (SM_TS + b * 16 + fr) * SM_BKE + slot * 8);
+        acc[b] = Mfma16x32<DT>::run(fw, fx, acc[b]);
+      }
+    }
+  }
+  // lane: row m = m0 + 16 wave + (lane & 15), columns n0 + 16 b + 4 (lane >> 4) + {0..3}
+  const int m = m0 + wave * 16 + fr;
+  if (m >= p.M) return;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int n = n0 + b * 16 + 4 * kg;
+    if (n >= p.N) continue;
+    const int nval = p.N - n < 4 ? p.N - n : 4;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[b][r] * p.alpha;
+    if (p.bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (r < nval) v[r] += p.bias[n + r];
+    }
+    const long long o = (long long)m * p.ldc + n;
+    const bool vec = nval == 4 && (p.ldc & 3) == 0;
+    if (p.act_add) {
+      const unsigned short* s = p.src + o;
+      if (vec) {
+        const ushort4_t sv = *(const ushort4_t*)s;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += Elem<DT>::to_f32(sv[r]);
+      } else {
+        for (int r = 0; r < nval; ++r) v[r] += Elem<DT>::to_f32(s[r]);
+      }
+    }
+    if (p.out_dtype == DLE_F32) {
+      float* c = (float*)p.C + o;
+      if (p.accumulate) for (int r = 0; r < nval; ++r) v[r] += c[r];
+      if (vec) *(float4_t*)c = (float4_t){v[0], v[1], v[2], v[3]};
+      else for (int r = 0; r < nval; ++r) c[r] = v[r];
+    } else {
+      unsigned short* c = (unsigned short*)p.C + o;
+      ushort4_t ov;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ov[r] = p.out_dtype == DLE_F16 ? Elem<DLE_F16>::from_f32(v[r]) : Elem<DLE_BF16>::from_f32(v[r]);
+      if (vec) *(ushort4_t*)c = ov;
+      else for (int r = 0; r < nval; ++r) c[r] = ov[r];
+    }
+  }
+}
+
+// 1: launched; 0: outside the envelope (the caller goes on to the other kernels); > 1: error.
+extern "C" int dle_gemm_smallm_try(const void* A, const void* B, void* C, const float* bias, const void* src, int M, int N, int K,
+                                   int64_t lda, int64_t ldb, int64_t ldc, int in_dtype, int out_dtype, int act_add, int accumulate,
+                                   float alpha, hipStream_t stream) {
+  static const int mode = getenv("DLE_GEMM_SMALLM") ? atoi(getenv("DLE_GEMM_SMALLM")) : 1;
+  if (!mode || M < 1 || M > 256 || N < 8 || K < 8) return 0;
+  if (((((uintptr_t)A) | ((uintptr_t)B)) & 15) != 0 || (lda & 7) != 0 || (ldb & 7) != 0 || (K & 7) != 0) return 0;
+  if ((long long)M * lda * 2 >= 0xFFFFFFE0LL || (long long)N * ldb * 2 >= 0xFFFFFFE0LL) return 0;
+  if (out_dtype != DLE_F32 && out_dtype != in_dtype) return 0;
+  if (out_dtype != DLE_F32 && ((((uintptr_t)C) | ((uintptr_t)src)) & 7) != 0) return 0;
+  if (out_dtype == DLE_F32 && (((uintptr_t)C) & 15) != 0) return 0;
+  if (act_add && (out_dtype != in_dtype || (((uintptr_t)src) & 7) != 0)) return 0;
+  // worth it only when the K range is long enough to stream (a 128-element chunk per stage) or the other kernels would leave
+  // most of the chip idle anyway
+  SmallMArgs p = {(const unsigned short*)A, (const unsigned short*)B, C, bias, (const unsigned short*)src, M, N, K,
+                  (long long)lda, (long long)ldb, (long long)ldc, out_dtype, act_add, accumulate, alpha};
+  const int tm = (M + SM_TS - 1) / SM_TS;
+  const bool wide = (long long)tm * ((N + 31) / 32) >= 192;
+  const int tiles = tm * (wide ? (N + 31) / 32 : (N + 15) / 16);
+#define GO(DT, TN)                                                                                                        \
+  do {                                                                                                                    \
+    constexpr int lds_bytes = SM_STAGES * (SM_TS + TN) * SM_BKE * 2;                                                      \
+    static bool attr_set = false;                                                                                         \
+    if (!attr_set) {                                                                                                      \
+      hipFuncSetAttribute((const void*)gemm_smallm_kernel<DT, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+      attr_set = true;                                                                                                    \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((gemm_smallm_kernel<DT, TN>), dim3(tiles), dim3(256), lds_bytes, stream, p);                       \
+  } while (0)
+  if (in_dtype == DLE_F16) { if (wide) GO(DLE_F16, 32); else GO(DLE_F16, 16); }
+  else { if (wide) GO(DLE_BF16, 32); else GO(DLE_BF16, 16); }
+#undef GO
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { dle_set_error("gemm_smallm launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
+  return 1;
+}

@@ -62,9 +62,13 @@ __global__ __launch_bounds__(T2_BLOCK) void t2_lstm_fwd_kernel(unsigned short* g
   }
 }
 
-// dh fp32 [B, H] (row stride ld_dh) = gradient wrt the (dropped) h; act = the saved activations; dgates may alias act.
+// dh fp32 [B, H] (row stride ld_dh) = gradient wrt the (dropped) h (+ dh1 + dh2 when given: the pieces that reach the hidden state
+// through different consumers -- projection, next step's gates, query -- are summed here, not by separate passes); act = the
+// saved activations; dgates may alias act.
 template <int DT>
 __global__ __launch_bounds__(T2_BLOCK) void t2_lstm_bwd_kernel(const float* __restrict__ dh, long long ld_dh,
+                                                               const float* __restrict__ dh1, long long ld_dh1,
+                                                               const float* __restrict__ dh2, long long ld_dh2,
                                                                const float* __restrict__ dc_next, const unsigned short* act,
                                                                long long ld_act, const float* __restrict__ c_prev,
                                                                unsigned short* dgates, long long ld_dg, float* __restrict__ dc_prev,
@@ -76,7 +80,9 @@ __global__ __launch_bounds__(T2_BLOCK) void t2_lstm_bwd_kernel(const float* __re
     const int b = (int)(idx / H), j = (int)(idx - (long long)b * H);
     const unsigned short* ar = act + b * ld_act + j;
     const float gi = t2_ld<DT>(ar), gf = t2_ld<DT>(ar + H), gg = t2_ld<DT>(ar + 2 * H), go = t2_ld<DT>(ar + 3 * H);
-    const float dh_in = dh[b * ld_dh + j];
+    float dh_in = dh[b * ld_dh + j];
+    if (dh1) dh_in += dh1[b * ld_dh1 + j];
+    if (dh2) dh_in += dh2[b * ld_dh2 + j];
     float g = dh_in;
     if (keep) {
       const long long e = keep_index + idx;
@@ -99,48 +105,78 @@ __global__ __launch_bounds__(T2_BLOCK) void t2_lstm_bwd_kernel(const float* __re
   }
 }
 
-// One workgroup per sample.  q fp32 [B, A]; pl [B*Ti, A] (processed memory + location term); v fp32 [A]; memory [B*Ti, E].
-// LDS: Ti floats (energies -> weights) + 16 (reductions).
+// ---- location-sensitive attention of one decoder step -------------------------------------------------------------------------
+// One workgroup of 8 wavefronts per sample (the softmax runs over the sample's text positions).  Round 2 ran 4 wavefronts with
+// 2-byte scalar loads and a serial per-channel context loop: 72 / 139 us per step for ~26 MB (0.4 TB/s), a third of the Tacotron2
+// iteration.  Here every global access is 16 bytes per lane: a row of A (or E) 16-bit values is covered by LP = pow2 >= A / 8 lanes,
+// a wavefront holds 64 / LP rows per pass, row sums are xor-shuffles inside the LP-lane group, per-channel sums stay in 8
+// registers per lane across the wavefront's rows and meet in LDS once.  Rows past the end are read at a clamped address with a
+// zero weight (unconditional loads: hipcc can then keep several in flight).
+#define T2A_BLOCK 512
+#define T2A_NW (T2A_BLOCK / 64)
+
+__device__ __forceinline__ void t2_ld8f(const float* p, float* v) {
+  const float4_t a = *(const float4_t*)p, b = *(const float4_t*)(p + 4);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { v[r] = a[r]; v[4 + r] = b[r]; }
+}
+
+// q fp32 [B, A]; pl [B*Ti, A] (processed memory + location term); v fp32 [A]; memory [B*Ti, E].
+// LDS: Ti floats (energies -> weights) + 16 (reductions) + T2A_NW x E (context partials).
 template <int DT>
-__global__ __launch_bounds__(T2_BLOCK) void t2_attention_fwd_kernel(const float* __restrict__ q, const unsigned short* __restrict__ pl,
-                                                                    const float* __restrict__ v, const unsigned short* __restrict__ memory,
-                                                                    const long long* __restrict__ lengths,
-                                                                    const unsigned short* __restrict__ awc_prev,
-                                                                    unsigned short* __restrict__ tanh_out, float* __restrict__ aw_out,
-                                                                    unsigned short* __restrict__ awc_next, unsigned short* d0, long long ld0,
-                                                                    unsigned short* d1, long long ld1, unsigned short* d2, long long ld2,
-                                                                    int Ti, int A, int E) {
+__global__ __launch_bounds__(T2A_BLOCK) void t2_attention_fwd_kernel(const float* __restrict__ q, const unsigned short* __restrict__ pl,
+                                                                     const float* __restrict__ v, const unsigned short* __restrict__ memory,
+                                                                     const long long* __restrict__ lengths,
+                                                                     const unsigned short* __restrict__ awc_prev,
+                                                                     unsigned short* __restrict__ tanh_out, float* __restrict__ aw_out,
+                                                                     unsigned short* __restrict__ awc_next, unsigned short* d0, long long ld0,
+                                                                     unsigned short* d1, long long ld1, unsigned short* d2, long long ld2,
+                                                                     int Ti, int A, int E, int lpa, int lpe) {
   extern __shared__ float sm[];
   float* en = sm;                 // [Ti]
   float* red = sm + Ti;           // [16]
+  float* part = red + 16;         // [T2A_NW][E]
   const int b = blockIdx.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int len = (int)lengths[b];
   if (len > Ti) len = Ti;
-  const float* qb = q + (long long)b * A;
-  for (int t = wave; t < Ti; t += nw) {
-    const long long row = (long long)b * Ti + t;
-    float acc = 0.f;
-    for (int a = lane; a < A; a += 64) {
-      const float th = tanhf(qb[a] + t2_ld<DT>(pl + row * A + a));
-      const unsigned short ts = Elem<DT>::from_f32(th);
-      tanh_out[row * A + a] = ts;
-      acc += v[a] * Elem<DT>::to_f32(ts);              // the saved (rounded) tanh is what the backward pass sees
+  {
+    const int sub = lane & (lpa - 1), rin = lane / lpa, rpp = 64 / lpa;
+    const bool act = sub * 8 < A;
+    const int col = act ? sub * 8 : 0;
+    float qv[8], vv[8];
+    t2_ld8f(q + (long long)b * A + col, qv);
+    t2_ld8f(v + col, vv);
+#pragma unroll 2
+    for (int t0 = wave * rpp; t0 < Ti; t0 += T2A_NW * rpp) {
+      const int t = t0 + rin, tc = t < Ti ? t : Ti - 1;
+      const long long row = (long long)b * Ti + tc;
+      float xf[8], th[8], tr[8];
+      unpack8<DT>(*(const ushort8_t*)(pl + row * A + col), xf);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) th[r] = fast_tanh(qv[r] + xf[r]);
+      const ushort8_t o = pack8<DT>(th);
+      if (t < Ti && act) *(ushort8_t*)(tanh_out + row * A + col) = o;
+      unpack8<DT>(o, tr);                                   // the saved (rounded) tanh is what the backward pass sees
+      float acc = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc += vv[r] * tr[r];
+      if (!act) acc = 0.f;
+      for (int s = lpa >> 1; s > 0; s >>= 1) acc += __shfl_xor(acc, s, 64);
+      if (t < Ti && sub == 0) en[t] = acc;
     }
-    acc = wave_sum(acc);
-    if (lane == 0) en[t] = acc;
   }
   __syncthreads();
   float mx = -3.0e38f;
-  for (int t = threadIdx.x; t < len; t += blockDim.x) mx = fmaxf(mx, en[t]);
+  for (int t = threadIdx.x; t < len; t += T2A_BLOCK) mx = fmaxf(mx, en[t]);
   mx = wave_max(mx);
   if (lane == 0) red[wave] = mx;
   __syncthreads();
   mx = red[0];
-  for (int i = 1; i < nw; ++i) mx = fmaxf(mx, red[i]);
+  for (int i = 1; i < T2A_NW; ++i) mx = fmaxf(mx, red[i]);
   __syncthreads();
   float s = 0.f;
-  for (int t = threadIdx.x; t < Ti; t += blockDim.x) {
+  for (int t = threadIdx.x; t < Ti; t += T2A_BLOCK) {
     const float e = t < len ? __expf(en[t] - mx) : 0.f;
     en[t] = e;
     s += e;
@@ -148,7 +184,7 @@ __global__ __launch_bounds__(T2_BLOCK) void t2_attention_fwd_kernel(const float*
   s = block_sum(s, red);
   const float inv = 1.0f / s;
   __syncthreads();
-  for (int t = threadIdx.x; t < Ti; t += blockDim.x) {
+  for (int t = threadIdx.x; t < Ti; t += T2A_BLOCK) {
     const float w = en[t] * inv;
     en[t] = w;
     const long long row = (long long)b * Ti + t;
@@ -160,69 +196,180 @@ __global__ __launch_bounds__(T2_BLOCK) void t2_attention_fwd_kernel(const float*
     *(ushort8_t*)(awc_next + row * 8) = o;
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < E; c += blockDim.x) {
+  {
+    const int sub = lane & (lpe - 1), rin = lane / lpe, rpp = 64 / lpe;
+    const bool act = sub * 8 < E;
+    const int col = act ? sub * 8 : 0;
+    const unsigned short* mb = memory + (long long)b * Ti * E + col;
+    float acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+#pragma unroll 4
+    for (int t0 = wave * rpp; t0 < len; t0 += T2A_NW * rpp) {
+      const int t = t0 + rin, tc = t < len ? t : (len > 0 ? len - 1 : 0);
+      const float w = t < len ? en[tc] : 0.f;
+      float xf[8];
+      unpack8<DT>(*(const ushort8_t*)(mb + (long long)tc * E), xf);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] += w * xf[r];
+    }
+    for (int o = 32; o >= lpe; o >>= 1) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] += __shfl_xor(acc[r], o, 64);
+    }
+    if (rin == 0 && act) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) part[wave * E + col + r] = acc[r];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < E; c += T2A_BLOCK) {
     float acc = 0.f;
-    const unsigned short* mb = memory + (long long)b * Ti * E + c;
-    for (int t = 0; t < len; ++t) acc += en[t] * t2_ld<DT>(mb + (long long)t * E);
+#pragma unroll
+    for (int w = 0; w < T2A_NW; ++w) acc += part[w * E + c];
     if (d0) t2_st<DT>(d0 + b * ld0 + c, acc);
     if (d1) t2_st<DT>(d1 + b * ld1 + c, acc);
     if (d2) t2_st<DT>(d2 + b * ld2 + c, acc);
   }
 }
 
-// One workgroup per sample.  LDS: Ti floats (d weights -> d energies) + A floats x waves (dq / dv partials) + 16.
+// Backward of the step above.  The gradient of the context arrives as the SUM of up to three fp32 row-strided pieces (projection
+// of this step, the decoder LSTM's gates of this step, the attention LSTM's gates of the next step) and the gradient of the
+// weights as the sum of two (through the location convolution's two input channels): summed on load, not by separate passes.
+// Writes d_pl (16-bit), dq (fp32 and / or 16-bit = the query GEMM's operand), the summed context gradient (16-bit, the operand of
+// the hoisted memory-gradient GEMM); accumulates d_pm (fp32) and the per-SAMPLE partials of dv (dv_acc [B, A]: one owner per row,
+// no atomics -- deterministic; the caller folds the B rows after the sweep).
+// LDS: Ti floats + 16 + T2A_NW x 2 x A.
 template <int DT>
-__global__ __launch_bounds__(T2_BLOCK) void t2_attention_bwd_kernel(const float* __restrict__ d_ctx, const float* __restrict__ d_aw_in,
-                                                                    const float* __restrict__ aw, const unsigned short* __restrict__ tanh_out,
-                                                                    const float* __restrict__ v, const unsigned short* __restrict__ memory,
-                                                                    float* __restrict__ d_memory, unsigned short* __restrict__ d_pl,
-                                                                    float* __restrict__ dq, float* __restrict__ dv_acc,
-                                                                    float* __restrict__ d_pm_acc, int Ti, int A, int E) {
+__global__ __launch_bounds__(T2A_BLOCK) void t2_attention_bwd_kernel(const float* __restrict__ dc0, long long ldc0,
+                                                                     const float* __restrict__ dc1, long long ldc1,
+                                                                     const float* __restrict__ dc2, long long ldc2,
+                                                                     const float* __restrict__ daw0, const float* __restrict__ daw1,
+                                                                     const float* __restrict__ aw, const unsigned short* __restrict__ tanh_out,
+                                                                     const float* __restrict__ v, const unsigned short* __restrict__ memory,
+                                                                     float* __restrict__ d_memory, unsigned short* __restrict__ d_pl,
+                                                                     float* __restrict__ dq, unsigned short* __restrict__ dq16,
+                                                                     unsigned short* __restrict__ dctx16, float* __restrict__ dv_acc,
+                                                                     float* __restrict__ d_pm_acc, int Ti, int A, int E, int lpa, int lpe) {
   extern __shared__ float sm[];
   float* de = sm;                           // [Ti]
   float* red = sm + Ti;                     // [16]
-  float* part = red + 16;                   // [2][nw][A]
+  float* part = red + 16;                   // [T2A_NW][2][A]
   const int b = blockIdx.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-  const float* dcb = d_ctx + (long long)b * E;
-  for (int t = wave; t < Ti; t += nw) {
-    const long long row = (long long)b * Ti + t;
-    const float w = aw[row];
-    float acc = 0.f;
-    for (int c = lane; c < E; c += 64) {
-      const float dc = dcb[c];
-      acc += t2_ld<DT>(memory + row * E + c) * dc;
-      if (d_memory) d_memory[row * E + c] += w * dc;        // NULL: the caller forms sum_t weights_t (x) d_ctx_t as one batched GEMM
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  {
+    const int sub = lane & (lpe - 1), rin = lane / lpe, rpp = 64 / lpe;
+    const bool act = sub * 8 < E;
+    const int col = act ? sub * 8 : 0;
+    float dcv[8];
+    t2_ld8f(dc0 + b * ldc0 + col, dcv);
+    if (dc1) { float t8[8]; t2_ld8f(dc1 + b * ldc1 + col, t8);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) dcv[r] += t8[r]; }
+    if (dc2) { float t8[8]; t2_ld8f(dc2 + b * ldc2 + col, t8);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) dcv[r] += t8[r]; }
+    if (dctx16 && wave == 0 && rin == 0 && act) *(ushort8_t*)(dctx16 + (long long)b * E + col) = pack8<DT>(dcv);
+    const unsigned short* mb = memory + (long long)b * Ti * E + col;
+#pragma unroll 4
+    for (int t0 = wave * rpp; t0 < Ti; t0 += T2A_NW * rpp) {
+      const int t = t0 + rin, tc = t < Ti ? t : Ti - 1;
+      const long long row = (long long)b * Ti + tc;
+      float xf[8];
+      unpack8<DT>(*(const ushort8_t*)(mb + (long long)tc * E), xf);
+      float acc = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc += xf[r] * dcv[r];
+      if (!act) acc = 0.f;
+      if (d_memory && t < Ti && act) {                     // NULL: the caller forms sum_t weights_t (x) d_ctx_t as one batched GEMM
+        const float w = aw[row];
+        float* dm = d_memory + row * E + col;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) dm[r] += w * dcv[r];
+      }
+      for (int s = lpe >> 1; s > 0; s >>= 1) acc += __shfl_xor(acc, s, 64);
+      if (t < Ti && sub == 0) de[t] = acc + daw0[row] + (daw1 ? daw1[row] : 0.f);
     }
-    acc = wave_sum(acc);
-    if (lane == 0) de[t] = acc + d_aw_in[row];
   }
   __syncthreads();
   float s = 0.f;
-  for (int t = threadIdx.x; t < Ti; t += blockDim.x) s += aw[(long long)b * Ti + t] * de[t];
+  for (int t = threadIdx.x; t < Ti; t += T2A_BLOCK) s += aw[(long long)b * Ti + t] * de[t];
   s = block_sum(s, red);
   __syncthreads();
-  for (int t = threadIdx.x; t < Ti; t += blockDim.x) de[t] = aw[(long long)b * Ti + t] * (de[t] - s);
+  for (int t = threadIdx.x; t < Ti; t += T2A_BLOCK) de[t] = aw[(long long)b * Ti + t] * (de[t] - s);
   __syncthreads();
-  for (int a = lane; a < A; a += 64) { part[wave * A + a] = 0.f; part[(nw + wave) * A + a] = 0.f; }
-  for (int t = wave; t < Ti; t += nw) {
-    const long long row = (long long)b * Ti + t;
-    const float e = de[t];
-    for (int a = lane; a < A; a += 64) {
-      const float th = t2_ld<DT>(tanh_out + row * A + a);
-      const float dpre = e * v[a] * (1.f - th * th);
-      d_pl[row * A + a] = Elem<DT>::from_f32(dpre);
-      d_pm_acc[row * A + a] += dpre;
-      part[wave * A + a] += dpre;
-      part[(nw + wave) * A + a] += e * th;
+  {
+    const int sub = lane & (lpa - 1), rin = lane / lpa, rpp = 64 / lpa;
+    const bool act = sub * 8 < A;
+    const int col = act ? sub * 8 : 0;
+    float vv[8], accq[8], accv[8];
+    t2_ld8f(v + col, vv);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { accq[r] = 0.f; accv[r] = 0.f; }
+#pragma unroll 2
+    for (int t0 = wave * rpp; t0 < Ti; t0 += T2A_NW * rpp) {
+      const int t = t0 + rin, tc = t < Ti ? t : Ti - 1;
+      const long long row = (long long)b * Ti + tc;
+      const float e = t < Ti ? de[tc] : 0.f;
+      float th[8], dpre[8];
+      unpack8<DT>(*(const ushort8_t*)(tanh_out + row * A + col), th);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        dpre[r] = e * vv[r] * (1.f - th[r] * th[r]);
+        accq[r] += dpre[r];
+        accv[r] += e * th[r];
+      }
+      if (t < Ti && act) {
+        *(ushort8_t*)(d_pl + row * A + col) = pack8<DT>(dpre);
+        float* pm = d_pm_acc + row * A + col;
+        float4_t p0 = *(float4_t*)pm, p1 = *(float4_t*)(pm + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { p0[r] += dpre[r]; p1[r] += dpre[4 + r]; }
+        *(float4_t*)pm = p0;
+        *(float4_t*)(pm + 4) = p1;
+      }
+    }
+    for (int o = 32; o >= lpa; o >>= 1) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { accq[r] += __shfl_xor(accq[r], o, 64); accv[r] += __shfl_xor(accv[r], o, 64); }
+    }
+    if (rin == 0 && act) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { part[(wave * 2) * A + col + r] = accq[r]; part[(wave * 2 + 1) * A + col + r] = accv[r]; }
     }
   }
   __syncthreads();
-  for (int a = threadIdx.x; a < A; a += blockDim.x) {
+  for (int a = threadIdx.x; a < A; a += T2A_BLOCK) {
     float sq = 0.f, sv = 0.f;
-    for (int w = 0; w < nw; ++w) { sq += part[w * A + a]; sv += part[(nw + w) * A + a]; }
-    dq[(long long)b * A + a] = sq;
-    atomicAdd(dv_acc + a, sv);
+#pragma unroll
+    for (int w = 0; w < T2A_NW; ++w) { sq += part[(w * 2) * A + a]; sv += part[(w * 2 + 1) * A + a]; }
+    if (dq) dq[(long long)b * A + a] = sq;
+    if (dq16) dq16[(long long)b * A + a] = Elem<DT>::from_f32(sq);
+    dv_acc[(long long)b * A + a] += sv;
+  }
+}
+
+// Transpose of the 2-channel location convolution's row gather (model.py:40-76 backward): dcol [B*Ti, KL*8] 16-bit = gradient of
+// the gathered rows col[(b, t), j*8 + c] = awc[b, t + j - KL/2, c].  Channel 0 (the previous step's weights) -> d_prev (written),
+// channel 1 (the cumulative weights) -> d_cum (accumulated: cumulative_t feeds every later step).  fp32 [B, Ti] both.
+template <int DT>
+__global__ __launch_bounds__(T2_BLOCK) void t2_location_bwd_kernel(const unsigned short* __restrict__ dcol, float* __restrict__ d_prev,
+                                                                   float* __restrict__ d_cum, int B, int Ti, int KL) {
+  const long long total = (long long)B * Ti;
+  const int pad = KL / 2, ld = KL * 8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int s = (int)(i % Ti);
+    const long long b = i / Ti;
+    float a0 = 0.f, a1 = 0.f;
+    for (int j = 0; j < KL; ++j) {
+      const int t = s - j + pad;
+      if (t < 0 || t >= Ti) continue;
+      const unsigned int x = *(const unsigned int*)(dcol + (b * Ti + t) * ld + j * 8);
+      a0 += Elem<DT>::to_f32((unsigned short)(x & 0xffffu));
+      a1 += Elem<DT>::to_f32((unsigned short)(x >> 16));
+    }
+    d_prev[i] = a0;
+    d_cum[i] += a1;
   }
 }
 
@@ -297,17 +444,21 @@ extern "C" int dle_t2_lstm_fwd(void* gates, int64_t ld_g, const float* c_prev, f
   return 0;
 }
 
-extern "C" int dle_t2_lstm_bwd(const float* dh, int64_t ld_dh, const float* dc_next, const void* act, int64_t ld_act,
+extern "C" int dle_t2_lstm_bwd(const float* dh, int64_t ld_dh, const float* dh1, int64_t ld_dh1, const float* dh2, int64_t ld_dh2,
+                               const float* dc_next, const void* act, int64_t ld_act,
                                const float* c_prev, void* dgates, int64_t ld_dg, float* dc_prev, const void* keep, int64_t keep_index,
                                float inv_keep, const float* live, float* dh_prev, int B, int H, int dtype, hipStream_t stream) {
   DLE_CHECK_ARG(dh && dc_next && act && c_prev && dgates && dc_prev && B > 0 && H > 0, "t2_lstm_bwd: bad args");
   DLE_CHECK_ARG(!live || dh_prev, "t2_lstm_bwd: live rows need dh_prev");
   T2_DT_CHECK("t2_lstm_bwd");
-  T2_GO(t2_lstm_bwd_kernel, t2_grid((long long)B * H), 0, dh, (long long)ld_dh, dc_next, (const unsigned short*)act, (long long)ld_act,
+  T2_GO(t2_lstm_bwd_kernel, t2_grid((long long)B * H), 0, dh, (long long)ld_dh, dh1, (long long)ld_dh1, dh2, (long long)ld_dh2, dc_next,
+        (const unsigned short*)act, (long long)ld_act,
         c_prev, (unsigned short*)dgates, (long long)ld_dg, dc_prev, (const unsigned char*)keep, (long long)keep_index, inv_keep, live,
         dh_prev, B, H);
   return 0;
 }
+
+static int t2_pow2_ge(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
 extern "C" int dle_t2_attention_fwd(const float* q, const void* pl, const float* v, const void* memory, const int64_t* lengths,
                                     const void* awc_prev, void* tanh_out, float* aw_out, void* awc_next, void* d0, int64_t ld0,
@@ -316,24 +467,61 @@ extern "C" int dle_t2_attention_fwd(const float* q, const void* pl, const float*
   DLE_CHECK_ARG(q && pl && v && memory && lengths && tanh_out && aw_out && awc_next && B > 0 && Ti > 0 && A > 0 && E > 0,
                 "t2_attention_fwd: bad args");
   DLE_CHECK_ARG(Ti <= 8192 && ((((uintptr_t)awc_next) | ((uintptr_t)awc_prev)) & 15) == 0, "t2_attention_fwd: Ti <= 8192, aligned weights rows");
+  DLE_CHECK_ARG(A % 8 == 0 && E % 8 == 0 && A <= 512 && E <= 512, "t2_attention_fwd: A, E multiples of 8, at most 512 (got %d, %d)", A, E);
+  DLE_CHECK_ARG(((((uintptr_t)q) | ((uintptr_t)pl) | ((uintptr_t)v) | ((uintptr_t)memory) | ((uintptr_t)tanh_out)) & 15) == 0,
+                "t2_attention_fwd: 16-byte aligned tensors");
   T2_DT_CHECK("t2_attention_fwd");
-  const size_t lds = (size_t)(Ti + 16) * 4;
-  T2_GO(t2_attention_fwd_kernel, B, lds, q, (const unsigned short*)pl, v, (const unsigned short*)memory, (const long long*)lengths,
-        (const unsigned short*)awc_prev, (unsigned short*)tanh_out, aw_out, (unsigned short*)awc_next, (unsigned short*)d0,
-        (long long)ld0, (unsigned short*)d1, (long long)ld1, (unsigned short*)d2, (long long)ld2, Ti, A, E);
+  const size_t lds = ((size_t)Ti + 16 + (size_t)T2A_NW * E) * 4;
+  DLE_CHECK_ARG(lds <= 64000, "t2_attention_fwd: Ti too large for one workgroup's LDS");
+  const int lpa = t2_pow2_ge(A / 8), lpe = t2_pow2_ge(E / 8);
+  if (dtype == DLE_F16)
+    hipLaunchKernelGGL(t2_attention_fwd_kernel<DLE_F16>, dim3(B), dim3(T2A_BLOCK), lds, stream, q, (const unsigned short*)pl, v,
+                       (const unsigned short*)memory, (const long long*)lengths, (const unsigned short*)awc_prev,
+                       (unsigned short*)tanh_out, aw_out, (unsigned short*)awc_next, (unsigned short*)d0, (long long)ld0,
+                       (unsigned short*)d1, (long long)ld1, (unsigned short*)d2, (long long)ld2, Ti, A, E, lpa, lpe);
+  else
+    hipLaunchKernelGGL(t2_attention_fwd_kernel<DLE_BF16>, dim3(B), dim3(T2A_BLOCK), lds, stream, q, (const unsigned short*)pl, v,
+                       (const unsigned short*)memory, (const long long*)lengths, (const unsigned short*)awc_prev,
+                       (unsigned short*)tanh_out, aw_out, (unsigned short*)awc_next, (unsigned short*)d0, (long long)ld0,
+                       (unsigned short*)d1, (long long)ld1, (unsigned short*)d2, (long long)ld2, Ti, A, E, lpa, lpe);
+  DLE_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int dle_t2_attention_bwd(const float* d_ctx, const float* d_aw_in, const float* aw, const void* tanh_out, const float* v,
-                                    const void* memory, float* d_memory, void* d_pl, float* dq, float* dv_acc, float* d_pm_acc,
-                                    int B, int Ti, int A, int E, int dtype, hipStream_t stream) {
-  DLE_CHECK_ARG(d_ctx && d_aw_in && aw && tanh_out && v && memory && d_pl && dq && dv_acc && d_pm_acc && B > 0 && Ti > 0 &&
+extern "C" int dle_t2_attention_bwd(const float* d_ctx0, int64_t ld_c0, const float* d_ctx1, int64_t ld_c1, const float* d_ctx2,
+                                    int64_t ld_c2, const float* d_aw0, const float* d_aw1, const float* aw, const void* tanh_out,
+                                    const float* v, const void* memory, float* d_memory, void* d_pl, float* dq, void* dq16,
+                                    void* dctx16, float* dv_acc, float* d_pm_acc, int B, int Ti, int A, int E, int dtype,
+                                    hipStream_t stream) {
+  DLE_CHECK_ARG(d_ctx0 && d_aw0 && aw && tanh_out && v && memory && d_pl && (dq || dq16) && dv_acc && d_pm_acc && B > 0 && Ti > 0 &&
                 A > 0 && E > 0, "t2_attention_bwd: bad args");
-  const size_t lds = ((size_t)Ti + 16 + 2 * (T2_BLOCK / 64) * (size_t)A) * 4;
-  DLE_CHECK_ARG(lds <= 60000, "t2_attention_bwd: Ti / attention_dim too large for one workgroup's LDS");
+  DLE_CHECK_ARG(A % 8 == 0 && E % 8 == 0 && A <= 512 && E <= 512, "t2_attention_bwd: A, E multiples of 8, at most 512 (got %d, %d)", A, E);
+  DLE_CHECK_ARG((ld_c0 & 3) == 0 && (!d_ctx1 || (ld_c1 & 3) == 0) && (!d_ctx2 || (ld_c2 & 3) == 0) &&
+                ((((uintptr_t)d_ctx0) | ((uintptr_t)d_ctx1) | ((uintptr_t)d_ctx2) | ((uintptr_t)tanh_out) | ((uintptr_t)memory) |
+                  ((uintptr_t)d_pl) | ((uintptr_t)d_pm_acc) | ((uintptr_t)v) | ((uintptr_t)dctx16)) & 15) == 0,
+                "t2_attention_bwd: 16-byte aligned tensors, row strides of the context gradients multiples of 4");
+  const size_t lds = ((size_t)Ti + 16 + 2 * T2A_NW * (size_t)A) * 4;
+  DLE_CHECK_ARG(lds <= 64000, "t2_attention_bwd: Ti / attention_dim too large for one workgroup's LDS");
   T2_DT_CHECK("t2_attention_bwd");
-  T2_GO(t2_attention_bwd_kernel, B, lds, d_ctx, d_aw_in, aw, (const unsigned short*)tanh_out, v, (const unsigned short*)memory,
-        d_memory, (unsigned short*)d_pl, dq, dv_acc, d_pm_acc, Ti, A, E);
+  const int lpa = t2_pow2_ge(A / 8), lpe = t2_pow2_ge(E / 8);
+  if (dtype == DLE_F16)
+    hipLaunchKernelGGL(t2_attention_bwd_kernel<DLE_F16>, dim3(B), dim3(T2A_BLOCK), lds, stream, d_ctx0, (long long)ld_c0, d_ctx1,
+                       (long long)ld_c1, d_ctx2, (long long)ld_c2, d_aw0, d_aw1, aw, (const unsigned short*)tanh_out, v,
+                       (const unsigned short*)memory, d_memory, (unsigned short*)d_pl, dq, (unsigned short*)dq16,
+                       (unsigned short*)dctx16, dv_acc, d_pm_acc, Ti, A, E, lpa, lpe);
+  else
+    hipLaunchKernelGGL(t2_attention_bwd_kernel<DLE_BF16>, dim3(B), dim3(T2A_BLOCK), lds, stream, d_ctx0, (long long)ld_c0, d_ctx1,
+                       (long long)ld_c1, d_ctx2, (long long)ld_c2, d_aw0, d_aw1, aw, (const unsigned short*)tanh_out, v,
+                       (const unsigned short*)memory, d_memory, (unsigned short*)d_pl, dq, (unsigned short*)dq16,
+                       (unsigned short*)dctx16, dv_acc, d_pm_acc, Ti, A, E, lpa, lpe);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dle_t2_location_bwd(const void* dcol, float* d_prev, float* d_cum, int B, int Ti, int KL, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dcol && d_prev && d_cum && B > 0 && Ti > 0 && KL > 0 && (((uintptr_t)dcol) & 3) == 0, "t2_location_bwd: bad args");
+  T2_DT_CHECK("t2_location_bwd");
+  T2_GO(t2_location_bwd_kernel, t2_grid((long long)B * Ti), 0, (const unsigned short*)dcol, d_prev, d_cum, B, Ti, KL);
   return 0;
 }
 

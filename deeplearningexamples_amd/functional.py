@@ -181,6 +181,20 @@ def cast_rows(x, out_dtype, cols_out=None, out=None):
     return out
 
 
+def transpose_cast(x, out_dtype, out=None):
+    """out[c, r] = (out_dtype) x[r, c] for a 2-D fp32 / 16-bit matrix with unit inner stride: the transposed 16-bit working copy."""
+    C.require_cuda(x, out)
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("transpose_cast: 2-D input with unit inner stride")
+    r, c = x.shape
+    if out is None:
+        out = torch.empty((c, r), dtype=out_dtype, device=x.device)
+    if out.shape != (c, r) or out.stride(1) != 1 or out.dtype != out_dtype:
+        raise ValueError("transpose_cast: output must be [cols, rows] of the requested dtype")
+    C.call("dle_transpose_cast", C.ptr(x), C.ptr(out), r, c, x.stride(0), out.stride(0), C.dt(x), C.dt(out), C.stream())
+    return out
+
+
 def cast(x, out_dtype, out=None):
     """Flat dtype cast of a contiguous tensor."""
     C.require_cuda(x, out)

@@ -133,6 +133,14 @@ class Tacotron2Trainer:
         w["proj_b"][NM:NM + 1].copy_(p["decoder.gate_layer.linear_layer.bias"])
         for i in range(self.cfg["postnet_n_convolutions"]):
             w["post%d" % i] = self._conv_w("postnet.convolutions.%d.0.conv.weight" % i)
+        # the recurrent cells' data gradients contract over the GATE dimension: transposed copies keep both operands of those
+        # few-row products k-contiguous (csrc/gemm_smallm.hip streams [N, K] weight rows)
+        w["a_catT"] = F.transpose_cast(w["a_cat"], dt)                                # [E + Ha, 4 Ha]
+        w["d_catT"] = F.transpose_cast(w["d_cat"], dt)                                # [Ha + E + Hd, 4 Hd]
+        w["qT"] = F.transpose_cast(w["q"], dt)                                        # [Ha, A]
+        w["locT"] = F.transpose_cast(w["loc"], dt)                                    # [KL * 8, A]
+        for sfx in ("", "_reverse"):
+            w["ehhT" + sfx] = F.transpose_cast(w["ehh" + sfx], dt)                    # [h, 4 h]
         self.w = w
 
     def _conv_bn(self, x, b, t, name, w16, act, p_drop):
@@ -182,16 +190,17 @@ class Tacotron2Trainer:
             gates = self._e(b, ti, 4 * h)                                # replaced by the gate activations step by step
             hprev = self._z(b, ti, h)                                    # the state each step started from (rows (b, t))
             c_all = self._z(ti + 1, b, h, dtype=torch.float32)          # cell state BEFORE the step processed k-th
-            hstate = self._z(b, h)
-            order = range(ti - 1, -1, -1) if d else range(ti)
+            order = list(range(ti - 1, -1, -1) if d else range(ti))
+            # the state a step starts from IS the row block hprev[:, t] (kept for the weight gradient): the cell writes the next
+            # step's block directly -- no copy, no per-step allocation
+            hlast = self._z(b, h)
             for k, t in enumerate(order):
-                F.copy_rows(hstate, hprev[:, t])
+                hstate = hprev[:, t]
+                hnext = hprev[:, order[k + 1]] if k + 1 < ti else hlast
                 F.gemm(hstate, w["ehh" + sfx], b, 4 * h, h, True, True, out=gates[:, t], act=C.ACT_ADD, mask_src=gx[:, t])
-                hnew = self._e(b, h)
-                ops.lstm_fwd(gates[:, t], c_all[k], c_all[k + 1], [hnew], live=live_all[t], h_prev=hstate,
+                ops.lstm_fwd(gates[:, t], c_all[k], c_all[k + 1], [hnext], live=live_all[t], h_prev=hstate,
                              out_dst=mem3[:, t, d * h:(d + 1) * h])
-                hstate = hnew
-            sv["lstm"][sfx] = dict(gates=gates, hprev=hprev, c_all=c_all, order=list(order))
+            sv["lstm"][sfx] = dict(gates=gates, hprev=hprev, c_all=c_all, order=order)
         sv["memory"] = memory
         pm = F.gemm(memory, w["mem"], b * ti, A, E, True, True)          # processed memory
         sv["pm"] = pm
@@ -219,12 +228,14 @@ class Tacotron2Trainer:
         aw = self._e(to, b, ti, dtype=torch.float32)
         tanh_all = self._e(to, b * ti, A)
         q_all = self._e(to, b, A, dtype=torch.float32)
+        col = self._e(b * ti, self.KL * 8)
+        pl = self._e(b * ti, A)
         for t in range(to):
             F.gemm(x_a[t], w["a_cat"], b, 4 * Ha, E + Ha, True, True, out=ga[t], act=C.ACT_ADD, mask_src=g_pre[t])
             ops.lstm_fwd(ga[t], ac[t], ac[t + 1], [x_d[t][:, :Ha], x_a[t + 1][:, E:]], keep=keep_a, keep_index=t * b * Ha, p=pa)
             F.gemm(x_d[t][:, :Ha], w["q"], b, A, Ha, True, True, out=q_all[t])
-            col = wops.taps(awc[t], b, ti, self.KL, 1, self.KL // 2)
-            pl = F.gemm(col, w["loc"], b * ti, A, self.KL * 8, True, True, act=C.ACT_ADD, mask_src=pm)
+            wops.taps(awc[t], b, ti, self.KL, 1, self.KL // 2, out=col)
+            F.gemm(col, w["loc"], b * ti, A, self.KL * 8, True, True, act=C.ACT_ADD, mask_src=pm, out=pl)
             ops.attention_fwd(q_all[t], pl, w["v"], memory, text_lengths, awc[t], tanh_all[t], aw[t], awc[t + 1],
                               [x_d[t][:, Ha:Ha + E], x_a[t + 1][:, :E], hc[:, t, Hd:]])
             F.gemm(x_d[t], w["d_cat"], b, 4 * Hd, Ha + E + Hd, True, True, out=gd[t], bias=w["d_b"])
@@ -316,52 +327,53 @@ class Tacotron2Trainer:
         to8 = (to + 7) // 8 * 8
         dctx_all = self._z(to8, b, E) if hoist else None
         d_pm = self._z(b * ti, A, dtype=f32)
-        dv = self._z(A, dtype=f32)
+        dv_acc = self._z(b, A, dtype=f32)                                # per-sample partial sums of dv (no atomics)
         dw_loc = self._z(A, self.KL * 8, dtype=f32)
         dq_all = self._e(to, b, A)
-        d_ah_rec = self._z(b, Ha, dtype=f32)                            # gradient wrt attention_hidden_t from step t+1's gates
-        d_ctx_rec = self._z(b, E, dtype=f32)                             # gradient wrt context_t from step t+1's gates
-        d_dh_rec = self._z(b, Hd, dtype=f32)
-        d_ac = self._z(b, Ha, dtype=f32)
-        d_dc = self._z(b, Hd, dtype=f32)
+        # Per-step scratch, allocated ONCE: every sum of gradient pieces (autograd's accumulation into a tensor that feeds several
+        # consumers) happens on load inside the kernel that consumes it -- the sweep holds no ATen arithmetic and no allocation.
+        #   dxd = gradient wrt x_d[t] = [attention_hidden_t | context_t | decoder_hidden_{t-1}]  (decoder LSTM's gates, step t)
+        #   dxa = gradient wrt x_a[t] = [context_{t-1} | attention_hidden_{t-1}]                  (attention LSTM's gates, step t)
+        # both zero before the first (= last in time) step: nothing follows it
+        dxd = self._z(b, Ha + E + Hd, dtype=f32)
+        dxa = self._z(b, E + Ha, dtype=f32)
+        d_ah_q = self._e(b, Ha, dtype=f32)                               # through the query layer
+        d_dc = [self._z(b, Hd, dtype=f32), self._e(b, Hd, dtype=f32)]
+        d_ac = [self._z(b, Ha, dtype=f32), self._e(b, Ha, dtype=f32)]
         d_aw_loc = self._z(b, ti, dtype=f32)                             # wrt weights_t as "previous weights" of step t+1
         d_cum = self._z(b, ti, dtype=f32)                                # wrt cumulative weights_t (all later steps)
+        dcol = self._e(b * ti, self.KL * 8)
+        # the location layer's weight gradient contracts over (step, sample, position): d_pl is kept for CH steps at a time and
+        # meets the gathered rows of the same steps in ONE split-K product per chunk
+        ch_steps = max(1, min(to, 64))
+        d_pl_ch = self._e(ch_steps, b * ti, A)
+        pa, pd = cfg["p_attention_dropout"], cfg["p_decoder_dropout"]
         for t in range(to - 1, -1, -1):
-            # decoder LSTM
-            dh = dhc[:, t, :Hd] + d_dh_rec
-            d_dc_prev = torch.empty_like(d_dc)
-            ops.lstm_bwd(dh, d_dc, gd[t], dc[t], gd[t], d_dc_prev, keep=sv["keep_d"], keep_index=t * b * Hd, p=cfg["p_decoder_dropout"])
-            d_dc = d_dc_prev
-            dxd = F.gemm(gd[t], w["d_cat"], b, Ha + E + Hd, 4 * Hd, True, False, out_dtype=f32)
-            d_dh_rec = dxd[:, Ha + E:]
-            # attention
-            d_ctx = dhc[:, t, Hd:] + dxd[:, Ha:Ha + E] + d_ctx_rec
-            d_cum_t = d_cum                                              # cumulative_t = cumulative_{t-1} + weights_t
-            d_pl = self._e(b * ti, A)
-            dq = self._e(b, A, dtype=f32)
-            d_ctx = d_ctx.contiguous()
-            ops.attention_bwd(d_ctx, (d_aw_loc + d_cum_t).contiguous(), aw[t], sv["tanh_all"][t], w["v"], memory,
-                              None if hoist else d_memory, d_pl, dq, dv, d_pm)
-            if hoist:
-                dctx_all[t].copy_(d_ctx)
-            dq_all[t].copy_(dq)
-            # location term: pl = taps(awc[t]) x W_loc^T + pm
-            col = wops.taps(awc[t], b, ti, self.KL, 1, self.KL // 2)
-            F.gemm(d_pl, col, A, self.KL * 8, b * ti, False, False, out=dw_loc, accumulate=True,
-                   splitk=F.pick_splitk(A, self.KL * 8, b * ti))              # K = B * Ti rows over the chip, slabs summed onto dw_loc
-            dcol = F.gemm(d_pl, w["loc"], b * ti, self.KL * 8, A, True, False)
-            d_awc = self._e(b * ti, 8)
-            wops.taps_bwd(dcol, b, ti, 8, self.KL, 1, self.KL // 2, out=d_awc)
-            d_awc3 = d_awc.view(b, ti, 8).float()
-            d_aw_loc = d_awc3[:, :, 0].contiguous()                      # awc[t] = (weights_{t-1}, cumulative_{t-1})
-            d_cum = d_cum + d_awc3[:, :, 1]
-            # attention LSTM
-            d_ah = dxd[:, :Ha] + d_ah_rec + F.gemm(dq_all[t], w["q"], b, Ha, A, True, False, out_dtype=f32)
-            d_ac_prev = torch.empty_like(d_ac)
-            ops.lstm_bwd(d_ah, d_ac, ga[t], ac[t], ga[t], d_ac_prev, keep=sv["keep_a"], keep_index=t * b * Ha, p=cfg["p_attention_dropout"])
-            d_ac = d_ac_prev
-            dxa = F.gemm(ga[t], w["a_cat"], b, E + Ha, 4 * Ha, True, False, out_dtype=f32)
-            d_ctx_rec, d_ah_rec = dxa[:, :E], dxa[:, E:]
+            cur, nxt = (to - 1 - t) & 1, ((to - 1 - t) & 1) ^ 1
+            # decoder LSTM: dh = projection piece + the piece through step t+1's gates
+            ops.lstm_bwd(dhc[:, t, :Hd], d_dc[cur], gd[t], dc[t], gd[t], d_dc[nxt], keep=sv["keep_d"], keep_index=t * b * Hd, p=pd,
+                         dh_add=(dxd[:, Ha + E:],))
+            F.gemm(gd[t], w["d_catT"], b, Ha + E + Hd, 4 * Hd, True, True, out=dxd)
+            # attention: d context_t = projection piece + decoder gates (step t) + attention gates (step t+1)
+            slot = t % ch_steps
+            ops.attention_bwd(dhc[:, t, Hd:], d_aw_loc, aw[t], sv["tanh_all"][t], w["v"], memory, None if hoist else d_memory,
+                              d_pl_ch[slot], None, dv_acc, d_pm, d_ctx_add=(dxd[:, Ha:Ha + E], dxa[:, :E]), d_aw_add=d_cum,
+                              dq16=dq_all[t], dctx16=dctx_all[t] if hoist else None)
+            # location term: pl = taps(awc[t]) x W_loc^T + pm; awc[t] = (weights_{t-1}, cumulative_{t-1})
+            F.gemm(d_pl_ch[slot], w["locT"], b * ti, self.KL * 8, A, True, True, out=dcol)
+            ops.location_bwd(dcol, d_aw_loc, d_cum, b, ti, self.KL)
+            if slot == 0:
+                n = min(ch_steps, to - t)
+                cols = wops.taps(awc[t:t + n].view(-1, 8), n * b, ti, self.KL, 1, self.KL // 2)
+                rows = n * b * ti
+                F.gemm(d_pl_ch[:n].view(rows, A), cols, A, self.KL * 8, rows, False, False, out=dw_loc, accumulate=True,
+                       splitk=F.pick_splitk(A, self.KL * 8, rows))
+                del cols
+            # attention LSTM: d attention_hidden_t = decoder gates (step t) + query layer + attention gates (step t+1)
+            F.gemm(dq_all[t], w["qT"], b, Ha, A, True, True, out=d_ah_q)
+            ops.lstm_bwd(dxd[:, :Ha], d_ac[cur], ga[t], ac[t], ga[t], d_ac[nxt], keep=sv["keep_a"], keep_index=t * b * Ha, p=pa,
+                         dh_add=(d_ah_q, dxa[:, E:]))
+            F.gemm(ga[t], w["a_catT"], b, E + Ha, 4 * Ha, True, True, out=dxa)
         # ---- weight gradients of the decoder: one GEMM each over all steps
         rt = to * b
         ga2, gd2 = ga.view(rt, 4 * Ha), gd.view(rt, 4 * Hd)
@@ -383,7 +395,7 @@ class Tacotron2Trainer:
         g["decoder.decoder_rnn.bias_hh"].copy_(g["decoder.decoder_rnn.bias_ih"])
         att = "decoder.attention_layer."
         self._wgrad(dq_all.view(rt, A), x_d.view(-1, Ha + E + Hd)[:, :Ha], g[att + "query_layer.linear_layer.weight"], rt)
-        g[att + "v.linear_layer.weight"].view(-1).copy_(dv)
+        F.colsum(dv_acc, out=g[att + "v.linear_layer.weight"].view(-1))
         dwl16 = self._cast(dw_loc)
         F.gemm(dwl16, w["loc_c"], A, self.NF, self.KL * 8, True, True, out=g[att + "location_layer.location_dense.linear_layer.weight"])
         dwc = torch.empty((self.NF, self.KL * 8), dtype=f32, device=self.dev)
@@ -415,17 +427,14 @@ class Tacotron2Trainer:
         for d, sfx in enumerate(("", "_reverse")):
             s = sv["lstm"][sfx]
             gates, hprev, c_all, order = s["gates"], s["hprev"], s["c_all"], s["order"]
-            dh_rec = self._z(b, h, dtype=f32)
-            d_c = self._z(b, h, dtype=f32)
+            dh_rec = [self._z(b, h, dtype=f32), self._e(b, h, dtype=f32)]
+            d_c = [self._z(b, h, dtype=f32), self._e(b, h, dtype=f32)]
             for k in range(ti - 1, -1, -1):
                 t = order[k]
-                dh = dm3[:, t, d * h:(d + 1) * h] + dh_rec
-                dh_prev = torch.empty_like(dh_rec)
-                d_c_prev = torch.empty_like(d_c)
-                ops.lstm_bwd(dh, d_c, gates[:, t], c_all[k], gates[:, t], d_c_prev, live=sv["live"][t], dh_prev=dh_prev)
-                d_c = d_c_prev
-                F.gemm(gates[:, t], w["ehh" + sfx], b, h, 4 * h, True, False, out=dh_prev, accumulate=True)
-                dh_rec = dh_prev
+                cur, nxt = (ti - 1 - k) & 1, ((ti - 1 - k) & 1) ^ 1
+                ops.lstm_bwd(dm3[:, t, d * h:(d + 1) * h], d_c[cur], gates[:, t], c_all[k], gates[:, t], d_c[nxt], live=sv["live"][t],
+                             dh_prev=dh_rec[nxt], dh_add=(dh_rec[cur],))
+                F.gemm(gates[:, t], w["ehhT" + sfx], b, h, 4 * h, True, True, out=dh_rec[nxt], accumulate=True)
             g2 = gates.view(b * ti, 4 * h)
             self._wgrad(g2, x_enc, g["encoder.lstm.weight_ih_l0" + sfx], b * ti)
             self._wgrad(g2, hprev.view(b * ti, h), g["encoder.lstm.weight_hh_l0" + sfx], b * ti)

@@ -45,10 +45,15 @@ def lstm_fwd(gates, c_prev, c_out, h_dsts, keep=None, keep_index=0, p=0.0, live=
            _ld(out_dst, "out_dst") if out_dst is not None else 0, b, hh, C.dt(gates), C.stream())
 
 
-def lstm_bwd(dh, dc_next, act, c_prev, dgates, dc_prev, keep=None, keep_index=0, p=0.0, live=None, dh_prev=None):
-    C.require_cuda(dh, dc_next, act, c_prev, dgates, dc_prev, keep, live, dh_prev)
+def lstm_bwd(dh, dc_next, act, c_prev, dgates, dc_prev, keep=None, keep_index=0, p=0.0, live=None, dh_prev=None, dh_add=()):
+    """dh_add: up to two more fp32 [B, H] row-strided pieces of the hidden state's gradient, summed on load."""
+    C.require_cuda(dh, dc_next, act, c_prev, dgates, dc_prev, keep, live, dh_prev, *dh_add)
     b, hh = dh.shape
-    C.call("dle_t2_lstm_bwd", C.ptr(dh), _ld(dh, "dh"), C.ptr(dc_next), C.ptr(act), _ld(act, "act"), C.ptr(c_prev), C.ptr(dgates),
+    if len(dh_add) > 2:
+        raise ValueError("lstm_bwd: at most two extra gradient pieces")
+    x = list(dh_add) + [None] * (2 - len(dh_add))
+    C.call("dle_t2_lstm_bwd", C.ptr(dh), _ld(dh, "dh"), C.ptr(x[0]), _ld(x[0], "dh") if x[0] is not None else 0, C.ptr(x[1]),
+           _ld(x[1], "dh") if x[1] is not None else 0, C.ptr(dc_next), C.ptr(act), _ld(act, "act"), C.ptr(c_prev), C.ptr(dgates),
            _ld(dgates, "dgates"), C.ptr(dc_prev), C.ptr(keep), int(keep_index), float(inv_keep(p) if keep is not None else 1.0),
            C.ptr(live), C.ptr(dh_prev), b, hh, C.dt(act), C.stream())
 
@@ -67,12 +72,33 @@ def attention_fwd(q, pl, v, memory, lengths, awc_prev, tanh_out, aw_out, awc_nex
            C.dt(pl), C.stream())
 
 
-def attention_bwd(d_ctx, d_aw_in, aw, tanh_out, v, memory, d_memory, d_pl, dq, dv_acc, d_pm_acc):
-    C.require_cuda(d_ctx, d_aw_in, aw, tanh_out, v, memory, d_memory, d_pl, dq, dv_acc, d_pm_acc)
+def attention_bwd(d_ctx, d_aw_in, aw, tanh_out, v, memory, d_memory, d_pl, dq, dv_acc, d_pm_acc, d_ctx_add=(), d_aw_add=None,
+                  dq16=None, dctx16=None):
+    """dv_acc fp32 [B, A] (per-sample partials); d_ctx_add: up to two more fp32 [B, E] row-strided pieces of the context gradient,
+    d_aw_add one more [B, Ti] piece of the weights' gradient (summed on load); dq16 / dctx16: 16-bit copies of dq / of the summed
+    context gradient (operands of the products that consume them).  See include/dle_mi355x.h."""
+    C.require_cuda(d_ctx, d_aw_in, aw, tanh_out, v, memory, d_memory, d_pl, dq, dv_acc, d_pm_acc, d_aw_add, dq16, dctx16, *d_ctx_add)
     b, ti = aw.shape
-    C.call("dle_t2_attention_bwd", C.ptr(d_ctx), C.ptr(d_aw_in), C.ptr(aw), C.ptr(tanh_out), C.ptr(v), C.ptr(memory),
-           C.ptr(d_memory), C.ptr(d_pl), C.ptr(dq), C.ptr(dv_acc), C.ptr(d_pm_acc), b, ti, v.numel(), memory.shape[1],
-           C.dt(tanh_out), C.stream())
+    if len(d_ctx_add) > 2:
+        raise ValueError("attention_bwd: at most two extra context-gradient pieces")
+    x = list(d_ctx_add) + [None] * (2 - len(d_ctx_add))
+    if dv_acc.shape != (b, v.numel()):
+        raise ValueError("attention_bwd: dv_acc holds one row of partial sums per sample, [B, A]")
+    for t in (d_aw_in, d_aw_add):
+        if t is not None and not t.is_contiguous():
+            raise ValueError("attention_bwd: contiguous [B, Ti] weight gradients")
+    C.call("dle_t2_attention_bwd", C.ptr(d_ctx), _ld(d_ctx, "d_ctx"), C.ptr(x[0]), _ld(x[0], "d_ctx") if x[0] is not None else 0,
+           C.ptr(x[1]), _ld(x[1], "d_ctx") if x[1] is not None else 0, C.ptr(d_aw_in), C.ptr(d_aw_add), C.ptr(aw), C.ptr(tanh_out),
+           C.ptr(v), C.ptr(memory), C.ptr(d_memory), C.ptr(d_pl), C.ptr(dq), C.ptr(dq16), C.ptr(dctx16), C.ptr(dv_acc),
+           C.ptr(d_pm_acc), b, ti, v.numel(), memory.shape[1], C.dt(tanh_out), C.stream())
+
+
+def location_bwd(dcol, d_prev, d_cum, b, ti, kl):
+    """dcol 16-bit [B*Ti, KL*8] -> d_prev fp32 [B, Ti] (written), d_cum fp32 [B, Ti] (accumulated)."""
+    C.require_cuda(dcol, d_prev, d_cum)
+    if not (dcol.is_contiguous() and d_prev.is_contiguous() and d_cum.is_contiguous()) or dcol.shape[1] != kl * 8:
+        raise ValueError("location_bwd: contiguous dcol [B*Ti, KL*8], d_prev / d_cum [B, Ti]")
+    C.call("dle_t2_location_bwd", C.ptr(dcol), C.ptr(d_prev), C.ptr(d_cum), b, ti, kl, C.dt(dcol), C.stream())
 
 
 def mel_loss(out_all, post, target, n_mel, scale, d_out, d_post):

@@ -177,6 +177,11 @@ int dle_mt_sgd(const int64_t* table_dev, int n_tensors, int64_t total_chunks, in
  * dle_check_nonfinite: found_inf = 1 if any element is inf/nan (GradScaler.unscale_'s check).        */
 int dle_cast_rows(const void* in, void* out, int64_t rows, int cols, int cols_out, int64_t ld_in,
                   int64_t ld_out, int in_dtype, int out_dtype, hipStream_t stream);
+/* y[c][r] = (16-bit) x[r][c]: transposed 16-bit working copy of a weight matrix (fp32 master or 16-bit copy), made once per
+ * iteration for the products that contract over the OUTPUT dimension with k-contiguous operands (data gradients of the
+ * recurrent cells, model.py:405-455 backward); torch.nn.LSTMCell's backward reads weight.t() the same way. */
+int dle_transpose_cast(const void* x, void* y, int rows, int cols, int64_t ld_x, int64_t ld_y, int in_dtype, int out_dtype,
+                       hipStream_t stream);
 int dle_bce_logits(const void* logits, const float* target, float* loss_out, void* dlogits,
                    const float* grad_scale_dev, int64_t n, int64_t ld_logits, int dtype, hipStream_t stream);
 int dle_amp_update_scale(float* scale, int* growth_tracker, float* found_inf, float* inv_scale,
@@ -412,23 +417,32 @@ int dle_wg_logdet_inv_batched(const float* base, const int64_t* table_dev, float
  * dle_t2_attention_fwd/bwd: Attention.forward of one decoder step (model.py:79-121): energies v . tanh(q + pl) (pl = processed
  *   memory + location term, [B*Ti, A]), softmax over the first lengths[b] text positions, context = weights x memory ([B*Ti, E]);
  *   awc rows = (weights, cumulative weights, 0 x 6) 16-bit = the next step's location-convolution input.  Backward accumulates
- *   d_memory (fp32; NULL: the caller sums weights_t (x) d_ctx_t over the steps itself) / d_pm (fp32) and dv across steps, writes
- *   d_pl (16-bit) and dq.
+ *   d_memory (fp32; NULL: the caller sums weights_t (x) d_ctx_t over the steps itself) / d_pm (fp32) and the per-sample partials
+ *   of dv (dv_acc fp32 [B, A]: one owner per row, no atomics; the caller folds the rows) across steps, writes d_pl (16-bit), dq
+ *   (fp32 [B, A] and / or 16-bit dq16 = the operand of the query layer's products) and, when dctx16 is given, the summed context
+ *   gradient in 16 bits.  The context gradient is the sum of up to three fp32 row-strided pieces d_ctx0..2 [B, E] (NULL = absent),
+ *   the gradient reaching the weights the sum of d_aw0 (+ d_aw1) fp32 [B, Ti]: autograd's accumulation of the gradients a tensor
+ *   receives from its consumers (model.py:405-455), done on load.  dh1 / dh2 of dle_t2_lstm_bwd likewise.
+ * dle_t2_location_bwd: transpose of the row gather of the 2-channel location convolution (model.py:40-76): dcol 16-bit
+ *   [B*Ti, KL*8] -> d_prev (channel 0, written) and d_cum (channel 1, accumulated), fp32 [B, Ti].
  * dle_t2_tanh_fwd: torch.tanh of the postnet (model.py:170).  dle_t2_mel_loss: MSE(mel_out) + MSE(mel_out + postnet) of
  *   Tacotron2Loss (loss_function.py:42-44) and its gradients (scaled by *scale_dev); workspace >= 1024 floats. */
 int dle_t2_tanh_fwd(const void* x, void* y, int64_t n, int dtype, hipStream_t stream);
 int dle_t2_lstm_fwd(void* gates, int64_t ld_g, const float* c_prev, float* c_out, void* d0, int64_t ld0, void* d1, int64_t ld1,
                     void* d2, int64_t ld2, const void* keep, int64_t keep_index, float inv_keep, const float* live,
                     const void* h_prev, int64_t ld_hp, void* out_dst, int64_t ld_out, int B, int H, int dtype, hipStream_t stream);
-int dle_t2_lstm_bwd(const float* dh, int64_t ld_dh, const float* dc_next, const void* act, int64_t ld_act, const float* c_prev,
+int dle_t2_lstm_bwd(const float* dh, int64_t ld_dh, const float* dh1, int64_t ld_dh1, const float* dh2, int64_t ld_dh2,
+                    const float* dc_next, const void* act, int64_t ld_act, const float* c_prev,
                     void* dgates, int64_t ld_dg, float* dc_prev, const void* keep, int64_t keep_index, float inv_keep,
                     const float* live, float* dh_prev, int B, int H, int dtype, hipStream_t stream);
 int dle_t2_attention_fwd(const float* q, const void* pl, const float* v, const void* memory, const int64_t* lengths,
                          const void* awc_prev, void* tanh_out, float* aw_out, void* awc_next, void* d0, int64_t ld0, void* d1,
                          int64_t ld1, void* d2, int64_t ld2, int B, int Ti, int A, int E, int dtype, hipStream_t stream);
-int dle_t2_attention_bwd(const float* d_ctx, const float* d_aw_in, const float* aw, const void* tanh_out, const float* v,
-                         const void* memory, float* d_memory, void* d_pl, float* dq, float* dv_acc, float* d_pm_acc, int B, int Ti,
-                         int A, int E, int dtype, hipStream_t stream);
+int dle_t2_attention_bwd(const float* d_ctx0, int64_t ld_c0, const float* d_ctx1, int64_t ld_c1, const float* d_ctx2, int64_t ld_c2,
+                         const float* d_aw0, const float* d_aw1, const float* aw, const void* tanh_out, const float* v,
+                         const void* memory, float* d_memory, void* d_pl, float* dq, void* dq16, void* dctx16, float* dv_acc,
+                         float* d_pm_acc, int B, int Ti, int A, int E, int dtype, hipStream_t stream);
+int dle_t2_location_bwd(const void* dcol, float* d_prev, float* d_cum, int B, int Ti, int KL, int dtype, hipStream_t stream);
 int dle_t2_mel_loss(const float* out_all, int64_t ld_out, const void* post, const float* target, const float* scale_dev,
                     void* d_out, int64_t ld_dout, void* d_post, float* loss, float* workspace, int64_t R, int n_mel, int dtype,
                     hipStream_t stream);

@@ -203,10 +203,13 @@ def lstm_fwd(gates, c_prev, c_out, h_dsts, keep=None, keep_index=0, p=0.0, live=
         d.copy_(h)
 
 
-def lstm_bwd(dh, dc_next, act, c_prev, dgates, dc_prev, keep=None, keep_index=0, p=0.0, live=None, dh_prev=None):
-    """Backward of lstm_fwd: dh fp32 [B, H] = gradient wrt the (dropped) h; act = saved activations (i, f, g, o); writes dgates
-    (16-bit, may be `act` itself), dc_prev fp32.  live: dead rows pass dh / dc through to dh_prev / dc_prev and get zero dgates."""
+def lstm_bwd(dh, dc_next, act, c_prev, dgates, dc_prev, keep=None, keep_index=0, p=0.0, live=None, dh_prev=None, dh_add=()):
+    """Backward of lstm_fwd: dh fp32 [B, H] (+ the pieces in dh_add) = gradient wrt the (dropped) h; act = saved activations
+    (i, f, g, o); writes dgates (16-bit, may be `act` itself), dc_prev fp32.  live: dead rows pass dh / dc through to dh_prev /
+    dc_prev and get zero dgates."""
     b, hh = dh.shape
+    for x in dh_add:
+        dh = dh + x
     a = act.float()
     i, f, gg, o = a[:, :hh], a[:, hh:2 * hh], a[:, 2 * hh:3 * hh], a[:, 3 * hh:]
     g = dh.clone()
@@ -250,23 +253,57 @@ def attention_fwd(q, pl, v, memory, lengths, awc_prev, tanh_out, aw_out, awc_nex
     awc_next.copy_(nxt.view(b * ti, 8))
 
 
-def attention_bwd(d_ctx, d_aw_in, aw, tanh_out, v, memory, d_memory, d_pl, dq, dv_acc, d_pm_acc):
-    """Backward of attention_fwd.  d_ctx fp32 [B, E]; d_aw_in fp32 [B, Ti] (gradient reaching the weights through the location
-    input / cumulative weights of later steps); accumulates d_memory fp32 [B*Ti, E], dv_acc fp32 [A], d_pm_acc fp32 [B*Ti, A];
-    writes d_pl 16-bit [B*Ti, A] (gradient of q + pl inside the tanh) and dq fp32 [B, A] (its sum over the text positions)."""
+def attention_bwd(d_ctx, d_aw_in, aw, tanh_out, v, memory, d_memory, d_pl, dq, dv_acc, d_pm_acc, d_ctx_add=(), d_aw_add=None,
+                  dq16=None, dctx16=None):
+    """Backward of attention_fwd.  d_ctx fp32 [B, E] (+ the pieces in d_ctx_add); d_aw_in (+ d_aw_add) fp32 [B, Ti] (gradient
+    reaching the weights through the location input / cumulative weights of later steps); accumulates d_memory fp32 [B*Ti, E],
+    dv_acc fp32 [B, A] (per-sample partial sums), d_pm_acc fp32 [B*Ti, A]; writes d_pl 16-bit [B*Ti, A] (gradient of q + pl inside
+    the tanh), dq fp32 [B, A] (its sum over the text positions) and / or its 16-bit copy dq16, and the summed context gradient in
+    16 bits (dctx16) when asked."""
     b, ti = aw.shape
     a = v.numel()
+    for x in d_ctx_add:
+        d_ctx = d_ctx + x
+    if d_aw_add is not None:
+        d_aw_in = d_aw_in + d_aw_add
+    if dctx16 is not None:
+        dctx16.copy_(d_ctx)
     mem = memory.float().view(b, ti, -1)
     if d_memory is not None:
         d_memory.add_((aw.unsqueeze(2) * d_ctx.unsqueeze(1)).reshape(b * ti, -1))
     d_aw = (mem * d_ctx.unsqueeze(1)).sum(2) + d_aw_in
     d_e = aw * (d_aw - (aw * d_aw).sum(1, keepdim=True))
     th = tanh_out.float().view(b, ti, a)
-    dv_acc.add_((d_e.unsqueeze(2) * th).sum((0, 1)))
+    dv_acc.add_((d_e.unsqueeze(2) * th).sum(1))
     d_pre = d_e.unsqueeze(2) * v.view(1, 1, a) * (1 - th * th)
     d_pl.copy_(d_pre.view(b * ti, a))
-    dq.copy_(d_pre.sum(1))
+    if dq is not None:
+        dq.copy_(d_pre.sum(1))
+    if dq16 is not None:
+        dq16.copy_(d_pre.sum(1))
     d_pm_acc.add_(d_pre.view(b * ti, a))                               # the fp32 value, not its 16-bit rounding
+
+
+def location_bwd(dcol, d_prev, d_cum, b, ti, kl):
+    """Transpose of the row gather col[(b, t), j*8 + c] = awc[b, t + j - kl//2, c] for the two live channels: d_prev (c = 0) is
+    written, d_cum (c = 1) accumulated; fp32 [B, Ti]."""
+    d = dcol.float().view(b, ti, kl, 8)
+    pad = kl // 2
+    out = torch.zeros(b, ti, 2)
+    for j in range(kl):
+        lo, hi = max(0, pad - j), min(ti, ti + pad - j)               # rows t with 0 <= t + j - pad < Ti
+        if lo < hi:
+            out[:, lo + j - pad:hi + j - pad] += d[:, lo:hi, j, :2]
+    d_prev.copy_(out[:, :, 0])
+    d_cum.add_(out[:, :, 1])
+
+
+def transpose_cast(x, out_dtype, out=None):
+    y = x.t().to(out_dtype)
+    if out is None:
+        return y.contiguous()
+    out.copy_(y)
+    return out
 
 
 def mel_loss(out_all, post, target, n_mel, scale, d_out, d_post):
@@ -293,13 +330,13 @@ def install(monkeypatch):
     me = globals()
     monkeypatch.setattr(C, "require_cuda", lambda *a: None)
     for name in ("gemm", "cast_rows", "cast", "bn_fwd", "bn_bwd", "dropout_fwd", "dropout_bwd", "rows_gather", "embed_scatter_add_",
-                 "act_bwd", "bce_with_logits", "relu_bwd", "axpby_"):
+                 "act_bwd", "bce_with_logits", "relu_bwd", "axpby_", "transpose_cast"):
         monkeypatch.setattr(F, name, me[name])
     for name in ("colsum", "copy_rows", "check_nonfinite_", "amp_update_scale_", "gemm_batched"):
         monkeypatch.setattr(F, name, getattr(W, name))
     for name in ("taps", "taps_bwd", "weight_norm_fwd", "weight_norm_bwd"):
         monkeypatch.setattr(wops, name, getattr(W, name))
-    for name in ("tanh_fwd", "lstm_fwd", "lstm_bwd", "attention_fwd", "attention_bwd", "mel_loss", "inv_keep"):
+    for name in ("tanh_fwd", "lstm_fwd", "lstm_bwd", "attention_fwd", "attention_bwd", "location_bwd", "mel_loss", "inv_keep"):
         monkeypatch.setattr(ops, name, me[name])
     fake_mt = types.SimpleNamespace(TableCache=W.TableCache, streaming_chunk=W.streaming_chunk, l2norm=W.l2norm, adam=W.adam)
     monkeypatch.setattr(engine, "mt", fake_mt)

@@ -195,3 +195,47 @@ def test_gemm_persistent_tile_walk(cuda, mnk, dtype):
         chk(y, "masked addend", ref + torch.where(keep, add.double(), torch.zeros((), dtype=torch.float64, device=cuda)))
     # the fp32-output path is not store-only (different output type): general epilogue on the same walk
     chk(F.gemm(a, b, m, n, k, True, True, out_dtype=torch.float32), "f32 out")
+
+
+SMALLM = [
+    # m, n, k: the per-step products of the recurrent loops (Tacotron2 gates / data gradients at batch 128, the encoder LSTM, the
+    # query layer), heads with few rows, edge sizes of the 64 x {32, 16} tile and of the 128-element K chunk
+    (128, 4096, 1536), (128, 4096, 2560), (128, 2560, 4096), (128, 1536, 4096), (128, 128, 1024), (128, 1024, 128),
+    (128, 1024, 256), (3, 384, 128), (4, 4096, 1536), (256, 1000, 2048), (70, 40, 264), (200, 8, 1024), (1, 16, 8),
+    (129, 36, 136),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("mnk", SMALLM)
+def test_gemm_few_rows_weight_streaming_kernel(cuda, mnk, dtype):
+    """csrc/gemm_smallm.hip (M <= 256, both operands k-contiguous): plain / bias / 16-bit addend / fp32 accumulate epilogues,
+    fp32 and 16-bit outputs, row-strided A and C -- against float64 on the same 16-bit-rounded inputs, and against the
+    128x128-tile kernel it replaces (DLE_GEMM_SMALLM=0 is read once per process, so the comparison is with float64 only)."""
+    F, C = _F()
+    m, n, k = mnk
+    gen = torch.Generator().manual_seed(m * 11 + n * 5 + k)
+    wide_a = _mk((m, k + 24), dtype, gen)                     # A = a column slice of a wider matrix (lda > K)
+    a = wide_a[:, 8:8 + k]
+    b = _mk((n, k), dtype, gen)
+    bias = torch.randn(n, generator=gen)
+    src = _mk((m, n), dtype, gen)
+    ref = a.double() @ b.double().T
+    tol = (2e-3 if dtype == torch.float16 else 1.6e-2) * np.sqrt(k)
+    ad, bd = wide_a.to(cuda)[:, 8:8 + k], b.to(cuda)
+
+    def chk(out, r, what, extra=0.0):
+        err = (out.cpu().double() - r).abs().max().item()
+        assert err <= tol + extra, "%s: max err %g (m,n,k=%s)" % (what, err, mnk)
+    chk(F.gemm(ad, bd, m, n, k, True, True, out_dtype=torch.float32), ref, "f32")
+    chk(F.gemm(ad, bd, m, n, k, True, True, out_dtype=torch.float32, bias=bias.to(cuda), alpha=0.5), 0.5 * ref + bias.double(),
+        "f32 + bias, alpha")
+    r16 = ref + src.double()
+    chk(F.gemm(ad, bd, m, n, k, True, True, act=C.ACT_ADD, mask_src=src.to(cuda)), r16, "16-bit + addend",
+        extra=float(r16.abs().max()) * (1e-3 if dtype == torch.float16 else 8e-3))
+    # fp32 accumulate into a row-strided C
+    base = torch.randn(m, n + 12, generator=gen)
+    cw = base.to(cuda)
+    F.gemm(ad, bd, m, n, k, True, True, out=cw[:, 4:4 + n], accumulate=True)
+    chk(cw[:, 4:4 + n], ref + base[:, 4:4 + n].double(), "accumulate, strided C")
+    assert torch.equal(cw[:, :4].cpu(), base[:, :4]) and torch.equal(cw[:, 4 + n:].cpu(), base[:, 4 + n:])

@@ -101,19 +101,80 @@ def test_attention_step_forward_backward(cuda, dtype, b, ti, a, e):
     # backward, from the CPU forward's saved tensors
     th, aw = ref[0], ref[1]
     d_ctx, d_aw_in = torch.randn(b, e, generator=g), torch.randn(b, ti, generator=g) * 0.1
-    base_mem, base_pm, base_dv = torch.randn(b * ti, e, generator=g), torch.randn(b * ti, a, generator=g), torch.randn(a, generator=g)
+    # the context gradient arrives in three row-strided pieces, the weights' gradient in two (summed on load)
+    wide = torch.randn(b, 3 * e + 8, generator=g)
+    pieces = (wide[:, 4:4 + e], wide[:, 8 + e:8 + 2 * e])
+    d_aw2 = torch.randn(b, ti, generator=g) * 0.05
+    base_mem, base_pm, base_dv = torch.randn(b * ti, e, generator=g), torch.randn(b * ti, a, generator=g), torch.randn(b, a, generator=g)
 
-    def runb(L, d):
+    def runb(L, d, extended):
         dmem, dpm, dv = d(base_mem.clone()), d(base_pm.clone()), d(base_dv.clone())
         dpl, dq = d(torch.zeros(b * ti, a, dtype=dtype)), d(torch.zeros(b, a))
-        L.attention_bwd(d(d_ctx), d(d_aw_in), d(aw), d(th), d(v), d(mem), dmem, dpl, dq, dv, dpm)
-        return dmem, dpl, dq, dv, dpm
-    got, ref = runb(ops, lambda t: t.to(cuda)), runb(D, lambda t: t)
-    _close(got[0], ref[0], rtol=1e-4, atol=1e-4)
-    _close(got[1], ref[1], **_tol(dtype))
-    _close(got[2], ref[2], rtol=2e-3, atol=2e-3)
-    _close(got[3], ref[3], rtol=2e-3, atol=5e-3)
-    _close(got[4], ref[4], rtol=2e-3, atol=2e-3)
+        dq16, dc16 = d(torch.zeros(b, a, dtype=dtype)), d(torch.zeros(b, e, dtype=dtype))
+        if extended:
+            w = d(wide)
+            L.attention_bwd(d(d_ctx), d(d_aw_in), d(aw), d(th), d(v), d(mem), None, dpl, None, dv, dpm,
+                            d_ctx_add=(w[:, 4:4 + e], w[:, 8 + e:8 + 2 * e]), d_aw_add=d(d_aw2), dq16=dq16, dctx16=dc16)
+        else:
+            L.attention_bwd(d(d_ctx), d(d_aw_in), d(aw), d(th), d(v), d(mem), dmem, dpl, dq, dv, dpm)
+        return dmem, dpl, dq, dv, dpm, dq16, dc16
+    for extended in (False, True):
+        got, ref = runb(ops, lambda t: t.to(cuda), extended), runb(D, lambda t: t, extended)
+        _close(got[0], ref[0], rtol=1e-4, atol=1e-4)
+        _close(got[1], ref[1], **_tol(dtype))
+        _close(got[3], ref[3], rtol=2e-3, atol=5e-3)
+        _close(got[4], ref[4], rtol=2e-3, atol=2e-3)
+        if extended:
+            _close(got[5], ref[5], **_tol(dtype))
+            _close(got[6], ref[6], **_tol(dtype))
+        else:
+            _close(got[2], ref[2], rtol=2e-3, atol=2e-3)
+    # deterministic: per-sample partial sums, no atomics
+    a1, a2 = runb(ops, lambda t: t.to(cuda), True), runb(ops, lambda t: t.to(cuda), True)
+    assert torch.equal(a1[3], a2[3]) and torch.equal(a1[4], a2[4])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,ti,kl", [(3, 23, 31), (16, 160, 31), (2, 9, 5)])
+def test_location_backward_and_transposed_copies(cuda, dtype, b, ti, kl):
+    ops = _ops()
+    from deeplearningexamples_amd import functional as F
+    g = torch.Generator().manual_seed(b + ti)
+    dcol = torch.randn(b * ti, kl * 8, generator=g).to(dtype)
+    prev0, cum0 = torch.randn(b, ti, generator=g), torch.randn(b, ti, generator=g)
+
+    def run(L, d):
+        p, c = d(prev0.clone()), d(cum0.clone())
+        L.location_bwd(d(dcol), p, c, b, ti, kl)
+        return p, c
+    got, ref = run(ops, lambda t: t.to(cuda)), run(D, lambda t: t)
+    _close(got[0], ref[0], rtol=1e-5, atol=1e-5)
+    _close(got[1], ref[1], rtol=1e-5, atol=1e-5)
+    # transposed 16-bit working copies: from the fp32 master and from a 16-bit row-strided view
+    w = torch.randn(70, 200, generator=g)
+    _close(F.transpose_cast(w.to(cuda), dtype), w.t().to(dtype), rtol=0, atol=0)
+    w16 = torch.randn(130, 96, generator=g).to(dtype)
+    _close(F.transpose_cast(w16.to(cuda)[:, 8:72], dtype), w16[:, 8:72].t(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_lstm_backward_sums_its_gradient_pieces(cuda, dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    b, h = 48, 256
+    act = torch.rand(b, 4 * h, generator=g).to(dtype)
+    act[:, 2 * h:3 * h] = (torch.rand(b, h, generator=g) * 2 - 1).to(dtype)
+    c_prev, dc_next = torch.randn(b, h, generator=g), torch.randn(b, h, generator=g)
+    wide = torch.randn(b, 3 * h + 4, generator=g)
+
+    def run(L, d):
+        w = d(wide)
+        dg, dcp = d(torch.zeros(b, 4 * h, dtype=dtype)), d(torch.zeros(b, h))
+        L.lstm_bwd(w[:, :h], d(dc_next), d(act), d(c_prev), dg, dcp, dh_add=(w[:, h + 4:2 * h + 4], w[:, 2 * h + 4:]))
+        return dg, dcp
+    got, ref = run(ops, lambda t: t.to(cuda)), run(D, lambda t: t)
+    _close(got[0], ref[0], **_tol(dtype))
+    _close(got[1], ref[1], rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
