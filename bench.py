@@ -395,15 +395,26 @@ class Tacotron2Workload:
         self.frames, self.text_len = int(ml.max()), int(tl.max())
         self.scaling = "weak"
         self.loss = None
+        # ~17,000 launches per iteration at 10-20 us of kernel each: eager, the step is bound by the HOST (Python + ctypes,
+        # ~14 us per launch).  The whole iteration is captured in a HIP graph (utils/graph.py, the reference's CudaGraphWrapper
+        # idea; the synthetic batch has one shape) and replayed; DLE_T2_GRAPH=0 runs it eagerly.  Multi-rank runs are eager.
+        from deeplearningexamples_amd.utils.graph import GraphedStep
+        self.graphed = world == 1 and os.environ.get("DLE_T2_GRAPH", "1") == "1"
+        self._step = GraphedStep(self.trainer.train_step, enabled=self.graphed, warmup_steps=1)
 
     def step(self):
-        self.loss = self.trainer.train_step(*self.data)
+        from deeplearningexamples_amd import _cabi
+        if self.graphed and _cabi._timer is not None:      # the per-launch event pass of bench.py needs real launches
+            self.loss = self.trainer.train_step(*self.data)
+        else:
+            self.loss = self._step(*self.data)
 
     def config(self):
         return {"workload": "Tacotron2 training (PyTorch/SpeechSynthesis/Tacotron2 -m Tacotron2), default network, teacher forcing, "
                             "synthetic LJSpeech-shaped padded batch (BASELINE.json configs[4], Tacotron2 half)",
                 "batch_per_gpu": self.batch, "max_text_len": self.text_len, "max_mel_frames": self.frames,
                 "mel_frames_per_step": self.samples_per_step // self.world, "unit_note": "mel frames / s",
+                "hip_graph": bool(self.graphed),
                 "parallelism": "single GPU" if self.world == 1 else "dp%d" % self.world}
 
     def dtype_name(self):

@@ -9,7 +9,7 @@
 // reuse: 64 rows x TN (32 | 16) columns x the full K range per workgroup -> ceil(M / 64) x N / TN workgroups (256 for a
 // 128 x 4096 gate matrix), K * 2 * (64 + TN) bytes each.
 //  * operands stream HBM/L2 -> LDS by LDS-DMA (buffer_load ... lds, 16 B / lane, 1 KiB per wave instruction) in K chunks of
-//    128 elements (256-byte rows, full cache lines), FOUR stages: three chunks in flight per workgroup while one is multiplied;
+//    128 elements (256-byte rows, full cache lines), 3-7 stages (all but one in flight while one chunk is multiplied);
 //    counted vmcnt (never 0 inside the loop), LDS-only barriers; every DMA goes through inline asm (gemm_tiles.h) so hipcc's
 //    wait-count pass inserts nothing;
 //  * the LDS image of a DMA is lane-linear, so bank conflicts are removed on the SOURCE address: slot s of row r holds the
@@ -22,7 +22,6 @@
 
 #define SM_BKE 128                     // K elements per chunk
 #define SM_TS 64                       // rows of A per workgroup
-#define SM_STAGES 4
 
 struct SmallMArgs {
   const unsigned short* A;
@@ -78,15 +77,19 @@ struct SmallMLoader {
   }
 };
 
-template <int N> __device__ __forceinline__ void sm_wait_vm() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+// s_waitcnt vmcnt(C * NPW): this wave's pieces of everything but its C youngest chunks have landed (vmcnt retires in order)
+template <int N> __device__ __forceinline__ void sm_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int NPW, int MAXC>
+__device__ __forceinline__ void sm_wait_chunks(int c) {
+  static_for<0, MAXC + 1>([&](auto I) __attribute__((always_inline)) {
+    if (c == decltype(I)::value) sm_wait_vm<decltype(I)::value * NPW>();
+  });
 }
 
-template <int DT, int TN>
+// NST stages of (64 + TN) x 256 B: NST - 1 chunks in flight while one is multiplied.  These launches are latency bound (one
+// workgroup per CU streams 0.3-0.8 MB through L2): the bytes in flight per CU set the rate, so the launcher gives a workgroup
+// ~140 KiB of stages when the grid is at most one workgroup per CU and ~80 KiB (two per CU) otherwise.
+template <int DT, int TN, int NST>
 __global__ __launch_bounds__(256) void gemm_smallm_kernel(SmallMArgs p) {
   typedef SmallMLoader<TN> L;
   constexpr int R = L::R, NB = TN / 16, STAGE = R * SM_BKE;      // halves per stage
@@ -100,20 +103,19 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(SmallMArgs p) {
   ld.init(p, wave, lane, m0, n0);
   const int nk = (p.K + SM_BKE - 1) / SM_BKE;
 #pragma unroll
-  for (int s = 0; s < SM_STAGES - 1; ++s)
+  for (int s = 0; s < NST - 1; ++s)
     if (s < nk) ld.issue(p, lds + s * STAGE, wave, s * SM_BKE);
   float4_t acc[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) acc[b] = (float4_t){0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, kg = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
-    // this wave's pieces of chunk kt have landed; the (at most two) younger chunks stay in flight
-    if (kt + 2 < nk) sm_wait_vm<2 * L::NPW>();
-    else if (kt + 1 < nk) sm_wait_vm<L::NPW>();
-    else sm_wait_vm<0>();
-    lds_barrier();                           // ... and everybody's; the stage chunk kt + 3 will overwrite is no longer read
-    if (kt + SM_STAGES - 1 < nk) ld.issue(p, lds + ((kt + SM_STAGES - 1) % SM_STAGES) * STAGE, wave, (kt + SM_STAGES - 1) * SM_BKE);
-    const unsigned short* st = lds + (kt % SM_STAGES) * STAGE;
+    // this wave's pieces of chunk kt have landed; the (at most NST - 2) younger chunks stay in flight
+    const int younger = nk - 1 - kt;
+    sm_wait_chunks<L::NPW, NST - 2>(younger < NST - 2 ? younger : NST - 2);
+    lds_barrier();                           // ... and everybody's; the stage the next chunk will overwrite is no longer read
+    if (kt + NST - 1 < nk) ld.issue(p, lds + ((kt + NST - 1) % NST) * STAGE, wave, (kt + NST - 1) * SM_BKE);
+    const unsigned short* st = lds + (kt % NST) * STAGE;
     const unsigned short* xa = st + (wave * 16 + fr) * SM_BKE;
 #pragma unroll
     for (int ks = 0; ks < SM_BKE / 32; ++ks) {
@@ -186,20 +188,27 @@ extern "C" int dle_gemm_smallm_try(const void* A, const void* B, void* C, const 
   SmallMArgs p = {(const unsigned short*)A, (const unsigned short*)B, C, bias, (const unsigned short*)src, M, N, K,
                   (long long)lda, (long long)ldb, (long long)ldc, out_dtype, act_add, accumulate, alpha};
   const int tm = (M + SM_TS - 1) / SM_TS;
-  const bool wide = (long long)tm * ((N + 31) / 32) >= 192;
-  const int tiles = tm * (wide ? (N + 31) / 32 : (N + 15) / 16);
-#define GO(DT, TN)                                                                                                        \
-  do {                                                                                                                    \
-    constexpr int lds_bytes = SM_STAGES * (SM_TS + TN) * SM_BKE * 2;                                                      \
-    static bool attr_set = false;                                                                                         \
-    if (!attr_set) {                                                                                                      \
-      hipFuncSetAttribute((const void*)gemm_smallm_kernel<DT, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
-      attr_set = true;                                                                                                    \
-    }                                                                                                                     \
-    hipLaunchKernelGGL((gemm_smallm_kernel<DT, TN>), dim3(tiles), dim3(256), lds_bytes, stream, p);                       \
+  const int tiles32 = tm * ((N + 31) / 32), tiles16 = tm * ((N + 15) / 16);
+  const bool wide = tiles32 >= 128;               // fewer, fatter workgroups: less re-reading of the A rows through L2
+  const int tiles = wide ? tiles32 : tiles16;
+  const bool deep = tiles <= 256;                 // at most one workgroup per CU: give it the CU's LDS
+#define GO(DT, TN, NST)                                                                                                        \
+  do {                                                                                                                         \
+    constexpr int lds_bytes = NST * (SM_TS + TN) * SM_BKE * 2;                                                                 \
+    static bool attr_set = false;                                                                                              \
+    if (!attr_set) {                                                                                                           \
+      (void)hipFuncSetAttribute((const void*)gemm_smallm_kernel<DT, TN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+      attr_set = true;                                                                                                         \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((gemm_smallm_kernel<DT, TN, NST>), dim3(tiles), dim3(256), lds_bytes, stream, p);                       \
   } while (0)
-  if (in_dtype == DLE_F16) { if (wide) GO(DLE_F16, 32); else GO(DLE_F16, 16); }
-  else { if (wide) GO(DLE_BF16, 32); else GO(DLE_BF16, 16); }
+#define PICK(DT)                                                            \
+  do {                                                                      \
+    if (wide) { if (deep) GO(DT, 32, 6); else GO(DT, 32, 3); }              \
+    else { if (deep) GO(DT, 16, 7); else GO(DT, 16, 4); }                   \
+  } while (0)
+  if (in_dtype == DLE_F16) PICK(DLE_F16); else PICK(DLE_BF16);
+#undef PICK
 #undef GO
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { dle_set_error("gemm_smallm launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }

@@ -319,8 +319,8 @@ __global__ __launch_bounds__(T2A_BLOCK) void t2_attention_bwd_kernel(const float
         accq[r] += dpre[r];
         accv[r] += e * th[r];
       }
-      if (t < Ti && act) {
-        *(ushort8_t*)(d_pl + row * A + col) = pack8<DT>(dpre);
+      if (t < Ti && act) *(ushort8_t*)(d_pl + row * A + col) = pack8<DT>(dpre);
+      if (d_pm_acc && t < Ti && act) {            // NULL: the caller sums the kept d_pl over the steps itself (dle_t2_sum_steps)
         float* pm = d_pm_acc + row * A + col;
         float4_t p0 = *(float4_t*)pm, p1 = *(float4_t*)(pm + 4);
 #pragma unroll
@@ -493,7 +493,7 @@ extern "C" int dle_t2_attention_bwd(const float* d_ctx0, int64_t ld_c0, const fl
                                     const float* v, const void* memory, float* d_memory, void* d_pl, float* dq, void* dq16,
                                     void* dctx16, float* dv_acc, float* d_pm_acc, int B, int Ti, int A, int E, int dtype,
                                     hipStream_t stream) {
-  DLE_CHECK_ARG(d_ctx0 && d_aw0 && aw && tanh_out && v && memory && d_pl && (dq || dq16) && dv_acc && d_pm_acc && B > 0 && Ti > 0 &&
+  DLE_CHECK_ARG(d_ctx0 && d_aw0 && aw && tanh_out && v && memory && d_pl && (dq || dq16) && dv_acc && B > 0 && Ti > 0 &&
                 A > 0 && E > 0, "t2_attention_bwd: bad args");
   DLE_CHECK_ARG(A % 8 == 0 && E % 8 == 0 && A <= 512 && E <= 512, "t2_attention_bwd: A, E multiples of 8, at most 512 (got %d, %d)", A, E);
   DLE_CHECK_ARG((ld_c0 & 3) == 0 && (!d_ctx1 || (ld_c1 & 3) == 0) && (!d_ctx2 || (ld_c2 & 3) == 0) &&
@@ -515,6 +515,51 @@ extern "C" int dle_t2_attention_bwd(const float* d_ctx0, int64_t ld_c0, const fl
                        (const unsigned short*)memory, d_memory, (unsigned short*)d_pl, dq, (unsigned short*)dq16,
                        (unsigned short*)dctx16, dv_acc, d_pm_acc, Ti, A, E, lpa, lpe);
   DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[r] += sum_s x[s][r] (16-bit x, fp32 out, R % 8 == 0): the per-step gradients of a tensor every decoder step reads (the
+// processed memory) are kept in 16 bits for a chunk of steps and folded here -- one pass over the chunk instead of an fp32
+// read-modify-write of the accumulator inside every step's attention kernel.
+template <int DT>
+__global__ __launch_bounds__(T2_BLOCK) void t2_sum_steps_kernel(const unsigned short* __restrict__ x, float* __restrict__ out, int n,
+                                                                long long R8) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < R8; i += (long long)gridDim.x * blockDim.x) {
+    float acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+    int s = 0;
+    for (; s + 4 <= n; s += 4) {
+      ushort8_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = ((const ushort8_t*)x)[(long long)(s + u) * R8 + i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[8];
+        unpack8<DT>(v[u], f);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] += f[r];
+      }
+    }
+    for (; s < n; ++s) {
+      float f[8];
+      unpack8<DT>(((const ushort8_t*)x)[(long long)s * R8 + i], f);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] += f[r];
+    }
+    float4_t* o = (float4_t*)(out + i * 8);
+    float4_t a = o[0], b = o[1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { a[r] += acc[r]; b[r] += acc[4 + r]; }
+    o[0] = a;
+    o[1] = b;
+  }
+}
+
+extern "C" int dle_t2_sum_steps(const void* x, float* out, int n_steps, int64_t R, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(x && out && n_steps > 0 && R > 0 && R % 8 == 0 && ((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0, "t2_sum_steps: bad args");
+  T2_DT_CHECK("t2_sum_steps");
+  T2_GO(t2_sum_steps_kernel, t2_grid(R / 8, 4096), 0, (const unsigned short*)x, out, n_steps, (long long)(R / 8));
   return 0;
 }
 

@@ -56,7 +56,10 @@ class Tacotron2Trainer:
         self.noop = torch.zeros(1, dtype=torch.int32, device=dev)
         self.lr_t = torch.full((1,), self.lr, dtype=torch.float32, device=dev)
         self._tables = mt.TableCache()
+        # dropout: counter-based masks; the call index INSIDE a step is host state, the per-step advance a device word the kernels add
+        # (a HIP-graph replay of the step then draws fresh masks, like torch's graph-safe Philox offsets)
         self.rng_seed, self._rng_calls = int(seed) + int(rank), 0
+        self._rng_base = torch.zeros(1, dtype=torch.int64, device=dev)
         self._buf = dict(model.named_buffers())
         self.buckets = None
         if world_size > 1:
@@ -75,7 +78,7 @@ class Tacotron2Trainer:
 
     def _drop(self, x, p):
         self._rng_calls += 1
-        return F.dropout_fwd(x, p, self.rng_seed, self._rng_calls)
+        return F.dropout_fwd(x, p, self.rng_seed, self._rng_calls, offset_base=self._rng_base)
 
     def _conv_w(self, name):
         """Conv1d weight [Co, Ci, K] -> GEMM operand [Co, K * Ci] (tap-major), 16-bit."""
@@ -168,6 +171,7 @@ class Tacotron2Trainer:
         b, ti = text.shape
         to = mel.shape[2]
         self._prepare_weights()
+        self._rng_calls = 0
         w = self.w
         sv = self.sv = dict(b=b, ti=ti, to=to, text=text.reshape(-1).contiguous(), lengths=text_lengths)
         # ---- encoder: embedding, 3 x (conv + BN + ReLU + dropout), bi-LSTM over the packed batch
@@ -357,7 +361,7 @@ class Tacotron2Trainer:
             # attention: d context_t = projection piece + decoder gates (step t) + attention gates (step t+1)
             slot = t % ch_steps
             ops.attention_bwd(dhc[:, t, Hd:], d_aw_loc, aw[t], sv["tanh_all"][t], w["v"], memory, None if hoist else d_memory,
-                              d_pl_ch[slot], None, dv_acc, d_pm, d_ctx_add=(dxd[:, Ha:Ha + E], dxa[:, :E]), d_aw_add=d_cum,
+                              d_pl_ch[slot], None, dv_acc, None, d_ctx_add=(dxd[:, Ha:Ha + E], dxa[:, :E]), d_aw_add=d_cum,
                               dq16=dq_all[t], dctx16=dctx_all[t] if hoist else None)
             # location term: pl = taps(awc[t]) x W_loc^T + pm; awc[t] = (weights_{t-1}, cumulative_{t-1})
             F.gemm(d_pl_ch[slot], w["locT"], b * ti, self.KL * 8, A, True, True, out=dcol)
@@ -369,6 +373,7 @@ class Tacotron2Trainer:
                 F.gemm(d_pl_ch[:n].view(rows, A), cols, A, self.KL * 8, rows, False, False, out=dw_loc, accumulate=True,
                        splitk=F.pick_splitk(A, self.KL * 8, rows))
                 del cols
+                ops.sum_steps(d_pl_ch[:n], d_pm.view(-1))                 # d processed memory = sum over the steps of d_pl
             # attention LSTM: d attention_hidden_t = decoder gates (step t) + query layer + attention gates (step t+1)
             F.gemm(dq_all[t], w["qT"], b, Ha, A, True, True, out=d_ah_q)
             ops.lstm_bwd(dxd[:, :Ha], d_ac[cur], ga[t], ac[t], ga[t], d_ac[nxt], keep=sv["keep_a"], keep_index=t * b * Ha, p=pa,
@@ -450,6 +455,8 @@ class Tacotron2Trainer:
         if self.buckets is not None:
             for _, _, name in self.buckets.buckets:
                 self.buckets.grad_ready(name)
+        if self._rng_calls:
+            self._rng_base += self._rng_calls          # on the device: the next step (or graph replay) draws new masks
 
     def _relu_mask(self, g, y):
         out = torch.empty_like(g)

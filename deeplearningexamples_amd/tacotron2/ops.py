@@ -93,6 +93,16 @@ def attention_bwd(d_ctx, d_aw_in, aw, tanh_out, v, memory, d_memory, d_pl, dq, d
            C.ptr(d_pm_acc), b, ti, v.numel(), memory.shape[1], C.dt(tanh_out), C.stream())
 
 
+def sum_steps(x, out):
+    """out (fp32, flat) += sum over the leading dimension of x (16-bit [n, ...], contiguous)."""
+    C.require_cuda(x, out)
+    n = x.shape[0]
+    r = x.numel() // n
+    if not x.is_contiguous() or not out.is_contiguous() or out.numel() != r or out.dtype != torch.float32:
+        raise ValueError("sum_steps: contiguous x [n, R] and fp32 out [R]")
+    C.call("dle_t2_sum_steps", C.ptr(x), C.ptr(out), n, r, C.dt(x), C.stream())
+
+
 def location_bwd(dcol, d_prev, d_cum, b, ti, kl):
     """dcol 16-bit [B*Ti, KL*8] -> d_prev fp32 [B, Ti] (written), d_cum fp32 [B, Ti] (accumulated)."""
     C.require_cuda(dcol, d_prev, d_cum)

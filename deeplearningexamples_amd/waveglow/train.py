@@ -166,10 +166,10 @@ def save_checkpoint(trainer, epoch, config, output_dir, model_name, local_rank, 
     ckpt = {"epoch": epoch, "cuda_rng_state_all": torch.stack(cudas), "random_rng_states_all": torch.stack(rngs),
             "config": config, "state_dict": {k: v.detach().cpu().clone() for k, v in trainer.model.state_dict().items()},
             "optimizer": optimizer_state_dict(trainer, names), "scaler": scaler_state_dict(trainer)}
-    if hasattr(trainer, "_rng_calls"):
+    if hasattr(trainer, "_rng_base"):
         # not a reference key (its loader ignores it): the position of the trainer's counter-based dropout stream (Tacotron2),
         # which torch's restored RNG state does not drive -- a resumed run continues the mask sequence
-        ckpt["dle_rng_calls"] = int(trainer._rng_calls)
+        ckpt["dle_rng_calls"] = int(trainer._rng_base.item())
     name = "checkpoint_{}_{}.pt".format(model_name, epoch)
     path = os.path.join(output_dir, name)
     torch.save(ckpt, path)
@@ -199,8 +199,8 @@ def load_checkpoint(trainer, filepath, local_rank, names=None):
         raise Exception("Model checkpoint must have either 'random_rng_state' or 'random_rng_states_all' key.")
     # the reference wraps the model in DistributedDataParallel when distributed: its multi-GPU files carry "module." keys
     trainer.model.load_reference_state({(k[7:] if k.startswith("module.") else k): v for k, v in ckpt["state_dict"].items()})
-    if hasattr(trainer, "_rng_calls"):
-        trainer._rng_calls = int(ckpt.get("dle_rng_calls", 0))
+    if hasattr(trainer, "_rng_base"):
+        trainer._rng_base.fill_(int(ckpt.get("dle_rng_calls", 0)))
     load_optimizer_state_dict(trainer, ckpt["optimizer"], names)
     load_scaler_state_dict(trainer, ckpt["scaler"])
     return ckpt["config"], ckpt["epoch"] + 1

@@ -417,7 +417,8 @@ int dle_wg_logdet_inv_batched(const float* base, const int64_t* table_dev, float
  * dle_t2_attention_fwd/bwd: Attention.forward of one decoder step (model.py:79-121): energies v . tanh(q + pl) (pl = processed
  *   memory + location term, [B*Ti, A]), softmax over the first lengths[b] text positions, context = weights x memory ([B*Ti, E]);
  *   awc rows = (weights, cumulative weights, 0 x 6) 16-bit = the next step's location-convolution input.  Backward accumulates
- *   d_memory (fp32; NULL: the caller sums weights_t (x) d_ctx_t over the steps itself) / d_pm (fp32) and the per-sample partials
+ *   d_memory (fp32; NULL: the caller sums weights_t (x) d_ctx_t over the steps itself) / d_pm (fp32; NULL: the caller folds the
+ *   kept d_pl with dle_t2_sum_steps) and the per-sample partials
  *   of dv (dv_acc fp32 [B, A]: one owner per row, no atomics; the caller folds the rows) across steps, writes d_pl (16-bit), dq
  *   (fp32 [B, A] and / or 16-bit dq16 = the operand of the query layer's products) and, when dctx16 is given, the summed context
  *   gradient in 16 bits.  The context gradient is the sum of up to three fp32 row-strided pieces d_ctx0..2 [B, E] (NULL = absent),
@@ -442,6 +443,9 @@ int dle_t2_attention_bwd(const float* d_ctx0, int64_t ld_c0, const float* d_ctx1
                          const float* d_aw0, const float* d_aw1, const float* aw, const void* tanh_out, const float* v,
                          const void* memory, float* d_memory, void* d_pl, float* dq, void* dq16, void* dctx16, float* dv_acc,
                          float* d_pm_acc, int B, int Ti, int A, int E, int dtype, hipStream_t stream);
+/* out[r] += sum over the n_steps rows of x (16-bit [n_steps, R], R % 8 == 0), fp32 out: folds the kept per-step gradients of the
+ * processed memory (d_pm_acc = NULL in dle_t2_attention_bwd). */
+int dle_t2_sum_steps(const void* x, float* out, int n_steps, int64_t R, int dtype, hipStream_t stream);
 int dle_t2_location_bwd(const void* dcol, float* d_prev, float* d_cum, int B, int Ti, int KL, int dtype, hipStream_t stream);
 int dle_t2_mel_loss(const float* out_all, int64_t ld_out, const void* post, const float* target, const float* scale_dev,
                     void* d_out, int64_t ld_dout, void* d_post, float* loss, float* workspace, int64_t R, int n_mel, int dtype,

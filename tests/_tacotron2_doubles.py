@@ -281,7 +281,12 @@ def attention_bwd(d_ctx, d_aw_in, aw, tanh_out, v, memory, d_memory, d_pl, dq, d
         dq.copy_(d_pre.sum(1))
     if dq16 is not None:
         dq16.copy_(d_pre.sum(1))
-    d_pm_acc.add_(d_pre.view(b * ti, a))                               # the fp32 value, not its 16-bit rounding
+    if d_pm_acc is not None:
+        d_pm_acc.add_(d_pre.view(b * ti, a))                           # the fp32 value, not its 16-bit rounding
+
+
+def sum_steps(x, out):
+    out.add_(x.double().sum(0).float().view(out.shape))
 
 
 def location_bwd(dcol, d_prev, d_cum, b, ti, kl):
@@ -336,7 +341,7 @@ def install(monkeypatch):
         monkeypatch.setattr(F, name, getattr(W, name))
     for name in ("taps", "taps_bwd", "weight_norm_fwd", "weight_norm_bwd"):
         monkeypatch.setattr(wops, name, getattr(W, name))
-    for name in ("tanh_fwd", "lstm_fwd", "lstm_bwd", "attention_fwd", "attention_bwd", "location_bwd", "mel_loss", "inv_keep"):
+    for name in ("tanh_fwd", "lstm_fwd", "lstm_bwd", "attention_fwd", "attention_bwd", "location_bwd", "sum_steps", "mel_loss", "inv_keep"):
         monkeypatch.setattr(ops, name, me[name])
     fake_mt = types.SimpleNamespace(TableCache=W.TableCache, streaming_chunk=W.streaming_chunk, l2norm=W.l2norm, adam=W.adam)
     monkeypatch.setattr(engine, "mt", fake_mt)

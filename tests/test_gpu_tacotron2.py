@@ -129,6 +129,13 @@ def test_attention_step_forward_backward(cuda, dtype, b, ti, a, e):
             _close(got[6], ref[6], **_tol(dtype))
         else:
             _close(got[2], ref[2], rtol=2e-3, atol=2e-3)
+    # the deferred fold of the kept per-step gradients
+    xs = torch.randn(7, b * ti * a, generator=g).to(dtype)
+    acc0 = torch.randn(b * ti * a, generator=g)
+    o1, o2 = acc0.clone().to(cuda), acc0.clone()
+    ops.sum_steps(xs.to(cuda), o1)
+    D.sum_steps(xs, o2)
+    _close(o1, o2, rtol=1e-5, atol=1e-5)
     # deterministic: per-sample partial sums, no atomics
     a1, a2 = runb(ops, lambda t: t.to(cuda), True), runb(ops, lambda t: t.to(cuda), True)
     assert torch.equal(a1[3], a2[3]) and torch.equal(a1[4], a2[4])
