@@ -388,3 +388,56 @@ extern "C" int dle_transpose_cast(const void* x, void* y, int rows, int cols, in
   DLE_LAUNCH_CHECK();
   return 0;
 }
+
+// Exchange buffer <-> interaction input of the bottom -> top all-to-all (Recommendation/DLRM/dlrm/model/distributed.py:32-98: the
+// `torch.cat(dim=1)` of the received blocks in forward, the `split` of the gradient in backward).  `blocks` is the concatenation
+// over the ranks s of contiguous [rows, w_s] matrices (what all_to_all_single receives / sends), `x` is [rows, sum_s w_s] with
+// block s in columns [base_s, base_s + w_s).  ONE launch per direction (the per-peer row copies were up to 8 + 8 launches per
+// step); 16 bytes per lane, a row of x is read / written contiguously.
+struct A2ABlocksArgs {
+  int world, rows, row_chunks;        // 16-byte chunks per row of x
+  int base[9];                        // first chunk of block s inside a row (base[world] = row_chunks)
+  long long start[8];                 // first chunk of block s inside `blocks`
+};
+template <bool PACK>
+__global__ __launch_bounds__(256) void a2a_blocks_kernel(uint4_t* __restrict__ blocks, uint4_t* __restrict__ x, A2ABlocksArgs a) {
+  const long long total = (long long)a.rows * a.row_chunks;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / a.row_chunks), c = (int)(i - (long long)r * a.row_chunks);
+    int b0 = a.base[0], b1 = a.base[1];             // (constant indices only: a run-time index would move the struct to scratch)
+    long long st = a.start[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q)
+      if (q < a.world && c >= a.base[q]) { b0 = a.base[q]; b1 = a.base[q + 1]; st = a.start[q]; }
+    const long long j = st + (long long)r * (b1 - b0) + (c - b0);
+    if (PACK) blocks[j] = x[i];
+    else x[i] = blocks[j];
+  }
+}
+
+// widths: elements per row of each rank's block; elem_size in bytes; every width * elem_size must be a multiple of 16.
+extern "C" int dle_a2a_blocks(void* blocks, void* x, int rows, int world, const int* widths, int elem_size, int pack,
+                              hipStream_t stream) {
+  DLE_CHECK_ARG(blocks && x && rows > 0 && world >= 1 && world <= 8 && widths && (elem_size == 2 || elem_size == 4),
+                "a2a_blocks: bad args (at most 8 ranks)");
+  DLE_CHECK_ARG(((((uintptr_t)blocks) | ((uintptr_t)x)) & 15) == 0, "a2a_blocks: 16-byte aligned buffers");
+  A2ABlocksArgs a = {};
+  a.world = world; a.rows = rows;
+  int c = 0;
+  long long st = 0;
+  for (int s = 0; s < world; ++s) {
+    DLE_CHECK_ARG(widths[s] >= 0 && (widths[s] * elem_size) % 16 == 0, "a2a_blocks: block widths must be multiples of 16 bytes");
+    a.base[s] = c;
+    a.start[s] = st;
+    c += widths[s] * elem_size / 16;
+    st += (long long)rows * (widths[s] * elem_size / 16);
+  }
+  for (int s = world; s <= 8; ++s) a.base[s] = c;
+  a.row_chunks = c;
+  if (c == 0) return 0;
+  const int grid = ew_grid((long long)rows * c, 256);
+  if (pack) hipLaunchKernelGGL(a2a_blocks_kernel<true>, dim3(grid), dim3(256), 0, stream, (uint4_t*)blocks, (uint4_t*)x, a);
+  else hipLaunchKernelGGL(a2a_blocks_kernel<false>, dim3(grid), dim3(256), 0, stream, (uint4_t*)blocks, (uint4_t*)x, a);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}

@@ -155,34 +155,41 @@ class DlrmTrainer:
                 F.cast_rows(self.bot_linears[i].weight.data, c.dtype, cols_out=c.shape[1], out=c)
 
     # ------------------------------------------------------------------ hybrid-parallel exchange
+    def _exchange(self, out, inp, out_splits, in_splits):
+        """The all-to-all on the COMMUNICATION stream, ordered after what the compute stream has enqueued; the caller waits
+        (`_exchange_wait`) right before the first consumer, so independent compute launched in between overlaps the transfer."""
+        cur = torch.cuda.current_stream()
+        self.comm_stream.wait_stream(cur)
+        with torch.cuda.stream(self.comm_stream):
+            comm.all_to_all_single(out, inp, out_splits, in_splits, group=self.pg)
+            self._a2a_event = torch.cuda.Event()
+            self._a2a_event.record(self.comm_stream)
+        for t in (out, inp):
+            t.record_stream(self.comm_stream)
+
+    def _exchange_wait(self):
+        """The compute stream waits for the LAST all-to-all only (not for what was queued behind it on the communication stream)."""
+        torch.cuda.current_stream().wait_event(self._a2a_event)
+
     def _bottom_to_top(self, local_out, plan=None):
-        """[B_global, n_r, D] -> [B_r, n_total, D] (device feature order).  all_to_all_single over RCCL."""
+        """[B_global, n_r, D] -> [B_r, n_total, D] (device feature order).  all_to_all_single over RCCL, then ONE unpack launch
+        (the reference's torch.cat(dim=1) of the received blocks, dlrm/model/distributed.py:70-75)."""
         p = plan or self.plan
         recv = torch.empty(sum(p.fwd_recv_splits), dtype=local_out.dtype, device=local_out.device)
-        comm.all_to_all_single(recv, local_out.view(-1), p.fwd_recv_splits, p.fwd_send_splits, group=self.pg)
+        self._exchange(recv, local_out.view(-1), p.fwd_recv_splits, p.fwd_send_splits)
+        self._exchange_wait()
         x = torch.empty((p.local_batch, p.n_total, p.dim), dtype=local_out.dtype, device=local_out.device)
-        for s in range(p.world):
-            if p.vectors[s] == 0:
-                continue
-            blk = recv[p.recv_block_start[s]:p.recv_block_start[s] + p.fwd_recv_splits[s]]
-            F.copy_rows(blk.view(p.local_batch, p.vectors[s] * p.dim),
-                        x.view(p.local_batch, -1)[:, p.recv_feature_base[s] * p.dim:
-                                                  (p.recv_feature_base[s] + p.vectors[s]) * p.dim])
+        F.a2a_blocks(recv, x, p.local_batch, [v * p.dim for v in p.vectors], pack=False)
         return x
 
-    def _top_to_bottom(self, grad_x):
-        """Reverse exchange of the gradient: [B_r, n_total, D] -> [B_global, n_r, D]."""
+    def _top_to_bottom_start(self, grad_x):
+        """Reverse exchange of the gradient: [B_r, n_total, D] -> [B_global, n_r, D].  ONE pack launch, then the all-to-all on
+        the communication stream; returns the receive buffer -- call _exchange_wait() before reading it."""
         p = self.plan
         send = torch.empty(sum(p.fwd_recv_splits), dtype=grad_x.dtype, device=grad_x.device)
-        for s in range(p.world):
-            if p.vectors[s] == 0:
-                continue
-            blk = send[p.recv_block_start[s]:p.recv_block_start[s] + p.fwd_recv_splits[s]]
-            F.copy_rows(grad_x.view(p.local_batch, -1)[:, p.recv_feature_base[s] * p.dim:
-                                                       (p.recv_feature_base[s] + p.vectors[s]) * p.dim],
-                        blk.view(p.local_batch, p.vectors[s] * p.dim))
+        F.a2a_blocks(send, grad_x.contiguous(), p.local_batch, [v * p.dim for v in p.vectors], pack=True)
         out = torch.empty((p.global_batch, p.n_local, p.dim), dtype=grad_x.dtype, device=grad_x.device)
-        comm.all_to_all_single(out.view(-1), send, p.fwd_send_splits, p.fwd_recv_splits, group=self.pg)
+        self._exchange(out.view(-1), send, p.fwd_send_splits, p.fwd_recv_splits)
         return out
 
     # ------------------------------------------------------------------ validation (dlrm/scripts/main.py:733-835 dist_evaluate)
@@ -239,15 +246,21 @@ class DlrmTrainer:
         loss, dlogits = F.bce_with_logits(logits, labels, grad_scale=sc.scale if sc.enabled else None)
         # one rank: the interaction backward itself reports inf / nan in the gradient it writes (no sweep over 450 MB)
         fused_check = sc.enabled and self.world == 1
-        grad_x = m.top_model.backward(dlogits.view(-1, 1), grads=self.top_grads.views[:-1],
-                                      out_grads=self.top_grads.views[-1], found_inf=sc.found_inf if fused_check else None)
         if self.world > 1:
-            # data-parallel mean of the top-MLP gradients, overlapped with the bottom backward
+            # data-gradient chain of the top model first; the gradient all-to-all (xGMI) then runs on the communication stream
+            # UNDER the top model's weight gradients, and the data-parallel mean of those follows it on the same stream
+            grad_x, finish = m.top_model.backward(dlogits.view(-1, 1), grads=self.top_grads.views[:-1],
+                                                  out_grads=self.top_grads.views[-1], defer_wgrad=True)
+            grad_bottom = self._top_to_bottom_start(grad_x)
+            finish()
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 allreduce_mean_(self.top_grads.flat, self.pg)
-            grad_bottom = self._top_to_bottom(grad_x)
+            # (stream order on comm_stream: all-to-all, then the all-reduce; the compute stream needs only the former here)
+            self._exchange_wait()
         else:
+            grad_x = m.top_model.backward(dlogits.view(-1, 1), grads=self.top_grads.views[:-1],
+                                          out_grads=self.top_grads.views[-1], found_inf=sc.found_inf if fused_check else None)
             grad_bottom = grad_x
         if sc.enabled:
             if not fused_check:

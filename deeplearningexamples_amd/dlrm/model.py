@@ -110,19 +110,21 @@ class Mlp(nn.Module):
         self._saved = acts
         return h
 
-    def backward(self, gy: torch.Tensor, need_input_grad: bool = False, grads=None, masked: bool = False):
+    def backward(self, gy: torch.Tensor, need_input_grad: bool = False, grads=None, masked: bool = False, defer_wgrad: bool = False):
         """gy: gradient w.r.t. the (post-ReLU) output of the last layer, 16-bit, may be a strided view;
         masked=True when the producer already applied the last ReLU's mask in its epilogue.
         Writes fp32 weight/bias gradients into `grads` [(gw, gb), ...] (views of a flat bucket) or into
-        .grad.  Returns the input gradient when asked."""
+        .grad.  Returns the input gradient when asked.
+        defer_wgrad: run the data-gradient chain only and return (input gradient, finish) -- finish() launches the weight / bias
+        gradients afterwards (the multi-rank step starts the gradient all-to-all as soon as the chain is through and overlaps
+        it with them)."""
         acts, w16, lins = self._saved, self.working_copies(), self.linears
         g = gy
-        for i in range(len(lins) - 1, -1, -1):
-            lin = lins[i]
-            y, x = acts[i + 1], acts[i]
+        pending = []
+
+        def wgrad(i, g):
+            lin, x = lins[i], acts[i]
             m = x.shape[0]
-            if not masked:
-                g = F.relu_bwd(g, y)
             gw, gb = grads[i] if grads is not None else (_grad_buf(lin.weight), _grad_buf(lin.bias))
             kp = w16[i].shape[1]
             # dW[n, k] = g[m, n]^T x[m, k]   (fp32, split-K)
@@ -133,15 +135,32 @@ class Mlp(nn.Module):
             if gw_full is not gw:
                 gw.copy_(gw_full[:, :lin.in_features])
             F.colsum(g, out=gb)
+
+        gin = None
+        for i in range(len(lins) - 1, -1, -1):
+            lin = lins[i]
+            y, x = acts[i + 1], acts[i]
+            m = x.shape[0]
+            if not masked:
+                g = F.relu_bwd(g, y)
+            kp = w16[i].shape[1]
+            if defer_wgrad:
+                pending.append((i, g))
+            else:
+                wgrad(i, g)
             if i > 0:
                 # dX = g W, masked by the ReLU of the previous layer in the epilogue
                 g = F.gemm(g, w16[i], m, kp, lin.out_features, True, False, out_dtype=self.compute_dtype,
                            act=C.ACT_RELU_BWD, mask_src=acts[i])
                 masked = True
             elif need_input_grad:
-                g = F.gemm(g, w16[i], m, kp, lin.out_features, True, False, out_dtype=self.compute_dtype)
-                return g
-        return None
+                gin = F.gemm(g, w16[i], m, kp, lin.out_features, True, False, out_dtype=self.compute_dtype)
+        if defer_wgrad:
+            def finish():
+                for i, gi in pending:
+                    wgrad(i, gi)
+            return gin, finish
+        return gin
 
 
 def _grad_buf(p: torch.Tensor) -> torch.Tensor:
@@ -310,18 +329,31 @@ class DlrmTop(nn.Module):
         return F.gemm(h, w, h.shape[0], w.shape[0], w.shape[1], True, True, out_dtype=self.compute_dtype,
                       bias=self.out.bias.data)
 
-    def backward(self, dlogits, grads=None, out_grads=None, grad_x_out=None, found_inf=None):
+    def backward(self, dlogits, grads=None, out_grads=None, grad_x_out=None, found_inf=None, defer_wgrad=False):
         """dlogits [B, 1] 16-bit -> gradient of the interaction input [B, R, D]; found_inf (optional fp32 [1]) is set by the
-        interaction backward when that gradient holds an inf / nan."""
+        interaction backward when that gradient holds an inf / nan.  defer_wgrad: -> (gradient, finish): the data-gradient chain
+        first, finish() launches every weight / bias gradient of the top model."""
         h, w = self._h, self.out_working_copy()
         m, n, k = h.shape[0], w.shape[0], w.shape[1]
         gw, gb = out_grads if out_grads is not None else (_grad_buf(self.out.weight), _grad_buf(self.out.bias))
-        F.gemm(dlogits, h, n, k, m, False, False, out=gw, splitk=F.pick_splitk(n, k, m))
-        F.colsum(dlogits, out=gb)
+
+        def out_wgrad():
+            F.gemm(dlogits, h, n, k, m, False, False, out=gw, splitk=F.pick_splitk(n, k, m))
+            F.colsum(dlogits, out=gb)
+        if not defer_wgrad:
+            out_wgrad()
         gh = F.gemm(dlogits, w, m, k, n, True, False, out_dtype=self.compute_dtype, act=C.ACT_RELU_BWD,
                     mask_src=h)
-        gz = self.mlp.backward(gh, need_input_grad=True, grads=grads, masked=True)
-        return self.interaction.backward(gz, grad_out=grad_x_out, found_inf=found_inf)
+        if not defer_wgrad:
+            gz = self.mlp.backward(gh, need_input_grad=True, grads=grads, masked=True)
+            return self.interaction.backward(gz, grad_out=grad_x_out, found_inf=found_inf)
+        gz, mlp_finish = self.mlp.backward(gh, need_input_grad=True, grads=grads, masked=True, defer_wgrad=True)
+        gx = self.interaction.backward(gz, grad_out=grad_x_out, found_inf=found_inf)
+
+        def finish():
+            out_wgrad()
+            mlp_finish()
+        return gx, finish
 
 
 class DistributedDlrm(nn.Module):

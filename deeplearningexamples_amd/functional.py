@@ -181,6 +181,21 @@ def cast_rows(x, out_dtype, cols_out=None, out=None):
     return out
 
 
+def a2a_blocks(blocks, x, rows, widths, pack):
+    """blocks: flat concatenation over ranks of [rows, widths[s]] matrices; x: [rows, sum(widths)] contiguous.  pack=False:
+    x <- blocks (after the forward all-to-all); pack=True: blocks <- x (before the backward one).  One launch."""
+    import ctypes
+    C.require_cuda(blocks, x)
+    if not (blocks.is_contiguous() and x.is_contiguous()) or blocks.dtype != x.dtype or blocks.numel() != x.numel():
+        raise ValueError("a2a_blocks: contiguous buffers of one dtype and size")
+    if x.numel() != rows * sum(widths):
+        raise ValueError("a2a_blocks: x must hold rows x sum(widths) elements")
+    w = (ctypes.c_int * len(widths))(*[int(v) for v in widths])
+    C.call("dle_a2a_blocks", C.ptr(blocks), C.ptr(x), int(rows), len(widths), ctypes.cast(w, ctypes.c_void_p), x.element_size(),
+           int(bool(pack)), C.stream())
+    return blocks if pack else x
+
+
 def transpose_cast(x, out_dtype, out=None):
     """out[c, r] = (out_dtype) x[r, c] for a 2-D fp32 / 16-bit matrix with unit inner stride: the transposed 16-bit working copy."""
     C.require_cuda(x, out)

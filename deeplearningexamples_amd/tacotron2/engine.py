@@ -68,6 +68,7 @@ class Tacotron2Trainer:
                                        comm_stream=self.comm_stream, reverse=True)
             from ..utils.comm import broadcast_
             broadcast_(self.p.flat, 0, process_group)
+            self._rev_names = [n for n, _, _ in reversed(list(model.layout))]
 
     # ------------------------------------------------------------------ helpers
     def _z(self, *shape, dtype=None):
@@ -302,6 +303,7 @@ class Tacotron2Trainer:
         b, ti, to, dt, cfg = sv["b"], sv["ti"], sv["to"], self.dtype, self.cfg
         f32 = torch.float32
         r = b * to
+        self._rev_pos = 0
         # ---- postnet
         npc = cfg["postnet_n_convolutions"]
         dy = sv["d_post"]
@@ -320,6 +322,7 @@ class Tacotron2Trainer:
         g["decoder.linear_projection.linear_layer.bias"].copy_(dbp[:NM])
         g["decoder.gate_layer.linear_layer.bias"].copy_(dbp[NM:NM + 1])
         dhc = F.gemm(d_out, w["proj"], r, Hd + E, NO, True, False, out_dtype=f32).view(b, to, Hd + E)
+        self._grads_final(("postnet.", "decoder.gate_layer.", "decoder.linear_projection."))    # reduced under the whole sweep
         # ---- decoder BPTT
         memory, pm = sv["memory"], sv["pm"]
         x_a, x_d, ga, gd, ac, dc, aw, awc = sv["x_a"], sv["x_d"], sv["ga"], sv["gd"], sv["ac"], sv["dc"], sv["aw"], sv["awc"]
@@ -425,6 +428,7 @@ class Tacotron2Trainer:
         d_l1d = F.gemm(d_pre2, w["pre1"], r_all, P, P, True, False)
         d_pre1 = self._relu_mask(F.dropout_bwd(d_l1d, sv["m1"], 0.5), sv["l1"])
         self._wgrad(d_pre1, sv["dec_in"].view(r_all, NM), g["decoder.prenet.layers.0.linear_layer.weight"], r_all)
+        self._grads_final(("decoder.",))                                # reduced under the encoder's backward pass
         # ---- encoder: bi-LSTM BPTT, convolutions, embedding
         dm3 = d_memory.view(b, ti, E)
         x_enc = sv["enc_out"]
@@ -452,11 +456,20 @@ class Tacotron2Trainer:
             dy = self._conv_bn_bwd(dy, sv["enc"][i], b, ti, w["enc%d" % i])
         g["embedding.weight"].zero_()
         F.embed_scatter_add_(g["embedding.weight"], dy, sv["text"])
-        if self.buckets is not None:
-            for _, _, name in self.buckets.buckets:
-                self.buckets.grad_ready(name)
+        self._grads_final(None)                                        # encoder + embedding: everything that is left
         if self._rng_calls:
             self._rng_base += self._rng_calls          # on the device: the next step (or graph replay) draws new masks
+
+    def _grads_final(self, prefixes):
+        """Gradients complete from the END of the flat buffer (postnet, projection, ... , embedding = reverse layout order).  Walk
+        the layout backwards over every parameter whose name starts with one of `prefixes` (None: all that is left) and fire the
+        buckets they close: their all-reduce runs on the communication stream under the rest of the backward pass."""
+        if self.buckets is None:
+            return
+        names = self._rev_names
+        while self._rev_pos < len(names) and (prefixes is None or names[self._rev_pos].startswith(prefixes)):
+            self.buckets.grad_ready(names[self._rev_pos])
+            self._rev_pos += 1
 
     def _relu_mask(self, g, y):
         out = torch.empty_like(g)

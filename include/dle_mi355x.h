@@ -182,6 +182,11 @@ int dle_cast_rows(const void* in, void* out, int64_t rows, int cols, int cols_ou
  * recurrent cells, model.py:405-455 backward); torch.nn.LSTMCell's backward reads weight.t() the same way. */
 int dle_transpose_cast(const void* x, void* y, int rows, int cols, int64_t ld_x, int64_t ld_y, int in_dtype, int out_dtype,
                        hipStream_t stream);
+/* Exchange buffer <-> interaction input of the DLRM bottom -> top all-to-all (dlrm/model/distributed.py:32-98: torch.cat(dim=1) of
+ * the received blocks forward, the split of the gradient backward).  blocks = concatenation over ranks s of contiguous
+ * [rows, widths[s]] matrices; x = [rows, sum widths]; pack = 0: x <- blocks, 1: blocks <- x.  widths in elements (host array of
+ * `world` <= 8 ints), widths[s] * elem_size a multiple of 16. */
+int dle_a2a_blocks(void* blocks, void* x, int rows, int world, const int* widths, int elem_size, int pack, hipStream_t stream);
 int dle_bce_logits(const void* logits, const float* target, float* loss_out, void* dlogits,
                    const float* grad_scale_dev, int64_t n, int64_t ld_logits, int dtype, hipStream_t stream);
 int dle_amp_update_scale(float* scale, int* growth_tracker, float* found_inf, float* inv_scale,

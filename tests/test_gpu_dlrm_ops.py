@@ -216,3 +216,22 @@ def test_dot_interact_bwd_reports_nonfinite(cuda, dtype, force_generic):
         F.dot_interact_bwd(x * 200, up * 200, force_generic=force_generic, fuse_mlp_grad=True, found_inf=flag)
         big, _ = F.dot_interact_bwd(x * 200, up * 200, force_generic=force_generic, fuse_mlp_grad=True)
         assert flag.item() == (0.0 if bool(torch.isfinite(big.float()).all()) else 1.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+def test_a2a_blocks_pack_and_unpack(cuda, dtype):
+    """The bottom -> top exchange buffer <-> interaction input (dlrm/model/distributed.py:32-98: torch.cat(dim=1) of the received
+    blocks forward, the split of the gradient backward) as ONE launch per direction, bit exact."""
+    from deeplearningexamples_amd import functional as F
+    g = torch.Generator().manual_seed(3)
+    rows, d = 37, 128
+    for vectors in ([1, 4, 4, 4, 4, 4, 4, 2], [0, 3, 5], [7]):
+        widths = [v * d for v in vectors]
+        blocks = [torch.randn(rows, w, generator=g).to(dtype) for w in widths]
+        flat = torch.cat([b.reshape(-1) for b in blocks]).to(cuda)
+        x = torch.empty(rows, sum(widths), dtype=dtype, device=cuda)
+        F.a2a_blocks(flat, x, rows, widths, pack=False)
+        assert torch.equal(x.cpu(), torch.cat(blocks, dim=1))
+        back = torch.zeros_like(flat)
+        F.a2a_blocks(back, x, rows, widths, pack=True)
+        assert torch.equal(back, flat)
