@@ -16,7 +16,7 @@
 //    16-byte chunk s ^ (r & 15); a fragment read (16 rows x one k chunk per 16-lane group) then touches 16 distinct slots of
 //    the 256-byte bank window;
 //  * v_mfma_f32_16x16x32 with the WEIGHT rows as the first operand: a lane ends up with 4 consecutive output columns of one row
-//    (8 / 16-byte stores); 4 wavefronts, one 16-row block each, TN / 16 column blocks.
+//    (8 / 16-byte stores); one 16 x 16 block per wavefront (8 wavefronts for TN = 32).
 // Epilogue: alpha, bias[n], 16-bit addend (DLE_ACT_ADD), fp32 accumulate, fp32 or 16-bit output.
 #include "gemm_tiles.h"
 
@@ -49,17 +49,17 @@ template <> struct Mfma16x32<DLE_BF16> {
 
 // One K chunk of the workgroup's (SM_TS + TN)-row operand panel into `stage`.  NPW pieces per wavefront; piece q covers rows
 // 4q .. 4q + 3 (A rows first); lane l -> row 4q + (l >> 4), LDS slot l & 15, source chunk slot ^ (row & 15).
-template <int TN>
+template <int TN, int NW>
 struct SmallMLoader {
-  static constexpr int R = SM_TS + TN, NPW = R / 16;
+  static constexpr int R = SM_TS + TN, NPW = R / 4 / NW, NPA = SM_TS / 4 / NW;     // pieces per wave: all / of the A rows
   unsigned off[NPW];        // byte offset of (row, chunk) inside its operand, k0 = 0
   int kin[NPW];             // first k element of the lane's chunk
   bool ok[NPW];
   __device__ __forceinline__ void init(const SmallMArgs& p, int wave, int lane, int m0, int n0) {
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
-      const int q = wave + 4 * j, row = 4 * q + (lane >> 4), chunk = (lane & 15) ^ (row & 15);
-      const bool is_a = row < SM_TS;
+      const int q = wave + NW * j, row = 4 * q + (lane >> 4), chunk = (lane & 15) ^ (row & 15);
+      const bool is_a = j < NPA;                 // (wave + NW j < 16 <=> j < 16 / NW: a piece lies entirely in one operand)
       const int g = is_a ? m0 + row : n0 + row - SM_TS;
       ok[j] = is_a ? g < p.M : g < p.N;
       kin[j] = chunk * 8;
@@ -67,12 +67,15 @@ struct SmallMLoader {
     }
   }
   __device__ __forceinline__ void issue(const SmallMArgs& p, unsigned short* stage, int wave, int k0) {
-    const int4v_t ra = rsrc_words(p.A), rb = rsrc_words(p.B);
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
-      const int q = wave + 4 * j;
+      const int q = wave + NW * j;
       const bool valid = ok[j] && k0 + kin[j] < p.K;
-      dma16_raw(4 * q < SM_TS ? ra : rb, stage + q * 512, valid ? off[j] + (unsigned)k0 * 2u : OOB_OFF);
+      const unsigned voff = valid ? off[j] + (unsigned)k0 * 2u : OOB_OFF;
+      // (the descriptor is rebuilt at the use: its words reach the asm statement straight from readfirstlane and stay in SGPRs;
+      //  `wave` itself must come through readfirstlane too, or hipcc treats everything derived from it as divergent)
+      if (j < NPA) dma16_raw(rsrc_words(p.A), stage + q * 512, voff);
+      else dma16_raw(rsrc_words(p.B), stage + q * 512, voff);
     }
   }
 };
@@ -86,13 +89,16 @@ __device__ __forceinline__ void sm_wait_chunks(int c) {
   });
 }
 
-// NST stages of (64 + TN) x 256 B: NST - 1 chunks in flight while one is multiplied.  These launches are latency bound (one
-// workgroup per CU streams 0.3-0.8 MB through L2): the bytes in flight per CU set the rate, so the launcher gives a workgroup
-// ~140 KiB of stages when the grid is at most one workgroup per CU and ~80 KiB (two per CU) otherwise.
-template <int DT, int TN, int NST>
-__global__ __launch_bounds__(256) void gemm_smallm_kernel(SmallMArgs p) {
-  typedef SmallMLoader<TN> L;
-  constexpr int R = L::R, NB = TN / 16, STAGE = R * SM_BKE;      // halves per stage
+// NST stages of (64 + TN) x 256 B: NST - 1 chunks in flight while one is multiplied.  (Deeper rings -- 6-7 stages, ~140 KiB per
+// workgroup -- measured 5-20 % SLOWER: the limit was the issue cost of the pieces, next comment, not the bytes in flight.)
+// NW wavefronts: 8 for the 64 x 32 tile, 4 for 64 x 16 -- ONE 16 x 16 output block per wavefront.  An LDS-DMA piece costs the
+// issuing wavefront ~100-180 cycles (MI355X_MICROARCH.md): with 4 wavefronts issuing 6 pieces per chunk each, the first version
+// of this kernel was bound by that issue cost (42 GB/s per CU whatever the pipeline depth); 8 wavefronts issue 3 each.
+template <int DT, int TN, int NW, int NST>
+__global__ __launch_bounds__(NW * 64) void gemm_smallm_kernel(SmallMArgs p) {
+  typedef SmallMLoader<TN, NW> L;
+  static_assert(4 * (TN / 16) == NW, "one 16x16 block per wavefront");
+  constexpr int R = L::R, STAGE = R * SM_BKE;      // halves per stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned short* lds = (unsigned short*)smem_raw;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -105,10 +111,9 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(SmallMArgs p) {
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
     if (s < nk) ld.issue(p, lds + s * STAGE, wave, s * SM_BKE);
-  float4_t acc[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) acc[b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  float4_t acc = {0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, kg = lane >> 4;
+  const int mb = wave & 3, nb = wave >> 2;         // this wavefront's block: rows 16 mb.., columns 16 nb..
   for (int kt = 0; kt < nk; ++kt) {
     // this wave's pieces of chunk kt have landed; the (at most NST - 2) younger chunks stay in flight
     const int younger = nk - 1 - kt;
@@ -116,29 +121,26 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(SmallMArgs p) {
     lds_barrier();                           // ... and everybody's; the stage the next chunk will overwrite is no longer read
     if (kt + NST - 1 < nk) ld.issue(p, lds + ((kt + NST - 1) % NST) * STAGE, wave, (kt + NST - 1) * SM_BKE);
     const unsigned short* st = lds + (kt % NST) * STAGE;
-    const unsigned short* xa = st + (wave * 16 + fr) * SM_BKE;
+    const unsigned short* xa = st + (mb * 16 + fr) * SM_BKE;
+    const unsigned short* wa = st + (SM_TS + nb * 16 + fr) * SM_BKE;
 #pragma unroll
     for (int ks = 0; ks < SM_BKE / 32; ++ks) {
       const int slot = (ks * 4 + kg) ^ fr;
       const ushort8_t fx = *(const ushort8_t*)(xa + slot * 8);
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const ushort8_t fw = *(const ushort8_t*)(st + (SM_TS + b * 16 + fr) * SM_BKE + slot * 8);
-        acc[b] = Mfma16x32<DT>::run(fw, fx, acc[b]);
-      }
+      const ushort8_t fw = *(const ushort8_t*)(wa + slot * 8);
+      acc = Mfma16x32<DT>::run(fw, fx, acc);
     }
   }
-  // lane: row m = m0 + 16 wave + (lane & 15), columns n0 + 16 b + 4 (lane >> 4) + {0..3}
-  const int m = m0 + wave * 16 + fr;
+  // lane: row m = m0 + 16 mb + (lane & 15), columns n0 + 16 nb + 4 (lane >> 4) + {0..3}
+  const int m = m0 + mb * 16 + fr;
   if (m >= p.M) return;
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int n = n0 + b * 16 + 4 * kg;
-    if (n >= p.N) continue;
+  {
+    const int n = n0 + nb * 16 + 4 * kg;
+    if (n >= p.N) return;
     const int nval = p.N - n < 4 ? p.N - n : 4;
     float v[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = acc[b][r] * p.alpha;
+    for (int r = 0; r < 4; ++r) v[r] = acc[r] * p.alpha;
     if (p.bias) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) if (r < nval) v[r] += p.bias[n + r];
@@ -188,24 +190,25 @@ extern "C" int dle_gemm_smallm_try(const void* A, const void* B, void* C, const 
   SmallMArgs p = {(const unsigned short*)A, (const unsigned short*)B, C, bias, (const unsigned short*)src, M, N, K,
                   (long long)lda, (long long)ldb, (long long)ldc, out_dtype, act_add, accumulate, alpha};
   const int tm = (M + SM_TS - 1) / SM_TS;
-  const int tiles32 = tm * ((N + 31) / 32), tiles16 = tm * ((N + 15) / 16);
-  const bool wide = tiles32 >= 128;               // fewer, fatter workgroups: less re-reading of the A rows through L2
-  const int tiles = wide ? tiles32 : tiles16;
-  const bool deep = tiles <= 256;                 // at most one workgroup per CU: give it the CU's LDS
-#define GO(DT, TN, NST)                                                                                                        \
+  // 64 x 32 tiles (8 wavefronts) unless that leaves more than half of the CUs without a workgroup while 64 x 16 tiles would not
+  const int t32 = tm * ((N + 31) / 32), t16 = tm * ((N + 15) / 16);
+  const bool wide = N > 16 && (t32 >= 128 || t16 > 256);
+  const int tiles = wide ? t32 : t16;
+  const bool deep = tiles <= 256;                 // at most one workgroup per CU: four stages; else three (two workgroups per CU)
+#define GO(DT, TN, NW, NST)                                                                                                    \
   do {                                                                                                                         \
     constexpr int lds_bytes = NST * (SM_TS + TN) * SM_BKE * 2;                                                                 \
     static bool attr_set = false;                                                                                              \
     if (!attr_set) {                                                                                                           \
-      (void)hipFuncSetAttribute((const void*)gemm_smallm_kernel<DT, TN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+      (void)hipFuncSetAttribute((const void*)gemm_smallm_kernel<DT, TN, NW, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
       attr_set = true;                                                                                                         \
     }                                                                                                                          \
-    hipLaunchKernelGGL((gemm_smallm_kernel<DT, TN, NST>), dim3(tiles), dim3(256), lds_bytes, stream, p);                       \
+    hipLaunchKernelGGL((gemm_smallm_kernel<DT, TN, NW, NST>), dim3(tiles), dim3(NW * 64), lds_bytes, stream, p);               \
   } while (0)
 #define PICK(DT)                                                            \
   do {                                                                      \
-    if (wide) { if (deep) GO(DT, 32, 6); else GO(DT, 32, 3); }              \
-    else { if (deep) GO(DT, 16, 7); else GO(DT, 16, 4); }                   \
+    if (wide) { if (deep) GO(DT, 32, 8, 4); else GO(DT, 32, 8, 3); }        \
+    else GO(DT, 16, 4, 4);                                                  \
   } while (0)
   if (in_dtype == DLE_F16) PICK(DLE_F16); else PICK(DLE_BF16);
 #undef PICK
