@@ -137,8 +137,9 @@ _SIGS = {
                                 c_i64, c_float, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
     "dle_t2_lstm_bwd": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_void_p,
                                 c_i64, c_void_p, c_void_p, c_i64, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "dle_t2_attention_fwd": (c_int, [c_void_p] * 10 + [c_i64, c_void_p, c_i64, c_void_p, c_i64] + [c_int] * 5 + [c_void_p]),
-    "dle_t2_attention_bwd": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64] + [c_void_p] * 13 + [c_int] * 5 + [c_void_p]),
+    "dle_t2_attention_fwd": (c_int, [c_void_p] * 10 + [c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "dle_t2_attention_bwd": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64] + [c_void_p] * 14 + [c_int, c_int, c_void_p, c_void_p] +
+                             [c_int] * 5 + [c_void_p]),
     "dle_a2a_blocks": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "dle_t2_sum_steps": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p]),
     "dle_t2_location_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

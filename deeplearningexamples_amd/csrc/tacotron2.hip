@@ -10,7 +10,7 @@
 //   tacotron2/loss_function.py:42-44    the two MSE terms of Tacotron2Loss and their gradient            -> t2_mel_loss
 // The decoder state is one row per sample (B ~ 50-100 rows): these are latency-bound kernels of a sequential loop, one thread per
 // (sample, unit) for the cells, one workgroup per sample for the attention (wave64 shuffle reductions over channels).
-#include "common.h"
+#include "gemm_tiles.h"
 
 #define T2_BLOCK 256
 
@@ -199,7 +199,13 @@ __global__ __launch_bounds__(128) void t2_lstm_bwd_kernel(const float* __restric
 #define T2A_NW (T2A_BLOCK / 64)
 
 // q fp32 [B, A]; pl [B*Ti, A] (processed memory + location term); v fp32 [A]; memory [B*Ti, E].
-// LDS: Ti floats (energies -> weights) + 16 (reductions) + T2A_NW x E (context partials).
+// wloc != NULL: `pl` is the processed memory ALONE and the location term (model.py:40-76: Conv1d(2 -> F, k = KL) on (previous,
+// cumulative) weights + Linear(F -> A), pre-multiplied by the caller into ONE [A, KK] matrix, k = tap * 2 + channel, KK = KL * 2
+// rounded up to 16, zero padded) is formed here on the matrix cores: the sample's (Ti + KL) x 2 weights sit in LDS, the im2col
+// operand of v_mfma_f32_32x32x16 is four consecutive LDS dwords per lane, the [Ti, A] result goes through LDS (fp32) to the
+// energy pass.  That removes, per decoder step, the row gather (10 MB written), a [B*Ti, A, KL*8] GEMM over 3/4 zero padding and
+// the round trip of the summed term through HBM (taps 4.5 us + GEMM 12 us -> ~2 us inside this kernel).
+// LDS: Ti floats (energies -> weights) + 16 (reductions) + T2A_NW x E (context partials) [+ Ti32 x (A + 4) + Ti32 + KK / 2 + 8].
 template <int DT>
 __global__ __launch_bounds__(T2A_BLOCK) void t2_attention_fwd_kernel(const float* __restrict__ q, const unsigned short* __restrict__ pl,
                                                                      const float* __restrict__ v, const unsigned short* __restrict__ memory,
@@ -208,15 +214,47 @@ __global__ __launch_bounds__(T2A_BLOCK) void t2_attention_fwd_kernel(const float
                                                                      unsigned short* __restrict__ tanh_out, float* __restrict__ aw_out,
                                                                      unsigned short* __restrict__ awc_next, unsigned short* d0, long long ld0,
                                                                      unsigned short* d1, long long ld1, unsigned short* d2, long long ld2,
-                                                                     int Ti, int A, int E, int lpa, int lpe) {
+                                                                     int Ti, int A, int E, int lpa, int lpe,
+                                                                     const unsigned short* __restrict__ wloc, int KL, int KK) {
   extern __shared__ float sm[];
-  float* en = sm;                 // [Ti]
-  float* red = sm + Ti;           // [16]
+  float* en = sm;                 // [Ti] (padded to a multiple of 4: what follows is read 16 bytes at a time)
+  float* red = sm + ((Ti + 3) & ~3);   // [16]
   float* part = red + 16;         // [T2A_NW][E]
+  const int Ti32 = (Ti + 31) & ~31, LS = A + 4;
+  float* loc = part + T2A_NW * E; // [Ti32][A + 4]  (wloc only)
+  unsigned* seq = (unsigned*)(loc + (size_t)Ti32 * LS);     // [Ti32 + KK / 2 + 8]: (previous, cumulative) weights, zero padded
   const int b = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int len = (int)lengths[b];
   if (len > Ti) len = Ti;
+  if (wloc) {
+    const int pad = KL / 2;
+    for (int p = threadIdx.x; p < Ti32 + KK / 2 + 8; p += T2A_BLOCK) {
+      const int t = p - pad;
+      unsigned x = 0;
+      if (t >= 0 && t < Ti && awc_prev) x = *(const unsigned*)(awc_prev + ((long long)b * Ti + t) * 8);
+      seq[p] = x;
+    }
+    __syncthreads();
+    const int nab = A >> 5, ntb = Ti32 >> 5, fr = lane & 31, fh = lane >> 5;
+    for (int job = wave; job < nab * ntb; job += T2A_NW) {
+      const int ab = job % nab, tb = job / nab;
+      float16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int ks = 0; ks < KK / 16; ++ks) {
+        const ushort8_t fa = *(const ushort8_t*)(wloc + (long long)(ab * 32 + fr) * KK + ks * 16 + fh * 8);
+        const unsigned* sp = seq + tb * 32 + fr + ks * 8 + fh * 4;         // taps ks*8 + fh*4 .. + 3, both channels
+        const uint4_t xb = {sp[0], sp[1], sp[2], sp[3]};
+        acc = Mfma32x16<DT>::run(fa, __builtin_bit_cast(ushort8_t, xb), acc);
+      }
+      // lane: position t = tb*32 + fr, channels ab*32 + 8 g + 4 fh + {0..3}
+      float* lp = loc + (size_t)(tb * 32 + fr) * LS + ab * 32 + 4 * fh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *(float4_t*)(lp + 8 * g) = (float4_t){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    }
+    __syncthreads();
+  }
   {
     const int sub = lane & (lpa - 1), rin = lane / lpa, rpp = 64 / lpa;
     const bool act = sub * 8 < A;
@@ -230,6 +268,12 @@ __global__ __launch_bounds__(T2A_BLOCK) void t2_attention_fwd_kernel(const float
       const long long row = (long long)b * Ti + tc;
       float xf[8], th[8], tr[8];
       unpack8<DT>(*(const ushort8_t*)(pl + row * A + col), xf);
+      if (wloc) {
+        const float* lp = loc + (size_t)tc * LS + col;
+        const float4_t l0 = *(const float4_t*)lp, l1 = *(const float4_t*)(lp + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { xf[r] += l0[r]; xf[4 + r] += l1[r]; }
+      }
 #pragma unroll
       for (int r = 0; r < 8; ++r) th[r] = fast_tanh(qv[r] + xf[r]);
       const ushort8_t o = pack8<DT>(th);
@@ -321,17 +365,28 @@ template <int DT>
 __global__ __launch_bounds__(T2A_BLOCK) void t2_attention_bwd_kernel(const float* __restrict__ dc0, long long ldc0,
                                                                      const float* __restrict__ dc1, long long ldc1,
                                                                      const float* __restrict__ dc2, long long ldc2,
-                                                                     const float* __restrict__ daw0, const float* __restrict__ daw1,
+                                                                     const float* daw0, const float* daw1,
                                                                      const float* __restrict__ aw, const unsigned short* __restrict__ tanh_out,
                                                                      const float* __restrict__ v, const unsigned short* __restrict__ memory,
                                                                      float* __restrict__ d_memory, unsigned short* __restrict__ d_pl,
                                                                      float* __restrict__ dq, unsigned short* __restrict__ dq16,
                                                                      unsigned short* __restrict__ dctx16, float* __restrict__ dv_acc,
-                                                                     float* __restrict__ d_pm_acc, int Ti, int A, int E, int lpa, int lpe) {
+                                                                     float* __restrict__ d_pm_acc, int Ti, int A, int E, int lpa, int lpe,
+                                                                     const unsigned short* __restrict__ wlocT, int KL, int KK,
+                                                                     float* d_prev, float* d_cum) {
   extern __shared__ float sm[];
-  float* de = sm;                           // [Ti]
-  float* red = sm + Ti;                     // [16]
+  float* de = sm;                           // [Ti] (padded to a multiple of 4)
+  float* red = sm + ((Ti + 3) & ~3);        // [16]
   float* part = red + 16;                   // [T2A_NW][2][A]
+  // wlocT != NULL: the backward of the location term (the transposed convolution) runs here too: d_pl stays in LDS (16-bit),
+  // dcol = d_pl x W_loc on the matrix cores, its anti-diagonal sums are the gradients of the previous / cumulative weights
+  const int Ti32 = (Ti + 31) & ~31, PS = A + 8, CS = KK + 4;
+  unsigned short* dpl_l = (unsigned short*)(part + T2A_NW * 2 * A);        // [Ti32][A + 8] 16-bit
+  float* dcol_l = (float*)(dpl_l + (size_t)Ti32 * PS);                     // [Ti32][KK + 4] fp32
+  if (wlocT) {
+    for (int i = Ti * PS / 8 + threadIdx.x; i < Ti32 * PS / 8; i += T2A_BLOCK)
+      ((ushort8_t*)dpl_l)[i] = (ushort8_t){0, 0, 0, 0, 0, 0, 0, 0};        // rows past the sample: zero operand rows
+  }
   const int b = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   {
@@ -396,7 +451,11 @@ __global__ __launch_bounds__(T2A_BLOCK) void t2_attention_bwd_kernel(const float
         accq[r] += dpre[r];
         accv[r] += e * th[r];
       }
-      if (t < Ti && act) *(ushort8_t*)(d_pl + row * A + col) = pack8<DT>(dpre);
+      if (t < Ti && act) {
+        const ushort8_t pv = pack8<DT>(dpre);
+        *(ushort8_t*)(d_pl + row * A + col) = pv;
+        if (wlocT) *(ushort8_t*)(dpl_l + (size_t)t * PS + col) = pv;
+      }
       if (d_pm_acc && t < Ti && act) {            // NULL: the caller sums the kept d_pl over the steps itself (dle_t2_sum_steps)
         float* pm = d_pm_acc + row * A + col;
         float4_t p0 = *(float4_t*)pm, p1 = *(float4_t*)(pm + 4);
@@ -423,6 +482,38 @@ __global__ __launch_bounds__(T2A_BLOCK) void t2_attention_bwd_kernel(const float
     if (dq) dq[(long long)b * A + a] = sq;
     if (dq16) dq16[(long long)b * A + a] = Elem<DT>::from_f32(sq);
     dv_acc[(long long)b * A + a] += sv;
+  }
+  if (wlocT) {
+    // dcol[t, k] = sum_a d_pl[t, a] W_loc[a, k]: first operand = rows k of W_loc^T (a contiguous), second = rows t of d_pl
+    const int nkb = KK >> 5, ntb = Ti32 >> 5, fr = lane & 31, fh = lane >> 5;
+    for (int job = wave; job < nkb * ntb; job += T2A_NW) {
+      const int kb = job % nkb, tb = job / nkb;
+      float16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int ks = 0; ks < A / 16; ++ks) {
+        const ushort8_t fa = *(const ushort8_t*)(wlocT + (long long)(kb * 32 + fr) * A + ks * 16 + fh * 8);
+        const ushort8_t fb = *(const ushort8_t*)(dpl_l + (size_t)(tb * 32 + fr) * PS + ks * 16 + fh * 8);
+        acc = Mfma32x16<DT>::run(fa, fb, acc);
+      }
+      float* cp = dcol_l + (size_t)(tb * 32 + fr) * CS + kb * 32 + 4 * fh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *(float4_t*)(cp + 8 * g) = (float4_t){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    }
+    __syncthreads();
+    // col[(t), j*2 + c] = weights[t + j - pad][c]  =>  d weights[s][c] = sum_j dcol[s - j + pad][j*2 + c]
+    const int pad = KL / 2;
+    for (int i = threadIdx.x; i < 2 * Ti; i += T2A_BLOCK) {
+      const int sx = i >> 1, c = i & 1;
+      float acc = 0.f;
+      for (int j = 0; j < KL; ++j) {
+        const int t = sx - j + pad;
+        if (t >= 0 && t < Ti) acc += dcol_l[(size_t)t * CS + j * 2 + c];
+      }
+      const long long o = (long long)b * Ti + sx;
+      if (c == 0) d_prev[o] = acc;           // gradient of weights_{t-1} through the "previous weights" channel
+      else d_cum[o] += acc;                  // cumulative weights feed every later step: accumulated
+    }
   }
 }
 
@@ -563,28 +654,38 @@ static int t2_pow2_ge(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
 extern "C" int dle_t2_attention_fwd(const float* q, const void* pl, const float* v, const void* memory, const int64_t* lengths,
                                     const void* awc_prev, void* tanh_out, float* aw_out, void* awc_next, void* d0, int64_t ld0,
-                                    void* d1, int64_t ld1, void* d2, int64_t ld2, int B, int Ti, int A, int E, int dtype,
-                                    hipStream_t stream) {
+                                    void* d1, int64_t ld1, void* d2, int64_t ld2, const void* wloc, int KL, int KK, int B, int Ti,
+                                    int A, int E, int dtype, hipStream_t stream) {
   DLE_CHECK_ARG(q && pl && v && memory && lengths && tanh_out && aw_out && awc_next && B > 0 && Ti > 0 && A > 0 && E > 0,
                 "t2_attention_fwd: bad args");
   DLE_CHECK_ARG(Ti <= 8192 && ((((uintptr_t)awc_next) | ((uintptr_t)awc_prev)) & 15) == 0, "t2_attention_fwd: Ti <= 8192, aligned weights rows");
   DLE_CHECK_ARG(A % 8 == 0 && E % 8 == 0 && A <= 512 && E <= 512, "t2_attention_fwd: A, E multiples of 8, at most 512 (got %d, %d)", A, E);
-  DLE_CHECK_ARG(((((uintptr_t)q) | ((uintptr_t)pl) | ((uintptr_t)v) | ((uintptr_t)memory) | ((uintptr_t)tanh_out)) & 15) == 0,
+  DLE_CHECK_ARG(((((uintptr_t)q) | ((uintptr_t)pl) | ((uintptr_t)v) | ((uintptr_t)memory) | ((uintptr_t)tanh_out) | ((uintptr_t)wloc)) & 15) == 0,
                 "t2_attention_fwd: 16-byte aligned tensors");
   T2_DT_CHECK("t2_attention_fwd");
-  const size_t lds = ((size_t)Ti + 16 + (size_t)T2A_NW * E) * 4;
-  DLE_CHECK_ARG(lds <= 64000, "t2_attention_fwd: Ti too large for one workgroup's LDS");
+  const int Ti32 = (Ti + 31) & ~31;
+  if (!wloc) KK = 0;
+  DLE_CHECK_ARG(!wloc || (KL > 0 && (KL & 1) && A % 32 == 0 && KK % 16 == 0 && KK >= 2 * KL),
+                "t2_attention_fwd: the fused location term needs an odd kernel size, A %% 32 == 0 and rows of KK >= 2 KL, KK %% 16 == 0");
+  size_t lds = ((size_t)((Ti + 3) & ~3) + 16 + (size_t)T2A_NW * E) * 4;
+  if (wloc) lds += ((size_t)Ti32 * (A + 4) + Ti32 + KK / 2 + 8) * 4;
+  DLE_CHECK_ARG(lds <= 160 * 1024, "t2_attention_fwd: Ti too large for one workgroup's LDS");
   const int lpa = t2_pow2_ge(A / 8), lpe = t2_pow2_ge(E / 8);
-  if (dtype == DLE_F16)
-    hipLaunchKernelGGL(t2_attention_fwd_kernel<DLE_F16>, dim3(B), dim3(T2A_BLOCK), lds, stream, q, (const unsigned short*)pl, v,
-                       (const unsigned short*)memory, (const long long*)lengths, (const unsigned short*)awc_prev,
-                       (unsigned short*)tanh_out, aw_out, (unsigned short*)awc_next, (unsigned short*)d0, (long long)ld0,
-                       (unsigned short*)d1, (long long)ld1, (unsigned short*)d2, (long long)ld2, Ti, A, E, lpa, lpe);
-  else
-    hipLaunchKernelGGL(t2_attention_fwd_kernel<DLE_BF16>, dim3(B), dim3(T2A_BLOCK), lds, stream, q, (const unsigned short*)pl, v,
-                       (const unsigned short*)memory, (const long long*)lengths, (const unsigned short*)awc_prev,
-                       (unsigned short*)tanh_out, aw_out, (unsigned short*)awc_next, (unsigned short*)d0, (long long)ld0,
-                       (unsigned short*)d1, (long long)ld1, (unsigned short*)d2, (long long)ld2, Ti, A, E, lpa, lpe);
+#define T2_ATT_FWD(DT)                                                                                                              \
+  do {                                                                                                                              \
+    static size_t lds_set = 0;                                                                                                      \
+    if (lds > 65536 && lds > lds_set) {                                                                                             \
+      (void)hipFuncSetAttribute((const void*)t2_attention_fwd_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+      lds_set = lds;                                                                                                                \
+    }                                                                                                                               \
+    hipLaunchKernelGGL(t2_attention_fwd_kernel<DT>, dim3(B), dim3(T2A_BLOCK), lds, stream, q, (const unsigned short*)pl, v,         \
+                       (const unsigned short*)memory, (const long long*)lengths, (const unsigned short*)awc_prev,                   \
+                       (unsigned short*)tanh_out, aw_out, (unsigned short*)awc_next, (unsigned short*)d0, (long long)ld0,           \
+                       (unsigned short*)d1, (long long)ld1, (unsigned short*)d2, (long long)ld2, Ti, A, E, lpa, lpe,                \
+                       (const unsigned short*)wloc, KL, KK);                                                                        \
+  } while (0)
+  if (dtype == DLE_F16) T2_ATT_FWD(DLE_F16); else T2_ATT_FWD(DLE_BF16);
+#undef T2_ATT_FWD
   DLE_LAUNCH_CHECK();
   return 0;
 }
@@ -592,29 +693,39 @@ extern "C" int dle_t2_attention_fwd(const float* q, const void* pl, const float*
 extern "C" int dle_t2_attention_bwd(const float* d_ctx0, int64_t ld_c0, const float* d_ctx1, int64_t ld_c1, const float* d_ctx2,
                                     int64_t ld_c2, const float* d_aw0, const float* d_aw1, const float* aw, const void* tanh_out,
                                     const float* v, const void* memory, float* d_memory, void* d_pl, float* dq, void* dq16,
-                                    void* dctx16, float* dv_acc, float* d_pm_acc, int B, int Ti, int A, int E, int dtype,
-                                    hipStream_t stream) {
+                                    void* dctx16, float* dv_acc, float* d_pm_acc, const void* wlocT, int KL, int KK, float* d_prev,
+                                    float* d_cum, int B, int Ti, int A, int E, int dtype, hipStream_t stream) {
   DLE_CHECK_ARG(d_ctx0 && d_aw0 && aw && tanh_out && v && memory && d_pl && (dq || dq16) && dv_acc && B > 0 && Ti > 0 &&
                 A > 0 && E > 0, "t2_attention_bwd: bad args");
   DLE_CHECK_ARG(A % 8 == 0 && E % 8 == 0 && A <= 512 && E <= 512, "t2_attention_bwd: A, E multiples of 8, at most 512 (got %d, %d)", A, E);
   DLE_CHECK_ARG((ld_c0 & 3) == 0 && (!d_ctx1 || (ld_c1 & 3) == 0) && (!d_ctx2 || (ld_c2 & 3) == 0) &&
                 ((((uintptr_t)d_ctx0) | ((uintptr_t)d_ctx1) | ((uintptr_t)d_ctx2) | ((uintptr_t)tanh_out) | ((uintptr_t)memory) |
-                  ((uintptr_t)d_pl) | ((uintptr_t)d_pm_acc) | ((uintptr_t)v) | ((uintptr_t)dctx16)) & 15) == 0,
+                  ((uintptr_t)d_pl) | ((uintptr_t)d_pm_acc) | ((uintptr_t)v) | ((uintptr_t)dctx16) | ((uintptr_t)wlocT)) & 15) == 0,
                 "t2_attention_bwd: 16-byte aligned tensors, row strides of the context gradients multiples of 4");
-  const size_t lds = ((size_t)Ti + 16 + 2 * T2A_NW * (size_t)A) * 4;
-  DLE_CHECK_ARG(lds <= 64000, "t2_attention_bwd: Ti / attention_dim too large for one workgroup's LDS");
+  const int Ti32 = (Ti + 31) & ~31;
+  if (!wlocT) KK = 0;
+  DLE_CHECK_ARG(!wlocT || (KL > 0 && (KL & 1) && A % 16 == 0 && KK % 32 == 0 && KK >= 2 * KL && d_prev && d_cum),
+                "t2_attention_bwd: the fused location backward needs an odd kernel size, A %% 16 == 0, KK >= 2 KL with KK %% 32 == 0, d_prev and d_cum");
+  size_t lds = ((size_t)((Ti + 3) & ~3) + 16 + 2 * T2A_NW * (size_t)A) * 4;
+  if (wlocT) lds += (size_t)Ti32 * (A + 8) * 2 + (size_t)Ti32 * (KK + 4) * 4;
+  DLE_CHECK_ARG(lds <= 160 * 1024, "t2_attention_bwd: Ti / attention_dim too large for one workgroup's LDS");
   T2_DT_CHECK("t2_attention_bwd");
   const int lpa = t2_pow2_ge(A / 8), lpe = t2_pow2_ge(E / 8);
-  if (dtype == DLE_F16)
-    hipLaunchKernelGGL(t2_attention_bwd_kernel<DLE_F16>, dim3(B), dim3(T2A_BLOCK), lds, stream, d_ctx0, (long long)ld_c0, d_ctx1,
-                       (long long)ld_c1, d_ctx2, (long long)ld_c2, d_aw0, d_aw1, aw, (const unsigned short*)tanh_out, v,
-                       (const unsigned short*)memory, d_memory, (unsigned short*)d_pl, dq, (unsigned short*)dq16,
-                       (unsigned short*)dctx16, dv_acc, d_pm_acc, Ti, A, E, lpa, lpe);
-  else
-    hipLaunchKernelGGL(t2_attention_bwd_kernel<DLE_BF16>, dim3(B), dim3(T2A_BLOCK), lds, stream, d_ctx0, (long long)ld_c0, d_ctx1,
-                       (long long)ld_c1, d_ctx2, (long long)ld_c2, d_aw0, d_aw1, aw, (const unsigned short*)tanh_out, v,
-                       (const unsigned short*)memory, d_memory, (unsigned short*)d_pl, dq, (unsigned short*)dq16,
-                       (unsigned short*)dctx16, dv_acc, d_pm_acc, Ti, A, E, lpa, lpe);
+#define T2_ATT_BWD(DT)                                                                                                              \
+  do {                                                                                                                              \
+    static size_t lds_set = 0;                                                                                                      \
+    if (lds > 65536 && lds > lds_set) {                                                                                             \
+      (void)hipFuncSetAttribute((const void*)t2_attention_bwd_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+      lds_set = lds;                                                                                                                \
+    }                                                                                                                               \
+    hipLaunchKernelGGL(t2_attention_bwd_kernel<DT>, dim3(B), dim3(T2A_BLOCK), lds, stream, d_ctx0, (long long)ld_c0, d_ctx1,        \
+                       (long long)ld_c1, d_ctx2, (long long)ld_c2, d_aw0, d_aw1, aw, (const unsigned short*)tanh_out, v,            \
+                       (const unsigned short*)memory, d_memory, (unsigned short*)d_pl, dq, (unsigned short*)dq16,                   \
+                       (unsigned short*)dctx16, dv_acc, d_pm_acc, Ti, A, E, lpa, lpe, (const unsigned short*)wlocT, KL, KK,         \
+                       d_prev, d_cum);                                                                                              \
+  } while (0)
+  if (dtype == DLE_F16) T2_ATT_BWD(DLE_F16); else T2_ATT_BWD(DLE_BF16);
+#undef T2_ATT_BWD
   DLE_LAUNCH_CHECK();
   return 0;
 }

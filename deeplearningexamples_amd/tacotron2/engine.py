@@ -143,6 +143,14 @@ class Tacotron2Trainer:
         w["d_catT"] = F.transpose_cast(w["d_cat"], dt)                                # [Ha + E + Hd, 4 Hd]
         w["qT"] = F.transpose_cast(w["q"], dt)                                        # [Ha, A]
         w["locT"] = F.transpose_cast(w["loc"], dt)                                    # [KL * 8, A]
+        # compact form for the fused location term of the attention kernels: k = tap * 2 + channel (the 6 padding channels of
+        # every tap dropped), zero padded to a multiple of 32
+        self.fuse_loc = A % 32 == 0 and self.KL % 2 == 1
+        if self.fuse_loc:
+            kk = (2 * self.KL + 31) // 32 * 32
+            w["loc2"] = self._z(A, kk)
+            w["loc2"][:, :2 * self.KL].view(A, self.KL, 2).copy_(w["loc"].view(A, self.KL, 8)[:, :, :2])
+            w["loc2T"] = F.transpose_cast(w["loc2"], dt)                              # [KK, A]
         for sfx in ("", "_reverse"):
             w["ehhT" + sfx] = F.transpose_cast(w["ehh" + sfx], dt)                    # [h, 4 h]
         self.w = w
@@ -239,10 +247,15 @@ class Tacotron2Trainer:
             F.gemm(x_a[t], w["a_cat"], b, 4 * Ha, E + Ha, True, True, out=ga[t], act=C.ACT_ADD, mask_src=g_pre[t])
             ops.lstm_fwd(ga[t], ac[t], ac[t + 1], [x_d[t][:, :Ha], x_a[t + 1][:, E:]], keep=keep_a, keep_index=t * b * Ha, p=pa)
             F.gemm(x_d[t][:, :Ha], w["q"], b, A, Ha, True, True, out=q_all[t])
-            wops.taps(awc[t], b, ti, self.KL, 1, self.KL // 2, out=col)
-            F.gemm(col, w["loc"], b * ti, A, self.KL * 8, True, True, act=C.ACT_ADD, mask_src=pm, out=pl)
-            ops.attention_fwd(q_all[t], pl, w["v"], memory, text_lengths, awc[t], tanh_all[t], aw[t], awc[t + 1],
-                              [x_d[t][:, Ha:Ha + E], x_a[t + 1][:, :E], hc[:, t, Hd:]])
+            if self.fuse_loc:
+                # the location term (2-channel k = 31 convolution + dense, one [A, 64] operand) is formed inside the kernel
+                ops.attention_fwd(q_all[t], pm, w["v"], memory, text_lengths, awc[t], tanh_all[t], aw[t], awc[t + 1],
+                                  [x_d[t][:, Ha:Ha + E], x_a[t + 1][:, :E], hc[:, t, Hd:]], wloc=w["loc2"], kl=self.KL)
+            else:
+                wops.taps(awc[t], b, ti, self.KL, 1, self.KL // 2, out=col)
+                F.gemm(col, w["loc"], b * ti, A, self.KL * 8, True, True, act=C.ACT_ADD, mask_src=pm, out=pl)
+                ops.attention_fwd(q_all[t], pl, w["v"], memory, text_lengths, awc[t], tanh_all[t], aw[t], awc[t + 1],
+                                  [x_d[t][:, Ha:Ha + E], x_a[t + 1][:, :E], hc[:, t, Hd:]])
             F.gemm(x_d[t], w["d_cat"], b, 4 * Hd, Ha + E + Hd, True, True, out=gd[t], bias=w["d_b"])
             ops.lstm_fwd(gd[t], dc[t], dc[t + 1], [x_d[t + 1][:, Ha + E:], hc[:, t, :Hd]], keep=keep_d, keep_index=t * b * Hd, p=pd)
         sv.update(g_pre=g_pre, keep_a=keep_a, keep_d=keep_d, x_a=x_a, x_d=x_d, hc=hc, ga=ga, gd=gd, ac=ac, dc=dc, awc=awc, aw=aw,
@@ -363,12 +376,15 @@ class Tacotron2Trainer:
             F.gemm(gd[t], w["d_catT"], b, Ha + E + Hd, 4 * Hd, True, True, out=dxd)
             # attention: d context_t = projection piece + decoder gates (step t) + attention gates (step t+1)
             slot = t % ch_steps
+            # location term: pl = taps(awc[t]) x W_loc^T + pm; awc[t] = (weights_{t-1}, cumulative_{t-1}).  Fused: the kernel also
+            # runs the transposed convolution and leaves d_aw_loc (for step t-1) / adds to d_cum in place
+            fz = dict(wloc_t=w["loc2T"], kl=self.KL, d_prev=d_aw_loc, d_cum=d_cum) if self.fuse_loc else {}
             ops.attention_bwd(dhc[:, t, Hd:], d_aw_loc, aw[t], sv["tanh_all"][t], w["v"], memory, None if hoist else d_memory,
                               d_pl_ch[slot], None, dv_acc, None, d_ctx_add=(dxd[:, Ha:Ha + E], dxa[:, :E]), d_aw_add=d_cum,
-                              dq16=dq_all[t], dctx16=dctx_all[t] if hoist else None)
-            # location term: pl = taps(awc[t]) x W_loc^T + pm; awc[t] = (weights_{t-1}, cumulative_{t-1})
-            F.gemm(d_pl_ch[slot], w["locT"], b * ti, self.KL * 8, A, True, True, out=dcol)
-            ops.location_bwd(dcol, d_aw_loc, d_cum, b, ti, self.KL)
+                              dq16=dq_all[t], dctx16=dctx_all[t] if hoist else None, **fz)
+            if not self.fuse_loc:
+                F.gemm(d_pl_ch[slot], w["locT"], b * ti, self.KL * 8, A, True, True, out=dcol)
+                ops.location_bwd(dcol, d_aw_loc, d_cum, b, ti, self.KL)
             if slot == 0:
                 n = min(ch_steps, to - t)
                 cols = wops.taps(awc[t:t + n].view(-1, 8), n * b, ti, self.KL, 1, self.KL // 2)

@@ -58,8 +58,9 @@ def lstm_bwd(dh, dc_next, act, c_prev, dgates, dc_prev, keep=None, keep_index=0,
            C.ptr(live), C.ptr(dh_prev), b, hh, C.dt(act), C.stream())
 
 
-def attention_fwd(q, pl, v, memory, lengths, awc_prev, tanh_out, aw_out, awc_next, ctx_dsts):
-    C.require_cuda(q, pl, v, memory, lengths, awc_prev, tanh_out, aw_out, awc_next, *ctx_dsts)
+def attention_fwd(q, pl, v, memory, lengths, awc_prev, tanh_out, aw_out, awc_next, ctx_dsts, wloc=None, kl=0):
+    """wloc (16-bit [A, KK], k = tap * 2 + channel): `pl` is the processed memory alone and the location term is formed inside."""
+    C.require_cuda(q, pl, v, memory, lengths, awc_prev, tanh_out, aw_out, awc_next, wloc, *ctx_dsts)
     b, a = q.shape
     ti = pl.shape[0] // b
     e = memory.shape[1]
@@ -68,16 +69,17 @@ def attention_fwd(q, pl, v, memory, lengths, awc_prev, tanh_out, aw_out, awc_nex
     d = list(ctx_dsts) + [None] * (3 - len(ctx_dsts))
     C.call("dle_t2_attention_fwd", C.ptr(q), C.ptr(pl), C.ptr(v), C.ptr(memory), C.ptr(lengths), C.ptr(awc_prev), C.ptr(tanh_out),
            C.ptr(aw_out), C.ptr(awc_next), C.ptr(d[0]), _ld(d[0], "ctx dst") if d[0] is not None else 0, C.ptr(d[1]),
-           _ld(d[1], "ctx dst") if d[1] is not None else 0, C.ptr(d[2]), _ld(d[2], "ctx dst") if d[2] is not None else 0, b, ti, a, e,
-           C.dt(pl), C.stream())
+           _ld(d[1], "ctx dst") if d[1] is not None else 0, C.ptr(d[2]), _ld(d[2], "ctx dst") if d[2] is not None else 0,
+           C.ptr(wloc), int(kl), wloc.shape[1] if wloc is not None else 0, b, ti, a, e, C.dt(pl), C.stream())
 
 
 def attention_bwd(d_ctx, d_aw_in, aw, tanh_out, v, memory, d_memory, d_pl, dq, dv_acc, d_pm_acc, d_ctx_add=(), d_aw_add=None,
-                  dq16=None, dctx16=None):
+                  dq16=None, dctx16=None, wloc_t=None, kl=0, d_prev=None, d_cum=None):
     """dv_acc fp32 [B, A] (per-sample partials); d_ctx_add: up to two more fp32 [B, E] row-strided pieces of the context gradient,
     d_aw_add one more [B, Ti] piece of the weights' gradient (summed on load); dq16 / dctx16: 16-bit copies of dq / of the summed
     context gradient (operands of the products that consume them).  See include/dle_mi355x.h."""
-    C.require_cuda(d_ctx, d_aw_in, aw, tanh_out, v, memory, d_memory, d_pl, dq, dv_acc, d_pm_acc, d_aw_add, dq16, dctx16, *d_ctx_add)
+    C.require_cuda(d_ctx, d_aw_in, aw, tanh_out, v, memory, d_memory, d_pl, dq, dv_acc, d_pm_acc, d_aw_add, dq16, dctx16, wloc_t, d_prev,
+                   d_cum, *d_ctx_add)
     b, ti = aw.shape
     if len(d_ctx_add) > 2:
         raise ValueError("attention_bwd: at most two extra context-gradient pieces")
@@ -90,7 +92,8 @@ def attention_bwd(d_ctx, d_aw_in, aw, tanh_out, v, memory, d_memory, d_pl, dq, d
     C.call("dle_t2_attention_bwd", C.ptr(d_ctx), _ld(d_ctx, "d_ctx"), C.ptr(x[0]), _ld(x[0], "d_ctx") if x[0] is not None else 0,
            C.ptr(x[1]), _ld(x[1], "d_ctx") if x[1] is not None else 0, C.ptr(d_aw_in), C.ptr(d_aw_add), C.ptr(aw), C.ptr(tanh_out),
            C.ptr(v), C.ptr(memory), C.ptr(d_memory), C.ptr(d_pl), C.ptr(dq), C.ptr(dq16), C.ptr(dctx16), C.ptr(dv_acc),
-           C.ptr(d_pm_acc), b, ti, v.numel(), memory.shape[1], C.dt(tanh_out), C.stream())
+           C.ptr(d_pm_acc), C.ptr(wloc_t), int(kl), wloc_t.shape[0] if wloc_t is not None else 0, C.ptr(d_prev), C.ptr(d_cum),
+           b, ti, v.numel(), memory.shape[1], C.dt(tanh_out), C.stream())
 
 
 def sum_steps(x, out):

@@ -429,6 +429,11 @@ int dle_wg_logdet_inv_batched(const float* base, const int64_t* table_dev, float
  *   gradient in 16 bits.  The context gradient is the sum of up to three fp32 row-strided pieces d_ctx0..2 [B, E] (NULL = absent),
  *   the gradient reaching the weights the sum of d_aw0 (+ d_aw1) fp32 [B, Ti]: autograd's accumulation of the gradients a tensor
  *   receives from its consumers (model.py:405-455), done on load.  dh1 / dh2 of dle_t2_lstm_bwd likewise.
+ *   wloc (forward) / wlocT (backward) non-NULL: the location term of the layer (model.py:40-76: Conv1d(2 -> F, kernel KL, no bias)
+ *   on (previous, cumulative) weights followed by Linear(F -> A)) is fused: `pl` is then the processed memory alone, wloc the
+ *   pre-multiplied 16-bit [A, KK] matrix (k = tap * 2 + channel, zero padded to KK >= 2 KL, KK % 16 == 0), wlocT its transpose
+ *   [KK, A] (KK % 32 == 0); the backward writes the gradient of the previous weights to d_prev (may be d_aw0's buffer) and
+ *   accumulates that of the cumulative weights into d_cum (may be d_aw1's), fp32 [B, Ti].
  * dle_t2_location_bwd: transpose of the row gather of the 2-channel location convolution (model.py:40-76): dcol 16-bit
  *   [B*Ti, KL*8] -> d_prev (channel 0, written) and d_cum (channel 1, accumulated), fp32 [B, Ti].
  * dle_t2_tanh_fwd: torch.tanh of the postnet (model.py:170).  dle_t2_mel_loss: MSE(mel_out) + MSE(mel_out + postnet) of
@@ -443,11 +448,13 @@ int dle_t2_lstm_bwd(const float* dh, int64_t ld_dh, const float* dh1, int64_t ld
                     const float* live, float* dh_prev, int B, int H, int dtype, hipStream_t stream);
 int dle_t2_attention_fwd(const float* q, const void* pl, const float* v, const void* memory, const int64_t* lengths,
                          const void* awc_prev, void* tanh_out, float* aw_out, void* awc_next, void* d0, int64_t ld0, void* d1,
-                         int64_t ld1, void* d2, int64_t ld2, int B, int Ti, int A, int E, int dtype, hipStream_t stream);
+                         int64_t ld1, void* d2, int64_t ld2, const void* wloc, int KL, int KK, int B, int Ti, int A, int E, int dtype,
+                         hipStream_t stream);
 int dle_t2_attention_bwd(const float* d_ctx0, int64_t ld_c0, const float* d_ctx1, int64_t ld_c1, const float* d_ctx2, int64_t ld_c2,
                          const float* d_aw0, const float* d_aw1, const float* aw, const void* tanh_out, const float* v,
                          const void* memory, float* d_memory, void* d_pl, float* dq, void* dq16, void* dctx16, float* dv_acc,
-                         float* d_pm_acc, int B, int Ti, int A, int E, int dtype, hipStream_t stream);
+                         float* d_pm_acc, const void* wlocT, int KL, int KK, float* d_prev, float* d_cum, int B, int Ti, int A, int E,
+                         int dtype, hipStream_t stream);
 /* out[r] += sum over the n_steps rows of x (16-bit [n_steps, R], R % 8 == 0), fp32 out: folds the kept per-step gradients of the
  * processed memory (d_pm_acc = NULL in dle_t2_attention_bwd). */
 int dle_t2_sum_steps(const void* x, float* out, int n_steps, int64_t R, int dtype, hipStream_t stream);

@@ -231,14 +231,27 @@ def lstm_bwd(dh, dc_next, act, c_prev, dgates, dc_prev, keep=None, keep_index=0,
     dc_prev.copy_(dcp)
 
 
-def attention_fwd(q, pl, v, memory, lengths, awc_prev, tanh_out, aw_out, awc_next, ctx_dsts):
+def _loc_cols(awc, b, ti, kl):
+    """[B, Ti, kl * 2]: cols[b, t, j*2 + c] = awc[b, t + j - kl//2, c] (zero outside the sample), the compact row gather."""
+    x = awc.float().view(b, ti, 8)[:, :, :2]
+    pad = kl // 2
+    xp = torch.zeros(b, ti + 2 * pad, 2)
+    xp[:, pad:pad + ti] = x
+    return torch.stack([xp[:, j:j + ti] for j in range(kl)], dim=2).reshape(b, ti, kl * 2)
+
+
+def attention_fwd(q, pl, v, memory, lengths, awc_prev, tanh_out, aw_out, awc_next, ctx_dsts, wloc=None, kl=0):
     """Location-sensitive attention of one decoder step (tacotron2/model.py:79-121): e = v . tanh(q + pl), masked softmax over the
     text positions, context = weights x memory.  q fp32 [B, A]; pl 16-bit [B*Ti, A] (processed memory + location term); v fp32 [A];
     memory 16-bit [B*Ti, E]; lengths int64 [B]; awc_prev / awc_next 16-bit [B*Ti, 8] = (previous weights, cumulative weights, 0 ...):
     the next step's location-convolution input; tanh_out 16-bit [B*Ti, A] saved; aw_out fp32 [B, Ti]; context (16-bit) to ctx_dsts."""
     b, a = q.shape
     ti = pl.shape[0] // b
-    th = torch.tanh(q.view(b, 1, a) + pl.float().view(b, ti, a))
+    plf = pl.float().view(b, ti, a)
+    if wloc is not None:                                             # pl = processed memory alone; + the location term
+        if awc_prev is not None:
+            plf = plf + (_loc_cols(awc_prev, b, ti, kl).double() @ wloc.double()[:, :kl * 2].t()).float()
+    th = torch.tanh(q.view(b, 1, a) + plf)
     tanh_out.copy_(th.view(b * ti, a))
     e = (tanh_out.float().view(b, ti, a) * v.view(1, 1, a)).sum(2)
     pad = torch.arange(ti)[None, :] >= lengths[:, None]
@@ -254,7 +267,7 @@ def attention_fwd(q, pl, v, memory, lengths, awc_prev, tanh_out, aw_out, awc_nex
 
 
 def attention_bwd(d_ctx, d_aw_in, aw, tanh_out, v, memory, d_memory, d_pl, dq, dv_acc, d_pm_acc, d_ctx_add=(), d_aw_add=None,
-                  dq16=None, dctx16=None):
+                  dq16=None, dctx16=None, wloc_t=None, kl=0, d_prev=None, d_cum=None):
     """Backward of attention_fwd.  d_ctx fp32 [B, E] (+ the pieces in d_ctx_add); d_aw_in (+ d_aw_add) fp32 [B, Ti] (gradient
     reaching the weights through the location input / cumulative weights of later steps); accumulates d_memory fp32 [B*Ti, E],
     dv_acc fp32 [B, A] (per-sample partial sums), d_pm_acc fp32 [B*Ti, A]; writes d_pl 16-bit [B*Ti, A] (gradient of q + pl inside
@@ -283,6 +296,18 @@ def attention_bwd(d_ctx, d_aw_in, aw, tanh_out, v, memory, d_memory, d_pl, dq, d
         dq16.copy_(d_pre.sum(1))
     if d_pm_acc is not None:
         d_pm_acc.add_(d_pre.view(b * ti, a))                           # the fp32 value, not its 16-bit rounding
+    if wloc_t is not None:
+        # transposed location convolution on the ROUNDED d_pl (what the kernel keeps in LDS): dcol = d_pl x W_loc, then the
+        # anti-diagonal sums d weights[s][c] = sum_j dcol[s - j + pad][j*2 + c]
+        dcol = (d_pl.double().view(b, ti, a) @ wloc_t.double()[:kl * 2].t()).float().view(b, ti, kl, 2)
+        pad = kl // 2
+        out = torch.zeros(b, ti, 2)
+        for j in range(kl):
+            lo, hi = max(0, pad - j), min(ti, ti + pad - j)
+            if lo < hi:
+                out[:, lo + j - pad:hi + j - pad] += dcol[:, lo:hi, j]
+        d_prev.copy_(out[:, :, 0])
+        d_cum.add_(out[:, :, 1])
 
 
 def sum_steps(x, out):

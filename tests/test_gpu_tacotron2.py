@@ -358,3 +358,54 @@ def test_three_steps_follow_torch_adam_on_the_oracle(cuda, case_name):
     dist = sum(float((sd[k].cpu() - p[k].detach()).norm()) ** 2 for k in p) ** 0.5
     assert dist <= 0.15 * moved, (dist, moved)         # Adam's sign-like first steps amplify 16-bit gradient noise near g = 0
     assert int(sd["postnet.convolutions.0.1.num_batches_tracked"]) == 3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,ti,a,e,kl", [(3, 23, 32, 64, 31), (24, 160, 128, 512, 31), (2, 40, 64, 128, 5)])
+def test_attention_step_with_the_location_term_fused(cuda, dtype, b, ti, a, e, kl):
+    """wloc / wloc_t given: the kernels form the location term (2-channel convolution over the previous / cumulative weights +
+    dense, one pre-multiplied [A, KK] operand, model.py:40-76) and its transposed convolution themselves -- against the plain-torch
+    statement, and against the unfused HIP path (row gather + GEMM + kernel) on the same inputs."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(b * 3 + ti)
+    kk = (2 * kl + 31) // 32 * 32
+    q = torch.randn(b, a, generator=g)
+    pm = torch.randn(b * ti, a, generator=g).to(dtype)
+    v = torch.randn(a, generator=g) * 0.5
+    mem = torch.randn(b * ti, e, generator=g).to(dtype)
+    lengths = torch.randint(ti // 2, ti + 1, (b,), generator=g)
+    lengths[0] = ti
+    awc_prev = torch.zeros(b * ti, 8, dtype=dtype)
+    awc_prev[:, :2] = torch.rand(b * ti, 2, generator=g).to(dtype)
+    wloc = torch.zeros(a, kk, dtype=dtype)
+    wloc[:, :2 * kl] = (torch.randn(a, 2 * kl, generator=g) * 0.3).to(dtype)
+    wloc_t = wloc.t().contiguous()
+
+    def run(L, d):
+        th, aw, nxt = d(torch.zeros(b * ti, a, dtype=dtype)), d(torch.zeros(b, ti)), d(torch.ones(b * ti, 8, dtype=dtype))
+        c0 = d(torch.zeros(b, e, dtype=dtype))
+        L.attention_fwd(d(q), d(pm), d(v), d(mem), d(lengths), d(awc_prev), th, aw, nxt, [c0], wloc=d(wloc), kl=kl)
+        return th, aw, nxt, c0
+    got, ref = run(ops, lambda t: t.to(cuda)), run(D, lambda t: t)
+    _close(got[0], ref[0], **_tol(dtype))
+    _close(got[1], ref[1], rtol=3e-2, atol=3e-4)
+    _close(got[2], ref[2], **_tol(dtype))
+    _close(got[3], ref[3], **_tol(dtype))
+    th, aw = ref[0], ref[1]
+    d_ctx, d_aw_in = torch.randn(b, e, generator=g), torch.randn(b, ti, generator=g) * 0.1
+    cum0 = torch.randn(b, ti, generator=g) * 0.1
+
+    def runb(L, d):
+        dpl, dq16 = d(torch.zeros(b * ti, a, dtype=dtype)), d(torch.zeros(b, a, dtype=dtype))
+        dv = d(torch.zeros(b, a))
+        prev, cum = d(d_aw_in.clone()), d(cum0.clone())           # in place: d_aw0 -> d_prev, d_aw1 -> d_cum
+        L.attention_bwd(d(d_ctx), prev, d(aw), d(th), d(v), d(mem), None, dpl, None, dv, None, d_aw_add=cum, dq16=dq16,
+                        wloc_t=d(wloc_t), kl=kl, d_prev=prev, d_cum=cum)
+        return dpl, dq16, dv, prev, cum
+    got, ref = runb(ops, lambda t: t.to(cuda)), runb(D, lambda t: t)
+    _close(got[0], ref[0], **_tol(dtype))
+    _close(got[1], ref[1], **_tol(dtype))
+    _close(got[2], ref[2], rtol=2e-3, atol=5e-3)
+    scale = float(ref[3].abs().max())
+    _close(got[3], ref[3], rtol=2e-3, atol=2e-3 * scale)
+    _close(got[4], ref[4], rtol=2e-3, atol=2e-3 * max(scale, float(ref[4].abs().max())))
