@@ -30,6 +30,14 @@ from .model import Tacotron2
 NPAD = 8          # the mel + gate projection runs (n_mel + 1) outputs wide, padded to a multiple of 8
 
 
+class _null_ctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class Tacotron2Trainer:
     def __init__(self, model: Tacotron2, lr=1e-3, weight_decay=1e-6, grad_clip_thresh=1.0, compute_dtype=torch.float16, amp=True,
                  init_loss_scale=65536.0, growth_interval=2000, world_size=1, process_group=None, bucket_mb=25, seed=1234, rank=0):
@@ -355,25 +363,45 @@ class Tacotron2Trainer:
         #   dxd = gradient wrt x_d[t] = [attention_hidden_t | context_t | decoder_hidden_{t-1}]  (decoder LSTM's gates, step t)
         #   dxa = gradient wrt x_a[t] = [context_{t-1} | attention_hidden_{t-1}]                  (attention LSTM's gates, step t)
         # both zero before the first (= last in time) step: nothing follows it
-        dxd = self._z(b, Ha + E + Hd, dtype=f32)
+        dxd_all = self._e(to + 1, b, Ha + E + Hd, dtype=f32)              # [t] = dxd of step t; [to] = zeros (nothing follows the last step)
+        dxd_all[to].zero_()
         dxa = self._z(b, E + Ha, dtype=f32)
         d_ah_q = self._e(b, Ha, dtype=f32)                               # through the query layer
         d_dc = [self._z(b, Hd, dtype=f32), self._e(b, Hd, dtype=f32)]
         d_ac = [self._z(b, Ha, dtype=f32), self._e(b, Ha, dtype=f32)]
         d_aw_loc = self._z(b, ti, dtype=f32)                             # wrt weights_t as "previous weights" of step t+1
         d_cum = self._z(b, ti, dtype=f32)                                # wrt cumulative weights_t (all later steps)
-        dcol = self._e(b * ti, self.KL * 8)
+        dcol = self._e(b * ti, self.KL * 8) if not self.fuse_loc else None
         # the location layer's weight gradient contracts over (step, sample, position): d_pl is kept for CH steps at a time and
         # meets the gathered rows of the same steps in ONE split-K product per chunk
         ch_steps = max(1, min(to, 64))
         d_pl_ch = self._e(ch_steps, b * ti, A)
         pa, pd = cfg["p_attention_dropout"], cfg["p_decoder_dropout"]
+        # The decoder LSTM's backward recurrence (cell of step t <- its own gates of step t+1) does not depend on the attention
+        # chain: it runs AHEAD on a second stream (one 160-workgroup product + one cell per step) and leaves dxd for every step;
+        # the attention chain of step t (128-workgroup attention kernel, query product, attention cell, its gate product) waits
+        # for the event of step t.  Both chains are a few-workgroup latency-bound launches each: side by side they share the chip.
+        main = torch.cuda.current_stream() if self.dev.type == "cuda" else None
+        side = self._side_stream() if main is not None else None
+        done = []
+        if side is not None:
+            side.wait_stream(main)
+        with (torch.cuda.stream(side) if side is not None else _null_ctx()):
+            for t in range(to - 1, -1, -1):
+                cur, nxt = (to - 1 - t) & 1, ((to - 1 - t) & 1) ^ 1
+                # decoder LSTM: dh = projection piece + the piece through step t+1's gates
+                ops.lstm_bwd(dhc[:, t, :Hd], d_dc[cur], gd[t], dc[t], gd[t], d_dc[nxt], keep=sv["keep_d"], keep_index=t * b * Hd, p=pd,
+                             dh_add=(dxd_all[t + 1][:, Ha + E:],))
+                F.gemm(gd[t], w["d_catT"], b, Ha + E + Hd, 4 * Hd, True, True, out=dxd_all[t])
+                if side is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    done.append(ev)
         for t in range(to - 1, -1, -1):
             cur, nxt = (to - 1 - t) & 1, ((to - 1 - t) & 1) ^ 1
-            # decoder LSTM: dh = projection piece + the piece through step t+1's gates
-            ops.lstm_bwd(dhc[:, t, :Hd], d_dc[cur], gd[t], dc[t], gd[t], d_dc[nxt], keep=sv["keep_d"], keep_index=t * b * Hd, p=pd,
-                         dh_add=(dxd[:, Ha + E:],))
-            F.gemm(gd[t], w["d_catT"], b, Ha + E + Hd, 4 * Hd, True, True, out=dxd)
+            dxd = dxd_all[t]
+            if side is not None:
+                main.wait_event(done[to - 1 - t])
             # attention: d context_t = projection piece + decoder gates (step t) + attention gates (step t+1)
             slot = t % ch_steps
             # location term: pl = taps(awc[t]) x W_loc^T + pm; awc[t] = (weights_{t-1}, cumulative_{t-1}).  Fused: the kernel also
@@ -398,6 +426,8 @@ class Tacotron2Trainer:
             ops.lstm_bwd(dxd[:, :Ha], d_ac[cur], ga[t], ac[t], ga[t], d_ac[nxt], keep=sv["keep_a"], keep_index=t * b * Ha, p=pa,
                          dh_add=(d_ah_q, dxa[:, E:]))
             F.gemm(ga[t], w["a_catT"], b, E + Ha, 4 * Ha, True, True, out=dxa)
+        if side is not None:
+            main.wait_stream(side)
         # ---- weight gradients of the decoder: one GEMM each over all steps
         rt = to * b
         ga2, gd2 = ga.view(rt, 4 * Ha), gd.view(rt, 4 * Hd)
@@ -486,6 +516,11 @@ class Tacotron2Trainer:
         while self._rev_pos < len(names) and (prefixes is None or names[self._rev_pos].startswith(prefixes)):
             self.buckets.grad_ready(names[self._rev_pos])
             self._rev_pos += 1
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
 
     def _relu_mask(self, g, y):
         out = torch.empty_like(g)
