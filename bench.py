@@ -448,7 +448,7 @@ class Tacotron2Workload:
 
 WORKLOADS = {"dlrm": DlrmWorkload, "rn50": Rn50Workload, "bert": BertWorkload, "waveglow": WaveGlowWorkload,
              "tacotron2": Tacotron2Workload}
-NESTED_STEPS = {"rn50": (30, 8), "bert": (12, 3), "dlrm": (100, 20), "waveglow": (10, 3), "tacotron2": (4, 1)}   # (timed steps, warm-up)
+NESTED_STEPS = {"rn50": (30, 8), "bert": (12, 3), "dlrm": (100, 20), "waveglow": (10, 3), "tacotron2": (4, 2)}   # (timed steps, warm-up)
 
 REFERENCE_PUBLISHED = {
     "rn50": {"value": 2470, "unit": "img/s", "hardware": "1x A100 80GB, mixed precision, bs 256",
