@@ -10,6 +10,7 @@
 //   tacotron2/loss_function.py:42-44    the two MSE terms of Tacotron2Loss and their gradient            -> t2_mel_loss
 // The decoder state is one row per sample (B ~ 50-100 rows): these are latency-bound kernels of a sequential loop, one thread per
 // (sample, unit) for the cells, one workgroup per sample for the attention (wave64 shuffle reductions over channels).
+#include <type_traits>
 #include "gemm_tiles.h"
 
 #define T2_BLOCK 256
@@ -568,6 +569,25 @@ __global__ __launch_bounds__(T2_BLOCK) void t2_mel_loss_kernel(const float* __re
   if (threadIdx.x == 0) partial[blockIdx.x] = t * invn;
 }
 
+// model.py:648-655 parse_output under --mask-padding: rows (b, t) with t >= lengths[b] of a [B * To, cols] block are overwritten
+// with one value (0 for the mel outputs and -- gradient side -- for what flows back into them, 1e3 for the gate energies).
+template <int DT>   // DLE_F32: T = float; else 16-bit storage
+__global__ __launch_bounds__(T2_BLOCK) void t2_mask_rows_kernel(void* __restrict__ xv, long long ld, int cols,
+                                                                const long long* __restrict__ lengths, long long R, int To, float fill) {
+  using T = typename std::conditional<DT == DLE_F32, float, unsigned short>::type;
+  T* x = (T*)xv;
+  T value;
+  if constexpr (DT == DLE_F32) value = fill;
+  else value = Elem<DT>::from_f32(fill);
+  const long long total = R * cols;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cols;
+    const int c = (int)(i - r * cols);
+    const long long b = r / To;
+    if ((long long)(r - b * To) >= lengths[b]) x[r * ld + c] = value;
+  }
+}
+
 __global__ __launch_bounds__(T2_BLOCK) void t2_sum_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
   __shared__ float red[16];
   float s = 0.f;
@@ -779,6 +799,25 @@ extern "C" int dle_t2_location_bwd(const void* dcol, float* d_prev, float* d_cum
   DLE_CHECK_ARG(dcol && d_prev && d_cum && B > 0 && Ti > 0 && KL > 0 && (((uintptr_t)dcol) & 3) == 0, "t2_location_bwd: bad args");
   T2_DT_CHECK("t2_location_bwd");
   T2_GO(t2_location_bwd_kernel, t2_grid((long long)B * Ti), 0, (const unsigned short*)dcol, d_prev, d_cum, B, Ti, KL);
+  return 0;
+}
+
+extern "C" int dle_t2_mask_rows(void* x, int64_t ld, int cols, const int64_t* lengths, int64_t B, int To, float value, int dtype,
+                                hipStream_t stream) {
+  DLE_CHECK_ARG(x && lengths && B > 0 && To > 0 && cols > 0 && ld >= cols, "t2_mask_rows: bad args");
+  DLE_CHECK_ARG(dtype == DLE_F32 || dtype == DLE_F16 || dtype == DLE_BF16, "t2_mask_rows: unknown dtype %d", dtype);
+  const long long R = (long long)B * To;
+  const int G = t2_grid(R * cols, 1024);
+  if (dtype == DLE_F32)
+    hipLaunchKernelGGL(t2_mask_rows_kernel<DLE_F32>, dim3(G), dim3(T2_BLOCK), 0, stream, x, (long long)ld, cols,
+                       (const long long*)lengths, R, To, value);
+  else if (dtype == DLE_F16)
+    hipLaunchKernelGGL(t2_mask_rows_kernel<DLE_F16>, dim3(G), dim3(T2_BLOCK), 0, stream, x, (long long)ld, cols,
+                       (const long long*)lengths, R, To, value);
+  else
+    hipLaunchKernelGGL(t2_mask_rows_kernel<DLE_BF16>, dim3(G), dim3(T2_BLOCK), 0, stream, x, (long long)ld, cols,
+                       (const long long*)lengths, R, To, value);
+  DLE_LAUNCH_CHECK();
   return 0;
 }
 

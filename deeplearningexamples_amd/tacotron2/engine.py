@@ -13,7 +13,12 @@ GEMM (location conv and dense pre-multiplied into one [A, 31*2] matrix, the proc
 dle_t2_attention_fwd (energies, masked softmax, context, cumulative weights) -> gates GEMM -> dle_t2_lstm_fwd.
 Vectors that feed several consumers are written by the producing kernel straight into the consumers' operand buffers
 (X_a[t] = [context | attention_hidden], X_d[t] = [attention_hidden | context | decoder_hidden], HC[:, t] = [decoder_hidden | context]).
-Restrictions: n_frames_per_step = 1, mask_padding = False (the reference's defaults).
+--mask-padding (model.py:648-655, off by default): the frames past each sample's output length are overwritten before the loss
+(mel outputs 0, gate energies 1e3) by dle_t2_mask_rows, and the gradients flowing back into them are zeroed by the same kernel --
+what the reference's masked_fill_ means for autograd.  (The reference's own training run with the flag raises in backward: the
+in-place fill touches a tensor the postnet's first convolution saved; oracle/make_golden.py asserts that and pins the gradients
+with its parse_output applied to clones.)
+Restriction: n_frames_per_step = 1 (the reference's default).
 """
 import torch
 
@@ -40,8 +45,11 @@ class _null_ctx:
 
 class Tacotron2Trainer:
     def __init__(self, model: Tacotron2, lr=1e-3, weight_decay=1e-6, grad_clip_thresh=1.0, compute_dtype=torch.float16, amp=True,
-                 init_loss_scale=65536.0, growth_interval=2000, world_size=1, process_group=None, bucket_mb=25, seed=1234, rank=0):
+                 init_loss_scale=65536.0, growth_interval=2000, world_size=1, process_group=None, bucket_mb=25, seed=1234, rank=0,
+                 mask_padding=False):
         self.model, self.cfg = model, model.cfg
+        self.mask_padding = bool(mask_padding)
+        self.training = True
         self.dev = dev = model.store.flat.device
         self.dtype = compute_dtype
         self.lr, self.wd, self.clip = float(lr), float(weight_decay), float(grad_clip_thresh)
@@ -170,6 +178,11 @@ class Tacotron2Trainer:
         col = wops.taps(x, b, t, k, 1, k // 2)
         pre = F.gemm(col, w16, b * t, cout, col.shape[1], True, True, bias=self.p[name + ".0.conv.bias"])
         bn = name + ".1"
+        if not self.training:                      # model.eval(): running statistics, no dropout (the validation pass)
+            rstd = torch.rsqrt(self._buf[bn + ".running_var"] + 1e-5)
+            y, _ = F.bn_fwd_apply(pre, self._buf[bn + ".running_mean"], rstd, self.p[bn + ".weight"], self.p[bn + ".bias"],
+                                  relu=(act == "relu"))
+            return (ops.tanh_fwd(y) if act == "tanh" else y), {}
         y, mean, rstd = F.bn_fwd(pre, self.p[bn + ".weight"], self.p[bn + ".bias"], self._buf[bn + ".running_mean"],
                                  self._buf[bn + ".running_var"], eps=1e-5, momentum=0.1, relu=(act == "relu"))
         self._buf[bn + ".num_batches_tracked"] += 1
@@ -181,8 +194,10 @@ class Tacotron2Trainer:
     # ------------------------------------------------------------------ forward
     def forward(self, text, text_lengths, mel, gate_target, output_lengths=None):
         """text int64 [B, Ti] (sorted by length, descending, 0-padded), text_lengths int64 [B], mel fp32 [B, n_mel, To] zero padded,
-        gate_target fp32 [B, To] -> loss fp32 [1]."""
-        C.require_cuda(text, text_lengths, mel, gate_target)
+        gate_target fp32 [B, To], output_lengths int64 [B] (read under mask_padding only) -> loss fp32 [1]."""
+        C.require_cuda(text, text_lengths, mel, gate_target, output_lengths)
+        if self.mask_padding and output_lengths is None:
+            raise ValueError("mask_padding needs the output lengths of the batch")
         E, A, Ha, Hd, P, NM, NO, h = self.E, self.A, self.Ha, self.Hd, self.P, self.NM, self.NO, self.h
         dt, cfg = self.dtype, self.cfg
         b, ti = text.shape
@@ -236,8 +251,10 @@ class Tacotron2Trainer:
         sv.update(dec_in=dec_in, l1=l1, l1d=l1d, m1=m1, l2=l2, l2d=l2d, m2=m2)
         g_pre = F.gemm(l2d[:to * b], w["a_pre"], to * b, 4 * Ha, P, True, True, bias=w["a_b"]).view(to, b, 4 * Ha)
         pa, pd = cfg["p_attention_dropout"], cfg["p_decoder_dropout"]
-        _, keep_a = self._drop(torch.ones(to * b * Ha, dtype=dt, device=self.dev), pa)
-        _, keep_d = self._drop(torch.ones(to * b * Hd, dtype=dt, device=self.dev), pd)
+        keep_a = keep_d = None                                           # eval: only the prenet's dropout stays on (model.py:133)
+        if self.training:
+            _, keep_a = self._drop(torch.ones(to * b * Ha, dtype=dt, device=self.dev), pa)
+            _, keep_d = self._drop(torch.ones(to * b * Hd, dtype=dt, device=self.dev), pd)
         x_a = self._z(to + 1, b, E + Ha)                                 # [context_{t-1} | attention_hidden_{t-1}]
         x_d = self._z(to + 1, b, Ha + E + Hd)                            # [attention_hidden_t | context_t | decoder_hidden_{t-1}]
         hc = self._z(b, to, Hd + E)                                      # [decoder_hidden_t | context_t], rows (b, t)
@@ -283,9 +300,16 @@ class Tacotron2Trainer:
         scale = self.scaler.scale
         d_out = self._z(r, NO)
         d_post = self._e(r, NM)
+        if self.mask_padding:
+            ops.mask_rows(out_all, NM, output_lengths, b, to, 0.0)
+            ops.mask_rows(out_all[:, NM:], 1, output_lengths, b, to, 1e3)
+            ops.mask_rows(y, NM, output_lengths, b, to, 0.0)
         mel_l = ops.mel_loss(out_all, y, target, NM, scale, d_out, d_post)
         gate_l, dgate = F.bce_with_logits(out_all[:, NM:], gate_target.reshape(-1).contiguous(), grad_scale=scale, ld_logits=NO)
         d_out[:, NM].copy_(dgate)
+        if self.mask_padding:
+            ops.mask_rows(d_out, NM + 1, output_lengths, b, to, 0.0)
+            ops.mask_rows(d_post, NM, output_lengths, b, to, 0.0)
         self.loss = mel_l + gate_l
         sv.update(out_all=out_all, d_out=d_out, d_post=d_post)
         return self.loss
@@ -548,6 +572,17 @@ class Tacotron2Trainer:
         if lr != self.lr:
             self.lr = float(lr)
             self.lr_t.fill_(self.lr)
+
+    def eval_loss(self, text, text_lengths, mel, gate_target, output_lengths=None):
+        """The validation pass of train.py:273-318: model.eval() forward + criterion, nothing kept for a backward pass, BatchNorm
+        buffers untouched.  The prenet's dropout stays on, as in the reference (F.dropout(..., training=True), model.py:133)."""
+        self.training = False
+        try:
+            loss = self.forward(text, text_lengths, mel, gate_target, output_lengths)
+        finally:
+            self.training = True
+            self.sv = None
+        return loss
 
     def train_step(self, text, text_lengths, mel, gate_target, output_lengths=None):
         loss = self.forward(text, text_lengths, mel, gate_target, output_lengths)

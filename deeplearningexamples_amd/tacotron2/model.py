@@ -62,7 +62,9 @@ def bn_names(cfg):
 
 
 class Tacotron2(nn.Module):
-    def __init__(self, device="cpu", **cfg):
+    def __init__(self, device="cpu", uniform_initialize_bn_weight=False, **cfg):
+        """cfg: the reference's model config keys (unknown / inference-only ones are ignored).  uniform_initialize_bn_weight:
+        models.get_model's init_bn (models.py:53-62, the training entry point's default): BatchNorm weights ~ U[0, 1)."""
         super().__init__()
         self.cfg = dict(DEFAULT_CONFIG)
         self.cfg.update({k: v for k, v in cfg.items() if k in DEFAULT_CONFIG})
@@ -79,6 +81,10 @@ class Tacotron2(nn.Module):
             node.register_buffer("running_var", torch.ones(c, device=device))
             node.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.long, device=device))
         self.reset_parameters()
+        if uniform_initialize_bn_weight:
+            with torch.no_grad():
+                for bn in bn_names(self.cfg):
+                    self.store[bn + ".weight"].uniform_()
 
     @torch.no_grad()
     def reset_parameters(self):

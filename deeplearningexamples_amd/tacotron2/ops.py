@@ -30,7 +30,8 @@ def tanh_fwd(x):
 
 
 def lstm_fwd(gates, c_prev, c_out, h_dsts, keep=None, keep_index=0, p=0.0, live=None, h_prev=None, out_dst=None):
-    """See tests/_tacotron2_doubles.py lstm_fwd for the statement.  gates: 16-bit [B, 4H] row-strided view, replaced by the gate
+    """Pointwise part of nn.LSTM / nn.LSTMCell + the dropout on the hidden state (statement: include/dle_mi355x.h,
+    dle_t2_lstm_fwd; reference tacotron2/model.py:205-214,425-444).  gates: 16-bit [B, 4H] row-strided view, replaced by the gate
     activations; h_dsts: up to three 16-bit [B, H] row-strided views."""
     C.require_cuda(gates, c_prev, c_out, keep, live, h_prev, out_dst, *h_dsts)
     b, h4 = gates.shape
@@ -122,3 +123,12 @@ def mel_loss(out_all, post, target, n_mel, scale, d_out, d_post):
     C.call("dle_t2_mel_loss", C.ptr(out_all), _ld(out_all, "out_all"), C.ptr(post), C.ptr(target), C.ptr(scale), C.ptr(d_out),
            _ld(d_out, "d_out"), C.ptr(d_post), C.ptr(loss), C.ptr(ws), r, n_mel, C.dt(post), C.stream())
     return loss
+
+
+def mask_rows(x, cols, lengths, b, to, value):
+    """--mask-padding: x [B*To, >= cols] (fp32 or 16-bit, row pitch from its stride) rows (b, t) with t >= lengths[b], columns
+    [0, cols) := value, in place."""
+    C.require_cuda(x, lengths)
+    if lengths.dtype != torch.int64 or lengths.numel() != b or x.shape[0] != b * to or x.shape[1] < cols or x.stride(1) != 1:
+        raise ValueError("mask_rows: x [B*To, >= cols] with unit column stride, int64 lengths [B]")
+    C.call("dle_t2_mask_rows", C.ptr(x), x.stride(0), cols, C.ptr(lengths), b, to, float(value), C.dt(x), C.stream())

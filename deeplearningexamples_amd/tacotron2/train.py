@@ -5,54 +5,40 @@
 
 Same flags (train.py:45-160, tacotron2/arg_parser.py:40-107), loop (train.py:444-500), DLLogger records (train_items_per_sec = mel
 frames / s) and checkpoint files (`checkpoint_Tacotron2_<epoch>.pt`, train.py:185-255) as the reference; the shared pieces live
-in waveglow/train.py.  Data: synthetic batches in TextMelCollate's layout (tacotron2/data_function.py:100-151: text sorted by
-length, zero-padded mels, gate target 1 from the last frame on); text cleaning / the STFT front end are host-side and out of scope.
+in waveglow/train.py (common flags, epoch loop with the per-epoch validation pass, checkpoints).  Data: the filelists of
+--training-files / --validation-files under -d through TextMelLoader + TextMelCollate (tacotron2/data_function.py; wavs through
+the STFT front end of tacotron2/audio.py or, with --load-mel-from-disk, saved mels), or -- with --synthetic-data, this port's
+benchmark mode -- device-resident batches in the collate's layout.  --mask-padding as model.py:648-655.
 """
-import argparse
-import os
-import time
-
-import numpy as np
 import torch
 
-from ..utils import dllogger as DLLogger
-from ..utils.dist import init_from_env
 from ..waveglow import train as WT
 from .engine import Tacotron2Trainer
 from .model import DEFAULT_CONFIG, Tacotron2, param_shapes
 
 
 def parse_args(argv=None):
-    p = argparse.ArgumentParser(description="Tacotron2 training on MI355X (train.py CLI of the reference, -m Tacotron2)")
-    p.add_argument("-o", "--output", type=str, required=True)
-    p.add_argument("-m", "--model-name", type=str, default="Tacotron2", choices=["Tacotron2"])
-    p.add_argument("--log-file", type=str, default="nvlog.json")
-    p.add_argument("--anneal-steps", nargs="*")
-    p.add_argument("--anneal-factor", type=float, choices=[0.1, 0.3], default=0.1)
-    p.add_argument("--seed", default=None, type=int)
-    p.add_argument("--epochs", type=int, required=True)
-    p.add_argument("--epochs-per-checkpoint", type=int, default=50)
-    p.add_argument("--checkpoint-path", type=str, default="")
-    p.add_argument("--resume-from-last", action="store_true")
-    p.add_argument("--amp", action="store_true")
-    p.add_argument("--cudnn-enabled", action="store_true", help="accepted for CLI compatibility; there is no cuDNN here")
-    p.add_argument("--cudnn-benchmark", action="store_true", help="accepted for CLI compatibility")
-    p.add_argument("-lr", "--learning-rate", type=float, required=True)
-    p.add_argument("--weight-decay", default=1e-6, type=float)
-    p.add_argument("--grad-clip-thresh", default=1.0, type=float)
-    p.add_argument("-bs", "--batch-size", type=int, required=True)
-    p.add_argument("--bench-class", type=str, default="")
-    for k, v in DEFAULT_CONFIG.items():                                # tacotron2/arg_parser.py: --n-mel-channels, --prenet-dim, ...
-        p.add_argument("--" + k.replace("_", "-"), default=v, type=type(v))
-    p.add_argument("--iters-per-epoch", default=50, type=int, help="synthetic data: iterations that make up one epoch")
-    p.add_argument("--compute-dtype", default="fp16", choices=["fp16", "bf16"])
+    p = WT.common_parser("Tacotron2 training on MI355X (train.py CLI of the reference, -m Tacotron2)", "Tacotron2")
+    m = p.add_argument_group("Tacotron2 parameters")                 # tacotron2/arg_parser.py:40-107
+    m.add_argument("--mask-padding", default=False, type=bool, help="Use mask padding")
+    for k, v in DEFAULT_CONFIG.items():                                # --n-mel-channels, --prenet-dim, --p-attention-dropout, ...
+        m.add_argument("--" + k.replace("_", "-"), default=v, type=type(v))
+    m.add_argument("--max-decoder-steps", default=2000, type=int, help="inference only: kept in the checkpoint's config")
+    m.add_argument("--gate-threshold", default=0.5, type=float, help="inference only: kept in the checkpoint's config")
+    m.add_argument("--decoder-no-early-stopping", action="store_true", help="inference only: kept in the checkpoint's config")
+    p.set_defaults(iters_per_epoch=50)
     args, _ = p.parse_known_args(argv)
     return args
 
 
 def get_model_config(args):
-    """models.get_model_config('Tacotron2', args) (models.py:97-130), the keys this port implements."""
-    return {k: getattr(args, k) for k in DEFAULT_CONFIG}
+    """models.get_model_config('Tacotron2', args) (models.py:97-130): the dict the checkpoint's `config` key holds, with the
+    reference's keys (its own load path rebuilds the model from it)."""
+    cfg = dict(mask_padding=args.mask_padding)
+    cfg.update({k: getattr(args, k) for k in DEFAULT_CONFIG})
+    cfg.update(max_decoder_steps=args.max_decoder_steps, gate_threshold=args.gate_threshold,
+               decoder_no_early_stopping=args.decoder_no_early_stopping)
+    return cfg
 
 
 def parameter_order(cfg):
@@ -61,7 +47,8 @@ def parameter_order(cfg):
 
 
 class SyntheticTextMel:
-    """Device-resident batches in TextMelCollate's layout; a fixed pool, cycled."""
+    """Device-resident batches in TextMelCollate's layout; a fixed pool, cycled.  pool[i] -> ((text, text_lengths, mel, gate,
+    output_lengths), mel frames in the batch)."""
 
     def __init__(self, batch, n_symbols, n_mel, device, seed, pool=4):
         g = torch.Generator(device="cpu").manual_seed(seed)
@@ -76,7 +63,7 @@ class SyntheticTextMel:
                 text[i, :tl[i]] = torch.randint(1, n_symbols, (int(tl[i]),), generator=g)
                 mel[i, :, :ml[i]] = torch.randn(n_mel, int(ml[i]), generator=g) * 1.5 - 4.0
                 gate[i, ml[i] - 1:] = 1
-            self.items.append(tuple(t.to(device) for t in (text, tl, mel, gate)))
+            self.items.append(tuple(t.to(device) for t in (text, tl, mel, gate, ml)))
             self.num_items.append(int(ml.sum()))
 
     def __getitem__(self, i):
@@ -85,67 +72,34 @@ class SyntheticTextMel:
 
 def main(argv=None):
     args = parse_args(argv)
-    rank, world, local = init_from_env("nccl")
-    dev = torch.device("cuda", local)
-    if args.seed is not None:
-        torch.manual_seed(args.seed + local)
-        np.random.seed(args.seed + local)
-    os.makedirs(args.output, exist_ok=True)
-    DLLogger.init(backends=[DLLogger.JSONStreamBackend(DLLogger.Verbosity.DEFAULT, os.path.join(args.output, args.log_file)),
-                            DLLogger.StdOutBackend(DLLogger.Verbosity.VERBOSE)] if rank == 0 else [])
-    for k, v in vars(args).items():
-        DLLogger.log(step="PARAMETER", data={k: v})
-    DLLogger.log(step="PARAMETER", data={"model_name": "Tacotron2_PyT"})
+    rank, world, local, dev = WT.init_run(args, "Tacotron2_PyT")
     config = get_model_config(args)
-    model = Tacotron2(device=dev, **config)
+    model = Tacotron2(device=dev, uniform_initialize_bn_weight=not args.disable_uniform_initialize_bn_weight, **config)
     trainer = Tacotron2Trainer(model, lr=args.learning_rate, weight_decay=args.weight_decay, grad_clip_thresh=args.grad_clip_thresh,
                                compute_dtype=torch.float16 if args.compute_dtype == "fp16" else torch.bfloat16, amp=args.amp,
-                               world_size=world, seed=(args.seed or 1234), rank=rank)
+                               world_size=world, seed=(args.seed or 1234), rank=rank, mask_padding=args.mask_padding)
     names = parameter_order(config)
     start_epoch = 0
     if args.resume_from_last:
         args.checkpoint_path = WT.get_last_checkpoint_filename(args.output, args.model_name)
     if args.checkpoint_path:
         config, start_epoch = WT.load_checkpoint(trainer, args.checkpoint_path, local, names)
-    data = SyntheticTextMel(args.batch_size, config["n_symbols"], config["n_mel_channels"], dev, (args.seed or 0) + 1000 * rank)
-    iteration = start_epoch * args.iters_per_epoch
-    torch.cuda.synchronize()
-    run_start = time.perf_counter()
-    loss_v, ips_epoch = float("nan"), 0.0
-    for epoch in range(start_epoch, args.epochs):
-        ips_sum = 0.0
-        t_epoch = time.perf_counter()
-        for i in range(args.iters_per_epoch):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            trainer.set_lr(WT.adjust_learning_rate(epoch, args.learning_rate, args.anneal_steps, args.anneal_factor))
-            batch, num_items = data[iteration]
-            loss = trainer.train_step(*batch)
-            if world > 1:
-                from ..utils.comm import allreduce_mean_
-                loss = allreduce_mean_(loss.clone())
-            loss_v = float(loss.item())
-            if np.isnan(loss_v):
-                raise Exception("loss is NaN")
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            ips = num_items * world / dt
-            ips_sum += ips
-            DLLogger.log(step=(epoch, i), data={"train_loss": loss_v, "train_items_per_sec": ips, "train_iter_time": dt})
-            iteration += 1
-        ips_epoch = ips_sum / max(args.iters_per_epoch, 1)
-        DLLogger.log(step=(epoch,), data={"train_items_per_sec": ips_epoch, "train_loss": loss_v,
-                                          "train_epoch_time": time.perf_counter() - t_epoch})
-        if epoch % args.epochs_per_checkpoint == 0 and args.bench_class in ("", "train"):
-            WT.save_checkpoint(trainer, epoch, config, args.output, args.model_name, local, world, names)
-        if rank == 0:
-            DLLogger.flush()
-    torch.cuda.synchronize()
-    DLLogger.log(step=tuple(), data={"run_time": time.perf_counter() - run_start, "train_loss": loss_v,
-                                     "train_items_per_sec": ips_epoch})
-    if rank == 0:
-        DLLogger.flush()
-    return loss_v
+        if args.use_saved_learning_rate:
+            args.learning_rate = trainer.lr
+    if args.synthetic_data:
+        seed = (args.seed or 0) + 1000 * rank
+        nsym, nmel = config["n_symbols"], config["n_mel_channels"]
+        train_data = WT.SyntheticEpochs(SyntheticTextMel(args.batch_size, nsym, nmel, dev, seed), args.iters_per_epoch)
+        val_data = WT.SyntheticEpochs(SyntheticTextMel(args.batch_size, nsym, nmel, dev, seed + 7, pool=2), 2)
+    else:
+        from .data_function import TextMelCollate, TextMelLoader, batch_to_gpu
+        collate = TextMelCollate(args.n_frames_per_step)
+        to_trainer = lambda x, y: (x[0], x[1], x[2], y[1], x[4])            # (text, text_lengths, mel, gate target, output_lengths)
+        mk = lambda which, train: WT.LoaderEpochs(TextMelLoader(args.dataset_path, WT.filelist(args, which), args), args.batch_size,
+                                                  collate, batch_to_gpu, to_trainer, dev, world, rank, args.seed, train,
+                                                  drop_last=train or args.bench_class == "perf-train")
+        train_data, val_data = mk("training_files", True), mk("validation_files", False)
+    return WT.train_loop(args, trainer, config, names, train_data, val_data, trainer.eval_loss, start_epoch, rank, world, local)
 
 
 if __name__ == "__main__":

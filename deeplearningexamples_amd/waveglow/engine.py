@@ -313,6 +313,11 @@ class WaveGlowTrainer:
             self.lr = float(lr)
             self.lr_t.fill_(self.lr)
 
+    def eval_loss(self, mel, audio):
+        """The validation pass of train.py:273-318: forward + criterion, nothing updated.  WaveGlow has neither dropout nor
+        BatchNorm, so eval mode runs the training forward; what it keeps for a backward pass is overwritten by the next forward."""
+        return self.forward(mel, audio)
+
     def train_step(self, mel, audio):
         loss = self.forward(mel, audio)
         self.backward()

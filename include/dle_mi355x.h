@@ -462,6 +462,11 @@ int dle_t2_location_bwd(const void* dcol, float* d_prev, float* d_cum, int B, in
 int dle_t2_mel_loss(const float* out_all, int64_t ld_out, const void* post, const float* target, const float* scale_dev,
                     void* d_out, int64_t ld_dout, void* d_post, float* loss, float* workspace, int64_t R, int n_mel, int dtype,
                     hipStream_t stream);
+/* --mask-padding (Tacotron2.parse_output, model.py:648-655): rows (b, t) with t >= lengths[b] of x[B*To, cols] (row pitch ld,
+ * dtype DLE_F32 / F16 / BF16) := value.  The trainer applies it to the mel outputs (0), the gate energies (1e3) and -- because
+ * masked_fill_ cuts the graph at those positions -- to the gradients that flow back into them (0). */
+int dle_t2_mask_rows(void* x, int64_t ld, int cols, const int64_t* lengths, int64_t B, int To, float value, int dtype,
+                     hipStream_t stream);
 
 #ifdef __cplusplus
 }

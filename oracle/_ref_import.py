@@ -146,3 +146,34 @@ def import_tacotron2():
         spec.loader.exec_module(mod)
         out[nm] = mod
     return types.SimpleNamespace(**out)
+
+
+def import_tacotron2_frontend():
+    """The host-side input pipeline of PyTorch/SpeechSynthesis/Tacotron2: tacotron2.text.text_to_sequence,
+    tacotron2.data_function.TextMelCollate, tacotron2_common.stft.STFT.  Absent third-party packages are stubbed: `inflect`
+    (numbers are never spelled out in the fixtures), `librosa` (pad_center restated: centre zero padding; the mel filter bank is
+    NOT provided -- nothing pinned here touches it)."""
+    import numpy as np
+    root = os.path.join(REF, "PyTorch", "SpeechSynthesis", "Tacotron2")
+    if root not in sys.path:
+        sys.path.insert(0, root)
+
+    def pad_center(data, size, axis=-1, **kw):
+        n = data.shape[axis]
+        lpad = (size - n) // 2
+        widths = [(0, 0)] * data.ndim
+        widths[axis] = (lpad, size - n - lpad)
+        return np.pad(data, widths)
+
+    util = _stub("librosa.util", pad_center=pad_center, tiny=lambda x: np.finfo(np.float32).tiny, normalize=None)
+    filt = _stub("librosa.filters", mel=None)
+    _stub("librosa", util=util, filters=filt)
+    _stub("inflect", engine=lambda: None)
+    import importlib
+    text = importlib.import_module("tacotron2.text")
+    stft = importlib.import_module("tacotron2_common.stft")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ref_tacotron2_data_function", os.path.join(root, "tacotron2", "data_function.py"))
+    data = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(data)
+    return types.SimpleNamespace(text=text, stft=stft, data_function=data)

@@ -384,6 +384,48 @@ def gen_waveglow():
 
 
 def gen_tacotron2():
+    """tacotron2_loss.npz (mask_padding = False, the default) and tacotron2_loss_masked.npz (--mask-padding, model.py:648-655)."""
+    _gen_tacotron2(False, "tacotron2_loss.npz")
+    _gen_tacotron2(True, "tacotron2_loss_masked.npz")
+    _gen_tacotron2_eval()
+
+
+def _gen_tacotron2_eval():
+    """tacotron2_loss_eval.npz: the validation pass (train.py:273-318) -- the reference model in eval() mode with seeded BatchNorm
+    running buffers; only the prenet's dropout is drawn."""
+    import torch.nn.functional as TF
+    from oracle import tacotron2_oracle as TO
+    ref = R.import_tacotron2()
+    c = TO.TACOTRON2_CASE
+    cfg = c["cfg"]
+    model = ref.model.Tacotron2(mask_padding=False, max_decoder_steps=2000, gate_threshold=0.5, decoder_no_early_stopping=False, **cfg)
+    state = dict(TO.seeded_state(cfg, c["seed"]))
+    state.update(TO.seeded_running_stats(cfg, c["seed"]))
+    model.load_state_dict(state, strict=False)
+    model.eval()
+    text, tl, mel, gate, ml = TO.seeded_batch(c)
+    stream = TO.MaskStream(c["seed"] + 2)
+    real_dropout = TF.dropout
+    TF.dropout = lambda x, p=0.5, training=True, inplace=False: stream(x, p) if training else x
+    try:
+        with torch.no_grad():
+            out = model((text, tl, mel, int(tl.max()), ml))
+            loss = ref.loss_function.Tacotron2Loss()(out, (mel, gate))
+    finally:
+        TF.dropout = real_dropout
+    stream2 = TO.MaskStream(c["seed"] + 2)
+    with torch.no_grad():
+        lo, (mo, mp, go, al) = TO.tacotron2_loss(state, cfg, text, tl, mel, gate, stream2, training=False)
+    assert stream.calls == stream2.calls == 2, (stream.calls, stream2.calls)
+    assert abs(float(lo) - float(loss)) <= 2e-6 * abs(float(loss)), (float(lo), float(loss))
+    assert torch.allclose(al, out[3], atol=1e-6) and torch.allclose(mp, out[1], atol=5e-5)
+    np.savez_compressed(os.path.join(GOLD, "tacotron2_loss_eval.npz"), loss=np.asarray([float(loss)], np.float64),
+                        dropout_calls=np.asarray([stream.calls], np.int64), alignment_last=out[3][:, -1].numpy(),
+                        mel_post_slice=out[1][:, :4, :].numpy())
+    print("tacotron2_loss_eval.npz loss", float(loss))
+
+
+def _gen_tacotron2(mask_padding, fname):
     """Loss and every parameter gradient of the REFERENCE's Tacotron2 + Tacotron2Loss on CPU (training mode, small widths, the
     full structure), with F.dropout bound to oracle.tacotron2_oracle.MaskStream so that reference and oracle draw the same masks:
     pins oracle/tacotron2_oracle.py (the Tacotron2 half of SURVEY.md 8 row f1)."""
@@ -392,13 +434,25 @@ def gen_tacotron2():
     ref = R.import_tacotron2()
     c = TO.TACOTRON2_CASE
     cfg = c["cfg"]
-    model = ref.model.Tacotron2(mask_padding=False, max_decoder_steps=2000, gate_threshold=0.5, decoder_no_early_stopping=False, **cfg)
+    model = ref.model.Tacotron2(mask_padding=mask_padding, max_decoder_steps=2000, gate_threshold=0.5, decoder_no_early_stopping=False, **cfg)
     state = TO.seeded_state(cfg, c["seed"])
     trainable = {k: tuple(v.shape) for k, v in model.named_parameters()}
     assert trainable == TO.param_shapes(cfg), set(trainable.items()) ^ set(TO.param_shapes(cfg).items())
     model.load_state_dict(state, strict=False)                       # BatchNorm running buffers keep their defaults
     model.train()
     text, tl, mel, gate, ml = TO.seeded_batch(c)
+    if mask_padding:
+        # the reference's parse_output fills mel_outputs IN PLACE after the postnet's first convolution has saved it for its
+        # weight gradient: loss.backward() of the unmodified reference raises ("modified by an inplace operation"); its forward
+        # and loss are fine.  To pin the gradients of the masking it INTENDS, its own parse_output runs on clones.
+        try:
+            ref.loss_function.Tacotron2Loss()(model((text, tl, mel, int(tl.max()), ml)), (mel, gate)).backward()
+            raise AssertionError("expected the reference's --mask-padding backward to raise")
+        except RuntimeError as e:
+            assert "inplace" in str(e), e
+        model.zero_grad()
+        parse = model.parse_output
+        model.parse_output = lambda outputs, lengths: parse([o.clone() for o in outputs], lengths)
     stream = TO.MaskStream(c["seed"] + 2)
     real_dropout = TF.dropout
     TF.dropout = lambda x, p=0.5, training=True, inplace=False: stream(x, p) if training else x
@@ -410,7 +464,7 @@ def gen_tacotron2():
         TF.dropout = real_dropout
     p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
     stream2 = TO.MaskStream(c["seed"] + 2)
-    lo, (mo, mp, go, al) = TO.tacotron2_loss(p, cfg, text, tl, mel, gate, stream2)
+    lo, (mo, mp, go, al) = TO.tacotron2_loss(p, cfg, text, tl, mel, gate, stream2, output_lengths=ml if mask_padding else None)
     lo.backward()
     assert stream.calls == stream2.calls, (stream.calls, stream2.calls)
     assert abs(float(lo) - float(loss)) <= 2e-6 * abs(float(loss)), (float(lo), float(loss))
@@ -419,18 +473,50 @@ def gen_tacotron2():
             "alignment_last": out[3][:, -1].detach().numpy()}
     for k, v in model.named_parameters():
         g, go_ = v.grad, p[k].grad
-        assert torch.allclose(g, go_, rtol=5e-4, atol=2e-7), (k, float((g - go_).abs().max()), float(g.abs().max()))
+        assert torch.allclose(g, go_, rtol=5e-4, atol=max(2e-7, 2e-6 * float(g.abs().max()))), (k, float((g - go_).abs().max()), float(g.abs().max()))
         arrs["gnorm." + k] = np.asarray([float(g.norm())], np.float64)
     for k in ("embedding.weight", "encoder.lstm.weight_hh_l0_reverse", "decoder.attention_rnn.weight_ih",
               "decoder.attention_layer.location_layer.location_conv.conv.weight", "decoder.prenet.layers.0.linear_layer.weight",
               "postnet.convolutions.2.0.conv.weight", "decoder.gate_layer.linear_layer.weight"):
         arrs["grad." + k] = dict(model.named_parameters())[k].grad.numpy().reshape(-1)[:64]
-    np.savez_compressed(os.path.join(GOLD, "tacotron2_loss.npz"), **arrs)
-    print("tacotron2_loss.npz loss", float(loss), "params", len(trainable), "dropout calls", stream.calls)
+    np.savez_compressed(os.path.join(GOLD, fname), **arrs)
+    print(fname, "loss", float(loss), "params", len(trainable), "dropout calls", stream.calls)
+
+
+FRONTEND_SENTENCES = ["Printing, in the only sense with which we are at present concerned, differs from most if not from all the arts.",
+                      "Turn left on {HH AW1 S S T AH0 N} Street; Mr. Smith and Dr. Jones agreed -- didn't they?",
+                      "  Odd   spacing\tand (parentheses), UPPER case: ok!  ", "St. Col. Ltd. esq. capt. ~ _ @ # weird*chars"]
+
+
+def gen_tacotron2_frontend():
+    """tests/golden/tacotron2_frontend.npz: the reference's own text_to_sequence (english / basic cleaners) on ASCII, digit-free
+    sentences, TextMelCollate on a seeded ragged batch (n_frames_per_step 1 and 3), and |STFT| of a seeded waveform through
+    tacotron2_common.stft.STFT (filter 1024, hop 256, Hann 1024): pins deeplearningexamples_amd/tacotron2/{text,data_function,
+    audio}.py."""
+    ref = R.import_tacotron2_frontend()
+    arrs = {}
+    for ci, cleaners in enumerate((["english_cleaners"], ["basic_cleaners"])):
+        for si, sent in enumerate(FRONTEND_SENTENCES):
+            arrs["seq.%d.%d" % (ci, si)] = np.asarray(ref.text.text_to_sequence(sent, cleaners), np.int64)
+    arrs["symbols"] = np.asarray(ref.text.symbols)
+    rng = np.random.default_rng(41)
+    lens, mels = [7, 12, 3, 12, 9], [19, 31, 8, 25, 31]
+    batch = [(torch.from_numpy(rng.integers(1, 148, l).astype(np.int32)), torch.from_numpy(rng.standard_normal((5, m)).astype(np.float32)), l + 2)
+             for l, m in zip(lens, mels)]
+    for nf in (1, 3):
+        out = ref.data_function.TextMelCollate(nf)(batch)
+        for k, t in zip(("text", "input_lengths", "mel", "gate", "output_lengths", "len_x"), out):
+            arrs["collate%d.%s" % (nf, k)] = t.numpy()
+    wav = (rng.random(5000) * 2 - 1).astype(np.float32)
+    mag, _ = ref.stft.STFT(1024, 256, 1024).transform(torch.from_numpy(wav)[None])
+    arrs["wav"] = wav
+    arrs["stft_mag"] = mag[0].numpy()[::8]                              # every 8th frequency bin of all 20 frames
+    np.savez_compressed(os.path.join(GOLD, "tacotron2_frontend.npz"), **arrs)
+    print("tacotron2_frontend.npz", {k: v.shape for k, v in arrs.items() if not k.startswith("seq")})
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dlrm", "dlrm_step", "rn50", "lamb", "bert", "floors", "waveglow", "tacotron2"]
+    which = sys.argv[1:] or ["dlrm", "dlrm_step", "rn50", "lamb", "bert", "floors", "waveglow", "tacotron2", "tacotron2_frontend"]
     os.makedirs(GOLD, exist_ok=True)
     if not R.have_reference():
         sys.exit("reference not mounted; fixtures are generated in the build container only")

@@ -10,11 +10,12 @@ Follows, in plain fp32 torch on the CPU (paths relative to /root/reference/PyTor
     tacotron2/model.py:405-455,457-519  Decoder.decode / forward: attention LSTMCell, dropout 0.1, attention, decoder LSTMCell,
                                         dropout 0.1, linear projection + gate on [decoder_hidden | context]
     tacotron2/model.py:138-174          Postnet: 4 x (Conv1d k5 + BN + tanh + dropout 0.5) + (Conv1d + BN + dropout 0.5)
-    tacotron2/loss_function.py:31-46    MSE(mel) + MSE(mel_postnet) + BCEWithLogits(gate)   (mask_padding = False, the default)
+    tacotron2/loss_function.py:31-46    MSE(mel) + MSE(mel_postnet) + BCEWithLogits(gate)
+    tacotron2/model.py:648-655          parse_output: --mask-padding (off by default) overwrites the frames past each sample's length
 Dropout is EXTERNAL: every dropout site asks `drop(x, p)` for its mask in the reference's call order, so that the reference run
 (F.dropout patched to the same stream), this oracle and the HIP path (counter-based masks, replayed site by site) see identical masks.
 BatchNorm uses batch statistics (training mode) and does not update running buffers here.  Parameter names are the reference's
-state_dict keys.  Pinned by tests/golden/tacotron2_loss.npz (oracle/make_golden.py gen_tacotron2: loss, every parameter gradient
+state_dict keys.  Pinned by tests/golden/tacotron2_loss.npz and tacotron2_loss_masked.npz (oracle/make_golden.py gen_tacotron2: loss, every parameter gradient
 norm, gradient slices; the generator asserts oracle == reference).
 """
 import numpy as np
@@ -50,10 +51,14 @@ class MaskStream:
         return x * keep / (1.0 - p)
 
 
-def _bn(x, p, name, eps=1e-5):
-    """BatchNorm1d in training mode on [B, C, T]: statistics over (B, T), biased variance (torch.nn.BatchNorm1d.forward)."""
-    mean = x.mean(dim=(0, 2), keepdim=True)
-    var = x.var(dim=(0, 2), unbiased=False, keepdim=True)
+def _bn(x, p, name, eps=1e-5, training=True):
+    """BatchNorm1d on [B, C, T].  Training mode: statistics over (B, T), biased variance (torch.nn.BatchNorm1d.forward); eval mode:
+    the running buffers p[name + ".running_mean" / ".running_var"]."""
+    if training:
+        mean = x.mean(dim=(0, 2), keepdim=True)
+        var = x.var(dim=(0, 2), unbiased=False, keepdim=True)
+    else:
+        mean, var = p[name + ".running_mean"].view(1, -1, 1), p[name + ".running_var"].view(1, -1, 1)
     return (x - mean) / torch.sqrt(var + eps) * p[name + ".weight"].view(1, -1, 1) + p[name + ".bias"].view(1, -1, 1)
 
 
@@ -83,9 +88,13 @@ def _lstm_dir(x, lengths, p, pre, reverse):
     return torch.stack(outs, dim=1)
 
 
-def tacotron2_loss(p, cfg, text, text_lengths, mel, gate_target, drop):
+def tacotron2_loss(p, cfg, text, text_lengths, mel, gate_target, drop, output_lengths=None, training=True):
     """Tacotron2.forward + Tacotron2Loss.  text int64 [B, T_in] (sorted by length, descending), mel [B, 80, T_out] zero padded,
-    gate_target [B, T_out]; p: name -> tensor; drop: MaskStream-like.  -> (loss, (mel_out, mel_post, gate_out, alignments))."""
+    gate_target [B, T_out]; p: name -> tensor; drop: MaskStream-like; output_lengths (int64 [B]) given = --mask-padding
+    (Tacotron2.parse_output, model.py:648-655: frames past a sample's length are overwritten -- mel outputs 0, gate energies 1e3 --
+    before the loss, which cuts their gradient).  training = False: model.eval() -- the validation pass of train.py:273-318 --
+    BatchNorm on its running buffers (p[<bn>.running_mean / .running_var]) and only the prenet's dropout drawn (model.py:133 passes
+    training=True unconditionally).  -> (loss, (mel_out, mel_post, gate_out, alignments))."""
     nconv, pconv = cfg["encoder_n_convolutions"], cfg["postnet_n_convolutions"]
     pa, pdrop = cfg["p_attention_dropout"], cfg["p_decoder_dropout"]
     x = TF.embedding(text, p["embedding.weight"]).transpose(1, 2)                       # [B, E, T_in]
@@ -93,7 +102,8 @@ def tacotron2_loss(p, cfg, text, text_lengths, mel, gate_target, drop):
         pre = "encoder.convolutions.%d." % i
         k = p[pre + "0.conv.weight"].shape[2]
         x = TF.conv1d(x, p[pre + "0.conv.weight"], p[pre + "0.conv.bias"], padding=(k - 1) // 2)
-        x = drop(torch.relu(_bn(x, p, pre + "1")), 0.5)
+        x = torch.relu(_bn(x, p, pre + "1", training=training))
+        x = drop(x, 0.5) if training else x
     x = x.transpose(1, 2)
     memory = torch.cat([_lstm_dir(x, text_lengths, p, "encoder.lstm.", False),
                         _lstm_dir(x, text_lengths, p, "encoder.lstm.", True)], dim=2)     # [B, T_in, E]
@@ -115,7 +125,7 @@ def tacotron2_loss(p, cfg, text, text_lengths, mel, gate_target, drop):
     for step in range(t_out):
         ah, ac = _lstm_cell(torch.cat([dec_in[step], ctx], dim=1), ah, ac, p["decoder.attention_rnn.weight_ih"],
                             p["decoder.attention_rnn.weight_hh"], p["decoder.attention_rnn.bias_ih"], p["decoder.attention_rnn.bias_hh"])
-        ah = drop(ah, pa)
+        ah = drop(ah, pa) if training else ah
         loc = TF.conv1d(torch.stack([aw, aw_cum], dim=1), p[att + "location_layer.location_conv.conv.weight"], padding=(kloc - 1) // 2)
         loc = loc.transpose(1, 2) @ p[att + "location_layer.location_dense.linear_layer.weight"].t()
         q = (ah @ p[att + "query_layer.linear_layer.weight"].t()).unsqueeze(1)
@@ -125,7 +135,7 @@ def tacotron2_loss(p, cfg, text, text_lengths, mel, gate_target, drop):
         aw_cum = aw_cum + aw
         dh, dc = _lstm_cell(torch.cat([ah, ctx], dim=1), dh, dc, p["decoder.decoder_rnn.weight_ih"], p["decoder.decoder_rnn.weight_hh"],
                             p["decoder.decoder_rnn.bias_ih"], p["decoder.decoder_rnn.bias_hh"])
-        dh = drop(dh, pdrop)
+        dh = drop(dh, pdrop) if training else dh
         hc = torch.cat([dh, ctx], dim=1)
         mel_outs.append(hc @ p["decoder.linear_projection.linear_layer.weight"].t() + p["decoder.linear_projection.linear_layer.bias"])
         gate_outs.append((hc @ p["decoder.gate_layer.linear_layer.weight"].t() + p["decoder.gate_layer.linear_layer.bias"]).squeeze(1))
@@ -136,9 +146,15 @@ def tacotron2_loss(p, cfg, text, text_lengths, mel, gate_target, drop):
     for i in range(pconv):
         pre = "postnet.convolutions.%d." % i
         k = p[pre + "0.conv.weight"].shape[2]
-        y = _bn(TF.conv1d(y, p[pre + "0.conv.weight"], p[pre + "0.conv.bias"], padding=(k - 1) // 2), p, pre + "1")
-        y = drop(torch.tanh(y) if i < pconv - 1 else y, 0.5)
+        y = _bn(TF.conv1d(y, p[pre + "0.conv.weight"], p[pre + "0.conv.bias"], padding=(k - 1) // 2), p, pre + "1", training=training)
+        y = torch.tanh(y) if i < pconv - 1 else y
+        y = drop(y, 0.5) if training else y
     mel_post = mel_out + y
+    if output_lengths is not None:
+        past = torch.arange(t_out)[None, :] >= output_lengths[:, None]                   # [B, T_out]
+        mel_out = mel_out.masked_fill(past[:, None, :], 0.0)
+        mel_post = mel_post.masked_fill(past[:, None, :], 0.0)
+        gate_out = gate_out.masked_fill(past, 1e3)
     loss = TF.mse_loss(mel_out, mel) + TF.mse_loss(mel_post, mel) + TF.binary_cross_entropy_with_logits(gate_out, gate_target)
     return loss, (mel_out, mel_post, gate_out, torch.stack(aligns, dim=1))
 
@@ -175,6 +191,17 @@ def param_shapes(cfg):
         sh[pre + "0.conv.weight"] = (cout, cin, cfg["postnet_kernel_size"])
         sh[pre + "0.conv.bias"] = sh[pre + "1.weight"] = sh[pre + "1.bias"] = (cout,)
     return sh
+
+
+def seeded_running_stats(cfg, seed):
+    """BatchNorm running buffers for the eval-mode fixtures: means ~ N(0, 0.3), variances in [0.5, 1.5]."""
+    rng = np.random.default_rng(seed + 101)
+    out = {}
+    for name, shape in sorted(param_shapes(cfg).items()):
+        if name.endswith(".1.weight"):
+            out[name[:-6] + "running_mean"] = torch.from_numpy((0.3 * rng.standard_normal(shape)).astype(np.float32))
+            out[name[:-6] + "running_var"] = torch.from_numpy((0.5 + rng.random(shape)).astype(np.float32))
+    return out
 
 
 def seeded_state(cfg, seed):

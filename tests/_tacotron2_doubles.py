@@ -77,6 +77,20 @@ def bn_fwd(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, moment
     return y, mean, rstd
 
 
+def bn_fwd_apply(x, mean, rstd, gamma, beta, residual=None, relu=True, want_mask=False):
+    """dle_bn_fwd_apply with given statistics (the eval-mode BatchNorm): -> (y, None)."""
+    assert residual is None and not want_mask
+    y = (x.float() - mean) * rstd * gamma + beta
+    return (torch.relu(y) if relu else y).to(x.dtype), None
+
+
+def mask_rows(x, cols, lengths, b, to, value):
+    """dle_t2_mask_rows: rows (b, t) with t >= lengths[b] of x [B*To, >= cols], columns [0, cols) := value (parse_output,
+    model.py:648-655)."""
+    past = (torch.arange(to)[None, :] >= lengths[:, None]).reshape(b * to)
+    x[:, :cols][past] = value
+
+
 def bn_bwd(dy, y, x, mean, rstd, gamma, dgamma, dbeta, want_skip_grad=False, dx_out=None, relu_mask=None):
     assert relu_mask is None and not want_skip_grad
     c = x.shape[-1]
@@ -360,13 +374,13 @@ def install(monkeypatch):
     me = globals()
     monkeypatch.setattr(C, "require_cuda", lambda *a: None)
     for name in ("gemm", "cast_rows", "cast", "bn_fwd", "bn_bwd", "dropout_fwd", "dropout_bwd", "rows_gather", "embed_scatter_add_",
-                 "act_bwd", "bce_with_logits", "relu_bwd", "axpby_", "transpose_cast"):
+                 "act_bwd", "bce_with_logits", "relu_bwd", "axpby_", "transpose_cast", "bn_fwd_apply"):
         monkeypatch.setattr(F, name, me[name])
     for name in ("colsum", "copy_rows", "check_nonfinite_", "amp_update_scale_", "gemm_batched"):
         monkeypatch.setattr(F, name, getattr(W, name))
     for name in ("taps", "taps_bwd", "weight_norm_fwd", "weight_norm_bwd"):
         monkeypatch.setattr(wops, name, getattr(W, name))
-    for name in ("tanh_fwd", "lstm_fwd", "lstm_bwd", "attention_fwd", "attention_bwd", "location_bwd", "sum_steps", "mel_loss", "inv_keep"):
+    for name in ("tanh_fwd", "lstm_fwd", "lstm_bwd", "attention_fwd", "attention_bwd", "location_bwd", "sum_steps", "mel_loss", "inv_keep", "mask_rows"):
         monkeypatch.setattr(ops, name, me[name])
     fake_mt = types.SimpleNamespace(TableCache=W.TableCache, streaming_chunk=W.streaming_chunk, l2norm=W.l2norm, adam=W.adam)
     monkeypatch.setattr(engine, "mt", fake_mt)

@@ -94,6 +94,121 @@ def test_reference_command_lines_parse():
         psrc = open(dm.__file__).read()
         missing = [x for x in flags if '"--%s"' % x not in psrc]
         assert not missing, missing
+        # SpeechSynthesis/Tacotron2: train.py:45-160 + tacotron2/arg_parser.py:40-107 + waveglow/arg_parser.py:30-64
+        from deeplearningexamples_amd.tacotron2 import train as t2
+        from deeplearningexamples_amd.waveglow import train as wg
+        base = ref + "/SpeechSynthesis/Tacotron2/"
+        common = set(re.findall(r"""add_argument\(\s*(?:'-[a-z]+',\s*)?'(--[a-zA-Z0-9_-]+)'""", "\n".join(l for l in open(base + "train.py") if not l.lstrip().startswith("#"))))
+        for mod, extra in ((t2, "tacotron2/arg_parser.py"), (wg, "waveglow/arg_parser.py")):
+            flags = common | set(re.findall(r"""add_argument\(\s*'(--[a-zA-Z0-9_-]+)'""", open(base + extra).read()))
+            known = _known_flags(mod)
+            missing = sorted(x for x in flags if x not in known)
+            assert not missing and len(flags) > 50 - 10 * (mod is wg), (mod.__name__, missing, len(flags))
+
+
+def _known_flags(mod):
+    """Option strings of the parser `mod.parse_args` builds (captured without parsing a command line)."""
+    import argparse
+    seen = {}
+    real = argparse.ArgumentParser.parse_known_args
+
+    def grab(self, args=None, namespace=None):
+        seen["p"] = self
+        return real(self, args, namespace)
+
+    argparse.ArgumentParser.parse_known_args = grab
+    try:
+        mod.parse_args(["-o", "x", "-lr", "1", "--epochs", "1", "-bs", "1"])
+    finally:
+        argparse.ArgumentParser.parse_known_args = real
+    return {o for act in seen["p"]._actions for o in act.option_strings}
+
+
+def test_speech_command_lines_parse_and_config_file(tmp_path):
+    """scripts/train_tacotron2.sh / train_waveglow.sh of the reference + --config-file (tacotron2_common/utils.py:36-49)."""
+    from deeplearningexamples_amd.tacotron2 import train as t2
+    from deeplearningexamples_amd.waveglow import train as wg
+    a = t2.parse_args("-m Tacotron2 -o ./output/ -lr 1e-3 --epochs 1501 -bs 48 --weight-decay 1e-6 --grad-clip-thresh 1.0 "
+                      "--cudnn-enabled --log-file nvlog.json --anneal-steps 500 1000 1500 --anneal-factor 0.1 --load-mel-from-disk "
+                      "--training-files filelists/ljs_mel_text_train_filelist.txt --validation-files filelists/ljs_mel_text_val_filelist.txt "
+                      "-d /data/LJSpeech-1.1 --mask-padding True --text-cleaners english_cleaners --resume-from-last".split())
+    assert a.load_mel_from_disk and a.mask_padding and a.dataset_path == "/data/LJSpeech-1.1" and not a.synthetic_data
+    assert t2.get_model_config(a)["mask_padding"] is True and set(t2.get_model_config(a)) >= {"max_decoder_steps", "gate_threshold"}
+    b = wg.parse_args("-m WaveGlow -o ./output/ -lr 1e-4 --epochs 1501 -bs 4 --segment-length 8000 --weight-decay 0 "
+                      "--grad-clip-thresh 3.4028234663852886e+38 --cudnn-enabled --cudnn-benchmark --log-file nvlog.json".split())
+    assert b.segment_length == 8000 and b.grad_clip_thresh > 3e38 and b.training_files.endswith("ljs_audio_text_train_filelist.txt")
+    cfg = tmp_path / "config.json"
+    cfg.write_text(json.dumps({"audio": {"sampling-rate": 16000, "hop-length": 200}, "model": {"prenet-dim": 128}}))
+    c = t2.parse_args(["-o", "x", "-lr", "1", "--epochs", "1", "-bs", "1", "--config-file", str(cfg)])
+    assert (c.sampling_rate, c.hop_length, c.prenet_dim) == (16000, 200, 128)
+
+
+def _speech_dataset(root, n_train=6, n_val=3, mels=True):
+    """A tiny LJSpeech-shaped dataset: 22.05 kHz int16 wavs, saved mels, `path|text` filelists."""
+    import torch
+    from scipy.io.wavfile import write
+    rng = np.random.default_rng(0)
+    os.makedirs(root / "wavs"), os.makedirs(root / "mels"), os.makedirs(root / "filelists")
+    words = "the quick brown fox jumps over a lazy dog while printing differs from most arts".split()
+    for split, n in (("train", n_train), ("val", n_val)):
+        la, lm = [], []
+        for i in range(n):
+            name = "%s%d" % (split, i)
+            samples = int(rng.integers(5000, 9000))
+            write(str(root / "wavs" / (name + ".wav")), 22050, (rng.standard_normal(samples) * 6000).astype(np.int16))
+            torch.save(torch.randn(80, int(rng.integers(18, 40))) * 1.5 - 4.0, str(root / "mels" / (name + ".pt")))
+            text = " ".join(rng.choice(words, int(rng.integers(3, 8)))).capitalize() + "."
+            la.append("wavs/%s.wav|%s" % (name, text))
+            lm.append("mels/%s.pt|%s" % (name, text))
+        (root / "filelists" / ("audio_%s.txt" % split)).write_text("\n".join(la) + "\n")
+        (root / "filelists" / ("mel_%s.txt" % split)).write_text("\n".join(lm) + "\n")
+
+
+@pytest.mark.gpu
+def test_speech_entry_points_train_validate_and_resume_from_filelists(cuda, tmp_path):
+    """the Tacotron2 and WaveGlow CLIs on a tiny on-disk dataset -- TextMelLoader (saved mels and wavs
+    through the STFT front end) + TextMelCollate, MelAudioLoader, --mask-padding, the per-epoch validation pass, checkpoint + resume."""
+    from deeplearningexamples_amd.tacotron2 import train as t2
+    from deeplearningexamples_amd.waveglow import train as wg
+    data = tmp_path / "data"
+    _speech_dataset(data)
+    small = ("--symbols-embedding-dim 64 --encoder-embedding-dim 64 --attention-rnn-dim 96 --attention-dim 32 "
+             "--attention-location-n-filters 8 --decoder-rnn-dim 96 --prenet-dim 48 --postnet-embedding-dim 64").split()
+    out = tmp_path / "t2"
+    common = ["-m", "Tacotron2", "-o", str(out), "-d", str(data), "--amp", "-lr", "1e-3", "-bs", "2", "--seed", "3",
+              "--epochs-per-checkpoint", "1", "--mask-padding", "True", "--text-cleaners", "english_cleaners"] + small
+    mel_lists = ["--load-mel-from-disk", "--training-files", "filelists/mel_train.txt", "--validation-files", "filelists/mel_val.txt"]
+    t2.main(common + mel_lists + ["--epochs", "2"])
+    recs = [json.loads(l[5:]) for l in open(out / "nvlog.json")]
+    val = [r["data"]["val_loss"] for r in recs if r["type"] == "LOG" and "val_loss" in r.get("data", {}) and r["step"] not in ([],)]
+    tl = [r["data"]["train_loss"] for r in recs if r["type"] == "LOG" and "train_loss" in r.get("data", {}) and len(r["step"]) == 2]
+    assert len(tl) == 2 * 3 and len(val) >= 2 and all(np.isfinite(v) for v in val + tl)          # 6 files / bs 2 x 2 epochs
+    assert os.path.islink(out / "checkpoint_Tacotron2_last.pt") and os.path.exists(out / "checkpoint_Tacotron2_1.pt")
+    import torch
+    ck = torch.load(out / "checkpoint_Tacotron2_1.pt", map_location="cpu", weights_only=False)
+    assert ck["config"]["mask_padding"] is True and ck["epoch"] == 1
+    t2.main(common + mel_lists + ["--epochs", "3", "--resume-from-last"])                         # one more epoch from the link
+    recs2 = [json.loads(l[5:]) for l in open(out / "nvlog.json")]
+    assert any(r.get("step") == [2, 0] for r in recs2) and os.path.exists(out / "checkpoint_Tacotron2_2.pt")
+    # wavs through the STFT front end
+    out_w = tmp_path / "t2w"
+    t2.main(["-m", "Tacotron2", "-o", str(out_w), "-d", str(data), "--amp", "-lr", "1e-3", "-bs", "3", "--epochs", "1",
+             "--training-files", "filelists/audio_train.txt", "--validation-files", "filelists/audio_val.txt"] + small)
+    recs = [json.loads(l[5:]) for l in open(out_w / "nvlog.json")]
+    assert sum("train_loss" in r.get("data", {}) and len(r.get("step", [])) == 2 for r in recs) == 2
+    # WaveGlow
+    out_g = tmp_path / "wg"
+    wg_small = "--flows 4 --wn-layers 2 --wn-channels 64 --early-every 2 --segment-length 2048".split()
+    wg.main(["-m", "WaveGlow", "-o", str(out_g), "-d", str(data), "--amp", "-lr", "1e-4", "-bs", "2", "--epochs", "1", "--weight-decay", "0",
+             "--grad-clip-thresh", "65504.0", "--training-files", "filelists/audio_train.txt", "--validation-files",
+             "filelists/audio_val.txt"] + wg_small)
+    recs = [json.loads(l[5:]) for l in open(out_g / "nvlog.json")]
+    assert sum("train_loss" in r.get("data", {}) and len(r.get("step", [])) == 2 for r in recs) == 3
+    assert any("val_loss" in r.get("data", {}) for r in recs) and os.path.exists(out_g / "checkpoint_WaveGlow_0.pt")
+    # synthetic mode + missing filelist
+    wg.main(["-o", str(tmp_path / "wgs"), "-lr", "1e-4", "-bs", "2", "--epochs", "1", "--amp", "--synthetic-data", "--iters-per-epoch", "2"] + wg_small)
+    with pytest.raises(SystemExit, match="no such filelist"):
+        t2.main(["-o", str(tmp_path / "none"), "-lr", "1e-3", "-bs", "2", "--epochs", "1"] + small)
 
 
 @pytest.mark.gpu

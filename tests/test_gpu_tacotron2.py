@@ -206,6 +206,26 @@ def test_mel_loss_and_tanh(cuda, dtype):
     _close(ops.tanh_fwd(x.to(cuda)), D.tanh_fwd(x), **_tol(dtype))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_mask_rows(cuda, dtype):
+    """dle_t2_mask_rows == masked_fill over the frames past each sample's length (parse_output, model.py:648-655), on a strided view."""
+    from deeplearningexamples_amd.tacotron2 import ops
+    g = torch.Generator().manual_seed(5)
+    b, to, cols, ld = 5, 37, 80, 88
+    lengths = torch.tensor([37, 30, 18, 1, 0], dtype=torch.int64)
+    x = torch.randn(b * to, ld, generator=g).to(dtype)
+    want = x.clone().view(b, to, ld)
+    past = torch.arange(to)[None, :] >= lengths[:, None]
+    want[:, :, :cols] = want[:, :, :cols].masked_fill(past[:, :, None], 0.0)
+    want[:, :, cols] = want[:, :, cols].masked_fill(past, 1e3)
+    xd = x.to(cuda)
+    ops.mask_rows(xd, cols, lengths.to(cuda), b, to, 0.0)
+    ops.mask_rows(xd[:, cols:], 1, lengths.to(cuda), b, to, 1e3)
+    assert torch.equal(xd.cpu(), want.view(b * to, ld))
+    with pytest.raises(ValueError):
+        ops.mask_rows(xd, cols, lengths.to(cuda).int(), b, to, 0.0)
+
+
 def _engine_masks(tr, F):
     """The keep masks the engine drew (HIP counter-based RNG), in the order tests/test_tacotron2_host.py _Replay expects."""
     sv = tr.sv
@@ -218,10 +238,12 @@ def _engine_masks(tr, F):
     return log
 
 
-@pytest.mark.parametrize("dtype,case", [(torch.float16, None), (torch.bfloat16, None),
-                                        # 24 text positions: the memory gradient of the context goes through the batched GEMM
-                                        (torch.float16, dict(text_lengths=[24, 17, 9], mel_lengths=[20, 29, 13]))])
-def test_step_loss_and_gradients_vs_oracle_under_the_hip_masks(cuda, dtype, case):
+@pytest.mark.parametrize("dtype,case,masked", [(torch.float16, None, False), (torch.bfloat16, None, False),
+                                               # 24 text positions: the memory gradient of the context goes through the batched GEMM
+                                               (torch.float16, dict(text_lengths=[24, 17, 9], mel_lengths=[20, 29, 13]), False),
+                                               # --mask-padding (model.py:648-655)
+                                               (torch.float16, None, True), (torch.bfloat16, None, True)])
+def test_step_loss_and_gradients_vs_oracle_under_the_hip_masks(cuda, dtype, case, masked):
     from oracle import tacotron2_oracle as TO
     from deeplearningexamples_amd import functional as F
     from deeplearningexamples_amd.tacotron2.engine import Tacotron2Trainer
@@ -233,16 +255,21 @@ def test_step_loss_and_gradients_vs_oracle_under_the_hip_masks(cuda, dtype, case
     model = Tacotron2(device=cuda, **cfg)
     model.load_reference_state(state)
     scale = 65536.0                                            # GradScaler's default: small fp16 gradients stay out of the subnormals
-    tr = Tacotron2Trainer(model, compute_dtype=dtype, init_loss_scale=scale)
+    tr = Tacotron2Trainer(model, compute_dtype=dtype, init_loss_scale=scale, mask_padding=masked)
     text, tl, mel, gate, ml = TO.seeded_batch(c)
-    loss = tr.forward(text.to(cuda), tl.to(cuda), mel.to(cuda), gate.to(cuda))
+    loss = tr.forward(text.to(cuda), tl.to(cuda), mel.to(cuda), gate.to(cuda), ml.to(cuda))
     tr.backward()
     assert bool(torch.isfinite(tr.g.flat).all())
     replay = _Replay(_engine_masks(tr, F), mel.shape[2], text.shape[0], cfg["attention_rnn_dim"], cfg["decoder_rnn_dim"])
     p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
-    lo, (_, _, _, align) = TO.tacotron2_loss(p, cfg, text, tl, mel, gate, replay)
+    lo, (_, _, _, align) = TO.tacotron2_loss(p, cfg, text, tl, mel, gate, replay, output_lengths=ml if masked else None)
     lo.backward()
     assert replay.calls == len(replay.sites)
+    if masked:                                                 # the flag changes the loss: the unmasked value is not within the bar
+        lo_un = TO.tacotron2_loss({k: v.detach() for k, v in p.items()}, cfg, text, tl, mel, gate,
+                                  _Replay(_engine_masks(tr, F), mel.shape[2], text.shape[0], cfg["attention_rnn_dim"],
+                                          cfg["decoder_rnn_dim"]))[0]
+        assert abs(float(lo_un) - float(lo.detach())) > 5e-3 * abs(float(lo.detach()))
     assert abs(float(loss) - float(lo.detach())) <= 1e-3 * abs(float(lo.detach())), (float(loss), float(lo.detach()))
     _close(tr.sv["aw"].permute(1, 0, 2), align, rtol=5e-2, atol=2e-3 if dtype == torch.float16 else 1e-2)
     # floor of the worst tensor (always an encoder one: its gradient crosses the decoder sweep, the attention, the bi-LSTM sweep and
@@ -258,6 +285,56 @@ def test_step_loss_and_gradients_vs_oracle_under_the_hip_masks(cuda, dtype, case
     # keep rates of the drawn masks
     log = _engine_masks(tr, F)
     assert abs(float(log[0].float().mean()) - 0.5) < 0.03 and abs(float(log[5].float().mean()) - 0.9) < 0.03
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_validation_pass_vs_oracle_in_eval_mode(cuda, dtype):
+    """Tacotron2Trainer.eval_loss == the oracle's eval-mode loss (train.py:273-318: BatchNorm on its running buffers, only the
+    prenet's dropout on) under the two prenet masks the engine drew; the pass leaves buffers and training state untouched."""
+    from oracle import tacotron2_oracle as TO
+    from deeplearningexamples_amd import functional as F
+    from deeplearningexamples_amd.tacotron2.engine import Tacotron2Trainer
+    from deeplearningexamples_amd.tacotron2.model import Tacotron2
+    c = TO.TACOTRON2_CASE
+    cfg = c["cfg"]
+    state = dict(TO.seeded_state(cfg, c["seed"]))
+    state.update(TO.seeded_running_stats(cfg, c["seed"]))
+    model = Tacotron2(device=cuda, **cfg)
+    model.load_reference_state(state)
+    tr = Tacotron2Trainer(model, compute_dtype=dtype)
+    text, tl, mel, gate, ml = TO.seeded_batch(c)
+    dev = [t.to(cuda) for t in (text, tl, mel, gate, ml)]
+    bufs = {k: v.clone() for k, v in model.named_buffers()}
+    # the engine clears what it saved after the pass: catch the prenet masks while it runs
+    masks = []
+    real = tr._drop
+
+    def spy(x, p):
+        y, m = real(x, p)
+        masks.append(F.unpack_dropout_mask(m, x.shape).cpu())
+        return y, m
+
+    tr._drop = spy
+    loss = tr.eval_loss(*dev)
+    tr._drop = real
+    assert len(masks) == 2 and tr.training and tr.sv is None
+    for k, v in model.named_buffers():
+        assert torch.equal(v, bufs[k]), k
+
+    class Replay:
+        calls = 0
+
+        def __call__(self, x, p):
+            keep = masks[self.calls].reshape(x.shape)
+            self.calls += 1
+            return x * keep / (1.0 - p)
+
+    with torch.no_grad():
+        lo, _ = TO.tacotron2_loss(state, cfg, text, tl, mel, gate, Replay(), training=False)
+    tol = 2e-3 if dtype == torch.float16 else 1e-2
+    assert abs(float(loss) - float(lo)) <= tol * abs(float(lo)), (float(loss), float(lo))
+    # and differs from the training-mode loss on the same batch (batch statistics, dropout everywhere)
+    assert abs(float(tr.forward(*dev[:4])) - float(lo)) > 5e-3 * abs(float(lo))
 
 
 def _oracle_under_engine_masks(TO, F, tr, p, cfg, batch):

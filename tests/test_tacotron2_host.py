@@ -160,3 +160,46 @@ def test_reference_widths_one_step(monkeypatch):
     for k, v in p.items():
         assert float((tr.g[k] / 64.0 - v.grad).norm()) <= 1e-3 * float(v.grad.norm()) + 2e-6, k
     assert sum(v.numel() for v in p.values()) == 28193153
+
+
+def test_mask_padding_and_validation_pass_follow_the_oracle(monkeypatch):
+    """--mask-padding (model.py:648-655) through the engine's sequence: loss and every gradient == the oracle's with output_lengths
+    given; eval_loss == the oracle in eval mode (running BatchNorm buffers, prenet dropout only) and leaves the buffers alone."""
+    TO, D, c, model, state, tr = _setup(monkeypatch, True, init_loss_scale=256.0, mask_padding=True)
+    text, tl, mel, gate, ml = TO.seeded_batch(c)
+    cfg = c["cfg"]
+    with pytest.raises(ValueError, match="output lengths"):
+        tr.forward(text, tl, mel, gate)
+    loss = tr.forward(text, tl, mel, gate, ml)
+    tr.backward()
+    replay = _Replay(D.Masks.log, mel.shape[2], text.shape[0], cfg["attention_rnn_dim"], cfg["decoder_rnn_dim"])
+    p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    lo, _ = TO.tacotron2_loss(p, cfg, text, tl, mel, gate, replay, output_lengths=ml)
+    lo.backward()
+    assert abs(float(loss) - float(lo.detach())) <= 5e-6 * abs(float(lo.detach())), (float(loss), float(lo.detach()))
+    s = float(tr.scaler.scale)
+    for k, v in p.items():
+        ref, got = v.grad, tr.g[k] / s
+        assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 2e-6, k
+    # validation pass
+    stats = TO.seeded_running_stats(cfg, c["seed"])
+    model.load_reference_state(dict(state, **stats))
+    bufs = {k: v.clone() for k, v in model.named_buffers()}
+    D.Masks.reset(5)
+    ev = tr.eval_loss(text, tl, mel, gate, ml)
+    assert len(D.Masks.log) == 2 and tr.training
+    for k, v in model.named_buffers():
+        assert torch.equal(v, bufs[k]), k
+    sites = list(D.Masks.log)
+
+    class Prenet:
+        calls = 0
+
+        def __call__(self, x, pr):
+            keep = sites[self.calls].reshape(x.shape)
+            self.calls += 1
+            return x * keep * D.inv_keep(pr)
+
+    with torch.no_grad():
+        lo_ev, _ = TO.tacotron2_loss(dict(state, **stats), cfg, text, tl, mel, gate, Prenet(), output_lengths=ml, training=False)
+    assert abs(float(ev) - float(lo_ev)) <= 5e-6 * abs(float(lo_ev)), (float(ev), float(lo_ev))
