@@ -192,7 +192,16 @@ extern "C" int dle_gemm_smallm_try(const void* A, const void* B, void* C, const 
   const int tm = (M + SM_TS - 1) / SM_TS;
   // 64 x 32 tiles (8 wavefronts) unless that leaves more than half of the CUs without a workgroup while 64 x 16 tiles would not
   const int t32 = tm * ((N + 31) / 32), t16 = tm * ((N + 15) / 16);
-  const bool wide = N > 16 && (t32 >= 128 || t16 > 256);
+  bool wide = N > 16 && (t32 >= 128 || t16 > 256);
+  {
+    // tools/probes/smallm_policy.py: DLE_GEMM_SMALLM_TN = 16 | 32 pins the tile (read per call, only when the variable exists)
+    static const bool probing = getenv("DLE_GEMM_SMALLM_TN") != nullptr;
+    if (probing) {
+      const int tn = atoi(getenv("DLE_GEMM_SMALLM_TN"));
+      if (tn == 16) wide = false;
+      else if (tn == 32 && N > 16) wide = true;
+    }
+  }
   const int tiles = wide ? t32 : t16;
   const bool deep = tiles <= 256;                 // at most one workgroup per CU: four stages; else three (two workgroups per CU)
 #define GO(DT, TN, NW, NST)                                                                                                    \
