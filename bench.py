@@ -547,7 +547,13 @@ def roofline_from(timer, steps, wl_name, samples_per_step_per_gpu, ms_per_step):
     bigname = shape_key(big)
     # PMC traffic: of the heaviest launch when profiles/traffic.json holds it, else of the heaviest PROFILED launch of the family
     traffic, traffic_shape, traffic_alg = None, None, None
-    for a in by_time:
+    fam_tb = lookup_traffic("family:%s@%s" % (top["name"], wl_name))
+    if fam_tb is not None:
+        # families of many small launches (the few-row GEMMs of Tacotron2 / WaveGlow): the counters are summed over every launch
+        # of the family inside the real step (tools/pmc_family.sh) -- a replayed single launch would find its weights in L2
+        traffic, traffic_shape = fam_tb, "average over all launches of the family inside the step (tools/pmc_family.sh)"
+        traffic_alg = top["bytes"] / top["calls"] if top["bytes"] else None
+    for a in (by_time if fam_tb is None else []):
         tb = lookup_traffic(shape_key(a))
         if tb is not None:
             traffic, traffic_shape = tb, shape_key(a)

@@ -193,13 +193,16 @@ extern "C" int dle_gemm_smallm_try(const void* A, const void* B, void* C, const 
   // 64 x 32 tiles (8 wavefronts) unless that leaves more than half of the CUs without a workgroup while 64 x 16 tiles would not
   const int t32 = tm * ((N + 31) / 32), t16 = tm * ((N + 15) / 16);
   bool wide = N > 16 && (t32 >= 128 || t16 > 256);
+  int nst_pin = 0;
   {
-    // tools/probes/smallm_policy.py: DLE_GEMM_SMALLM_TN = 16 | 32 pins the tile (read per call, only when the variable exists)
+    // tools/probes/smallm_policy.py: DLE_GEMM_SMALLM_TN = 16 | 32 pins the tile, DLE_GEMM_SMALLM_NST the ring depth (read per
+    // call, only when the first variable exists)
     static const bool probing = getenv("DLE_GEMM_SMALLM_TN") != nullptr;
     if (probing) {
       const int tn = atoi(getenv("DLE_GEMM_SMALLM_TN"));
       if (tn == 16) wide = false;
       else if (tn == 32 && N > 16) wide = true;
+      if (getenv("DLE_GEMM_SMALLM_NST")) nst_pin = atoi(getenv("DLE_GEMM_SMALLM_NST"));
     }
   }
   const int tiles = wide ? t32 : t16;
@@ -216,8 +219,13 @@ extern "C" int dle_gemm_smallm_try(const void* A, const void* B, void* C, const 
   } while (0)
 #define PICK(DT)                                                            \
   do {                                                                      \
-    if (wide) { if (deep) GO(DT, 32, 8, 4); else GO(DT, 32, 8, 3); }        \
-    else GO(DT, 16, 4, 4);                                                  \
+    if (wide) {                                                             \
+      if (nst_pin == 6) GO(DT, 32, 8, 6);                                   \
+      else if (nst_pin == 3 || (!deep && nst_pin != 4)) GO(DT, 32, 8, 3);   \
+      else GO(DT, 32, 8, 4);                                                \
+    } else {                                                                \
+      if (nst_pin == 7) GO(DT, 16, 4, 7); else GO(DT, 16, 4, 4);            \
+    }                                                                       \
   } while (0)
   if (in_dtype == DLE_F16) PICK(DLE_F16); else PICK(DLE_BF16);
 #undef PICK

@@ -18,7 +18,7 @@ SHAPES = [(128, 1536, 4096, False), (128, 2560, 4096, False), (128, 4096, 2560, 
           (256, 4096, 1536, False), (128, 88, 1536, False)]
 
 
-def bench(m, n, k, add, tn, dtype=torch.float16, iters=200):
+def bench(m, n, k, add, tn, nst=0, dtype=torch.float16, iters=200):
     dev = torch.device("cuda", 0)
     copies = max(2, min(64, int(192e6 // (n * k * 2)) + 1))
     ws = [torch.randn(n, k, device=dev, dtype=dtype) * 0.05 for _ in range(copies)]
@@ -26,6 +26,7 @@ def bench(m, n, k, add, tn, dtype=torch.float16, iters=200):
     src = torch.randn(m, n, device=dev, dtype=dtype) if add else None
     out = torch.empty(m, n, device=dev, dtype=dtype)
     os.environ["DLE_GEMM_SMALLM_TN"] = str(tn)
+    os.environ["DLE_GEMM_SMALLM_NST"] = str(nst)
     run = lambda i: F.gemm(x, ws[i % copies], m, n, k, True, True, out=out, act=C.ACT_ADD if add else C.ACT_NONE, mask_src=src)
     for i in range(20):
         run(i)
@@ -51,11 +52,13 @@ def bench(m, n, k, add, tn, dtype=torch.float16, iters=200):
 
 
 def main():
-    print("%-28s %10s %10s %10s   (us per launch, weights from beyond L2)" % ("M x N x K", "policy", "64x16/4w", "64x32/8w"))
+    variants = [(0, 0), (16, 4), (16, 7), (32, 3), (32, 4), (32, 6)]
+    print("us per launch, weights from beyond L2; columns: tile columns / ring stages (0/0 = the built-in policy)")
+    print("%-24s " % "M x N x K" + " ".join("%8s" % ("%d/%d" % v) for v in variants))
     for m, n, k, add in SHAPES:
-        t = [bench(m, n, k, add, tn) for tn in (0, 16, 32)]
+        t = [bench(m, n, k, add, tn, nst) for tn, nst in variants]
         assert all(e < 2e-2 for _, e in t), t
-        print("%-28s %10.2f %10.2f %10.2f" % ("%dx%dx%d%s" % (m, n, k, "+src" if add else ""), t[0][0], t[1][0], t[2][0]))
+        print("%-24s " % ("%dx%dx%d%s" % (m, n, k, "+src" if add else "")) + " ".join("%8.2f" % x for x, _ in t))
 
 
 if __name__ == "__main__":
