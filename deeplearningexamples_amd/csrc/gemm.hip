@@ -449,6 +449,10 @@ extern "C" int dle_gemm_smallm_try(const void* A, const void* B, void* C, const 
                                    int64_t lda, int64_t ldb, int64_t ldc, int in_dtype, int out_dtype, int act_add, int accumulate,
                                    float alpha, hipStream_t stream);     // gemm_smallm.hip
 
+extern "C" int dle_gemm_expand_try(const void* A, const void* B, void* C, const void* src, const void* bits, float* stats, int M,
+                                   int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_kc, int in_dtype, int out_dtype,
+                                   int act, hipStream_t stream);           // gemm_expand.hip
+
 // C ABI.  a_kc / b_kc: operand stored with the contraction dimension contiguous (see header).
 extern "C" int dle_gemm(const void* A, const void* B, void* C, void* aux, const float* bias,
                         const void* mask_src, int M, int N, int K, int64_t lda, int64_t ldb,
@@ -487,6 +491,18 @@ extern "C" int dle_gemm(const void* A, const void* B, void* C, void* aux, const 
                                         alpha, stream);
       if (r == 1) return 0;
       if (r != 0) return r;
+    }
+    // many rows, K <= 256, N >= 2 K (the channel-widening 1x1 convolutions): the streaming kernel of gemm_expand.hip
+    // (store-only products with K = 64 stay on the tile kernel's PLAIN epilogue: 135 vs 152 us at 802816 x 256 x 64)
+    if (!legacy && a_kc && splitk == 1 && !accumulate && !bias && alpha == 1.0f &&
+        (act == ACT_NONE ? (!aux && K >= 128) : act == 4 ? !aux : act == 8)) {
+      static const bool pinned = getenv("DLE_GEMM_EXPAND") != nullptr;      // probes: read per call when the variable exists
+      if (!pinned || atoi(getenv("DLE_GEMM_EXPAND")) != 0) {
+        const int r = dle_gemm_expand_try(A, B, C, mask_src, act == 8 ? aux : nullptr, nullptr, M, N, K, lda, ldb, ldc, b_kc,
+                                          in_dtype, out_dtype, act == 0 ? 0 : act == 4 ? 1 : 2, stream);
+        if (r == 1) return 0;
+        if (r != 0) return r;
+      }
     }
     if (!legacy && K > 0) {
       const int r = dle_gemm_dma_try(A, B, C, aux, bias, mask_src, M, N, K, lda, ldb, ldc, a_kc, b_kc, in_dtype,

@@ -1004,6 +1004,11 @@ extern "C" int dle_conv2d_fwd(const void* x, const void* w, void* y, const float
   return conv_launch(p, dtype, 2, 0, stream);
 }
 
+extern "C" int dle_gemm_expand_groups(int M, int N, int K);                // gemm_expand.hip
+extern "C" int dle_gemm_expand_try(const void* A, const void* B, void* C, const void* src, const void* bits, float* stats, int M,
+                                   int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_kc, int in_dtype, int out_dtype,
+                                   int act, hipStream_t stream);
+
 // dle_conv2d_fwd (no bias / activation) that ALSO leaves, per 128-row tile of the [N*P*Q, Ko] output, the column sums
 // and sums of squares of the ROUNDED output in col_partial[tile_row][2][Ko] -- the BatchNorm that follows gets its
 // batch statistics without re-reading the activation (dle_bn_stats_from_partials).  1x1 stride-1 convolutions run as
@@ -1024,12 +1029,23 @@ extern "C" int dle_conv2d_fwd_colstats(const void* x, const void* w, void* y, in
     if (rc == 1) { *groups = (int)(((long long)N * (H + 1) * (W + 2) + 255) / 256); return 0; }
     if (rc > 1) return rc;
   }
+  const bool plain = R == 1 && S == 1 && stride == 1 && pad == 0;
+  if (plain && M < 0x7FFFFFFF) {
+    // channel-widening 1x1 convolutions: the streaming kernel of gemm_expand.hip (one partial row per workgroup group)
+    static const bool pinned = getenv("DLE_GEMM_EXPAND") != nullptr;      // probes: read per call when the variable exists
+    static const int kmin = getenv("DLE_EXPAND_STATS_KMIN") ? atoi(getenv("DLE_EXPAND_STATS_KMIN")) : 64;
+    const int eg = dle_gemm_expand_groups((int)M, Ko, C);
+    if ((!pinned || atoi(getenv("DLE_GEMM_EXPAND")) != 0) && C >= kmin && col_partial_bytes >= (long long)eg * 2 * Ko * 4) {
+      const int rc = dle_gemm_expand_try(x, w, y, nullptr, nullptr, col_partial, (int)M, Ko, C, C, C, Ko, 1, dtype, dtype, 0, stream);
+      if (rc == 1) { *groups = eg; return 0; }
+      if (rc > 1) return rc;
+    }
+  }
   Gemm2Args p = {};
   p.A = (const unsigned short*)x; p.B = (const unsigned short*)w; p.C = y;
   p.M = (int)M; p.N = Ko; p.K = R * S * C; p.ldb = (long long)R * S * C; p.ldc = Ko;
   p.out_dtype = dtype; p.act = ACT_NONE; p.splitk = 1; p.accumulate = 0; p.alpha = 1.f;
   p.stats = col_partial; p.force_small = 1;
-  const bool plain = R == 1 && S == 1 && stride == 1 && pad == 0;
   p.lda = plain ? C : 0;
   p.cg = make_geom(H, W, C, P, Q, R, S, stride, pad, Ko);
   return conv_launch(p, dtype, plain ? 0 : 2, 0, stream);

@@ -1,0 +1,276 @@
+// "Expand" GEMM for gfx950: C[M, N] = A[M, K] B^T (+ addend) with M in the 10^5..10^6, K <= 256 and N >= 2 K -- the 1x1
+// convolutions of a ResNet bottleneck that WIDEN the channel count (Classification/ConvNets/image_classification/models/
+// resnet.py:148-175: conv3 forward, conv1 data gradient + the masked residual gradient of the block input).  At 28-110 flop/B
+// these products sit far on the HBM side of the ridge (312 flop/B): per output row they read 2 K bytes of A and write (and, with
+// an addend, read) 2 N >= 4 K bytes.  The MFMA tile kernels of gemm_dma.hip run them at 2.4-3.0 TB/s: one or two workgroups per
+// CU walk load -> MFMA -> addend -> store phases one after the other.  This kernel is a STREAMING kernel with a matrix product
+// in the middle, built like the BatchNorm apply passes (5.5 TB/s) rather than like a GEMM:
+//  * the weight tile (128 output columns x K, <= 66 KiB) is loaded ONCE per workgroup into LDS and the workgroup then walks
+//    row tiles (persistent along M): after the prologue every byte a wave touches is stream data;
+//  * 4 wavefronts per workgroup, each owning 16 rows x 128 columns; 3-4 workgroups per CU (LDS 18-66 KiB, <= 128 VGPRs), so
+//    12-16 waves per CU are in different phases and the loads of some cover the stores of others;
+//  * no LDS and no DMA on the stream side: A fragments, addend rows and mask bytes go global -> VGPR in the layout the MFMA /
+//    the epilogue need.  v_mfma_f32_16x16x32 with the WEIGHT rows as the first operand leaves a lane with 4 consecutive output
+//    columns of one row; the weight rows of two MFMA blocks are interleaved (LDS position 32 j + 16 q + i holds column
+//    32 j + 8 (i >> 2) + 4 q + (i & 3)), so that the pair leaves the lane with 8 CONSECUTIVE columns = one 16-byte load of the
+//    addend and one 16-byte store of the output, 64-byte segments per row across the 4 lane groups;
+//  * weights in either layout ([N, K] k-contiguous or [K, N]): the transposition happens on the way into LDS.
+// Epilogues: none / + addend (DLE_ACT_ADD) / + addend under bit-packed keep bits (DLE_ACT_ADD_MASKED); optional column sums and
+// sums of squares of the ROUNDED output for the BatchNorm that follows (one partial row per workgroup, no atomics).
+#include "gemm_tiles.h"
+
+#define EX_TN 128
+#define EX_PAD 8                        // halves of padding per LDS weight row: (K + 8) / 2 dwords = 4 (mod 8) -> conflict-free b128 reads
+
+struct ExpandArgs {
+  const unsigned short* A;
+  const unsigned short* B;
+  unsigned short* C;
+  const unsigned short* src;
+  const unsigned char* bits;
+  float* stats;                         // [groups][2][N] or NULL
+  int M, N, K;
+  long long lda, ldb, ldc;
+  int b_kc, row_tiles, groups, col_tiles;
+};
+
+template <int DT> struct ExMfma;
+template <> struct ExMfma<DLE_F16> {
+  static __device__ __forceinline__ float4_t run(ushort8_t a, ushort8_t b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct ExMfma<DLE_BF16> {
+  static __device__ __forceinline__ float4_t run(ushort8_t a, ushort8_t b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+// LDS row position of local output column nl (0..127): see the header comment
+__device__ __forceinline__ int ex_pos(int nl) {
+  const int j = nl >> 5, r = nl & 31;
+  return 32 * j + 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
+}
+
+// The stream registers of one row tile of a wave: A fragments, addend, keep bits (all loads unconditional: clamped row).
+template <int KS, int ACT>
+struct ExStream {
+  ushort8_t fa[KS];
+  ushort8_t sv[ACT ? 4 : 1];
+  uint4_t mb;                                                          // ACT == 2: 16 mask bytes = columns n0 .. n0 + 127 of the row
+  long long o0;
+  bool live;
+  __device__ __forceinline__ void load_a(const ExpandArgs& p, int m, int kg) {
+    const long long mr = m < p.M ? m : p.M - 1;
+    const unsigned short* arow = p.A + mr * p.lda + kg * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) fa[ks] = *(const ushort8_t*)(arow + ks * 32);
+  }
+  __device__ __forceinline__ void load_src(const ExpandArgs& p, int m, int n0, int kg) {
+    live = m < p.M;
+    const long long mr = live ? m : p.M - 1;
+    o0 = mr * p.ldc + n0 + kg * 8;                                     // + 32 j
+    if (ACT) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sv[j] = *(const ushort8_t*)(p.src + o0 + 32 * j);
+    }
+    if (ACT == 2) mb = *(const uint4_t*)(p.bits + ((mr * p.ldc + n0) >> 3));   // (ldc, n0 multiples of 128: 16-byte aligned)
+  }
+};
+
+// ACT: 0 none, 1 + addend, 2 + addend under keep bits.  KS = K / 32 (2, 4 or 8).  STATS: column sums of the rounded output.
+// NW wavefronts of 16 rows each: 4, or 8 for K = 256 (its 66 KiB weight tile allows two workgroups per CU; 16 waves per CU either way).
+template <int DT, int KS, int ACT, bool STATS, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(STATS ? 3 : 4)))
+void gemm_expand_kernel(ExpandArgs p) {
+  constexpr int K = KS * 32, LDW = K + EX_PAD, TM = NW * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* wl = (unsigned short*)smem_raw;                     // [128][LDW]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, kg = lane >> 4;
+  // workgroups are dealt to the 8 XCDs round-robin (blockIdx & 7): the column tiles of one row group share their A rows, so they
+  // are given consecutive slots of ONE XCD and meet in its L2 (groups is a multiple of 8)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tn = slot % p.col_tiles, g = (slot / p.col_tiles) * 8 + xcd;
+  const int n0 = tn * EX_TN;
+  // ---- weight tile -> LDS (once)
+  if (p.b_kc) {
+    constexpr int CPR = K / 8;                                         // 16-byte chunks per row
+    for (int c = threadIdx.x; c < EX_TN * CPR; c += NW * 64) {
+      const int nl = c / CPR, kc = c - nl * CPR;
+      const ushort8_t v = *(const ushort8_t*)(p.B + (long long)(n0 + nl) * p.ldb + kc * 8);
+      *(ushort8_t*)(wl + ex_pos(nl) * LDW + kc * 8) = v;
+    }
+  } else {
+    for (int c = threadIdx.x; c < K * (EX_TN / 8); c += NW * 64) {
+      const int k = c >> 4, nc = c & 15;
+      const ushort8_t v = *(const ushort8_t*)(p.B + (long long)k * p.ldb + n0 + nc * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wl[ex_pos(nc * 8 + e) * LDW + k] = v[e];
+    }
+  }
+  __syncthreads();
+  float s1[STATS ? 32 : 1], s2[STATS ? 32 : 1];
+  if (STATS) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  }
+  const unsigned short* wrow = wl + fr * LDW + kg * 8;                  // + (32 j + 16 q) * LDW + 32 ks
+  const int mrow = wave * 16 + fr;
+  // Software pipeline over the row tiles: the NEXT tile's loads are issued before this tile's stores, into the registers the
+  // product / the epilogue arithmetic have just finished with.  vmcnt retires in order and counts stores: a wave that stores and
+  // then loads must see its stores acknowledged before the loaded data can be waited for; with the loads in front, the stores of
+  // tile i are only waited for together with the loads of tile i + 2.
+  ExStream<KS, ACT> cur;
+  cur.load_a(p, g * TM + mrow, kg);
+  cur.load_src(p, g * TM + mrow, n0, kg);
+  for (int tm = g; tm < p.row_tiles; tm += p.groups) {
+    const int m_next = (tm + p.groups) * TM + mrow;                    // past the end: the clamped last row, never stored
+    // ---- product: 8 blocks of 16 columns
+    float4_t acc[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const ushort8_t fw = *(const ushort8_t*)(wrow + b * 16 * LDW + ks * 32);
+        acc[b] = ExMfma<DT>::run(fw, cur.fa[ks], acc[b]);
+      }
+      // one k step's weight fragments at a time: without the fence hipcc hoists every LDS read of the unrolled product above the
+      // first MFMA (8 KS fragments = up to 256 VGPRs, occupancy 1)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    cur.load_a(p, m_next, kg);
+    // ---- epilogue: pair j = blocks 2j, 2j + 1 -> columns n0 + 32 j + 8 kg + {0..7} of row m
+    ushort8_t outv[4];
+    const long long o_cur = cur.o0;
+    const bool live_cur = cur.live;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r] = acc[2 * j][r]; v[4 + r] = acc[2 * j + 1][r]; }
+      if (ACT) {
+        float y[8];
+        unpack8<DT>(cur.sv[j], y);
+        const unsigned int bits8 = ACT == 2 ? (cur.mb[j] >> (8 * kg)) & 0xffu : 0xffu;   // byte 4 j + kg of the row's 16
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          if (ACT == 2) { if ((bits8 >> r) & 1u) v[r] += y[r]; }
+          else v[r] += y[r];
+        }
+      }
+      const ushort8_t ov = pack8<DT>(v);
+      outv[j] = ov;
+      if (STATS) {
+        float z[8];
+        unpack8<DT>(ov, z);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float zz = live_cur ? z[r] : 0.f;
+          s1[8 * j + r] += zz;
+          s2[8 * j + r] += zz * zz;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cur.load_src(p, m_next, n0, kg);
+    __builtin_amdgcn_sched_barrier(0);
+    if (live_cur) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(ushort8_t*)(p.C + o_cur + 32 * j) = outv[j];
+    }
+  }
+  if (STATS) {
+    // rows: the 16 fr lanes of a wave, then the waves (LDS, reusing the weight tile's space after a barrier)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        s1[i] += __shfl_xor(s1[i], o, 64);
+        s2[i] += __shfl_xor(s2[i], o, 64);
+      }
+    }
+    __syncthreads();
+    float* red = (float*)smem_raw;                                      // [NW waves][2][128]
+    if (fr == 0) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const int col = 32 * (i >> 3) + 8 * kg + (i & 7);
+        red[(wave * 2 + 0) * EX_TN + col] = s1[i];
+        red[(wave * 2 + 1) * EX_TN + col] = s2[i];
+      }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * EX_TN; t += NW * 64) {
+      const int which = t / EX_TN, col = t - which * EX_TN;
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) tot += red[(w * 2 + which) * EX_TN + col];
+      p.stats[((long long)g * 2 + which) * p.N + n0 + col] = tot;
+    }
+  }
+}
+
+// Number of partial rows the stats variant writes for (M, N): the caller sizes `stats` for it and folds that many rows.
+static int ex_rows_per_tile(int K) { return K > 128 ? 128 : 64; }
+extern "C" int dle_gemm_expand_groups(int M, int N, int K) {
+  const int tm = ex_rows_per_tile(K), row_tiles = (M + tm - 1) / tm, col_tiles = N / EX_TN;
+  static const int per_cu_env = getenv("DLE_EXPAND_WG_PER_CU") ? atoi(getenv("DLE_EXPAND_WG_PER_CU")) : 0;   // probe knob
+  const int per_cu = per_cu_env > 0 ? per_cu_env : (K > 128 ? 2 : 4);  // workgroups a CU holds at once (16 waves per CU)
+  const int resident = 256 * per_cu;
+  int groups = (resident + col_tiles - 1) / (col_tiles > 0 ? col_tiles : 1);
+  if (groups > row_tiles) groups = row_tiles;
+  return (groups + 7) / 8 * 8;                                         // XCD-aware dealing (see the kernel); idle groups run no tile
+}
+
+// 1: launched; 0: outside the envelope (the caller goes on to the tile kernels); > 1: error.
+// act: 0 none, 1 DLE_ACT_ADD, 2 DLE_ACT_ADD_MASKED (bits = keep bits of the addend, bit (m ldc + n) & 7 of byte (m ldc + n) >> 3).
+extern "C" int dle_gemm_expand_try(const void* A, const void* B, void* C, const void* src, const void* bits, float* stats, int M,
+                                   int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_kc, int in_dtype, int out_dtype,
+                                   int act, hipStream_t stream) {
+  if (M < 4096 || (K != 64 && K != 128 && K != 256) || (N % EX_TN) != 0 || N < 2 * K || out_dtype != in_dtype) return 0;
+  if (((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)src)) & 15) != 0 || (lda & 7) || (ldb & 7) || (ldc & 7)) return 0;
+  if (act == 2 && !bits) return 0;
+  if (act && !src) return 0;
+  ExpandArgs p = {(const unsigned short*)A, (const unsigned short*)B, (unsigned short*)C, (const unsigned short*)src,
+                  (const unsigned char*)bits, stats, M, N, K, (long long)lda, (long long)ldb, (long long)ldc, b_kc, 0, 0, 0};
+  const int tmr = ex_rows_per_tile(K);
+  p.row_tiles = (M + tmr - 1) / tmr;
+  p.col_tiles = N / EX_TN;
+  p.groups = dle_gemm_expand_groups(M, N, K);
+  const int lds_bytes = EX_TN * (K + EX_PAD) * 2 > 8 * 2 * EX_TN * 4 ? EX_TN * (K + EX_PAD) * 2 : 8 * 2 * EX_TN * 4;
+  const dim3 grid((unsigned)(p.groups * p.col_tiles)), block(tmr * 4);
+#define GO(DT, KS, ACT, ST)                                                                                              \
+  do {                                                                                                                   \
+    constexpr int NW_ = KS > 4 ? 8 : 4;                                                                                  \
+    static bool attr_set = false;                                                                                        \
+    if (!attr_set) {                                                                                                     \
+      (void)hipFuncSetAttribute((const void*)gemm_expand_kernel<DT, KS, ACT, ST, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                EX_TN * (KS * 32 + EX_PAD) * 2);                                                         \
+      attr_set = true;                                                                                                   \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((gemm_expand_kernel<DT, KS, ACT, ST, NW_>), grid, block, lds_bytes, stream, p);                   \
+  } while (0)
+#define PICK_ACT(DT, KS)                                              \
+  do {                                                                \
+    if (stats) { if (act != 0) return 0; GO(DT, KS, 0, true); }       \
+    else if (act == 0) GO(DT, KS, 0, false);                          \
+    else if (act == 1) GO(DT, KS, 1, false);                          \
+    else GO(DT, KS, 2, false);                                        \
+  } while (0)
+#define PICK_K(DT)                                   \
+  do {                                               \
+    if (K == 64) PICK_ACT(DT, 2);                    \
+    else if (K == 128) PICK_ACT(DT, 4);              \
+    else PICK_ACT(DT, 8);                            \
+  } while (0)
+  if (in_dtype == DLE_F16) PICK_K(DLE_F16); else PICK_K(DLE_BF16);
+#undef PICK_K
+#undef PICK_ACT
+#undef GO
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { dle_set_error("gemm_expand launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
+  return 1;
+}
