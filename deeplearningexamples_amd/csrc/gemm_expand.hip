@@ -144,7 +144,6 @@ void gemm_expand_kernel(ExpandArgs p) {
     cur.load_a(p, m_next, kg);
     // ---- epilogue: pair j = blocks 2j, 2j + 1 -> columns n0 + 32 j + 8 kg + {0..7} of row m
     ushort8_t outv[4];
-    const long long o_cur = cur.o0;
     const bool live_cur = cur.live;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -177,9 +176,31 @@ void gemm_expand_kernel(ExpandArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     cur.load_src(p, m_next, n0, kg);
     __builtin_amdgcn_sched_barrier(0);
-    if (live_cur) {
+    // Full 128-byte lines per store instruction: rows come in (even, odd) lane pairs (fr, fr ^ 1); of a pair's two 64-byte
+    // pieces (column blocks 2 h, 2 h + 1) the even lane stores row 2a's left piece then row 2a+1's left piece, the odd lane the
+    // right pieces -- one dword-for-dword swap with the neighbour lane per piece pair (DPP), 8 lanes x 16 B = one full line of one
+    // row per instruction instead of two half lines of two rows.
+    {
+      const bool odd = fr & 1;
+      const int m_cur = tm * TM + mrow;                                 // (the load offsets are of the CLAMPED row: recompute)
+      const bool live_other = (odd ? m_cur - 1 : m_cur + 1) < p.M;
+      const long long o_own = (long long)m_cur * p.ldc + n0 + kg * 8;
+      const long long o_other = odd ? o_own - p.ldc : o_own + p.ldc;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *(ushort8_t*)(p.C + o_cur + 32 * j) = outv[j];
+      for (int h = 0; h < 2; ++h) {
+        const uint4_t mine0 = __builtin_bit_cast(uint4_t, outv[2 * h]), mine1 = __builtin_bit_cast(uint4_t, outv[2 * h + 1]);
+        const uint4_t give = odd ? mine0 : mine1;
+        uint4_t got;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) got[q] = (unsigned)__shfl_xor((int)give[q], 1, 64);
+        // even lane: (row 2a, block 2h) own, then (row 2a+1, block 2h) received; odd lane: (row 2a, block 2h+1) received, then own
+        const uint4_t first = odd ? got : mine0, second = odd ? mine1 : got;
+        const long long o_first = (odd ? o_other : o_own) + 64 * h + (odd ? 32 : 0);
+        const long long o_second = (odd ? o_own : o_other) + 64 * h + (odd ? 32 : 0);
+        const bool live_first = odd ? live_other : live_cur, live_second = odd ? live_cur : live_other;
+        if (live_first) *(uint4_t*)(p.C + o_first) = first;
+        if (live_second) *(uint4_t*)(p.C + o_second) = second;
+      }
     }
   }
   if (STATS) {
