@@ -533,7 +533,9 @@ def conv2d_fwd_bnstats(x, w, stride=1, pad=0, running_mean=None, running_var=Non
     p, q = _conv_out(h, wd, r, s, stride, pad)
     m = n * p * q
     y = torch.empty((n, p, q, ko), dtype=x.dtype, device=x.device)
-    groups = (m + 127) // 128
+    # partial rows: one per 128-row tile, or one per workgroup group of the streaming 1x1 kernel (gemm_expand.hip: at most
+    # 1032, at most one per 64 rows rounded up to a multiple of 8); the call reports how many it wrote
+    groups = max((m + 127) // 128, min(1032, (m + 63) // 64 + 8))
     ws = splitk_workspace(x.device, (groups + 32) * 2 * ko * 4)
     part, fold = ws[:groups * 2 * ko], ws[groups * 2 * ko:(groups + 32) * 2 * ko]
     import ctypes

@@ -239,3 +239,69 @@ def test_gemm_few_rows_weight_streaming_kernel(cuda, mnk, dtype):
     F.gemm(ad, bd, m, n, k, True, True, out=cw[:, 4:4 + n], accumulate=True)
     chk(cw[:, 4:4 + n], ref + base[:, 4:4 + n].double(), "accumulate, strided C")
     assert torch.equal(cw[:, :4].cpu(), base[:, :4]) and torch.equal(cw[:, 4 + n:].cpu(), base[:, 4 + n:])
+
+
+EXPAND = [  # m, n, k, epilogue, weights k-contiguous: the envelope of csrc/gemm_expand.hip (m >= 4096, k in 64 / 128 / 256, n >= 2 k, n % 128 == 0)
+    (4096, 128, 64, "masked", False), (4101, 256, 64, "masked", False), (8191, 256, 128, "add", False), (5000, 512, 256, "masked", False),
+    (4097, 512, 128, "none", True), (6001, 1024, 256, "none", True), (4160, 256, 64, "add", True), (70001, 256, 64, "masked", True)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", EXPAND)
+def test_gemm_streaming_expand_kernel(cuda, case, dtype, monkeypatch):
+    """The channel-widening 1x1-convolution shapes (many rows, K <= 256, N >= 2 K) go to gemm_expand.hip: ragged and ODD row counts
+    (its stores pair neighbouring rows), both weight layouts, the three epilogues -- against float64 and, bit for bit, against the
+    tile kernel (DLE_GEMM_EXPAND=0 pins it)."""
+    F, C = _F()
+    m, n, k, epi, b_kc = case
+    gen = torch.Generator().manual_seed(m + n + k)
+    a = _mk((m, k), dtype, gen, 0.5)
+    w = _mk((n, k) if b_kc else (k, n), dtype, gen, 0.1)
+    src = _mk((m, n), dtype, gen) if epi != "none" else None
+    bits = torch.randint(0, 256, (m * n // 8,), generator=gen, dtype=torch.uint8) if epi == "masked" else None
+    ref = a.double() @ (w.double().T if b_kc else w.double())
+    if epi == "add":
+        ref = ref + src.double()
+    elif epi == "masked":
+        keep = ((bits.to(torch.int32).unsqueeze(1) >> torch.arange(8, dtype=torch.int32)) & 1).reshape(m, n)
+        ref = ref + src.double() * keep
+    act = {"none": C.ACT_NONE, "add": C.ACT_ADD, "masked": C.ACT_ADD_MASKED}[epi]
+    dev = lambda t: None if t is None else t.to(cuda)
+    ad, wd, sd, bd = dev(a), dev(w), dev(src), dev(bits)
+    outs = {}
+    for pin in ("1", "0"):
+        monkeypatch.setenv("DLE_GEMM_EXPAND", pin)
+        guard = torch.full((m + 2, n), 7.0, dtype=dtype, device=cuda)             # rows past m must stay untouched
+        F.gemm(ad, wd, m, n, k, True, b_kc, out=guard[:m], act=act, mask_src=sd, aux=bd)
+        assert bool((guard[m:] == 7.0).all())
+        outs[pin] = guard[:m].clone()
+    err = (outs["1"].cpu().double() - ref).abs().max().item()
+    assert err <= (2e-3 if dtype == torch.float16 else 1.6e-2) * max(1.0, float(ref.abs().max())), err
+    if not (epi == "none" and k < 128):                   # (store-only K = 64 products stay on the tile kernel either way)
+        assert torch.equal(outs["1"], outs["0"]), "expand and tile kernels round differently"
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 56, 64, 256), (3, 28, 128, 512), (9, 23, 256, 1024), (5, 29, 64, 128)])
+def test_conv1x1_statistics_from_the_expand_kernel(cuda, shape, dtype, monkeypatch):
+    """dle_conv2d_fwd_colstats on channel-widening 1x1 convolutions: output identical to the tile kernel's, BatchNorm statistics
+    of the STORED output (one partial row per workgroup group of gemm_expand.hip, folded by dle_bn_stats_from_partials)."""
+    F, C = _F()
+    nb, hw, c, ko = shape
+    gen = torch.Generator().manual_seed(nb + hw + c)
+    x = _mk((nb, hw, hw, c), dtype, gen, 0.5).to(cuda)
+    w = _mk((ko, 1, 1, c), dtype, gen, 0.1).to(cuda)
+    res = {}
+    for pin in ("1", "0"):
+        monkeypatch.setenv("DLE_GEMM_EXPAND", pin)
+        rm, rv = torch.zeros(ko, device=cuda), torch.ones(ko, device=cuda)
+        y, mean, rstd = F.conv2d_fwd_bnstats(x, w, 1, 0, rm, rv)
+        res[pin] = (y.clone(), mean.clone(), rstd.clone(), rm, rv)
+    y1, mean1, rstd1, rm1, rv1 = res["1"]
+    assert torch.equal(y1, res["0"][0])
+    yf = y1.double().view(-1, ko)
+    ref_mean, ref_var = yf.mean(0), yf.var(0, unbiased=False)
+    assert float((mean1.double() - ref_mean).abs().max()) <= 1e-5 * float(ref_mean.abs().max()) + 1e-6
+    assert float((rstd1.double() - (ref_var + 1e-5).rsqrt()).abs().max()) <= 1e-4 * float((ref_var + 1e-5).rsqrt().max())
+    for a, b in zip(res["1"][1:], res["0"][1:]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7
