@@ -496,8 +496,8 @@ extern "C" int dle_gemm(const void* A, const void* B, void* C, void* aux, const 
     // (store-only products with K = 64 stay on the tile kernel's PLAIN epilogue: 135 vs 152 us at 802816 x 256 x 64)
     if (!legacy && a_kc && splitk == 1 && !accumulate && !bias && alpha == 1.0f &&
         (act == ACT_NONE ? (!aux && K >= 128) : act == 4 ? !aux : act == 8)) {
-      static const bool pinned = getenv("DLE_GEMM_EXPAND") != nullptr;      // probes: read per call when the variable exists
-      if (!pinned || atoi(getenv("DLE_GEMM_EXPAND")) != 0) {
+      const char* pin = getenv("DLE_GEMM_EXPAND");                          // probes / tests: "0" pins the tile kernels
+      if (!pin || atoi(pin) != 0) {
         const int r = dle_gemm_expand_try(A, B, C, mask_src, act == 8 ? aux : nullptr, nullptr, M, N, K, lda, ldb, ldc, b_kc,
                                           in_dtype, out_dtype, act == 0 ? 0 : act == 4 ? 1 : 2, stream);
         if (r == 1) return 0;

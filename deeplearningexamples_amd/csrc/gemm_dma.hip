@@ -1032,10 +1032,10 @@ extern "C" int dle_conv2d_fwd_colstats(const void* x, const void* w, void* y, in
   const bool plain = R == 1 && S == 1 && stride == 1 && pad == 0;
   if (plain && M < 0x7FFFFFFF) {
     // channel-widening 1x1 convolutions: the streaming kernel of gemm_expand.hip (one partial row per workgroup group)
-    static const bool pinned = getenv("DLE_GEMM_EXPAND") != nullptr;      // probes: read per call when the variable exists
+    const char* pin = getenv("DLE_GEMM_EXPAND");                          // probes / tests: "0" pins the tile kernels
     static const int kmin = getenv("DLE_EXPAND_STATS_KMIN") ? atoi(getenv("DLE_EXPAND_STATS_KMIN")) : 64;
     const int eg = dle_gemm_expand_groups((int)M, Ko, C);
-    if ((!pinned || atoi(getenv("DLE_GEMM_EXPAND")) != 0) && C >= kmin && col_partial_bytes >= (long long)eg * 2 * Ko * 4) {
+    if ((!pin || atoi(pin) != 0) && C >= kmin && col_partial_bytes >= (long long)eg * 2 * Ko * 4) {
       const int rc = dle_gemm_expand_try(x, w, y, nullptr, nullptr, col_partial, (int)M, Ko, C, C, C, Ko, 1, dtype, dtype, 0, stream);
       if (rc == 1) { *groups = eg; return 0; }
       if (rc > 1) return rc;

@@ -196,10 +196,10 @@ extern "C" int dle_gemm_smallm_try(const void* A, const void* B, void* C, const 
   int nst_pin = 0;
   {
     // tools/probes/smallm_policy.py: DLE_GEMM_SMALLM_TN = 16 | 32 pins the tile, DLE_GEMM_SMALLM_NST the ring depth (read per
-    // call, only when the first variable exists)
-    static const bool probing = getenv("DLE_GEMM_SMALLM_TN") != nullptr;
-    if (probing) {
-      const int tn = atoi(getenv("DLE_GEMM_SMALLM_TN"));
+    // call)
+    const char* pin = getenv("DLE_GEMM_SMALLM_TN");
+    if (pin) {
+      const int tn = atoi(pin);
       if (tn == 16) wide = false;
       else if (tn == 32 && N > 16) wide = true;
       if (getenv("DLE_GEMM_SMALLM_NST")) nst_pin = atoi(getenv("DLE_GEMM_SMALLM_NST"));
