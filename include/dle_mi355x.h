@@ -217,9 +217,11 @@ int dle_bn_fwd_stats(const void* x, int64_t M, int C, float eps, float momentum,
                      float* running_mean, float* running_var, void* workspace, int64_t workspace_bytes,
                      int dtype, hipStream_t stream);
 /* Batch statistics without re-reading the activation: dle_conv2d_fwd_colstats is dle_conv2d_fwd (no bias / act) whose
- * epilogue also leaves per-128-row-tile column sums of the rounded output in col_partial[groups][2][Ko]
- * (>= ceil(N*P*Q / 128) * 2 * Ko floats; *groups receives the count); dle_bn_stats_from_partials folds them (fixed
- * order, deterministic) into mean / rstd / running stats exactly like dle_bn_fwd_stats.  workspace: >= 64*C floats. */
+ * epilogue also leaves column sums of the rounded output in col_partial[groups][2][Ko]: one row per 128-row tile, or -- the
+ * channel-widening 1x1 convolutions on the streaming kernel (csrc/gemm_expand.hip), chosen when the buffer also holds
+ * min(1032, ceil(M / 64) + 8) rows -- one row per workgroup group; the buffer holds >= ceil(N*P*Q / 128) * 2 * Ko floats and
+ * *groups receives the number of rows written; dle_bn_stats_from_partials folds them (fixed order, deterministic) into
+ * mean / rstd / running stats exactly like dle_bn_fwd_stats.  workspace: >= 64*C floats. */
 int dle_conv2d_fwd_colstats(const void* x, const void* w, void* y, int N, int H, int W, int C, int Ko, int R, int S,
                             int stride, int pad, int dtype, float* col_partial, int64_t col_partial_bytes,
                             int* groups, hipStream_t stream);
