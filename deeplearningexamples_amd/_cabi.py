@@ -99,6 +99,8 @@ _SIGS = {
     "dle_attention_fwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_float, c_float, c_u64, c_u64, c_void_p, c_int, c_void_p]),
     "dle_attention_bwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_float, c_float, c_u64, c_u64, c_void_p, c_int, c_void_p]),
     "dle_colsum": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p, c_i64, c_void_p]),
+    "dle_colsum_batched_workspace_bytes": (c_i64, [c_int, c_i64, c_int]),
+    "dle_colsum_batched": (c_int, [c_void_p, c_int, c_i64, c_int, c_i64, c_int, c_void_p, c_i64, c_void_p]),
     "dle_mt_table_len": (c_i64, [c_int, c_int]),
     "dle_mt_table_fill": (c_i64, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]),
     "dle_mt_l2norm": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,

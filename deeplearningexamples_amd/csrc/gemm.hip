@@ -299,9 +299,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 template <int DT>
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, float* __restrict__ out,
                                                      long long M, int N, long long ld, long long rows_per_block,
-                                                     int lpr, float* __restrict__ partial) {
+                                                     int lpr, float* __restrict__ partial, const long long* __restrict__ table = nullptr) {
   constexpr int V = DT == DLE_F32 ? 4 : 8;
   __shared__ float red[256 * 8];
+  if (table) {                           // batched form: matrix blockIdx.z of the table, its own slab of partial rows
+    x = (const void*)table[2 * blockIdx.z];
+    partial += (long long)blockIdx.z * gridDim.y * N;
+  }
   const int cl = threadIdx.x % lpr, rl = threadIdx.x / lpr, rstep = 256 / lpr;
   const int c0 = (blockIdx.x * lpr + cl) * V;
   const long long r0 = (long long)blockIdx.y * rows_per_block;
@@ -366,8 +370,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
 // out[n] (+)= sum_g partial[g][n]; 16 columns x 16 group slices per workgroup (latency-bound: spread wide,
 // 4 loads in flight per lane)
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                            int N, int groups, int accumulate) {
+                                                            int N, int groups, int accumulate, const long long* __restrict__ table = nullptr) {
   __shared__ float red[256];
+  if (table) {
+    out = (float*)table[2 * blockIdx.y + 1];
+    partial += (long long)blockIdx.y * groups * N;
+  }
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int n = blockIdx.x * 16 + cl;
   float s = 0.f;
@@ -436,6 +444,42 @@ extern "C" int dle_colsum(const void* x, float* out, int64_t M, int N, int64_t l
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, (const float*)partial, out, N, (int)gy, accumulate);
     DLE_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+// Column sums of n same-shaped 16-bit matrices in ONE launch pair: table = n x { source address, fp32 destination address }
+// (device, int64).  workspace: n * groups * N floats, groups = dle_colsum_batched_groups(n, M, N).
+static void colsum_batched_plan(int n, long long M, int N, int& lpr, int& gx, long long& rpb, long long& gy) {
+  const int cols_v = (N + 7) / 8;
+  lpr = 1;
+  while (lpr < cols_v && lpr < 32) lpr <<= 1;
+  gx = (cols_v + lpr - 1) / lpr;
+  long long want = 2048 / ((long long)gx * n);           // ~8 workgroups per CU over all matrices
+  if (want < 1) want = 1;
+  rpb = (M + want - 1) / want;
+  const long long min_rows = 8LL * (256 / lpr);
+  if (rpb < min_rows) rpb = min_rows;
+  gy = (M + rpb - 1) / rpb;
+}
+extern "C" int64_t dle_colsum_batched_workspace_bytes(int n, int64_t M, int N) {
+  int lpr, gx; long long rpb, gy;
+  if (n <= 0 || M <= 0 || N <= 0) return 0;
+  colsum_batched_plan(n, M, N, lpr, gx, rpb, gy);
+  return (int64_t)n * gy * N * 4;
+}
+extern "C" int dle_colsum_batched(const int64_t* table_dev, int n, int64_t M, int N, int64_t ld, int dtype, void* workspace,
+                                  int64_t workspace_bytes, hipStream_t stream) {
+  DLE_CHECK_ARG(table_dev && n > 0 && n <= 65535 && M > 0 && N > 0 && ld >= N, "colsum_batched: bad args");
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "colsum_batched: 16-bit matrices only (got %d)", dtype);
+  int lpr, gx; long long rpb, gy;
+  colsum_batched_plan(n, M, N, lpr, gx, rpb, gy);
+  DLE_CHECK_ARG(workspace && workspace_bytes >= (long long)n * gy * N * 4, "colsum_batched: workspace too small");
+  dim3 grid(gx, (unsigned)gy, (unsigned)n), block(256);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(colsum_kernel<DLE_F16>, grid, block, 0, stream, (const void*)nullptr, (float*)nullptr, (long long)M, N, (long long)ld, rpb, lpr, (float*)workspace, (const long long*)table_dev);
+  else hipLaunchKernelGGL(colsum_kernel<DLE_BF16>, grid, block, 0, stream, (const void*)nullptr, (float*)nullptr, (long long)M, N, (long long)ld, rpb, lpr, (float*)workspace, (const long long*)table_dev);
+  DLE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 15) / 16, (unsigned)n), dim3(256), 0, stream, (const float*)workspace, (float*)nullptr, N, (int)gy, 0, (const long long*)table_dev);
+  DLE_LAUNCH_CHECK();
   return 0;
 }
 

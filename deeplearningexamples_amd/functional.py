@@ -317,6 +317,31 @@ def colsum(x, out=None, accumulate=False):
     return out
 
 
+class ColsumTable:
+    """Device table of (matrix, fp32 destination) pairs for colsum_batched; the tensors are kept alive here (their ADDRESSES are
+    in the table: they must be persistent buffers)."""
+
+    def __init__(self, entries):
+        self.entries = list(entries)
+        src0 = self.entries[0][0]
+        for x, out in self.entries:
+            C.require_cuda(x, out)
+            if x.shape != src0.shape or x.dtype != src0.dtype or not x.is_contiguous() or x.dim() != 2:
+                raise ValueError("ColsumTable: contiguous 2-D matrices of one shape and dtype")
+            if out.dtype != torch.float32 or out.numel() != x.shape[1] or not out.is_contiguous():
+                raise ValueError("ColsumTable: fp32 destinations of N elements")
+        self.n = len(self.entries)
+        self.dev = torch.tensor([[x.data_ptr(), o.data_ptr()] for x, o in self.entries], dtype=torch.int64).to(src0.device)
+
+
+def colsum_batched(table, m, n, ld, dtype):
+    """fp32 column sums of every matrix of a ColsumTable ([m, n], row pitch ld) into its destination: one launch pair."""
+    need = int(C.lib().dle_colsum_batched_workspace_bytes(table.n, m, n))
+    ws = splitk_workspace(table.dev.device, need)
+    C.annotate(bytes=float(table.n) * m * n * 2, tag="b%dx%dx%d" % (table.n, m, n))
+    C.call("dle_colsum_batched", C.ptr(table.dev), table.n, m, n, ld, C.dt(dtype), C.ptr(ws), ws.numel() * 4, C.stream())
+
+
 def pick_splitk(m_out, n_out, k, target_blocks=512):
     """Split the contraction so that a skinny wgrad still fills 256 CUs (K tiles of 64).  Outputs of at least 256x256
     run on the 256x256 tile (gemm_dma.hip launch_gemm): ONE slice per CU (256 // tiles, each >= 4 K tiles deep) -- the big

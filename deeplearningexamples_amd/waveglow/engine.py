@@ -66,7 +66,11 @@ class WaveGlowTrainer:
         self.dw_cond = torch.zeros((self.cond_cols, kc), dtype=torch.float32, device=dev)
         self.w_in = torch.zeros((self.nf * nl, 2 * nc, ks * nc), dtype=dt, device=dev)
         self.dw_in = torch.zeros((self.nf * nl, 2 * nc, ks * nc), dtype=torch.float32, device=dev)
-        self.dw_rs = torch.zeros((self.nf, nl, 2 * nc, nc), dtype=torch.float32, device=dev)    # last layer: first nc rows (skip only)
+        # res_skip operands of every (flow, layer): rows [0, nc) = residual half, [nc, 2nc) = skip half; the last layer of a flow has
+        # the skip half only and lives in the SECOND half of its slot, so that the skip rows of all layers sit at one stride
+        self.w_rs_all = torch.zeros((self.nf, nl, 2 * nc, nc), dtype=dt, device=dev)
+        self.dw_rs = torch.zeros((self.nf, nl, 2 * nc, nc), dtype=torch.float32, device=dev)
+        self._bwd_shape = None                                           # persistent backward buffers (allocated per batch shape)
         self.flows, fwd, bwd, ld = [], [], [], []
         for k, (c, nh) in enumerate(self.chans):
             f = _Flow()
@@ -76,8 +80,8 @@ class WaveGlowTrainer:
             f.dw_start = torch.zeros((nc, 8), dtype=torch.float32, device=dev)
             f.w_end = torch.zeros((8, nc), dtype=dt, device=dev)         # rows >= 2 nh stay zero
             f.w_in = [self.w_in[k * nl + i] for i in range(nl)]
-            f.w_rs = [torch.zeros((2 * nc if i < nl - 1 else nc, nc), dtype=dt, device=dev) for i in range(nl)]
-            f.dw_rs = [self.dw_rs[k, i, :(2 * nc if i < nl - 1 else nc)] for i in range(nl)]
+            f.w_rs = [self.w_rs_all[k, i] if i < nl - 1 else self.w_rs_all[k, i, nc:] for i in range(nl)]
+            f.dw_rs = [self.dw_rs[k, i] if i < nl - 1 else self.dw_rs[k, i, nc:] for i in range(nl)]
 
             def normed(name, w16, dw, cip=None, as_shape=None):
                 v, dv = p[name + ".weight_v"], g[name + ".weight_v"]
@@ -195,6 +199,26 @@ class WaveGlowTrainer:
         self.loss = ops.loss(state, self.logs_partial.view(-1), self.logdets, self.sigma)
         return self.loss
 
+    def _backward_buffers(self, m):
+        """Persistent gradient buffers of the res_skip outputs for M = m rows + the table of their bias-gradient column sums."""
+        if self._bwd_shape != m:
+            nc, nl, dev, dt = self.nc, self.nl, self.dev, self.dtype
+            self._d_res_all = torch.empty((self.nf, max(nl - 1, 1), m, nc), dtype=dt, device=dev)     # layers 0 .. nl-2
+            self._d_skip_all = torch.empty((self.nf, m, nc), dtype=dt, device=dev)
+            self._dskip_w = torch.empty((nl, m, nc), dtype=dt, device=dev)
+            entries = []
+            for k in range(self.nf):
+                for i in range(nl):
+                    gb = self.g["WN.%d.res_skip_layers.%d.bias" % (k, i)]
+                    if i < nl - 1:
+                        entries.append((self._d_res_all[k, i], gb[:nc]))
+                        entries.append((self._d_skip_all[k], gb[nc:]))
+                    else:
+                        entries.append((self._d_skip_all[k], gb))
+            self._rs_bias_table = F.ColsumTable(entries)
+            self._bwd_shape = m
+        return self._d_res_all, self._d_skip_all, self._dskip_w
+
     # ------------------------------------------------------------------ backward (gradients scaled by the loss scale)
     def backward(self):
         nc, nl, m, b, ks = self.nc, self.nl, self.M, self.b, self.ks
@@ -202,38 +226,43 @@ class WaveGlowTrainer:
         count = float(m * self.ng)
         dz = ops.dz_init(self.z, scale, 1.0 / (self.sigma * self.sigma * count))
         ds_all = torch.empty((m, self.cond_cols), dtype=self.dtype, device=self.dev)
-        # gradient of every res_skip output, [d audio_{i+1} | d output] per (flow, layer): kept so that ALL res_skip weight
-        # gradients are two batched GEMMs after the sweep (one by one: 96 x (1024 x 512 x M split-K GEMM + slab reduction) = 6 ms)
-        d_rs_all = torch.empty((self.nf, nl, m, 2 * nc), dtype=self.dtype, device=self.dev)
-        batched = m % 8 == 0                 # the batched kernel wants the contraction (M rows) in 16-byte steps
+        # Gradients of the res_skip outputs.  `output` is the plain sum of the skip halves, so ONE tensor per flow (d_skip) is the
+        # gradient of every layer's skip half; the residual halves differ per layer.  Both are kept (persistent buffers: the
+        # bias-gradient table holds their addresses) so that all res_skip weight gradients are two batched GEMMs and all bias
+        # gradients one batched column sum after the sweep.
+        d_res_all, d_skip_all, dskip_w = self._backward_buffers(m)
+        batched = m % 8 == 0                 # the batched weight-gradient kernel wants the contraction (M rows) in 16-byte steps
         for k in range(self.nf - 1, -1, -1):
             f = self.flows[k]
             pre = "WN.%d." % k
             dy, d_o = ops.coupling_bwd(dz, f.y, f.o, scale, 1.0 / count, f.c, self.dtype)
-            # end: data gradient straight into the skip half of the last layer's buffer (copied to the other layers' skip halves:
-            # `output` is the plain sum of the skips), weight / bias gradients into their 8-wide slots
-            d_out = d_rs_all[k, nl - 1, :, nc:]
-            F.gemm(d_o, f.w_end, m, nc, 8, True, False, out=d_out)
-            for i in range(nl - 1):
-                F.copy_rows(d_out, d_rs_all[k, i, :, nc:])
+            d_skip = d_skip_all[k]
+            F.gemm(d_o, f.w_end, m, nc, 8, True, False, out=d_skip)
             F.gemm(d_o, f.out, 8, nc, m, False, False, out=g.slot(pre + "end.weight").view(8, nc), splitk=F.pick_splitk(8, nc, m))
             F.colsum(d_o, out=g.slot(pre + "end.bias"))
+            # the skip half's share of EVERY layer's data gradient in one batched product (N = nl x nc columns of work instead of nl
+            # half-empty launches): dskip_w[i] = d_skip x W_rs[i][skip rows]
+            F.gemm_batched(d_skip, self.w_rs_all[k, 0, nc:], dskip_w, m, nc, nc, nc, nc, nc, True, False, nl, nl,
+                           (0, 0), (0, 2 * nc * nc), (0, m * nc))
             d_x0 = None
             for i in range(nl - 1, -1, -1):
                 last = i == nl - 1
                 z = k * nl + i
                 c0 = z * 2 * nc
-                g_rs = d_out if last else d_rs_all[k, i]                 # last layer: res_skip has the skip half only
-                rs = nc if last else 2 * nc
-                d_acts = F.gemm(g_rs, f.w_rs[i], m, nc, rs, True, False)
+                if last:                                                 # the last layer's res_skip has the skip half only
+                    d_acts = dskip_w[i]
+                else:
+                    d_acts = F.gemm(d_res_all[k, i], f.w_rs[i][:nc], m, nc, nc, True, False, act=C.ACT_ADD, mask_src=dskip_w[i])
                 if not batched:
-                    F.gemm(g_rs, self.acts_all[z], rs, nc, m, False, False, out=f.dw_rs[i], splitk=F.pick_splitk(rs, nc, m))
-                F.colsum(g_rs, out=g[pre + "res_skip_layers.%d.bias" % i])
+                    F.gemm(d_skip, self.acts_all[z], nc, nc, m, False, False, out=f.dw_rs[i][-nc:], splitk=F.pick_splitk(nc, nc, m))
+                    if not last:
+                        F.gemm(d_res_all[k, i], self.acts_all[z], nc, nc, m, False, False, out=f.dw_rs[i][:nc],
+                               splitk=F.pick_splitk(nc, nc, m))
                 ds_i = ops.gate_bwd(d_acts, self.s_all[:, c0:c0 + 2 * nc], ds_all[:, c0:c0 + 2 * nc])
                 dcol = F.gemm(ds_i, f.w_in[i], m, ks * nc, 2 * nc, True, False)
-                add = None if last else d_rs_all[k, i, :, :nc]           # + the residual path's gradient (audio = res + audio)
+                add = None if last else d_res_all[k, i]                  # + the residual path's gradient (audio = res + audio)
                 if i > 0:
-                    ops.taps_bwd(dcol, b, self.tg, nc, ks, 2 ** i, ks // 2, out=d_rs_all[k, i - 1, :, :nc], addend=add)
+                    ops.taps_bwd(dcol, b, self.tg, nc, ks, 2 ** i, ks // 2, out=d_res_all[k, i - 1], addend=add)
                 else:
                     d_x0 = torch.empty((m, nc), dtype=self.dtype, device=self.dev)
                     ops.taps_bwd(dcol, b, self.tg, nc, ks, 1, ks // 2, out=d_x0, addend=add)
@@ -246,17 +275,19 @@ class WaveGlowTrainer:
         # ---- everything that spans the flows, once
         kc = self.mel * self.ng
         nz = self.nf * nl
+        # res_skip bias gradients of every (flow, layer): [column sums of the residual half | column sums of d_skip]
+        F.colsum_batched(self._rs_bias_table, m, nc, nc, self.dtype)
         # in_layer weight gradients of every (flow, layer): slice z = ds_all[:, z*2nc:(z+1)*2nc]^T x col_all[z]
         if batched:
             F.gemm_batched(ds_all, self.col_all, self.dw_in, 2 * nc, ks * nc, m, self.cond_cols, ks * nc, ks * nc, False, False,
                            nz, 1, (2 * nc, 0), (m * ks * nc, 0), (2 * nc * ks * nc, 0))
-            # res_skip weight gradients: slice (k, i) = d_rs_all[k, i]^T x acts_all[k, i]; layers 0 .. nl-2 are 2nc x nc, the last
-            # layer of every flow nc x nc from the skip half only
+            # res_skip weight gradients: skip rows of slice (k, i) = d_skip[k]^T x acts_all[k, i] (all layers), residual rows =
+            # d_res_all[k, i]^T x acts_all[k, i] (layers 0 .. nl-2)
+            F.gemm_batched(d_skip_all, self.acts_all, self.dw_rs[0, 0, nc:], nc, nc, m, nc, nc, nc, False, False, nz, nl,
+                           (m * nc, 0), (nl * m * nc, m * nc), (nl * 2 * nc * nc, 2 * nc * nc))
             if nl > 1:
-                F.gemm_batched(d_rs_all, self.acts_all, self.dw_rs, 2 * nc, nc, m, 2 * nc, nc, nc, False, False, self.nf * (nl - 1),
-                               nl - 1, (nl * m * 2 * nc, m * 2 * nc), (nl * m * nc, m * nc), (nl * 2 * nc * nc, 2 * nc * nc))
-            F.gemm_batched(d_rs_all[0, nl - 1, :, nc:], self.acts_all[nl - 1], self.dw_rs[0, nl - 1], nc, nc, m, 2 * nc, nc, nc,
-                           False, False, self.nf, 1, (nl * m * 2 * nc, 0), (nl * m * nc, 0), (nl * 2 * nc * nc, 0))
+                F.gemm_batched(d_res_all, self.acts_all, self.dw_rs, nc, nc, m, nc, nc, nc, False, False, self.nf * (nl - 1),
+                               nl - 1, ((nl - 1) * m * nc, m * nc), (nl * m * nc, m * nc), (nl * 2 * nc * nc, 2 * nc * nc))
         else:                          # any other batch x segment goes slice by slice through dle_gemm (which has an unaligned path)
             for z in range(nz):
                 F.gemm(ds_all[:, z * 2 * nc:(z + 1) * 2 * nc], self.col_all[z], 2 * nc, ks * nc, m, False, False, out=self.dw_in[z],

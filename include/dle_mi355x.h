@@ -132,6 +132,13 @@ int dle_conv2d_wgrad(const void* dy, const void* x, float* dw, int N, int H, int
  * enough): row groups are combined through it instead of through same-address atomics. */
 int dle_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, int accumulate,
                void* workspace, int64_t workspace_bytes, hipStream_t stream);
+/* The same sums for n same-shaped 16-bit matrices in one launch pair (the bias gradients of a stack of layers whose output
+ * gradients are kept until the end of backward: WaveGlow's 96 res_skip layers, waveglow/model.py:138-157).  table_dev: n x
+ * { int64 address of the [M, N] matrix (row pitch ld), int64 address of its fp32 [N] destination } in device memory;
+ * workspace >= dle_colsum_batched_workspace_bytes(n, M, N). */
+int64_t dle_colsum_batched_workspace_bytes(int n, int64_t M, int N);
+int dle_colsum_batched(const int64_t* table_dev, int n, int64_t M, int N, int64_t ld, int dtype, void* workspace,
+                       int64_t workspace_bytes, hipStream_t stream);
 
 /* ---- multi-tensor optimizer kernels -----------------------------------------------------------
  * replaces fused_lamb_CUDA.multi_tensor_l2norm / multi_tensor_lamb

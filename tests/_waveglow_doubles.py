@@ -264,6 +264,13 @@ def gemm_batched(a, b, c, m, n, k, lda, ldb, ldc, a_kc, b_kc, batch, batch_inner
     return c
 
 
+def colsum_batched(table, m, n, ld, dtype):
+    """dle_colsum_batched: fp32 column sums of every [m, n] matrix of the table into its destination."""
+    for x, out in table.entries:
+        assert x.shape == (m, n) and ld == n
+        out.copy_(x.double().sum(0).float())
+
+
 # ---------------------------------------------------------------- csrc/multi_tensor.hip (as the engine uses it)
 class _Table:
     def __init__(self, lists, chunk):
@@ -312,7 +319,7 @@ def install(monkeypatch):
     from deeplearningexamples_amd.waveglow import engine, ops
     me = globals()
     monkeypatch.setattr(C, "require_cuda", lambda *a: None)
-    for name in ("gemm", "gemm_batched", "colsum", "copy_rows", "nchw_to_nhwc", "check_nonfinite_", "amp_update_scale_"):
+    for name in ("gemm", "gemm_batched", "colsum", "colsum_batched", "copy_rows", "nchw_to_nhwc", "check_nonfinite_", "amp_update_scale_"):
         monkeypatch.setattr(F, name, me[name])
     for name in ("taps", "taps_bwd", "gate_fwd", "gate_bwd", "invconv_fwd", "logdet_inv", "invconv_bwd", "coupling_partials",
                  "coupling_fwd", "coupling_bwd", "loss", "dz_init", "weight_norm_fwd", "weight_norm_bwd", "upsample_weight",

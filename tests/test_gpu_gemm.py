@@ -305,3 +305,24 @@ def test_conv1x1_statistics_from_the_expand_kernel(cuda, shape, dtype, monkeypat
     assert float((rstd1.double() - (ref_var + 1e-5).rsqrt()).abs().max()) <= 1e-4 * float((ref_var + 1e-5).rsqrt().max())
     for a, b in zip(res["1"][1:], res["0"][1:]):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 1000, 512), (40, 10000, 512), (5, 77, 24), (1, 4096, 1024)])
+def test_colsum_batched(cuda, shape, dtype):
+    """dle_colsum_batched: n same-shaped matrices -> n fp32 destinations (views of one flat buffer, as the gradient slots are),
+    against float64 sums; the same matrix may appear several times (WaveGlow's d_skip feeds every layer of a flow)."""
+    F, C = _F()
+    n, m, cols = shape
+    gen = torch.Generator().manual_seed(n + m + cols)
+    xs = [_mk((m, cols), dtype, gen).to(cuda) for _ in range(n)]
+    flat = torch.full(((n + 2) * cols + 3,), 7.0, dtype=torch.float32, device=cuda)
+    entries = [(xs[i], flat[1 + i * cols:1 + (i + 1) * cols] if cols % 4 == 0 else flat[i * cols:(i + 1) * cols]) for i in range(n)]
+    entries.append((xs[0], flat[1 + n * cols:1 + (n + 1) * cols] if cols % 4 == 0 else flat[n * cols:(n + 1) * cols]))
+    F.colsum_batched(F.ColsumTable(entries), m, cols, cols, dtype)
+    for x, out in entries:
+        ref = x.double().sum(0)
+        assert float((out.double() - ref).abs().max()) <= 2e-6 * float(x.double().abs().sum(0).max()) + 1e-6
+    assert float(flat[-1]) == 7.0
+    with pytest.raises(ValueError):
+        F.ColsumTable([(xs[0], flat[:cols]), (xs[0][:-1], flat[:cols])])
