@@ -148,6 +148,9 @@ _SIGS = {
     "dle_transpose_cast": (c_int, [c_void_p, c_void_p, c_int, c_int, c_i64, c_i64, c_int, c_int, c_void_p]),
     "dle_t2_mel_loss": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64,
                                 c_int, c_int, c_void_p]),
+    "dle_t2_lstm_gemm_fwd": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p,
+                                     c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_float, c_int, c_int, c_int, c_int,
+                                     c_void_p]),
     "dle_t2_mask_rows": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_i64, c_int, c_float, c_int, c_void_p]),
 }
 

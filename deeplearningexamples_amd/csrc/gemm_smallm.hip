@@ -33,6 +33,15 @@ struct SmallMArgs {
   long long lda, ldb, ldc;
   int out_dtype, act_add, accumulate;
   float alpha;
+  // fused LSTM cell (LSTM instantiation only): N = 4 H gate columns (i | f | g | o blocks of H); tile tn owns units 8 tn .. 8 tn + 7
+  int H;
+  const float* c_prev;
+  float* c_out;
+  unsigned short* hd[3];
+  long long ldh[3];
+  const unsigned char* keep;
+  long long keep_index;
+  float inv_keep;
 };
 
 template <int DT> struct Mfma16x32;
@@ -49,7 +58,7 @@ template <> struct Mfma16x32<DLE_BF16> {
 
 // One K chunk of the workgroup's (SM_TS + TN)-row operand panel into `stage`.  NPW pieces per wavefront; piece q covers rows
 // 4q .. 4q + 3 (A rows first); lane l -> row 4q + (l >> 4), LDS slot l & 15, source chunk slot ^ (row & 15).
-template <int TN, int NW>
+template <int TN, int NW, bool LSTM = false>
 struct SmallMLoader {
   static constexpr int R = SM_TS + TN, NPW = R / 4 / NW, NPA = SM_TS / 4 / NW;     // pieces per wave: all / of the A rows
   unsigned off[NPW];        // byte offset of (row, chunk) inside its operand, k0 = 0
@@ -60,7 +69,9 @@ struct SmallMLoader {
     for (int j = 0; j < NPW; ++j) {
       const int q = wave + NW * j, row = 4 * q + (lane >> 4), chunk = (lane & 15) ^ (row & 15);
       const bool is_a = j < NPA;                 // (wave + NW j < 16 <=> j < 16 / NW: a piece lies entirely in one operand)
-      const int g = is_a ? m0 + row : n0 + row - SM_TS;
+      // LSTM: tile-local weight row r <-> gate r >> 3, unit n0 / 4 + (r & 7): the four gate rows of 8 units (n0 = 32 tn)
+      const int rl = row - SM_TS;
+      const int g = is_a ? m0 + row : LSTM ? (rl >> 3) * p.H + (n0 >> 2) + (rl & 7) : n0 + rl;
       ok[j] = is_a ? g < p.M : g < p.N;
       kin[j] = chunk * 8;
       off[j] = (unsigned)(((long long)g * (is_a ? p.lda : p.ldb) + chunk * 8) * 2);
@@ -94,9 +105,12 @@ __device__ __forceinline__ void sm_wait_chunks(int c) {
 // NW wavefronts: 8 for the 64 x 32 tile, 4 for 64 x 16 -- ONE 16 x 16 output block per wavefront.  An LDS-DMA piece costs the
 // issuing wavefront ~100-180 cycles (MI355X_MICROARCH.md): with 4 wavefronts issuing 6 pieces per chunk each, the first version
 // of this kernel was bound by that issue cost (42 GB/s per CU whatever the pipeline depth); 8 wavefronts issue 3 each.
-template <int DT, int TN, int NW, int NST>
+__device__ __forceinline__ float sm_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+template <int DT, int TN, int NW, int NST, bool LSTM = false>
 __global__ __launch_bounds__(NW * 64) void gemm_smallm_kernel(SmallMArgs p) {
-  typedef SmallMLoader<TN, NW> L;
+  typedef SmallMLoader<TN, NW, LSTM> L;
+  static_assert(!LSTM || (TN == 32 && NW == 8), "the fused cell runs on the 64 x 32 tile");
   static_assert(4 * (TN / 16) == NW, "one 16x16 block per wavefront");
   constexpr int R = L::R, STAGE = R * SM_BKE;      // halves per stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -130,6 +144,68 @@ __global__ __launch_bounds__(NW * 64) void gemm_smallm_kernel(SmallMArgs p) {
       const ushort8_t fw = *(const ushort8_t*)(wa + slot * 8);
       acc = Mfma16x32<DT>::run(fw, fx, acc);
     }
+  }
+  if constexpr (LSTM) {
+    // ---- fused LSTM cell (tacotron2/model.py:425-444: nn.LSTMCell + F.dropout on the hidden state).  The tile holds the four
+    // gate pre-activations of 8 units for 64 samples.  They meet through LDS (the stages are idle now): [64][32] fp32, column
+    // 8 gate + unit; then one thread per (sample, unit) runs the cell, and the activations / hidden states leave as 16-byte rows.
+    const int H = p.H, u0 = n0 >> 2;
+    __syncthreads();                                   // every wave is done reading the last stage
+    float* pre = (float*)smem_raw;                     // [64][33] (padded)
+    unsigned short* hb = (unsigned short*)(pre + 64 * 33);   // [64][8] hidden states (16-bit)
+    {
+      const int row = mb * 16 + fr, m = m0 + row;
+      const int c = nb * 16 + 4 * kg;                  // tile column of acc[0]: gate c >> 3, units (c & 7) .. + 3
+      const int gate = c >> 3, un = c & 7;
+      const long long ng = (long long)gate * H + u0 + un;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[r] * p.alpha;
+      if (m < p.M) {
+        if (p.bias) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += p.bias[ng + r];
+        }
+        if (p.act_add) {
+          const ushort4_t sv = *(const ushort4_t*)(p.src + (long long)m * p.ldc + ng);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += Elem<DT>::to_f32(sv[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)                      // the pre-activation is a 16-bit tensor in the unfused sequence: same rounding
+        pre[row * 33 + c + r] = Elem<DT>::to_f32(Elem<DT>::from_f32(v[r]));
+    }
+    __syncthreads();
+    {
+      const int row = threadIdx.x >> 3, un = threadIdx.x & 7, m = m0 + row;
+      float* pr = pre + row * 33 + un;
+      const float gi = sm_sigmoid(pr[0]), gf = sm_sigmoid(pr[8]), gg = fast_tanh(pr[16]), go = sm_sigmoid(pr[24]);
+      const long long idx = (long long)(m < p.M ? m : p.M - 1) * H + u0 + un;
+      const float c = gf * p.c_prev[idx] + gi * gg;
+      float h = go * fast_tanh(c);
+      if (p.keep) {
+        const long long e = p.keep_index + idx;
+        h = ((p.keep[e >> 3] >> (e & 7)) & 1u) ? h * p.inv_keep : 0.f;
+      }
+      if (m < p.M) p.c_out[idx] = c;
+      pr[0] = gi; pr[8] = gf; pr[16] = gg; pr[24] = go;
+      hb[row * 8 + un] = Elem<DT>::from_f32(h);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {                           // activations: 64 rows x 4 gates, 16 bytes each
+      const int row = threadIdx.x >> 2, gate = threadIdx.x & 3, m = m0 + row;
+      if (m < p.M) {
+        float a[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a[r] = pre[row * 33 + gate * 8 + r];
+        *(ushort8_t*)((unsigned short*)p.C + (long long)m * p.ldc + (long long)gate * H + u0) = pack8<DT>(a);
+      }
+    } else if (threadIdx.x < 256 + 192) {              // hidden state: 64 rows x up to 3 destinations
+      const int t = threadIdx.x - 256, row = t & 63, d = t >> 6, m = m0 + row;
+      if (m < p.M && p.hd[d]) *(ushort8_t*)(p.hd[d] + (long long)m * p.ldh[d] + u0) = *(const ushort8_t*)(hb + row * 8);
+    }
+    return;
   }
   // lane: row m = m0 + 16 mb + (lane & 15), columns n0 + 16 nb + 4 (lane >> 4) + {0..3}
   const int m = m0 + mb * 16 + fr;
@@ -233,4 +309,44 @@ extern "C" int dle_gemm_smallm_try(const void* A, const void* B, void* C, const 
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { dle_set_error("gemm_smallm launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
   return 1;
+}
+
+
+// One decoder-step LSTMCell in ONE launch: gates = x W^T (+ bias) (+ addend), cell, dropout, hidden state to its consumers'
+// operand buffers.  See include/dle_mi355x.h (dle_t2_lstm_gemm_fwd).  0 = launched, -1 = argument error.
+extern "C" int dle_t2_lstm_gemm_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, const void* addend,
+                                    const float* c_prev, float* c_out, void* gates, int64_t ld_g, void* d0, int64_t ld0, void* d1,
+                                    int64_t ld1, void* d2, int64_t ld2, const void* keep, int64_t keep_index, float inv_keep, int B,
+                                    int H, int K, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(x && w && c_prev && c_out && gates && B > 0 && H > 0 && K > 0, "t2_lstm_gemm_fwd: bad args");
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "t2_lstm_gemm_fwd: 16-bit dtypes only (got %d)", dtype);
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  DLE_CHECK_ARG((H & 7) == 0 && (K & 7) == 0 && (ldx & 7) == 0 && (ldw & 7) == 0 && (ld_g & 7) == 0 && al16(x) && al16(w) &&
+                al16(gates) && al16(c_prev) && al16(c_out) && (!addend || (((uintptr_t)addend) & 7) == 0) &&
+                (!d0 || (al16(d0) && (ld0 & 7) == 0)) && (!d1 || (al16(d1) && (ld1 & 7) == 0)) && (!d2 || (al16(d2) && (ld2 & 7) == 0)),
+                "t2_lstm_gemm_fwd: H, K and every row pitch must be multiples of 8 with 16-byte aligned bases");
+  DLE_CHECK_ARG((long long)B * ldx * 2 < 0xFFFFFFE0LL && (long long)4 * H * ldw * 2 < 0xFFFFFFE0LL, "t2_lstm_gemm_fwd: operand above 4 GiB");
+  SmallMArgs p = {(const unsigned short*)x, (const unsigned short*)w, gates, bias, (const unsigned short*)addend, B, 4 * H, K,
+                  (long long)ldx, (long long)ldw, (long long)ld_g, dtype, addend ? 1 : 0, 0, 1.0f};
+  p.H = H; p.c_prev = c_prev; p.c_out = c_out;
+  p.hd[0] = (unsigned short*)d0; p.hd[1] = (unsigned short*)d1; p.hd[2] = (unsigned short*)d2;
+  p.ldh[0] = ld0; p.ldh[1] = ld1; p.ldh[2] = ld2;
+  p.keep = (const unsigned char*)keep; p.keep_index = keep_index; p.inv_keep = inv_keep;
+  const int tiles = ((B + SM_TS - 1) / SM_TS) * (H / 8);
+  const bool deep = tiles <= 256;
+#define GOL(DT, NST)                                                                                                          \
+  do {                                                                                                                         \
+    constexpr int lds_bytes = NST * (SM_TS + 32) * SM_BKE * 2;                                                                 \
+    static bool attr_set = false;                                                                                              \
+    if (!attr_set) {                                                                                                           \
+      (void)hipFuncSetAttribute((const void*)gemm_smallm_kernel<DT, 32, 8, NST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+      attr_set = true;                                                                                                         \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((gemm_smallm_kernel<DT, 32, 8, NST, true>), dim3(tiles), dim3(512), lds_bytes, stream, p);              \
+  } while (0)
+  if (dtype == DLE_F16) { if (deep) GOL(DLE_F16, 4); else GOL(DLE_F16, 3); }
+  else { if (deep) GOL(DLE_BF16, 4); else GOL(DLE_BF16, 3); }
+#undef GOL
+  DLE_LAUNCH_CHECK();
+  return 0;
 }

@@ -269,8 +269,9 @@ class Tacotron2Trainer:
         col = self._e(b * ti, self.KL * 8)
         pl = self._e(b * ti, A)
         for t in range(to):
-            F.gemm(x_a[t], w["a_cat"], b, 4 * Ha, E + Ha, True, True, out=ga[t], act=C.ACT_ADD, mask_src=g_pre[t])
-            ops.lstm_fwd(ga[t], ac[t], ac[t + 1], [x_d[t][:, :Ha], x_a[t + 1][:, E:]], keep=keep_a, keep_index=t * b * Ha, p=pa)
+            # gates product + cell + dropout in one launch (the cell is the epilogue of the few-row GEMM)
+            ops.lstm_gemm_fwd(x_a[t], w["a_cat"], None, g_pre[t], ac[t], ac[t + 1], ga[t], [x_d[t][:, :Ha], x_a[t + 1][:, E:]],
+                              keep=keep_a, keep_index=t * b * Ha, p=pa)
             F.gemm(x_d[t][:, :Ha], w["q"], b, A, Ha, True, True, out=q_all[t])
             if self.fuse_loc:
                 # the location term (2-channel k = 31 convolution + dense, one [A, 64] operand) is formed inside the kernel
@@ -281,8 +282,8 @@ class Tacotron2Trainer:
                 F.gemm(col, w["loc"], b * ti, A, self.KL * 8, True, True, act=C.ACT_ADD, mask_src=pm, out=pl)
                 ops.attention_fwd(q_all[t], pl, w["v"], memory, text_lengths, awc[t], tanh_all[t], aw[t], awc[t + 1],
                                   [x_d[t][:, Ha:Ha + E], x_a[t + 1][:, :E], hc[:, t, Hd:]])
-            F.gemm(x_d[t], w["d_cat"], b, 4 * Hd, Ha + E + Hd, True, True, out=gd[t], bias=w["d_b"])
-            ops.lstm_fwd(gd[t], dc[t], dc[t + 1], [x_d[t + 1][:, Ha + E:], hc[:, t, :Hd]], keep=keep_d, keep_index=t * b * Hd, p=pd)
+            ops.lstm_gemm_fwd(x_d[t], w["d_cat"], w["d_b"], None, dc[t], dc[t + 1], gd[t], [x_d[t + 1][:, Ha + E:], hc[:, t, :Hd]],
+                              keep=keep_d, keep_index=t * b * Hd, p=pd)
         sv.update(g_pre=g_pre, keep_a=keep_a, keep_d=keep_d, x_a=x_a, x_d=x_d, hc=hc, ga=ga, gd=gd, ac=ac, dc=dc, awc=awc, aw=aw,
                   tanh_all=tanh_all, q_all=q_all)
         # ---- mel + gate projection of every step at once, postnet, loss

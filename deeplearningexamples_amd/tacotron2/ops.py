@@ -46,6 +46,25 @@ def lstm_fwd(gates, c_prev, c_out, h_dsts, keep=None, keep_index=0, p=0.0, live=
            _ld(out_dst, "out_dst") if out_dst is not None else 0, b, hh, C.dt(gates), C.stream())
 
 
+def lstm_gemm_fwd(x, w, bias, addend, c_prev, c_out, gates, h_dsts, keep=None, keep_index=0, p=0.0):
+    """One LSTMCell step in one launch: gates = x w^T (+ bias) (+ addend) -> lstm_fwd (statement: include/dle_mi355x.h,
+    dle_t2_lstm_gemm_fwd).  x 16-bit [B, K] row-strided, w 16-bit [4H, K], gates 16-bit [B, 4H] row-strided (receives the gate
+    activations), addend 16-bit [B, 4H] with the pitch of `gates`; h_dsts: up to three 16-bit [B, H] row-strided views."""
+    C.require_cuda(x, w, bias, addend, c_prev, c_out, gates, keep, *h_dsts)
+    b, k = x.shape
+    h4 = w.shape[0]
+    hh = h4 // 4
+    if len(h_dsts) > 3:
+        raise ValueError("lstm_gemm_fwd: at most three destinations")
+    if addend is not None and _ld(addend, "addend") != _ld(gates, "gates"):
+        raise ValueError("lstm_gemm_fwd: the addend shares the row pitch of the gates")
+    d = list(h_dsts) + [None] * (3 - len(h_dsts))
+    C.call("dle_t2_lstm_gemm_fwd", C.ptr(x), _ld(x, "x"), C.ptr(w), _ld(w, "w"), C.ptr(bias), C.ptr(addend), C.ptr(c_prev),
+           C.ptr(c_out), C.ptr(gates), _ld(gates, "gates"), C.ptr(d[0]), _ld(d[0], "h dst") if d[0] is not None else 0, C.ptr(d[1]),
+           _ld(d[1], "h dst") if d[1] is not None else 0, C.ptr(d[2]), _ld(d[2], "h dst") if d[2] is not None else 0, C.ptr(keep),
+           int(keep_index), float(inv_keep(p) if keep is not None else 1.0), b, hh, k, C.dt(x), C.stream())
+
+
 def lstm_bwd(dh, dc_next, act, c_prev, dgates, dc_prev, keep=None, keep_index=0, p=0.0, live=None, dh_prev=None, dh_add=()):
     """dh_add: up to two more fp32 [B, H] row-strided pieces of the hidden state's gradient, summed on load."""
     C.require_cuda(dh, dc_next, act, c_prev, dgates, dc_prev, keep, live, dh_prev, *dh_add)

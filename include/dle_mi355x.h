@@ -451,6 +451,14 @@ int dle_t2_tanh_fwd(const void* x, void* y, int64_t n, int dtype, hipStream_t st
 int dle_t2_lstm_fwd(void* gates, int64_t ld_g, const float* c_prev, float* c_out, void* d0, int64_t ld0, void* d1, int64_t ld1,
                     void* d2, int64_t ld2, const void* keep, int64_t keep_index, float inv_keep, const float* live,
                     const void* h_prev, int64_t ld_hp, void* out_dst, int64_t ld_out, int B, int H, int dtype, hipStream_t stream);
+/* One LSTMCell of the decoder in ONE launch (the few-row weight-streaming kernel of csrc/gemm_smallm.hip with the cell as its
+ * epilogue): gates [B, 4H] = x [B, K] w [4H, K]^T (+ bias[4H]) (+ addend [B, 4H], 16-bit, row pitch ld_g), rounded to 16 bits as
+ * the unfused dle_gemm output would be, then exactly dle_t2_lstm_fwd: activations to `gates`, c_out, dropout(h) to d0..d2.
+ * H, K and every pitch multiples of 8, 16-byte aligned bases. */
+int dle_t2_lstm_gemm_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, const void* addend,
+                         const float* c_prev, float* c_out, void* gates, int64_t ld_g, void* d0, int64_t ld0, void* d1, int64_t ld1,
+                         void* d2, int64_t ld2, const void* keep, int64_t keep_index, float inv_keep, int B, int H, int K, int dtype,
+                         hipStream_t stream);
 int dle_t2_lstm_bwd(const float* dh, int64_t ld_dh, const float* dh1, int64_t ld_dh1, const float* dh2, int64_t ld_dh2,
                     const float* dc_next, const void* act, int64_t ld_act, const float* c_prev,
                     void* dgates, int64_t ld_dg, float* dc_prev, const void* keep, int64_t keep_index, float inv_keep,

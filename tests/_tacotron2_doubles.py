@@ -365,6 +365,17 @@ def mel_loss(out_all, post, target, n_mel, scale, d_out, d_post):
     return loss.reshape(1)
 
 
+def lstm_gemm_fwd(x, w, bias, addend, c_prev, c_out, gates, h_dsts, keep=None, keep_index=0, p=0.0):
+    """dle_t2_lstm_gemm_fwd = the gates product (rounded to the storage type like a dle_gemm output) followed by lstm_fwd."""
+    pre = x.double() @ w.double().t()
+    if bias is not None:
+        pre = pre + bias.double()
+    if addend is not None:
+        pre = pre + addend.double()
+    gates.copy_(pre.to(gates.dtype))
+    lstm_fwd(gates, c_prev, c_out, h_dsts, keep=keep, keep_index=keep_index, p=p)
+
+
 def install(monkeypatch):
     from deeplearningexamples_amd import _cabi as C
     from deeplearningexamples_amd import functional as F
@@ -380,7 +391,7 @@ def install(monkeypatch):
         monkeypatch.setattr(F, name, getattr(W, name))
     for name in ("taps", "taps_bwd", "weight_norm_fwd", "weight_norm_bwd"):
         monkeypatch.setattr(wops, name, getattr(W, name))
-    for name in ("tanh_fwd", "lstm_fwd", "lstm_bwd", "attention_fwd", "attention_bwd", "location_bwd", "sum_steps", "mel_loss", "inv_keep", "mask_rows"):
+    for name in ("tanh_fwd", "lstm_fwd", "lstm_gemm_fwd", "lstm_bwd", "attention_fwd", "attention_bwd", "location_bwd", "sum_steps", "mel_loss", "inv_keep", "mask_rows"):
         monkeypatch.setattr(ops, name, me[name])
     fake_mt = types.SimpleNamespace(TableCache=W.TableCache, streaming_chunk=W.streaming_chunk, l2norm=W.l2norm, adam=W.adam)
     monkeypatch.setattr(engine, "mt", fake_mt)

@@ -73,6 +73,47 @@ def test_lstm_cell_forward_backward(cuda, dtype, b, h, with_drop, with_live):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,h,k,bias,add,drop", [(128, 1024, 1536, False, True, True), (128, 1024, 2560, True, False, True),
+                                                 (3, 96, 160, True, True, False), (70, 32, 72, False, False, True), (200, 64, 64, True, True, True)])
+def test_lstm_cell_fused_into_the_gates_product(cuda, dtype, b, h, k, bias, add, drop):
+    """dle_t2_lstm_gemm_fwd (the cell as the epilogue of the few-row GEMM) == dle_gemm followed by dle_t2_lstm_fwd BIT FOR BIT (the
+    pre-activation is rounded to the storage type exactly as the unfused product's output is), on strided operand / destination
+    views as the decoder uses them; both against the double."""
+    ops = _ops()
+    from deeplearningexamples_amd import functional as F, _cabi as C
+    g = torch.Generator().manual_seed(b + h + k)
+    xw = (torch.randn(b, k + 16, generator=g) * 0.5).to(dtype)                    # operand = a column slice of a wider buffer
+    w = (torch.randn(4 * h, k, generator=g) * (1.0 / k ** 0.5)).to(dtype)
+    bs = torch.randn(4 * h, generator=g) * 0.1 if bias else None
+    ad = (torch.randn(b, 4 * h, generator=g) * 0.5).to(dtype) if add else None
+    c_prev = torch.randn(b, h, generator=g)
+    keep, bits = _keep_bits(3 * b * h, 0.1, g) if drop else (None, None)
+    kidx = b * h if drop else 0
+
+    def run(L, d, fused):
+        x = d(xw.clone())[:, 8:8 + k]
+        gates = d(torch.zeros(b, 4 * h, dtype=dtype))
+        c_out, dst0, dst1 = d(torch.zeros(b, h)), d(torch.zeros(b, 2 * h + 8, dtype=dtype)), d(torch.zeros(b, h, dtype=dtype))
+        dsts = [dst0[:, h:2 * h], dst1]
+        kw = dict(keep=d(bits) if drop else None, keep_index=kidx, p=0.1)
+        if fused:
+            L.lstm_gemm_fwd(x, d(w), d(bs) if bias else None, d(ad) if add else None, d(c_prev), c_out, gates, dsts, **kw)
+        else:
+            F.gemm(x, d(w), b, 4 * h, k, True, True, out=gates, bias=d(bs) if bias else None, act=C.ACT_ADD if add else C.ACT_NONE,
+                   mask_src=d(ad) if add else None)
+            L.lstm_fwd(gates, d(c_prev), c_out, dsts, **kw)
+        return gates, c_out, dst0, dst1
+    dev = lambda t: t.to(cuda)
+    got, two = run(ops, dev, True), run(ops, dev, False)
+    for a, r in zip(got, two):
+        assert torch.equal(a, r), "fused and unfused LSTM steps differ"
+    ref = run(D, lambda t: t, True)
+    for a, r in zip(got, ref):
+        _close(a, r, **_tol(dtype))
+    assert float(got[2][:, :h].abs().max()) == 0 and float(got[2][:, 2 * h:].abs().max()) == 0      # neighbours of the strided view
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("b,ti,a,e", [(3, 23, 32, 64), (48, 150, 128, 512), (2, 300, 128, 512)])
 def test_attention_step_forward_backward(cuda, dtype, b, ti, a, e):
     ops = _ops()
