@@ -122,6 +122,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_smallm_kernel(SmallMArgs p) {
   L ld;
   ld.init(p, wave, lane, m0, n0);
   const int nk = (p.K + SM_BKE - 1) / SM_BKE;
+  // LSTM: everything the cell reads besides the product (bias, addend, previous cell state, keep bits) is requested NOW: behind the
+  // K loop these would be two dependent global round trips (~2.5 us of a ~12 us launch) with nothing to hide them
+  float4_t pf_bias = {0.f, 0.f, 0.f, 0.f};
+  ushort4_t pf_src = {0, 0, 0, 0};
+  float pf_c = 0.f;
+  unsigned pf_keep = 0xffu;
+  if constexpr (LSTM) {
+    const int fr_ = lane & 15, kg_ = lane >> 4, mb_ = wave & 3, nb_ = wave >> 2;
+    const int m_ = m0 + mb_ * 16 + fr_, c_ = nb_ * 16 + 4 * kg_;
+    const long long ng_ = (long long)(c_ >> 3) * p.H + (n0 >> 2) + (c_ & 7);
+    const int mc_ = m_ < p.M ? m_ : p.M - 1;
+    if (p.bias) pf_bias = *(const float4_t*)(p.bias + ng_);
+    if (p.act_add) pf_src = *(const ushort4_t*)(p.src + (long long)mc_ * p.ldc + ng_);
+    const int row2 = threadIdx.x >> 3, m2 = m0 + row2 < p.M ? m0 + row2 : p.M - 1;
+    const long long idx2 = (long long)m2 * p.H + (n0 >> 2) + (threadIdx.x & 7);
+    pf_c = p.c_prev[idx2];
+    if (p.keep) pf_keep = p.keep[(p.keep_index + idx2) >> 3];
+  }
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
     if (s < nk) ld.issue(p, lds + s * STAGE, wave, s * SM_BKE);
@@ -161,16 +179,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_smallm_kernel(SmallMArgs p) {
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[r] * p.alpha;
-      if (m < p.M) {
-        if (p.bias) {
+      (void)ng; (void)m;
+      if (p.bias) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += p.bias[ng + r];
-        }
-        if (p.act_add) {
-          const ushort4_t sv = *(const ushort4_t*)(p.src + (long long)m * p.ldc + ng);
+        for (int r = 0; r < 4; ++r) v[r] += pf_bias[r];
+      }
+      if (p.act_add) {                                 // (same order of additions as the unfused epilogue: bit-identical gates)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += Elem<DT>::to_f32(sv[r]);
-        }
+        for (int r = 0; r < 4; ++r) v[r] += Elem<DT>::to_f32(pf_src[r]);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r)                      // the pre-activation is a 16-bit tensor in the unfused sequence: same rounding
@@ -182,12 +198,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_smallm_kernel(SmallMArgs p) {
       float* pr = pre + row * 33 + un;
       const float gi = sm_sigmoid(pr[0]), gf = sm_sigmoid(pr[8]), gg = fast_tanh(pr[16]), go = sm_sigmoid(pr[24]);
       const long long idx = (long long)(m < p.M ? m : p.M - 1) * H + u0 + un;
-      const float c = gf * p.c_prev[idx] + gi * gg;
+      const float c = gf * pf_c + gi * gg;
       float h = go * fast_tanh(c);
-      if (p.keep) {
-        const long long e = p.keep_index + idx;
-        h = ((p.keep[e >> 3] >> (e & 7)) & 1u) ? h * p.inv_keep : 0.f;
-      }
+      if (p.keep) h = ((pf_keep >> ((p.keep_index + idx) & 7)) & 1u) ? h * p.inv_keep : 0.f;
       if (m < p.M) p.c_out[idx] = c;
       pr[0] = gi; pr[8] = gf; pr[16] = gg; pr[24] = go;
       hb[row * 8 + un] = Elem<DT>::from_f32(h);

@@ -105,8 +105,9 @@ def test_lstm_cell_fused_into_the_gates_product(cuda, dtype, b, h, k, bias, add,
         return gates, c_out, dst0, dst1
     dev = lambda t: t.to(cuda)
     got, two = run(ops, dev, True), run(ops, dev, False)
-    for a, r in zip(got, two):
-        assert torch.equal(a, r), "fused and unfused LSTM steps differ"
+    assert torch.equal(got[0], two[0]), "fused and unfused gate activations differ"
+    for a, r in zip(got[1:], two[1:]):                        # (the cell's fp32 arithmetic may contract its multiply-adds differently)
+        assert float((a.float() - r.float()).abs().max()) <= 2.0 ** -9 * max(1.0, float(r.float().abs().max()))
     ref = run(D, lambda t: t, True)
     for a, r in zip(got, ref):
         _close(a, r, **_tol(dtype))
