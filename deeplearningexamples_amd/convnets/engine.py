@@ -16,6 +16,8 @@ import math
 from typing import Optional
 
 import numpy as np
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -120,6 +122,14 @@ class ResNetTrainer:
                 u.gw = self.gview[u.name_conv + ".weight"].view(ko, r, s, ci)
             else:                                   # stem: gradient of the channel-padded weight, cropped later
                 u.gw = torch.zeros((ko, r, s, cp), dtype=torch.float32, device=self.dev)
+        # weight gradients on a second stream (resnet.ConvBN.backward); DLE_RN50_WGRAD_STREAM=0 keeps everything on one stream
+        self.wgrad_stream = torch.cuda.Stream(device=self.dev) if (self.dev.type == "cuda" and
+                                                                   os.environ.get("DLE_RN50_WGRAD_STREAM", "1") != "0") else None
+        self._wgrad_keepalive = []
+        for u in units:
+            u.wgrad_stream, u.keepalive = self.wgrad_stream, self._wgrad_keepalive
+        if self.buckets is not None and self.wgrad_stream is not None:
+            self.buckets.extra_streams.append(self.wgrad_stream)
         self.fc_w16 = torch.empty(model.fc.weight.shape, dtype=compute_dtype, device=self.dev)
         self.w16["fc.weight"] = self.fc_w16
         self.refresh_working_copies()
@@ -254,6 +264,9 @@ class ResNetTrainer:
         self.stem.backward(g, need_dx=False)
         gw = self.stem.gw
         ko, r, s, cp = gw.shape
+        if self.wgrad_stream is not None:            # every weight gradient has landed before anything reads the flat buffer
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+            self._wgrad_keepalive.clear()
         F.copy_rows(gw.view(ko * r * s, cp)[:, :3], self.gview["conv1.weight"].view(ko * r * s, 3))
         self._done(self.stem)
 

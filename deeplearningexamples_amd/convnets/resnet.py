@@ -9,6 +9,7 @@ The nn.Conv2d / nn.BatchNorm2d / nn.Linear submodules exist only to own the para
 reference's names (checkpoint compatible); conv weights are kept in channels_last memory so that the fp32
 master, its gradient and the 16-bit working copy all share the KRSC element order the kernels read.
 """
+from contextlib import nullcontext as _nullcontext
 from typing import List
 
 import torch
@@ -45,6 +46,8 @@ class ConvBN:
         self.w16 = None                 # [Ko, R, S, Cp] 16-bit working copy (Cp = cin padded to 8)
         self.gw = self.ggamma = self.gbeta = None   # fp32 gradient views (set by the trainer)
         self.saved = None
+        self.wgrad_stream = None                    # set by the trainer: weight gradients run beside the data-gradient chain
+        self.keepalive = None                       # ... with the list that keeps their operands alive until the streams join
 
     def forward(self, x, residual=None):
         # conv + batch statistics in one pass over the activation (the statistics come out of the convolution
@@ -76,12 +79,25 @@ class ConvBN:
         gt, _ = F.bn_bwd(dy, None, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta, relu_mask=rmask)
         n, h, w, c = x.shape
         masked = isinstance(dx_addend, tuple)
+        # The weight gradient is a leaf of the backward graph (nothing downstream reads it before the optimizer) while the data
+        # gradient is on the critical chain: it goes to a second stream, where its split-K slices (one workgroup per CU, bound by
+        # HBM latency rather than bandwidth) share the chip with the next unit's BatchNorm / data-gradient kernels.
+        ws = self.wgrad_stream
+        if ws is not None:
+            ws.wait_stream(torch.cuda.current_stream())
+            self.keepalive.append((gt, x))          # freed only after the trainer has joined the streams (no record_stream: that
+                                                    # call is not capturable, and the step may be recorded into a HIP graph)
+        with (torch.cuda.stream(ws) if ws is not None else _nullcontext()):
+            if self.k == 1 and self.stride == 1:
+                m = n * h * w
+                F.gemm(gt.view(m, self.cout), x.view(m, c), self.cout, c, m, False, False, out=self.gw.view(self.cout, c),
+                       splitk=F.pick_splitk(self.cout, c, m, target_blocks=1024))
+            else:
+                F.conv2d_wgrad(gt, x, (self.k, self.k), self.stride, self.pad, out=self.gw)
+        dx = None
         if self.k == 1 and self.stride == 1:
             m = n * h * w
-            g2, x2 = gt.view(m, self.cout), x.view(m, c)
-            F.gemm(g2, x2, self.cout, c, m, False, False, out=self.gw.view(self.cout, c),
-                   splitk=F.pick_splitk(self.cout, c, m, target_blocks=1024))
-            dx = None
+            g2 = gt.view(m, self.cout)
             if need_dx:
                 if masked:
                     dx = F.gemm(g2, self.w16.view(self.cout, c), m, c, self.cout, True, False, act=C.ACT_ADD_MASKED,
@@ -92,7 +108,6 @@ class ConvBN:
                                 mask_src=dx_addend.view(m, c) if dx_addend is not None else None).view(n, h, w, c)
         else:
             assert not masked, "masked residual gradients enter through the 1x1 convolution of a bottleneck"
-            F.conv2d_wgrad(gt, x, (self.k, self.k), self.stride, self.pad, out=self.gw)
             dx = F.conv2d_dgrad(gt, self.w16, (h, w), self.stride, self.pad, addend=dx_addend) if need_dx else None
         return dx
 

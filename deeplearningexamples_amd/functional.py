@@ -293,11 +293,14 @@ _splitk_ws = {}
 
 
 def splitk_workspace(device, nbytes):
-    """Per-device fp32 scratch for split-K partial slabs (grown on demand, reused by every GEMM on the stream)."""
-    w = _splitk_ws.get(device)
+    """fp32 scratch for split-K partial slabs, reduction partials and the like: one buffer per (device, CURRENT STREAM), grown on
+    demand -- launches of one stream use it one after the other; two streams running kernels side by side (the weight-gradient
+    stream of the ResNet engine) must not share it."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    w = _splitk_ws.get(key)
     if w is None or w.numel() * 4 < nbytes:
         w = torch.empty(max(nbytes // 4, 1 << 22), dtype=torch.float32, device=device)
-        _splitk_ws[device] = w
+        _splitk_ws[key] = w
     return w
 
 

@@ -45,6 +45,7 @@ class GradBuckets:
         self.flat, self.group, self.stream = flat, group, comm_stream
         self.wire_dtype = wire_dtype
         self._wire = None
+        self.extra_streams = []
         if reverse:
             total = sum(n for _, n in named_numels)
             cut = cut_buckets(list(reversed(list(named_numels))), bucket_mb * (1 << 20))
@@ -65,6 +66,8 @@ class GradBuckets:
         self.fired += 1
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
+            for extra in self.extra_streams:          # streams that write gradients beside the current one (weight-gradient stream)
+                self.stream.wait_stream(extra)
             with torch.cuda.stream(self.stream):
                 self._reduce(s, e)
         else:
