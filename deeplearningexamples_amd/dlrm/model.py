@@ -14,6 +14,8 @@ The autograd-Function form of the individual ops (the reference's dlrm.cuda_ext 
 cuda_ext.py.
 """
 import math
+import os
+from contextlib import nullcontext as _nullcontext
 from typing import List, Optional, Sequence
 
 import torch
@@ -276,26 +278,48 @@ class DlrmBottom(nn.Module):
         b = numerical_input.shape[0] if numerical_input is not None else categorical_inputs.shape[0]
         dev = self.embeddings.weight.device if self.embeddings is not None else numerical_input.device
         out = torch.empty((b, n_vec, d), dtype=self.compute_dtype, device=dev)
-        slot = 0
+        slot = 1 if self.mlp is not None else 0
+        # the gather (HBM-bound, no LDS) and the bottom MLP (MFMA tiles) write disjoint slots of `out` and want different
+        # resources: they run side by side on two streams and join before anything reads `out`
+        side = self._side_stream(dev) if (self.mlp is not None and self.embeddings is not None) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+        if self.embeddings is not None:
+            with (torch.cuda.stream(side) if side is not None else _nullcontext()):
+                self.embeddings(categorical_inputs, out=out[:, slot:, :], out_batch_stride=n_vec * d)
         if self.mlp is not None:
             x16 = F.cast_rows(numerical_input, self.compute_dtype, cols_out=self.mlp.k_padded(0))
             self.mlp(x16, out=out[:, 0, :])
-            slot = 1
-        if self.embeddings is not None:
-            self.embeddings(categorical_inputs, out=out[:, slot:, :], out_batch_stride=n_vec * d)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         self._out = out
         return out
+
+    def _side_stream(self, dev):
+        """Second stream of this module (None on the CPU test doubles or with DLE_DLRM_TWO_STREAMS=0)."""
+        if dev.type != "cuda" or os.environ.get("DLE_DLRM_TWO_STREAMS", "1") == "0":
+            return None
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
 
     def backward(self, grad_out, emb_lr, inv_scale=None, skip_flag=None, mlp_grads=None, freeze_embeddings=False):
         """grad_out [B, n_local, D] 16-bit.  Embedding rows are updated in place (fused sparse SGD);
         bottom-MLP gradients are produced for the dense optimizer."""
         n_vec, d = self.num_feature_vectors, self._embedding_dim
         slot = 1 if self.mlp is not None else 0
+        both = self.embeddings is not None and not freeze_embeddings and self.mlp is not None
+        side = self._side_stream(grad_out.device) if both else None
+        if side is not None:                       # the sparse update (HBM-bound row read-modify-writes) beside the MLP backward
+            side.wait_stream(torch.cuda.current_stream())
         if self.embeddings is not None and not freeze_embeddings:
-            self.embeddings.apply_sparse_sgd(grad_out[:, slot:, :], emb_lr, inv_scale, skip_flag,
-                                             grad_batch_stride=n_vec * d)
+            with (torch.cuda.stream(side) if side is not None else _nullcontext()):
+                self.embeddings.apply_sparse_sgd(grad_out[:, slot:, :], emb_lr, inv_scale, skip_flag,
+                                                 grad_batch_stride=n_vec * d)
         if self.mlp is not None:
             self.mlp.backward(grad_out[:, 0, :], grads=mlp_grads)
+        if side is not None:                       # joined here: the caller may now raise found_inf for the dense gradients
+            torch.cuda.current_stream().wait_stream(side)
 
 
 class DlrmTop(nn.Module):
