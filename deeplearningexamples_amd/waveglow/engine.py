@@ -19,9 +19,6 @@ Weight normalisation (fp32 masters -> 16-bit operands, GEMM-layout gradients -> 
 table-driven launch each.  The flow state stays fp32 ([M, 8]); 16-bit tensors are the GEMM operands and WN activations, as
 under autocast.
 """
-import os
-from contextlib import nullcontext as _nullcontext
-
 import torch
 
 from .. import _cabi as C
@@ -202,14 +199,6 @@ class WaveGlowTrainer:
         self.loss = ops.loss(state, self.logs_partial.view(-1), self.logdets, self.sigma)
         return self.loss
 
-    def _side_stream(self):
-        """Second stream for the per-flow weight gradients (None on the CPU doubles or with DLE_WG_TWO_STREAMS=0)."""
-        if self.dev.type != "cuda" or os.environ.get("DLE_WG_TWO_STREAMS", "1") == "0":
-            return None
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.dev)
-        return self._side
-
     def _backward_buffers(self, m):
         """Persistent gradient buffers of the res_skip outputs for M = m rows + the table of their bias-gradient column sums."""
         if self._bwd_shape != m:
@@ -283,30 +272,23 @@ class WaveGlowTrainer:
             F.colsum(d_x0, out=g[pre + "start.bias"])
             dz = ops.invconv_bwd(dy, da0, f.state, p["convinv.%d.conv.weight" % k], f.winv_t,
                                  g["convinv.%d.conv.weight" % k], scale, 1.0 / self.ng, f.c)
-            if batched:
-                # this flow's in_layer / res_skip weight gradients (leaves of the backward graph: 3 batched products, 192 tiles each)
-                # go to a second stream and fill the CUs the next flow's chain of M = 10,000-row products leaves idle (160-316 tiles)
-                side = self._side_stream()
-                if side is not None:
-                    side.wait_stream(torch.cuda.current_stream())
-                with (torch.cuda.stream(side) if side is not None else _nullcontext()):
-                    z0 = k * nl
-                    # slice z = ds_all[:, z*2nc:(z+1)*2nc]^T x col_all[z]
-                    F.gemm_batched(ds_all[:, z0 * 2 * nc:], self.col_all[z0], self.dw_in[z0], 2 * nc, ks * nc, m, self.cond_cols,
-                                   ks * nc, ks * nc, False, False, nl, 1, (2 * nc, 0), (m * ks * nc, 0), (2 * nc * ks * nc, 0))
-                    # res_skip: skip rows of slice (k, i) = d_skip[k]^T x acts_all[k, i] (all layers), residual rows =
-                    # d_res_all[k, i]^T x acts_all[k, i] (layers 0 .. nl-2)
-                    F.gemm_batched(d_skip, self.acts_all[z0], self.dw_rs[k, 0, nc:], nc, nc, m, nc, nc, nc, False, False, nl, nl,
-                                   (0, 0), (0, m * nc), (0, 2 * nc * nc))
-                    if nl > 1:
-                        F.gemm_batched(d_res_all[k], self.acts_all[z0], self.dw_rs[k], nc, nc, m, nc, nc, nc, False, False, nl - 1,
-                                       nl - 1, (0, m * nc), (0, m * nc), (0, 2 * nc * nc))
         # ---- everything that spans the flows, once
         kc = self.mel * self.ng
         nz = self.nf * nl
         # res_skip bias gradients of every (flow, layer): [column sums of the residual half | column sums of d_skip]
         F.colsum_batched(self._rs_bias_table, m, nc, nc, self.dtype)
-        if not batched:                # any other batch x segment goes slice by slice through dle_gemm (which has an unaligned path)
+        # in_layer weight gradients of every (flow, layer): slice z = ds_all[:, z*2nc:(z+1)*2nc]^T x col_all[z]
+        if batched:
+            F.gemm_batched(ds_all, self.col_all, self.dw_in, 2 * nc, ks * nc, m, self.cond_cols, ks * nc, ks * nc, False, False,
+                           nz, 1, (2 * nc, 0), (m * ks * nc, 0), (2 * nc * ks * nc, 0))
+            # res_skip weight gradients: skip rows of slice (k, i) = d_skip[k]^T x acts_all[k, i] (all layers), residual rows =
+            # d_res_all[k, i]^T x acts_all[k, i] (layers 0 .. nl-2)
+            F.gemm_batched(d_skip_all, self.acts_all, self.dw_rs[0, 0, nc:], nc, nc, m, nc, nc, nc, False, False, nz, nl,
+                           (m * nc, 0), (nl * m * nc, m * nc), (nl * 2 * nc * nc, 2 * nc * nc))
+            if nl > 1:
+                F.gemm_batched(d_res_all, self.acts_all, self.dw_rs, nc, nc, m, nc, nc, nc, False, False, self.nf * (nl - 1),
+                               nl - 1, ((nl - 1) * m * nc, m * nc), (nl * m * nc, m * nc), (nl * 2 * nc * nc, 2 * nc * nc))
+        else:                          # any other batch x segment goes slice by slice through dle_gemm (which has an unaligned path)
             for z in range(nz):
                 F.gemm(ds_all[:, z * 2 * nc:(z + 1) * 2 * nc], self.col_all[z], 2 * nc, ks * nc, m, False, False, out=self.dw_in[z],
                        splitk=F.pick_splitk(2 * nc, ks * nc, m))
@@ -316,8 +298,6 @@ class WaveGlowTrainer:
         gb = self._bias_block(g, "WN.0.cond_layers.0.bias")
         F.colsum(ds_all, out=gb)
         self._bias_block(g, "WN.0.in_layers.0.bias").copy_(gb)
-        if batched and self._side_stream() is not None:                  # the per-flow weight gradients have landed
-            torch.cuda.current_stream().wait_stream(self._side_stream())
         ops.weight_norm_bwd_batched(self.wn_bwd)                         # every dv, dg from the GEMM-layout gradients
         d_spect = F.gemm(ds_all, self.w_cond, m, kc, self.cond_cols, True, False)
         # upsampling
