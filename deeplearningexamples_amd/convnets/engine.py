@@ -128,8 +128,13 @@ class ResNetTrainer:
         self._wgrad_keepalive = []
         for u in units:
             u.wgrad_stream, u.keepalive = self.wgrad_stream, self._wgrad_keepalive
-        if self.buckets is not None and self.wgrad_stream is not None:
-            self.buckets.extra_streams.append(self.wgrad_stream)
+        # the downsample branch of a layer's first block (1x1 convolution + BatchNorm beside conv1 -> conv2 -> conv3) on a third
+        # stream, forward and backward; DLE_RN50_BRANCH_STREAM=0 keeps it in line
+        self.branch_stream = torch.cuda.Stream(device=self.dev) if (self.dev.type == "cuda" and
+                                                                    os.environ.get("DLE_RN50_BRANCH_STREAM", "1") != "0") else None
+        self._branch_keep = []
+        if self.buckets is not None:
+            self.buckets.extra_streams += [st for st in (self.wgrad_stream, self.branch_stream) if st is not None]
         self.fc_w16 = torch.empty(model.fc.weight.shape, dtype=compute_dtype, device=self.dev)
         self.w16["fc.weight"] = self.fc_w16
         self.refresh_working_copies()
@@ -225,9 +230,20 @@ class ResNetTrainer:
         m0, self._amax = F.maxpool_fwd(a0)
         self._pool_in_hw = a0.shape[1:3]
         h = m0
+        bs = self.branch_stream
         for (u1, u2, u3, ud) in self.blocks:
-            res = ud.forward(h) if ud is not None else h
-            o = u2.forward(u1.forward(h))
+            if ud is not None and bs is not None:
+                cur = torch.cuda.current_stream()
+                bs.wait_stream(cur)
+                self._branch_keep.clear()        # (what the branch stream produced earlier has been consumed before this point)
+                with torch.cuda.stream(bs):
+                    res = ud.forward(h)
+                o = u2.forward(u1.forward(h))
+                cur.wait_stream(bs)
+                self._branch_keep.append(res)    # allocated on the branch stream, read on this one: alive until the next fork
+            else:
+                res = ud.forward(h) if ud is not None else h
+                o = u2.forward(u1.forward(h))
             h = u3.forward(o, residual=res)
         self._feat_hw = h.shape[1:3]
         self._pooled = F.avgpool_fwd(h)
@@ -249,15 +265,26 @@ class ResNetTrainer:
             # the block ends in relu(bn3(conv3) + shortcut): g * (out > 0) flows into BOTH branches.  It is never written:
             # bn3's backward applies the mask on load, the shortcut side gets (g, mask) and applies it where it is consumed
             mask3 = u3.relu_mask()
+            bs = self.branch_stream if ud is not None else None
+            if bs is not None:                   # the downsample branch's backward beside bn3 / conv3 / conv2's
+                cur = torch.cuda.current_stream()
+                bs.wait_stream(cur)
+                self._branch_keep.clear()
+                with torch.cuda.stream(bs):
+                    gskip = ud.backward(g, dy_mask=mask3)
+                self._branch_keep.append((gskip, g))
             g3 = u3.backward(g)
             self._done(u3)
-            if ud is not None:
+            if ud is not None and bs is None:
                 gskip = ud.backward(g, dy_mask=mask3)
-                self._done(ud)
-            else:
+            elif ud is None:
                 gskip = (g, mask3)
             g2 = u2.backward(g3)
             self._done(u2)
+            if bs is not None:
+                cur.wait_stream(bs)
+            if ud is not None:
+                self._done(ud)
             g = u1.backward(g2, dx_addend=gskip)
             self._done(u1)
         g = F.maxpool_bwd(g, self._amax, self._pool_in_hw)
@@ -267,6 +294,7 @@ class ResNetTrainer:
         if self.wgrad_stream is not None:            # every weight gradient has landed before anything reads the flat buffer
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
             self._wgrad_keepalive.clear()
+        self._branch_keep.clear()
         F.copy_rows(gw.view(ko * r * s, cp)[:, :3], self.gview["conv1.weight"].view(ko * r * s, 3))
         self._done(self.stem)
 
