@@ -114,6 +114,10 @@ class DlrmWorkload:
         self.scaling = "strong"      # the reference keeps the GLOBAL batch at 64k for 1..8 GPUs (README.md:905-924)
         self.loss = None
 
+    def single_stream(self, on):
+        torch.cuda.synchronize()
+        os.environ["DLE_DLRM_TWO_STREAMS"] = "0" if on else "1"          # read per call by DlrmBottom
+
     def step(self):
         self.trainer.set_lr_factor(self.sched.step())
         self.loss = self.trainer.train_step(self.num, self.cat, self.click)
@@ -177,6 +181,9 @@ class Rn50Workload:
         self.scaling = "weak"
         self.loss = None
         self.it = 0
+
+    def single_stream(self, on):
+        self.trainer.set_side_streams(not on)
 
     def step(self):
         self.trainer.set_lr(float(self.lr_fn(self.it, 0)))
@@ -614,11 +621,19 @@ def run_workload(name, args, rank, world, device, steps, warmup):
     timer = None
     if not args.no_kernel_timer:
         timer = _cabi.KernelTimer()
+        # per-kernel durations are taken with every kernel ALONE on the chip: the engines' second streams (weight gradients,
+        # downsample branch, embedding update) are folded into one stream for this pass only -- side by side a kernel's event
+        # pair would also measure its neighbour's share of the machine
+        solo = getattr(wl, "single_stream", None)
+        if solo is not None:
+            solo(True)
         _cabi.set_timer(timer)
         for _ in range(steps):
             wl.step()
         torch.cuda.synchronize()
         _cabi.set_timer(None)
+        if solo is not None:
+            solo(False)
         if world > 1:
             dist.barrier()
     if world > 1:

@@ -179,6 +179,15 @@ class ResNetTrainer:
         self.lr.fill_(lr)
 
     # ------------------------------------------------------------------ communication
+    def set_side_streams(self, enabled):
+        """Second / third stream on or off (off: every kernel in line on the current stream -- bench.py's per-kernel timing pass)."""
+        if not hasattr(self, "_streams_saved"):
+            self._streams_saved = (self.wgrad_stream, self.branch_stream)
+        torch.cuda.synchronize(self.dev)
+        self.wgrad_stream, self.branch_stream = self._streams_saved if enabled else (None, None)
+        for u in self.units:
+            u.wgrad_stream = self.wgrad_stream
+
     def _maybe_reduce(self, finished_param_name):
         """Launch the all-reduce of a gradient bucket once its last gradient has been produced."""
         if self.buckets is not None and getattr(self, "_reduce_now", True):
