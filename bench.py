@@ -188,10 +188,6 @@ class Rn50Workload:
     def step(self):
         self.trainer.set_lr(float(self.lr_fn(self.it, 0)))
         self.loss = self.trainer.train_step(self.x, self.y)
-            cur.wait_stream(self.hp)
-            self.it += 1
-            return
-        self.loss = self.trainer.train_step(self.x, self.y)
         self.it += 1
 
     def config(self):
