@@ -219,14 +219,31 @@ class KernelTimer:
     # entry points whose duration depends on state they consume (row lists, touched-row sets): never replayed
     _STATEFUL = ("emb_sgd", "emb_sparse", "emb_link", "emb_grad", "amp_update")
 
-    def replay(self, name, tag, iters=20, warmup=3):
+    def replay(self, name, tag, iters=20, warmup=3, cold=False):
         """Average duration (ms) of the recorded call re-launched back to back: ONE event pair around `iters`
         launches on the launch stream, so the host-side cost of a per-call event pair (which leaves the queue idle
         between short kernels and inflates their event-to-event time) is out of the measurement.  Returns None for
-        entry points that are not pure functions of their inputs."""
+        entry points that are not pure functions of their inputs.
+        cold=True (launches whose operands fit in L2: a back-to-back replay would find them there, inside the step they come from
+        the Infinity Cache / HBM): a 64 MB fill runs in front of every launch and each launch gets its own event pair (the fill
+        keeps the queue busy up to the launch, so the pair measures the kernel, not an idle queue)."""
         if any(k in name for k in self._STATEFUL) or (name, tag) not in self.last:
             return None
         fn, args = self.last[(name, tag)]
+        if cold:
+            if getattr(self, "_flush", None) is None:
+                self._flush = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+            pairs = []
+            for i in range(warmup + iters):
+                self._flush.fill_(i & 1)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                fn(*args)
+                e.record()
+                if i >= warmup:
+                    pairs.append((s, e))
+            torch.cuda.synchronize()
+            return sum(s.elapsed_time(e) for s, e in pairs) / len(pairs)
         for _ in range(warmup):
             fn(*args)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
