@@ -236,6 +236,16 @@ class DlrmTrainer:
         return auc, float(loss.item())
 
     # ------------------------------------------------------------------ the step
+    def _wgrad_stream(self):
+        """Second stream for the top model's weight gradients (one rank; None with DLE_DLRM_TWO_STREAMS=0 or off the GPU)."""
+        import os
+        dev = self.scaler.scale.device
+        if dev.type != "cuda" or os.environ.get("DLE_DLRM_TWO_STREAMS", "1") == "0":
+            return None
+        if getattr(self, "_wside", None) is None:
+            self._wside = torch.cuda.Stream(device=dev)
+        return self._wside
+
     def train_step(self, numerical_features, categorical_features, click):
         """One optimisation step on a (global) batch.  Returns the device-resident fp32 loss [1]."""
         m, p, sc = self.model, self.plan, self.scaler
@@ -259,8 +269,18 @@ class DlrmTrainer:
             # (stream order on comm_stream: all-to-all, then the all-reduce; the compute stream needs only the former here)
             self._exchange_wait()
         else:
-            grad_x = m.top_model.backward(dlogits.view(-1, 1), grads=self.top_grads.views[:-1],
-                                          out_grads=self.top_grads.views[-1], found_inf=sc.found_inf if fused_check else None)
+            # one rank: the top model's weight / bias gradients are leaves -- they run on a second stream beside the bottom model's
+            # backward (embedding update on its own stream there), joined before anything reads the flat gradient buffers
+            wside = self._wgrad_stream()
+            grad_x, finish = m.top_model.backward(dlogits.view(-1, 1), grads=self.top_grads.views[:-1],
+                                                  out_grads=self.top_grads.views[-1],
+                                                  found_inf=sc.found_inf if fused_check else None, defer_wgrad=True)
+            if wside is not None:
+                wside.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(wside):
+                    finish()
+            else:
+                finish()
             grad_bottom = grad_x
         if sc.enabled:
             if not fused_check:
@@ -275,6 +295,8 @@ class DlrmTrainer:
                                 freeze_embeddings=self.freeze_embeddings)
         if self.world > 1:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        elif self._wgrad_stream() is not None:
+            torch.cuda.current_stream().wait_stream(self._wgrad_stream())
         if sc.enabled:
             F.check_nonfinite_(self.top_grads.flat, sc.found_inf)
             if self.bot_grads is not None:
