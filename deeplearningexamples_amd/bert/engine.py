@@ -14,6 +14,7 @@ Token-major layout [B*S, H]; the per-(sequence, head) attention contractions are
 slices of the fused QKV activation, scores/probabilities are kept for the backward pass.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -297,14 +298,44 @@ class BertTrainer:
         return loss_mlm + loss_nsp, dlogits, dnsp
 
     # ------------------------------------------------------------------ backward
+    def _leaf_stream(self):
+        """Second stream for the leaves of the backward graph (weight / bias gradients): beside the data-gradient chain they fill
+        the matrix pipes while the chain runs its HBM-bound LayerNorm / attention / dropout kernels.  None: DLE_BERT_WGRAD_STREAM=0
+        or off the GPU."""
+        if self.dev.type != "cuda" or os.environ.get("DLE_BERT_WGRAD_STREAM", "1") == "0":
+            return None
+        if getattr(self, "_wstream", None) is None:
+            self._wstream = torch.cuda.Stream(device=self.dev)
+            self._leaf_keep = []
+            if self.buckets is not None:
+                self.buckets.extra_streams.append(self._wstream)
+        return self._wstream
+
+    def _on_leaf_stream(self, fn, *operands):
+        """Run fn() on the leaf stream after everything enqueued so far; its operands stay alive until the streams join."""
+        ws = self._leaf_stream()
+        if ws is None:
+            fn()
+            return
+        ws.wait_stream(torch.cuda.current_stream())
+        self._leaf_keep.append(operands)
+        with torch.cuda.stream(ws):
+            fn()
+
+    def _join_leaf_stream(self):
+        ws = self._leaf_stream()
+        if ws is not None:
+            torch.cuda.current_stream().wait_stream(ws)
+            self._leaf_keep.clear()
+
     def _wgrad(self, name, g, x, accumulate):
         gw = self.gview[name]
         nout, kin = gw.shape
-        F.gemm(g, x, nout, kin, g.shape[0], False, False, out=gw, splitk=F.pick_splitk(nout, kin, g.shape[0], 1024),
-               accumulate=accumulate)
+        self._on_leaf_stream(lambda: F.gemm(g, x, nout, kin, g.shape[0], False, False, out=gw,
+                                            splitk=F.pick_splitk(nout, kin, g.shape[0], 1024), accumulate=accumulate), g, x)
 
     def _bgrad(self, name, g, accumulate):
-        F.colsum(g, out=self.gview[name], accumulate=accumulate)
+        self._on_leaf_stream(lambda: F.colsum(g, out=self.gview[name], accumulate=accumulate), g)
 
     def backward(self, dlogits, dnsp, accumulate=False):
         cfg, m, sv, dt = self.cfg, self.model, self._sv, self.dtype
@@ -409,10 +440,12 @@ class BertTrainer:
                                (nh * s * s, s * s), (s * h, d), (s * 3 * h, d))                             # dV = dropout(P)^T dO
             gq = self.gview[pre + "attention.self.query.weight"]
             gqkv = torch.as_strided(gq, (3 * h, h), (h, 1))
-            F.gemm(dqkv, a["x"], 3 * h, h, t, False, False, out=gqkv, splitk=F.pick_splitk(3 * h, h, t, 1024), accumulate=acc)
             gbq = self.gview[pre + "attention.self.query.bias"]
-            # fused path: the attention backward left per-sequence column sums [B, 3H]; fold those B rows instead of T
-            F.colsum(cs if sv["fused_attn"] else dqkv, out=torch.as_strided(gbq, (3 * h,), (1,)), accumulate=acc)
+            csrc = cs if sv["fused_attn"] else dqkv
+            # (fused path: the attention backward left per-sequence column sums [B, 3H]; fold those B rows instead of T)
+            self._on_leaf_stream(lambda dqkv=dqkv, ax=a["x"], gqkv=gqkv, csrc=csrc, gbq=gbq: (
+                F.gemm(dqkv, ax, 3 * h, h, t, False, False, out=gqkv, splitk=F.pick_splitk(3 * h, h, t, 1024), accumulate=acc),
+                F.colsum(csrc, out=torch.as_strided(gbq, (3 * h,), (1,)), accumulate=acc)), dqkv, a["x"], csrc)
             dx = F.gemm(dqkv, layer.qkv16, t, h, 3 * h, True, False, act=C.ACT_ADD, mask_src=dz1)
             self._grads_final((pre,))
         # ---- embeddings
@@ -427,6 +460,7 @@ class BertTrainer:
             gpos[s:].zero_()
         F.colsum(dz0.view(b, s * h), out=gpos[:s].view(-1), accumulate=acc)
         F.rows_select_sum(dz0, sv["tt"], cfg["type_vocab"], self.gview["bert.embeddings.token_type_embeddings.weight"], acc)
+        self._join_leaf_stream()                   # every weight / bias gradient has landed
         self._grads_final(("bert.embeddings.",))
         self._last_sv = sv if self.keep_activations else None     # tests read the dropout masks
         self._sv = None
