@@ -453,27 +453,44 @@ class Tacotron2Trainer:
             F.gemm(ga[t], w["a_catT"], b, E + Ha, 4 * Ha, True, True, out=dxa)
         if side is not None:
             main.wait_stream(side)
-        # ---- weight gradients of the decoder: one GEMM each over all steps
-        rt = to * b
-        ga2, gd2 = ga.view(rt, 4 * Ha), gd.view(rt, 4 * Hd)
-        dwa = torch.empty((4 * Ha, E + Ha), dtype=f32, device=self.dev)
-        self._wgrad(ga2, x_a.view(-1, E + Ha), dwa, rt)
-        dwa_pre = torch.empty((4 * Ha, P), dtype=f32, device=self.dev)
-        self._wgrad(ga2, sv["l2d"], dwa_pre, rt)
-        gih = g["decoder.attention_rnn.weight_ih"]
-        gih[:, :P].copy_(dwa_pre)
-        gih[:, P:].copy_(dwa[:, :E])
-        g["decoder.attention_rnn.weight_hh"].copy_(dwa[:, E:])
-        F.colsum(ga2, out=g["decoder.attention_rnn.bias_ih"])
-        g["decoder.attention_rnn.bias_hh"].copy_(g["decoder.attention_rnn.bias_ih"])
-        dwd = torch.empty((4 * Hd, Ha + E + Hd), dtype=f32, device=self.dev)
-        self._wgrad(gd2, x_d.view(-1, Ha + E + Hd), dwd, rt)
-        g["decoder.decoder_rnn.weight_ih"].copy_(dwd[:, :Ha + E])
-        g["decoder.decoder_rnn.weight_hh"].copy_(dwd[:, Ha + E:])
-        F.colsum(gd2, out=g["decoder.decoder_rnn.bias_ih"])
-        g["decoder.decoder_rnn.bias_hh"].copy_(g["decoder.decoder_rnn.bias_ih"])
+        # ---- leaves of the backward graph on the second stream: the decoder's weight gradients (one GEMM each over all To*B rows,
+        # ~8 ms of full-chip work) and the whole prenet backward run beside the memory gradient and the encoder's backward, whose
+        # bi-LSTM sweep is 2 x Ti dependent few-row launches that leave the chip almost empty
+        if side is not None:
+            side.wait_stream(main)
+        with (torch.cuda.stream(side) if side is not None else _null_ctx()):
+            # ---- weight gradients of the decoder: one GEMM each over all steps
+            rt = to * b
+            ga2, gd2 = ga.view(rt, 4 * Ha), gd.view(rt, 4 * Hd)
+            dwa = torch.empty((4 * Ha, E + Ha), dtype=f32, device=self.dev)
+            self._wgrad(ga2, x_a.view(-1, E + Ha), dwa, rt)
+            dwa_pre = torch.empty((4 * Ha, P), dtype=f32, device=self.dev)
+            self._wgrad(ga2, sv["l2d"], dwa_pre, rt)
+            gih = g["decoder.attention_rnn.weight_ih"]
+            gih[:, :P].copy_(dwa_pre)
+            gih[:, P:].copy_(dwa[:, :E])
+            g["decoder.attention_rnn.weight_hh"].copy_(dwa[:, E:])
+            F.colsum(ga2, out=g["decoder.attention_rnn.bias_ih"])
+            g["decoder.attention_rnn.bias_hh"].copy_(g["decoder.attention_rnn.bias_ih"])
+            dwd = torch.empty((4 * Hd, Ha + E + Hd), dtype=f32, device=self.dev)
+            self._wgrad(gd2, x_d.view(-1, Ha + E + Hd), dwd, rt)
+            g["decoder.decoder_rnn.weight_ih"].copy_(dwd[:, :Ha + E])
+            g["decoder.decoder_rnn.weight_hh"].copy_(dwd[:, Ha + E:])
+            F.colsum(gd2, out=g["decoder.decoder_rnn.bias_ih"])
+            g["decoder.decoder_rnn.bias_hh"].copy_(g["decoder.decoder_rnn.bias_ih"])
+            att = "decoder.attention_layer."
+            self._wgrad(dq_all.view(rt, A), x_d.view(-1, Ha + E + Hd)[:, :Ha], g[att + "query_layer.linear_layer.weight"], rt)
+            # ---- prenet
+            r_all = (to + 1) * b
+            d_l2d = self._z(r_all, P)
+            F.gemm(ga2, w["a_pre"], rt, P, 4 * Ha, True, False, out=d_l2d[:rt])
+            d_l2 = F.dropout_bwd(d_l2d, sv["m2"], 0.5)
+            d_pre2 = self._relu_mask(d_l2, sv["l2"])
+            self._wgrad(d_pre2, sv["l1d"], g["decoder.prenet.layers.1.linear_layer.weight"], r_all)
+            d_l1d = F.gemm(d_pre2, w["pre1"], r_all, P, P, True, False)
+            d_pre1 = self._relu_mask(F.dropout_bwd(d_l1d, sv["m1"], 0.5), sv["l1"])
+            self._wgrad(d_pre1, sv["dec_in"].view(r_all, NM), g["decoder.prenet.layers.0.linear_layer.weight"], r_all)
         att = "decoder.attention_layer."
-        self._wgrad(dq_all.view(rt, A), x_d.view(-1, Ha + E + Hd)[:, :Ha], g[att + "query_layer.linear_layer.weight"], rt)
         F.colsum(dv_acc, out=g[att + "v.linear_layer.weight"].view(-1))
         dwl16 = self._cast(dw_loc)
         F.gemm(dwl16, w["loc_c"], A, self.NF, self.KL * 8, True, True, out=g[att + "location_layer.location_dense.linear_layer.weight"])
@@ -489,16 +506,6 @@ class Tacotron2Trainer:
         d_pm16 = self._cast(d_pm)
         self._wgrad(d_pm16, memory, g[att + "memory_layer.linear_layer.weight"], b * ti)
         F.gemm(d_pm16, w["mem"], b * ti, E, A, True, False, out=d_memory, accumulate=True)
-        # ---- prenet
-        r_all = (to + 1) * b
-        d_l2d = self._z(r_all, P)
-        F.gemm(ga2, w["a_pre"], rt, P, 4 * Ha, True, False, out=d_l2d[:rt])
-        d_l2 = F.dropout_bwd(d_l2d, sv["m2"], 0.5)
-        d_pre2 = self._relu_mask(d_l2, sv["l2"])
-        self._wgrad(d_pre2, sv["l1d"], g["decoder.prenet.layers.1.linear_layer.weight"], r_all)
-        d_l1d = F.gemm(d_pre2, w["pre1"], r_all, P, P, True, False)
-        d_pre1 = self._relu_mask(F.dropout_bwd(d_l1d, sv["m1"], 0.5), sv["l1"])
-        self._wgrad(d_pre1, sv["dec_in"].view(r_all, NM), g["decoder.prenet.layers.0.linear_layer.weight"], r_all)
         self._grads_final(("decoder.",))                                # reduced under the encoder's backward pass
         # ---- encoder: bi-LSTM BPTT, convolutions, embedding
         dm3 = d_memory.view(b, ti, E)
@@ -527,6 +534,8 @@ class Tacotron2Trainer:
             dy = self._conv_bn_bwd(dy, sv["enc"][i], b, ti, w["enc%d" % i])
         g["embedding.weight"].zero_()
         F.embed_scatter_add_(g["embedding.weight"], dy, sv["text"])
+        if side is not None:
+            main.wait_stream(side)
         self._grads_final(None)                                        # encoder + embedding: everything that is left
         if self._rng_calls:
             self._rng_base += self._rng_calls          # on the device: the next step (or graph replay) draws new masks
@@ -545,6 +554,8 @@ class Tacotron2Trainer:
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.dev)
+            if getattr(self, "buckets", None) is not None:             # gradients are written on it: the bucket hooks wait for it too
+                self.buckets.extra_streams.append(self._side)
         return self._side
 
     def _relu_mask(self, g, y):
