@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstring>
 #include <vector>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) unsigned short ushort8_t;
 typedef __attribute__((ext_vector_type(4))) unsigned short ushort4_t;
@@ -36,6 +37,9 @@ __device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_c
 
 struct Stage8 { ushort8_t a[8], b[8]; };        // one K tile of one thread: 8 + 8 chunks of 16 bytes (64 VGPRs)
 
+// VAR = 1: no output stores (main loop alone).  The loop body is branch-free (the last two K tiles are peeled), so that the staging
+// writes / loads sit in the same basic block as the MFMAs of k step 3 (first version, one `if` per tile: 908 TFLOP/s at 8192^3).
+template <int VAR>
 __global__ __launch_bounds__(256) void gemm4w_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
                                                      unsigned short* __restrict__ C, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const unsigned short* __res
   lstore(st, 0);                                              // (the compiler waits for the loads here)
   if (nk > 1) gload(st, 1);
   const int fr = lane & 31, fh = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
+  auto body = [&](int kt, auto STORE, auto LOAD) __attribute__((always_inline)) {
     __syncthreads();                                          // stage kt & 1 is complete; stage (kt + 1) & 1 is no longer read
     const unsigned short* ta = lds + (kt & 1) * STAGE_HALVES + (wm * 128 + fr) * BK;
     const unsigned short* tb = lds + (kt & 1) * STAGE_HALVES + TM * BK + (wn * 128 + fr) * BK;
@@ -99,9 +103,9 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const unsigned short* __res
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       if (ks < 3) fread((ks + 1) & 1, ks + 1);
-      if (ks == 3 && kt + 1 < nk) {                           // next tile: registers -> the other stage (its loads have had three
-        lstore(st, (kt + 1) & 1);                             // k steps to land), then the registers take the tile after it
-        if (kt + 2 < nk) gload(st, kt + 2);
+      if (ks == 3) {                                          // next tile: registers -> the other stage (its loads have had three
+        if (decltype(STORE)::value) lstore(st, (kt + 1) & 1); // k steps to land), then the registers take the tile after it
+        if (decltype(LOAD)::value) gload(st, kt + 2);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -111,7 +115,16 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const unsigned short* __res
                                                               __builtin_bit_cast(bf16x8_t, fa[ks & 1][i]), acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);                     // one k step at a time (the unrolled loop would hoist every read)
     }
+  };
+  typedef std::integral_constant<bool, true> Yes;
+  typedef std::integral_constant<bool, false> No;
+  {                                                           // branch-free body: the last two K tiles are peeled
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) body(kt, Yes(), Yes());
+    if (kt + 1 < nk) { body(kt, Yes(), No()); ++kt; }
+    body(kt, No(), No());
   }
+  if ((VAR & 1) && acc[0][0][0] != 12345.678f) return;        // main loop alone: nothing is stored (the test keeps the loop alive)
   // ---- probe epilogue: straight from the accumulator layout (lane: row fr of the block, columns 8 (r >> 2) + 4 fh + (r & 3))
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -147,7 +160,8 @@ static float h_bf2f(unsigned short h) {
 int main() {
   const int shapes[][3] = {{8192, 8192, 8192}, {32768, 4096, 1024}, {32768, 1024, 4096}, {32768, 1024, 1024}, {65536, 1024, 1024},
                            {10240, 1024, 1536}};
-  hipFuncSetAttribute((const void*)gemm4w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_HALVES * 2);
+  hipFuncSetAttribute((const void*)gemm4w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_HALVES * 2);
+  hipFuncSetAttribute((const void*)gemm4w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_HALVES * 2);
   for (auto& sh : shapes) {
     const int M = sh[0], N = sh[1], K = sh[2];
     std::vector<unsigned short> ha((size_t)M * K), hb((size_t)N * K);
@@ -161,17 +175,25 @@ int main() {
     hipMemcpy(db, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
     const dim3 grid((M / TM) * (N / TN)), block(256);
     const size_t ldsb = 2 * STAGE_HALVES * 2;
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm4w_kernel, grid, block, ldsb, 0, da, db, dc, M, N, K);
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    const int iters = 10;
-    hipEventRecord(e0, 0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(gemm4w_kernel, grid, block, ldsb, 0, da, db, dc, M, N, K);
-    hipEventRecord(e1, 0);
-    hipEventSynchronize(e1);
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    ms /= iters;
+    float msv[2];
+    for (int var = 1; var >= 0; --var) {                       // variant 0 last: its output is the one that is checked
+      auto launch = [&]() {
+        if (var == 0) hipLaunchKernelGGL(gemm4w_kernel<0>, grid, block, ldsb, 0, da, db, dc, M, N, K);
+        else hipLaunchKernelGGL(gemm4w_kernel<1>, grid, block, ldsb, 0, da, db, dc, M, N, K);
+      };
+      for (int i = 0; i < 3; ++i) launch();
+      hipEvent_t e0, e1;
+      hipEventCreate(&e0); hipEventCreate(&e1);
+      const int iters = 10;
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < iters; ++i) launch();
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      hipEventElapsedTime(&msv[var], e0, e1);
+      msv[var] /= iters;
+      hipEventDestroy(e0); hipEventDestroy(e1);
+    }
+    const float ms = msv[0];
     std::vector<unsigned short> hc((size_t)M * N);
     hipMemcpy(hc.data(), dc, hc.size() * 2, hipMemcpyDeviceToHost);
     double worst = 0.0;
@@ -183,10 +205,10 @@ int main() {
       const double err = fabs(got - ref) / (fabs(ref) + 1e-2 * sqrt((double)K));
       if (err > worst) worst = err;
     }
-    printf("%6d x %5d x %5d   %8.3f ms   %7.1f TFLOP/s   worst sampled rel. error %.2e %s\n", M, N, K, ms,
-           2.0 * M * N * K / (ms * 1e-3) / 1e12, worst, worst < 2e-2 ? "" : "  <-- WRONG");
+    const double fl = 2.0 * M * N * K / 1e9;
+    printf("%6d x %5d x %5d   %7.1f TFLOP/s  | main loop alone %7.1f |  worst sampled rel. error %.2e %s\n",
+           M, N, K, fl / ms, fl / msv[1], worst, worst < 2e-2 ? "" : "  <-- WRONG");
     hipFree(da); hipFree(db); hipFree(dc);
-    hipEventDestroy(e0); hipEventDestroy(e1);
   }
   return 0;
 }
