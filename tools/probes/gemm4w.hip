@@ -37,7 +37,7 @@ __device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_c
 
 struct Stage8 { ushort8_t a[8], b[8]; };        // one K tile of one thread: 8 + 8 chunks of 16 bytes (64 VGPRs)
 
-// VAR = 1: no output stores (main loop alone).  The loop body is branch-free (the last two K tiles are peeled), so that the staging
+// VAR bit 0: no output stores (main loop alone); VAR >= 2: staging writes / loads spread over k steps 1..3.  The loop body is branch-free (the last two K tiles are peeled), so that the staging
 // writes / loads sit in the same basic block as the MFMAs of k step 3 (first version, one `if` per tile: 908 TFLOP/s at 8192^3).
 template <int VAR>
 __global__ __launch_bounds__(256) void gemm4w_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
@@ -103,9 +103,23 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const unsigned short* __res
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       if (ks < 3) fread((ks + 1) & 1, ks + 1);
-      if (ks == 3) {                                          // next tile: registers -> the other stage (its loads have had three
-        if (decltype(STORE)::value) lstore(st, (kt + 1) & 1); // k steps to land), then the registers take the tile after it
-        if (decltype(LOAD)::value) gload(st, kt + 2);
+      if (VAR < 2) {
+        if (ks == 3) {                                        // next tile: registers -> the other stage (its loads have had three
+          if (decltype(STORE)::value) lstore(st, (kt + 1) & 1); // k steps to land), then the registers take the tile after it
+          if (decltype(LOAD)::value) gload(st, kt + 2);
+        }
+      } else if (ks >= 1) {                                   // VAR >= 2: the same traffic spread over k steps 1..3 (3 + 3 + 2 chunk pairs)
+        const int j0 = ks == 1 ? 0 : ks == 2 ? 3 : 6, j1 = ks == 1 ? 3 : ks == 2 ? 6 : 8;
+        unsigned short* wa = lds + ((kt + 1) & 1) * STAGE_HALVES + loff;
+        unsigned short* wb = wa + TM * BK;
+#pragma unroll
+        for (int j = j0; j < j1; ++j) {
+          if (decltype(STORE)::value) { *(ushort8_t*)(wa + j * 32 * BK) = st.a[j]; *(ushort8_t*)(wb + j * 32 * BK) = st.b[j]; }
+          if (decltype(LOAD)::value) {
+            st.a[j] = *(const ushort8_t*)(baseA + j * rstep + (long long)(kt + 2) * (BK * 2) + voff);
+            st.b[j] = *(const ushort8_t*)(baseB + j * rstep + (long long)(kt + 2) * (BK * 2) + voff);
+          }
+        }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -162,6 +176,8 @@ int main() {
                            {10240, 1024, 1536}};
   hipFuncSetAttribute((const void*)gemm4w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_HALVES * 2);
   hipFuncSetAttribute((const void*)gemm4w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_HALVES * 2);
+  hipFuncSetAttribute((const void*)gemm4w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_HALVES * 2);
+  hipFuncSetAttribute((const void*)gemm4w_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_HALVES * 2);
   for (auto& sh : shapes) {
     const int M = sh[0], N = sh[1], K = sh[2];
     std::vector<unsigned short> ha((size_t)M * K), hb((size_t)N * K);
@@ -175,11 +191,13 @@ int main() {
     hipMemcpy(db, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
     const dim3 grid((M / TM) * (N / TN)), block(256);
     const size_t ldsb = 2 * STAGE_HALVES * 2;
-    float msv[2];
-    for (int var = 1; var >= 0; --var) {                       // variant 0 last: its output is the one that is checked
+    float msv[4];
+    for (int var = 3; var >= 0; --var) {                       // variant 0 last: its output is the one that is checked
       auto launch = [&]() {
         if (var == 0) hipLaunchKernelGGL(gemm4w_kernel<0>, grid, block, ldsb, 0, da, db, dc, M, N, K);
-        else hipLaunchKernelGGL(gemm4w_kernel<1>, grid, block, ldsb, 0, da, db, dc, M, N, K);
+        else if (var == 1) hipLaunchKernelGGL(gemm4w_kernel<1>, grid, block, ldsb, 0, da, db, dc, M, N, K);
+        else if (var == 2) hipLaunchKernelGGL(gemm4w_kernel<2>, grid, block, ldsb, 0, da, db, dc, M, N, K);
+        else hipLaunchKernelGGL(gemm4w_kernel<3>, grid, block, ldsb, 0, da, db, dc, M, N, K);
       };
       for (int i = 0; i < 3; ++i) launch();
       hipEvent_t e0, e1;
@@ -206,8 +224,8 @@ int main() {
       if (err > worst) worst = err;
     }
     const double fl = 2.0 * M * N * K / 1e9;
-    printf("%6d x %5d x %5d   %7.1f TFLOP/s  | main loop alone %7.1f |  worst sampled rel. error %.2e %s\n",
-           M, N, K, fl / ms, fl / msv[1], worst, worst < 2e-2 ? "" : "  <-- WRONG");
+    printf("%6d x %5d x %5d   %7.1f TFLOP/s  | main loop alone %7.1f | staging spread over k steps: %7.1f, alone %7.1f |  worst sampled rel. error %.2e %s\n",
+           M, N, K, fl / ms, fl / msv[1], fl / msv[2], fl / msv[3], worst, worst < 2e-2 ? "" : "  <-- WRONG");
     hipFree(da); hipFree(db); hipFree(dc);
   }
   return 0;
