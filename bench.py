@@ -58,13 +58,21 @@ def init_dist(n):
     if world != n:
         raise SystemExit("bench.py --gpus %d must be launched with WORLD_SIZE=%d (got %d); use "
                          "python -m torch.distributed.run --nproc-per-node %d" % (n, n, world, n))
+    # DLE_BENCH_BACKEND=gloo: the N > 1 path on a box with fewer GPUs than ranks (the one-GPU boxes of the test pool: RCCL refuses
+    # two ranks on one device) -- the ranks share the visible GPUs round-robin and the engines stage their collectives through
+    # host memory (utils/comm.py).  Everything else (self-launch, rendezvous, nested workloads, max-over-ranks timing, the one
+    # JSON line) is the code the driver's 8-GPU run executes.  The default, and what the driver runs, is nccl = RCCL.
+    backend = os.environ.get("DLE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import datetime
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
-                                timeout=datetime.timedelta(seconds=int(os.environ.get("DLE_BENCH_PG_TIMEOUT", "300"))))
+        kw = dict(device_id=torch.device("cuda", local)) if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("DLE_BENCH_PG_TIMEOUT", "300"))), **kw)
     return rank, world, torch.device("cuda", local)
 
 
@@ -455,7 +463,7 @@ class Tacotron2Workload:
 
 WORKLOADS = {"dlrm": DlrmWorkload, "rn50": Rn50Workload, "bert": BertWorkload, "waveglow": WaveGlowWorkload,
              "tacotron2": Tacotron2Workload}
-NESTED_STEPS = {"rn50": (30, 8), "bert": (12, 3), "dlrm": (100, 20), "waveglow": (10, 3), "tacotron2": (4, 2)}   # (timed steps, warm-up)
+NESTED_STEPS = {"rn50": (30, 8), "bert": (20, 3), "dlrm": (100, 20), "waveglow": (20, 3), "tacotron2": (8, 2)}   # (timed steps, warm-up)
 
 REFERENCE_PUBLISHED = {
     "rn50": {"value": 2470, "unit": "img/s", "hardware": "1x A100 80GB, mixed precision, bs 256",
@@ -591,6 +599,13 @@ def roofline_from(timer, steps, wl_name, samples_per_step_per_gpu, ms_per_step):
                   "tflops": round(f["flops"] / (f["ms"] * 1e-3) / 1e12, 1) if f["flops"] else None,
                   "gbs": round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1) if f["bytes"] else None}
                  for f in fams[:nb]]
+    if len(fams) > nb:          # everything below the cut in ONE row, so that the rows add up to the timed kernel total
+        rest = fams[nb:]
+        breakdown.append({"kernel": "(other: %d entry points)" % len(rest), "ms_per_step": round(sum(f["ms"] for f in rest) / steps, 4),
+                          "calls_per_step": round(sum(f["calls"] for f in rest) / steps, 2), "tflops": None, "gbs": None})
+    # sum over every C-ABI launch of the step, each kernel alone on the chip (single-stream pass): what the step would take with
+    # no overlap between streams, no launch gap and no ATen kernel -- next to ms_per_step it shows what the breakdown leaves out
+    r["kernel_sum_ms_per_step"] = round(sum(f["ms"] for f in fams) / steps, 4)
     if os.environ.get("DLE_BENCH_SHAPES"):
         rows.sort(key=lambda a: -a["avg_ms"] * a["calls"])
         breakdown += [{"kernel": a["name"] + ("[" + a["tag"] + "]" if a["tag"] else ""),
@@ -604,6 +619,9 @@ def run_workload(name, args, rank, world, device, steps, warmup):
     """Build the workload, warm up, time exactly `steps` steps (barrier + synchronize on both sides, nothing else
     inside), then the instrumented pass for the roofline.  Returns the record of this workload (rank 0) or None."""
     from deeplearningexamples_amd import _cabi
+    inject = os.environ.get("DLE_BENCH_FAIL_NESTED", "")           # "<workload>:<rank>": tests of the nested-failure path
+    if inject and inject.split(":")[0] == name and int(inject.split(":")[1]) == rank:
+        raise RuntimeError("injected failure of %s on rank %d (DLE_BENCH_FAIL_NESTED)" % (name, rank))
     wl = WORKLOADS[name](args, rank, world, device)
     for _ in range(warmup):
         wl.step()
@@ -640,7 +658,7 @@ def run_workload(name, args, rank, world, device, steps, warmup):
         if world > 1:
             dist.barrier()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(wl.loss.item()) if wl.loss is not None else None
@@ -685,6 +703,8 @@ def compact(name, rec, cpu):
     out = {"value": rec["value"], "unit": UNITS[name], "ms_per_step": round(rec["ms_per_step"], 3), "steps": rec["steps"],
            "dtype": rec["dtype"], "workload": SHORT[name],
            "roofline": {k: r.get(k) for k in ("bound", "frac", "step_frac", "kernel", "ms_per_step", "traffic")} if r else None}
+    if r.get("kernel_sum_ms_per_step") is not None:
+        out["kernel_sum_ms"] = round(r["kernel_sum_ms_per_step"], 2)
     if cpu:
         out["cpu_baseline"] = {k: cpu.get(k) for k in ("value", "cores", "kind", "steps")}
     return out
@@ -746,6 +766,9 @@ def main():
         nested_names = [w for w in ("waveglow", "tacotron2") if w != args.workload] \
             if os.environ.get("DLE_BENCH_WAVEGLOW", "1") != "0" else []
         nested_names += [w for w in ("dlrm", "bert", "rn50") if w != args.workload]
+        if os.environ.get("DLE_BENCH_NESTED"):                     # restrict the nested set (tests): comma-separated names
+            keep = os.environ["DLE_BENCH_NESTED"].split(",")
+            nested_names = [w for w in nested_names if w in keep]
     # ---- CPU leg first (rank 0, N = 1): the oracle on the host cores, bounded samples (>= 3 timed steps each); the GPU legs
     # then run back to back to the end of the process
     cpu = {}
@@ -796,6 +819,8 @@ def main():
     dog = Watchdog(emit, rank) if nested_names else None
     for w in nested_names:
         st, wu = NESTED_STEPS[w]
+        if os.environ.get("DLE_BENCH_NESTED_STEPS"):               # "steps,warmup" for every nested workload (tests)
+            st, wu = (int(x) for x in os.environ["DLE_BENCH_NESTED_STEPS"].split(","))
         if dog:
             dog.arm(float(os.environ.get("DLE_BENCH_NESTED_TIMEOUT", "240")))
         try:

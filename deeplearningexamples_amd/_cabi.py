@@ -217,7 +217,8 @@ class KernelTimer:
         self.last = {}             # (name, tag) -> (fn, args) of the most recent such call, for replay()
 
     # entry points whose duration depends on state they consume (row lists, touched-row sets): never replayed
-    _STATEFUL = ("emb_sgd", "emb_sparse", "emb_link", "emb_grad", "amp_update")
+    # (the optimizer updates are not pure either: a replay would step the weights / moments again)
+    _STATEFUL = ("emb_sgd", "emb_sparse", "emb_link", "emb_grad", "amp_update", "mt_lamb", "mt_sgd", "mt_adam")
 
     def replay(self, name, tag, iters=20, warmup=3, cold=False):
         """Average duration (ms) of the recorded call re-launched back to back: ONE event pair around `iters`

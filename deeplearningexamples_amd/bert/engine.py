@@ -114,7 +114,7 @@ class BertTrainer:
         self.max_norm_t = torch.full((1,), max_grad_norm, dtype=torch.float32, device=dev)
         self.one = torch.ones(1, dtype=torch.float32, device=dev)
         self.noop = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.grad_divisor = 1          # gradient-accumulation micro-steps summed into the flat gradient
+        self._grad_divisor = 1         # gradient-accumulation micro-steps summed into the flat gradient (property below)
         self._batch_key, self._sel, self._idx0, self._mask_add, self._dense_labels = None, None, None, None, None
         self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
         # gradient buckets over the flat buffer, all-reduced (mean) on the side stream while the backward pass is still
@@ -297,6 +297,18 @@ class BertTrainer:
                                         grad_dtype=dt, ld_out=8)
         return loss_mlm + loss_nsp, dlogits, dnsp
 
+    @property
+    def grad_divisor(self):
+        return self._grad_divisor
+
+    @grad_divisor.setter
+    def grad_divisor(self, n):
+        """Accumulation count: joins the loss scale in optimizer_step; with a 16-bit wire format the buckets also pre-divide by it
+        before rounding (the reference's wire copy carries loss / count gradients: same fp16 headroom, same overflow pattern)."""
+        self._grad_divisor = int(n)
+        if getattr(self, "buckets", None) is not None and self.buckets.wire_dtype is not None:
+            self.buckets.wire_divisor = float(n)
+
     # ------------------------------------------------------------------ backward
     def _leaf_stream(self):
         """Second stream for the leaves of the backward graph (weight / bias gradients): beside the data-gradient chain they fill
@@ -449,6 +461,11 @@ class BertTrainer:
             dx = F.gemm(dqkv, layer.qkv16, t, h, 3 * h, True, False, act=C.ACT_ADD, mask_src=dz1)
             self._grads_final((pre,))
         # ---- embeddings
+        # The tied decoder's weight gradient (first launch on the leaf stream, accumulate=False: it OVERWRITES the word-embedding
+        # gradient) must have landed before the scatter-add below adds the lookup gradient into the same buffer: join the leaf
+        # stream here, not after the embedding kernels (nothing ordered the two writers before; under graph capture there was no
+        # edge between the two nodes).
+        self._join_leaf_stream()                   # every weight / bias gradient has landed
         emb = m.bert.embeddings
         if sv["mask0"] is not None:
             dx = F.dropout_bwd(dx, sv["mask0"], self.p_hidden)
@@ -460,7 +477,6 @@ class BertTrainer:
             gpos[s:].zero_()
         F.colsum(dz0.view(b, s * h), out=gpos[:s].view(-1), accumulate=acc)
         F.rows_select_sum(dz0, sv["tt"], cfg["type_vocab"], self.gview["bert.embeddings.token_type_embeddings.weight"], acc)
-        self._join_leaf_stream()                   # every weight / bias gradient has landed
         self._grads_final(("bert.embeddings.",))
         self._last_sv = sv if self.keep_activations else None     # tests read the dropout masks
         self._sv = None

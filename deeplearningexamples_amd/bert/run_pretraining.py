@@ -74,11 +74,34 @@ def parse_arguments(argv=None):
     p.add_argument("--cuda_graphs", action="store_true",
                    help="capture the micro-step and the optimizer step in HIP graphs (run_pretraining.py:310,602-640)")
     args = p.parse_args(argv)
+    args._defaults = {k: p.get_default(k) for k in IGNORED_FLAGS}
     if args.steps_this_run < 0:
         args.steps_this_run = int(args.max_steps)
     if args.train_batch_size % args.gradient_accumulation_steps:
         raise ValueError("train_batch_size must be divisible by gradient_accumulation_steps")
     return args
+
+
+IGNORED_FLAGS = {
+    # flag -> what happens instead (printed once at start-up by rank 0: a flag that parses must not silently do nothing)
+    "input_dir": "the lddl parquet loader (run_pretraining.py:557-570) is an external package that is not part of this path: "
+                 "training runs on SYNTHETIC batches of the same 5-key int64 schema, the shards under this directory are NOT read",
+    "checkpoint_activations": "activations are kept (they fit in 288 GB); no recomputation happens",
+    "amp": "16-bit compute is always on; --fp16 / --bf16 choose the type (default bf16)",
+    "disable_jit_fusions": "there is no TorchScript in this path; the fused kernels are always used",
+    "allreduce_post_accumulation": "gradients are always reduced once per optimizer step, on the last micro-batch",
+    "vocab_file": "no text is tokenised in this path (synthetic batches)",
+    "profile": "use rocprofv3 around the command instead",
+    "no_dense_sequence_output": "the MLM head always runs on the masked rows only (dense sequence output)",
+}
+
+
+def warn_ignored_flags(args, defaults, log=print):
+    """One line per flag that was GIVEN (differs from its default) and has no effect here.  Returns the list of flag names."""
+    hit = [k for k in IGNORED_FLAGS if getattr(args, k, None) != defaults.get(k)]
+    for k in hit:
+        log("WARNING: --%s is accepted for command-line compatibility and IGNORED: %s" % (k, IGNORED_FLAGS[k]))
+    return hit
 
 
 def synthetic_batches(cfg, micro_batch, seq, max_pred, device, seed):
@@ -108,7 +131,9 @@ def main(argv=None):
     if is_main_process():
         dllogger.init([dllogger.JSONStreamBackend(dllogger.Verbosity.VERBOSE, args.json_summary),
                        dllogger.StdOutBackend(dllogger.Verbosity.DEFAULT)])
-        dllogger.log(step="PARAMETER", data={"Config": [str(vars(args))]})
+        dllogger.log(step="PARAMETER", data={"Config": [str({k: v for k, v in vars(args).items() if k != "_defaults"})]})
+        import sys
+        warn_ignored_flags(args, args._defaults, log=lambda m: print(m, file=sys.stderr, flush=True))
     model = BertForPreTraining(cfg, device=device)
     dtype = torch.float16 if args.fp16 else torch.bfloat16
     trainer = BertTrainer(model, lr=args.learning_rate, warmup=args.warmup_proportion, total_steps=int(args.max_steps),

@@ -254,6 +254,9 @@ extern "C" int dle_gemm_expand_try(const void* A, const void* B, void* C, const 
   if (M < 4096 || (K != 64 && K != 128 && K != 256) || (N % EX_TN) != 0 || N < 2 * K || out_dtype != in_dtype) return 0;
   if (((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)src)) & 15) != 0 || (lda & 7) || (ldb & 7) || (ldc & 7)) return 0;
   if (act == 2 && !bits) return 0;
+  // the masked epilogue reads a row's 16 keep bytes with ONE 16-byte load at bits + ((m ldc + n0) >> 3): needs ldc % 128 == 0 and
+  // a 16-byte aligned bit plane (other pitches go to the tile kernel's per-byte form)
+  if (act == 2 && ((ldc % EX_TN) != 0 || (((uintptr_t)bits) & 15) != 0)) return 0;
   if (act && !src) return 0;
   ExpandArgs p = {(const unsigned short*)A, (const unsigned short*)B, (unsigned short*)C, (const unsigned short*)src,
                   (const unsigned char*)bits, stats, M, N, K, (long long)lda, (long long)ldb, (long long)ldc, b_kc, 0, 0, 0};

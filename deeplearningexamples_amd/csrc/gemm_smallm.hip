@@ -335,7 +335,7 @@ extern "C" int dle_t2_lstm_gemm_fwd(const void* x, int64_t ldx, const void* w, i
   DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "t2_lstm_gemm_fwd: 16-bit dtypes only (got %d)", dtype);
   auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
   DLE_CHECK_ARG((H & 7) == 0 && (K & 7) == 0 && (ldx & 7) == 0 && (ldw & 7) == 0 && (ld_g & 7) == 0 && al16(x) && al16(w) &&
-                al16(gates) && al16(c_prev) && al16(c_out) && (!addend || (((uintptr_t)addend) & 7) == 0) &&
+                al16(gates) && al16(c_prev) && al16(c_out) && (!bias || al16(bias)) && (!addend || (((uintptr_t)addend) & 7) == 0) &&
                 (!d0 || (al16(d0) && (ld0 & 7) == 0)) && (!d1 || (al16(d1) && (ld1 & 7) == 0)) && (!d2 || (al16(d2) && (ld2 & 7) == 0)),
                 "t2_lstm_gemm_fwd: H, K and every row pitch must be multiples of 8 with 16-byte aligned bases");
   DLE_CHECK_ARG((long long)B * ldx * 2 < 0xFFFFFFE0LL && (long long)4 * H * ldw * 2 < 0xFFFFFFE0LL, "t2_lstm_gemm_fwd: operand above 4 GiB");

@@ -47,6 +47,7 @@ class TensorTable:
         ptrs = np.asarray([[t.data_ptr() for t in lst] for lst in lists], dtype=np.int64).reshape(-1)
         host = np.concatenate([sizes, start, ptrs]).astype(np.int64)
         self.total_chunks = int(start[-1])
+        self.total_elems = int(sizes.sum())
         self.key = host.tobytes()
         self.table = torch.from_numpy(host).to(dev)
         self.dtypes = [lst[0].dtype if n else torch.float32 for lst in lists]
@@ -56,6 +57,12 @@ class TensorTable:
     @staticmethod
     def key_of(lists, chunk=CHUNK):
         return (chunk,) + tuple(t.data_ptr() for lst in lists for t in lst) + tuple(t.numel() for t in lists[0])
+
+
+def _note(table, bytes_per_elem):
+    """Algorithmic bytes + a per-table tag for bench.py's kernel timer: launches over different tables (the decay / no-decay
+    groups, the whole-model norm) are different shapes of one entry point and must not share a replay record."""
+    C.annotate(bytes=float(table.total_elems) * bytes_per_elem, tag="%dt,%de" % (table.n, table.total_elems))
 
 
 class TableCache:
@@ -80,6 +87,7 @@ def l2norm(table, noop_flag=None, per_tensor=False):
     ret = torch.empty(1, dtype=torch.float32, device=dev)
     per = torch.empty(table.n if per_tensor else 0, dtype=torch.float32, device=dev)
     scratch = torch.empty(max(table.total_chunks, 1), dtype=torch.float32, device=dev)
+    _note(table, table._keep[0][0].element_size() if table.n else 4)
     C.call("dle_mt_l2norm", C.ptr(table.table), table.n, table.total_chunks, table.chunk, C.dt(table.dtypes[0]),
            C.ptr(scratch), C.ptr(ret), C.ptr(per) if per_tensor else 0, int(per_tensor), C.ptr(noop_flag),
            C.stream())
@@ -88,6 +96,7 @@ def l2norm(table, noop_flag=None, per_tensor=False):
 
 def lamb_stage1(table, noop_flag, beta1, beta2, beta3, step, bias_correction, eps, mode, weight_decay,
                 global_grad_norm, max_grad_norm, inv_scale):
+    _note(table, 7 * 4)                 # reads g, p, m, v; writes the update (over g), m, v
     C.call("dle_mt_lamb_stage1", C.ptr(table.table), table.n, table.total_chunks, table.chunk,
            C.dt(table.dtypes[0]), C.ptr(noop_flag), beta1, beta2, beta3, C.ptr(step), int(bias_correction),
            eps, int(mode), weight_decay, C.ptr(global_grad_norm), C.ptr(max_grad_norm), C.ptr(inv_scale),
@@ -95,6 +104,7 @@ def lamb_stage1(table, noop_flag, beta1, beta2, beta3, step, bias_correction, ep
 
 
 def lamb_stage2(table, noop_flag, param_norm, update_norm, lr, weight_decay, use_nvlamb):
+    _note(table, 3 * 4 + (2 if table.n_lists == 3 else 0))      # reads the update and p, writes p (+ the 16-bit model copy)
     C.call("dle_mt_lamb_stage2", C.ptr(table.table), table.n, table.total_chunks, table.chunk,
            C.dt(table.dtypes[0]), C.dt(table.dtypes[2]) if table.n_lists == 3 else -1, C.ptr(noop_flag), C.ptr(param_norm),
            C.ptr(update_norm), C.ptr(lr), weight_decay, int(bool(use_nvlamb)), C.stream())
@@ -107,6 +117,7 @@ def sgd(table, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False
     if has_momentum is None:
         has_momentum = (table.n_lists - int(model_copy)) >= 3
     copy_dt = C.dt(table.dtypes[-1]) if model_copy else -1
+    _note(table, 4 * (3 + 2 * int(bool(has_momentum))) + (2 if model_copy else 0))
     C.call("dle_mt_sgd", C.ptr(table.table), table.n, table.total_chunks, table.chunk, C.dt(table.dtypes[0]),
            int(has_momentum), C.ptr(skip_flag), C.ptr(lr_dev), 0.0 if lr_dev is not None else float(lr),
            momentum, dampening, weight_decay, int(nesterov), int(first_step), C.ptr(inv_scale), copy_dt,
@@ -120,6 +131,7 @@ def adam(table, lr, beta1, beta2, eps, weight_decay, step, skip_flag=None, inv_s
     if table.n_lists != 4 or any(d != torch.float32 for d in table.dtypes):
         raise ValueError("adam expects four fp32 lists: g, p, exp_avg, exp_avg_sq")
     lr_dev = lr if isinstance(lr, torch.Tensor) else None
+    _note(table, 7 * 4)
     C.call("dle_mt_adam", C.ptr(table.table), table.n, table.total_chunks, table.chunk, C.ptr(skip_flag), C.ptr(lr_dev),
            0.0 if lr_dev is not None else float(lr), beta1, beta2, eps, weight_decay, C.ptr(step), C.ptr(inv_scale),
            C.ptr(grad_norm), float(max_grad_norm if grad_norm is not None else 0.0), C.stream())

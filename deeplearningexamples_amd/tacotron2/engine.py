@@ -594,6 +594,11 @@ class Tacotron2Trainer:
         finally:
             self.training = True
             self.sv = None
+            if self._rng_calls:
+                # the prenet's dropout drew masks at counters base + 1 .. base + calls: move the base on, so that the next
+                # validation batch and the next training step draw fresh ones (F.dropout(training=True) in the reference)
+                self._rng_base += self._rng_calls
+                self._rng_calls = 0
         return loss
 
     def train_step(self, text, text_lengths, mel, gate_target, output_lengths=None):

@@ -27,8 +27,7 @@ def parse_args(argv=None):
     m.add_argument("--gate-threshold", default=0.5, type=float, help="inference only: kept in the checkpoint's config")
     m.add_argument("--decoder-no-early-stopping", action="store_true", help="inference only: kept in the checkpoint's config")
     p.set_defaults(iters_per_epoch=50)
-    args, _ = p.parse_known_args(argv)
-    return args
+    return p.parse_args(argv)          # (parse_known_args swallowed typos: an unknown flag is an error, as in the reference)
 
 
 def get_model_config(args):

@@ -45,6 +45,8 @@ class GradBuckets:
         self.flat, self.group, self.stream = flat, group, comm_stream
         self.wire_dtype = wire_dtype
         self._wire = None
+        self.wire_divisor = 1.0     # extra pre-division of the 16-bit wire copy (gradient-accumulation count: the reference's
+                                    # micro-step losses are already divided by it, run_pretraining.py:521), undone after widening
         self.extra_streams = []
         if reverse:
             total = sum(n for _, n in named_numels)
@@ -82,10 +84,12 @@ class GradBuckets:
             n = max(b[1] - b[0] for b in self.buckets)                                    # on the communication stream)
             self._wire = torch.empty(n, dtype=self.wire_dtype, device=self.flat.device)
         w = self._wire[:e - s]
-        torch.div(self.flat[s:e], float(dist.get_world_size(self.group)), out=self.flat[s:e])
+        torch.div(self.flat[s:e], float(dist.get_world_size(self.group)) * float(self.wire_divisor), out=self.flat[s:e])
         w.copy_(self.flat[s:e])
         allreduce_sum_(w, self.group)
         self.flat[s:e].copy_(w)
+        if self.wire_divisor != 1.0:    # the optimizer's scale bookkeeping expects the undivided sum of the micro-steps
+            self.flat[s:e].mul_(float(self.wire_divisor))
 
     def wait(self):
         """Make the compute stream wait for every bucket; all of them must have been launched by now."""

@@ -114,8 +114,7 @@ def parse_args(argv=None):
     w.add_argument("--wn-kernel-size", default=3, type=int)
     w.add_argument("--wn-channels", default=512, type=int)
     w.add_argument("--wn-layers", default=8, type=int)
-    args, _ = p.parse_known_args(argv)
-    return args
+    return p.parse_args(argv)          # (parse_known_args swallowed typos: an unknown flag is an error, as in the reference)
 
 
 def get_model_config(args):

@@ -192,3 +192,28 @@ BERT_STEP_CONFIG = dict(cfg=BERT_TINY, seed=21, batch=4, steps=5, lr=6e-3, warmu
 BERT_LARGE_1L = dict(hidden=1024, heads=16, layers=1, intermediate=4096, vocab=30528, real_vocab=30522, max_pos=512,
                      type_vocab=2, seq=128)
 BERT_STEP_CONFIG_LARGE = dict(cfg=BERT_LARGE_1L, seed=33, batch=4, steps=2, lr=6e-3, warmup=0.2843, total_steps=20)
+
+# The full 24-layer BERT-Large of BASELINE.json configs[2] (the model bench.py times), batch 4, S = 128, 20 masked positions per
+# sequence, 2 LAMB steps: ~40 s per forward + backward on the CPU reference.  Fixture: tests/golden/bert_step_large24.npz.
+BERT_LARGE_24L = dict(BERT_LARGE_1L, layers=24)
+BERT_STEP_CONFIG_LARGE24 = dict(cfg=BERT_LARGE_24L, seed=44, batch=4, steps=2, lr=6e-3, warmup=0.2843, total_steps=20)
+
+
+def large24_probe_names(cfg=None):
+    """The parameters whose first-step gradients the 24-layer fixture keeps: embeddings, encoder layers 0 / 12 / 23 (all 16
+    tensors each), pooler and the heads."""
+    cfg = cfg or BERT_LARGE_24L
+    keep = []
+    for name, _ in param_shapes(cfg):
+        if name.startswith("bert.encoder.layer."):
+            if int(name.split(".")[3]) in (0, cfg["layers"] // 2, cfg["layers"] - 1):
+                keep.append(name)
+        else:
+            keep.append(name)
+    return keep
+
+
+def grad_sample_index(n, cap=4096):
+    """Strided sample of a flattened gradient (<= cap elements): what the fixture stores of each probed tensor."""
+    step = max(1, n // cap)
+    return np.arange(0, n, step)[:cap]

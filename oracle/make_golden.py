@@ -268,6 +268,83 @@ def gen_bert_large():
     gen_bert(cfg_name="BERT_STEP_CONFIG_LARGE", out_name="bert_step_large1l.npz", last_layer=0)
 
 
+def gen_bert_large24():
+    """The 24-layer BERT-Large bench.py times (BASELINE configs[2]) through the reference's BertForPreTraining + criterion
+    (run_pretraining.py:75-95,518-536, modeling.py:788-958), batch 4 x S 128, 20 masked positions, dropout 0, 2 LAMB steps:
+    per-step losses, strided samples + norms of the first-step gradients of the embeddings / layers 0, 12, 23 / heads, and the
+    16-bit STORAGE floors (loss and per-tensor gradient error of the storage-emulating oracle) next to them."""
+    from oracle import bert_oracle as BO
+    ref = R.import_bert()
+    c = BO.BERT_STEP_CONFIG_LARGE24
+    cfg = c["cfg"]
+    conf = ref.modeling.BertConfig(cfg["vocab"], hidden_size=cfg["hidden"], num_hidden_layers=cfg["layers"],
+                                   num_attention_heads=cfg["heads"], intermediate_size=cfg["intermediate"],
+                                   hidden_act="gelu", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                                   max_position_embeddings=cfg["max_pos"], type_vocab_size=cfg["type_vocab"])
+    conf.output_all_encoded_layers = False
+    model = ref.modeling.BertForPreTraining(conf, sequence_output_is_dense=True)
+    state0 = BO.seeded_state(cfg, c["seed"])
+    assert sorted(n for n, _ in model.named_parameters()) == sorted(state0)
+    model.train()
+    ids, tt, mask, labels, nsp = BO.seeded_batch(cfg, c["seed"] + 1, c["batch"])
+    assert int((labels != -1).sum()) == 20 * c["batch"]
+    orc = BO.BertOracle(cfg, state0, c["lr"], c["warmup"], c["total_steps"])
+    loss_fn = torch.nn.CrossEntropyLoss(ignore_index=-1)
+    probes = BO.large24_probe_names(cfg)
+    out, losses = {}, []
+    for step in range(c["steps"]):
+        model.load_state_dict({k: v.detach().clone() for k, v in orc.p.items()}, strict=False)
+        model.zero_grad()
+        scores, nsp_scores = model(ids, tt, mask, labels)
+        flat = labels.view(-1)
+        loss = loss_fn(scores.view(-1, cfg["vocab"]), flat[flat != -1]) + loss_fn(nsp_scores.view(-1, 2), nsp.view(-1))
+        loss.backward()
+        losses.append(float(loss.detach()))
+        grads = {k: v.grad.detach().clone() for k, v in model.named_parameters()}
+        if step == 0:
+            # the restatement's forward / backward == the reference module's, on the model the bench times
+            for v in orc.p.values():
+                v.grad = None
+            lo = orc.loss(ids, tt, mask, labels, nsp)
+            lo.backward()
+            assert abs(float(lo.detach()) - losses[0]) <= 1e-5 * losses[0], (float(lo), losses[0])
+            for k in probes:
+                assert torch.allclose(grads[k], orc.p[k].grad, rtol=2e-3, atol=2e-6), k
+            for i, k in enumerate(probes):
+                g = grads[k].reshape(-1).double().numpy()
+                out["g%03d" % i] = g[BO.grad_sample_index(g.size)].astype(np.float32)
+                out["gn%03d" % i] = np.float64(np.linalg.norm(g))
+            ref_g = {k: grads[k].reshape(-1).double() for k in probes}
+        orc.lamb_update({k: v.numpy() for k, v in grads.items()})
+        print("large24 step", step, "loss", losses[-1], flush=True)
+    out["losses"] = np.asarray(losses, np.float64)
+    out["final_pooler_bias"] = orc.p["bert.pooler.dense_act.bias"].detach().numpy()
+    out["final_query_row"] = orc.p["bert.encoder.layer.0.attention.self.query.weight"].detach().numpy()[:4]
+    del model, grads
+    for nm, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        so = BO.BertOracle(cfg, state0, c["lr"], c["warmup"], c["total_steps"], storage_dtype=dt)
+        ls, fl = [], []
+        for step in range(c["steps"]):
+            for v in so.p.values():
+                v.grad = None
+            lo = so.loss(ids, tt, mask, labels, nsp)
+            lo.backward()
+            ls.append(float(lo.detach()))
+            if step == 0:
+                for k in probes:
+                    r = ref_g[k]
+                    g = so.p[k].grad.reshape(-1).double()
+                    idx = torch.from_numpy(BO.grad_sample_index(r.numel()))
+                    fl.append(float((g[idx] - r[idx]).norm() / (r[idx].norm() + 1e-30)))
+            so.lamb_update({k: v.grad.numpy() for k, v in so.p.items()})
+        out["losses_%s_storage" % nm] = np.asarray(ls, np.float64)
+        out["grad_floor_%s" % nm] = np.asarray(fl, np.float64)
+        print("large24 storage", nm, ls, "worst gradient floor", max(fl), flush=True)
+        del so
+    np.savez_compressed(os.path.join(GOLD, "bert_step_large24.npz"), **out)
+    print("bert_step_large24.npz losses", losses)
+
+
 def gen_bert(cfg_name="BERT_STEP_CONFIG", out_name="bert_step.npz", last_layer=1):
     """Per-step losses of the REFERENCE's BertForPreTraining (eager CPU, dropout 0) + the oracle's LAMB."""
     from oracle import bert_oracle as BO

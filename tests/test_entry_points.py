@@ -335,3 +335,21 @@ def test_bert_lr_schedule_matches_reference_scheduler():
             sch.step()                    # run_pretraining.py:529 steps the scheduler BEFORE the optimizer
             got.append(float(opt.param_groups[0]["lr"]))
         assert max(abs(a - b) for a, b in zip(got, ours[:11])) < 1e-9
+
+
+def test_flags_without_effect_are_reported_and_typos_are_errors():
+    """A flag that parses must not silently do nothing (run_pretraining.py:557-570 --input_dir feeds the lddl loader in the reference;
+    here the batches are synthetic and the run says so), and an unknown flag is an error in every entry point."""
+    from deeplearningexamples_amd.bert import run_pretraining as bp
+    from deeplearningexamples_amd.tacotron2 import train as t2
+    from deeplearningexamples_amd.waveglow import train as wg
+    a = bp.parse_arguments(["--input_dir", "/data/lddl", "--checkpoint_activations", "--amp", "--bf16"])
+    lines = []
+    hit = bp.warn_ignored_flags(a, a._defaults, log=lines.append)
+    assert sorted(hit) == ["amp", "checkpoint_activations", "input_dir"] and len(lines) == 3
+    assert any("--input_dir" in l and "SYNTHETIC" in l for l in lines)
+    b = bp.parse_arguments(["--bf16"])
+    assert bp.warn_ignored_flags(b, b._defaults, log=lines.append) == []
+    for mod in (t2, wg):
+        with pytest.raises(SystemExit):
+            mod.parse_args(["-o", "x", "-lr", "1", "--epochs", "1", "-bs", "1", "--no-such-flag"])

@@ -1,0 +1,59 @@
+"""`bench.py --gpus 2` executed for real before the driver's 8-GPU node does it: the self-launch through torch.distributed.run
+(127.0.0.1 rendezvous), process-group init, the headline + the four nested workloads at world size 2, max-over-ranks timing, ONE
+JSON line on rank 0 -- and the clean exit when a nested workload fails on one rank while the other sits in its collectives.
+
+With >= 2 GPUs the ranks use RCCL (backend nccl, what the driver runs).  On the ONE-GPU boxes of this pool RCCL refuses two ranks
+on one device: DLE_BENCH_BACKEND=gloo makes the ranks share cuda:0 and stage their collectives through host memory
+(utils/comm.py); every other line of bench.py is the code of the N = 2/4/8 runs (ConvNets/multiproc.py,
+BERT/run_pretraining.py:323-375 are the reference's launch paths this mirrors)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra_env, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", DLE_BENCH_NESTED_STEPS="2,1")
+    if torch.cuda.device_count() < 2:
+        env["DLE_BENCH_BACKEND"] = "gloo"
+    env.update(extra_env)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, lines
+
+
+def test_bench_two_ranks_prints_one_line_with_five_records():
+    r, lines = _bench({})
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-6000:])
+    assert len(lines) == 1, (lines, r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]      # whole-job rate over both ranks
+    assert "cpu_baseline" not in d                                                     # rank 0 at N = 1 only
+    w = d["workloads"]
+    assert list(w) == ["waveglow", "tacotron2", "dlrm", "bert", "rn50"]
+    for name, rec in w.items():
+        assert "error" not in rec, (name, rec, r.stderr[-3000:])
+        assert rec["value"] > 0 and rec["ms_per_step"] > 0 and rec["roofline"]["frac"] > 0, (name, rec)
+    assert list(d)[-1] == "workloads"
+
+
+def test_bench_two_ranks_survives_a_nested_failure_on_one_rank():
+    # rank 1 fails before building DLRM; rank 0 enters DLRM's parameter broadcast alone: the watchdog (or the process-group
+    # timeout) ends the nested phase, the headline line is still printed ONCE and every process leaves with exit code 0
+    r, lines = _bench({"DLE_BENCH_NESTED": "dlrm,bert", "DLE_BENCH_FAIL_NESTED": "dlrm:1", "DLE_BENCH_NESTED_TIMEOUT": "25",
+                       "DLE_BENCH_PG_TIMEOUT": "60"}, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-6000:])
+    assert len(lines) == 1, (lines, r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["workloads"]["rn50"]["value"] > 0
+    assert "error" in d["workloads"]["dlrm"] and "error" in d["workloads"]["bert"]     # neither nested record was produced
+    assert d.get("note") == "nested phase timed out" or "injected" in r.stderr or "failed" in r.stderr

@@ -254,3 +254,56 @@ def test_dropout_add_layernorm_bwd_equals_the_three_passes(cuda, dtype):
     assert torch.allclose(bias1, bias2, rtol=1e-5, atol=1e-3)
     F.dropout_add_layernorm_bwd(dy, z, mean, rstd, gamma, mask, p, dg2, db2, dbias=bias2, accumulate=True)
     assert torch.allclose(bias2, 2 * bias1, rtol=1e-5, atol=2e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_bert_large_24_layers_vs_reference(cuda, golden_dir, dtype):
+    """The model bench.py times -- 24-layer BERT-Large, S = 128, 20 masked positions per sequence (BASELINE.json configs[2]) --
+    against the reference's own BertForPreTraining + criterion run on CPU at batch 4 (tests/golden/bert_step_large24.npz,
+    oracle/make_golden.py gen_bert_large24; run_pretraining.py:518-536, modeling.py:788-958): the losses of 2 LAMB steps within
+    1e-3 + the measured 16-bit storage floor, and the first-step gradients of the embeddings, encoder layers 0 / 12 / 23 and the
+    heads (strided samples of every probed tensor) within 1.5 x the storage floor the oracle measured for the same tensor
+    (+ 0.5 % / 1 % absolute: the floor is one realisation of the rounding noise, not a bound)."""
+    c = BO.BERT_STEP_CONFIG_LARGE24
+    gold = np.load(os.path.join(golden_dir, "bert_step_large24.npz"))
+    tag = "fp16" if dtype == torch.float16 else "bf16"
+    state = BO.seeded_state(c["cfg"], c["seed"])
+    model, tr = _build(cuda, dtype, c, state)
+    del state
+    batch = [t.to(cuda) for t in BO.seeded_batch(c["cfg"], c["seed"] + 1, c["batch"])]
+    # ---- step 1 split into its parts: forward + backward (gradients), then the optimizer
+    loss, dlog, dnsp = tr.forward(*batch)
+    tr._reduce_now = True
+    tr.backward(dlog, dnsp)
+    torch.cuda.synchronize()
+    scale = float(tr.scaler.scale.item()) if tr.scaler.enabled else 1.0
+    floors = gold["grad_floor_" + tag]
+    slack = 0.005 if dtype == torch.float16 else 0.01
+    bad, report = [], []
+    for i, n in enumerate(BO.large24_probe_names(c["cfg"])):
+        ref, ref_norm = gold["g%03d" % i].astype(np.float64), float(gold["gn%03d" % i])
+        g = tr.gview[n].reshape(-1)
+        idx = torch.from_numpy(BO.grad_sample_index(g.numel())).to(cuda)
+        got = g[idx].double().cpu().numpy() / scale
+        if ref_norm < 1e-6:
+            # key biases: softmax is invariant to a per-row constant, the exact gradient is 0 and the reference's is rounding noise
+            qn = float(gold["gn%03d" % (i - 2)])                       # the query bias of the same layer
+            assert float(tr.gview[n].double().norm()) / scale < 2e-2 * qn + 1e-6, n
+            continue
+        rel = float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30))
+        nrm = float(tr.gview[n].double().norm()) / scale
+        report.append((n.replace("bert.encoder.layer.", "L"), round(rel, 4), round(float(floors[i]), 4)))
+        if rel > 1.5 * floors[i] + slack or abs(nrm - ref_norm) > (1.5 * floors[i] + slack) * ref_norm:
+            bad.append(report[-1] + (nrm, ref_norm))
+    print(tag, "gradient error / storage floor (every 6th):", report[::6])
+    assert not bad, bad[:12]
+    tr.optimizer_step()
+    losses = [float(loss.item()), float(tr.train_step(*batch).item())]
+    ref = gold["losses"]
+    rel = np.abs(np.asarray(losses) - ref) / ref
+    floor = np.abs(gold["losses_%s_storage" % tag] - ref) / ref
+    print(tag, "24-layer losses", losses, "reference", ref.tolist(), "rel err", rel.tolist(), "storage floor", floor.tolist())
+    assert np.all(rel <= 1e-3 + floor), (rel, floor)
+    named = dict(model.named_parameters())
+    r = gold["final_pooler_bias"]
+    assert np.abs(named["bert.pooler.dense_act.bias"].detach().cpu().numpy() - r).max() <= 0.05 * np.abs(r).max() + 1e-4
