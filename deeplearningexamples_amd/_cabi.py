@@ -58,6 +58,11 @@ _SIGS = {
     "dle_conv2d_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "dle_conv2d_wgrad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_i64, c_void_p]),
     "dle_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p]),
+    "dle_stem_conv7_groups": (c_int, [c_int, c_int]),
+    "dle_stem_conv7_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p]),
+    "dle_stem_conv7_wgrad_workspace": (c_i64, [c_int, c_int]),
+    "dle_stem_conv7_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dle_stem_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "dle_bn_workspace_bytes": (c_i64, [c_i64, c_int]),
     "dle_bn_fwd_stats": (c_int, [c_void_p, c_i64, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_i64, c_int, c_void_p]),

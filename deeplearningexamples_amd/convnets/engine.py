@@ -135,6 +135,11 @@ class ResNetTrainer:
         self._branch_keep = []
         if self.buckets is not None:
             self.buckets.extra_streams += [st for st in (self.wgrad_stream, self.branch_stream) if st is not None]
+        # the stem's own kernels (csrc/stem.hip) on a 4-channel image, for inputs up to 224 pixels wide; DLE_RN50_STEM4=0 keeps
+        # the generic implicit-GEMM path (8-channel image) -- which wider inputs take in any case
+        self.stem4 = os.environ.get("DLE_RN50_STEM4", "1") != "0"
+        self.stem.w2 = torch.zeros((64, 7, 8, 4), dtype=compute_dtype, device=self.dev)
+        self.stem.gw_flat = self.gview["conv1.weight"]
         self.fc_w16 = torch.empty(model.fc.weight.shape, dtype=compute_dtype, device=self.dev)
         self.w16["fc.weight"] = self.fc_w16
         self.refresh_working_copies()
@@ -155,6 +160,19 @@ class ResNetTrainer:
             F.cast_rows(self._phys(w).view(ko * r * s, ci), self.dtype, cols_out=u.w16.shape[-1],
                         out=u.w16.view(ko * r * s, -1))
         F.cast(self.model.fc.weight.data, self.dtype, out=self.fc_w16)
+        F.stem_pack_weight(self.model.conv1.weight.data, self.dtype, out=self.stem.w2)
+
+    def _stem_image(self, images):
+        """Input batch -> the 16-bit NHWC image the stem reads: 4 channels (8 bytes per pixel) for its own kernels, 8 for the
+        generic convolution path (DLE_RN50_STEM4=0, or images wider than 224 pixels)."""
+        cp = 4 if (self.stem4 and images.shape[-1] <= 224) else 8
+        if images.dtype == torch.uint8:
+            # decoded images straight from the loader: normalisation fused with the layout change (dataloaders.py:354-384)
+            if getattr(self, "_mean_std", None) is None:
+                from .dataloaders import IMAGENET_MEAN, IMAGENET_STD
+                self._mean_std = (torch.tensor(IMAGENET_MEAN, device=self.dev) * 255.0, torch.tensor(IMAGENET_STD, device=self.dev) * 255.0)
+            return F.u8_nchw_normalize_nhwc(images, self._mean_std[0], self._mean_std[1], self.dtype, cp)
+        return F.nchw_to_nhwc(images, self.dtype, cp)
 
     def _build_tables(self):
         named = dict(zip(self.names, self.params))
@@ -202,14 +220,7 @@ class ResNetTrainer:
     def infer(self, images):
         """Evaluation-mode forward (Executor.forward under model.eval(), training.py:98-105): running BatchNorm statistics,
         no state kept.  -> fp32 logits [N, classes]."""
-        images = self._input(images)
-        if images.dtype == torch.uint8:
-            if getattr(self, "_mean_std", None) is None:
-                from .dataloaders import IMAGENET_MEAN, IMAGENET_STD
-                self._mean_std = (torch.tensor(IMAGENET_MEAN, device=self.dev) * 255.0, torch.tensor(IMAGENET_STD, device=self.dev) * 255.0)
-            x = F.u8_nchw_normalize_nhwc(images, self._mean_std[0], self._mean_std[1], self.dtype, 8)
-        else:
-            x = F.nchw_to_nhwc(images, self.dtype, 8)
+        x = self._stem_image(self._input(images))
         h, _ = F.maxpool_fwd(self.stem.forward_eval(x))
         for (u1, u2, u3, ud) in self.blocks:
             res = ud.forward_eval(h) if ud is not None else h
@@ -226,15 +237,7 @@ class ResNetTrainer:
 
     def forward(self, images):
         """images fp32 NCHW (as produced by the reference's loaders) -> fp32 logits [N, classes]."""
-        images = self._input(images)
-        if images.dtype == torch.uint8:
-            # decoded images straight from the loader: normalisation fused with the layout change (dataloaders.py:354-384)
-            if getattr(self, "_mean_std", None) is None:
-                from .dataloaders import IMAGENET_MEAN, IMAGENET_STD
-                self._mean_std = (torch.tensor(IMAGENET_MEAN, device=self.dev) * 255.0, torch.tensor(IMAGENET_STD, device=self.dev) * 255.0)
-            x = F.u8_nchw_normalize_nhwc(images, self._mean_std[0], self._mean_std[1], self.dtype, 8)
-        else:
-            x = F.nchw_to_nhwc(images, self.dtype, 8)
+        x = self._stem_image(self._input(images))
         a0 = self.stem.forward(x)
         m0, self._amax = F.maxpool_fwd(a0)
         self._pool_in_hw = a0.shape[1:3]
@@ -300,11 +303,13 @@ class ResNetTrainer:
         self.stem.backward(g, need_dx=False)
         gw = self.stem.gw
         ko, r, s, cp = gw.shape
+        stem_generic = self.stem.saved_c != 4        # (set by the stem's backward: which image layout this step ran on)
         if self.wgrad_stream is not None:            # every weight gradient has landed before anything reads the flat buffer
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
             self._wgrad_keepalive.clear()
         self._branch_keep.clear()
-        F.copy_rows(gw.view(ko * r * s, cp)[:, :3], self.gview["conv1.weight"].view(ko * r * s, 3))
+        if stem_generic:                             # gradient of the channel-padded weight, cropped into the flat buffer
+            F.copy_rows(gw.view(ko * r * s, cp)[:, :3], self.gview["conv1.weight"].view(ko * r * s, 3))
         self._done(self.stem)
 
     def _done(self, u):
@@ -320,10 +325,12 @@ class ResNetTrainer:
         mt.sgd(self.t_decay_copy, self.lr, weight_decay=self.wd, model_copy=True, **kw)
         mt.sgd(self.t_decay_plain, self.lr, weight_decay=self.wd, **kw)
         mt.sgd(self.t_nodecay, self.lr, weight_decay=0.0, **kw)
-        # channel-padded stem weight: refresh its working copy from the master
+        # stem weight: refresh its working copies from the master (packed 4-channel form for the stem kernels; the channel-padded
+        # 8-channel form only when the generic path is in use)
         u = self.stem
         w = self.model.conv1.weight
-        ko, ci, r, s = w.shape
+        F.stem_pack_weight(w.data, self.dtype, out=u.w2)
+        ko, ci, r, s = w.shape                       # (the 8-channel copy serves inputs wider than 224 pixels / DLE_RN50_STEM4=0)
         F.cast_rows(self._phys(w).view(ko * r * s, ci), self.dtype, cols_out=u.w16.shape[-1], out=u.w16.view(ko * r * s, -1))
         self.first_step = False
 

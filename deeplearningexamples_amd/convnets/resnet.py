@@ -46,14 +46,21 @@ class ConvBN:
         self.w16 = None                 # [Ko, R, S, Cp] 16-bit working copy (Cp = cin padded to 8)
         self.gw = self.ggamma = self.gbeta = None   # fp32 gradient views (set by the trainer)
         self.saved = None
+        # the stem (7x7 / 2 on a 3-channel image) has its own kernels on a 4-channel image (csrc/stem.hip); the trainer sets
+        # w2 (packed [64, 7, 8, 4] weights) and gw_flat (the flat fp32 gradient view in the master's KRSC order)
+        self.w2 = self.gw_flat = None
         self.wgrad_stream = None                    # set by the trainer: weight gradients run beside the data-gradient chain
         self.keepalive = None                       # ... with the list that keeps their operands alive until the streams join
 
     def forward(self, x, residual=None):
         # conv + batch statistics in one pass over the activation (the statistics come out of the convolution
         # epilogue), then normalise + residual + ReLU; the backward pass rebuilds the ReLU mask from 1 bit per element
-        t, mean, rstd = F.conv2d_fwd_bnstats(x, self.w16, self.stride, self.pad, self.bn.running_mean,
-                                             self.bn.running_var, eps=self.bn.eps, momentum=self.bn.momentum)
+        if x.shape[-1] == 4:                        # stem on its 4-channel image
+            t, mean, rstd = F.stem_conv_fwd_bnstats(x, self.w2, self.bn.running_mean, self.bn.running_var, eps=self.bn.eps,
+                                                    momentum=self.bn.momentum)
+        else:
+            t, mean, rstd = F.conv2d_fwd_bnstats(x, self.w16, self.stride, self.pad, self.bn.running_mean,
+                                                 self.bn.running_var, eps=self.bn.eps, momentum=self.bn.momentum)
         y, mask = F.bn_fwd_apply(t, mean, rstd, self.bn.weight.data, self.bn.bias.data, residual=residual,
                                  relu=self.relu, want_mask=True)
         self.saved = (x, t, mask, mean, rstd)
@@ -62,7 +69,7 @@ class ConvBN:
     def forward_eval(self, x, residual=None):
         """Inference-mode unit (model.eval(): BatchNorm normalises with its running statistics, nothing is saved) -- the
         validation pass of training.py:257-311."""
-        t = F.conv2d_fwd(x, self.w16, self.stride, self.pad)
+        t = F.stem_conv_fwd(x, self.w2, want_stats=False)[0] if x.shape[-1] == 4 else F.conv2d_fwd(x, self.w16, self.stride, self.pad)
         rstd = torch.rsqrt(self.bn.running_var + self.bn.eps)
         y, _ = F.bn_fwd_apply(t, self.bn.running_mean, rstd, self.bn.weight.data, self.bn.bias.data, residual=residual,
                               relu=self.relu, want_mask=False)
@@ -75,6 +82,7 @@ class ConvBN:
         materialised: the data-gradient GEMM adds it under the mask in its epilogue.  Returns dx or None."""
         x, t, mask, mean, rstd = self.saved
         self.saved = None
+        self.saved_c = x.shape[-1]
         rmask = mask if self.relu else dy_mask
         gt, _ = F.bn_bwd(dy, None, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta, relu_mask=rmask)
         n, h, w, c = x.shape
@@ -88,7 +96,9 @@ class ConvBN:
             self.keepalive.append((gt, x))          # freed only after the trainer has joined the streams (no record_stream: that
                                                     # call is not capturable, and the step may be recorded into a HIP graph)
         with (torch.cuda.stream(ws) if ws is not None else _nullcontext()):
-            if self.k == 1 and self.stride == 1:
+            if c == 4:                              # stem: straight into the flat gradient of the channels_last master
+                F.stem_conv_wgrad(gt, x, self.gw_flat)
+            elif self.k == 1 and self.stride == 1:
                 m = n * h * w
                 F.gemm(gt.view(m, self.cout), x.view(m, c), self.cout, c, m, False, False, out=self.gw.view(self.cout, c),
                        splitk=F.pick_splitk(self.cout, c, m, target_blocks=1024))

@@ -48,13 +48,40 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
   }
 }
 
+// C_padded = 4 (the stem kernels' 8-byte pixels): one 8-byte store per pixel; u8 != 0: uint8 source normalised by mean / std
+template <int DT, bool U8>
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const void* __restrict__ xv, unsigned short* __restrict__ y,
+                                                            long long N, int C, long long HW, const float* __restrict__ mean,
+                                                            const float* __restrict__ std) {
+  const long long total = N * HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / HW, hw = i - n * HW;
+    ushort4_t o = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c < C) {
+        if (U8) o[c] = dn16<DT>(((float)((const unsigned char*)xv)[(n * C + c) * HW + hw] - mean[c]) / std[c]);
+        else o[c] = dn16<DT>(((const float*)xv)[(n * C + c) * HW + hw]);
+      }
+    }
+    *(ushort4_t*)(y + i * 4) = o;
+  }
+}
+
 extern "C" int dle_nchw_to_nhwc(const float* x, void* y, int64_t N, int C, int64_t HW, int C_padded, int out_dtype,
                                 hipStream_t stream) {
   DLE_CHECK_ARG(out_dtype == DLE_F16 || out_dtype == DLE_BF16, "nchw_to_nhwc: 16-bit output only");
-  DLE_CHECK_ARG(C > 0 && C_padded >= C && C_padded % 8 == 0, "nchw_to_nhwc: padded channel count must be a multiple of 8");
+  DLE_CHECK_ARG(C > 0 && C_padded >= C && (C_padded % 8 == 0 || C_padded == 4),
+                "nchw_to_nhwc: padded channel count must be 4 or a multiple of 8");
   if (N * HW == 0) return 0;
   DLE_CHECK_ARG(x && y, "nchw_to_nhwc: null pointer");
   const int grid = cn_grid(N * HW, 256);
+  if (C_padded == 4) {
+    if (out_dtype == DLE_F16) hipLaunchKernelGGL((nchw_to_nhwc4_kernel<DLE_F16, false>), dim3(grid), dim3(256), 0, stream, (const void*)x, (unsigned short*)y, (long long)N, C, (long long)HW, nullptr, nullptr);
+    else hipLaunchKernelGGL((nchw_to_nhwc4_kernel<DLE_BF16, false>), dim3(grid), dim3(256), 0, stream, (const void*)x, (unsigned short*)y, (long long)N, C, (long long)HW, nullptr, nullptr);
+    DLE_LAUNCH_CHECK();
+    return 0;
+  }
   if (out_dtype == DLE_F16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, x, (unsigned short*)y, (long long)N, C, (long long)HW, C_padded);
   else hipLaunchKernelGGL(nchw_to_nhwc_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, x, (unsigned short*)y, (long long)N, C, (long long)HW, C_padded);
   DLE_LAUNCH_CHECK();
@@ -87,10 +114,17 @@ __global__ __launch_bounds__(256) void u8_nchw_norm_nhwc_kernel(const unsigned c
 extern "C" int dle_u8_nchw_normalize_nhwc(const void* x, void* y, const float* mean, const float* std, int64_t N, int C,
                                           int64_t HW, int C_padded, int out_dtype, hipStream_t stream) {
   DLE_CHECK_ARG(out_dtype == DLE_F16 || out_dtype == DLE_BF16, "u8_nchw_normalize_nhwc: 16-bit output only");
-  DLE_CHECK_ARG(C > 0 && C_padded >= C && C_padded % 8 == 0, "u8_nchw_normalize_nhwc: padded channel count must be a multiple of 8");
+  DLE_CHECK_ARG(C > 0 && C_padded >= C && (C_padded % 8 == 0 || C_padded == 4),
+                "u8_nchw_normalize_nhwc: padded channel count must be 4 or a multiple of 8");
   if (N * HW == 0) return 0;
   DLE_CHECK_ARG(x && y && mean && std, "u8_nchw_normalize_nhwc: null pointer");
   const int grid = cn_grid(N * HW, 256);
+  if (C_padded == 4) {
+    if (out_dtype == DLE_F16) hipLaunchKernelGGL((nchw_to_nhwc4_kernel<DLE_F16, true>), dim3(grid), dim3(256), 0, stream, x, (unsigned short*)y, (long long)N, C, (long long)HW, mean, std);
+    else hipLaunchKernelGGL((nchw_to_nhwc4_kernel<DLE_BF16, true>), dim3(grid), dim3(256), 0, stream, x, (unsigned short*)y, (long long)N, C, (long long)HW, mean, std);
+    DLE_LAUNCH_CHECK();
+    return 0;
+  }
   if (out_dtype == DLE_F16) hipLaunchKernelGGL(u8_nchw_norm_nhwc_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned char*)x, (unsigned short*)y, (long long)N, C, (long long)HW, C_padded, mean, std);
   else hipLaunchKernelGGL(u8_nchw_norm_nhwc_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned char*)x, (unsigned short*)y, (long long)N, C, (long long)HW, C_padded, mean, std);
   DLE_LAUNCH_CHECK();
@@ -347,6 +381,49 @@ __global__ __launch_bounds__(256) void bn_partial_fold_kernel(const float* __res
   }
 }
 
+// One-launch finish for up to ~1100 partial rows (the streaming 1x1 kernel's <= 1032 rows, every tile-kernel producer from the
+// 28x28 layers down): 8 columns x 32 group slices per workgroup, 8 loads per stream in flight (<= 5 dependent batches), sums in
+// fp64, fixed order.  It replaces the fold + finish PAIR (two 5 us launches on the forward chain of each of the 53 BatchNorms)
+// wherever the second level of parallelism is not needed.
+__global__ __launch_bounds__(256) void bn_stats_finish_wide_kernel(const float* __restrict__ partial, int groups, int C,
+                                                                   long long M, float eps, float momentum,
+                                                                   float* __restrict__ mean, float* __restrict__ rstd,
+                                                                   float* __restrict__ running_mean,
+                                                                   float* __restrict__ running_var) {
+  __shared__ double red[2][256];
+  const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C) {
+    int g = sl;
+    for (; g + 7 * 32 < groups; g += 8 * 32) {
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a[u] = partial[((long long)(g + 32 * u) * 2) * C + c]; b[u] = partial[((long long)(g + 32 * u) * 2 + 1) * C + c]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s0 += a[u]; s1 += b[u]; }
+    }
+    for (; g < groups; g += 32) { s0 += partial[((long long)g * 2) * C + c]; s1 += partial[((long long)g * 2 + 1) * C + c]; }
+  }
+  red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) { t0 += red[0][q * 8 + cl]; t1 += red[1][q * 8 + cl]; }
+    const double m = t0 / (double)M;
+    double var = t1 / (double)M - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+      const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  }
+}
+
 // mean / rstd / running statistics from per-group column sums [groups][2][C] (dle_conv2d_fwd_colstats);
 // workspace: >= 32 * 2 * C floats.
 extern "C" int dle_bn_stats_from_partials(const float* partial, int groups, int64_t M, int C, float eps, float momentum,
@@ -357,6 +434,13 @@ extern "C" int dle_bn_stats_from_partials(const float* partial, int groups, int6
   DLE_CHECK_ARG(workspace_bytes >= 32LL * 2 * C * 4, "bn_stats_from_partials: workspace too small");
   const float* src = partial;
   int g = groups;
+  static const int wide_max = getenv("DLE_BN_FINISH_WIDE") ? atoi(getenv("DLE_BN_FINISH_WIDE")) : 1100;   // 0: always fold + finish
+  if (groups > 32 && groups <= wide_max) {
+    hipLaunchKernelGGL(bn_stats_finish_wide_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, partial, groups, C, (long long)M, eps,
+                       momentum, mean, rstd, running_mean, running_var);
+    DLE_LAUNCH_CHECK();
+    return 0;
+  }
   if (groups > 32) {
     hipLaunchKernelGGL(bn_partial_fold_kernel, dim3((C + 15) / 16, 32), dim3(256), 0, stream, partial, groups, C, (float*)workspace);
     DLE_LAUNCH_CHECK();

@@ -579,6 +579,68 @@ def conv2d_fwd_bnstats(x, w, stride=1, pad=0, running_mean=None, running_var=Non
     return y, mean, rstd
 
 
+# ---- the ResNet stem on its own kernels (csrc/stem.hip): 4-channel image, packed weights
+def stem_pack_weight(w_master, out_dtype, out=None):
+    """fp32 master of the stem convolution, a channels_last [64, 3, 7, 7] parameter (memory order [64][7][7][3]) -> the packed
+    16-bit [64, 7, 8, 4] operand of the stem kernels (tap 7 / channel 3 zero)."""
+    C.require_cuda(w_master, out)
+    ko, ci, r, s = w_master.shape
+    phys = w_master.permute(0, 2, 3, 1)
+    if (ko, ci, r, s) != (64, 3, 7, 7) or not phys.is_contiguous() or w_master.dtype != torch.float32:
+        raise ValueError("stem_pack_weight expects a channels_last fp32 [64, 3, 7, 7] weight")
+    if out is None:
+        out = torch.empty((64, 7, 8, 4), dtype=out_dtype, device=w_master.device)
+    C.call("dle_stem_pack_weight", C.ptr(w_master), C.ptr(out), C.dt(out), C.stream())
+    return out
+
+
+def stem_conv_fwd(x4, w2, want_stats=True):
+    """x4 [N, H, W, 4] 16-bit, w2 packed [64, 7, 8, 4] -> (y [N, P, Q, 64], partial [groups, 2, 64] fp32 or None)."""
+    C.require_cuda(x4, w2)
+    n, h, wd, c = x4.shape
+    if c != 4 or not x4.is_contiguous() or tuple(w2.shape) != (64, 7, 8, 4) or w2.dtype != x4.dtype or not w2.is_contiguous():
+        raise ValueError("stem_conv_fwd: x4 must be [N, H, W, 4] and w2 the packed [64, 7, 8, 4] weight of the same dtype")
+    p, q = (h - 1) // 2 + 1, (wd - 1) // 2 + 1
+    y = torch.empty((n, p, q, 64), dtype=x4.dtype, device=x4.device)
+    part = None
+    if want_stats:
+        groups = C.lib().dle_stem_conv7_groups(n, h)
+        part = splitk_workspace(x4.device, (groups + 32) * 2 * 64 * 4)[:(groups + 32) * 2 * 64]
+    C.annotate(flops=2.0 * n * p * q * 64 * 147, tag="stem fwd%s %dx%dx%d" % ("+stats" if want_stats else "", n, h, wd),
+               bytes=float(x4.numel() + y.numel()) * 2)
+    C.call("dle_stem_conv7_fwd", C.ptr(x4), C.ptr(w2), C.ptr(y), C.ptr(part), part.numel() * 4 if part is not None else 0, n, h, wd,
+           C.dt(x4), C.stream())
+    return y, part
+
+
+def stem_conv_fwd_bnstats(x4, w2, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+    """Stem convolution + the training-mode BatchNorm statistics of its output (the contract of conv2d_fwd_bnstats)."""
+    y, part = stem_conv_fwd(x4, w2, want_stats=True)
+    n, p, q, ko = y.shape
+    groups = C.lib().dle_stem_conv7_groups(n, x4.shape[1])
+    mean = torch.empty(ko, dtype=torch.float32, device=y.device)
+    rstd = torch.empty(ko, dtype=torch.float32, device=y.device)
+    fold = part[groups * 2 * ko:]
+    C.call("dle_bn_stats_from_partials", C.ptr(part), groups, n * p * q, ko, float(eps), float(momentum), C.ptr(mean),
+           C.ptr(rstd), C.ptr(running_mean), C.ptr(running_var), C.ptr(fold), fold.numel() * 4, C.stream())
+    return y, mean, rstd
+
+
+def stem_conv_wgrad(dy, x4, out, accumulate=False):
+    """dy [N, P, Q, 64], x4 [N, H, W, 4] -> out: fp32 [64 * 7 * 7 * 3] in the master's KRSC memory order (the flat gradient view of
+    the channels_last [64, 3, 7, 7] parameter)."""
+    C.require_cuda(dy, x4, out)
+    n, h, wd, c = x4.shape
+    if c != 4 or not x4.is_contiguous() or not dy.is_contiguous() or dy.shape[0] != n or dy.shape[3] != 64 or \
+            out.numel() != 64 * 147 or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("stem_conv_wgrad: shape mismatch")
+    ws = splitk_workspace(x4.device, int(C.lib().dle_stem_conv7_wgrad_workspace(n, h)))
+    C.annotate(flops=2.0 * dy.numel() * 147, tag="stem wgrad %dx%dx%d" % (n, h, wd), bytes=float(dy.numel() + x4.numel()) * 2)
+    C.call("dle_stem_conv7_wgrad", C.ptr(dy), C.ptr(x4), C.ptr(out), C.ptr(ws), ws.numel() * 4, n, h, wd, C.dt(x4), int(accumulate),
+           C.stream())
+    return out
+
+
 def bn_fwd_apply(x, mean, rstd, gamma, beta, residual=None, relu=True, want_mask=False):
     """y = act((x - mean) * rstd * gamma + beta (+ residual)) with given statistics -> (y, relu_mask or None)."""
     C.require_cuda(x, mean, rstd, gamma, beta, residual)

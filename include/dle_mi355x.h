@@ -250,6 +250,23 @@ int dle_bn_bwd_reduce(const void* dy, const void* y, const void* relu_mask, cons
 int dle_bn_bwd_apply(const void* dy, const void* y, const void* relu_mask, const void* x, void* dx, void* g_out,
                      const float* mean, const float* rstd, const float* gamma, const float* dgamma,
                      const float* dbeta, int64_t M, int C, int dtype, hipStream_t stream);
+/* ---- the ResNet stem (csrc/stem.hip): conv7x7 / stride 2 / pad 3 of a 3-channel image, forward (+ BatchNorm partial sums) and
+ * weight gradient, on a 4-channel NHWC image (dle_nchw_to_nhwc with C_padded = 4: 8 bytes per pixel, channel 3 zero).
+ *   replaces cuDNN behind builder.conv7x7(3, 64, stride=2) + bn1's statistics: Classification/ConvNets/image_classification/
+ *   models/resnet.py:262-268,318-322, models/common.py:31-60.
+ * w2: packed 16-bit weights [64][7][8][4] (k = r*32 + s*4 + c, zero for s = 7 / c = 3) written by dle_stem_pack_weight from the
+ * fp32 master in KRSC memory order [64][7][7][3] (a channels_last nn.Conv2d.weight).  Images up to 224 pixels wide.
+ * fwd: y [N, P, Q, 64]; stats (optional): [dle_stem_conv7_groups(N, H)][2][64] column sums / sums of squares of the ROUNDED output
+ *      (contract of dle_conv2d_fwd_colstats; fold with dle_bn_stats_from_partials).
+ * wgrad: dw [64][7][7][3] fp32 in the master's memory order (+)= sum over pixels dy x im2col(x); workspace >=
+ *      dle_stem_conv7_wgrad_workspace(N, H) bytes (one partial per persistent workgroup, folded in a fixed order).      */
+int dle_stem_conv7_groups(int N, int H);
+int dle_stem_conv7_fwd(const void* x4, const void* w2, void* y, float* stats, int64_t stats_bytes, int N, int H, int W,
+                       int dtype, hipStream_t stream);
+int64_t dle_stem_conv7_wgrad_workspace(int N, int H);
+int dle_stem_conv7_wgrad(const void* dy, const void* x4, float* dw, void* workspace, int64_t workspace_bytes, int N, int H,
+                         int W, int dtype, int accumulate, hipStream_t stream);
+int dle_stem_pack_weight(const float* w_krsc, void* out, int dtype, hipStream_t stream);
 /* argmax: uint8 [N,P,Q,C] window-scan index of the first maximum (ATen tie rule) */
 int dle_maxpool_fwd(const void* x, void* y, void* argmax, int N, int H, int W, int C, int ksize, int stride,
                     int pad, int dtype, hipStream_t stream);
