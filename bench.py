@@ -259,6 +259,10 @@ class BertWorkload:
         self.scaling = "weak"
         self.loss = None
 
+    def single_stream(self, on):
+        torch.cuda.synchronize()
+        os.environ["DLE_BERT_WGRAD_STREAM"] = "0" if on else "1"          # read per call by BertTrainer._leaf_stream
+
     def step(self):
         self.loss = self.trainer.train_step(*self.data)
 

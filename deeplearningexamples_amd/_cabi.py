@@ -58,6 +58,10 @@ _SIGS = {
     "dle_conv2d_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "dle_conv2d_wgrad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_i64, c_void_p]),
     "dle_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p]),
+    "dle_gemm_expand_add_up2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_int,
+                                        c_int, c_int, c_int, c_void_p]),
+    "dle_conv3x3_wgrad_workspace": (c_i64, []),
+    "dle_conv3x3_wgrad_mode": (c_int, [c_int]),
     "dle_stem_conv7_groups": (c_int, [c_int, c_int]),
     "dle_stem_conv7_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p]),
     "dle_stem_conv7_wgrad_workspace": (c_i64, [c_int, c_int]),
@@ -235,7 +239,13 @@ class KernelTimer:
         keeps the queue busy up to the launch, so the pair measures the kernel, not an idle queue)."""
         if any(k in name for k in self._STATEFUL) or (name, tag) not in self.last:
             return None
-        fn, args = self.last[(name, tag)]
+        fn, args, st = self.last[(name, tag)]
+        # the recorded arguments carry the stream the call was launched on (a side stream for leaves of the backward graph): the
+        # timing events must sit on THAT stream, or they bracket nothing
+        with torch.cuda.stream(st):
+            return self._replay_on_current_stream(fn, args, iters, warmup, cold)
+
+    def _replay_on_current_stream(self, fn, args, iters, warmup, cold):
         if cold:
             if getattr(self, "_flush", None) is None:
                 self._flush = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
@@ -302,7 +312,7 @@ def call(name, *args):
     rc = fn(*args)
     e.record()
     t.records.append((name, s, e, t.meta))
-    t.last[(name, t.meta.get("tag") if t.meta else None)] = (fn, args)
+    t.last[(name, t.meta.get("tag") if t.meta else None)] = (fn, args, torch.cuda.current_stream())
     t.meta = None
     check(rc, name)
 

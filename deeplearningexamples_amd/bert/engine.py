@@ -471,7 +471,16 @@ class BertTrainer:
             dx = F.dropout_bwd(dx, sv["mask0"], self.p_hidden)
         dz0 = F.layernorm_bwd(dx, sv["z0"], sv["ln0"][0], sv["ln0"][1], emb.LayerNorm.weight.data,
                               self.gview["bert.embeddings.LayerNorm.weight"], self.gview["bert.embeddings.LayerNorm.bias"], acc)
-        F.embed_scatter_add_(self.gview["bert.embeddings.word_embeddings.weight"], dz0, sv["ids"])
+        # lookup gradient of the word embeddings: rows of dz0 added into the (tied) embedding gradient.  Duplicate-free row update
+        # (the DLRM sparse-update kernels with lr = -1: one 4-byte exchange per token threads the tokens of a vocabulary row into a
+        # list, its head sums them and does ONE plain read-modify-write of the row) instead of 33 M fp32 atomics (0.88 ms / step)
+        gw_word = self.gview["bert.embeddings.word_embeddings.weight"]
+        if getattr(self, "_emb_ws", None) is None:
+            self._emb_ws = F.EmbUpdateWorkspace([0, gw_word.shape[0]], h, self.dev)
+        if os.environ.get("DLE_BERT_EMB_DEDUP", "1") != "0":
+            F.emb_sgd_dedup_(gw_word, sv["ids"].view(-1, 1), dz0, self._emb_ws, lr=-1.0)
+        else:
+            F.embed_scatter_add_(gw_word, dz0, sv["ids"])
         gpos = self.gview["bert.embeddings.position_embeddings.weight"]
         if not acc:
             gpos[s:].zero_()

@@ -138,6 +138,9 @@ class ResNetTrainer:
         # the stem's own kernels (csrc/stem.hip) on a 4-channel image, for inputs up to 224 pixels wide; DLE_RN50_STEM4=0 keeps
         # the generic implicit-GEMM path (8-channel image) -- which wider inputs take in any case
         self.stem4 = os.environ.get("DLE_RN50_STEM4", "1") != "0"
+        # the stride-2 downsample branch's data gradient stays on its own grid and is added at the even pixels by conv1's
+        # data-gradient kernel (no zero-stuffed tensor); DLE_RN50_FUSE_UP2=0 materialises it as before
+        self.fuse_up2 = os.environ.get("DLE_RN50_FUSE_UP2", "1") != "0"
         self.stem.w2 = torch.zeros((64, 7, 8, 4), dtype=compute_dtype, device=self.dev)
         self.stem.gw_flat = self.gview["conv1.weight"]
         self.fc_w16 = torch.empty(model.fc.weight.shape, dtype=compute_dtype, device=self.dev)
@@ -283,12 +286,12 @@ class ResNetTrainer:
                 bs.wait_stream(cur)
                 self._branch_keep.clear()
                 with torch.cuda.stream(bs):
-                    gskip = ud.backward(g, dy_mask=mask3)
+                    gskip = ud.backward(g, dy_mask=mask3, compact_dx=self.fuse_up2)
                 self._branch_keep.append((gskip, g))
             g3 = u3.backward(g)
             self._done(u3)
             if ud is not None and bs is None:
-                gskip = ud.backward(g, dy_mask=mask3)
+                gskip = ud.backward(g, dy_mask=mask3, compact_dx=self.fuse_up2)
             elif ud is None:
                 gskip = (g, mask3)
             g2 = u2.backward(g3)

@@ -75,18 +75,21 @@ class ConvBN:
                               relu=self.relu, want_mask=False)
         return y
 
-    def backward(self, dy, need_dx=True, dx_addend=None, dy_mask=None):
+    def backward(self, dy, need_dx=True, dx_addend=None, dy_mask=None, compact_dx=False):
         """dy: gradient w.r.t. the unit's output; dy_mask (optional): bit-packed keep bits to apply to dy first (the
         ReLU that follows the residual add sits on the OTHER branch's unit: its mask gates this branch's gradient too).
         dx_addend: a tensor, or (tensor, keep bits) = the residual-branch gradient dy * (y > 0) that is never
-        materialised: the data-gradient GEMM adds it under the mask in its epilogue.  Returns dx or None."""
+        materialised: the data-gradient GEMM adds it under the mask in its epilogue -- or ("up2", compact, (H, W)) = the gradient
+        of a stride-2 1x1 branch on its own P x Q grid, added at the even pixels without its zero-stuffed form being written.
+        compact_dx (1x1 stride-2 units): return that triple instead of the full-resolution dx.  Returns dx or None."""
         x, t, mask, mean, rstd = self.saved
         self.saved = None
         self.saved_c = x.shape[-1]
         rmask = mask if self.relu else dy_mask
         gt, _ = F.bn_bwd(dy, None, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta, relu_mask=rmask)
         n, h, w, c = x.shape
-        masked = isinstance(dx_addend, tuple)
+        up2 = isinstance(dx_addend, tuple) and dx_addend[0] == "up2"
+        masked = isinstance(dx_addend, tuple) and not up2
         # The weight gradient is a leaf of the backward graph (nothing downstream reads it before the optimizer) while the data
         # gradient is on the critical chain: it goes to a second stream, where its split-K slices (one workgroup per CU, bound by
         # HBM latency rather than bandwidth) share the chip with the next unit's BatchNorm / data-gradient kernels.
@@ -113,12 +116,20 @@ class ConvBN:
                     dx = F.gemm(g2, self.w16.view(self.cout, c), m, c, self.cout, True, False, act=C.ACT_ADD_MASKED,
                                 mask_src=dx_addend[0].view(m, c), aux=dx_addend[1]).view(n, h, w, c)
                 else:
+                    if up2:
+                        dx = F.gemm_add_upsampled2(g2, self.w16.view(self.cout, c), dx_addend[1], dx_addend[2])
+                        if dx is not None:
+                            return dx.view(n, h, w, c)
+                        dx_addend = F.upsample_zero(dx_addend[1], dx_addend[2], 2)       # outside the fused kernel's envelope
                     dx = F.gemm(g2, self.w16.view(self.cout, c), m, c, self.cout, True, False,
                                 act=C.ACT_ADD if dx_addend is not None else C.ACT_NONE,
                                 mask_src=dx_addend.view(m, c) if dx_addend is not None else None).view(n, h, w, c)
         else:
-            assert not masked, "masked residual gradients enter through the 1x1 convolution of a bottleneck"
-            dx = F.conv2d_dgrad(gt, self.w16, (h, w), self.stride, self.pad, addend=dx_addend) if need_dx else None
+            assert not masked and not up2, "masked / compact residual gradients enter through the 1x1 convolution of a bottleneck"
+            if need_dx and compact_dx and self.k == 1 and self.stride == 2 and dx_addend is None and h % 2 == 0 and w % 2 == 0:
+                dx = ("up2", F.conv1x1_s2_dgrad_compact(gt, self.w16), (h, w))
+            else:
+                dx = F.conv2d_dgrad(gt, self.w16, (h, w), self.stride, self.pad, addend=dx_addend) if need_dx else None
         return dx
 
     def relu_mask(self):

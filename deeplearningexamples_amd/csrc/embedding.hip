@@ -485,7 +485,14 @@ __global__ __launch_bounds__(256) void emb_link(const long long* __restrict__ ro
   }
 }
 
-// pass 2: the head of each list applies the summed update with a plain read-modify-write
+// pass 2: the head of each list applies the summed update with a plain read-modify-write.
+// The first form walked a chain of FOUR dependent loads per lookup (row id -> list head -> gradient / next -> table row), two
+// lookups in flight per wavefront: 3.6 TB/s, bound by the chain's latency, not by bytes.  Here the depth is two:
+//   level 0 (depends on the lookup index only): row id, next pointer, the lookup's own gradient row;
+//   level 1 (depends on the row id): list head AND the table row, requested together (speculatively: a lookup that turns out not
+//           to be its list's head wastes one row read, which duplicates of the small and medium tables find in L2);
+//   then the store.  Duplicates behind the head are walked as before (gradient + next per step).
+// Two lookups per half-wavefront (four per wavefront) are in flight, every load unconditional on a clamped address.
 template <int IDT>
 __global__ __launch_bounds__(256) void emb_sgd_lists(float* __restrict__ weight, const long long* __restrict__ rows,
                                                      const typename In4<IDT>::V* __restrict__ grad,
@@ -499,26 +506,57 @@ __global__ __launch_bounds__(256) void emb_sgd_lists(float* __restrict__ weight,
   const float lr = lr_dev ? *lr_dev : lr_host;
   const float alpha = -lr * (scale ? *scale : 1.0f);
   const int sub = (threadIdx.x & 63) >> 5, l = threadIdx.x & 31;
+  const int lc = l < D4 ? l : D4 - 1;             // (dim < 128: the upper lanes shadow the last column and do not store)
   const long long wave_id = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
-  for (long long base = wave_id * 2; base < n; base += n_waves * 2) {
-    const long long i = base + sub;
-    if (i >= n) continue;
-    if (is_small && is_small[i % T]) continue;
-    const long long r = rows[i];
-    if (head[r] != (int)i) continue;            // not the list head: the head does the work
-    for (int c = l; c < D4; c += 32) {
-      float4_t s = {0.f, 0.f, 0.f, 0.f};
-      long long j = i;
+  constexpr int U = 2;
+  for (long long base = wave_id * (2 * U); base < n; base += n_waves * (2 * U)) {
+    long long iu[U], r[U];
+    int nx[U], h[U];
+    bool ok[U];
+    typename In4<IDT>::V g[U];
+    float4_t wv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long i = base + 2 * u + sub;
+      ok[u] = i < n;
+      iu[u] = ok[u] ? i : 0;
+      const long long jb = iu[u] / T;
+      const int t = (int)(iu[u] - jb * T);
+      ok[u] = ok[u] && !(is_small && is_small[t]);
+      r[u] = rows[iu[u]];
+      nx[u] = next[iu[u]];
+      g[u] = grad[jb * g_bstride4 + (long long)t * D4 + lc];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      h[u] = head[r[u]];
+      wv[u] = ((const float4_t*)(weight + r[u] * (long long)(D4 * 4)))[lc];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u] || h[u] != (int)iu[u]) continue;   // small-table lookup / not the list head: the head does the work
+      float4_t sacc = In4<IDT>::up(g[u]);
+      long long j = nx[u];
       while (j >= 0) {
         const long long jb = j / T;
-        s += In4<IDT>::up(grad[jb * g_bstride4 + (j - jb * T) * D4 + c]);
+        sacc += In4<IDT>::up(grad[jb * g_bstride4 + (j - jb * T) * D4 + lc]);
         j = next[j];
       }
-      float4_t* w = (float4_t*)(weight + r * (long long)(D4 * 4)) + c;
-      *w = *w + alpha * s;
+      float4_t* w = (float4_t*)(weight + r[u] * (long long)(D4 * 4));
+      if (l < D4) w[l] = wv[u] + alpha * sacc;
+      for (int c = l + 32; c < D4; c += 32) {       // dim > 128: the remaining columns, chain walked again per trip
+        float4_t s2 = {0.f, 0.f, 0.f, 0.f};
+        long long j2 = iu[u];
+        while (j2 >= 0) {
+          const long long jb = j2 / T;
+          s2 += In4<IDT>::up(grad[jb * g_bstride4 + (j2 - jb * T) * D4 + c]);
+          j2 = next[j2];
+        }
+        w[c] = w[c] + alpha * s2;
+      }
+      if (l == 0) head[r[u]] = -1;                  // restore the workspace invariant
     }
-    if (l == 0) head[r] = -1;                     // restore the workspace invariant
   }
 }
 
@@ -633,7 +671,7 @@ extern "C" int dle_emb_sgd_dedup(float* weight, const int64_t* rows, const void*
     hipLaunchKernelGGL(emb_link, dim3(grid_for(n, 256)), dim3(256), 0, stream, (const long long*)rows, head, next,
                        is_small_dev, skip_flag_dev, n, tables);
     DLE_LAUNCH_CHECK();
-    const int grid = grid_for(n, 4 * 2);
+    const int grid = grid_for(n, 4 * 4);
 #define GO(IDT, VT) hipLaunchKernelGGL(emb_sgd_lists<IDT>, dim3(grid), dim3(256), 0, stream, weight, (const long long*)rows, (const VT*)grad, head, (const int*)next, is_small_dev, lr_dev, lr_host, scale_dev, skip_flag_dev, n, tables, D4, gs4)
     if (grad_dtype == DLE_F32) GO(DLE_F32, float4_t);
     else if (grad_dtype == DLE_F16) GO(DLE_F16, ushort4_t);

@@ -1071,6 +1071,9 @@ extern "C" int dle_conv2d_dgrad(const void* dy, const void* w, void* dx, const v
   return conv_launch(p, dtype, 4, 5, stream);
 }
 
+extern "C" int dle_conv3x3_wgrad_try(const void* dy, const void* x, float* dw, int N, int H, int W, int C, int Ko, int dtype,
+                                     int accumulate, void* workspace, int64_t workspace_bytes, hipStream_t stream);   // conv3x3_wgrad.hip
+
 // dw[Ko,R,S,C] (fp32) (+)= sum over pixels dy[N,P,Q,Ko]^T im2col(x[N,H,W,C]); workspace: split-K slabs.
 extern "C" int dle_conv2d_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, int C, int Ko, int R,
                                 int S, int stride, int pad, int dtype, int splitk, int accumulate, void* workspace,
@@ -1078,6 +1081,12 @@ extern "C" int dle_conv2d_wgrad(const void* dy, const void* x, float* dw, int N,
   const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
   if (int rc = conv_check("conv2d_wgrad", N, H, W, C, Ko, R, S, stride, pad, P, Q, dtype)) return rc;
   DLE_CHECK_ARG(dy && x && dw, "conv2d_wgrad: null pointer");
+  if (R == 3 && S == 3 && stride == 1 && pad == 1) {
+    // halo-tile kernel (conv3x3_wgrad.hip): the nine taps share one activation patch and one dy tile per pixel tile
+    const int rc = dle_conv3x3_wgrad_try(dy, x, dw, N, H, W, C, Ko, dtype, accumulate, workspace, workspace_bytes, stream);
+    if (rc == 1) return 0;
+    if (rc > 1) return rc;
+  }
   Gemm2Args p = {};
   p.A = (const unsigned short*)dy; p.B = (const unsigned short*)x; p.C = dw;
   p.M = Ko; p.N = R * S * C; p.K = N * P * Q; p.lda = Ko; p.ldb = 0; p.ldc = (long long)R * S * C;

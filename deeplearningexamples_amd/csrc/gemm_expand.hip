@@ -32,6 +32,11 @@ struct ExpandArgs {
   int M, N, K;
   long long lda, ldb, ldc;
   int b_kc, row_tiles, groups, col_tiles;
+  // ACT == 3: the addend is the ZERO-STUFFED form of a compact [n, H/2, W/2, N] tensor (the data gradient of a 1x1 stride-2
+  // convolution on its own P x Q grid): row m = (n, h, w) reads compact row (n, h/2, w/2) when h and w are even, nothing otherwise
+  FastDiv dHW, dW;
+  int up_HW, up_W, up_P, up_Q;
+  long long ld_src;
 };
 
 template <int DT> struct ExMfma;
@@ -60,6 +65,7 @@ struct ExStream {
   uint4_t mb;                                                          // ACT == 2: 16 mask bytes = columns n0 .. n0 + 127 of the row
   long long o0;
   bool live;
+  bool has;                                                            // ACT == 3: this row has an addend row
   __device__ __forceinline__ void load_a(const ExpandArgs& p, int m, int kg) {
     const long long mr = m < p.M ? m : p.M - 1;
     const unsigned short* arow = p.A + mr * p.lda + kg * 8;
@@ -70,7 +76,16 @@ struct ExStream {
     live = m < p.M;
     const long long mr = live ? m : p.M - 1;
     o0 = mr * p.ldc + n0 + kg * 8;                                     // + 32 j
-    if (ACT) {
+    if (ACT == 3) {
+      const int mi = (int)mr;
+      const int n = fd_div(mi, p.dHW), rem = mi - n * p.up_HW;
+      const int h = fd_div(rem, p.dW), w = rem - h * p.up_W;
+      has = !((h | w) & 1);
+      const long long cr = has ? ((long long)n * p.up_P + (h >> 1)) * p.up_Q + (w >> 1) : 0;      // (unconditional, clamped load)
+      const unsigned short* srow = p.src + cr * p.ld_src + n0 + kg * 8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sv[j] = *(const ushort8_t*)(srow + 32 * j);
+    } else if (ACT) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) sv[j] = *(const ushort8_t*)(p.src + o0 + 32 * j);
     }
@@ -145,6 +160,7 @@ void gemm_expand_kernel(ExpandArgs p) {
     // ---- epilogue: pair j = blocks 2j, 2j + 1 -> columns n0 + 32 j + 8 kg + {0..7} of row m
     ushort8_t outv[4];
     const bool live_cur = cur.live;
+    const bool has_cur = ACT == 3 ? cur.has : true;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float v[8];
@@ -157,6 +173,7 @@ void gemm_expand_kernel(ExpandArgs p) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           if (ACT == 2) { if ((bits8 >> r) & 1u) v[r] += y[r]; }
+          else if (ACT == 3) { if (has_cur) v[r] += y[r]; }
           else v[r] += y[r];
         }
       }
@@ -253,6 +270,7 @@ extern "C" int dle_gemm_expand_try(const void* A, const void* B, void* C, const 
                                    int act, hipStream_t stream) {
   if (M < 4096 || (K != 64 && K != 128 && K != 256) || (N % EX_TN) != 0 || N < 2 * K || out_dtype != in_dtype) return 0;
   if (((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)src)) & 15) != 0 || (lda & 7) || (ldb & 7) || (ldc & 7)) return 0;
+  if (act < 0 || act > 2) return 0;
   if (act == 2 && !bits) return 0;
   // the masked epilogue reads a row's 16 keep bytes with ONE 16-byte load at bits + ((m ldc + n0) >> 3): needs ldc % 128 == 0 and
   // a 16-byte aligned bit plane (other pitches go to the tile kernel's per-byte form)
@@ -296,5 +314,48 @@ extern "C" int dle_gemm_expand_try(const void* A, const void* B, void* C, const 
 #undef GO
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { dle_set_error("gemm_expand launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
+  return 1;
+}
+
+// C [M = N_img * H * W, N] = A [M, K] B^T + zero-stuffed(compact [N_img * (H/2) * (W/2), N]): the 1x1 data gradient of a
+// bottleneck's first convolution + the gradient of the stride-2 1x1 downsample branch, whose zero-stuffed full-resolution form
+// (dle_upsample_zero: 4x the bytes, written and read once) is never materialised.  1: launched; 0: outside the envelope.
+extern "C" int dle_gemm_expand_add_up2(const void* A, const void* B, void* C, const void* compact, int M, int N, int K, int64_t lda,
+                                       int64_t ldb, int64_t ldc, int64_t ld_compact, int b_kc, int H, int W, int dtype,
+                                       hipStream_t stream) {
+  if (M < 4096 || (K != 64 && K != 128 && K != 256) || (N % EX_TN) != 0 || N < 2 * K) return 0;
+  if (dtype != DLE_F16 && dtype != DLE_BF16) return 0;
+  if ((H & 1) || (W & 1) || H <= 0 || W <= 0 || (M % (H * W)) != 0 || !compact) return 0;
+  if (((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)compact)) & 15) != 0 || (lda & 7) || (ldb & 7) || (ldc & 7) ||
+      (ld_compact & 7)) return 0;
+  static const char* pin = getenv("DLE_GEMM_EXPAND");
+  if (pin && atoi(pin) == 0) return 0;
+  ExpandArgs p = {(const unsigned short*)A, (const unsigned short*)B, (unsigned short*)C, (const unsigned short*)compact, nullptr,
+                  nullptr, M, N, K, (long long)lda, (long long)ldb, (long long)ldc, b_kc, 0, 0, 0};
+  p.dHW = make_fastdiv(H * W); p.dW = make_fastdiv(W);
+  p.up_HW = H * W; p.up_W = W; p.up_P = H / 2; p.up_Q = W / 2; p.ld_src = ld_compact;
+  const int tmr = ex_rows_per_tile(K);
+  p.row_tiles = (M + tmr - 1) / tmr;
+  p.col_tiles = N / EX_TN;
+  p.groups = dle_gemm_expand_groups(M, N, K);
+  const int lds_bytes = EX_TN * (K + EX_PAD) * 2;
+  const dim3 grid((unsigned)(p.groups * p.col_tiles)), block(tmr * 4);
+#define GO3(DT, KS)                                                                                                      \
+  do {                                                                                                                   \
+    constexpr int NW_ = KS > 4 ? 8 : 4;                                                                                  \
+    static bool attr_set = false;                                                                                        \
+    if (!attr_set) {                                                                                                     \
+      (void)hipFuncSetAttribute((const void*)gemm_expand_kernel<DT, KS, 3, false, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                EX_TN * (KS * 32 + EX_PAD) * 2);                                                         \
+      attr_set = true;                                                                                                   \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((gemm_expand_kernel<DT, KS, 3, false, NW_>), grid, block, lds_bytes, stream, p);                  \
+  } while (0)
+#define PICK3(DT) do { if (K == 64) GO3(DT, 2); else if (K == 128) GO3(DT, 4); else GO3(DT, 8); } while (0)
+  if (dtype == DLE_F16) PICK3(DLE_F16); else PICK3(DLE_BF16);
+#undef PICK3
+#undef GO3
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { dle_set_error("gemm_expand_add_up2 launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
   return 1;
 }

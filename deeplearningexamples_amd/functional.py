@@ -471,6 +471,57 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, addend=None, out=None):
     return out
 
 
+def upsample_zero(compact, in_hw, stride):
+    """compact [N,P,Q,C] -> [N,H,W,C] with compact at the pixels (stride * i, stride * j) and zeros elsewhere."""
+    C.require_cuda(compact)
+    n, p, q, c = compact.shape
+    h, wd = in_hw
+    out = torch.empty((n, h, wd, c), dtype=compact.dtype, device=compact.device)
+    C.annotate(bytes=float(out.numel() + compact.numel()) * 2, tag="N%dx%dx%dxC%d s%d" % (n, h, wd, c, stride))
+    C.call("dle_upsample_zero", C.ptr(compact), C.ptr(out), n, p, q, h, wd, c, stride, C.dt(compact), C.stream())
+    return out
+
+
+def conv1x1_s2_dgrad_compact(dy, w):
+    """The data gradient of a 1x1 stride-2 convolution ON ITS OWN GRID: dy [N,P,Q,Ko], w [Ko,1,1,C] -> [N,P,Q,C] (the non-zero
+    pixels of dx; conv2d_dgrad zero-stuffs it to [N,2P,2Q,C], gemm_add_upsampled2 adds it without materialising that)."""
+    n, p, q, ko = dy.shape
+    c = w.shape[-1]
+    m = n * p * q
+    return gemm(dy.view(m, ko), w.view(ko, c), m, c, ko, True, False).view(n, p, q, c)
+
+
+def gemm_add_upsampled2(a, b, compact, hw):
+    """out [M, N] = a [M, K] @ b [K, N] + zero_stuffed(compact [n, H/2, W/2, N]) for M = n*H*W rows (the bottleneck's conv1 data
+    gradient + the stride-2 downsample branch's, csrc/gemm_expand.hip).  Returns None when the shape is outside the streaming
+    kernel's envelope (the caller materialises the zero-stuffed tensor instead)."""
+    C.require_cuda(a, b, compact)
+    m, k = a.shape
+    k2, nn = b.shape
+    h, wd = hw
+    if k2 != k or a.stride(1) != 1 or b.stride(1) != 1 or not compact.is_contiguous() or compact.shape[-1] != nn or \
+            a.dtype != b.dtype or compact.dtype != a.dtype:
+        raise ValueError("gemm_add_upsampled2: shape / layout mismatch")
+    out = torch.empty((m, nn), dtype=a.dtype, device=a.device)
+    C.annotate(flops=2.0 * m * nn * k, tag="%dx%dx%d+up2" % (m, nn, k), bytes=float(a.numel() + b.numel() + out.numel() + compact.numel()) * 2)
+    t = C._timer
+    if t is not None:          # (a call that may decline is not a C.call: record it by hand when it launches)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+    rc = C.lib().dle_gemm_expand_add_up2(C.ptr(a), C.ptr(b), C.ptr(out), C.ptr(compact), m, nn, k, a.stride(0), b.stride(0), nn, nn, 0,
+                                         h, wd, C.dt(a), C.stream())
+    if t is not None:
+        e.record()
+        meta, t.meta = t.meta, None
+        if rc == 1:
+            t.records.append(("dle_gemm", s, e, meta))
+    if rc == 0:
+        return None
+    if rc != 1:
+        C.check(rc - 1000 if rc > 1000 else rc, "dle_gemm_expand_add_up2")
+    return out
+
+
 def conv2d_wgrad(dy, x, rs, stride=1, pad=0, out=None, accumulate=False, splitk=None):
     """dy [N,P,Q,Ko], x [N,H,W,C] -> dw [Ko,R,S,C] fp32."""
     C.require_cuda(dy, x, out)
@@ -485,7 +536,10 @@ def conv2d_wgrad(dy, x, rs, stride=1, pad=0, out=None, accumulate=False, splitk=
     m_out, n_out, k = ko, r * s * c, n * p * q
     if splitk is None:
         splitk = pick_splitk(m_out, n_out, k, target_blocks=1024)
-    ws = splitk_workspace(x.device, splitk * m_out * n_out * 4) if splitk > 1 else None
+    need = splitk * m_out * n_out * 4 if splitk > 1 else 0
+    if (r, s, stride, pad) == (3, 3, 1, 1):                 # the halo-tile kernel's partial blocks (csrc/conv3x3_wgrad.hip)
+        need = max(need, int(C.lib().dle_conv3x3_wgrad_workspace()))
+    ws = splitk_workspace(x.device, need) if need else None
     C.annotate(flops=2.0 * n * p * q * ko * r * s * c, tag="wgrad %dx%dx%dx%d k%d %dx%d s%d" % (n, h, wd, c, ko, r, s, stride),
                bytes=float(dy.numel() + x.numel()) * 2 + out.numel() * 4.0)
     C.call("dle_conv2d_wgrad", C.ptr(dy), C.ptr(x), C.ptr(out), n, h, wd, c, ko, r, s, stride, pad, C.dt(x), splitk,

@@ -127,6 +127,11 @@ int dle_conv2d_dgrad(const void* dy, const void* w, void* dx, const void* addend
 int dle_conv2d_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, int C, int Ko, int R, int S,
                      int stride, int pad, int dtype, int splitk, int accumulate, void* workspace,
                      int64_t workspace_bytes, hipStream_t stream);
+/* 3x3 / stride 1 / pad 1 weight gradients with C, Ko multiples of 64 run on the halo-tile kernel of csrc/conv3x3_wgrad.hip when the
+ * workspace holds dle_conv3x3_wgrad_workspace() bytes (256 partial blocks of 64 x 9 x 64 fp32, folded in a fixed order);
+ * dle_conv3x3_wgrad_mode(0 / 1) switches it off / on for A/B measurements (returns the previous value). */
+int64_t dle_conv3x3_wgrad_workspace(void);
+int dle_conv3x3_wgrad_mode(int mode);
 
 /* out[n] (+)= sum_m x[m][n]  (bias gradients).  workspace (optional, fp32, >= 2048*N*4 bytes is always
  * enough): row groups are combined through it instead of through same-address atomics. */
@@ -274,6 +279,13 @@ int dle_maxpool_bwd(const void* dy, const void* argmax, void* dx, int N, int H, 
                     int stride, int pad, int dtype, hipStream_t stream);
 int dle_avgpool_fwd(const void* x, void* y, int64_t N, int HW, int C, int dtype, hipStream_t stream);
 int dle_avgpool_bwd(const void* dy, void* dx, int64_t N, int HW, int C, int dtype, hipStream_t stream);
+/* C [M = n_img*H*W, N] = A [M, K] B^T + zero_stuffed(compact [n_img*(H/2)*(W/2), N]): the data gradient of a bottleneck's first 1x1
+ * convolution plus the gradient of the stride-2 1x1 downsample branch (models/resnet.py:148-175,150-158), whose full-resolution
+ * zero-stuffed form is never written (csrc/gemm_expand.hip).  Returns 1 when launched, 0 when the shape is outside the streaming
+ * kernel's envelope (K in {64, 128, 256}, N % 128 == 0, N >= 2 K, H and W even): the caller then materialises dle_upsample_zero
+ * and uses dle_gemm with DLE_ACT_ADD. */
+int dle_gemm_expand_add_up2(const void* A, const void* B, void* C, const void* compact, int M, int N, int K, int64_t lda,
+                            int64_t ldb, int64_t ldc, int64_t ld_compact, int b_kc, int H, int W, int dtype, hipStream_t stream);
 /* y[n,h,w,:] = x[n,h/s,w/s,:] where h, w are multiples of s, else 0: with a plain GEMM on the P x Q grid this is the
  * data gradient of a 1x1 stride-s convolution (ResNet downsample branches, models/resnet.py:150-158)           */
 int dle_upsample_zero(const void* x, void* y, int64_t N, int P, int Q, int H, int W, int C, int stride, int dtype,

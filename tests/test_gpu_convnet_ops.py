@@ -153,3 +153,24 @@ def test_softmax_xent_wide_rows_mlm_head(cuda, gdtype):
     tol = dict(rtol=1e-4, atol=1e-6) if gdtype == torch.float32 else dict(rtol=1e-2, atol=1e-5)
     np.testing.assert_allclose(got[:, :classes], ref, **tol)
     assert not got[:, classes:].any()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,h,w,k,nn", [(2, 56, 56, 128, 256), (8, 28, 28, 256, 512), (2, 48, 48, 64, 128)])
+def test_gemm_add_upsampled2_equals_materialised_path(cuda, dtype, n, h, w, k, nn):
+    """conv1's data gradient + the stride-2 downsample branch's compact gradient added at the even pixels (csrc/gemm_expand.hip,
+    dle_gemm_expand_add_up2) == the same GEMM with the zero-stuffed tensor as a DLE_ACT_ADD addend (models/resnet.py:148-175)."""
+    from deeplearningexamples_amd import _cabi as C
+    from deeplearningexamples_amd import functional as F
+    g = torch.Generator().manual_seed(h * 7 + k)
+    m = n * h * w
+    a = torch.randn((m, k), generator=g).to(dtype).to(cuda)
+    b = (torch.randn((k, nn), generator=g) * 0.1).to(dtype).to(cuda)
+    compact = torch.randn((n, h // 2, w // 2, nn), generator=g).to(dtype).to(cuda)
+    fused = F.gemm_add_upsampled2(a, b, compact, (h, w))
+    assert fused is not None, "inside the streaming kernel's envelope"
+    full = F.upsample_zero(compact, (h, w), 2)
+    ref = F.gemm(a, b, m, nn, k, True, False, act=C.ACT_ADD, mask_src=full.view(m, nn))
+    torch.cuda.synchronize()
+    assert torch.equal(fused, ref)
+    assert F.gemm_add_upsampled2(a[:, :32].contiguous(), b[:32].contiguous(), compact, (h, w)) is None     # K = 32: declined

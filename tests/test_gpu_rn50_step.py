@@ -168,10 +168,19 @@ def test_rn50_unit_backward_teacher_forced_vs_fp32(cuda, dtype):
     records = []
     orig = R.ConvBN.backward
 
-    def spy(self, dy, need_dx=True, dx_addend=None, dy_mask=None):
+    def stuffed(t3):
+        """("up2", compact [N,P,Q,C], (H, W)) -> the zero-stuffed [N,H,W,C] tensor it stands for."""
+        _, compact, (hh, ww) = t3
+        full = torch.zeros((compact.shape[0], hh, ww, compact.shape[3]), dtype=compact.dtype, device=compact.device)
+        full[:, ::2, ::2] = compact
+        return full
+
+    def spy(self, dy, need_dx=True, dx_addend=None, dy_mask=None, compact_dx=False):
         saved = self.saved
-        dx = orig(self, dy, need_dx=need_dx, dx_addend=dx_addend, dy_mask=dy_mask)
-        records.append((self, dy, dx_addend, dy_mask, saved, dx))
+        dx = orig(self, dy, need_dx=need_dx, dx_addend=dx_addend, dy_mask=dy_mask, compact_dx=compact_dx)
+        is_up2 = lambda v: isinstance(v, tuple) and v[0] == "up2"
+        records.append((self, dy, stuffed(dx_addend) if is_up2(dx_addend) else dx_addend, dy_mask, saved,
+                        stuffed(dx) if is_up2(dx) else dx))
         return dx
     R.ConvBN.backward = spy
     try:
