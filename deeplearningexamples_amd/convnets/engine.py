@@ -26,7 +26,7 @@ from .. import multi_tensor as mt
 from ..dlrm.engine import GradScalerState
 from ..utils.buckets import GradBuckets
 from ..utils import comm
-from .resnet import ResNet50
+from .resnet import Deferred, ResNet50
 
 
 def lr_cosine_policy(base_lr, warmup_length, epochs, end_lr=0.0):
@@ -141,6 +141,9 @@ class ResNetTrainer:
         # the stride-2 downsample branch's data gradient stays on its own grid and is added at the even pixels by conv1's
         # data-gradient kernel (no zero-stuffed tensor); DLE_RN50_FUSE_UP2=0 materialises it as before
         self.fuse_up2 = os.environ.get("DLE_RN50_FUSE_UP2", "1") != "0"
+        # BatchNorm-apply of bn2 / bn3 on the operand load of the consuming 1x1 convolution (conv + BN + ReLU as one unit,
+        # csrc/conv_bnload.hip); DLE_RN50_FUSE_BN=0 keeps the stand-alone apply passes
+        self.fuse_bn = os.environ.get("DLE_RN50_FUSE_BN", "1") != "0"
         self.stem.w2 = torch.zeros((64, 7, 8, 4), dtype=compute_dtype, device=self.dev)
         self.stem.gw_flat = self.gview["conv1.weight"]
         self.fc_w16 = torch.empty(model.fc.weight.shape, dtype=compute_dtype, device=self.dev)
@@ -246,20 +249,28 @@ class ResNetTrainer:
         self._pool_in_hw = a0.shape[1:3]
         h = m0
         bs = self.branch_stream
+        fuse = self.fuse_bn
         for (u1, u2, u3, ud) in self.blocks:
+            # conv + BN + ReLU as one unit where the consumer is a 1x1 convolution: bn2's apply runs inside conv3's kernel, bn3's
+            # (+ residual) inside the NEXT block's conv1 (csrc/conv_bnload.hip); `h` is then a Deferred whose applied form `h.y`
+            # exists after u1 has consumed it (side output of the fused kernel, or the stand-alone pass)
+            o1 = u1.forward(h)
+            hy = h.y if isinstance(h, Deferred) else h
             if ud is not None and bs is not None:
                 cur = torch.cuda.current_stream()
                 bs.wait_stream(cur)
                 self._branch_keep.clear()        # (what the branch stream produced earlier has been consumed before this point)
                 with torch.cuda.stream(bs):
-                    res = ud.forward(h)
-                o = u2.forward(u1.forward(h))
+                    res = ud.forward(hy)
+                o2 = u2.forward(o1, defer=fuse)
                 cur.wait_stream(bs)
                 self._branch_keep.append(res)    # allocated on the branch stream, read on this one: alive until the next fork
             else:
-                res = ud.forward(h) if ud is not None else h
-                o = u2.forward(u1.forward(h))
-            h = u3.forward(o, residual=res)
+                res = ud.forward(hy) if ud is not None else hy
+                o2 = u2.forward(o1, defer=fuse)
+            h = u3.forward(o2, residual=res, defer=fuse)
+        if isinstance(h, Deferred):
+            h = h.materialize()
         self._feat_hw = h.shape[1:3]
         self._pooled = F.avgpool_fwd(h)
         n = self._pooled.shape[0]

@@ -35,6 +35,30 @@ def _bn(c, device, zero_init=False):
     return m
 
 
+class Deferred:
+    """A unit's output BEFORE its BatchNorm-apply: the convolution result t, the batch statistics, and the residual the apply will
+    add.  The consumer either runs the apply inside its own convolution kernel (1x1 consumers: csrc/conv_bnload.hip -- conv + BN +
+    ReLU as one unit, models/resnet.py:148-175) or materialises it with the stand-alone pass.  Either way `y` (the applied 16-bit
+    output) and the unit's ReLU keep bits exist afterwards: the residual / downsample branches and the backward pass read them."""
+    __slots__ = ("unit", "t", "mean", "rstd", "residual", "y")
+
+    def __init__(self, unit, t, mean, rstd, residual):
+        self.unit, self.t, self.mean, self.rstd, self.residual, self.y = unit, t, mean, rstd, residual, None
+
+    def _done(self, y, mask):
+        u = self.unit
+        u.saved = (u.saved[0], self.t, mask, self.mean, self.rstd)
+        self.y = y
+
+    def materialize(self):
+        if self.y is None:
+            u = self.unit
+            y, mask = F.bn_fwd_apply(self.t, self.mean, self.rstd, u.bn.weight.data, u.bn.bias.data, residual=self.residual,
+                                     relu=u.relu, want_mask=True)
+            self._done(y, mask)
+        return self.y
+
+
 class ConvBN:
     """One conv + BN (+ ReLU) (+ residual) unit of the step: forward keeps what backward needs."""
 
@@ -52,15 +76,33 @@ class ConvBN:
         self.wgrad_stream = None                    # set by the trainer: weight gradients run beside the data-gradient chain
         self.keepalive = None                       # ... with the list that keeps their operands alive until the streams join
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, defer=False):
+        """x: the input tensor, or the producer's Deferred output -- a 1x1 stride-1 unit then applies the producer's BatchNorm
+        (+ residual) + ReLU on its own operand load (one kernel: csrc/conv_bnload.hip) where the shape allows, and materialises
+        it otherwise.  defer: return this unit's output as a Deferred (conv + statistics done, apply left to the consumer)."""
         # conv + batch statistics in one pass over the activation (the statistics come out of the convolution
         # epilogue), then normalise + residual + ReLU; the backward pass rebuilds the ReLU mask from 1 bit per element
-        if x.shape[-1] == 4:                        # stem on its 4-channel image
-            t, mean, rstd = F.stem_conv_fwd_bnstats(x, self.w2, self.bn.running_mean, self.bn.running_var, eps=self.bn.eps,
-                                                    momentum=self.bn.momentum)
-        else:
-            t, mean, rstd = F.conv2d_fwd_bnstats(x, self.w16, self.stride, self.pad, self.bn.running_mean,
-                                                 self.bn.running_var, eps=self.bn.eps, momentum=self.bn.momentum)
+        t = None
+        if isinstance(x, Deferred):
+            d, r = x, None
+            if self.k == 1 and self.stride == 1 and d.unit.relu and d.y is None:
+                r = F.conv1x1_bnload_fwd(d.t, d.residual, self.w16, d.mean, d.rstd, d.unit.bn.weight.data, d.unit.bn.bias.data,
+                                         self.bn.running_mean, self.bn.running_var, eps=self.bn.eps, momentum=self.bn.momentum)
+            if r is not None:
+                t, x, bits, mean, rstd = r
+                d._done(x, bits)
+            else:
+                x = d.materialize()
+        if t is None:
+            if x.shape[-1] == 4:                    # stem on its 4-channel image
+                t, mean, rstd = F.stem_conv_fwd_bnstats(x, self.w2, self.bn.running_mean, self.bn.running_var, eps=self.bn.eps,
+                                                        momentum=self.bn.momentum)
+            else:
+                t, mean, rstd = F.conv2d_fwd_bnstats(x, self.w16, self.stride, self.pad, self.bn.running_mean,
+                                                     self.bn.running_var, eps=self.bn.eps, momentum=self.bn.momentum)
+        if defer:
+            self.saved = (x, t, None, mean, rstd)
+            return Deferred(self, t, mean, rstd, residual)
         y, mask = F.bn_fwd_apply(t, mean, rstd, self.bn.weight.data, self.bn.bias.data, residual=residual,
                                  relu=self.relu, want_mask=True)
         self.saved = (x, t, mask, mean, rstd)

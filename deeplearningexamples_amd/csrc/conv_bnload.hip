@@ -1,0 +1,268 @@
+// Fused BatchNorm-apply (+ residual) + ReLU + 1x1 convolution for gfx950: the normalisation of the PRODUCER unit happens on the
+// operand load of the CONSUMER convolution -- the "conv + BN + ReLU as one unit" of the ResNet bottleneck
+// (Classification/ConvNets/image_classification/models/resnet.py:148-175: out = relu(bn2(.)) -> conv3; out = relu(bn3(.) +
+// residual) -> the next block's conv1; models/common.py:31-128 LayerBuilder.conv / batchnorm / activation).
+//
+//   y[m, :]   = relu(t[m, :] * sc + sh (+ res[m, :]))      sc = rstd * gamma, sh = beta - mean * sc   (the producer's BatchNorm)
+//   out[m, :] = y[m, :] W^T                                 (this unit's 1x1 convolution, K -> N channels)
+//   side outputs: y (16-bit, what the weight gradient and the residual / downsample branches read), its keep bits (1 bit per
+//   element, the backward pass's ReLU mask), column sums / sums of squares of the ROUNDED out (this unit's BatchNorm statistics).
+// Separate passes read t (+ res), write y, and the convolution reads y again: the fused form never re-reads y.  Arithmetic and
+// rounding points are those of bn_apply_pf_kernel followed by gemm_expand_kernel: y, the bits, out and the statistics are
+// bit-identical to the two-launch sequence (tests/test_gpu_conv_bnload.py).
+//
+// Built like gemm_expand.hip (streaming kernel, weight tile resident in LDS, A fragments global -> VGPR in MFMA layout): the
+// BatchNorm runs on the A fragments in registers.  A lane's fragment of k step ks is 8 consecutive channels (ks * 32 + kg * 8)
+// of one row: one 16-byte load of t (and of res), one 16-byte store of y, one byte of keep bits; scale / shift come from LDS.
+#include "gemm_tiles.h"
+
+#define BL_PAD 8
+
+struct BnlArgs {
+  const unsigned short* T;      // [M, K] pre-BatchNorm activations of the producer
+  const unsigned short* R;      // residual [M, K] or NULL
+  const unsigned short* B;      // weights [N, K], k contiguous
+  unsigned short* C;            // [M, N]
+  unsigned short* Y;            // [M, K]
+  unsigned char* bits;          // [M * K / 8]
+  const float* mean; const float* rstd; const float* gamma; const float* beta;
+  float* stats;                 // [groups][2][N] or NULL
+  int M, N, K;
+  int row_tiles, groups, col_tiles;
+};
+
+template <int DT> struct BlMfma;
+template <> struct BlMfma<DLE_F16> {
+  static __device__ __forceinline__ float4_t run(ushort8_t a, ushort8_t b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct BlMfma<DLE_BF16> {
+  static __device__ __forceinline__ float4_t run(ushort8_t a, ushort8_t b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+// LDS row of local output column nl: the rows of two 16-column MFMA blocks are interleaved so that the pair leaves a lane with 8
+// consecutive output columns (gemm_expand.hip)
+__device__ __forceinline__ int bl_pos(int nl) {
+  const int j = nl >> 5, r = nl & 31;
+  return 32 * j + 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
+}
+
+// NB: 16-column blocks per workgroup tile (4 -> 64 output columns, 8 -> 128); NW wavefronts of 16 rows each.
+template <int DT, int KS, bool RES, int NB, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_bnload_kernel(BnlArgs p) {
+  constexpr int K = KS * 32, LDW = K + BL_PAD, TM = NW * 16, TN = NB * 16, NP = NB / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* wl = (unsigned short*)smem_raw;                      // [TN][LDW]
+  float* scl = (float*)(smem_raw + TN * LDW * 2);                      // [K] scale | [K] shift
+  float* shl = scl + K;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, kg = lane >> 4;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tn = slot % p.col_tiles, g = (slot / p.col_tiles) * 8 + xcd;
+  const int n0 = tn * TN;
+  {
+    constexpr int CPR = K / 8;
+    for (int c = threadIdx.x; c < TN * CPR; c += NW * 64) {
+      const int nl = c / CPR, kc = c - nl * CPR;
+      const ushort8_t v = *(const ushort8_t*)(p.B + (long long)(n0 + nl) * K + kc * 8);
+      *(ushort8_t*)(wl + bl_pos(nl) * LDW + kc * 8) = v;
+    }
+    for (int c = threadIdx.x; c < K; c += NW * 64) {
+      const float sc = p.rstd[c] * p.gamma[c];                         // (the same two roundings as bn_apply_pf_kernel)
+      scl[c] = sc;
+      shl[c] = p.beta[c] - p.mean[c] * sc;
+    }
+  }
+  __syncthreads();
+  float s1[NB * 4], s2[NB * 4];
+#pragma unroll
+  for (int i = 0; i < NB * 4; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  const unsigned short* wrow = wl + fr * LDW + kg * 8;
+  const int mrow = wave * 16 + fr;
+  const bool writer = tn == 0;                                         // one column tile writes the side outputs
+  ushort8_t fa[KS], fr_[RES ? KS : 1];
+  auto load_rows = [&](int m) __attribute__((always_inline)) {
+    const long long mr = m < p.M ? m : p.M - 1;
+    const long long o = mr * K + kg * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      fa[ks] = *(const ushort8_t*)(p.T + o + ks * 32);
+      if (RES) fr_[ks] = *(const ushort8_t*)(p.R + o + ks * 32);
+    }
+  };
+  load_rows(g * TM + mrow);
+  for (int tm = g; tm < p.row_tiles; tm += p.groups) {
+    const int m_cur = tm * TM + mrow;
+    const bool live = m_cur < p.M;
+    // ---- the producer's BatchNorm (+ residual) + ReLU on the fragments; side outputs
+    {
+      const long long o = (long long)(live ? m_cur : 0) * K + kg * 8;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4_t c0 = *(const float4_t*)(scl + ks * 32 + kg * 8), c1 = *(const float4_t*)(scl + ks * 32 + kg * 8 + 4);
+        const float4_t h0 = *(const float4_t*)(shl + ks * 32 + kg * 8), h1 = *(const float4_t*)(shl + ks * 32 + kg * 8 + 4);
+        const float sc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        const float sh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        float xf[8], rf[8], of[8];
+        unpack8<DT>(fa[ks], xf);
+        if (RES) unpack8<DT>(fr_[ks], rf);
+        unsigned bits = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float v = xf[k] * sc[k] + sh[k];
+          if (RES) v += rf[k];
+          v = v > 0.f ? v : 0.f;
+          of[k] = v;
+          bits |= (v > 0.f ? 1u : 0u) << k;
+        }
+        fa[ks] = pack8<DT>(of);
+        if (writer && live) {
+          *(ushort8_t*)(p.Y + o + ks * 32) = fa[ks];
+          p.bits[(o + ks * 32) >> 3] = (unsigned char)bits;
+        }
+      }
+    }
+    // ---- product
+    float4_t acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const ushort8_t fw = *(const ushort8_t*)(wrow + b * 16 * LDW + ks * 32);
+        acc[b] = BlMfma<DT>::run(fw, fa[ks], acc[b]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    load_rows((tm + p.groups) * TM + mrow);          // the next tile's rows, in front of this tile's output stores (vmcnt is in order)
+    // ---- epilogue: pair j = blocks 2j, 2j + 1 -> columns n0 + 32 j + 8 kg + {0..7}
+    ushort8_t outv[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r] = acc[2 * j][r]; v[4 + r] = acc[2 * j + 1][r]; }
+      const ushort8_t ov = pack8<DT>(v);
+      outv[j] = ov;
+      float z[8];
+      unpack8<DT>(ov, z);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float zz = live ? z[r] : 0.f;
+        s1[8 * j + r] += zz;
+        s2[8 * j + r] += zz * zz;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      // full 128-byte lines per store instruction (gemm_expand.hip): neighbouring rows swap half of their pieces
+      const bool odd = fr & 1;
+      const bool live_other = (odd ? m_cur - 1 : m_cur + 1) < p.M;
+      const long long o_own = (long long)m_cur * p.N + n0 + kg * 8;
+      const long long o_other = odd ? o_own - p.N : o_own + p.N;
+#pragma unroll
+      for (int h = 0; h < NP / 2; ++h) {
+        const uint4_t mine0 = __builtin_bit_cast(uint4_t, outv[2 * h]), mine1 = __builtin_bit_cast(uint4_t, outv[2 * h + 1]);
+        const uint4_t give = odd ? mine0 : mine1;
+        uint4_t got;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) got[q] = (unsigned)__shfl_xor((int)give[q], 1, 64);
+        const uint4_t first = odd ? got : mine0, second = odd ? mine1 : got;
+        const long long o_first = (odd ? o_other : o_own) + 64 * h + (odd ? 32 : 0);
+        const long long o_second = (odd ? o_own : o_other) + 64 * h + (odd ? 32 : 0);
+        const bool live_first = odd ? live_other : live, live_second = odd ? live : live_other;
+        if (live_first) *(uint4_t*)(p.C + o_first) = first;
+        if (live_second) *(uint4_t*)(p.C + o_second) = second;
+      }
+    }
+  }
+  if (p.stats) {
+#pragma unroll
+    for (int i = 0; i < NB * 4; ++i) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        s1[i] += __shfl_xor(s1[i], o, 64);
+        s2[i] += __shfl_xor(s2[i], o, 64);
+      }
+    }
+    __syncthreads();
+    float* red = (float*)smem_raw;                                      // [NW waves][2][TN]
+    if (fr == 0) {
+#pragma unroll
+      for (int i = 0; i < NB * 4; ++i) {
+        const int col = 32 * (i >> 3) + 8 * kg + (i & 7);
+        red[(wave * 2 + 0) * TN + col] = s1[i];
+        red[(wave * 2 + 1) * TN + col] = s2[i];
+      }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * TN; t += NW * 64) {
+      const int which = t / TN, col = t - which * TN;
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) tot += red[(w * 2 + which) * TN + col];
+      p.stats[((long long)g * 2 + which) * p.N + n0 + col] = tot;
+    }
+  }
+}
+
+static int bl_tn(int N) { return (N % 128) == 0 ? 128 : 64; }
+// wavefronts per workgroup: 8 only where the weight tile is large (K = 256 x 128 columns: 66 KiB, two workgroups per CU); the
+// 64-column tiles of K = 256 (34 KiB, 140 registers: three wavefronts per SIMD) run three 4-wave workgroups per CU
+static int bl_nw(int K, int N) { return (K > 128 && bl_tn(N) == 128) ? 8 : 4; }
+
+// Number of statistics rows dle_conv1x1_bnload_fwd writes for (M, N, K); 0: the shape is outside the kernel's envelope.
+extern "C" int dle_conv1x1_bnload_groups(int M, int N, int K) {
+  if (M < 4096 || (K != 64 && K != 128 && K != 256) || (N % 64) != 0 || N < 64) return 0;
+  const int tm = bl_nw(K, N) * 16, row_tiles = (M + tm - 1) / tm, col_tiles = N / bl_tn(N);
+  // every column tile re-reads the rows (through L2) and REPEATS the BatchNorm arithmetic on them: with more than two column
+  // tiles the two-launch sequence wins (measured, batch-256 ResNet-50: 50176 x 1024 x 256 fused 87 us vs 12 + 55 us apart,
+  // 200704 x 512 x 128 96 vs 20 + 69; 802816 x 256 x 64 142 vs 46 + 127, 802816 x 64 x 256 + residual 301 vs 233 + 122)
+  if (col_tiles > 2) return 0;
+  const int per_cu = K > 128 ? (bl_tn(N) == 128 ? 2 : 3) : 4;
+  int groups = (256 * per_cu + col_tiles - 1) / col_tiles;
+  if (groups > row_tiles) groups = row_tiles;
+  return (groups + 7) / 8 * 8;
+}
+
+// out [M, N] = relu(bn(t) (+ res)) W^T with the side outputs y [M, K], bits [M K / 8] and the column statistics of out
+// (stats [dle_conv1x1_bnload_groups][2][N], may be NULL).  Returns 1 when launched, 0 outside the envelope (K in {64, 128, 256},
+// N a multiple of 64, M >= 4096, dense 16-byte aligned operands), > 1 on a launch error.
+extern "C" int dle_conv1x1_bnload_fwd(const void* t, const void* res, const void* w, void* out, void* y, void* bits, const float* mean,
+                                      const float* rstd, const float* gamma, const float* beta, float* stats, int64_t stats_bytes,
+                                      int M, int N, int K, int dtype, hipStream_t stream) {
+  static const char* pin = getenv("DLE_CONV_BNLOAD");
+  if (pin && atoi(pin) == 0) return 0;
+  if (dtype != DLE_F16 && dtype != DLE_BF16) return 0;
+  const int groups = dle_conv1x1_bnload_groups(M, N, K);
+  if (groups == 0 || !t || !w || !out || !y || !bits || !mean || !rstd || !gamma || !beta) return 0;
+  if (((((uintptr_t)t) | ((uintptr_t)res) | ((uintptr_t)w) | ((uintptr_t)out) | ((uintptr_t)y)) & 15) != 0) return 0;
+  if (stats && stats_bytes < (long long)groups * 2 * N * 4) { dle_set_error("conv1x1_bnload_fwd: statistics buffer too small"); return 2; }
+  BnlArgs p;
+  p.T = (const unsigned short*)t; p.R = (const unsigned short*)res; p.B = (const unsigned short*)w; p.C = (unsigned short*)out;
+  p.Y = (unsigned short*)y; p.bits = (unsigned char*)bits; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.stats = stats;
+  p.M = M; p.N = N; p.K = K;
+  const int TN = bl_tn(N), NWv = bl_nw(K, N), tm = NWv * 16;
+  p.row_tiles = (M + tm - 1) / tm; p.col_tiles = N / TN; p.groups = groups;
+  size_t lds = (size_t)TN * (K + BL_PAD) * 2 + 2 * K * 4;
+  if (lds < (size_t)NWv * 2 * TN * 4) lds = (size_t)NWv * 2 * TN * 4;
+  const dim3 grid((unsigned)(groups * p.col_tiles)), block(NWv * 64);
+#define BL_GO(DT, KS, RS, NBV, NWV) do { static bool attr_set = false; \
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_bnload_kernel<DT, KS, RS, NBV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set = true; } \
+    hipLaunchKernelGGL((conv_bnload_kernel<DT, KS, RS, NBV, NWV>), grid, block, lds, stream, p); } while (0)
+#define BL_NB(DT, KS, RS, NWV) do { if (TN == 128) BL_GO(DT, KS, RS, 8, NWV); else BL_GO(DT, KS, RS, 4, NWV); } while (0)
+#define BL_RES(DT, KS, NWV) do { if (res) BL_NB(DT, KS, true, NWV); else BL_NB(DT, KS, false, NWV); } while (0)
+#define BL_K(DT) do { if (K == 64) BL_RES(DT, 2, 4); else if (K == 128) BL_RES(DT, 4, 4); else if (NWv == 8) BL_RES(DT, 8, 8); else BL_RES(DT, 8, 4); } while (0)
+  if (dtype == DLE_F16) BL_K(DLE_F16); else BL_K(DLE_BF16);
+#undef BL_K
+#undef BL_RES
+#undef BL_NB
+#undef BL_GO
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { dle_set_error("conv1x1_bnload_fwd launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
+  return 1;
+}

@@ -633,6 +633,50 @@ def conv2d_fwd_bnstats(x, w, stride=1, pad=0, running_mean=None, running_var=Non
     return y, mean, rstd
 
 
+def conv1x1_bnload_fwd(t, res, w, mean, rstd, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+    """The producer's BatchNorm-apply (+ residual) + ReLU on the operand load of a 1x1 convolution (csrc/conv_bnload.hip).
+    t [.., K] pre-BatchNorm activations, res like t or None, w [N, 1, 1, K]; mean / rstd / gamma / beta: the PRODUCER's BatchNorm;
+    running_mean / running_var / eps / momentum: THIS convolution's BatchNorm (its batch statistics come out of the epilogue).
+    -> (out [.., N], y [.., K], bits, mean_out, rstd_out), or None when the shape is outside the kernel's envelope."""
+    C.require_cuda(t, res, w, mean, rstd, gamma, beta, running_mean, running_var)
+    k = t.shape[-1]
+    n = w.shape[0]
+    m = t.numel() // k
+    if not t.is_contiguous() or not w.is_contiguous() or w.numel() != n * k or w.dtype != t.dtype or \
+            (res is not None and (res.shape != t.shape or not res.is_contiguous() or res.dtype != t.dtype)):
+        raise ValueError("conv1x1_bnload_fwd: dense operands of one 16-bit dtype expected")
+    groups = C.lib().dle_conv1x1_bnload_groups(m, n, k)
+    if groups == 0:
+        return None
+    out = torch.empty(t.shape[:-1] + (n,), dtype=t.dtype, device=t.device)
+    y = torch.empty_like(t)
+    bits = torch.empty(t.numel() // 8, dtype=torch.uint8, device=t.device)
+    ws = splitk_workspace(t.device, (groups + 32) * 2 * n * 4)
+    part, fold = ws[:groups * 2 * n], ws[groups * 2 * n:(groups + 32) * 2 * n]
+    C.annotate(flops=2.0 * m * n * k, tag="bn+conv %dx%dx%d%s" % (m, n, k, "+res" if res is not None else ""),
+               bytes=float(t.numel() * (3 if res is not None else 2) + out.numel() + w.numel()) * 2 + bits.numel())
+    tm = C._timer
+    if tm is not None:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+    rc = C.lib().dle_conv1x1_bnload_fwd(C.ptr(t), C.ptr(res), C.ptr(w), C.ptr(out), C.ptr(y), C.ptr(bits), C.ptr(mean), C.ptr(rstd),
+                                        C.ptr(gamma), C.ptr(beta), C.ptr(part), part.numel() * 4, m, n, k, C.dt(t), C.stream())
+    if tm is not None:
+        e.record()
+        meta, tm.meta = tm.meta, None
+        if rc == 1:
+            tm.records.append(("dle_conv1x1_bnload_fwd", s, e, meta))
+    if rc == 0:
+        return None
+    if rc != 1:
+        C.check(rc - 1000 if rc > 1000 else -1, "dle_conv1x1_bnload_fwd")
+    mean_o = torch.empty(n, dtype=torch.float32, device=t.device)
+    rstd_o = torch.empty(n, dtype=torch.float32, device=t.device)
+    C.call("dle_bn_stats_from_partials", C.ptr(part), groups, m, n, float(eps), float(momentum), C.ptr(mean_o), C.ptr(rstd_o),
+           C.ptr(running_mean), C.ptr(running_var), C.ptr(fold), fold.numel() * 4, C.stream())
+    return out, y, bits, mean_o, rstd_o
+
+
 # ---- the ResNet stem on its own kernels (csrc/stem.hip): 4-channel image, packed weights
 def stem_pack_weight(w_master, out_dtype, out=None):
     """fp32 master of the stem convolution, a channels_last [64, 3, 7, 7] parameter (memory order [64][7][7][3]) -> the packed

@@ -255,6 +255,17 @@ int dle_bn_bwd_reduce(const void* dy, const void* y, const void* relu_mask, cons
 int dle_bn_bwd_apply(const void* dy, const void* y, const void* relu_mask, const void* x, void* dx, void* g_out,
                      const float* mean, const float* rstd, const float* gamma, const float* dgamma,
                      const float* dbeta, int64_t M, int C, int dtype, hipStream_t stream);
+/* ---- conv + BatchNorm + ReLU as ONE unit (csrc/conv_bnload.hip): the PRODUCER unit's BatchNorm-apply (+ residual) + ReLU runs on
+ * the operand load of the CONSUMER 1x1 convolution (models/resnet.py:148-175: relu(bn2(.)) -> conv3, relu(bn3(.) + residual) ->
+ * the next block's conv1; models/common.py:31-128).  out [M, N] = relu(t * sc + sh (+ res)) W^T with sc = rstd * gamma,
+ * sh = beta - mean * sc; side outputs y [M, K] (16-bit), bits [M*K/8] (bit k of byte i = y[8 i + k] > 0) and, when stats != NULL,
+ * the column sums / sums of squares of the rounded out ([dle_conv1x1_bnload_groups(M, N, K)][2][N], fold with
+ * dle_bn_stats_from_partials).  Bit-identical to dle_bn_fwd_apply followed by dle_conv2d_fwd_colstats.  Returns 1 when launched,
+ * 0 when the shape is outside the envelope (K in {64, 128, 256}, N % 64 == 0, M >= 4096), > 1 on error.                      */
+int dle_conv1x1_bnload_groups(int M, int N, int K);
+int dle_conv1x1_bnload_fwd(const void* t, const void* res, const void* w, void* out, void* y, void* bits, const float* mean,
+                           const float* rstd, const float* gamma, const float* beta, float* stats, int64_t stats_bytes, int M,
+                           int N, int K, int dtype, hipStream_t stream);
 /* ---- the ResNet stem (csrc/stem.hip): conv7x7 / stride 2 / pad 3 of a 3-channel image, forward (+ BatchNorm partial sums) and
  * weight gradient, on a 4-channel NHWC image (dle_nchw_to_nhwc with C_padded = 4: 8 bytes per pixel, channel 3 zero).
  *   replaces cuDNN behind builder.conv7x7(3, 64, stride=2) + bn1's statistics: Classification/ConvNets/image_classification/
