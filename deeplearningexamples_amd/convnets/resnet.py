@@ -145,8 +145,11 @@ class ConvBN:
                 F.stem_conv_wgrad(gt, x, self.gw_flat)
             elif self.k == 1 and self.stride == 1:
                 m = n * h * w
-                F.gemm(gt.view(m, self.cout), x.view(m, c), self.cout, c, m, False, False, out=self.gw.view(self.cout, c),
-                       splitk=F.pick_splitk(self.cout, c, m, target_blocks=1024))
+                # long contraction, small output: the streaming kernel that holds the whole Ko x C block in one workgroup
+                # (csrc/wgrad1x1.hip); every other shape: split-K tile GEMM
+                if not F.wgrad1x1(gt.view(m, self.cout), x.view(m, c), self.gw.view(self.cout, c)):
+                    F.gemm(gt.view(m, self.cout), x.view(m, c), self.cout, c, m, False, False, out=self.gw.view(self.cout, c),
+                           splitk=F.pick_splitk(self.cout, c, m, target_blocks=1024))
             else:
                 F.conv2d_wgrad(gt, x, (self.k, self.k), self.stride, self.pad, out=self.gw)
         dx = None

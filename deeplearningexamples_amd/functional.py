@@ -482,6 +482,23 @@ def upsample_zero(compact, in_hw, stride):
     return out
 
 
+def _timed_optional(name, fn, args):
+    """A C-ABI call that may DECLINE (return 0) cannot go through C.call (which raises on non-zero): run it, and when bench.py's
+    kernel timer is installed record it like C.call does (event pair on the launch stream, replayable) if it launched.  -> rc"""
+    tm = C._timer
+    if tm is None:
+        return fn(*args)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    rc = fn(*args)
+    e.record()
+    meta, tm.meta = tm.meta, None
+    if rc == 1:
+        tm.records.append((name, s, e, meta))
+        tm.last[(name, meta.get("tag") if meta else None)] = (fn, args, torch.cuda.current_stream())
+    return rc
+
+
 def conv1x1_s2_dgrad_compact(dy, w):
     """The data gradient of a 1x1 stride-2 convolution ON ITS OWN GRID: dy [N,P,Q,Ko], w [Ko,1,1,C] -> [N,P,Q,C] (the non-zero
     pixels of dx; conv2d_dgrad zero-stuffs it to [N,2P,2Q,C], gemm_add_upsampled2 adds it without materialising that)."""
@@ -504,22 +521,33 @@ def gemm_add_upsampled2(a, b, compact, hw):
         raise ValueError("gemm_add_upsampled2: shape / layout mismatch")
     out = torch.empty((m, nn), dtype=a.dtype, device=a.device)
     C.annotate(flops=2.0 * m * nn * k, tag="%dx%dx%d+up2" % (m, nn, k), bytes=float(a.numel() + b.numel() + out.numel() + compact.numel()) * 2)
-    t = C._timer
-    if t is not None:          # (a call that may decline is not a C.call: record it by hand when it launches)
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-    rc = C.lib().dle_gemm_expand_add_up2(C.ptr(a), C.ptr(b), C.ptr(out), C.ptr(compact), m, nn, k, a.stride(0), b.stride(0), nn, nn, 0,
-                                         h, wd, C.dt(a), C.stream())
-    if t is not None:
-        e.record()
-        meta, t.meta = t.meta, None
-        if rc == 1:
-            t.records.append(("dle_gemm", s, e, meta))
+    rc = _timed_optional("dle_gemm", C.lib().dle_gemm_expand_add_up2,
+                         (C.ptr(a), C.ptr(b), C.ptr(out), C.ptr(compact), m, nn, k, a.stride(0), b.stride(0), nn, nn, 0, h, wd, C.dt(a),
+                          C.stream()))
     if rc == 0:
         return None
     if rc != 1:
         C.check(rc - 1000 if rc > 1000 else rc, "dle_gemm_expand_add_up2")
     return out
+
+
+def wgrad1x1(dy2d, x2d, out, accumulate=False):
+    """out [Ko, C] fp32 (+)= dy2d [M, Ko]^T x2d [M, C] on the streaming weight-gradient kernel (csrc/wgrad1x1.hip).  Returns False
+    when the shape is outside its envelope (the caller then uses gemm() with split-K)."""
+    C.require_cuda(dy2d, x2d, out)
+    m, ko = dy2d.shape
+    c = x2d.shape[1]
+    if x2d.shape[0] != m or not dy2d.is_contiguous() or not x2d.is_contiguous() or not out.is_contiguous() or \
+            out.numel() != ko * c or out.dtype != torch.float32 or dy2d.dtype != x2d.dtype:
+        return False
+    ws = splitk_workspace(dy2d.device, int(C.lib().dle_wgrad1x1_workspace()))
+    C.annotate(flops=2.0 * m * ko * c, tag="%dx%dx%d" % (ko, c, m), bytes=float(dy2d.numel() + x2d.numel()) * 2 + out.numel() * 4.0)
+    # (recorded in the family of the split-K GEMM it replaces: the 1x1 gradients)
+    rc = _timed_optional("dle_gemm", C.lib().dle_wgrad1x1_try,
+                         (C.ptr(dy2d), C.ptr(x2d), C.ptr(out), m, ko, c, C.dt(dy2d), int(accumulate), C.ptr(ws), ws.numel() * 4, C.stream()))
+    if rc > 1:
+        C.check(rc - 1000 if rc > 1000 else -1, "dle_wgrad1x1_try")
+    return rc == 1
 
 
 def conv2d_wgrad(dy, x, rs, stride=1, pad=0, out=None, accumulate=False, splitk=None):
@@ -655,17 +683,9 @@ def conv1x1_bnload_fwd(t, res, w, mean, rstd, gamma, beta, running_mean=None, ru
     part, fold = ws[:groups * 2 * n], ws[groups * 2 * n:(groups + 32) * 2 * n]
     C.annotate(flops=2.0 * m * n * k, tag="bn+conv %dx%dx%d%s" % (m, n, k, "+res" if res is not None else ""),
                bytes=float(t.numel() * (3 if res is not None else 2) + out.numel() + w.numel()) * 2 + bits.numel())
-    tm = C._timer
-    if tm is not None:
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-    rc = C.lib().dle_conv1x1_bnload_fwd(C.ptr(t), C.ptr(res), C.ptr(w), C.ptr(out), C.ptr(y), C.ptr(bits), C.ptr(mean), C.ptr(rstd),
-                                        C.ptr(gamma), C.ptr(beta), C.ptr(part), part.numel() * 4, m, n, k, C.dt(t), C.stream())
-    if tm is not None:
-        e.record()
-        meta, tm.meta = tm.meta, None
-        if rc == 1:
-            tm.records.append(("dle_conv1x1_bnload_fwd", s, e, meta))
+    rc = _timed_optional("dle_conv1x1_bnload_fwd", C.lib().dle_conv1x1_bnload_fwd,
+                         (C.ptr(t), C.ptr(res), C.ptr(w), C.ptr(out), C.ptr(y), C.ptr(bits), C.ptr(mean), C.ptr(rstd), C.ptr(gamma),
+                          C.ptr(beta), C.ptr(part), part.numel() * 4, m, n, k, C.dt(t), C.stream()))
     if rc == 0:
         return None
     if rc != 1:

@@ -127,6 +127,15 @@ int dle_conv2d_dgrad(const void* dy, const void* w, void* dx, const void* addend
 int dle_conv2d_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, int C, int Ko, int R, int S,
                      int stride, int pad, int dtype, int splitk, int accumulate, void* workspace,
                      int64_t workspace_bytes, hipStream_t stream);
+/* dw [Ko, C] fp32 (+)= dy [M, Ko]^T x [M, C] for the 1x1 convolutions whose whole output fits one workgroup's accumulators
+ * ((Ko, C) in {(256,64), (64,256), (64,64), (128,256), (256,128), (512,128), (128,512)}, M >= 8192): a streaming kernel that reads
+ * every operand byte once (csrc/wgrad1x1.hip; replaces cuDNN's bwd-filter behind the 1x1 nn.Conv2d of models/resnet.py:148-175).
+ * Returns 1 when launched, 0 outside the envelope (use dle_gemm with split-K); workspace >= dle_wgrad1x1_workspace() bytes.
+ * dle_wgrad1x1_mode(0 / 1): off / on for A/B measurements. */
+int64_t dle_wgrad1x1_workspace(void);
+int dle_wgrad1x1_mode(int mode);
+int dle_wgrad1x1_try(const void* dy, const void* x, float* dw, int M, int Ko, int C, int dtype, int accumulate, void* workspace,
+                     int64_t workspace_bytes, hipStream_t stream);
 /* 3x3 / stride 1 / pad 1 weight gradients with C, Ko multiples of 64 run on the halo-tile kernel of csrc/conv3x3_wgrad.hip when the
  * workspace holds dle_conv3x3_wgrad_workspace() bytes (256 partial blocks of 64 x 9 x 64 fp32, folded in a fixed order);
  * dle_conv3x3_wgrad_mode(0 / 1) switches it off / on for A/B measurements (returns the previous value). */

@@ -29,8 +29,9 @@ if key is None:
     roof, _ = bench.roofline_from(timer, 1, a.workload, spp, 1.0)
     key = roof["heaviest_shape"]
 name, tag = (key[:key.index("[")], key[key.index("[") + 1:-1]) if "[" in key else (key, None)
-fn, cargs = timer.last[(name, tag)]
-for _ in range(a.iters):
-    fn(*cargs)
+fn, cargs, st = timer.last[(name, tag)]
+with torch.cuda.stream(st):
+    for _ in range(a.iters):
+        fn(*cargs)
 torch.cuda.synchronize()
 print(json.dumps({"replayed": key, "iters": a.iters}))
