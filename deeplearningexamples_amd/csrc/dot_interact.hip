@@ -92,31 +92,37 @@ __global__ __launch_bounds__(256) void dot_fwd_mfma(const unsigned short* __rest
 #define DOT_BWD_USTRIDE 40   // halves per U row (32 + 8 pad -> 80 B, keeps 16 B alignment)
 // NB = 32-wide column blocks of the gradient kept in accumulators (C <= 32 NB); sized per launch so that a C = 128
 // sample costs 64 accumulator registers, not the 128 of the C = 256 maximum (which left one wave per SIMD).
+// Persistent form: a wavefront walks samples b = wave, wave + #waves, ... on its OWN LDS slice (no workgroup barrier: LDS operations of
+// one wavefront execute in order), and the loads of sample b + #waves are requested -- into registers -- before the products of
+// sample b.  The one-shot form was a ~13 us chain per sample (HBM round trip -> LDS -> unrank -> MFMA -> stage -> store) hidden only
+// by three workgroups per CU: 273 us for batch 65536 (3.5 TB/s).
 template <int DT, int NB>
 __global__ __launch_bounds__(256) void dot_bwd_mfma(const unsigned short* __restrict__ x,
                                                     const unsigned short* __restrict__ ug,
                                                     unsigned short* __restrict__ grad,
                                                     unsigned short* __restrict__ mlp_grad, int B,
-                                                    int R, int C, int OW, float* __restrict__ found_inf) {
+                                                    int R, int C_rt, int OW, float* __restrict__ found_inf) {
+  constexpr int C = 32 * NB;                             // (the launcher instantiates NB = C / 32: row arithmetic is shifts)
+  (void)C_rt;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + wave;
   unsigned bad = 0;                                      // OR of the exponent-all-ones tests of the 16-bit values written
-  const int XS = C + 8;                                  // halves per staged X row
-  const size_t per_wave = (size_t)32 * XS + 32 * DOT_BWD_USTRIDE;
+  constexpr int XS = C + 8;                              // halves per staged X row
+  const size_t per_wave = (size_t)32 * XS + 32 * DOT_BWD_USTRIDE + 256;
   unsigned short* xs = (unsigned short*)smem_raw + wave * per_wave;
   unsigned short* us = xs + 32 * XS;
+  unsigned short* ms = us + 32 * DOT_BWD_USTRIDE;        // upstream[:, :C] of the sample (bottom-MLP gradient / row-0 addend)
   const int row = lane & 31, h = lane >> 5;
-  const bool act = b < B;
   const int ntril = R * (R - 1) / 2;
-  // Prologue.  Every global load of the sample -- the 2 * NB 16-byte pieces of X per lane and the <= 8 pairwise-gradient
-  // values per lane -- is requested up front from UNCONDITIONAL (clamped) addresses and masked afterwards: written as
-  // "if (row < R) v = load; store to LDS" in a counted loop, hipcc kept one load in flight per lane (load, wait, ds_write)
-  // and the kernel was bound by ~14 dependent memory round trips per sample (2.4 TB/s).
-  const int cpr = C >> 3;                                // 16-byte chunks per row
-  ushort8_t xv[2 * NB];
+  constexpr int cpr = C >> 3;                            // 16-byte chunks per row
+  constexpr int nb_n = NB;                               // 32-wide column blocks (<= 8)
+  const int nwaves = gridDim.x * 4;
+  // Every global load of a sample -- the 2 * NB 16-byte pieces of X per lane, the <= 8 pairwise-gradient values per lane and the
+  // C leading entries of the upstream row -- is requested from UNCONDITIONAL (clamped) addresses and masked afterwards (loads under
+  // run-time conditions are serialised by hipcc's wait-count pass).
+  ushort8_t xv[2 * NB], mv;
   unsigned short tv[8];
-  if (act) {
+  auto issue = [&](int b) __attribute__((always_inline)) {
     const unsigned short* xb = x + (size_t)b * R * C;
 #pragma unroll
     for (int it = 0; it < 2 * NB; ++it) {
@@ -124,15 +130,19 @@ __global__ __launch_bounds__(256) void dot_bwd_mfma(const unsigned short* __rest
       const int rr = q / cpr, cc = q - rr * cpr;
       const bool ok = q < 32 * cpr && rr < R;
       xv[it] = *(const ushort8_t*)(xb + (ok ? (size_t)rr * C + cc * 8 : 0));
-      if (!ok) xv[it] = ushort8_t{0, 0, 0, 0, 0, 0, 0, 0};
     }
-    const unsigned short* ut = ug + (size_t)b * OW + C;
+    const unsigned short* ub = ug + (size_t)b * OW;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int t = lane + 64 * it;
-      tv[it] = ut[t < ntril ? t : 0];
+      tv[it] = ub[C + (t < ntril ? t : 0)];
     }
-    // zero U, stage X (pad rows R..31 are zeros)
+    mv = *(const ushort8_t*)(ub + (lane * 8 < C ? lane * 8 : 0));
+  };
+  int b = blockIdx.x * 4 + wave;
+  if (b < B) issue(b);
+  for (; b < B; b += nwaves) {
+    // ---- commit this sample's operands to the wavefront's LDS slice: zero U, stage X (pad rows R..31 are zeros), upstream head
     for (int q = lane; q < 32 * DOT_BWD_USTRIDE / 8; q += 64) {
       ushort8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
       *(ushort8_t*)(us + q * 8) = z;
@@ -142,18 +152,12 @@ __global__ __launch_bounds__(256) void dot_bwd_mfma(const unsigned short* __rest
       const int q = lane + 64 * it;
       if (q < 32 * cpr) {
         const int rr = q / cpr, cc = q - rr * cpr;
-        *(ushort8_t*)(xs + rr * XS + cc * 8) = xv[it];
+        const ushort8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+        *(ushort8_t*)(xs + rr * XS + cc * 8) = rr < R ? xv[it] : z;
       }
     }
-    // bottom-MLP gradient = first C entries of the upstream gradient
-    const unsigned short* ub = ug + (size_t)b * OW;
-    if (mlp_grad) {
-      unsigned short* mg = mlp_grad + (size_t)b * C;
-      for (int q = lane * 8; q < C; q += 512) *(ushort8_t*)(mg + q) = *(const ushort8_t*)(ub + q);
-    }
-  }
-  __syncthreads();
-  if (act) {
+    if (lane * 8 < C) *(ushort8_t*)(ms + lane * 8) = mv;
+    if (mlp_grad && lane * 8 < C) *(ushort8_t*)(mlp_grad + (size_t)b * C + lane * 8) = mv;   // bottom-MLP gradient = upstream[:, :C]
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int t = lane + 64 * it;
@@ -164,15 +168,14 @@ __global__ __launch_bounds__(256) void dot_bwd_mfma(const unsigned short* __rest
         us[j * DOT_BWD_USTRIDE + i] = tv[it];
       }
     }
-  }
-  __syncthreads();
-  const int nb_n = C >> 5;   // 32-wide column blocks (<= 8)
-  float16_t acc[NB];
-  if (act) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // ---- the next sample's loads fly under this sample's products and stores (xv / tv / mv are free again)
+    if (b + nwaves < B) issue(b + nwaves);
     // grad = U X.  U rows are k-contiguous in LDS (one 16-byte read per fragment); X is the contraction-strided
     // operand, B(n, k) = X[k][n], read with the LDS transpose read (4 k lines x 4 columns per 16-lane group) instead
     // of 16 two-byte reads.  Operands are swapped (D = X^T-fragment x U-fragment) so that a lane owns 4 CONSECUTIVE
     // columns of one gradient row: register r <-> column 8 (r >> 2) + 4 h + (r & 3), lane & 31 <-> row i.
+    float16_t acc[NB];
     const ushort8_t a0 = *(const ushort8_t*)(us + row * DOT_BWD_USTRIDE + h * 8);
     const ushort8_t a1 = *(const ushort8_t*)(us + row * DOT_BWD_USTRIDE + 16 + h * 8);
     const int tg = lane >> 4, ti = lane & 15;
@@ -198,44 +201,42 @@ __global__ __launch_bounds__(256) void dot_bwd_mfma(const unsigned short* __rest
         acc[nb] = Mfma32<DT>::run(bf[1], a1, acc[nb]);
       }
     }
-  }
-  __syncthreads();   // every B-fragment read is done: reuse xs as the output stage
-  if (act && row < R) {
-    typedef __attribute__((ext_vector_type(4))) unsigned short ushort4_t;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // every B-fragment read is done: reuse xs as the output stage
+    if (row < R) {
+      typedef __attribute__((ext_vector_type(4))) unsigned short ushort4_t;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      if (nb < nb_n) {
+      for (int nb = 0; nb < NB; ++nb) {
+        if (nb < nb_n) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = nb * 32 + 8 * q + 4 * h;
-          float v[4];
+          for (int q = 0; q < 4; ++q) {
+            const int n = nb * 32 + 8 * q + 4 * h;
+            float v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[nb][q * 4 + e];
-          // fused form (mlp_grad == NULL): row 0 also receives upstream[:, :C] (what autograd adds later)
-          if (!mlp_grad && row == 0) {
+            for (int e = 0; e < 4; ++e) v[e] = acc[nb][q * 4 + e];
+            // fused form (mlp_grad == NULL): row 0 also receives upstream[:, :C] (what autograd adds later)
+            if (!mlp_grad && row == 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += Elem<DT>::to_f32(ug[(size_t)b * OW + n + e]);
+              for (int e = 0; e < 4; ++e) v[e] += Elem<DT>::to_f32(ms[n + e]);
+            }
+            ushort4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o[e] = Elem<DT>::from_f32(v[e]);
+              constexpr unsigned EXPM = DT == DLE_F16 ? 0x7C00u : 0x7F80u;
+              bad |= ((unsigned)o[e] & EXPM) == EXPM;
+            }
+            *(ushort4_t*)(xs + row * XS + n) = o;
           }
-          ushort4_t o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o[e] = Elem<DT>::from_f32(v[e]);
-            constexpr unsigned EXPM = DT == DLE_F16 ? 0x7C00u : 0x7F80u;
-            bad |= ((unsigned)o[e] & EXPM) == EXPM;
-          }
-          *(ushort4_t*)(xs + row * XS + n) = o;
         }
       }
     }
-  }
-  __syncthreads();
-  if (act) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     unsigned short* gb = grad + (size_t)b * R * C;
-    const int cpr = C >> 3;
     for (int q = lane; q < R * cpr; q += 64) {
       const int rr = q / cpr, cc = q - rr * cpr;
       *(ushort8_t*)(gb + (size_t)rr * C + cc * 8) = *(const ushort8_t*)(xs + rr * XS + cc * 8);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the slice is re-staged at the top of the next trip
   }
   // GradScaler's inf / nan test on the gradient this kernel just produced (the values as stored, like a pass over the
   // tensor would see them): the train step's separate 450 MB sweep of the embedding gradient goes away
@@ -379,11 +380,15 @@ extern "C" int dle_dot_interact_bwd_checked(const void* x, const void* upstream,
   if (batch == 0) return 0;
   DLE_CHECK_ARG(x && upstream && grad, "dot_interact_bwd: null pointer");
   const int OW = out_width(rows, cols);
-  const bool fast = !force_generic && dtype != DLE_F32 && rows <= 32 && (cols % 32) == 0 && cols <= 256 &&
+  const bool fast = !force_generic && dtype != DLE_F32 && rows <= 32 && (cols == 32 || cols == 64 || cols == 128 || cols == 256) &&
                     aligned16(x) && aligned16(upstream) && aligned16(grad) && aligned16(mlp_grad);   /* NULL is aligned */
   if (fast) {
-    const size_t lds = (size_t)4 * (32 * (cols + 8) + 32 * DOT_BWD_USTRIDE) * 2;
-    dim3 grid((batch + 3) / 4), block(256);
+    const size_t lds = (size_t)4 * (32 * (cols + 8) + 32 * DOT_BWD_USTRIDE + 256) * 2;
+    // persistent: two workgroups per CU (180 registers at C = 128), each wavefront walks its samples
+    static const int per_cu = getenv("DLE_DOT_BWD_WG_PER_CU") ? atoi(getenv("DLE_DOT_BWD_WG_PER_CU")) : 2;
+    int nblk = (batch + 3) / 4;
+    if (nblk > 256 * per_cu) nblk = 256 * per_cu;
+    dim3 grid(nblk), block(256);
 #define GO(DT, NB) hipLaunchKernelGGL((dot_bwd_mfma<DT, NB>), grid, block, lds, stream, (const unsigned short*)x, \
                          (const unsigned short*)upstream, (unsigned short*)grad, (unsigned short*)mlp_grad, batch, rows, cols, OW, found_inf)
 #define PICK(DT) do { if (cols <= 32) GO(DT, 1); else if (cols <= 64) GO(DT, 2); else if (cols <= 128) GO(DT, 4); else GO(DT, 8); } while (0)
