@@ -62,6 +62,7 @@ _SIGS = {
                                         c_int, c_int, c_int, c_void_p]),
     "dle_conv1x1_bnload_groups": (c_int, [c_int, c_int, c_int]),
     "dle_conv1x1_bnload_fwd": (c_int, [c_void_p] * 11 + [c_i64, c_int, c_int, c_int, c_int, c_void_p]),
+    "dle_bn_relu_maxpool_fwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dle_wgrad1x1_workspace": (c_i64, []),
     "dle_wgrad1x1_mode": (c_int, [c_int]),
     "dle_wgrad1x1_try": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_i64, c_void_p]),

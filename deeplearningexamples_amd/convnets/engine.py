@@ -244,9 +244,16 @@ class ResNetTrainer:
     def forward(self, images):
         """images fp32 NCHW (as produced by the reference's loaders) -> fp32 logits [N, classes]."""
         x = self._stem_image(self._input(images))
-        a0 = self.stem.forward(x)
-        m0, self._amax = F.maxpool_fwd(a0)
-        self._pool_in_hw = a0.shape[1:3]
+        d0 = self.stem.forward(x, defer=self.fuse_bn)
+        if isinstance(d0, Deferred) and d0.t.shape[1] % 2 == 0 and d0.t.shape[2] % 2 == 0:
+            # bn1 + ReLU + max pooling in one pass: the stem's 16-bit activation is never written (csrc/convnet.hip)
+            m0, self._amax, mask0 = F.bn_relu_maxpool_fwd(d0.t, d0.mean, d0.rstd, self.stem.bn.weight.data, self.stem.bn.bias.data)
+            d0._done(None, mask0)
+            self._pool_in_hw = d0.t.shape[1:3]
+        else:
+            a0 = d0.materialize() if isinstance(d0, Deferred) else d0
+            m0, self._amax = F.maxpool_fwd(a0)
+            self._pool_in_hw = a0.shape[1:3]
         h = m0
         bs = self.branch_stream
         fuse = self.fuse_bn

@@ -1053,6 +1053,158 @@ __global__ __launch_bounds__(256) void maxpool_bwd_k3s2_kernel(const unsigned sh
   }
 }
 
+// The same pooling backward with one thread per 2 x 2 PATCH of input pixels (2 p', 2 q') .. (2 p' + 1, 2 q' + 1): the patch is
+// covered by the four windows (p', q'), (p', q' + 1), (p' + 1, q'), (p' + 1, q' + 1) and by no other, so their gradient / argmax
+// vectors are loaded ONCE for four outputs (the per-pixel form above requests 16 window vectors per patch, 12 of them twice).
+// Summation order per pixel = the per-pixel form's (bit-identical results).
+template <int DT>
+__global__ __launch_bounds__(256) void maxpool_bwd_k3s2_patch_kernel(const unsigned short* __restrict__ dy,
+                                                                     const unsigned char* __restrict__ amax,
+                                                                     unsigned short* __restrict__ dx, int N, int H, int W, int C8,
+                                                                     int P, int Q) {
+  const unsigned total = (unsigned)N * P * Q * C8;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned c8 = i % (unsigned)C8;
+    unsigned t = i / (unsigned)C8;
+    const int q = (int)(t % (unsigned)Q); t /= (unsigned)Q;
+    const int p = (int)(t % (unsigned)P);
+    const int n = (int)(t / (unsigned)P);
+    const bool vp1 = p + 1 < P, vq1 = q + 1 < Q;
+    const int p1 = vp1 ? p + 1 : p, q1 = vq1 ? q + 1 : q;
+    ushort8_t g[4];
+    uint2_t am[4];
+    const int pp[2] = {p, p1}, qq[2] = {q, q1};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const unsigned o = (((unsigned)n * P + pp[a]) * Q + qq[b]) * C8 + c8;
+        g[a * 2 + b] = ((const ushort8_t*)dy)[o];
+        am[a * 2 + b] = ((const uint2_t*)amax)[o];
+      }
+    // window (a, b) -> index a * 2 + b; term(win, code): the window's gradient where its argmax is `code`, else 0
+    auto term = [&](int win, unsigned code, bool valid, float* acc) __attribute__((always_inline)) {
+      const unsigned want = valid ? code : 0xFFu;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const unsigned c = (am[win][k >> 2] >> ((k & 3) * 8)) & 0xffu;
+        if (c == want) acc[k] += up16<DT>(g[win][k]);
+      }
+    };
+    auto store = [&](int dh, int dw, const float* acc) __attribute__((always_inline)) {
+      ushort8_t o8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o8[k] = dn16<DT>(acc[k]);
+      ((ushort8_t*)dx)[((((unsigned)n * H + 2 * p + dh) * W) + 2 * q + dw) * C8 + c8] = o8;
+    };
+    float a00[8], a01[8], a10[8], a11[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a00[k] = 0.f; a01[k] = 0.f; a10[k] = 0.f; a11[k] = 0.f; }
+    // (even, even): window (p, q) tap (1, 1)
+    term(0, 4, true, a00);
+    // (even, odd): windows (p, q + 1) tap (1, 0), then (p, q) tap (1, 2)
+    term(1, 3, vq1, a01); term(0, 5, true, a01);
+    // (odd, even): windows (p + 1, q) tap (0, 1), then (p, q) tap (2, 1)
+    term(2, 1, vp1, a10); term(0, 7, true, a10);
+    // (odd, odd): (p + 1, q + 1) tap (0, 0), (p + 1, q) tap (0, 2), (p, q + 1) tap (2, 0), (p, q) tap (2, 2)
+    term(3, 0, vp1 && vq1, a11); term(2, 2, vp1, a11); term(1, 6, vq1, a11); term(0, 8, true, a11);
+    store(0, 0, a00); store(0, 1, a01); store(1, 0, a10); store(1, 1, a11);
+  }
+}
+
+// BatchNorm-apply + ReLU + MaxPool2d(3, 2, 1) in ONE pass (the ResNet stem: bn1 -> relu -> maxpool, models/resnet.py:318-322):
+// the 16-bit activation between them (411 MB at batch 256, written once and read once) never exists.  One thread per pooled
+// pixel x 8 channels: nine (clamped, masked) loads of t, y = relu(t * sc + sh) rounded to 16 bits exactly as dle_bn_fwd_apply stores
+// it, first-maximum argmax in window-scan order (dle_maxpool_fwd's rule), and the ReLU keep bits of the 2 x 2 input pixels
+// (2 p, 2 q) .. (2 p + 1, 2 q + 1) = taps (1..2, 1..2), which this window alone owns.  Outputs are bit-identical to the two launches.
+template <int DT>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_k3s2_kernel(const unsigned short* __restrict__ x,
+                                                                   unsigned short* __restrict__ y, unsigned char* __restrict__ amax,
+                                                                   unsigned char* __restrict__ mask, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, int N, int H, int W, int C8, int P,
+                                                                   int Q) {
+  const unsigned total = (unsigned)N * P * Q * C8;
+  const unsigned first = blockIdx.x * blockDim.x + threadIdx.x;
+  if (first >= total) return;
+  float sc[8], sh[8];
+  {
+    const int c0 = (int)(first % (unsigned)C8) * 8;            // (the launcher makes the grid stride a multiple of C8)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = rstd[c0 + k] * gamma[c0 + k]; sh[k] = beta[c0 + k] - mean[c0 + k] * sc[k]; }
+  }
+  for (unsigned i = first; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned c8 = i % (unsigned)C8;
+    unsigned t = i / (unsigned)C8;
+    const int q = (int)(t % (unsigned)Q); t /= (unsigned)Q;
+    const int p = (int)(t % (unsigned)P);
+    const int n = (int)(t / (unsigned)P);
+    ushort8_t v[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2) {
+        int h = 2 * p - 1 + r, w = 2 * q - 1 + s2;
+        h = h < 0 ? 0 : (h >= H ? H - 1 : h);
+        w = w < 0 ? 0 : (w >= W ? W - 1 : w);
+        v[r * 3 + s2] = ((const ushort8_t*)x)[(((unsigned)n * H + h) * W + w) * C8 + c8];
+      }
+    float best[8];
+    unsigned bi[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; bi[k] = 0; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2) {
+        const int h = 2 * p - 1 + r, w = 2 * q - 1 + s2;
+        const bool valid = h >= 0 && h < H && w >= 0 && w < W;
+        float xf[8];
+        unpack8<DT>(v[r * 3 + s2], xf);
+        unsigned bits = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float f = xf[k] * sc[k] + sh[k];
+          f = f > 0.f ? f : 0.f;
+          bits |= (f > 0.f ? 1u : 0u) << k;
+          const float fr = up16<DT>(dn16<DT>(f));              // the value the stand-alone apply pass stores
+          if (valid && (fr > best[k] || fr != fr)) { best[k] = fr; bi[k] = (unsigned)(r * 3 + s2); }
+        }
+        if (r >= 1 && s2 >= 1 && h < H && w < W) mask[(((unsigned)n * H + h) * W + w) * C8 + c8] = (unsigned char)bits;
+      }
+    ushort8_t o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = dn16<DT>(best[k]);
+    ((ushort8_t*)y)[i] = o;
+    uint2_t packed;
+    packed[0] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    packed[1] = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+    ((uint2_t*)amax)[i] = packed;
+  }
+}
+
+// y [N, H/2, W/2, C] = maxpool3x3/2/pad1(relu(bn(x))), argmax (dle_maxpool_fwd's encoding), relu_mask [N*H*W*C/8] (dle_bn_fwd_apply's
+// encoding).  H, W even.
+extern "C" int dle_bn_relu_maxpool_fwd(const void* x, void* y, void* argmax, void* relu_mask, const float* mean, const float* rstd,
+                                       const float* gamma, const float* beta, int N, int H, int W, int C, int dtype,
+                                       hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "bn_relu_maxpool_fwd: 16-bit activations only");
+  DLE_CHECK_ARG(N >= 0 && H > 0 && W > 0 && (H & 1) == 0 && (W & 1) == 0 && C > 0 && C % 8 == 0, "bn_relu_maxpool_fwd: bad shape (H, W even, C % 8 == 0)");
+  if (N == 0) return 0;
+  DLE_CHECK_ARG(x && y && argmax && relu_mask && mean && rstd && gamma && beta, "bn_relu_maxpool_fwd: null pointer");
+  DLE_CHECK_ARG((long long)N * H * W * (C / 8) < 0x7FFFFFFFLL, "bn_relu_maxpool_fwd: tensor too large");
+  const int P = H / 2, Q = W / 2, C8 = C / 8;
+  long long g = ((long long)N * P * Q * C8 + 255) / 256;
+  if (g > 8192) g = 8192;
+  while (((g * 256) % C8) != 0) --g;                          // a thread keeps its channel group over its whole walk
+  if (g < 1) g = 1;
+  DLE_CHECK_ARG(((g * 256) % C8) == 0, "bn_relu_maxpool_fwd: channel count %d does not divide the grid stride", C);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(bn_relu_maxpool_k3s2_kernel<DLE_F16>, dim3((unsigned)g), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, (unsigned char*)argmax, (unsigned char*)relu_mask, mean, rstd, gamma, beta, N, H, W, C8, P, Q);
+  else hipLaunchKernelGGL(bn_relu_maxpool_k3s2_kernel<DLE_BF16>, dim3((unsigned)g), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)y, (unsigned char*)argmax, (unsigned char*)relu_mask, mean, rstd, gamma, beta, N, H, W, C8, P, Q);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int dle_maxpool_bwd(const void* dy, const void* argmax, void* dx, int N, int H, int W, int C, int ksize,
                                int stride, int pad, int dtype, hipStream_t stream) {
   DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "maxpool_bwd: 16-bit activations only");
@@ -1061,6 +1213,14 @@ extern "C" int dle_maxpool_bwd(const void* dy, const void* argmax, void* dx, int
   DLE_CHECK_ARG(dy && dx && argmax, "maxpool_bwd: null pointer");
   const int P = (H + 2 * pad - ksize) / stride + 1, Q = (W + 2 * pad - ksize) / stride + 1;
   const int grid = cn_grid((long long)N * H * W * (C / 8), 256, 8192);
+  static const int patch_mode = getenv("DLE_MAXPOOL_BWD_PATCH") ? atoi(getenv("DLE_MAXPOOL_BWD_PATCH")) : 1;
+  if (patch_mode && ksize == 3 && stride == 2 && pad == 1 && (H & 1) == 0 && (W & 1) == 0 && (long long)N * H * W * (C / 8) < 0x7FFFFFFFLL) {
+    const int gp = cn_grid((long long)N * P * Q * (C / 8), 256, 8192);
+    if (dtype == DLE_F16) hipLaunchKernelGGL(maxpool_bwd_k3s2_patch_kernel<DLE_F16>, dim3(gp), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned char*)argmax, (unsigned short*)dx, N, H, W, C / 8, P, Q);
+    else hipLaunchKernelGGL(maxpool_bwd_k3s2_patch_kernel<DLE_BF16>, dim3(gp), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned char*)argmax, (unsigned short*)dx, N, H, W, C / 8, P, Q);
+    DLE_LAUNCH_CHECK();
+    return 0;
+  }
   if (ksize == 3 && stride == 2 && pad == 1 && (long long)N * H * W * (C / 8) < 0x7FFFFFFFLL && P >= 1 && Q >= 1) {
     if (dtype == DLE_F16) hipLaunchKernelGGL(maxpool_bwd_k3s2_kernel<DLE_F16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned char*)argmax, (unsigned short*)dx, N, H, W, C / 8, P, Q);
     else hipLaunchKernelGGL(maxpool_bwd_k3s2_kernel<DLE_BF16>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy, (const unsigned char*)argmax, (unsigned short*)dx, N, H, W, C / 8, P, Q);

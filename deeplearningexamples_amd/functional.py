@@ -773,6 +773,22 @@ def bn_fwd_apply(x, mean, rstd, gamma, beta, residual=None, relu=True, want_mask
     return y, mask
 
 
+def bn_relu_maxpool_fwd(t, mean, rstd, gamma, beta):
+    """maxpool3x3/2/pad1(relu(bn(t))) in one pass (the ResNet stem) -> (pooled [N,H/2,W/2,C], argmax uint8, relu_mask of the
+    never-materialised activation); bit-identical to bn_fwd_apply + maxpool_fwd.  H, W even."""
+    C.require_cuda(t, mean, rstd, gamma, beta)
+    n, h, w, c = t.shape
+    if h % 2 or w % 2 or not t.is_contiguous():
+        raise ValueError("bn_relu_maxpool_fwd: contiguous NHWC input with even H, W expected")
+    y = torch.empty((n, h // 2, w // 2, c), dtype=t.dtype, device=t.device)
+    am = torch.empty((n, h // 2, w // 2, c), dtype=torch.uint8, device=t.device)
+    mask = torch.empty(t.numel() // 8, dtype=torch.uint8, device=t.device)
+    C.annotate(bytes=float(t.numel() + y.numel()) * 2 + am.numel() + mask.numel(), tag="N%dx%dx%dxC%d" % (n, h, w, c))
+    C.call("dle_bn_relu_maxpool_fwd", C.ptr(t), C.ptr(y), C.ptr(am), C.ptr(mask), C.ptr(mean), C.ptr(rstd), C.ptr(gamma), C.ptr(beta),
+           n, h, w, c, C.dt(t), C.stream())
+    return y, am, mask
+
+
 def bn_bwd(dy, y, x, mean, rstd, gamma, dgamma, dbeta, want_skip_grad=False, dx_out=None, relu_mask=None):
     """-> (dx, g) ; y = saved post-ReLU output or relu_mask = its bit-packed y > 0 mask (both None when the BN had no
     ReLU); g = dy*(y>0) if requested."""

@@ -295,6 +295,11 @@ int dle_stem_pack_weight(const float* w_krsc, void* out, int dtype, hipStream_t 
 /* argmax: uint8 [N,P,Q,C] window-scan index of the first maximum (ATen tie rule) */
 int dle_maxpool_fwd(const void* x, void* y, void* argmax, int N, int H, int W, int C, int ksize, int stride,
                     int pad, int dtype, hipStream_t stream);
+/* BatchNorm-apply + ReLU + MaxPool2d(3, 2, 1) in one pass (the stem: models/resnet.py:318-322 bn1 -> relu -> maxpool): y
+ * [N, H/2, W/2, C], argmax and relu_mask exactly as dle_bn_fwd_apply + dle_maxpool_fwd would leave them (bit-identical); the
+ * 16-bit activation between the two never exists.  H, W even. */
+int dle_bn_relu_maxpool_fwd(const void* x, void* y, void* argmax, void* relu_mask, const float* mean, const float* rstd,
+                            const float* gamma, const float* beta, int N, int H, int W, int C, int dtype, hipStream_t stream);
 int dle_maxpool_bwd(const void* dy, const void* argmax, void* dx, int N, int H, int W, int C, int ksize,
                     int stride, int pad, int dtype, hipStream_t stream);
 int dle_avgpool_fwd(const void* x, void* y, int64_t N, int HW, int C, int dtype, hipStream_t stream);

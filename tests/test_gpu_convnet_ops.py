@@ -174,3 +174,29 @@ def test_gemm_add_upsampled2_equals_materialised_path(cuda, dtype, n, h, w, k, n
     torch.cuda.synchronize()
     assert torch.equal(fused, ref)
     assert F.gemm_add_upsampled2(a[:, :32].contiguous(), b[:32].contiguous(), compact, (h, w)) is None     # K = 32: declined
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,h,w,c", [(2, 112, 112, 64), (3, 8, 12, 64), (1, 2, 2, 8), (2, 30, 18, 128)])
+def test_bn_relu_maxpool_fused_equals_two_passes_and_pool_backward_patch(cuda, dtype, n, h, w, c):
+    """bn1 -> relu -> maxpool in one pass == dle_bn_fwd_apply then dle_maxpool_fwd, bit for bit (models/resnet.py:318-322); and the
+    2x2-patch pooling backward == the per-pixel form."""
+    from deeplearningexamples_amd import functional as F
+    g = torch.Generator().manual_seed(h * 13 + c)
+    t = torch.randn((n, h, w, c), generator=g).to(dtype).to(cuda)
+    mean = (torch.randn(c, generator=g) * 0.2).to(cuda)
+    rstd = (torch.rand(c, generator=g) + 0.5).to(cuda)
+    gamma = (torch.rand(c, generator=g) + 0.5).to(cuda)
+    beta = (torch.randn(c, generator=g) * 0.3).to(cuda)
+    y, am, mask = F.bn_relu_maxpool_fwd(t, mean, rstd, gamma, beta)
+    a0, mask_ref = F.bn_fwd_apply(t, mean, rstd, gamma, beta, relu=True, want_mask=True)
+    y_ref, am_ref = F.maxpool_fwd(a0)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref) and torch.equal(am.view(-1), am_ref.view(-1)) and torch.equal(mask, mask_ref)
+    dy = torch.randn(y.shape, generator=g).to(dtype).to(cuda)
+    dx = F.maxpool_bwd(dy, am, (h, w))
+    yy, idx = torch.nn.functional.max_pool2d(a0.float().cpu().permute(0, 3, 1, 2), 3, 2, 1, return_indices=True)
+    gr = torch.zeros((n, c, h * w))
+    gr.scatter_add_(2, idx.reshape(n, c, -1), dy.float().cpu().permute(0, 3, 1, 2).reshape(n, c, -1))
+    ref = gr.reshape(n, c, h, w).permute(0, 2, 3, 1)
+    assert torch.allclose(dx.float().cpu(), ref.to(dtype).float(), atol=0.02, rtol=0.01)
