@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void emb_link(const long long* __restrict__ ro
 //           to be its list's head wastes one row read, which duplicates of the small and medium tables find in L2);
 //   then the store.  Duplicates behind the head are walked as before (gradient + next per step).
 // Two lookups per half-wavefront (four per wavefront) are in flight, every load unconditional on a clamped address.
-template <int IDT>
+template <int IDT, bool SPEC>
 __global__ __launch_bounds__(256) void emb_sgd_lists(float* __restrict__ weight, const long long* __restrict__ rows,
                                                      const typename In4<IDT>::V* __restrict__ grad,
                                                      int* __restrict__ head, const int* __restrict__ next,
@@ -531,11 +531,12 @@ __global__ __launch_bounds__(256) void emb_sgd_lists(float* __restrict__ weight,
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       h[u] = head[r[u]];
-      wv[u] = ((const float4_t*)(weight + r[u] * (long long)(D4 * 4)))[lc];
+      if (SPEC) wv[u] = ((const float4_t*)(weight + r[u] * (long long)(D4 * 4)))[lc];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (!ok[u] || h[u] != (int)iu[u]) continue;   // small-table lookup / not the list head: the head does the work
+      if (!SPEC) wv[u] = ((const float4_t*)(weight + r[u] * (long long)(D4 * 4)))[lc];     // (DLE_EMB_SPEC=0: heads only, depth 3)
       float4_t sacc = In4<IDT>::up(g[u]);
       long long j = nx[u];
       while (j >= 0) {
@@ -672,7 +673,9 @@ extern "C" int dle_emb_sgd_dedup(float* weight, const int64_t* rows, const void*
                        is_small_dev, skip_flag_dev, n, tables);
     DLE_LAUNCH_CHECK();
     const int grid = grid_for(n, 4 * 4);
-#define GO(IDT, VT) hipLaunchKernelGGL(emb_sgd_lists<IDT>, dim3(grid), dim3(256), 0, stream, weight, (const long long*)rows, (const VT*)grad, head, (const int*)next, is_small_dev, lr_dev, lr_host, scale_dev, skip_flag_dev, n, tables, D4, gs4)
+    static const int spec = getenv("DLE_EMB_SPEC") ? atoi(getenv("DLE_EMB_SPEC")) : 1;
+#define GO(IDT, VT) do { if (spec) hipLaunchKernelGGL((emb_sgd_lists<IDT, true>), dim3(grid), dim3(256), 0, stream, weight, (const long long*)rows, (const VT*)grad, head, (const int*)next, is_small_dev, lr_dev, lr_host, scale_dev, skip_flag_dev, n, tables, D4, gs4); \
+    else hipLaunchKernelGGL((emb_sgd_lists<IDT, false>), dim3(grid), dim3(256), 0, stream, weight, (const long long*)rows, (const VT*)grad, head, (const int*)next, is_small_dev, lr_dev, lr_host, scale_dev, skip_flag_dev, n, tables, D4, gs4); } while (0)
     if (grad_dtype == DLE_F32) GO(DLE_F32, float4_t);
     else if (grad_dtype == DLE_F16) GO(DLE_F16, ushort4_t);
     else GO(DLE_BF16, ushort4_t);
