@@ -273,18 +273,6 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
     static_for<0, 4>([&](auto J) __attribute__((always_inline)) { issue_b(kt, stage, J); });
   };
 
-  // Staggered start (256x256 tile, one workgroup per CU): every tile takes the same time, so the 256 workgroups of a launch
-  // run in lockstep and all their epilogues -- 32 MB of stores -- hit HBM in the same few microseconds, with no CU computing
-  // meanwhile.  The first wave of workgroups starts in `phases` groups (interleaved inside each XCD) a fraction of a tile
-  // apart; the ones dispatched behind them inherit the offset.
-  if (BIG && p.debug_skip) {
-    const int phases = p.debug_skip >> 8, sl = p.debug_skip & 255;
-    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (lin < 256u) {
-      const int ph = (int)(lin >> 3) % phases;
-      for (int i = 0; i < ph * sl; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-  }
   float16_t acc[WTM][WTN];
   if (kt0 < kt1) issue_all(kt0, 0);
   int s0 = 0;                              // stage of this tile's first K tile (128x128 tile)
@@ -799,16 +787,6 @@ static int launch_gemm(const Gemm2Args& p_in, int in_dtype, int amode, int bmode
     const size_t lds_stages = 2 * (256 * BK + 256 * BK) * 2;
     p.lds_src = lds_src_mode && lds_max >= (int)(lds_stages + 32768) && (long long)p.M * p.ldc * 2 < 0xFFFFFFE0LL;
     const size_t lds_big = lds_stages + (lds_max >= (int)(lds_stages + 32768) ? 32768 : 0);
-    // DLE_GEMM_STAGGER = "phases:sleeps" (s_sleep 127 units, ~3.5 us, per phase step); sleeps 0 = from the K extent
-    static const int stag_ph = getenv("DLE_GEMM_STAGGER") ? atoi(getenv("DLE_GEMM_STAGGER")) : 0;
-    static const int stag_sl = getenv("DLE_GEMM_STAGGER") && strchr(getenv("DLE_GEMM_STAGGER"), ':')
-                                   ? atoi(strchr(getenv("DLE_GEMM_STAGGER"), ':') + 1) : 0;
-    if (stag_ph > 1 && work_big > 256) {
-      const float tile_us = 1.31f * kt_per_item + 8.5f;
-      int sl = stag_sl > 0 ? stag_sl : (int)(tile_us / stag_ph / 3.5f + 0.5f);
-      sl = sl < 1 ? 1 : sl > 255 ? 255 : sl;
-      p.debug_skip = (stag_ph << 8) | sl;
-    }
 #define GOBIG(DT, AM, BMODE) do { static bool attr_set = false; \
       if (!attr_set) { hipFuncSetAttribute((const void*)gemm2_kernel<DT, AM, BMODE, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big); attr_set = true; } \
       hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE, 2, 1>), grid, block, lds_big, stream, p); } while (0)

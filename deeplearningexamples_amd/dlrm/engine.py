@@ -102,6 +102,10 @@ class DlrmTrainer:
         self.noop = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.comm_stream = torch.cuda.Stream(device=self.device) if world_size > 1 else None
         self.moving_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        import os
+        # last layer + loss + their backward as one kernel (DLE_DLRM_FUSE_HEAD=0: the separate GEMM / loss launches)
+        self.fuse_head = (os.environ.get("DLE_DLRM_FUSE_HEAD", "1") != "0" and self.device.type == "cuda"
+                          and model.top_model.head_fusable())
 
     # ------------------------------------------------------------------ optimizer plumbing
     def _build_tables(self):
@@ -251,15 +255,22 @@ class DlrmTrainer:
         m, p, sc = self.model, self.plan, self.scaler
         bottom_out = m.bottom_model(numerical_features, categorical_features)
         x = self._bottom_to_top(bottom_out) if self.world > 1 else bottom_out
-        logits = m.top_model(x)
         labels = click[p.batch_start[self.rank]:p.batch_start[self.rank + 1]] if self.world > 1 else click
-        loss, dlogits = F.bce_with_logits(logits, labels, grad_scale=sc.scale if sc.enabled else None)
+        if self.fuse_head:
+            # last layer + loss + their backward in one pass over the last hidden activation (csrc/dlrm_head.hip)
+            loss = m.top_model.forward_loss_backward_head(x, labels, grad_scale=sc.scale if sc.enabled else None,
+                                                          grads=self.top_grads.views[:-1], out_grads=self.top_grads.views[-1])
+            dlogits = None
+        else:
+            logits = m.top_model(x)
+            loss, dlogits = F.bce_with_logits(logits, labels, grad_scale=sc.scale if sc.enabled else None)
+            dlogits = dlogits.view(-1, 1)
         # one rank: the interaction backward itself reports inf / nan in the gradient it writes (no sweep over 450 MB)
         fused_check = sc.enabled and self.world == 1
         if self.world > 1:
             # data-gradient chain of the top model first; the gradient all-to-all (xGMI) then runs on the communication stream
             # UNDER the top model's weight gradients, and the data-parallel mean of those follows it on the same stream
-            grad_x, finish = m.top_model.backward(dlogits.view(-1, 1), grads=self.top_grads.views[:-1],
+            grad_x, finish = m.top_model.backward(dlogits, grads=self.top_grads.views[:-1],
                                                   out_grads=self.top_grads.views[-1], defer_wgrad=True)
             grad_bottom = self._top_to_bottom_start(grad_x)
             finish()
@@ -272,7 +283,7 @@ class DlrmTrainer:
             # one rank: the top model's weight / bias gradients are leaves -- they run on a second stream beside the bottom model's
             # backward (embedding update on its own stream there), joined before anything reads the flat gradient buffers
             wside = self._wgrad_stream()
-            grad_x, finish = m.top_model.backward(dlogits.view(-1, 1), grads=self.top_grads.views[:-1],
+            grad_x, finish = m.top_model.backward(dlogits, grads=self.top_grads.views[:-1],
                                                   out_grads=self.top_grads.views[-1],
                                                   found_inf=sc.found_inf if fused_check else None, defer_wgrad=True)
             if wside is not None:

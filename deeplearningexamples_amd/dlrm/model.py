@@ -112,14 +112,15 @@ class Mlp(nn.Module):
         self._saved = acts
         return h
 
-    def backward(self, gy: torch.Tensor, need_input_grad: bool = False, grads=None, masked: bool = False, defer_wgrad: bool = False):
+    def backward(self, gy: torch.Tensor, need_input_grad: bool = False, grads=None, masked: bool = False, defer_wgrad: bool = False,
+                 skip_last_bias: bool = False):
         """gy: gradient w.r.t. the (post-ReLU) output of the last layer, 16-bit, may be a strided view;
         masked=True when the producer already applied the last ReLU's mask in its epilogue.
         Writes fp32 weight/bias gradients into `grads` [(gw, gb), ...] (views of a flat bucket) or into
         .grad.  Returns the input gradient when asked.
         defer_wgrad: run the data-gradient chain only and return (input gradient, finish) -- finish() launches the weight / bias
         gradients afterwards (the multi-rank step starts the gradient all-to-all as soon as the chain is through and overlaps
-        it with them)."""
+        it with them).  skip_last_bias: the producer of gy also wrote the last layer's bias gradient (its column sums)."""
         acts, w16, lins = self._saved, self.working_copies(), self.linears
         g = gy
         pending = []
@@ -136,7 +137,8 @@ class Mlp(nn.Module):
                    splitk=F.pick_splitk(lin.out_features, kp, m))
             if gw_full is not gw:
                 gw.copy_(gw_full[:, :lin.in_features])
-            F.colsum(g, out=gb)
+            if not (skip_last_bias and i == len(lins) - 1):       # (the fused head already wrote the last layer's bias gradient)
+                F.colsum(g, out=gb)
 
         gin = None
         for i in range(len(lins) - 1, -1, -1):
@@ -353,25 +355,58 @@ class DlrmTop(nn.Module):
         return F.gemm(h, w, h.shape[0], w.shape[0], w.shape[1], True, True, out_dtype=self.compute_dtype,
                       bias=self.out.bias.data)
 
+    def head_fusable(self):
+        """The fused head (csrc/dlrm_head.hip) covers out_features == 1 over a 16-bit hidden layer of <= 512 columns."""
+        return (self.out.out_features == 1 and self.out.in_features % 8 == 0 and self.out.in_features <= 512
+                and self.compute_dtype in (torch.float16, torch.bfloat16))
+
+    def forward_loss_backward_head(self, bottom_output, target, grad_scale=None, grads=None, out_grads=None,
+                                   bottom_mlp_output=None):
+        """forward() + BCEWithLogitsLoss(mean) + the backward of the loss and the `out` layer, the last three in ONE pass over the
+        last hidden activation: -> loss fp32 [1].  The gradient w.r.t. that activation (ReLU mask applied) is kept for
+        backward(None, ...); `out`'s weight / bias gradients and the bias gradient of the last MLP layer are written here."""
+        z = self.interaction.interact(bottom_output, bottom_mlp_output)
+        h = self.mlp(z)
+        self._h = h
+        w = self.out_working_copy()
+        gw, gb = out_grads if out_grads is not None else (_grad_buf(self.out.weight), _grad_buf(self.out.bias))
+        last = len(self.mlp.linears) - 1
+        gprev = grads[last][1] if grads is not None else _grad_buf(self.mlp.linears[last].bias)
+        ws = getattr(self, "_head_ws", None)
+        if ws is None or ws.m != h.shape[0] or ws.k != h.shape[1] or ws.buf.device != h.device:
+            ws = self._head_ws = F.HeadWorkspace(h.shape[0], h.shape[1], h.device)
+        loss, self._gh, _ = F.head_bce_fwd_bwd(h, w.view(-1), self.out.bias.data, target, grad_scale, gw.view(-1), gb, ws,
+                                               gprev_bias=gprev)
+        return loss
+
     def backward(self, dlogits, grads=None, out_grads=None, grad_x_out=None, found_inf=None, defer_wgrad=False):
         """dlogits [B, 1] 16-bit -> gradient of the interaction input [B, R, D]; found_inf (optional fp32 [1]) is set by the
         interaction backward when that gradient holds an inf / nan.  defer_wgrad: -> (gradient, finish): the data-gradient chain
-        first, finish() launches every weight / bias gradient of the top model."""
+        first, finish() launches every weight / bias gradient of the top model.  dlogits = None: after
+        forward_loss_backward_head (the head's share of the backward is done)."""
         h, w = self._h, self.out_working_copy()
         m, n, k = h.shape[0], w.shape[0], w.shape[1]
-        gw, gb = out_grads if out_grads is not None else (_grad_buf(self.out.weight), _grad_buf(self.out.bias))
+        fused = dlogits is None
+        if fused:
+            gh, self._gh = self._gh, None
 
-        def out_wgrad():
-            F.gemm(dlogits, h, n, k, m, False, False, out=gw, splitk=F.pick_splitk(n, k, m))
-            F.colsum(dlogits, out=gb)
+            def out_wgrad():
+                pass
+        else:
+            gw, gb = out_grads if out_grads is not None else (_grad_buf(self.out.weight), _grad_buf(self.out.bias))
+
+            def out_wgrad():
+                F.gemm(dlogits, h, n, k, m, False, False, out=gw, splitk=F.pick_splitk(n, k, m))
+                F.colsum(dlogits, out=gb)
+            if not defer_wgrad:
+                out_wgrad()
+            gh = F.gemm(dlogits, w, m, k, n, True, False, out_dtype=self.compute_dtype, act=C.ACT_RELU_BWD,
+                        mask_src=h)
         if not defer_wgrad:
-            out_wgrad()
-        gh = F.gemm(dlogits, w, m, k, n, True, False, out_dtype=self.compute_dtype, act=C.ACT_RELU_BWD,
-                    mask_src=h)
-        if not defer_wgrad:
-            gz = self.mlp.backward(gh, need_input_grad=True, grads=grads, masked=True)
+            gz = self.mlp.backward(gh, need_input_grad=True, grads=grads, masked=True, skip_last_bias=fused)
             return self.interaction.backward(gz, grad_out=grad_x_out, found_inf=found_inf)
-        gz, mlp_finish = self.mlp.backward(gh, need_input_grad=True, grads=grads, masked=True, defer_wgrad=True)
+        gz, mlp_finish = self.mlp.backward(gh, need_input_grad=True, grads=grads, masked=True, defer_wgrad=True,
+                                           skip_last_bias=fused)
         gx = self.interaction.backward(gz, grad_out=grad_x_out, found_inf=found_inf)
 
         def finish():

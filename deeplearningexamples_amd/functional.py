@@ -234,6 +234,39 @@ def bce_with_logits(logits, target, grad_scale=None, want_grad=True, ld_logits=1
     return loss, dl
 
 
+class HeadWorkspace:
+    """Scratch of head_bce_fwd_bwd for one (batch, K): one partial row per workgroup."""
+
+    def __init__(self, m, k, device):
+        self.m, self.k = int(m), int(k)
+        nbytes = int(C.lib().dle_head_bce_workspace_bytes(self.m, self.k))
+        self.buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+
+
+def head_bce_fwd_bwd(h, w16, bias, target, grad_scale, gw, gb, ws, gprev_bias=None, dh=None, want_logits=False):
+    """Last linear layer (out_features = 1) + BCEWithLogitsLoss(mean) + the backward of both in one pass over h [M, K] (16-bit):
+    -> (loss fp32 [1], dh [M, K] masked by the ReLU of h, logits [M] or None); gw [K], gb [1] and (optional) gprev_bias [K] =
+    column sums of dh are written in place (fp32)."""
+    C.require_cuda(h, w16, bias, target, grad_scale, gw, gb, gprev_bias, dh)
+    if h.dim() != 2 or h.stride(1) != 1 or target.dtype != torch.float32 or h.dtype != w16.dtype:
+        raise ValueError("head_bce_fwd_bwd: h [M, K] 16-bit with unit inner stride, w16 of the same dtype, fp32 targets")
+    m, k = h.shape
+    if target.numel() != m or w16.numel() != k or gw.numel() != k or ws.m != m or ws.k != k:
+        raise ValueError("head_bce_fwd_bwd: shape mismatch")
+    for t in (gw, gb, gprev_bias):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise ValueError("head_bce_fwd_bwd: gradients are contiguous fp32 buffers")
+    if dh is None:
+        dh = torch.empty((m, k), dtype=h.dtype, device=h.device)
+    loss = torch.empty(1, dtype=torch.float32, device=h.device)
+    logits = torch.empty(m, dtype=h.dtype, device=h.device) if want_logits else None
+    C.annotate(bytes=2.0 * m * k * h.element_size() + 6.0 * m, tag="%dx%d" % (m, k))
+    C.call("dle_head_bce_fwd_bwd", C.ptr(h), C.ptr(w16), C.ptr(bias), C.ptr(target), C.ptr(grad_scale), C.ptr(loss),
+           C.ptr(logits), C.ptr(dh), C.ptr(gw), C.ptr(gb), C.ptr(gprev_bias), C.ptr(ws.buf), ws.buf.numel() * 4, m, k,
+           h.stride(0), dh.stride(0), C.dt(h), C.stream())
+    return loss, dh, logits
+
+
 def amp_update_scale_(scale, growth_tracker, found_inf, inv_scale=None, growth_factor=2.0, backoff_factor=0.5,
                       growth_interval=2000, clear_found_inf=True):
     C.require_cuda(scale, growth_tracker, found_inf, inv_scale)

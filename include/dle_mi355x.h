@@ -210,6 +210,20 @@ int dle_transpose_cast(const void* x, void* y, int rows, int cols, int64_t ld_x,
 int dle_a2a_blocks(void* blocks, void* x, int rows, int world, const int* widths, int elem_size, int pack, hipStream_t stream);
 int dle_bce_logits(const void* logits, const float* target, float* loss_out, void* dlogits,
                    const float* grad_scale_dev, int64_t n, int64_t ld_logits, int dtype, hipStream_t stream);
+/* The head of the DLRM top model in one pass (csrc/dlrm_head.hip): the last linear layer (out_features = 1,
+ * dlrm/model/distributed.py top MLP, dlrm/nn/mlps.py:38-43), BCEWithLogitsLoss(mean) (scripts/main.py:556,589-592) and the
+ * backward of both -- replaces dle_gemm (batch x 1 x K) + dle_bce_logits + dle_gemm (batch x K x 1, ReLU mask) + dle_gemm
+ * (1 x K x batch) + dle_colsum x 2 with the same 16-bit rounding points:
+ *   z = (16-bit) (h w + bias); loss_out[0] = mean BCE(z, target); dz = (16-bit) ((sigmoid(z) - target) * (*grad_scale) / M);
+ *   dh[m, k] = h[m, k] > 0 ? (16-bit) (dz[m] w[k]) : 0; gw[k] = sum_m dz[m] h[m, k]; gb = sum_m dz[m];
+ *   gprev_bias[k] (optional) = sum_m dh[m, k]  (bias gradient of the layer that produced h); logits_out (optional) = z.
+ * K % 8 == 0, K <= 512; ws: dle_head_bce_workspace_bytes(M, K) bytes of scratch (one partial row per workgroup, folded in a
+ * fixed order by a second small launch: bit-reproducible). */
+int64_t dle_head_bce_workspace_bytes(int64_t M, int K);
+int dle_head_bce_fwd_bwd(const void* h, const void* w16, const float* bias, const float* target,
+                         const float* grad_scale_dev, float* loss_out, void* logits_out, void* dh, float* gw, float* gb,
+                         float* gprev_bias, void* ws, int64_t ws_bytes, int64_t M, int K, int64_t ldh, int64_t ldd,
+                         int dtype, hipStream_t stream);
 int dle_amp_update_scale(float* scale, int* growth_tracker, float* found_inf, float* inv_scale,
                          float growth_factor, float backoff_factor, int growth_interval,
                          int clear_found_inf, hipStream_t stream);
