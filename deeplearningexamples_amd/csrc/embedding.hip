@@ -474,14 +474,49 @@ __global__ __launch_bounds__(1024) void emb_sgd_tiny(float* __restrict__ weight,
 }
 
 // pass 1: thread every lookup of a "large" table into its row's list
+// Lookups of the LARGE tables only: i in [0, batch * nl) -> sample b = i / nl, table t[i % nl], lookup index b * T + t (the value
+// threaded through head[] / next[]).  The walk used to cover all batch * T lookups and skip the small tables' ones after
+// loading their row id, next pointer and GRADIENT ROW (8 of criteo_f15's 26 tables: 134 MB of reads nobody used), with a 64-bit
+// division by T per lookup; 32-bit multiply-shift divisions here (batch * T < 2^31 is checked by the launcher).
+struct LookupMap {
+  int nl, T;                 // nl == 0: every table, small ones skipped through is_small[] (more than 128 tables)
+  unsigned mul_nl, shr_nl, mul_t, shr_t;
+  unsigned char t[128];
+};
+static void emb_make_div(int d, unsigned& mul, unsigned& shr) {
+  if (d <= 1) { mul = 0; shr = 0; return; }
+  unsigned lg = 0;
+  while ((1u << lg) < (unsigned)d) ++lg;
+  const unsigned p = 31 + lg;
+  mul = (unsigned)(((1ull << p) + (unsigned)d - 1) / (unsigned)d);
+  shr = p - 32;
+}
+__device__ __forceinline__ int emb_div(int n, int d, unsigned mul, unsigned shr) {
+  return d <= 1 ? n : (int)(__umulhi((unsigned)n, mul) >> shr);
+}
+// -> lookup index (or -1 for a small table's lookup in the every-table form) and its (sample, table)
+__device__ __forceinline__ int emb_lookup(const LookupMap& m, const unsigned char* t_lds, const unsigned char* is_small, int i,
+                                          int& b, int& t) {
+  const int nl = m.nl ? m.nl : m.T;
+  b = emb_div(i, nl, m.nl ? m.mul_nl : m.mul_t, m.nl ? m.shr_nl : m.shr_t);
+  const int k = i - b * nl;
+  t = m.nl ? (int)t_lds[k] : k;
+  if (!m.nl && is_small && is_small[t]) return -1;
+  return b * m.T + t;
+}
+
 __global__ __launch_bounds__(256) void emb_link(const long long* __restrict__ rows, int* __restrict__ head,
                                                 int* __restrict__ next, const unsigned char* __restrict__ is_small,
-                                                const float* __restrict__ skip_flag, long long n, int T) {
+                                                const float* __restrict__ skip_flag, int n_lookups, LookupMap map) {
+  __shared__ unsigned char t_lds[128];
   if (skip_flag && *skip_flag != 0.0f) return;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x) {
-    if (is_small && is_small[i % T]) continue;
-    next[i] = atomicExch(head + rows[i], (int)i);
+  if (threadIdx.x < 128) t_lds[threadIdx.x] = map.t[threadIdx.x];
+  __syncthreads();
+  for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n_lookups; i += (int)(gridDim.x * blockDim.x)) {
+    int b, t;
+    const int li = emb_lookup(map, t_lds, is_small, i, b, t);
+    if (li < 0) continue;
+    next[li] = atomicExch(head + rows[li], li);
   }
 }
 
@@ -500,30 +535,33 @@ __global__ __launch_bounds__(256) void emb_sgd_lists(float* __restrict__ weight,
                                                      const unsigned char* __restrict__ is_small,
                                                      const float* __restrict__ lr_dev, float lr_host,
                                                      const float* __restrict__ scale,
-                                                     const float* __restrict__ skip_flag, long long n, int T,
+                                                     const float* __restrict__ skip_flag, int n, LookupMap map,
                                                      int D4, long long g_bstride4) {
+  __shared__ unsigned char t_lds[128];
   if (skip_flag && *skip_flag != 0.0f) return;
+  if (threadIdx.x < 128) t_lds[threadIdx.x] = map.t[threadIdx.x];
+  __syncthreads();
+  const int T = map.T;
   const float lr = lr_dev ? *lr_dev : lr_host;
   const float alpha = -lr * (scale ? *scale : 1.0f);
   const int sub = (threadIdx.x & 63) >> 5, l = threadIdx.x & 31;
   const int lc = l < D4 ? l : D4 - 1;             // (dim < 128: the upper lanes shadow the last column and do not store)
-  const long long wave_id = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+  const int wave_id = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
   constexpr int U = 2;
-  for (long long base = wave_id * (2 * U); base < n; base += n_waves * (2 * U)) {
-    long long iu[U], r[U];
-    int nx[U], h[U];
+  for (int base = wave_id * (2 * U); base < n; base += n_waves * (2 * U)) {
+    long long r[U];
+    int iu[U], nx[U], h[U];
     bool ok[U];
     typename In4<IDT>::V g[U];
     float4_t wv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long long i = base + 2 * u + sub;
-      ok[u] = i < n;
-      iu[u] = ok[u] ? i : 0;
-      const long long jb = iu[u] / T;
-      const int t = (int)(iu[u] - jb * T);
-      ok[u] = ok[u] && !(is_small && is_small[t]);
+      const int i = base + 2 * u + sub;
+      int jb, t;
+      const int li = emb_lookup(map, t_lds, is_small, i < n ? i : 0, jb, t);
+      ok[u] = i < n && li >= 0;
+      iu[u] = li >= 0 ? li : jb * T + t;            // (a small table's lookup: loads stay in range, nothing is stored)
       r[u] = rows[iu[u]];
       nx[u] = next[iu[u]];
       g[u] = grad[jb * g_bstride4 + (long long)t * D4 + lc];
@@ -535,23 +573,23 @@ __global__ __launch_bounds__(256) void emb_sgd_lists(float* __restrict__ weight,
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (!ok[u] || h[u] != (int)iu[u]) continue;   // small-table lookup / not the list head: the head does the work
+      if (!ok[u] || h[u] != iu[u]) continue;        // small-table lookup / not the list head: the head does the work
       if (!SPEC) wv[u] = ((const float4_t*)(weight + r[u] * (long long)(D4 * 4)))[lc];     // (DLE_EMB_SPEC=0: heads only, depth 3)
       float4_t sacc = In4<IDT>::up(g[u]);
-      long long j = nx[u];
+      int j = nx[u];
       while (j >= 0) {
-        const long long jb = j / T;
-        sacc += In4<IDT>::up(grad[jb * g_bstride4 + (j - jb * T) * D4 + lc]);
+        const int jb = emb_div(j, T, map.mul_t, map.shr_t);
+        sacc += In4<IDT>::up(grad[jb * g_bstride4 + (long long)(j - jb * T) * D4 + lc]);
         j = next[j];
       }
       float4_t* w = (float4_t*)(weight + r[u] * (long long)(D4 * 4));
       if (l < D4) w[l] = wv[u] + alpha * sacc;
       for (int c = l + 32; c < D4; c += 32) {       // dim > 128: the remaining columns, chain walked again per trip
         float4_t s2 = {0.f, 0.f, 0.f, 0.f};
-        long long j2 = iu[u];
+        int j2 = iu[u];
         while (j2 >= 0) {
-          const long long jb = j2 / T;
-          s2 += In4<IDT>::up(grad[jb * g_bstride4 + (j2 - jb * T) * D4 + c]);
+          const int jb = emb_div(j2, T, map.mul_t, map.shr_t);
+          s2 += In4<IDT>::up(grad[jb * g_bstride4 + (long long)(j2 - jb * T) * D4 + c]);
           j2 = next[j2];
         }
         w[c] = w[c] + alpha * s2;
@@ -602,11 +640,19 @@ extern "C" int dle_emb_small_table_mask(const int64_t* table_offsets_host, int t
   return 0;
 }
 
-extern "C" int dle_emb_sgd_dedup(float* weight, const int64_t* rows, const void* grad, int32_t* head,
-                                 int32_t* next, const unsigned char* is_small_dev,
-                                 const int64_t* table_offsets_host, const float* lr_dev, float lr_host,
-                                 const float* scale_dev, const float* skip_flag_dev, int64_t batch, int tables,
-                                 int dim, int64_t grad_batch_stride, int grad_dtype, hipStream_t stream) {
+extern "C" int dle_emb_onehot_try(float* weight, const int64_t* rows, const void* grad, const float* lr_dev, float lr_host,
+                                  const float* scale_dev, const float* skip_flag_dev, const int* tab_t, const int64_t* tab_base,
+                                  const int* tab_rows, int n_tab, int64_t batch, int tables, int dim, int64_t grad_batch_stride,
+                                  int grad_dtype, void* ws, int64_t ws_bytes, hipStream_t stream);
+
+// ws (optional, dle_emb_onehot_workspace_bytes(number of tiny tables, batch) bytes): the tiny tables run as the one-hot MFMA
+// segment sum of emb_onehot.hip instead of the register form below
+extern "C" int dle_emb_sgd_dedup_ws(float* weight, const int64_t* rows, const void* grad, int32_t* head,
+                                    int32_t* next, const unsigned char* is_small_dev,
+                                    const int64_t* table_offsets_host, const float* lr_dev, float lr_host,
+                                    const float* scale_dev, const float* skip_flag_dev, int64_t batch, int tables,
+                                    int dim, int64_t grad_batch_stride, int grad_dtype, void* ws, int64_t ws_bytes,
+                                    hipStream_t stream) {
   DLE_CHECK_ARG(dim > 0 && dim % 4 == 0 && tables > 0, "emb_sgd_dedup: bad shape");
   if (batch == 0) return 0;
   DLE_CHECK_ARG(weight && rows && grad && head && next && is_small_dev && table_offsets_host, "emb_sgd_dedup: null pointer");
@@ -643,6 +689,14 @@ extern "C" int dle_emb_sgd_dedup(float* weight, const int64_t* rows, const void*
     if (is_tiny) { if (st.rows[i] > max_rows_tiny) max_rows_tiny = st.rows[i]; }
     else if (st.rows[i] > max_rows) max_rows = st.rows[i];
   }
+  if (tiny.n > 0 && ws) {
+    static_assert(sizeof(long long) == sizeof(int64_t), "table bases are passed as int64");
+    const int rc = dle_emb_onehot_try(weight, rows, grad, lr_dev, lr_host, scale_dev, skip_flag_dev, tiny.t,
+                                      (const int64_t*)tiny.base, tiny.rows, tiny.n, batch, tables, dim, grad_batch_stride,
+                                      grad_dtype, ws, ws_bytes, stream);
+    if (rc > 1) return rc;
+    if (rc == 1) tiny.n = 0;
+  }
   if (tiny.n > 0) {
     // one 16-wavefront workgroup per CU and table slice; >= 2048 samples per workgroup
     int slices = (int)((256 + tiny.n - 1) / tiny.n);
@@ -669,13 +723,28 @@ extern "C" int dle_emb_sgd_dedup(float* weight, const int64_t* rows, const void*
     DLE_LAUNCH_CHECK();
   }
   if (n_large > 0) {
-    hipLaunchKernelGGL(emb_link, dim3(grid_for(n, 256)), dim3(256), 0, stream, (const long long*)rows, head, next,
-                       is_small_dev, skip_flag_dev, n, tables);
+    LookupMap map;
+    map.T = tables; map.nl = 0;
+    emb_make_div(tables, map.mul_t, map.shr_t);
+    map.mul_nl = map.mul_t; map.shr_nl = map.shr_t;
+    for (int i = 0; i < 128; ++i) map.t[i] = 0;
+    if (tables <= 128) {
+      int k = 0, q = 0;
+      for (int t = 0; t < tables; ++t) {
+        if (q < st.n && st.t[q] == t) { ++q; continue; }                 // (st lists the small tables in ascending order)
+        map.t[k++] = (unsigned char)t;
+      }
+      map.nl = k;
+      emb_make_div(k, map.mul_nl, map.shr_nl);
+    }
+    const long long n_lk = (long long)batch * (map.nl ? map.nl : tables);
+    hipLaunchKernelGGL(emb_link, dim3(grid_for(n_lk, 256)), dim3(256), 0, stream, (const long long*)rows, head, next,
+                       is_small_dev, skip_flag_dev, (int)n_lk, map);
     DLE_LAUNCH_CHECK();
-    const int grid = grid_for(n, 4 * 4);
+    const int grid = grid_for(n_lk, 4 * 4);
     static const int spec = getenv("DLE_EMB_SPEC") ? atoi(getenv("DLE_EMB_SPEC")) : 1;
-#define GO(IDT, VT) do { if (spec) hipLaunchKernelGGL((emb_sgd_lists<IDT, true>), dim3(grid), dim3(256), 0, stream, weight, (const long long*)rows, (const VT*)grad, head, (const int*)next, is_small_dev, lr_dev, lr_host, scale_dev, skip_flag_dev, n, tables, D4, gs4); \
-    else hipLaunchKernelGGL((emb_sgd_lists<IDT, false>), dim3(grid), dim3(256), 0, stream, weight, (const long long*)rows, (const VT*)grad, head, (const int*)next, is_small_dev, lr_dev, lr_host, scale_dev, skip_flag_dev, n, tables, D4, gs4); } while (0)
+#define GO(IDT, VT) do { if (spec) hipLaunchKernelGGL((emb_sgd_lists<IDT, true>), dim3(grid), dim3(256), 0, stream, weight, (const long long*)rows, (const VT*)grad, head, (const int*)next, is_small_dev, lr_dev, lr_host, scale_dev, skip_flag_dev, (int)n_lk, map, D4, gs4); \
+    else hipLaunchKernelGGL((emb_sgd_lists<IDT, false>), dim3(grid), dim3(256), 0, stream, weight, (const long long*)rows, (const VT*)grad, head, (const int*)next, is_small_dev, lr_dev, lr_host, scale_dev, skip_flag_dev, (int)n_lk, map, D4, gs4); } while (0)
     if (grad_dtype == DLE_F32) GO(DLE_F32, float4_t);
     else if (grad_dtype == DLE_F16) GO(DLE_F16, ushort4_t);
     else GO(DLE_BF16, ushort4_t);
@@ -683,4 +752,13 @@ extern "C" int dle_emb_sgd_dedup(float* weight, const int64_t* rows, const void*
     DLE_LAUNCH_CHECK();
   }
   return 0;
+}
+
+extern "C" int dle_emb_sgd_dedup(float* weight, const int64_t* rows, const void* grad, int32_t* head,
+                                 int32_t* next, const unsigned char* is_small_dev,
+                                 const int64_t* table_offsets_host, const float* lr_dev, float lr_host,
+                                 const float* scale_dev, const float* skip_flag_dev, int64_t batch, int tables,
+                                 int dim, int64_t grad_batch_stride, int grad_dtype, hipStream_t stream) {
+  return dle_emb_sgd_dedup_ws(weight, rows, grad, head, next, is_small_dev, table_offsets_host, lr_dev, lr_host, scale_dev,
+                              skip_flag_dev, batch, tables, dim, grad_batch_stride, grad_dtype, nullptr, 0, stream);
 }

@@ -89,6 +89,22 @@ int dle_emb_sgd_dedup(float* weight, const int64_t* rows, const void* grad, int3
                       const float* lr_dev, float lr_host, const float* scale_dev,
                       const float* skip_flag_dev, int64_t batch, int tables, int dim,
                       int64_t grad_batch_stride, int grad_dtype, hipStream_t stream);
+/* The same with a scratch buffer: tables of <= 128 rows (dim 128, 16-bit gradients) are summed as OneHot(ids)^T G on the matrix
+ * pipe (csrc/emb_onehot.hip: the gradient rows stream HBM -> LDS once, the one-hot operand is built in registers; one fp32
+ * partial block per (table, batch slice), folded in slice order -- bit-reproducible, no float atomics; replaces the per-lookup
+ * atomicAdd of gather_gpu_fused.cu:161-202 on the tables every sample hits).  ws: dle_emb_onehot_workspace_bytes(number of
+ * such tables, batch) bytes, or NULL (= dle_emb_sgd_dedup).  dle_emb_onehot_try is the kernel's own entry (1 launched,
+ * 0 outside its envelope): tab_t / tab_base / tab_rows = column index, first joint row and row count of each table (host). */
+int64_t dle_emb_onehot_workspace_bytes(int n_tables, int64_t batch);
+int dle_emb_sgd_dedup_ws(float* weight, const int64_t* rows, const void* grad, int32_t* head, int32_t* next,
+                         const unsigned char* is_small_dev, const int64_t* table_offsets_host,
+                         const float* lr_dev, float lr_host, const float* scale_dev,
+                         const float* skip_flag_dev, int64_t batch, int tables, int dim,
+                         int64_t grad_batch_stride, int grad_dtype, void* ws, int64_t ws_bytes, hipStream_t stream);
+int dle_emb_onehot_try(float* weight, const int64_t* rows, const void* grad, const float* lr_dev, float lr_host,
+                       const float* scale_dev, const float* skip_flag_dev, const int* tab_t, const int64_t* tab_base,
+                       const int* tab_rows, int n_tab, int64_t batch, int tables, int dim, int64_t grad_batch_stride,
+                       int grad_dtype, void* ws, int64_t ws_bytes, hipStream_t stream);
 
 /* ---- dense contraction with fused epilogue ---------------------------------------------------
  * replaces cuBLAS GEMM + NVFuser/apex epilogues: apex.mlp (Recommendation/DLRM/dlrm/nn/mlps.py:18-43),

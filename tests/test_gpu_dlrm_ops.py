@@ -235,3 +235,53 @@ def test_a2a_blocks_pack_and_unpack(cuda, dtype):
         back = torch.zeros_like(flat)
         F.a2a_blocks(back, x, rows, widths, pack=True)
         assert torch.equal(back, flat)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("batch", [64, 1000, 4099, 65536])
+def test_tiny_tables_onehot_mfma_vs_oracle(cuda, batch, dtype):
+    """Tables of <= 128 rows through the one-hot MFMA segment sum (csrc/emb_onehot.hip) vs the float64 oracle: every lookup of the
+    batch lands on a handful of rows (gather_gpu_fused.cu:161-202 semantics), ragged batch tails, scale, skip flag, untouched rows
+    keep their bits, two runs are bit-identical (fixed fold order)."""
+    F = _F()
+    rng = np.random.default_rng(batch + (1 if dtype == torch.float16 else 2))
+    sizes = [4, 128, 1, 97, 300, 11, 63, 5000, 104, 35]        # 300 / 5000 rows: the list path of the same call
+    dim = 128
+    off = O.table_offsets(sizes)
+    w = rng.standard_normal((int(off[-1]), dim)).astype(np.float32)
+    idx = np.stack([rng.integers(0, max(s - 1, 1), batch) for s in sizes], 1).astype(np.int64)   # the LAST row of a table is never hit
+    rows = O.offset_indices(idx, off)
+    g16 = torch.from_numpy(rng.standard_normal((batch, len(sizes) + 1, dim)).astype(np.float32) * 0.05).to(dtype)
+    gd = g16.to(cuda)
+    gf = g16[:, 1:, :].to(torch.float32).numpy()
+    rd = torch.from_numpy(rows).to(cuda)
+    inv = torch.tensor([0.25], device=cuda)
+    lr = 0.5
+    exp = O.sparse_sgd(w, rows, gf * 0.25, lr)
+
+    def run():
+        wd = torch.from_numpy(w).to(cuda)
+        ws = F.EmbUpdateWorkspace(off, dim, cuda)
+        assert ws.n_onehot == 8
+        F.emb_sgd_dedup_(wd, rd, gd[:, 1:, :], ws, lr, scale=inv, grad_batch_stride=(len(sizes) + 1) * dim)
+        assert int((ws.head != -1).sum().item()) == 0
+        return wd
+    a = run()
+    # fp32 sums of up to `batch` 16-bit values per row: error ~ sqrt(n) * 2^-24 * sum|g|
+    mag = np.zeros_like(w, dtype=np.float64)
+    np.add.at(mag, rows.reshape(-1), np.abs(gf.reshape(-1, dim)) * 0.25)
+    err = np.abs(a.cpu().numpy().astype(np.float64) - exp)
+    assert np.all(err <= 2e-6 * lr * mag + 1e-6 * np.abs(exp) + 1e-7), float((err - 2e-6 * lr * mag).max())
+    untouched = mag.sum(1) == 0
+    assert untouched.any() and np.array_equal(a.cpu().numpy()[untouched], w[untouched])
+    # bit-reproducible on the one-hot tables (fixed fold order; the list path's order of duplicates follows the atomics)
+    b2 = run()
+    for ti, sz in enumerate(sizes):
+        if sz <= 128:
+            assert torch.equal(a[int(off[ti]):int(off[ti + 1])], b2[int(off[ti]):int(off[ti + 1])])
+    # skip flag: nothing moves
+    wd = torch.from_numpy(w).to(cuda)
+    ws = F.EmbUpdateWorkspace(off, dim, cuda)
+    F.emb_sgd_dedup_(wd, rd, gd[:, 1:, :], ws, lr, scale=inv, skip_flag=torch.ones(1, device=cuda),
+                     grad_batch_stride=(len(sizes) + 1) * dim)
+    assert torch.equal(wd.cpu(), torch.from_numpy(w))
