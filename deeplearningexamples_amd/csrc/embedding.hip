@@ -557,10 +557,13 @@ __global__ __launch_bounds__(256) void emb_sgd_lists(float* __restrict__ weight,
     float4_t wv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int i = base + 2 * u + sub;
+      // LAST lookup first: the head of a row's list is the lookup that was linked last, i.e. (nearly always) the one with the
+      // highest sample index -- walking the batch from its end starts the long duplicate chains of the 1-2 k-row tables (~70
+      // dependent hops each) at the START of the kernel, under everything else, instead of as its tail
+      const int i = n - 1 - (base + 2 * u + sub);
       int jb, t;
-      const int li = emb_lookup(map, t_lds, is_small, i < n ? i : 0, jb, t);
-      ok[u] = i < n && li >= 0;
+      const int li = emb_lookup(map, t_lds, is_small, i >= 0 ? i : 0, jb, t);
+      ok[u] = i >= 0 && li >= 0;
       iu[u] = li >= 0 ? li : jb * T + t;            // (a small table's lookup: loads stay in range, nothing is stored)
       r[u] = rows[iu[u]];
       nx[u] = next[iu[u]];

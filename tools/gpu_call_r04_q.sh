@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python -m pytest tests/test_gpu_dlrm_ops.py tests/test_gpu_dlrm_step.py -x -q 2>&1 | tail -8
-for v in 1 1 0; do
+for v in 1 1; do
   DLE_EMB_ONEHOT=$v python bench.py --workload dlrm --no-nested --no-cpu-baseline --no-kernel-timer --steps 100 --warmup 10 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('onehot=$v', d['ms_per_step'], d['value'])"
