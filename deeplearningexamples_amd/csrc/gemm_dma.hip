@@ -55,6 +55,7 @@ struct Gemm2Args {
   int debug_skip;        // reserved (profiling ablations)
   float* stats;          // per-tile-row column sums of the ROUNDED output: [tiles_m][2][N] (sum, sum of squares); NULL: off
   int force_small;       // keep the 128x128 tile (stats layout is indexed by 128-row tiles)
+  int stats_sums;        // stats holds column SUMS only, one partial row per tile row: [tiles_m][N] (bias gradients); 0: [tiles_m][2][N]
   long long row_extra;   // output row m lives at m * ldc + (m / row_div.d) * row_extra (+ column): rows of a strided sub-grid
   FastDiv row_div;
   int lds_src;           // 256x256 tile: 32 KiB of LDS beyond the two stages are available for epilogue source rows
@@ -193,7 +194,10 @@ __device__ __forceinline__ void epi_store8(const Gemm2Args& p, float* v, int m, 
 // loop (its LDS-DMA goes through inline asm), so hipcc's wait-count pass has nothing to drain: with the general epilogue in
 // the same code it inserts s_waitcnt vmcnt(0) at the head of every tile (a bias / addend load of some path might still be
 // in flight when a register is reused), which waits for the previous tile's STORES before the next DMA can be issued.
-template <int DT, int A_MODE, int B_MODE, int NSTAGE, int BIG, int PLAIN = 0>
+// BST = 1: the ReLU-mask epilogue (ACT_RELU_BWD) also leaves the column sums of its rounded output (p.stats, p.stats_sums) -- the
+// bias gradient of the layer whose mask it applies.  A separate instantiation: the 8 extra live registers spill in the 256 x 256
+// kernel (8 -> 20 VGPRs), which the BERT / WaveGlow GEMMs must not pay for.
+template <int DT, int A_MODE, int B_MODE, int NSTAGE, int BIG, int PLAIN = 0, int BST = 0>
 __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) void gemm2_kernel(Gemm2Args p) {
   constexpr int WGN = BIG ? 4 : 2;                     // wave grid 2 x WGN
   constexpr int NW = 2 * WGN, NT = 64 * NW;
@@ -541,11 +545,13 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
       const ushort8_t ov = pack8<DT>(v);
       if (remap) *(ushort8_t*)(c + it * step + (long long)fd_div(mrow0 + it * RPI, p.row_div) * p.row_extra) = ov;
       else *(ushort8_t*)(c + it * step) = ov;
-      if (!BIG && act == ACT_NONE && p.stats) {          // BatchNorm statistics of what the next pass will read
+      if ((BST ? (act == ACT_RELU_BWD || (!BIG && act == ACT_NONE)) : (!BIG && act == ACT_NONE)) && p.stats) {
+        // column sums of the ROUNDED output: BatchNorm statistics of what the next pass will read (sums + squares), or the
+        // bias gradient of the layer whose ReLU mask this epilogue applies (sums only)
         float vr[8];
         unpack8<DT>(ov, vr);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { st0[r] += vr[r]; st1[r] += vr[r] * vr[r]; }
+        for (int r = 0; r < 8; ++r) { st0[r] += vr[r]; if (!BIG) st1[r] += vr[r] * vr[r]; }
       }
     }
   };
@@ -632,7 +638,16 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
                   v[r] *= 0.5f * (1.f + th) + 0.5f * y * (1.f - th * th) * k0 * (1.f + 3.f * k1 * y * y);
                 }
               }
-              *(ushort8_t*)(c + it * step) = pack8<DT>(v);
+              const ushort8_t ov = pack8<DT>(v);
+              *(ushort8_t*)(c + it * step) = ov;
+              if constexpr (BST && act == ACT_RELU_BWD) {
+                if (p.stats) {                    // bias gradient of the layer below: column sums of the rounded, masked output
+                  float vr[8];
+                  unpack8<DT>(ov, vr);
+#pragma unroll
+                  for (int r = 0; r < 8; ++r) st0[r] += vr[r];
+                }
+              }
             }
           }
         }
@@ -722,26 +737,27 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
     epi_store8<DT>(p, v, m, n, nval, vec16, blockIdx.y);
   }
   }
-  if (!BIG && p.stats && fast) {
+  }   // !epilogue_done
+  if ((BST || !BIG) && p.stats && fast) {
     // the 16 threads that share a column group meet in LDS; one plain store per (tile row, statistic, column):
-    // deterministic, no atomics -- dle_bn_stats_from_partials sums the tile rows in a fixed order
+    // deterministic, no atomics -- dle_bn_stats_from_partials / the column-sum fold add the tile rows in a fixed order
+    const int nst = (BST && p.stats_sums) ? 1 : 2;
     lds_barrier();
-    float* red = epi;                                    // [2][RPI][TN]
+    float* red = epi;                                    // [nst][RPI][TN]
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       red[(0 * RPI + f_ml0) * TN + f_nl + r] = st0[r];
-      red[(1 * RPI + f_ml0) * TN + f_nl + r] = st1[r];
+      if (!BIG) { if (nst == 2) red[(1 * RPI + f_ml0) * TN + f_nl + r] = st1[r]; }
     }
     lds_barrier();
-    for (int cidx = tid; cidx < 2 * TN; cidx += NT) {
+    for (int cidx = tid; cidx < nst * TN; cidx += NT) {
       const int which = cidx / TN, col = cidx - which * TN;
       float t = 0.f;
 #pragma unroll
       for (int q = 0; q < RPI; ++q) t += red[(which * RPI + q) * TN + col];
-      if (n0 + col < p.N) p.stats[((long long)tm * 2 + which) * p.N + n0 + col] = t;
+      if (n0 + col < p.N) p.stats[((long long)tm * nst + which) * p.N + n0 + col] = t;
     }
   }
-  }   // !epilogue_done
   if (!CAN_PERSIST || !has_next) break;
   counted_wait = fast && m0 + TM <= p.M && n0 + TN <= p.N && 2 * ITERS >= 8;
   vbid += vstep;
@@ -759,7 +775,8 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
 //  across tile boundaries, the epilogue through the 32 KiB of LDS the stages leave free -- measured 8% SLOWER at
 //  16384x4096x1024: its output stores still meet a vmcnt(0) three k-steps later and the 8-pass epilogue costs more
 //  than the tile turnover it saves; it was removed.)
-static int launch_gemm(const Gemm2Args& p_in, int in_dtype, int amode, int bmode, int batch, hipStream_t stream) {
+static int launch_gemm(const Gemm2Args& p_in, int in_dtype, int amode, int bmode, int batch, hipStream_t stream,
+                       int* tile_rows_out = nullptr) {
   Gemm2Args p = p_in;
   static const int gm_env = getenv("DLE_GEMM_GM") ? atoi(getenv("DLE_GEMM_GM")) : 8;
   p.gm = gm_env > 0 ? gm_env : 8;
@@ -778,6 +795,7 @@ static int launch_gemm(const Gemm2Args& p_in, int in_dtype, int amode, int bmode
   const long long work_big = tiles_big * (batch > 0 ? batch : 1) * (SLAB_MODE(p) ? p.splitk : 1);
   const bool want = !p.force_small && (big_mode >= 1 || (big_mode != 0 && (p.splitk == 1 || SLAB_MODE(p)) && kt_per_item >= 4 &&
                                                          work_big >= (p.splitk == 1 ? 160 : 128)));
+  if (tile_rows_out) *tile_rows_out = (fits && want) ? 256 : BM;
   if (fits && want) {
     dim3 grid((unsigned)tiles_big, p.splitk, batch > 0 ? batch : 1), block(512);
     // 128 KiB of operand stages + (when the device grants a workgroup the whole 160 KiB) 32 KiB for epilogue source rows
@@ -791,7 +809,13 @@ static int launch_gemm(const Gemm2Args& p_in, int in_dtype, int amode, int bmode
       if (!attr_set) { hipFuncSetAttribute((const void*)gemm2_kernel<DT, AM, BMODE, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big); attr_set = true; } \
       hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE, 2, 1>), grid, block, lds_big, stream, p); } while (0)
 #define PICKBIG(DT) do { if (amode == 0 && bmode == 0) GOBIG(DT, 0, 0); else if (amode == 0) GOBIG(DT, 0, 1); else GOBIG(DT, 1, 1); } while (0)
-    if (in_dtype == DLE_F16) PICKBIG(DLE_F16); else PICKBIG(DLE_BF16);
+#define GOBIGST(DT) do { static bool attr_set = false; \
+      if (!attr_set) { hipFuncSetAttribute((const void*)gemm2_kernel<DT, 0, 1, 2, 1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big); attr_set = true; } \
+      hipLaunchKernelGGL((gemm2_kernel<DT, 0, 1, 2, 1, 0, 1>), grid, block, lds_big, stream, p); } while (0)
+    if (p.stats) {                                   // (launch_gemm's caller checked: sums only, ReLU-mask epilogue, operands (0, 1))
+      if (in_dtype == DLE_F16) GOBIGST(DLE_F16); else GOBIGST(DLE_BF16);
+    } else if (in_dtype == DLE_F16) PICKBIG(DLE_F16); else PICKBIG(DLE_BF16);
+#undef GOBIGST
 #undef GOBIG
 #undef PICKBIG
   } else {
@@ -811,12 +835,14 @@ static int launch_gemm(const Gemm2Args& p_in, int in_dtype, int amode, int bmode
                        (((uintptr_t)p.C) & 15) == 0;
 #define GO(DT, AM, BMODE) hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE, 2, 0>), grid, block, lds, stream, p)
 #define GOP(DT, AM, BMODE) hipLaunchKernelGGL((gemm2_kernel<DT, AM, BMODE, 2, 0, 1>), grid, block, lds, stream, p)
-#define PICK(DT) do { if (plain) { if (amode == 0 && bmode == 0) GOP(DT, 0, 0); else if (amode == 0) GOP(DT, 0, 1); else GOP(DT, 1, 1); } \
+#define GOST(DT) hipLaunchKernelGGL((gemm2_kernel<DT, 0, 1, 2, 0, 0, 1>), grid, block, lds, stream, p)
+#define PICK(DT) do { if (p.stats && p.stats_sums) GOST(DT); else if (plain) { if (amode == 0 && bmode == 0) GOP(DT, 0, 0); else if (amode == 0) GOP(DT, 0, 1); else GOP(DT, 1, 1); } \
       else if (amode == 0 && bmode == 0) GO(DT, 0, 0); else if (amode == 0) GO(DT, 0, 1); else if (amode == 1 && bmode == 1) GO(DT, 1, 1); \
       else if (amode == 2) GO(DT, 2, 0); else if (amode == 4) GO(DT, 4, 5); else GO(DT, 1, 3); } while (0)
     if (in_dtype == DLE_F16) PICK(DLE_F16); else PICK(DLE_BF16);
 #undef GO
 #undef GOP
+#undef GOST
 #undef PICK
   }
   hipError_t e = hipGetLastError();
@@ -958,6 +984,65 @@ extern "C" int dle_gemm_dma_try(const void* A, const void* B, void* C, void* aux
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { dle_set_error("splitk_reduce launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
   }
+  return 1;
+}
+
+// out[n] = sum over the tile rows g of partial[g][n] (fixed order): 16 columns x 16 row slices per workgroup
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ partial, float* __restrict__ out, int N,
+                                                          int groups) {
+  __shared__ float red[256];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int n = blockIdx.x * 16 + cl;
+  float s = 0.f;
+  if (n < N) {
+    int g = sl;
+    for (; g + 48 < groups; g += 64) {
+      float a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = partial[(long long)(g + 16 * u) * N + n];
+      s += (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    for (; g < groups; g += 16) s += partial[(long long)g * N + n];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sl == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q * 16 + cl];
+    out[n] = t;
+  }
+}
+
+// C[M, N] = (A[M, K] B[K, N]) under the ReLU mask of mask_src (same shape / pitch as C) AND colsum_out[n] = sum_m C[m, n] of the
+// ROUNDED output: the data gradient of a linear layer together with the bias gradient of the layer below it
+// (Recommendation/DLRM/dlrm/nn/mlps.py:38-43 backward: dX = (dY W) * relu'(x), db = sum_m dX) -- the separate column-sum pass
+// re-read every dX the step had just written (114 us per DLRM step at batch 65536).  One partial row per tile row, folded in a
+// fixed order.  1: launched; 0: outside the envelope (the caller runs dle_gemm + dle_colsum); > 1: error.
+extern "C" int dle_gemm_relu_bwd_colsum(const void* A, const void* B, void* C, const void* mask_src, float* colsum_out, int M, int N,
+                                        int K, int64_t lda, int64_t ldb, int64_t ldc, int dtype, void* workspace,
+                                        int64_t workspace_bytes, hipStream_t stream) {
+  static const int mode = getenv("DLE_GEMM_COLSUM") ? atoi(getenv("DLE_GEMM_COLSUM")) : 1;
+  if (!mode || !A || !B || !C || !mask_src || !colsum_out || !workspace) return 0;
+  if (dtype != DLE_F16 && dtype != DLE_BF16) return 0;
+  const bool al = ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)mask_src) | ((uintptr_t)workspace)) & 15) == 0 &&
+                  (lda & 7) == 0 && (ldb & 7) == 0 && (ldc & 7) == 0;
+  if (!al || (K & 7) != 0 || (N & 7) != 0 || M < 1 || N < 8 || K < 8) return 0;
+  if ((long long)lda * BM * 2 > 0x7FFFFFFFLL || (long long)ldb * BK * 2 > 0x7FFFFFFFLL) return 0;
+  const long long groups_max = (M + BM - 1) / BM;
+  if (workspace_bytes < groups_max * N * 4) return 0;
+  Gemm2Args p = {};
+  p.A = (const unsigned short*)A; p.B = (const unsigned short*)B; p.C = C; p.mask_src = (const unsigned short*)mask_src;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.out_dtype = dtype; p.act = ACT_RELU_BWD; p.splitk = 1; p.alpha = 1.0f;
+  p.cg = make_geom(1, 1, 1, 1, 1, 1, 1, 1, 0, 1);
+  p.stats = (float*)workspace; p.stats_sums = 1;
+  int tile_rows = 0;
+  { const int rc = launch_gemm(p, dtype, 0, 1, 0, stream, &tile_rows); if (rc) return rc + 1000; }
+  hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, (const float*)workspace, colsum_out, N,
+                     (M + tile_rows - 1) / tile_rows);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { dle_set_error("colsum_fold launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
   return 1;
 }
 

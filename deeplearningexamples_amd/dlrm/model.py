@@ -124,6 +124,7 @@ class Mlp(nn.Module):
         acts, w16, lins = self._saved, self.working_copies(), self.linears
         g = gy
         pending = []
+        bias_done = {len(lins) - 1} if skip_last_bias else set()
 
         def wgrad(i, g):
             lin, x = lins[i], acts[i]
@@ -137,7 +138,7 @@ class Mlp(nn.Module):
                    splitk=F.pick_splitk(lin.out_features, kp, m))
             if gw_full is not gw:
                 gw.copy_(gw_full[:, :lin.in_features])
-            if not (skip_last_bias and i == len(lins) - 1):       # (the fused head already wrote the last layer's bias gradient)
+            if i not in bias_done:           # (written by the producer of g: the fused head / the data-gradient GEMM above)
                 F.colsum(g, out=gb)
 
         gin = None
@@ -153,9 +154,17 @@ class Mlp(nn.Module):
             else:
                 wgrad(i, g)
             if i > 0:
-                # dX = g W, masked by the ReLU of the previous layer in the epilogue
-                g = F.gemm(g, w16[i], m, kp, lin.out_features, True, False, out_dtype=self.compute_dtype,
-                           act=C.ACT_RELU_BWD, mask_src=acts[i])
+                # dX = g W, masked by the ReLU of the previous layer in the epilogue -- which also leaves the column sums of dX,
+                # the bias gradient of the layer below (one pass less over every dX)
+                gb_prev = grads[i - 1][1] if grads is not None else _grad_buf(lins[i - 1].bias)
+                gn = F.gemm_relu_bwd_colsum(g, w16[i], m, kp, lin.out_features, acts[i], gb_prev) \
+                    if kp == lins[i - 1].out_features else None
+                if gn is not None:
+                    bias_done.add(i - 1)
+                    g = gn
+                else:
+                    g = F.gemm(g, w16[i], m, kp, lin.out_features, True, False, out_dtype=self.compute_dtype,
+                               act=C.ACT_RELU_BWD, mask_src=acts[i])
                 masked = True
             elif need_input_grad:
                 gin = F.gemm(g, w16[i], m, kp, lin.out_features, True, False, out_dtype=self.compute_dtype)
