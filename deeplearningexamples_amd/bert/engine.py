@@ -410,10 +410,17 @@ class BertTrainer:
                 do2 = dz2
                 self._bgrad(pre + "output.dense.bias", do2, acc)
             self._wgrad(pre + "output.dense.weight", do2, a["it"], acc)
-            dpre = F.gemm(do2, self.w16[pre + "output.dense.weight"], t, inter, h, True, False, act=C.ACT_MUL,
-                          mask_src=a["pre"])
+            # ... times the stored GELU derivative; the epilogue also leaves the column sums = the bias gradient of dense_act
+            dpre = F.gemm_colsum(do2, self.w16[pre + "output.dense.weight"], t, inter, h, a["pre"],
+                                 self.gview[pre + "intermediate.dense_act.bias"], act=C.ACT_MUL, accumulate=acc) \
+                if os.environ.get("DLE_BERT_FUSE_BIAS_GRAD", "1") != "0" else None
+            fused_b = dpre is not None
+            if not fused_b:
+                dpre = F.gemm(do2, self.w16[pre + "output.dense.weight"], t, inter, h, True, False, act=C.ACT_MUL,
+                              mask_src=a["pre"])
             self._wgrad(pre + "intermediate.dense_act.weight", dpre, a["x1"], acc)
-            self._bgrad(pre + "intermediate.dense_act.bias", dpre, acc)
+            if not fused_b:
+                self._bgrad(pre + "intermediate.dense_act.bias", dpre, acc)
             dx1 = F.gemm(dpre, self.w16[pre + "intermediate.dense_act.weight"], t, h, inter, True, False, act=C.ACT_ADD,
                          mask_src=dz2)
             if a["mask_1"] is not None:

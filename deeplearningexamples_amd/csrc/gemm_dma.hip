@@ -194,8 +194,8 @@ __device__ __forceinline__ void epi_store8(const Gemm2Args& p, float* v, int m, 
 // loop (its LDS-DMA goes through inline asm), so hipcc's wait-count pass has nothing to drain: with the general epilogue in
 // the same code it inserts s_waitcnt vmcnt(0) at the head of every tile (a bias / addend load of some path might still be
 // in flight when a register is reused), which waits for the previous tile's STORES before the next DMA can be issued.
-// BST = 1: the ReLU-mask epilogue (ACT_RELU_BWD) also leaves the column sums of its rounded output (p.stats, p.stats_sums) -- the
-// bias gradient of the layer whose mask it applies.  A separate instantiation: the 8 extra live registers spill in the 256 x 256
+// BST = 1: the ReLU-mask / activation-derivative epilogues (ACT_RELU_BWD, ACT_MUL) also leave the column sums of their rounded
+// output (p.stats, p.stats_sums) -- the bias gradient of the layer whose activation derivative they apply.  A separate instantiation: the 8 extra live registers spill in the 256 x 256
 // kernel (8 -> 20 VGPRs), which the BERT / WaveGlow GEMMs must not pay for.
 template <int DT, int A_MODE, int B_MODE, int NSTAGE, int BIG, int PLAIN = 0, int BST = 0>
 __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) void gemm2_kernel(Gemm2Args p) {
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
       const ushort8_t ov = pack8<DT>(v);
       if (remap) *(ushort8_t*)(c + it * step + (long long)fd_div(mrow0 + it * RPI, p.row_div) * p.row_extra) = ov;
       else *(ushort8_t*)(c + it * step) = ov;
-      if ((BST ? (act == ACT_RELU_BWD || (!BIG && act == ACT_NONE)) : (!BIG && act == ACT_NONE)) && p.stats) {
+      if ((BST ? (act == ACT_RELU_BWD || act == ACT_MUL || (!BIG && act == ACT_NONE)) : (!BIG && act == ACT_NONE)) && p.stats) {
         // column sums of the ROUNDED output: BatchNorm statistics of what the next pass will read (sums + squares), or the
         // bias gradient of the layer whose ReLU mask this epilogue applies (sums only)
         float vr[8];
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : (NSTAGE == 1 ? 4 : 2)) v
               }
               const ushort8_t ov = pack8<DT>(v);
               *(ushort8_t*)(c + it * step) = ov;
-              if constexpr (BST && act == ACT_RELU_BWD) {
+              if constexpr (BST && (act == ACT_RELU_BWD || act == ACT_MUL)) {
                 if (p.stats) {                    // bias gradient of the layer below: column sums of the rounded, masked output
                   float vr[8];
                   unpack8<DT>(ov, vr);
@@ -989,7 +989,7 @@ extern "C" int dle_gemm_dma_try(const void* A, const void* B, void* C, void* aux
 
 // out[n] = sum over the tile rows g of partial[g][n] (fixed order): 16 columns x 16 row slices per workgroup
 __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ partial, float* __restrict__ out, int N,
-                                                          int groups) {
+                                                          int groups, int accumulate) {
   __shared__ float red[256];
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int n = blockIdx.x * 16 + cl;
@@ -1010,18 +1010,22 @@ __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restric
     float t = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) t += red[q * 16 + cl];
-    out[n] = t;
+    out[n] = accumulate ? out[n] + t : t;
   }
 }
 
-// C[M, N] = (A[M, K] B[K, N]) under the ReLU mask of mask_src (same shape / pitch as C) AND colsum_out[n] = sum_m C[m, n] of the
-// ROUNDED output: the data gradient of a linear layer together with the bias gradient of the layer below it
-// (Recommendation/DLRM/dlrm/nn/mlps.py:38-43 backward: dX = (dY W) * relu'(x), db = sum_m dX) -- the separate column-sum pass
-// re-read every dX the step had just written (114 us per DLRM step at batch 65536).  One partial row per tile row, folded in a
-// fixed order.  1: launched; 0: outside the envelope (the caller runs dle_gemm + dle_colsum); > 1: error.
-extern "C" int dle_gemm_relu_bwd_colsum(const void* A, const void* B, void* C, const void* mask_src, float* colsum_out, int M, int N,
-                                        int K, int64_t lda, int64_t ldb, int64_t ldc, int dtype, void* workspace,
-                                        int64_t workspace_bytes, hipStream_t stream) {
+// C[M, N] = f(A[M, K] B[K, N], src[M, N]) AND colsum_out[n] (+)= sum_m C[m, n] of the ROUNDED output: the data gradient of a linear
+// layer through the activation derivative of the layer below, together with that layer's bias gradient.  act = DLE_ACT_RELU_BWD
+// (C = product where src > 0: Recommendation/DLRM/dlrm/nn/mlps.py:38-43 backward) or DLE_ACT_MUL (C = product * src, src = the
+// stored GELU derivative: LanguageModeling/BERT/modeling.py:130-160 backward of bias_gelu).  The separate column-sum pass re-read
+// every such gradient the step had just written (114 us per DLRM step at batch 65536, 1.06 ms per BERT-Large step).  One
+// partial row per tile row, folded in a fixed order.  1: launched; 0: outside the envelope (the caller runs dle_gemm +
+// dle_colsum); > 1: error.
+extern "C" int dle_gemm_colsum(const void* A, const void* B, void* C, const void* src, float* colsum_out, int M, int N, int K,
+                               int64_t lda, int64_t ldb, int64_t ldc, int dtype, int act, int accumulate_colsum, void* workspace,
+                               int64_t workspace_bytes, hipStream_t stream) {
+  const void* mask_src = src;
+  if (act != ACT_RELU_BWD && act != ACT_MUL) return 0;
   static const int mode = getenv("DLE_GEMM_COLSUM") ? atoi(getenv("DLE_GEMM_COLSUM")) : 1;
   if (!mode || !A || !B || !C || !mask_src || !colsum_out || !workspace) return 0;
   if (dtype != DLE_F16 && dtype != DLE_BF16) return 0;
@@ -1034,13 +1038,13 @@ extern "C" int dle_gemm_relu_bwd_colsum(const void* A, const void* B, void* C, c
   Gemm2Args p = {};
   p.A = (const unsigned short*)A; p.B = (const unsigned short*)B; p.C = C; p.mask_src = (const unsigned short*)mask_src;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-  p.out_dtype = dtype; p.act = ACT_RELU_BWD; p.splitk = 1; p.alpha = 1.0f;
+  p.out_dtype = dtype; p.act = act; p.splitk = 1; p.alpha = 1.0f;
   p.cg = make_geom(1, 1, 1, 1, 1, 1, 1, 1, 0, 1);
   p.stats = (float*)workspace; p.stats_sums = 1;
   int tile_rows = 0;
   { const int rc = launch_gemm(p, dtype, 0, 1, 0, stream, &tile_rows); if (rc) return rc + 1000; }
   hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, (const float*)workspace, colsum_out, N,
-                     (M + tile_rows - 1) / tile_rows);
+                     (M + tile_rows - 1) / tile_rows, accumulate_colsum);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { dle_set_error("colsum_fold launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
   return 1;

@@ -157,7 +157,7 @@ class Mlp(nn.Module):
                 # dX = g W, masked by the ReLU of the previous layer in the epilogue -- which also leaves the column sums of dX,
                 # the bias gradient of the layer below (one pass less over every dX)
                 gb_prev = grads[i - 1][1] if grads is not None else _grad_buf(lins[i - 1].bias)
-                gn = F.gemm_relu_bwd_colsum(g, w16[i], m, kp, lin.out_features, acts[i], gb_prev) \
+                gn = F.gemm_colsum(g, w16[i], m, kp, lin.out_features, acts[i], gb_prev) \
                     if kp == lins[i - 1].out_features else None
                 if gn is not None:
                     bias_done.add(i - 1)

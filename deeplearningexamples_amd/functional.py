@@ -372,27 +372,28 @@ def splitk_workspace(device, nbytes):
     return w
 
 
-def gemm_relu_bwd_colsum(g, w, m, n, k, mask_src, colsum_out):
-    """dX [m, n] = (g [m, k] w [k, n]) under the ReLU mask of mask_src [m, n], and colsum_out [n] (fp32, overwritten) = column
-    sums of the rounded dX: the data gradient of a linear layer + the bias gradient of the layer below in one launch (+ a small
-    fold).  -> dX, or None outside the kernel's envelope (the caller runs gemm + colsum)."""
-    C.require_cuda(g, w, mask_src, colsum_out)
-    if (g.dtype not in (torch.float16, torch.bfloat16) or w.dtype != g.dtype or mask_src.dtype != g.dtype
-            or g.stride(1) != 1 or w.stride(1) != 1 or mask_src.stride(1) != 1
+def gemm_colsum(g, w, m, n, k, src, colsum_out, act=C.ACT_RELU_BWD, accumulate=False):
+    """dX [m, n] = f(g [m, k] w [k, n], src [m, n]) and colsum_out [n] (fp32) (+)= column sums of the rounded dX: the data gradient
+    of a linear layer through the activation derivative of the layer below + that layer's bias gradient in one launch (+ a small
+    fold).  act = ACT_RELU_BWD (dX = product where src > 0) or ACT_MUL (dX = product * src).  -> dX, or None outside the kernel's
+    envelope (the caller runs gemm + colsum)."""
+    C.require_cuda(g, w, src, colsum_out)
+    if (g.dtype not in (torch.float16, torch.bfloat16) or w.dtype != g.dtype or src.dtype != g.dtype
+            or g.stride(1) != 1 or w.stride(1) != 1 or src.stride(1) != 1 or act not in (C.ACT_RELU_BWD, C.ACT_MUL)
             or colsum_out.dtype != torch.float32 or not colsum_out.is_contiguous() or colsum_out.numel() != n):
         return None
     out = torch.empty((m, n), dtype=g.dtype, device=g.device)
-    if mask_src.stride(0) != out.stride(0):
+    if src.stride(0) != out.stride(0):
         return None
     ws = splitk_workspace(g.device, ((m + 127) // 128) * n * 4)
     by = float(m) * (k + 2 * n) * g.element_size() + float(k) * n * w.element_size()
     C.annotate(bytes=by, flops=2.0 * m * n * k, tag="%dx%dx%d+src+colsum" % (m, n, k))
     # (recorded in the family of the GEMM it replaces)
-    rc = _timed_optional("dle_gemm", C.lib().dle_gemm_relu_bwd_colsum,
-                         (C.ptr(g), C.ptr(w), C.ptr(out), C.ptr(mask_src), C.ptr(colsum_out), m, n, k, g.stride(0), w.stride(0),
-                          out.stride(0), C.dt(g), C.ptr(ws), ws.numel() * 4, C.stream()))
+    rc = _timed_optional("dle_gemm", C.lib().dle_gemm_colsum,
+                         (C.ptr(g), C.ptr(w), C.ptr(out), C.ptr(src), C.ptr(colsum_out), m, n, k, g.stride(0), w.stride(0),
+                          out.stride(0), C.dt(g), int(act), int(accumulate), C.ptr(ws), ws.numel() * 4, C.stream()))
     if rc > 1:
-        C.check(rc - 1000 if rc > 1000 else -1, "dle_gemm_relu_bwd_colsum")
+        C.check(rc - 1000 if rc > 1000 else -1, "dle_gemm_colsum")
     return out if rc == 1 else None
 
 

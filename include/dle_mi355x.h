@@ -232,13 +232,15 @@ int dle_transpose_cast(const void* x, void* y, int rows, int cols, int64_t ld_x,
 int dle_a2a_blocks(void* blocks, void* x, int rows, int world, const int* widths, int elem_size, int pack, hipStream_t stream);
 int dle_bce_logits(const void* logits, const float* target, float* loss_out, void* dlogits,
                    const float* grad_scale_dev, int64_t n, int64_t ld_logits, int dtype, hipStream_t stream);
-/* Data gradient of a linear layer + bias gradient of the layer below in one launch (csrc/gemm_dma.hip; dlrm/nn/mlps.py:38-43
- * backward, apex.mlp): C[M, N] = (A[M, K] B[K, N]) where mask_src[M, N] > 0 else 0 (16-bit, pitch ldc for both), colsum_out[n] =
- * sum_m C[m, n] of the rounded output (fp32; one partial row per tile row in `workspace` >= ceil(M / 128) * N * 4 bytes, folded
- * in a fixed order).  A k-contiguous, B n-contiguous.  1: launched; 0: outside the envelope (run dle_gemm + dle_colsum). */
-int dle_gemm_relu_bwd_colsum(const void* A, const void* B, void* C, const void* mask_src, float* colsum_out, int M, int N, int K,
-                             int64_t lda, int64_t ldb, int64_t ldc, int dtype, void* workspace, int64_t workspace_bytes,
-                             hipStream_t stream);
+/* Data gradient of a linear layer through the activation derivative of the layer below + that layer's bias gradient in one launch
+ * (csrc/gemm_dma.hip): C[M, N] = f(A[M, K] B[K, N], src[M, N]) (16-bit, pitch ldc for C and src), colsum_out[n] (+)= sum_m C[m, n]
+ * of the rounded output (fp32).  act = DLE_ACT_RELU_BWD: C = product where src > 0 else 0 (dlrm/nn/mlps.py:38-43 backward, apex.mlp);
+ * DLE_ACT_MUL: C = product * src, src = the stored GELU derivative (BERT/modeling.py:130-160, bias_gelu backward).  One partial row
+ * per tile row in `workspace` (>= ceil(M / 128) * N * 4 bytes), folded in a fixed order.  A k-contiguous, B n-contiguous.
+ * 1: launched; 0: outside the envelope (run dle_gemm + dle_colsum). */
+int dle_gemm_colsum(const void* A, const void* B, void* C, const void* src, float* colsum_out, int M, int N, int K, int64_t lda,
+                    int64_t ldb, int64_t ldc, int dtype, int act, int accumulate_colsum, void* workspace,
+                    int64_t workspace_bytes, hipStream_t stream);
 /* The head of the DLRM top model in one pass (csrc/dlrm_head.hip): the last linear layer (out_features = 1,
  * dlrm/model/distributed.py top MLP, dlrm/nn/mlps.py:38-43), BCEWithLogitsLoss(mean) (scripts/main.py:556,589-592) and the
  * backward of both -- replaces dle_gemm (batch x 1 x K) + dle_bce_logits + dle_gemm (batch x K x 1, ReLU mask) + dle_gemm

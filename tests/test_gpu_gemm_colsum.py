@@ -1,5 +1,6 @@
-"""dle_gemm_relu_bwd_colsum: the data gradient of a linear layer under the ReLU mask of the layer below AND that layer's bias
-gradient (column sums of the rounded output) from one launch (dlrm/nn/mlps.py:38-43 backward) -- against the separate launches
+"""dle_gemm_colsum: the data gradient of a linear layer through the activation derivative of the layer below (ReLU mask: dlrm/nn/
+mlps.py:38-43 backward; stored GELU derivative: BERT/modeling.py:130-160) AND that layer's bias gradient (column sums of the
+rounded output) from one launch -- against the separate launches
 (dle_gemm with the same epilogue: bit-identical output; dle_colsum / a float64 sum for the column sums).  GPU only."""
 import numpy as np
 import pytest
@@ -19,7 +20,7 @@ def test_masked_dgrad_with_column_sums(cuda, m, n, k, dtype):
     y = torch.relu(torch.randn(m, n, generator=gen)).to(dtype).to(cuda)          # forward activation of the layer below
     ref = F.gemm(g, w, m, n, k, True, False, out_dtype=dtype, act=C.ACT_RELU_BWD, mask_src=y)
     cs = torch.full((n,), 3.0, device=cuda)
-    out = F.gemm_relu_bwd_colsum(g, w, m, n, k, y, cs)
+    out = F.gemm_colsum(g, w, m, n, k, y, cs)
     assert out is not None
     assert torch.equal(out, ref)
     exact = out.to(torch.float64).sum(0)
@@ -29,8 +30,15 @@ def test_masked_dgrad_with_column_sums(cuda, m, n, k, dtype):
     # masked columns really are zero where the activation was
     assert torch.all(out[y == 0] == 0)
     cs2 = torch.empty_like(cs)
-    out2 = F.gemm_relu_bwd_colsum(g, w, m, n, k, y, cs2)
+    out2 = F.gemm_colsum(g, w, m, n, k, y, cs2)
     assert torch.equal(out2, out) and torch.equal(cs2, cs)                       # fixed fold order
+    # the multiplicative epilogue (stored activation derivative), accumulating into the bias gradient
+    refm = F.gemm(g, w, m, n, k, True, False, out_dtype=dtype, act=C.ACT_MUL, mask_src=y)
+    cs3 = cs.clone()
+    outm = F.gemm_colsum(g, w, m, n, k, y, cs3, act=C.ACT_MUL, accumulate=True)
+    assert torch.equal(outm, refm)
+    exm, magm = refm.to(torch.float64).sum(0), refm.to(torch.float64).abs().sum(0)
+    assert torch.all((cs3.to(torch.float64) - cs.to(torch.float64) - exm).abs() <= 2e-6 * (magm + mag) + 1e-9)
 
 
 def test_declines_outside_its_envelope(cuda):
@@ -38,5 +46,5 @@ def test_declines_outside_its_envelope(cuda):
     g = torch.randn(64, 12, device=cuda).half()
     w = torch.randn(12, 20, device=cuda).half()
     y = torch.randn(64, 20, device=cuda).half()
-    assert F.gemm_relu_bwd_colsum(g, w, 64, 20, 12, y, torch.empty(20, device=cuda)) is None       # K, N not multiples of 8
-    assert F.gemm_relu_bwd_colsum(g.float(), w.float(), 64, 20, 12, y.float(), torch.empty(20, device=cuda)) is None
+    assert F.gemm_colsum(g, w, 64, 20, 12, y, torch.empty(20, device=cuda)) is None       # K, N not multiples of 8
+    assert F.gemm_colsum(g.float(), w.float(), 64, 20, 12, y.float(), torch.empty(20, device=cuda)) is None
