@@ -536,23 +536,11 @@ __global__ __launch_bounds__(256) void emb_sgd_lists(float* __restrict__ weight,
                                                      const float* __restrict__ lr_dev, float lr_host,
                                                      const float* __restrict__ scale,
                                                      const float* __restrict__ skip_flag, int n, LookupMap map,
-                                                     int D4, long long g_bstride4, int prelinked) {
+                                                     int D4, long long g_bstride4) {
   __shared__ unsigned char t_lds[128];
-  const bool skip = skip_flag && *skip_flag != 0.0f;
-  if (skip && !prelinked) return;                   // (pass 1 saw the same flag: nothing is linked)
+  if (skip_flag && *skip_flag != 0.0f) return;
   if (threadIdx.x < 128) t_lds[threadIdx.x] = map.t[threadIdx.x];
   __syncthreads();
-  if (skip) {
-    // the lists were threaded before the flag was known (dle_emb_link): empty head[] again, touch nothing else
-    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x)) {
-      int b, t;
-      const int li = emb_lookup(map, t_lds, is_small, i, b, t);
-      if (li < 0) continue;
-      const long long r = rows[li];
-      if (head[r] == li) head[r] = -1;
-    }
-    return;
-  }
   const int T = map.T;
   const float lr = lr_dev ? *lr_dev : lr_host;
   const float alpha = -lr * (scale ? *scale : 1.0f);
@@ -660,45 +648,6 @@ extern "C" int dle_emb_onehot_try(float* weight, const int64_t* rows, const void
                                   const int* tab_rows, int n_tab, int64_t batch, int tables, int dim, int64_t grad_batch_stride,
                                   int grad_dtype, void* ws, int64_t ws_bytes, hipStream_t stream);
 
-// lookups of the tables that are NOT small (dle_emb_small_table_mask's rule, at most 64 small ones)
-static LookupMap emb_large_map(const int64_t* table_offsets_host, int tables, int dim) {
-  LookupMap map;
-  map.T = tables; map.nl = 0;
-  emb_make_div(tables, map.mul_t, map.shr_t);
-  map.mul_nl = map.mul_t; map.shr_nl = map.shr_t;
-  for (int i = 0; i < 128; ++i) map.t[i] = 0;
-  if (tables <= 128) {
-    int k = 0, n_small = 0;
-    for (int t = 0; t < tables; ++t) {
-      const long long r = table_offsets_host[t + 1] - table_offsets_host[t];
-      if (r * dim * 4 <= DLE_EMB_SMALL_LDS_BYTES && n_small < 64) { ++n_small; continue; }
-      map.t[k++] = (unsigned char)t;
-    }
-    map.nl = k;
-    emb_make_div(k, map.mul_nl, map.shr_nl);
-  }
-  return map;
-}
-
-// Pass 1 of dle_emb_sgd_dedup on its own: the lists depend on the row ids only, so a train step can thread them while the
-// forward pass is still running (the pass is bound by the round trips of its 4-byte exchanges, not by bytes: 64 us at batch
-// 65536 that hide under the top MLP instead of sitting at the tail of the step).  The update that follows is called with
-// prelinked = 1; it empties head[] again -- also when the step is skipped.
-extern "C" int dle_emb_link(const int64_t* rows, int32_t* head, int32_t* next, const unsigned char* is_small_dev,
-                            const int64_t* table_offsets_host, int64_t batch, int tables, int dim, hipStream_t stream) {
-  DLE_CHECK_ARG(dim > 0 && tables > 0, "emb_link: bad shape");
-  if (batch == 0) return 0;
-  DLE_CHECK_ARG(rows && head && next && is_small_dev && table_offsets_host, "emb_link: null pointer");
-  DLE_CHECK_ARG(batch * tables < 2147483647LL, "emb_link: more than 2^31 lookups per call");
-  const LookupMap map = emb_large_map(table_offsets_host, tables, dim);
-  const long long n_lk = (long long)batch * (map.nl ? map.nl : tables);
-  if (n_lk == 0) return 0;
-  hipLaunchKernelGGL(emb_link, dim3(grid_for(n_lk, 256)), dim3(256), 0, stream, (const long long*)rows, head, next,
-                     is_small_dev, (const float*)nullptr, (int)n_lk, map);
-  DLE_LAUNCH_CHECK();
-  return 0;
-}
-
 // ws (optional, dle_emb_onehot_workspace_bytes(number of tiny tables, batch) bytes): the tiny tables run as the one-hot MFMA
 // segment sum of emb_onehot.hip instead of the register form below
 extern "C" int dle_emb_sgd_dedup_ws(float* weight, const int64_t* rows, const void* grad, int32_t* head,
@@ -706,7 +655,7 @@ extern "C" int dle_emb_sgd_dedup_ws(float* weight, const int64_t* rows, const vo
                                     const int64_t* table_offsets_host, const float* lr_dev, float lr_host,
                                     const float* scale_dev, const float* skip_flag_dev, int64_t batch, int tables,
                                     int dim, int64_t grad_batch_stride, int grad_dtype, void* ws, int64_t ws_bytes,
-                                    int prelinked, hipStream_t stream) {
+                                    hipStream_t stream) {
   DLE_CHECK_ARG(dim > 0 && dim % 4 == 0 && tables > 0, "emb_sgd_dedup: bad shape");
   if (batch == 0) return 0;
   DLE_CHECK_ARG(weight && rows && grad && head && next && is_small_dev && table_offsets_host, "emb_sgd_dedup: null pointer");
@@ -777,17 +726,28 @@ extern "C" int dle_emb_sgd_dedup_ws(float* weight, const int64_t* rows, const vo
     DLE_LAUNCH_CHECK();
   }
   if (n_large > 0) {
-    const LookupMap map = emb_large_map(table_offsets_host, tables, dim);
-    const long long n_lk = (long long)batch * (map.nl ? map.nl : tables);
-    if (!prelinked) {
-      hipLaunchKernelGGL(emb_link, dim3(grid_for(n_lk, 256)), dim3(256), 0, stream, (const long long*)rows, head, next,
-                         is_small_dev, skip_flag_dev, (int)n_lk, map);
-      DLE_LAUNCH_CHECK();
+    LookupMap map;
+    map.T = tables; map.nl = 0;
+    emb_make_div(tables, map.mul_t, map.shr_t);
+    map.mul_nl = map.mul_t; map.shr_nl = map.shr_t;
+    for (int i = 0; i < 128; ++i) map.t[i] = 0;
+    if (tables <= 128) {
+      int k = 0, q = 0;
+      for (int t = 0; t < tables; ++t) {
+        if (q < st.n && st.t[q] == t) { ++q; continue; }                 // (st lists the small tables in ascending order)
+        map.t[k++] = (unsigned char)t;
+      }
+      map.nl = k;
+      emb_make_div(k, map.mul_nl, map.shr_nl);
     }
+    const long long n_lk = (long long)batch * (map.nl ? map.nl : tables);
+    hipLaunchKernelGGL(emb_link, dim3(grid_for(n_lk, 256)), dim3(256), 0, stream, (const long long*)rows, head, next,
+                       is_small_dev, skip_flag_dev, (int)n_lk, map);
+    DLE_LAUNCH_CHECK();
     const int grid = grid_for(n_lk, 4 * 4);
     static const int spec = getenv("DLE_EMB_SPEC") ? atoi(getenv("DLE_EMB_SPEC")) : 1;
-#define GO(IDT, VT) do { if (spec) hipLaunchKernelGGL((emb_sgd_lists<IDT, true>), dim3(grid), dim3(256), 0, stream, weight, (const long long*)rows, (const VT*)grad, head, (const int*)next, is_small_dev, lr_dev, lr_host, scale_dev, skip_flag_dev, (int)n_lk, map, D4, gs4, prelinked); \
-    else hipLaunchKernelGGL((emb_sgd_lists<IDT, false>), dim3(grid), dim3(256), 0, stream, weight, (const long long*)rows, (const VT*)grad, head, (const int*)next, is_small_dev, lr_dev, lr_host, scale_dev, skip_flag_dev, (int)n_lk, map, D4, gs4, prelinked); } while (0)
+#define GO(IDT, VT) do { if (spec) hipLaunchKernelGGL((emb_sgd_lists<IDT, true>), dim3(grid), dim3(256), 0, stream, weight, (const long long*)rows, (const VT*)grad, head, (const int*)next, is_small_dev, lr_dev, lr_host, scale_dev, skip_flag_dev, (int)n_lk, map, D4, gs4); \
+    else hipLaunchKernelGGL((emb_sgd_lists<IDT, false>), dim3(grid), dim3(256), 0, stream, weight, (const long long*)rows, (const VT*)grad, head, (const int*)next, is_small_dev, lr_dev, lr_host, scale_dev, skip_flag_dev, (int)n_lk, map, D4, gs4); } while (0)
     if (grad_dtype == DLE_F32) GO(DLE_F32, float4_t);
     else if (grad_dtype == DLE_F16) GO(DLE_F16, ushort4_t);
     else GO(DLE_BF16, ushort4_t);
@@ -803,5 +763,5 @@ extern "C" int dle_emb_sgd_dedup(float* weight, const int64_t* rows, const void*
                                  const float* scale_dev, const float* skip_flag_dev, int64_t batch, int tables,
                                  int dim, int64_t grad_batch_stride, int grad_dtype, hipStream_t stream) {
   return dle_emb_sgd_dedup_ws(weight, rows, grad, head, next, is_small_dev, table_offsets_host, lr_dev, lr_host, scale_dev,
-                              skip_flag_dev, batch, tables, dim, grad_batch_stride, grad_dtype, nullptr, 0, 0, stream);
+                              skip_flag_dev, batch, tables, dim, grad_batch_stride, grad_dtype, nullptr, 0, stream);
 }

@@ -103,10 +103,6 @@ class DlrmTrainer:
         self.comm_stream = torch.cuda.Stream(device=self.device) if world_size > 1 else None
         self.moving_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         import os
-        # DLE_DLRM_PRELINK=1: the list pass of the sparse embedding update is issued during the forward pass (behind the gather
-        # on the side stream).  Measured neutral at batch 65536 (2.566 / 2.579 ms against 2.561 / 2.565 ms inside the update: the
-        # step is bound by the chip's throughput, not by that pass's position), so it stays off.
-        self.prelink = os.environ.get("DLE_DLRM_PRELINK", "0") == "1" and self.device.type == "cuda"
         # last layer + loss + their backward as one kernel (DLE_DLRM_FUSE_HEAD=0: the separate GEMM / loss launches)
         self.fuse_head = (os.environ.get("DLE_DLRM_FUSE_HEAD", "1") != "0" and self.device.type == "cuda"
                           and model.top_model.head_fusable())
@@ -257,11 +253,7 @@ class DlrmTrainer:
     def train_step(self, numerical_features, categorical_features, click):
         """One optimisation step on a (global) batch.  Returns the device-resident fp32 loss [1]."""
         m, p, sc = self.model, self.plan, self.scaler
-        m.bottom_model.prelink_update = self.prelink and not self.freeze_embeddings
-        try:
-            bottom_out = m.bottom_model(numerical_features, categorical_features)
-        finally:
-            m.bottom_model.prelink_update = False
+        bottom_out = m.bottom_model(numerical_features, categorical_features)
         x = self._bottom_to_top(bottom_out) if self.world > 1 else bottom_out
         labels = click[p.batch_start[self.rank]:p.batch_start[self.rank + 1]] if self.world > 1 else click
         if self.fuse_head:

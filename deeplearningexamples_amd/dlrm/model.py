@@ -227,10 +227,6 @@ class JointEmbedding(nn.Module):
         return F.emb_gather_fwd(self.weight.data, self._rows, out_dtype=self.out_dtype, out=out,
                                 out_batch_stride=out_batch_stride)
 
-    def prelink(self):
-        """Thread the lists of the coming apply_sparse_sgd now (train step only: the next call on this module must be it)."""
-        F.emb_link_(self._rows, self.workspace())
-
     def apply_sparse_sgd(self, grad, lr, inv_scale=None, skip_flag=None, grad_batch_stride=0):
         F.emb_sgd_dedup_(self.weight.data, self._rows, grad, self.workspace(), lr, scale=inv_scale,
                          skip_flag=skip_flag, grad_batch_stride=grad_batch_stride)
@@ -274,8 +270,6 @@ class DlrmBottom(nn.Module):
                                           out_dtype=compute_dtype)
                            if len(categorical_feature_sizes) > 0 else None)
         self.mlp = Mlp(num_numerical_features, bottom_mlp_sizes, device, compute_dtype) if bottom_mlp_sizes else None
-        # set by the trainer around a train step's forward: forward() also threads the lists of the sparse update that follows
-        self.prelink_update = False
         if self.embeddings is not None:
             for size, w in zip(categorical_feature_sizes, self.embeddings.weights):
                 nn.init.uniform_(w, -math.sqrt(1. / size), math.sqrt(1. / size))
@@ -301,23 +295,13 @@ class DlrmBottom(nn.Module):
         side = self._side_stream(dev) if (self.mlp is not None and self.embeddings is not None) else None
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
-        gathered = None
         if self.embeddings is not None:
             with (torch.cuda.stream(side) if side is not None else _nullcontext()):
                 self.embeddings(categorical_inputs, out=out[:, slot:, :], out_batch_stride=n_vec * d)
-                if self.prelink_update:
-                    # the list pass of the sparse update depends on the row ids only: queued behind the gather on the side
-                    # stream it runs under the top model's forward GEMMs; the main stream waits for the GATHER only
-                    if side is not None:
-                        gathered = torch.cuda.Event()
-                        gathered.record(side)
-                    self.embeddings.prelink()
         if self.mlp is not None:
             x16 = F.cast_rows(numerical_input, self.compute_dtype, cols_out=self.mlp.k_padded(0))
             self.mlp(x16, out=out[:, 0, :])
-        if gathered is not None:
-            torch.cuda.current_stream().wait_event(gathered)
-        elif side is not None:
+        if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         self._out = out
         return out

@@ -158,21 +158,6 @@ class EmbUpdateWorkspace:
         return self.next
 
 
-def emb_link_(rows, ws):
-    """Pass 1 of emb_sgd_dedup_ ahead of time (during the forward pass): thread the large tables' lookups of `rows` [B, T] into
-    per-row lists in `ws`.  The NEXT emb_sgd_dedup_ on this workspace must be given the same `rows`; it skips its own pass 1."""
-    import ctypes
-    rows = _i64(rows, "rows")
-    C.require_cuda(rows)
-    b, t = rows.shape
-    if t != ws.tables:
-        raise ValueError("workspace was built for %d tables" % ws.tables)
-    nxt = ws.next_for(b * t, rows.device)
-    C.call("dle_emb_link", C.ptr(rows), C.ptr(ws.head), C.ptr(nxt), C.ptr(ws.is_small),
-           ws.offsets_host.ctypes.data_as(ctypes.c_void_p), b, t, ws.dim, C.stream())
-    ws.linked = (rows.data_ptr(), b, t)
-
-
 def emb_sgd_dedup_(weight, rows, grad, ws, lr, scale=None, skip_flag=None, grad_batch_stride=0):
     """In place W[rows[b,t]] -= lr*scale*grad[b,t] with duplicate rows summed first (no float atomics).
     rows int64 [B,T]; grad: tensor whose element (b,t,0) sits at data_ptr + b*grad_batch_stride + t*dim."""
@@ -190,14 +175,10 @@ def emb_sgd_dedup_(weight, rows, grad, ws, lr, scale=None, skip_flag=None, grad_
     # algorithmic: grad row read + table row read-modify-write + row id
     C.annotate(bytes=float(b) * t * (ws.dim * grad.element_size() + 2 * ws.dim * 4 + 8))
     oh = ws.onehot_for(b, weight.device) if grad.dtype in (torch.float16, torch.bfloat16) else None
-    linked = getattr(ws, "linked", None)
-    if linked is not None and linked != (rows.data_ptr(), b, t):
-        raise ValueError("emb_sgd_dedup_: the workspace holds lists threaded by emb_link_ for a different rows tensor")
-    ws.linked = None
     C.call("dle_emb_sgd_dedup_ws", C.ptr(weight), C.ptr(rows), C.ptr(grad), C.ptr(ws.head), C.ptr(nxt),
            C.ptr(ws.is_small), ws.offsets_host.ctypes.data_as(ctypes.c_void_p), C.ptr(lr_dev), lr_host,
            C.ptr(scale), C.ptr(skip_flag), b, t, ws.dim, grad_batch_stride, C.dt(grad), C.ptr(oh),
-           oh.numel() * 4 if oh is not None else 0, int(linked is not None), C.stream())
+           oh.numel() * 4 if oh is not None else 0, C.stream())
     return weight
 
 

@@ -93,20 +93,14 @@ int dle_emb_sgd_dedup(float* weight, const int64_t* rows, const void* grad, int3
  * pipe (csrc/emb_onehot.hip: the gradient rows stream HBM -> LDS once, the one-hot operand is built in registers; one fp32
  * partial block per (table, batch slice), folded in slice order -- bit-reproducible, no float atomics; replaces the per-lookup
  * atomicAdd of gather_gpu_fused.cu:161-202 on the tables every sample hits).  ws: dle_emb_onehot_workspace_bytes(number of
- * such tables, batch) bytes, or NULL (with prelinked = 0: = dle_emb_sgd_dedup).  dle_emb_onehot_try is the kernel's own entry (1 launched,
+ * such tables, batch) bytes, or NULL (= dle_emb_sgd_dedup).  dle_emb_onehot_try is the kernel's own entry (1 launched,
  * 0 outside its envelope): tab_t / tab_base / tab_rows = column index, first joint row and row count of each table (host). */
 int64_t dle_emb_onehot_workspace_bytes(int n_tables, int64_t batch);
 int dle_emb_sgd_dedup_ws(float* weight, const int64_t* rows, const void* grad, int32_t* head, int32_t* next,
                          const unsigned char* is_small_dev, const int64_t* table_offsets_host,
                          const float* lr_dev, float lr_host, const float* scale_dev,
                          const float* skip_flag_dev, int64_t batch, int tables, int dim,
-                         int64_t grad_batch_stride, int grad_dtype, void* ws, int64_t ws_bytes, int prelinked,
-                         hipStream_t stream);
-/* Pass 1 of the update (threading every large-table lookup into its row's list) on its own: it depends on the row ids only,
- * so the train step issues it during the forward pass; the update is then called with prelinked = 1 (same rows / head / next)
- * and leaves head[] all -1 again, also when *skip_flag_dev != 0. */
-int dle_emb_link(const int64_t* rows, int32_t* head, int32_t* next, const unsigned char* is_small_dev,
-                 const int64_t* table_offsets_host, int64_t batch, int tables, int dim, hipStream_t stream);
+                         int64_t grad_batch_stride, int grad_dtype, void* ws, int64_t ws_bytes, hipStream_t stream);
 int dle_emb_onehot_try(float* weight, const int64_t* rows, const void* grad, const float* lr_dev, float lr_host,
                        const float* scale_dev, const float* skip_flag_dev, const int* tab_t, const int64_t* tab_base,
                        const int* tab_rows, int n_tab, int64_t batch, int tables, int dim, int64_t grad_batch_stride,

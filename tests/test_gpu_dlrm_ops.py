@@ -285,21 +285,3 @@ def test_tiny_tables_onehot_mfma_vs_oracle(cuda, batch, dtype):
     F.emb_sgd_dedup_(wd, rd, gd[:, 1:, :], ws, lr, scale=inv, skip_flag=torch.ones(1, device=cuda),
                      grad_batch_stride=(len(sizes) + 1) * dim)
     assert torch.equal(wd.cpu(), torch.from_numpy(w))
-    # lists threaded ahead of time (dle_emb_link, as the train step does during its forward pass): same update; with the skip
-    # flag raised AFTER the link the workspace is emptied and nothing else moves
-    F.emb_link_(rd, ws)
-    assert int((ws.head != -1).sum().item()) > 0
-    F.emb_sgd_dedup_(wd, rd, gd[:, 1:, :], ws, lr, scale=inv, grad_batch_stride=(len(sizes) + 1) * dim)
-    assert int((ws.head != -1).sum().item()) == 0
-    err = np.abs(wd.cpu().numpy().astype(np.float64) - exp)
-    assert np.all(err <= 2e-6 * lr * mag + 1e-6 * np.abs(exp) + 1e-7)
-    before = wd.clone()
-    F.emb_link_(rd, ws)
-    F.emb_sgd_dedup_(wd, rd, gd[:, 1:, :], ws, lr, scale=inv, skip_flag=torch.ones(1, device=cuda),
-                     grad_batch_stride=(len(sizes) + 1) * dim)
-    assert torch.equal(wd, before) and int((ws.head != -1).sum().item()) == 0
-    F.emb_link_(rd, ws)
-    with pytest.raises(ValueError):
-        F.emb_sgd_dedup_(wd, rd.clone(), gd[:, 1:, :], ws, lr, grad_batch_stride=(len(sizes) + 1) * dim)
-    ws.linked = None
-    ws.head.fill_(-1)
