@@ -47,6 +47,7 @@ _SIGS = {
                                      c_void_p, c_float, c_void_p, c_void_p, c_i64, c_int, c_int, c_i64, c_int,
                                      c_void_p, c_i64, c_void_p]),
     "dle_emb_onehot_workspace_bytes": (c_i64, [c_int, c_i64]),
+    "dle_emb_sgd_workspace_bytes": (c_i64, [c_void_p, c_int, c_int, c_i64]),
     "dle_emb_onehot_try": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int, c_i64, c_int, c_int, c_i64, c_int, c_void_p, c_i64, c_void_p]),
     "dle_cast_rows": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_i64, c_i64, c_int, c_int, c_void_p]),

@@ -494,29 +494,61 @@ static void emb_make_div(int d, unsigned& mul, unsigned& shr) {
 __device__ __forceinline__ int emb_div(int n, int d, unsigned mul, unsigned shr) {
   return d <= 1 ? n : (int)(__umulhi((unsigned)n, mul) >> shr);
 }
-// -> lookup index (or -1 for a small table's lookup in the every-table form) and its (sample, table)
+// -> lookup index (or -1 for a small table's lookup in the every-table form), its (sample, table) and its slot k in the map
 __device__ __forceinline__ int emb_lookup(const LookupMap& m, const unsigned char* t_lds, const unsigned char* is_small, int i,
-                                          int& b, int& t) {
+                                          int& b, int& t, int& k) {
   const int nl = m.nl ? m.nl : m.T;
   b = emb_div(i, nl, m.nl ? m.mul_nl : m.mul_t, m.nl ? m.shr_nl : m.shr_t);
-  const int k = i - b * nl;
+  k = i - b * nl;
   t = m.nl ? (int)t_lds[k] : k;
   if (!m.nl && is_small && is_small[t]) return -1;
   return b * m.T + t;
 }
 
+// MID tables (more rows than the LDS / one-hot forms take, at most EMB_MID_ROWS): 65536 lookups on 1-2 k rows make lists of ~70
+// duplicates, and a list is walked by ONE half-wavefront, one dependent hop (next pointer + gradient row) at a time: ~95 hops
+// x 2.5 us for the longest one, which no amount of parallelism elsewhere shortens (tools/probes/emb_chain_probe.py: -92 us when
+// those tables have no duplicates).  Their rows get EMB_MID_S lists each, one per residue of the sample index: 8 x shorter
+// chains, walked by 8 half-wavefronts; a list's head writes its fp32 partial sum into scratch instead of updating the row,
+// and a small third pass adds a row's partials in residue order and does the ONE read-modify-write.
+#define EMB_MID_S 8
+#define EMB_MID_ROWS 4096
+#define EMB_MID_TABLES 16
+struct MidMap {
+  int n;                               // mid tables (0: the feature is off)
+  int rows_total;                      // sum of their row counts
+  int* head;                           // [rows_total * S]: -1 on entry (memset per call); a head that has written its partial: -2
+  float* partial;                      // [rows_total * S][dim]
+  int off[128];                        // per slot k of the LookupMap: first row of that table in head / partial, -1: not a mid table
+  long long base[128];                 // per slot k: first joint row of the table
+};
+struct MidFold {                       // the same tables, listed for the fold pass
+  int n, rows_total;
+  int off[EMB_MID_TABLES], rows[EMB_MID_TABLES];
+  long long base[EMB_MID_TABLES];
+};
+
 __global__ __launch_bounds__(256) void emb_link(const long long* __restrict__ rows, int* __restrict__ head,
                                                 int* __restrict__ next, const unsigned char* __restrict__ is_small,
-                                                const float* __restrict__ skip_flag, int n_lookups, LookupMap map) {
+                                                const float* __restrict__ skip_flag, int n_lookups, LookupMap map, MidMap mid) {
   __shared__ unsigned char t_lds[128];
+  __shared__ int moff_lds[128];
+  __shared__ long long mbase_lds[128];
   if (skip_flag && *skip_flag != 0.0f) return;
-  if (threadIdx.x < 128) t_lds[threadIdx.x] = map.t[threadIdx.x];
+  if (threadIdx.x < 128) {
+    t_lds[threadIdx.x] = map.t[threadIdx.x];
+    moff_lds[threadIdx.x] = mid.n ? mid.off[threadIdx.x] : -1;
+    mbase_lds[threadIdx.x] = mid.n ? mid.base[threadIdx.x] : 0;
+  }
   __syncthreads();
   for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n_lookups; i += (int)(gridDim.x * blockDim.x)) {
-    int b, t;
-    const int li = emb_lookup(map, t_lds, is_small, i, b, t);
+    int b, t, k;
+    const int li = emb_lookup(map, t_lds, is_small, i, b, t, k);
     if (li < 0) continue;
-    next[li] = atomicExch(head + rows[li], li);
+    const long long r = rows[li];
+    const int mo = map.nl ? moff_lds[k] : -1;
+    int* slot = mo >= 0 ? mid.head + ((long long)(mo + (int)(r - mbase_lds[k])) * EMB_MID_S + (b & (EMB_MID_S - 1))) : head + r;
+    next[li] = atomicExch(slot, li);
   }
 }
 
@@ -536,10 +568,16 @@ __global__ __launch_bounds__(256) void emb_sgd_lists(float* __restrict__ weight,
                                                      const float* __restrict__ lr_dev, float lr_host,
                                                      const float* __restrict__ scale,
                                                      const float* __restrict__ skip_flag, int n, LookupMap map,
-                                                     int D4, long long g_bstride4) {
+                                                     int D4, long long g_bstride4, MidMap mid) {
   __shared__ unsigned char t_lds[128];
+  __shared__ int moff_lds[128];
+  __shared__ long long mbase_lds[128];
   if (skip_flag && *skip_flag != 0.0f) return;
-  if (threadIdx.x < 128) t_lds[threadIdx.x] = map.t[threadIdx.x];
+  if (threadIdx.x < 128) {
+    t_lds[threadIdx.x] = map.t[threadIdx.x];
+    moff_lds[threadIdx.x] = mid.n ? mid.off[threadIdx.x] : -1;
+    mbase_lds[threadIdx.x] = mid.n ? mid.base[threadIdx.x] : 0;
+  }
   __syncthreads();
   const int T = map.T;
   const float lr = lr_dev ? *lr_dev : lr_host;
@@ -551,7 +589,7 @@ __global__ __launch_bounds__(256) void emb_sgd_lists(float* __restrict__ weight,
   constexpr int U = 2;
   for (int base = wave_id * (2 * U); base < n; base += n_waves * (2 * U)) {
     long long r[U];
-    int iu[U], nx[U], h[U];
+    int iu[U], nx[U], h[U], ms[U];                  // ms: sub-list slot of a mid table's lookup, -1 otherwise
     bool ok[U];
     typename In4<IDT>::V g[U];
     float4_t wv[U];
@@ -561,17 +599,19 @@ __global__ __launch_bounds__(256) void emb_sgd_lists(float* __restrict__ weight,
       // highest sample index -- walking the batch from its end starts the long duplicate chains of the 1-2 k-row tables (~70
       // dependent hops each) at the START of the kernel, under everything else, instead of as its tail
       const int i = n - 1 - (base + 2 * u + sub);
-      int jb, t;
-      const int li = emb_lookup(map, t_lds, is_small, i >= 0 ? i : 0, jb, t);
+      int jb, t, k;
+      const int li = emb_lookup(map, t_lds, is_small, i >= 0 ? i : 0, jb, t, k);
       ok[u] = i >= 0 && li >= 0;
       iu[u] = li >= 0 ? li : jb * T + t;            // (a small table's lookup: loads stay in range, nothing is stored)
       r[u] = rows[iu[u]];
       nx[u] = next[iu[u]];
       g[u] = grad[jb * g_bstride4 + (long long)t * D4 + lc];
+      const int mo = map.nl ? moff_lds[k] : -1;
+      ms[u] = mo >= 0 ? (mo + (int)(r[u] - mbase_lds[k])) * EMB_MID_S + (jb & (EMB_MID_S - 1)) : -1;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      h[u] = head[r[u]];
+      h[u] = *(ms[u] >= 0 ? (const int*)mid.head + ms[u] : (const int*)head + r[u]);
       if (SPEC) wv[u] = ((const float4_t*)(weight + r[u] * (long long)(D4 * 4)))[lc];
     }
 #pragma unroll
@@ -584,6 +624,11 @@ __global__ __launch_bounds__(256) void emb_sgd_lists(float* __restrict__ weight,
         const int jb = emb_div(j, T, map.mul_t, map.shr_t);
         sacc += In4<IDT>::up(grad[jb * g_bstride4 + (long long)(j - jb * T) * D4 + lc]);
         j = next[j];
+      }
+      if (ms[u] >= 0) {                             // mid table: this list's share of the row's sum goes to scratch (D4 <= 32)
+        if (l < D4) ((float4_t*)(mid.partial + (long long)ms[u] * (D4 * 4)))[l] = sacc;
+        if (l == 0) mid.head[ms[u]] = -2;
+        continue;
       }
       float4_t* w = (float4_t*)(weight + r[u] * (long long)(D4 * 4));
       if (l < D4) w[l] = wv[u] + alpha * sacc;
@@ -600,6 +645,37 @@ __global__ __launch_bounds__(256) void emb_sgd_lists(float* __restrict__ weight,
       if (l == 0) head[r[u]] = -1;                  // restore the workspace invariant
     }
   }
+}
+
+// pass 3 (mid tables): a half-wavefront per row adds the partial sums of its EMB_MID_S lists in residue order and updates the row
+__global__ __launch_bounds__(256) void emb_mid_fold(float* __restrict__ weight, const int* __restrict__ mhead,
+                                                    const float* __restrict__ partial, const float* __restrict__ lr_dev,
+                                                    float lr_host, const float* __restrict__ scale,
+                                                    const float* __restrict__ skip_flag, MidFold mf, int D4) {
+  if (skip_flag && *skip_flag != 0.0f) return;
+  const int q = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 5), l = threadIdx.x & 31;
+  if (q >= mf.rows_total) return;
+  int j = 0;
+  while (j + 1 < mf.n && q >= mf.off[j + 1]) ++j;
+  const long long row = mf.base[j] + (q - mf.off[j]);
+  const int lc = l < D4 ? l : D4 - 1;
+  int f[EMB_MID_S];
+  float4_t v[EMB_MID_S];
+#pragma unroll
+  for (int s2 = 0; s2 < EMB_MID_S; ++s2) {
+    f[s2] = mhead[q * EMB_MID_S + s2];
+    v[s2] = ((const float4_t*)(partial + ((long long)q * EMB_MID_S + s2) * (D4 * 4)))[lc];   // (unwritten scratch is never USED)
+  }
+  float4_t sum = {0.f, 0.f, 0.f, 0.f};
+  bool any = false;
+#pragma unroll
+  for (int s2 = 0; s2 < EMB_MID_S; ++s2)
+    if (f[s2] == -2) { sum += v[s2]; any = true; }
+  if (!any || l >= D4) return;
+  const float lr = lr_dev ? *lr_dev : lr_host;
+  const float alpha = -lr * (scale ? *scale : 1.0f);
+  float4_t* w = (float4_t*)(weight + row * (long long)(D4 * 4));
+  w[l] = w[l] + alpha * sum;
 }
 
 extern "C" int dle_emb_sparse_sgd(float* weight, const int64_t* rows, const void* grad,
@@ -648,8 +724,41 @@ extern "C" int dle_emb_onehot_try(float* weight, const int64_t* rows, const void
                                   const int* tab_rows, int n_tab, int64_t batch, int tables, int dim, int64_t grad_batch_stride,
                                   int grad_dtype, void* ws, int64_t ws_bytes, hipStream_t stream);
 
-// ws (optional, dle_emb_onehot_workspace_bytes(number of tiny tables, batch) bytes): the tiny tables run as the one-hot MFMA
-// segment sum of emb_onehot.hip instead of the register form below
+extern "C" int64_t dle_emb_onehot_workspace_bytes(int n_tables, int64_t batch);
+
+// Scratch layout of dle_emb_sgd_dedup_ws for 16-bit gradients: [one-hot partial blocks of the tiny tables | sub-list heads of the mid
+// tables | their partial sums], each part 256-byte aligned.
+struct EmbScratchPlan {
+  int n_tiny, n_mid, mid_rows;
+  long long onehot_bytes, mid_head_off, mid_partial_off, total;
+};
+static EmbScratchPlan emb_scratch_plan(const int64_t* table_offsets_host, int tables, int dim, int64_t batch) {
+  EmbScratchPlan pl = {};
+  static const int mid_mode = getenv("DLE_EMB_MID") ? atoi(getenv("DLE_EMB_MID")) : 1;
+  int n_small = 0;
+  for (int t = 0; t < tables; ++t) {
+    const long long r = table_offsets_host[t + 1] - table_offsets_host[t];
+    if (r * dim * 4 <= DLE_EMB_SMALL_LDS_BYTES && n_small < 64) {
+      ++n_small;
+      if (r <= 128 && dim <= 128 && (dim & 1) == 0) ++pl.n_tiny;
+    } else if (mid_mode && r <= EMB_MID_ROWS && dim <= 128 && tables <= 128 && pl.n_mid < EMB_MID_TABLES) {
+      ++pl.n_mid;
+      pl.mid_rows += (int)r;
+    }
+  }
+  pl.onehot_bytes = dim == 128 ? dle_emb_onehot_workspace_bytes(pl.n_tiny, batch) : 0;
+  pl.mid_head_off = (pl.onehot_bytes + 255) / 256 * 256;
+  pl.mid_partial_off = (pl.mid_head_off + (long long)pl.mid_rows * EMB_MID_S * 4 + 255) / 256 * 256;
+  pl.total = pl.mid_partial_off + (long long)pl.mid_rows * EMB_MID_S * dim * 4;
+  return pl;
+}
+extern "C" int64_t dle_emb_sgd_workspace_bytes(const int64_t* table_offsets_host, int tables, int dim, int64_t batch) {
+  if (!table_offsets_host || tables <= 0 || dim <= 0 || batch <= 0) return 0;
+  return emb_scratch_plan(table_offsets_host, tables, dim, batch).total;
+}
+
+// ws (optional, dle_emb_sgd_workspace_bytes() bytes, 16-bit gradients): the tiny tables run as the one-hot MFMA segment sum of
+// emb_onehot.hip instead of the register form below, the mid tables (<= 4096 rows) thread 8 lists per row (MidMap above)
 extern "C" int dle_emb_sgd_dedup_ws(float* weight, const int64_t* rows, const void* grad, int32_t* head,
                                     int32_t* next, const unsigned char* is_small_dev,
                                     const int64_t* table_offsets_host, const float* lr_dev, float lr_host,
@@ -692,11 +801,14 @@ extern "C" int dle_emb_sgd_dedup_ws(float* weight, const int64_t* rows, const vo
     if (is_tiny) { if (st.rows[i] > max_rows_tiny) max_rows_tiny = st.rows[i]; }
     else if (st.rows[i] > max_rows) max_rows = st.rows[i];
   }
-  if (tiny.n > 0 && ws) {
+  const bool plan_ok = ws && grad_dtype != DLE_F32 && (((uintptr_t)ws) & 255) == 0;
+  const EmbScratchPlan pl = plan_ok ? emb_scratch_plan(table_offsets_host, tables, dim, batch) : EmbScratchPlan{};
+  const bool ws_ok = plan_ok && ws_bytes >= pl.total;
+  if (tiny.n > 0 && ws_ok && pl.onehot_bytes > 0 && tiny.n == pl.n_tiny) {
     static_assert(sizeof(long long) == sizeof(int64_t), "table bases are passed as int64");
     const int rc = dle_emb_onehot_try(weight, rows, grad, lr_dev, lr_host, scale_dev, skip_flag_dev, tiny.t,
                                       (const int64_t*)tiny.base, tiny.rows, tiny.n, batch, tables, dim, grad_batch_stride,
-                                      grad_dtype, ws, ws_bytes, stream);
+                                      grad_dtype, ws, pl.onehot_bytes, stream);
     if (rc > 1) return rc;
     if (rc == 1) tiny.n = 0;
   }
@@ -741,18 +853,53 @@ extern "C" int dle_emb_sgd_dedup_ws(float* weight, const int64_t* rows, const vo
       emb_make_div(k, map.mul_nl, map.shr_nl);
     }
     const long long n_lk = (long long)batch * (map.nl ? map.nl : tables);
+    // mid tables: 8 lists per row in scratch (emptied here: nothing persists between calls)
+    MidMap mid;
+    MidFold mf;
+    mid.n = 0; mid.rows_total = 0; mid.head = nullptr; mid.partial = nullptr;
+    mf.n = 0; mf.rows_total = 0;
+    for (int i = 0; i < 128; ++i) { mid.off[i] = -1; mid.base[i] = 0; }
+    if (ws_ok && pl.n_mid > 0 && map.nl > 0) {
+      int n_small = 0;
+      for (int k = 0; k < map.nl; ++k) {
+        const int t = map.t[k];
+        const long long r = table_offsets_host[t + 1] - table_offsets_host[t];
+        if (r <= EMB_MID_ROWS && mf.n < EMB_MID_TABLES) {
+          mid.off[k] = mf.rows_total; mid.base[k] = table_offsets_host[t];
+          mf.off[mf.n] = mf.rows_total; mf.rows[mf.n] = (int)r; mf.base[mf.n] = table_offsets_host[t];
+          ++mf.n;
+          mf.rows_total += (int)r;
+        }
+      }
+      (void)n_small;
+      if (mf.n == pl.n_mid && mf.rows_total == pl.mid_rows) {
+        mid.n = mf.n; mid.rows_total = mf.rows_total;
+        mid.head = (int*)((char*)ws + pl.mid_head_off);
+        mid.partial = (float*)((char*)ws + pl.mid_partial_off);
+        hipError_t e = hipMemsetAsync(mid.head, 0xFF, (size_t)mid.rows_total * EMB_MID_S * 4, stream);
+        if (e != hipSuccess) { dle_set_error("emb_sgd_dedup memset: %s", hipGetErrorString(e)); return (int)e; }
+      } else {
+        for (int i = 0; i < 128; ++i) mid.off[i] = -1;
+        mf.n = 0;
+      }
+    }
     hipLaunchKernelGGL(emb_link, dim3(grid_for(n_lk, 256)), dim3(256), 0, stream, (const long long*)rows, head, next,
-                       is_small_dev, skip_flag_dev, (int)n_lk, map);
+                       is_small_dev, skip_flag_dev, (int)n_lk, map, mid);
     DLE_LAUNCH_CHECK();
     const int grid = grid_for(n_lk, 4 * 4);
     static const int spec = getenv("DLE_EMB_SPEC") ? atoi(getenv("DLE_EMB_SPEC")) : 1;
-#define GO(IDT, VT) do { if (spec) hipLaunchKernelGGL((emb_sgd_lists<IDT, true>), dim3(grid), dim3(256), 0, stream, weight, (const long long*)rows, (const VT*)grad, head, (const int*)next, is_small_dev, lr_dev, lr_host, scale_dev, skip_flag_dev, (int)n_lk, map, D4, gs4); \
-    else hipLaunchKernelGGL((emb_sgd_lists<IDT, false>), dim3(grid), dim3(256), 0, stream, weight, (const long long*)rows, (const VT*)grad, head, (const int*)next, is_small_dev, lr_dev, lr_host, scale_dev, skip_flag_dev, (int)n_lk, map, D4, gs4); } while (0)
+#define GO(IDT, VT) do { if (spec) hipLaunchKernelGGL((emb_sgd_lists<IDT, true>), dim3(grid), dim3(256), 0, stream, weight, (const long long*)rows, (const VT*)grad, head, (const int*)next, is_small_dev, lr_dev, lr_host, scale_dev, skip_flag_dev, (int)n_lk, map, D4, gs4, mid); \
+    else hipLaunchKernelGGL((emb_sgd_lists<IDT, false>), dim3(grid), dim3(256), 0, stream, weight, (const long long*)rows, (const VT*)grad, head, (const int*)next, is_small_dev, lr_dev, lr_host, scale_dev, skip_flag_dev, (int)n_lk, map, D4, gs4, mid); } while (0)
     if (grad_dtype == DLE_F32) GO(DLE_F32, float4_t);
     else if (grad_dtype == DLE_F16) GO(DLE_F16, ushort4_t);
     else GO(DLE_BF16, ushort4_t);
 #undef GO
     DLE_LAUNCH_CHECK();
+    if (mid.n > 0) {
+      hipLaunchKernelGGL(emb_mid_fold, dim3((mid.rows_total * 32 + 255) / 256), dim3(256), 0, stream, weight, (const int*)mid.head,
+                         (const float*)mid.partial, lr_dev, lr_host, scale_dev, skip_flag_dev, mf, D4);
+      DLE_LAUNCH_CHECK();
+    }
   }
   return 0;
 }

@@ -137,20 +137,20 @@ class EmbUpdateWorkspace:
         self.is_small = torch.from_numpy(mask).to(device)
         self.head = torch.full((int(off[-1]),), -1, dtype=torch.int32, device=device)
         self.next = None
-        # tables the one-hot MFMA segment sum takes (csrc/emb_onehot.hip: <= 128 rows at dim 128) and its scratch
+        # scratch of the update (one-hot partial blocks of the tiny tables, sub-lists of the mid tables), sized per batch
         sizes = off[1:] - off[:-1]
         self.n_onehot = int((sizes <= 128).sum()) if dim == 128 else 0
-        self.onehot_ws = None
+        self.scratch = None
 
-    def onehot_for(self, batch, device):
-        if self.n_onehot == 0:
-            return None
-        need = int(C.lib().dle_emb_onehot_workspace_bytes(self.n_onehot, batch))
+    def scratch_for(self, batch, device):
+        import ctypes
+        need = int(C.lib().dle_emb_sgd_workspace_bytes(self.offsets_host.ctypes.data_as(ctypes.c_void_p), self.tables, self.dim,
+                                                       batch))
         if need == 0:
             return None
-        if self.onehot_ws is None or self.onehot_ws.numel() * 4 < need:
-            self.onehot_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
-        return self.onehot_ws
+        if self.scratch is None or self.scratch.numel() * 4 < need:
+            self.scratch = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+        return self.scratch
 
     def next_for(self, n, device):
         if self.next is None or self.next.numel() < n:
@@ -174,7 +174,7 @@ def emb_sgd_dedup_(weight, rows, grad, ws, lr, scale=None, skip_flag=None, grad_
     nxt = ws.next_for(b * t, weight.device)
     # algorithmic: grad row read + table row read-modify-write + row id
     C.annotate(bytes=float(b) * t * (ws.dim * grad.element_size() + 2 * ws.dim * 4 + 8))
-    oh = ws.onehot_for(b, weight.device) if grad.dtype in (torch.float16, torch.bfloat16) else None
+    oh = ws.scratch_for(b, weight.device) if grad.dtype in (torch.float16, torch.bfloat16) else None
     C.call("dle_emb_sgd_dedup_ws", C.ptr(weight), C.ptr(rows), C.ptr(grad), C.ptr(ws.head), C.ptr(nxt),
            C.ptr(ws.is_small), ws.offsets_host.ctypes.data_as(ctypes.c_void_p), C.ptr(lr_dev), lr_host,
            C.ptr(scale), C.ptr(skip_flag), b, t, ws.dim, grad_batch_stride, C.dt(grad), C.ptr(oh),

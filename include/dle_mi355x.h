@@ -92,9 +92,12 @@ int dle_emb_sgd_dedup(float* weight, const int64_t* rows, const void* grad, int3
 /* The same with a scratch buffer: tables of <= 128 rows (dim 128, 16-bit gradients) are summed as OneHot(ids)^T G on the matrix
  * pipe (csrc/emb_onehot.hip: the gradient rows stream HBM -> LDS once, the one-hot operand is built in registers; one fp32
  * partial block per (table, batch slice), folded in slice order -- bit-reproducible, no float atomics; replaces the per-lookup
- * atomicAdd of gather_gpu_fused.cu:161-202 on the tables every sample hits).  ws: dle_emb_onehot_workspace_bytes(number of
- * such tables, batch) bytes, or NULL (= dle_emb_sgd_dedup).  dle_emb_onehot_try is the kernel's own entry (1 launched,
- * 0 outside its envelope): tab_t / tab_base / tab_rows = column index, first joint row and row count of each table (host). */
+ * atomicAdd of gather_gpu_fused.cu:161-202 on the tables every sample hits); tables of <= 4096 rows thread EIGHT lists per row
+ * (one per residue of the sample index: the ~70-deep duplicate chains of 1-2 k-row tables become 8 chains walked side by side),
+ * whose partial sums meet in a third small pass.  ws: dle_emb_sgd_workspace_bytes() bytes of scratch, 256-byte aligned, or NULL
+ * (= dle_emb_sgd_dedup).  dle_emb_onehot_try is the one-hot kernel's own entry (1 launched, 0 outside its envelope; scratch
+ * dle_emb_onehot_workspace_bytes): tab_t / tab_base / tab_rows = column index, first joint row, row count of each table (host). */
+int64_t dle_emb_sgd_workspace_bytes(const int64_t* table_offsets_host, int tables, int dim, int64_t batch);
 int64_t dle_emb_onehot_workspace_bytes(int n_tables, int64_t batch);
 int dle_emb_sgd_dedup_ws(float* weight, const int64_t* rows, const void* grad, int32_t* head, int32_t* next,
                          const unsigned char* is_small_dev, const int64_t* table_offsets_host,

@@ -240,12 +240,12 @@ def test_a2a_blocks_pack_and_unpack(cuda, dtype):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("batch", [64, 1000, 4099, 65536])
 def test_tiny_tables_onehot_mfma_vs_oracle(cuda, batch, dtype):
-    """Tables of <= 128 rows through the one-hot MFMA segment sum (csrc/emb_onehot.hip) vs the float64 oracle: every lookup of the
-    batch lands on a handful of rows (gather_gpu_fused.cu:161-202 semantics), ragged batch tails, scale, skip flag, untouched rows
+    """Tables of <= 128 rows through the one-hot MFMA segment sum (csrc/emb_onehot.hip), tables of <= 4096 rows through eight lists
+    per row + the fold pass, vs the float64 oracle: every lookup of the batch lands on a handful of rows (gather_gpu_fused.cu:161-202 semantics), ragged batch tails, scale, skip flag, untouched rows
     keep their bits, two runs are bit-identical (fixed fold order)."""
     F = _F()
     rng = np.random.default_rng(batch + (1 if dtype == torch.float16 else 2))
-    sizes = [4, 128, 1, 97, 300, 11, 63, 5000, 104, 35]        # 300 / 5000 rows: the list path of the same call
+    sizes = [4, 128, 1, 97, 300, 11, 63, 5000, 104, 35, 2209]  # 300 / 2209 rows: eight lists per row; 5000: one list per row
     dim = 128
     off = O.table_offsets(sizes)
     w = rng.standard_normal((int(off[-1]), dim)).astype(np.float32)
