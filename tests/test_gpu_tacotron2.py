@@ -396,7 +396,7 @@ def test_default_widths_step_vs_oracle_under_the_hip_masks(cuda, dtype, monkeypa
     gradient (tacotron2/model.py:405-519, loss_function.py:31-46).  Gradient bars = 1.3 x the 16-bit STORAGE floor of this case
     UNDER THE SAME MASKS: the product engine re-run on the CPU over the fp64-accumulating doubles with 16-bit storage
     (tools/storage_floor_f1.py's measurement; over mask draws the worst-tensor floor moves between 1.9 and 3 % in fp16, 8 - 10 %
-    in bf16 -- profiles/r03_t2_default_storage_floor.txt -- so it is taken for the draw at hand, not from a table)."""
+    in bf16 -- profiles/old/r03_t2_default_storage_floor.txt -- so it is taken for the draw at hand, not from a table)."""
     from oracle import tacotron2_oracle as TO
     from deeplearningexamples_amd import functional as F
     from deeplearningexamples_amd.tacotron2.engine import Tacotron2Trainer

@@ -16,3 +16,6 @@ echo "== stem7 kernels (tools/probes/stem_bench.py)"; run stem7_ tools/probes/st
 echo "== gemm_expand_kernel / conv_bnload_kernel (ResNet-50 step, tools/replay_step.py rn50)"; run gemm_expand_kernel tools/replay_step.py rn50
 run conv_bnload_kernel tools/replay_step.py rn50
 echo "== gemm_smallm_kernel (Tacotron2 probe, tools/probes/smallm_policy.py)"; run gemm_smallm_kernel tools/probes/smallm_policy.py
+echo "== head_bce_kernel / emb_onehot_kernel / emb_sgd_lists (DLRM step, tools/replay_step.py dlrm)"; run head_bce_kernel tools/replay_step.py dlrm
+run emb_onehot_kernel tools/replay_step.py dlrm
+run emb_sgd_lists tools/replay_step.py dlrm

@@ -2,7 +2,7 @@
 tests/test_gpu_tacotron2.py add to north_star's 1e-3): the product engines run on the CPU over the fp64-accumulating test doubles
 of the C-ABI calls (tests/_waveglow_doubles.py, tests/_tacotron2_doubles.py) with fp16 / bf16 storage, against the fp32 oracles.
 
-    python tools/storage_floor_f1.py [--full]  > profiles/r02_f1_storage_floors.txt      (CPU only; --full adds the 268 M network)
+    python tools/storage_floor_f1.py [--full]  > profiles/old/r02_f1_storage_floors.txt      (CPU only; --full adds the 268 M network)
 """
 import os
 import sys
