@@ -277,32 +277,6 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(BnRedArgs a) {
   }
 }
 
-// Sum of rows sl, sl + SL, ... of a [groups][2][C] partial buffer for column c, UN rows (2 UN loads) in flight per trip, every load
-// unconditional on a clamped row.  These finish kernels sit between two passes of every BatchNorm (106 launches per ResNet-50
-// step) and are pure latency: 8 rows per trip + a one-row-at-a-time tail made them 8 dependent round trips (6.4-6.8 us each).
-// DLE_BN_FINISH_DEEP=0: 8 rows per trip (the round-3 form), for A/B
-static int bn_finish_deep() {
-  static const int v = getenv("DLE_BN_FINISH_DEEP") ? atoi(getenv("DLE_BN_FINISH_DEEP")) : 1;
-  return v;
-}
-template <int SL, int UN>
-__device__ __forceinline__ void bn_fold_pairs(const float* __restrict__ partial, int groups, int C, int c, int sl, double& s0,
-                                              double& s1) {
-  for (int g0 = sl; g0 < groups; g0 += SL * UN) {
-    float a[UN], b[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int g = g0 + SL * u;
-      const long long gc = g < groups ? g : groups - 1;
-      a[u] = partial[(gc * 2) * C + c];
-      b[u] = partial[(gc * 2 + 1) * C + c];
-    }
-#pragma unroll
-    for (int u = 0; u < UN; ++u)
-      if (g0 + SL * u < groups) { s0 += a[u]; s1 += b[u]; }
-  }
-}
-
 // finish of MODE 0: mean, biased var -> rstd; running stats (momentum, unbiased var) like nn.BatchNorm2d
 __global__ __launch_bounds__(256) void bn_stats_finish_kernel(const float* __restrict__ partial, int groups, int C,
                                                               long long M, float eps, float momentum,
@@ -346,12 +320,22 @@ __global__ __launch_bounds__(256) void bn_stats_finish_kernel(const float* __res
 // floats): 8 columns x 32 group slices per workgroup, 8 loads per stream in flight -> <= 4 dependent batches.
 __global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float* __restrict__ partial, int groups, int C,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int accumulate, int deep) {
+                                                            int accumulate) {
   __shared__ double red[2][256];
   const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cl;
   double s0 = 0.0, s1 = 0.0;
-  if (c < C) { if (deep) bn_fold_pairs<32, 32>(partial, groups, C, c, sl, s0, s1); else bn_fold_pairs<32, 8>(partial, groups, C, c, sl, s0, s1); }
+  if (c < C) {
+    int g = sl;
+    for (; g + 7 * 32 < groups; g += 8 * 32) {
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a[u] = partial[((long long)(g + 32 * u) * 2) * C + c]; b[u] = partial[((long long)(g + 32 * u) * 2 + 1) * C + c]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s0 += a[u]; s1 += b[u]; }
+    }
+    for (; g < groups; g += 32) { s0 += partial[((long long)g * 2) * C + c]; s1 += partial[((long long)g * 2 + 1) * C + c]; }
+  }
   red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
   __syncthreads();
   if (sl == 0 && c < C) {
@@ -405,12 +389,22 @@ __global__ __launch_bounds__(256) void bn_stats_finish_wide_kernel(const float* 
                                                                    long long M, float eps, float momentum,
                                                                    float* __restrict__ mean, float* __restrict__ rstd,
                                                                    float* __restrict__ running_mean,
-                                                                   float* __restrict__ running_var, int deep) {
+                                                                   float* __restrict__ running_var) {
   __shared__ double red[2][256];
   const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cl;
   double s0 = 0.0, s1 = 0.0;
-  if (c < C) { if (deep) bn_fold_pairs<32, 32>(partial, groups, C, c, sl, s0, s1); else bn_fold_pairs<32, 8>(partial, groups, C, c, sl, s0, s1); }
+  if (c < C) {
+    int g = sl;
+    for (; g + 7 * 32 < groups; g += 8 * 32) {
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a[u] = partial[((long long)(g + 32 * u) * 2) * C + c]; b[u] = partial[((long long)(g + 32 * u) * 2 + 1) * C + c]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s0 += a[u]; s1 += b[u]; }
+    }
+    for (; g < groups; g += 32) { s0 += partial[((long long)g * 2) * C + c]; s1 += partial[((long long)g * 2 + 1) * C + c]; }
+  }
   red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
   __syncthreads();
   if (sl == 0 && c < C) {
@@ -443,7 +437,7 @@ extern "C" int dle_bn_stats_from_partials(const float* partial, int groups, int6
   static const int wide_max = getenv("DLE_BN_FINISH_WIDE") ? atoi(getenv("DLE_BN_FINISH_WIDE")) : 1100;   // 0: always fold + finish
   if (groups > 32 && groups <= wide_max) {
     hipLaunchKernelGGL(bn_stats_finish_wide_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, partial, groups, C, (long long)M, eps,
-                       momentum, mean, rstd, running_mean, running_var, bn_finish_deep());
+                       momentum, mean, rstd, running_mean, running_var);
     DLE_LAUNCH_CHECK();
     return 0;
   }
@@ -696,7 +690,7 @@ extern "C" int dle_bn_bwd_reduce(const void* dy, const void* y, const void* relu
 #undef BN_RED
   DLE_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, (const float*)workspace, (int)gy, C,
-                     dgamma, dbeta, accumulate, bn_finish_deep());
+                     dgamma, dbeta, accumulate);
   DLE_LAUNCH_CHECK();
   return 0;
 }
