@@ -86,3 +86,33 @@ def test_product_never_imports_the_oracle_or_the_test_doubles():
         head = src[:m.start()]
         last_def = head.rfind("\n    def ")
         assert head[last_def:].lstrip().startswith("def cpu_baseline("), src[m.start():m.start() + 60]
+
+
+def test_host_side_planning_entry_points():
+    """The host-only sizing functions of the round-4 kernels (no GPU needed): scratch of the DLRM sparse update (one-hot partial
+    blocks of the tiny tables + eight lists per row for the mid tables), of the fused head, of the streaming weight gradients."""
+    import numpy as np
+    from deeplearningexamples_amd import _cabi
+    lib = _cabi.lib()
+    crit = [7912889, 33823, 582469, 245828, 11, 2209, 10667, 104, 4, 968, 15, 8165896, 17139, 2675940, 7156453, 302516, 12022, 97,
+            35, 7339, 20046, 4, 7105, 1382, 63, 5554114]
+    off = np.concatenate([[0], np.cumsum(crit)]).astype(np.int64)
+    p = off.ctypes.data_as(ctypes.c_void_p)
+    batch, dim = 65536, 128
+    # 8 tables of <= 128 rows -> 512 // 8 = 64 batch slices of one [128][128] fp32 block each
+    assert lib.dle_emb_onehot_workspace_bytes(8, batch) == 8 * 64 * 128 * 128 * 4
+    assert lib.dle_emb_onehot_workspace_bytes(0, batch) == 0
+    total = lib.dle_emb_sgd_workspace_bytes(p, len(crit), dim, batch)
+    mid_rows = 968 + 1382 + 2209                       # (7105 / 7339 rows: above the 4096-row envelope of the sub-lists)
+    onehot = 8 * 64 * 128 * 128 * 4
+    heads = (mid_rows * 8 * 4 + 255) // 256 * 256
+    assert total == onehot + heads + mid_rows * 8 * dim * 4
+    # a table list without tiny / mid tables needs no scratch; a small batch still gets >= 4 tiles per slice
+    big = np.asarray([0, 100000, 300000], dtype=np.int64)
+    assert lib.dle_emb_sgd_workspace_bytes(big.ctypes.data_as(ctypes.c_void_p), 2, dim, batch) == 0
+    assert lib.dle_emb_onehot_workspace_bytes(8, 256) == 8 * 1 * 128 * 128 * 4
+    # fused DLRM head: one partial row [dw | column sums | d bias, loss] per workgroup, at most 1024 workgroups
+    assert lib.dle_head_bce_workspace_bytes(65536, 256) == 1024 * (2 * 256 + 2) * 4
+    assert lib.dle_head_bce_workspace_bytes(100, 64) == 2 * (2 * 64 + 2) * 4
+    assert lib.dle_wgrad1x1_workspace() == 64 << 20
+    assert lib.dle_conv3x3_wgrad_workspace() == 256 * 64 * 9 * 64 * 4
