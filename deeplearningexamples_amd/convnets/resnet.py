@@ -12,6 +12,8 @@ master, its gradient and the 16-bit working copy all share the KRSC element orde
 from contextlib import nullcontext as _nullcontext
 from typing import List
 
+import os
+
 import torch
 from torch import nn
 
@@ -74,6 +76,7 @@ class ConvBN:
         # w2 (packed [64, 7, 8, 4] weights) and gw_flat (the flat fp32 gradient view in the master's KRSC order)
         self.w2 = self.gw_flat = None
         self.wgrad_stream = None                    # set by the trainer: weight gradients run beside the data-gradient chain
+        self.fuse_bnbwd = os.environ.get("DLE_RN50_FUSE_BNBWD", "1") != "0"      # BatchNorm backward on the data gradient's operand load
         self.keepalive = None                       # ... with the list that keeps their operands alive until the streams join
 
     def forward(self, x, residual=None, defer=False):
@@ -128,8 +131,17 @@ class ConvBN:
         self.saved = None
         self.saved_c = x.shape[-1]
         rmask = mask if self.relu else dy_mask
-        gt, _ = F.bn_bwd(dy, None, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta, relu_mask=rmask)
         n, h, w, c = x.shape
+        # conv3 / bn3 of the 56 x 56 stage: the BatchNorm backward runs on the operand load of the unit's own data gradient
+        # (csrc/conv_bnbwd.hip) -- dt is written once for the weight gradient and never read back by the data gradient
+        fused = None
+        if (self.fuse_bnbwd and self.k == 1 and self.stride == 1 and need_dx and dx_addend is None and not compact_dx):
+            fused = F.bn_bwd_conv1x1_dgrad(dy, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta,
+                                           self.w16.view(self.cout, c), relu_mask=rmask)
+        if fused is not None:
+            gt = fused[0]
+        else:
+            gt, _ = F.bn_bwd(dy, None, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta, relu_mask=rmask)
         up2 = isinstance(dx_addend, tuple) and dx_addend[0] == "up2"
         masked = isinstance(dx_addend, tuple) and not up2
         # The weight gradient is a leaf of the backward graph (nothing downstream reads it before the optimizer) while the data
@@ -153,7 +165,9 @@ class ConvBN:
             else:
                 F.conv2d_wgrad(gt, x, (self.k, self.k), self.stride, self.pad, out=self.gw)
         dx = None
-        if self.k == 1 and self.stride == 1:
+        if fused is not None:
+            dx = fused[1].view(n, h, w, c)
+        elif self.k == 1 and self.stride == 1:
             m = n * h * w
             g2 = gt.view(m, self.cout)
             if need_dx:

@@ -886,6 +886,37 @@ def bn_bwd(dy, y, x, mean, rstd, gamma, dgamma, dbeta, want_skip_grad=False, dx_
     return dx, g
 
 
+def bn_bwd_conv1x1_dgrad(dy, x, mean, rstd, gamma, dgamma, dbeta, w, relu_mask=None):
+    """BatchNorm backward of a conv + BN unit whose convolution is 1x1 / stride 1, with the unit's data gradient in the same
+    pass: the reduction (dgamma, dbeta) as in bn_bwd, then ONE kernel that applies the backward on the operand load of
+    dx = dt W (csrc/conv_bnbwd.hip).  x: the convolution output [.., K]; w: the 16-bit weight [K, N] (n contiguous).
+    -> (dt, dx [m, N]) or None outside the kernel's envelope (nothing has been launched then: run bn_bwd + gemm)."""
+    C.require_cuda(dy, x, mean, rstd, gamma, dgamma, dbeta, w, relu_mask)
+    k = x.shape[-1]
+    m = x.numel() // k
+    n = w.shape[-1]
+    if (m < 4096 or k != 256 or n != 64 or w.numel() != k * n or not (dy.is_contiguous() and x.is_contiguous() and w.is_contiguous())
+            or x.dtype not in (torch.float16, torch.bfloat16) or dy.dtype != x.dtype or w.dtype != x.dtype
+            or os.environ.get("DLE_CONV_BNBWD", "1") == "0"):
+        return None
+    ws = _bn_ws(x.reshape(m, k))
+    act_bytes = 0.125 if relu_mask is not None else 0.0
+    relu_tag = "+relu" if relu_mask is not None else ""
+    C.annotate(bytes=float(x.numel()) * (4 + act_bytes), tag="M%dxC%d%s" % (m, k, relu_tag))
+    C.call("dle_bn_bwd_reduce", C.ptr(dy), None, C.ptr(relu_mask), C.ptr(x), C.ptr(mean), C.ptr(rstd), C.ptr(dgamma),
+           C.ptr(dbeta), m, k, 0, C.ptr(ws), ws.numel() * 4, C.dt(x), C.stream())
+    dt = torch.empty_like(x)
+    dx = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    C.annotate(bytes=float(x.numel()) * (6 + act_bytes) + dx.numel() * 2.0, flops=2.0 * m * n * k,
+               tag="bn_bwd+dgrad %dx%dx%d%s" % (m, n, k, relu_tag))
+    rc = _timed_optional("dle_conv1x1_bnbwd_dgrad", C.lib().dle_conv1x1_bnbwd_dgrad,
+                         (C.ptr(dy), C.ptr(x), C.ptr(relu_mask), C.ptr(w), C.ptr(dt), C.ptr(dx), C.ptr(mean), C.ptr(rstd),
+                          C.ptr(gamma), C.ptr(dgamma), C.ptr(dbeta), m, n, k, C.dt(x), C.stream()))
+    if rc != 1:
+        C.check(rc - 1000 if rc > 1000 else -1, "dle_conv1x1_bnbwd_dgrad")       # (the envelope was checked above)
+    return dt, dx
+
+
 def maxpool_fwd(x, ksize=3, stride=2, pad=1):
     C.require_cuda(x)
     n, h, w, c = x.shape

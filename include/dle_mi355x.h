@@ -317,6 +317,14 @@ int dle_conv1x1_bnload_groups(int M, int N, int K);
 int dle_conv1x1_bnload_fwd(const void* t, const void* res, const void* w, void* out, void* y, void* bits, const float* mean,
                            const float* rstd, const float* gamma, const float* beta, float* stats, int64_t stats_bytes, int M,
                            int N, int K, int dtype, hipStream_t stream);
+/* The backward counterpart (csrc/conv_bnbwd.hip): BatchNorm backward (second pass) on the operand load of the 1x1 data gradient
+ * that consumes it -- the conv3 / bn3 unit of a bottleneck (models/resnet.py:148-175 backward).  dt [M, K] = ka (g - dbeta / M -
+ * xhat dgamma / M) with g = dy under relu_mask (bit-packed, may be NULL), dx [M, N] = dt W, W [K][N] n-contiguous; dgamma / dbeta
+ * = the sums dle_bn_bwd_reduce left.  dt and dx are bit-identical to dle_bn_bwd_apply + dle_gemm; dt is never re-read.
+ * 1: launched; 0: outside the envelope (K = 256, N = 64, M >= 4096, 16-byte aligned dense operands). */
+int dle_conv1x1_bnbwd_dgrad(const void* dy, const void* t, const void* relu_mask, const void* w, void* dt, void* dx,
+                            const float* mean, const float* rstd, const float* gamma, const float* dgamma, const float* dbeta,
+                            int M, int N, int K, int dtype, hipStream_t stream);
 /* ---- the ResNet stem (csrc/stem.hip): conv7x7 / stride 2 / pad 3 of a 3-channel image, forward (+ BatchNorm partial sums) and
  * weight gradient, on a 4-channel NHWC image (dle_nchw_to_nhwc with C_padded = 4: 8 bytes per pixel, channel 3 zero).
  *   replaces cuDNN behind builder.conv7x7(3, 64, stride=2) + bn1's statistics: Classification/ConvNets/image_classification/
