@@ -135,7 +135,7 @@ class ConvBN:
         # conv3 / bn3 of the 56 x 56 stage: the BatchNorm backward runs on the operand load of the unit's own data gradient
         # (csrc/conv_bnbwd.hip) -- dt is written once for the weight gradient and never read back by the data gradient
         fused = None
-        if (self.fuse_bnbwd and self.k == 1 and self.stride == 1 and need_dx and dx_addend is None and not compact_dx):
+        if self.fuse_bnbwd and self.k == 1 and self.stride == 1 and need_dx and dx_addend is None:   # (compact_dx: stride 2 only)
             fused = F.bn_bwd_conv1x1_dgrad(dy, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta,
                                            self.w16.view(self.cout, c), relu_mask=rmask)
         if fused is not None:

@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python -m pytest tests/test_gpu_conv_bnbwd.py tests/test_gpu_rn50_step.py -x -q 2>&1 | tail -6
-for v in 1 0 1 0; do
+for v in 1 0; do
   DLE_RN50_FUSE_BNBWD=$v python bench.py --workload rn50 --no-nested --no-cpu-baseline --no-kernel-timer --steps 20 --warmup 5 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('fuse_bnbwd=$v', d['ms_per_step'], d['value'])"
