@@ -144,6 +144,8 @@ class ResNetTrainer:
         # BatchNorm-apply of bn2 / bn3 on the operand load of the consuming 1x1 convolution (conv + BN + ReLU as one unit,
         # csrc/conv_bnload.hip); DLE_RN50_FUSE_BN=0 keeps the stand-alone apply passes
         self.fuse_bn = os.environ.get("DLE_RN50_FUSE_BN", "1") != "0"
+        # the backward reduction of a block's bn3 taken in the epilogue of the NEXT block's conv1 data gradient (gemm_expand BRED)
+        self.fuse_bnred = os.environ.get("DLE_RN50_FUSE_BNRED", "1") != "0"
         self.stem.w2 = torch.zeros((64, 7, 8, 4), dtype=compute_dtype, device=self.dev)
         self.stem.gw_flat = self.gview["conv1.weight"]
         self.fc_w16 = torch.empty(model.fc.weight.shape, dtype=compute_dtype, device=self.dev)
@@ -294,7 +296,8 @@ class ResNetTrainer:
         self._maybe_reduce("fc.weight"); self._maybe_reduce("fc.bias")
         gp = F.gemm(dlogits, fcw, n, fcw.shape[1], fcw.shape[0], True, False)
         g = F.avgpool_bwd(gp, self._feat_hw)
-        for (u1, u2, u3, ud) in reversed(self.blocks):
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            u1, u2, u3, ud = self.blocks[bi]
             # the block ends in relu(bn3(conv3) + shortcut): g * (out > 0) flows into BOTH branches.  It is never written:
             # bn3's backward applies the mask on load, the shortcut side gets (g, mask) and applies it where it is consumed
             mask3 = u3.relu_mask()
@@ -318,7 +321,9 @@ class ResNetTrainer:
                 cur.wait_stream(bs)
             if ud is not None:
                 self._done(ud)
-            g = u1.backward(g2, dx_addend=gskip)
+            # (no downsample branch: g is the gradient of the previous block's output -- its bn3 reduction rides on this GEMM)
+            prev3 = self.blocks[bi - 1][2] if (self.fuse_bnred and ud is None and bi > 0) else None
+            g = u1.backward(g2, dx_addend=gskip, bnred=prev3)
             self._done(u1)
         g = F.maxpool_bwd(g, self._amax, self._pool_in_hw)
         self.stem.backward(g, need_dx=False)

@@ -77,6 +77,7 @@ class ConvBN:
         self.w2 = self.gw_flat = None
         self.wgrad_stream = None                    # set by the trainer: weight gradients run beside the data-gradient chain
         self.fuse_bnbwd = os.environ.get("DLE_RN50_FUSE_BNBWD", "1") != "0"      # BatchNorm backward on the data gradient's operand load
+        self.reduce_done = False                    # set by the unit that PRODUCED this unit's output gradient (backward(bnred=))
         self.keepalive = None                       # ... with the list that keeps their operands alive until the streams join
 
     def forward(self, x, residual=None, defer=False):
@@ -120,13 +121,16 @@ class ConvBN:
                               relu=self.relu, want_mask=False)
         return y
 
-    def backward(self, dy, need_dx=True, dx_addend=None, dy_mask=None, compact_dx=False):
+    def backward(self, dy, need_dx=True, dx_addend=None, dy_mask=None, compact_dx=False, bnred=None):
         """dy: gradient w.r.t. the unit's output; dy_mask (optional): bit-packed keep bits to apply to dy first (the
         ReLU that follows the residual add sits on the OTHER branch's unit: its mask gates this branch's gradient too).
         dx_addend: a tensor, or (tensor, keep bits) = the residual-branch gradient dy * (y > 0) that is never
         materialised: the data-gradient GEMM adds it under the mask in its epilogue -- or ("up2", compact, (H, W)) = the gradient
         of a stride-2 1x1 branch on its own P x Q grid, added at the even pixels without its zero-stuffed form being written.
-        compact_dx (1x1 stride-2 units): return that triple instead of the full-resolution dx.  Returns dx or None."""
+        compact_dx (1x1 stride-2 units): return that triple instead of the full-resolution dx.
+        bnred (with a masked dx_addend): the conv + BN unit whose output gradient this dx IS (the previous block's conv3 / bn3) --
+        its BatchNorm's backward reduction is taken in the epilogue that produces dx, and that unit's backward() skips it.
+        Returns dx or None."""
         x, t, mask, mean, rstd = self.saved
         self.saved = None
         self.saved_c = x.shape[-1]
@@ -134,14 +138,16 @@ class ConvBN:
         n, h, w, c = x.shape
         # conv3 / bn3 of the 56 x 56 stage: the BatchNorm backward runs on the operand load of the unit's own data gradient
         # (csrc/conv_bnbwd.hip) -- dt is written once for the weight gradient and never read back by the data gradient
+        reduce_done, self.reduce_done = self.reduce_done, False
         fused = None
         if self.fuse_bnbwd and self.k == 1 and self.stride == 1 and need_dx and dx_addend is None:   # (compact_dx: stride 2 only)
             fused = F.bn_bwd_conv1x1_dgrad(dy, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta,
-                                           self.w16.view(self.cout, c), relu_mask=rmask)
+                                           self.w16.view(self.cout, c), relu_mask=rmask, reduce_done=reduce_done)
         if fused is not None:
             gt = fused[0]
         else:
-            gt, _ = F.bn_bwd(dy, None, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta, relu_mask=rmask)
+            gt, _ = F.bn_bwd(dy, None, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta, relu_mask=rmask,
+                             reduce_done=reduce_done)
         up2 = isinstance(dx_addend, tuple) and dx_addend[0] == "up2"
         masked = isinstance(dx_addend, tuple) and not up2
         # The weight gradient is a leaf of the backward graph (nothing downstream reads it before the optimizer) while the data
@@ -172,8 +178,18 @@ class ConvBN:
             g2 = gt.view(m, self.cout)
             if need_dx:
                 if masked:
-                    dx = F.gemm(g2, self.w16.view(self.cout, c), m, c, self.cout, True, False, act=C.ACT_ADD_MASKED,
-                                mask_src=dx_addend[0].view(m, c), aux=dx_addend[1]).view(n, h, w, c)
+                    dxf = None
+                    if bnred is not None and bnred.saved is not None and bnred.relu:
+                        # dx is the gradient of the previous block's output: take its bn3's backward reduction here
+                        _, pt, pmask, pmean, prstd = bnred.saved
+                        dxf = F.gemm_masked_add_bnred(g2, self.w16.view(self.cout, c), m, c, self.cout, dx_addend[0].view(m, c),
+                                                      dx_addend[1], pt.view(m, c), pmask, pmean, prstd, bnred.ggamma,
+                                                      bnred.gbeta) if pt.numel() == m * c else None
+                        if dxf is not None:
+                            bnred.reduce_done = True
+                    dx = (dxf if dxf is not None else
+                          F.gemm(g2, self.w16.view(self.cout, c), m, c, self.cout, True, False, act=C.ACT_ADD_MASKED,
+                                 mask_src=dx_addend[0].view(m, c), aux=dx_addend[1])).view(n, h, w, c)
                 else:
                     if up2:
                         dx = F.gemm_add_upsampled2(g2, self.w16.view(self.cout, c), dx_addend[1], dx_addend[2])

@@ -695,6 +695,16 @@ extern "C" int dle_bn_bwd_reduce(const void* dy, const void* y, const void* relu
   return 0;
 }
 
+// The fold half of dle_bn_bwd_reduce on its own: dgamma / dbeta from `groups` partial rows [groups][2][C] of (sum g, sum g xhat)
+// that another kernel left (dle_gemm_expand_masked_bnred takes the reduction in the epilogue that PRODUCES the gradient).
+extern "C" int dle_bn_bwd_finish(const float* partial, int groups, int C, float* dgamma, float* dbeta, int accumulate,
+                                 hipStream_t stream) {
+  DLE_CHECK_ARG(partial && dgamma && dbeta && groups > 0 && C > 0, "bn_bwd_finish: bad args");
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, partial, groups, C, dgamma, dbeta, accumulate);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
 // backward pass 2: dx = gamma * rstd * (g - dbeta/M - xhat * dgamma/M), g = dy * (y > 0);
 // g_out (optional) receives g: the gradient that flows into the residual branch.
 template <int DT, int TR>

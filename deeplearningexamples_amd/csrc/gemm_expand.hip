@@ -37,6 +37,12 @@ struct ExpandArgs {
   FastDiv dHW, dW;
   int up_HW, up_W, up_P, up_Q;
   long long ld_src;
+  // BRED: the output is also the gradient that enters ANOTHER BatchNorm (the previous block's bn3): its backward reduction --
+  // sum g, sum g xhat with g = C under bits2, xhat = (t2 - mean2) rstd2 -- is taken here, from the values about to be stored
+  const unsigned short* t2;             // [M, N], pitch ldc
+  const unsigned char* bits2;           // keep bits, same indexing as `bits`
+  const float* mean2;
+  const float* rstd2;
 };
 
 template <int DT> struct ExMfma;
@@ -58,11 +64,13 @@ __device__ __forceinline__ int ex_pos(int nl) {
 }
 
 // The stream registers of one row tile of a wave: A fragments, addend, keep bits (all loads unconditional: clamped row).
-template <int KS, int ACT>
+template <int KS, int ACT, bool BRED = false>
 struct ExStream {
   ushort8_t fa[KS];
   ushort8_t sv[ACT ? 4 : 1];
+  ushort8_t tv[BRED ? 4 : 1];                                          // BRED: the row of t2
   uint4_t mb;                                                          // ACT == 2: 16 mask bytes = columns n0 .. n0 + 127 of the row
+  uint4_t mb2;                                                         // BRED: the row's 16 bytes of bits2
   long long o0;
   bool live;
   bool has;                                                            // ACT == 3: this row has an addend row
@@ -90,13 +98,44 @@ struct ExStream {
       for (int j = 0; j < 4; ++j) sv[j] = *(const ushort8_t*)(p.src + o0 + 32 * j);
     }
     if (ACT == 2) mb = *(const uint4_t*)(p.bits + ((mr * p.ldc + n0) >> 3));   // (ldc, n0 multiples of 128: 16-byte aligned)
+    if (BRED) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tv[j] = *(const ushort8_t*)(p.t2 + o0 + 32 * j);
+      mb2 = *(const uint4_t*)(p.bits2 + ((mr * p.ldc + n0) >> 3));
+    }
   }
 };
 
+// v[32] per lane, 16 lanes (fr = lane & 15) -> acc[b] += sum over the 16 lanes of v[2 fr + b]
+__device__ __forceinline__ void ex_reduce_scatter16(const float* v, int fr, float* acc) {
+  float w16[16], w8[8], w4[4];
+  const bool h8 = fr & 8, h4 = fr & 4, h2 = fr & 2, h1 = fr & 1;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const float keep = h8 ? v[16 + q] : v[q], send = h8 ? v[q] : v[16 + q];
+    w16[q] = keep + __shfl_xor(send, 8, 64);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float keep = h4 ? w16[8 + q] : w16[q], send = h4 ? w16[q] : w16[8 + q];
+    w8[q] = keep + __shfl_xor(send, 4, 64);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float keep = h2 ? w8[4 + q] : w8[q], send = h2 ? w8[q] : w8[4 + q];
+    w4[q] = keep + __shfl_xor(send, 2, 64);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float keep = h1 ? w4[2 + q] : w4[q], send = h1 ? w4[q] : w4[2 + q];
+    acc[q] += keep + __shfl_xor(send, 1, 64);
+  }
+}
+
 // ACT: 0 none, 1 + addend, 2 + addend under keep bits.  KS = K / 32 (2, 4 or 8).  STATS: column sums of the rounded output.
 // NW wavefronts of 16 rows each: 4, or 8 for K = 256 (its 66 KiB weight tile allows two workgroups per CU; 16 waves per CU either way).
-template <int DT, int KS, int ACT, bool STATS, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(STATS ? 3 : 4)))
+template <int DT, int KS, int ACT, bool STATS, int NW, bool BRED = false>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((STATS || BRED) ? 3 : 4)))
 void gemm_expand_kernel(ExpandArgs p) {
   constexpr int K = KS * 32, LDW = K + EX_PAD, TM = NW * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -124,19 +163,24 @@ void gemm_expand_kernel(ExpandArgs p) {
       for (int e = 0; e < 8; ++e) wl[ex_pos(nc * 8 + e) * LDW + k] = v[e];
     }
   }
+  float* mu2 = (float*)(smem_raw + EX_TN * LDW * 2);                  // BRED: mean2 | rstd2 of this column tile
+  if (BRED) {
+    for (int c = threadIdx.x; c < EX_TN; c += NW * 64) { mu2[c] = p.mean2[n0 + c]; mu2[EX_TN + c] = p.rstd2[n0 + c]; }
+  }
   __syncthreads();
   float s1[STATS ? 32 : 1], s2[STATS ? 32 : 1];
   if (STATS) {
 #pragma unroll
     for (int i = 0; i < 32; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
   }
+  float b1[2] = {0.f, 0.f}, b2s[2] = {0.f, 0.f};     // BRED: this lane's two columns (2 fr, 2 fr + 1 of its 32) over every tile so far
   const unsigned short* wrow = wl + fr * LDW + kg * 8;                  // + (32 j + 16 q) * LDW + 32 ks
   const int mrow = wave * 16 + fr;
   // Software pipeline over the row tiles: the NEXT tile's loads are issued before this tile's stores, into the registers the
   // product / the epilogue arithmetic have just finished with.  vmcnt retires in order and counts stores: a wave that stores and
   // then loads must see its stores acknowledged before the loaded data can be waited for; with the loads in front, the stores of
   // tile i are only waited for together with the loads of tile i + 2.
-  ExStream<KS, ACT> cur;
+  ExStream<KS, ACT, BRED> cur;
   cur.load_a(p, g * TM + mrow, kg);
   cur.load_src(p, g * TM + mrow, n0, kg);
   for (int tm = g; tm < p.row_tiles; tm += p.groups) {
@@ -159,6 +203,7 @@ void gemm_expand_kernel(ExpandArgs p) {
     cur.load_a(p, m_next, kg);
     // ---- epilogue: pair j = blocks 2j, 2j + 1 -> columns n0 + 32 j + 8 kg + {0..7} of row m
     ushort8_t outv[4];
+    float tg[BRED ? 32 : 1], tx[BRED ? 32 : 1];         // BRED: this row's 32 values of g and g xhat
     const bool live_cur = cur.live;
     const bool has_cur = ACT == 3 ? cur.has : true;
 #pragma unroll
@@ -189,6 +234,28 @@ void gemm_expand_kernel(ExpandArgs p) {
           s2[8 * j + r] += zz * zz;
         }
       }
+      if (BRED) {                                      // (the arithmetic of bn_reduce_kernel on the rounded output)
+        float z[8], tf[8];
+        unpack8<DT>(ov, z);
+        unpack8<DT>(cur.tv[j], tf);
+        const unsigned b2 = (cur.mb2[j] >> (8 * kg)) & 0xffu;
+        const float4_t m0 = *(const float4_t*)(mu2 + 32 * j + 8 * kg), m1 = *(const float4_t*)(mu2 + 32 * j + 8 * kg + 4);
+        const float4_t r0 = *(const float4_t*)(mu2 + EX_TN + 32 * j + 8 * kg), r1 = *(const float4_t*)(mu2 + EX_TN + 32 * j + 8 * kg + 4);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float gz = (live_cur && ((b2 >> r) & 1u)) ? z[r] : 0.f;
+          const float mu = r < 4 ? m0[r & 3] : m1[r & 3], rs = r < 4 ? r0[r & 3] : r1[r & 3];
+          tg[8 * j + r] = gz;
+          tx[8 * j + r] = gz * (tf[r] - mu) * rs;
+        }
+      }
+    }
+    if (BRED) {
+      // 64 accumulators per lane do not fit beside the stream registers (the kernel spilled 150-190 VGPRs): the 16 row lanes of
+      // a column group reduce-scatter the tile's values instead -- after xor-8 / 4 / 2 / 1 exchanges lane fr holds the sums of
+      // the 16 rows for values 2 fr and 2 fr + 1 of the 32
+      ex_reduce_scatter16(tg, fr, b1);
+      ex_reduce_scatter16(tx, fr, b2s);
     }
     __builtin_amdgcn_sched_barrier(0);
     cur.load_src(p, m_next, n0, kg);
@@ -218,6 +285,25 @@ void gemm_expand_kernel(ExpandArgs p) {
         if (live_first) *(uint4_t*)(p.C + o_first) = first;
         if (live_second) *(uint4_t*)(p.C + o_second) = second;
       }
+    }
+  }
+  if (BRED) {
+    // lane fr holds values 2 fr, 2 fr + 1 of its column group's 32: value i = column 32 (i >> 3) + 8 kg + (i & 7)
+    __syncthreads();
+    float* red = (float*)smem_raw;                                      // [NW waves][2][128]
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int i = 2 * fr + b, col = 32 * (i >> 3) + 8 * kg + (i & 7);
+      red[(wave * 2 + 0) * EX_TN + col] = b1[b];
+      red[(wave * 2 + 1) * EX_TN + col] = b2s[b];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * EX_TN; t += NW * 64) {
+      const int which = t / EX_TN, col = t - which * EX_TN;
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) tot += red[(w * 2 + which) * EX_TN + col];
+      p.stats[((long long)g * 2 + which) * p.N + n0 + col] = tot;
     }
   }
   if (STATS) {
@@ -314,6 +400,57 @@ extern "C" int dle_gemm_expand_try(const void* A, const void* B, void* C, const 
 #undef GO
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { dle_set_error("gemm_expand launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
+  return 1;
+}
+
+// The masked-addend form (act 2) that ALSO takes the backward reduction of the BatchNorm its output flows into (ExpandArgs BRED):
+// partial [dle_gemm_expand_groups(M, N, K)][2][N] receives per-workgroup-group rows of (sum g, sum g xhat); the caller folds them
+// with dle_bn_bwd_finish.  In a ResNet bottleneck chain the output of conv1's data gradient IS the gradient of the previous
+// block's output: its bn3 reduction re-read dy + t + mask (848 MB at 56 x 56 x 256, batch 256) -- here t and the mask are read
+// once more beside the store, dy not at all.  1: launched; 0: outside the envelope.
+extern "C" int dle_gemm_expand_masked_bnred(const void* A, const void* B, void* C, const void* src, const void* bits, const void* t2,
+                                            const void* bits2, const float* mean2, const float* rstd2, float* partial,
+                                            int64_t partial_bytes, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                                            int b_kc, int dtype, hipStream_t stream) {
+  static const char* pin = getenv("DLE_GEMM_EXPAND");
+  if (pin && atoi(pin) == 0) return 0;
+  // (K = 256 is built and correct, but its 8-wave workgroup spills and runs slower than the two launches: 104 us against 60 + 39 at
+  //  50176 x 1024 x 256; DLE_GEMM_BNRED_K256=1 lets it through for measurement)
+  static const int k256 = getenv("DLE_GEMM_BNRED_K256") ? atoi(getenv("DLE_GEMM_BNRED_K256")) : 0;
+  if (M < 4096 || (K != 64 && K != 128 && !(K == 256 && k256)) || (N % EX_TN) != 0 || N < 2 * K) return 0;
+  if (dtype != DLE_F16 && dtype != DLE_BF16) return 0;
+  if (!A || !B || !C || !src || !bits || !t2 || !bits2 || !mean2 || !rstd2 || !partial) return 0;
+  if (((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)src) | ((uintptr_t)t2) | ((uintptr_t)bits) | ((uintptr_t)bits2)) & 15) != 0 ||
+      (lda & 7) || (ldb & 7) || (ldc % EX_TN) != 0)
+    return 0;
+  ExpandArgs p = {(const unsigned short*)A, (const unsigned short*)B, (unsigned short*)C, (const unsigned short*)src,
+                  (const unsigned char*)bits, partial, M, N, K, (long long)lda, (long long)ldb, (long long)ldc, b_kc, 0, 0, 0};
+  p.t2 = (const unsigned short*)t2; p.bits2 = (const unsigned char*)bits2; p.mean2 = mean2; p.rstd2 = rstd2;
+  const int tmr = ex_rows_per_tile(K);
+  p.row_tiles = (M + tmr - 1) / tmr;
+  p.col_tiles = N / EX_TN;
+  p.groups = dle_gemm_expand_groups(M, N, K);
+  if (partial_bytes < (long long)p.groups * 2 * N * 4) return 0;
+  size_t lds_bytes = (size_t)EX_TN * (K + EX_PAD) * 2 + 2 * EX_TN * 4;
+  if (lds_bytes < (size_t)8 * 2 * EX_TN * 4) lds_bytes = (size_t)8 * 2 * EX_TN * 4;
+  const dim3 grid((unsigned)(p.groups * p.col_tiles)), block(tmr * 4);
+#define GO(DT, KS)                                                                                                       \
+  do {                                                                                                                   \
+    constexpr int NW_ = KS > 4 ? 8 : 4;                                                                                  \
+    static bool attr_set = false;                                                                                        \
+    if (!attr_set) {                                                                                                     \
+      (void)hipFuncSetAttribute((const void*)gemm_expand_kernel<DT, KS, 2, false, NW_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                EX_TN * (KS * 32 + EX_PAD) * 2 + 2 * EX_TN * 4);                                         \
+      attr_set = true;                                                                                                   \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((gemm_expand_kernel<DT, KS, 2, false, NW_, true>), grid, block, lds_bytes, stream, p);            \
+  } while (0)
+#define PICK_K(DT) do { if (K == 64) GO(DT, 2); else if (K == 128) GO(DT, 4); else GO(DT, 8); } while (0)
+  if (dtype == DLE_F16) PICK_K(DLE_F16); else PICK_K(DLE_BF16);
+#undef PICK_K
+#undef GO
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { dle_set_error("gemm_expand_masked_bnred launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
   return 1;
 }
 

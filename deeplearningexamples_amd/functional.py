@@ -863,7 +863,7 @@ def bn_relu_maxpool_fwd(t, mean, rstd, gamma, beta):
     return y, am, mask
 
 
-def bn_bwd(dy, y, x, mean, rstd, gamma, dgamma, dbeta, want_skip_grad=False, dx_out=None, relu_mask=None):
+def bn_bwd(dy, y, x, mean, rstd, gamma, dgamma, dbeta, want_skip_grad=False, dx_out=None, relu_mask=None, reduce_done=False):
     """-> (dx, g) ; y = saved post-ReLU output or relu_mask = its bit-packed y > 0 mask (both None when the BN had no
     ReLU); g = dy*(y>0) if requested."""
     C.require_cuda(dy, y, x, mean, rstd, gamma, dgamma, dbeta, relu_mask)
@@ -874,9 +874,10 @@ def bn_bwd(dy, y, x, mean, rstd, gamma, dgamma, dbeta, want_skip_grad=False, dx_
         y = None
     act_bytes = 0.125 if relu_mask is not None else (2.0 if y is not None else 0.0)
     relu_tag = "+relu" if (y is not None or relu_mask is not None) else ""
-    C.annotate(bytes=float(x.numel()) * (4 + act_bytes), tag="M%dxC%d%s" % (x.numel() // c, c, relu_tag))
-    C.call("dle_bn_bwd_reduce", C.ptr(dy), C.ptr(y), C.ptr(relu_mask), C.ptr(x), C.ptr(mean), C.ptr(rstd), C.ptr(dgamma),
-           C.ptr(dbeta), m, c, 0, C.ptr(ws), ws.numel() * 4, C.dt(x), C.stream())
+    if not reduce_done:                      # (reduce_done: the producer of dy already left dgamma / dbeta: gemm_masked_add_bnred)
+        C.annotate(bytes=float(x.numel()) * (4 + act_bytes), tag="M%dxC%d%s" % (x.numel() // c, c, relu_tag))
+        C.call("dle_bn_bwd_reduce", C.ptr(dy), C.ptr(y), C.ptr(relu_mask), C.ptr(x), C.ptr(mean), C.ptr(rstd), C.ptr(dgamma),
+               C.ptr(dbeta), m, c, 0, C.ptr(ws), ws.numel() * 4, C.dt(x), C.stream())
     dx = torch.empty_like(x) if dx_out is None else dx_out
     g = torch.empty_like(x) if want_skip_grad else None
     C.annotate(bytes=float(x.numel()) * (6 + act_bytes + 2 * int(want_skip_grad)),
@@ -886,7 +887,37 @@ def bn_bwd(dy, y, x, mean, rstd, gamma, dgamma, dbeta, want_skip_grad=False, dx_
     return dx, g
 
 
-def bn_bwd_conv1x1_dgrad(dy, x, mean, rstd, gamma, dgamma, dbeta, w, relu_mask=None):
+def gemm_masked_add_bnred(g2, w, m, n, k, addend, bits, t2, bits2, mean2, rstd2, dgamma2, dbeta2):
+    """dx [m, n] = g2 [m, k] w [k, n] + addend under `bits` (the masked residual gradient, as gemm(act=ACT_ADD_MASKED)) AND the
+    backward reduction of the BatchNorm that dx flows into: dgamma2 / dbeta2 (fp32 [n], overwritten) from g = dx under bits2 and
+    xhat = (t2 - mean2) rstd2 -- what bn_bwd's first pass computes from a re-read of dx, t2 and the mask.  -> dx, or None outside
+    the streaming kernel's envelope (nothing launched: run gemm and let the unit reduce for itself)."""
+    C.require_cuda(g2, w, addend, bits, t2, bits2, mean2, rstd2, dgamma2, dbeta2)
+    if (g2.dtype not in (torch.float16, torch.bfloat16) or m < 4096 or k not in (64, 128, 256) or n % 128 != 0 or n < 2 * k
+            or (k == 256 and os.environ.get("DLE_GEMM_BNRED_K256", "0") != "1")
+            or not (g2.is_contiguous() and w.is_contiguous() and addend.is_contiguous() and t2.is_contiguous())
+            or t2.numel() != m * n or os.environ.get("DLE_RN50_FUSE_BNRED", "1") == "0"):
+        return None
+    groups = int(C.lib().dle_gemm_expand_groups(m, n, k))
+    if groups <= 0:
+        return None
+    ws = splitk_workspace(g2.device, groups * 2 * n * 4)
+    out = torch.empty((m, n), dtype=g2.dtype, device=g2.device)
+    by = float(m) * (k + 3 * n) * g2.element_size() + float(m) * n * 0.25 + float(k) * n * 2
+    C.annotate(bytes=by, flops=2.0 * m * n * k, tag="%dx%dx%d+src+aux+bnred" % (m, n, k))
+    rc = _timed_optional("dle_gemm", C.lib().dle_gemm_expand_masked_bnred,
+                         (C.ptr(g2), C.ptr(w), C.ptr(out), C.ptr(addend), C.ptr(bits), C.ptr(t2), C.ptr(bits2), C.ptr(mean2),
+                          C.ptr(rstd2), C.ptr(ws), ws.numel() * 4, m, n, k, g2.stride(0), w.stride(0), out.stride(0), 0, C.dt(g2),
+                          C.stream()))
+    if rc > 1:
+        C.check(rc - 1000 if rc > 1000 else -1, "dle_gemm_expand_masked_bnred")
+    if rc != 1:
+        return None
+    C.call("dle_bn_bwd_finish", C.ptr(ws), groups, n, C.ptr(dgamma2), C.ptr(dbeta2), 0, C.stream())
+    return out
+
+
+def bn_bwd_conv1x1_dgrad(dy, x, mean, rstd, gamma, dgamma, dbeta, w, relu_mask=None, reduce_done=False):
     """BatchNorm backward of a conv + BN unit whose convolution is 1x1 / stride 1, with the unit's data gradient in the same
     pass: the reduction (dgamma, dbeta) as in bn_bwd, then ONE kernel that applies the backward on the operand load of
     dx = dt W (csrc/conv_bnbwd.hip).  x: the convolution output [.., K]; w: the 16-bit weight [K, N] (n contiguous).
@@ -902,9 +933,10 @@ def bn_bwd_conv1x1_dgrad(dy, x, mean, rstd, gamma, dgamma, dbeta, w, relu_mask=N
     ws = _bn_ws(x.reshape(m, k))
     act_bytes = 0.125 if relu_mask is not None else 0.0
     relu_tag = "+relu" if relu_mask is not None else ""
-    C.annotate(bytes=float(x.numel()) * (4 + act_bytes), tag="M%dxC%d%s" % (m, k, relu_tag))
-    C.call("dle_bn_bwd_reduce", C.ptr(dy), None, C.ptr(relu_mask), C.ptr(x), C.ptr(mean), C.ptr(rstd), C.ptr(dgamma),
-           C.ptr(dbeta), m, k, 0, C.ptr(ws), ws.numel() * 4, C.dt(x), C.stream())
+    if not reduce_done:                      # (reduce_done: the producer of dy already left dgamma / dbeta: gemm_masked_add_bnred)
+        C.annotate(bytes=float(x.numel()) * (4 + act_bytes), tag="M%dxC%d%s" % (m, k, relu_tag))
+        C.call("dle_bn_bwd_reduce", C.ptr(dy), None, C.ptr(relu_mask), C.ptr(x), C.ptr(mean), C.ptr(rstd), C.ptr(dgamma),
+               C.ptr(dbeta), m, k, 0, C.ptr(ws), ws.numel() * 4, C.dt(x), C.stream())
     dt = torch.empty_like(x)
     dx = torch.empty((m, n), dtype=x.dtype, device=x.device)
     C.annotate(bytes=float(x.numel()) * (6 + act_bytes) + dx.numel() * 2.0, flops=2.0 * m * n * k,

@@ -325,6 +325,16 @@ int dle_conv1x1_bnload_fwd(const void* t, const void* res, const void* w, void* 
 int dle_conv1x1_bnbwd_dgrad(const void* dy, const void* t, const void* relu_mask, const void* w, void* dt, void* dx,
                             const float* mean, const float* rstd, const float* gamma, const float* dgamma, const float* dbeta,
                             int M, int N, int K, int dtype, hipStream_t stream);
+/* The backward reduction of a BatchNorm taken where its input gradient is PRODUCED (csrc/gemm_expand.hip, BRED): conv1's data
+ * gradient of the next bottleneck, C = A B^T + src under `bits` (the DLE_ACT_ADD_MASKED form of dle_gemm), is the gradient of the
+ * previous block's output; with g = C under bits2 and xhat = (t2 - mean2) rstd2 the kernel also leaves partial [groups][2][N] rows
+ * of (sum g, sum g xhat) -- groups = dle_gemm_expand_groups(M, N, K) -- which dle_bn_bwd_finish folds into dgamma / dbeta (what
+ * dle_bn_bwd_reduce computes from dy + t + mask in a pass of its own).  t2 [M, N] with C's pitch; bits2 indexed like bits.
+ * 1: launched; 0: outside the envelope (K in {64, 128}, N >= 2 K, N % 128 == 0, M >= 4096, 16-byte aligned operands). */
+int dle_gemm_expand_masked_bnred(const void* A, const void* B, void* C, const void* src, const void* bits, const void* t2,
+                                 const void* bits2, const float* mean2, const float* rstd2, float* partial, int64_t partial_bytes,
+                                 int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_kc, int dtype, hipStream_t stream);
+int dle_bn_bwd_finish(const float* partial, int groups, int C, float* dgamma, float* dbeta, int accumulate, hipStream_t stream);
 /* ---- the ResNet stem (csrc/stem.hip): conv7x7 / stride 2 / pad 3 of a 3-channel image, forward (+ BatchNorm partial sums) and
  * weight gradient, on a 4-channel NHWC image (dle_nchw_to_nhwc with C_padded = 4: 8 bytes per pixel, channel 3 zero).
  *   replaces cuDNN behind builder.conv7x7(3, 64, stride=2) + bn1's statistics: Classification/ConvNets/image_classification/

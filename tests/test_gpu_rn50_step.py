@@ -175,9 +175,9 @@ def test_rn50_unit_backward_teacher_forced_vs_fp32(cuda, dtype):
         full[:, ::2, ::2] = compact
         return full
 
-    def spy(self, dy, need_dx=True, dx_addend=None, dy_mask=None, compact_dx=False):
+    def spy(self, dy, need_dx=True, dx_addend=None, dy_mask=None, compact_dx=False, bnred=None):
         saved = self.saved
-        dx = orig(self, dy, need_dx=need_dx, dx_addend=dx_addend, dy_mask=dy_mask, compact_dx=compact_dx)
+        dx = orig(self, dy, need_dx=need_dx, dx_addend=dx_addend, dy_mask=dy_mask, compact_dx=compact_dx, bnred=bnred)
         is_up2 = lambda v: isinstance(v, tuple) and v[0] == "up2"
         records.append((self, dy, stuffed(dx_addend) if is_up2(dx_addend) else dx_addend, dy_mask, saved,
                         stuffed(dx) if is_up2(dx) else dx))

@@ -19,3 +19,4 @@ echo "== gemm_smallm_kernel (Tacotron2 probe, tools/probes/smallm_policy.py)"; r
 echo "== head_bce_kernel / emb_onehot_kernel / emb_sgd_lists (DLRM step, tools/replay_step.py dlrm)"; run head_bce_kernel tools/replay_step.py dlrm
 run emb_onehot_kernel tools/replay_step.py dlrm
 run emb_sgd_lists tools/replay_step.py dlrm
+echo "== conv_bnbwd_kernel (ResNet-50 step)"; run conv_bnbwd_kernel tools/replay_step.py rn50
