@@ -52,8 +52,8 @@ _SIGS = {
                                    c_void_p, c_int, c_i64, c_int, c_int, c_i64, c_int, c_void_p, c_i64, c_void_p]),
     "dle_cast_rows": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_i64, c_i64, c_int, c_int, c_void_p]),
     "dle_bce_logits": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p]),
-    "dle_conv1x1_bnbwd_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                        c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dle_conv1x1_bnbwd_dgrad": (c_int, [c_void_p] * 16 + [c_i64, c_int, c_int, c_int, c_int, c_void_p]),
+    "dle_conv1x1_bnbwd_groups": (c_int, [c_int]),
     "dle_gemm_expand_masked_bnred": (c_int, [c_void_p] * 10 + [c_i64, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_void_p]),
     "dle_bn_bwd_finish": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "dle_gemm_colsum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_int,

@@ -309,7 +309,7 @@ class ResNetTrainer:
                 with torch.cuda.stream(bs):
                     gskip = ud.backward(g, dy_mask=mask3, compact_dx=self.fuse_up2)
                 self._branch_keep.append((gskip, g))
-            g3 = u3.backward(g)
+            g3 = u3.backward(g, bnred=u2 if self.fuse_bnred else None)     # (bn2's reduction rides on conv3's fused data gradient)
             self._done(u3)
             if ud is not None and bs is None:
                 gskip = ud.backward(g, dy_mask=mask3, compact_dx=self.fuse_up2)

@@ -141,10 +141,16 @@ class ConvBN:
         reduce_done, self.reduce_done = self.reduce_done, False
         fused = None
         if self.fuse_bnbwd and self.k == 1 and self.stride == 1 and need_dx and dx_addend is None:   # (compact_dx: stride 2 only)
+            b2 = None
+            if bnred is not None and bnred.saved is not None and bnred.relu:
+                # dx of this unit is the gradient entering `bnred`'s BatchNorm (bn2 of the bottleneck): its reduction rides along
+                b2 = (bnred.saved[1], bnred.saved[2], bnred.saved[3], bnred.saved[4], bnred.ggamma, bnred.gbeta)
             fused = F.bn_bwd_conv1x1_dgrad(dy, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta,
-                                           self.w16.view(self.cout, c), relu_mask=rmask, reduce_done=reduce_done)
+                                           self.w16.view(self.cout, c), relu_mask=rmask, reduce_done=reduce_done, bnred=b2)
         if fused is not None:
             gt = fused[0]
+            if fused[2]:
+                bnred.reduce_done = True
         else:
             gt, _ = F.bn_bwd(dy, None, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta, relu_mask=rmask,
                              reduce_done=reduce_done)

@@ -27,6 +27,12 @@ struct BnbArgs {
   float inv_m;
   int M, N, K;
   int row_tiles, groups;
+  // optional: dx is itself the gradient entering ANOTHER BatchNorm (bn2 of the same bottleneck): its backward reduction -- sum g,
+  // sum g xhat with g = dx under bits2, xhat = (t2 - mean2) rstd2 -- is taken from the values about to be stored (bn_reduce_kernel)
+  const unsigned short* t2;     // [M, N] or NULL
+  const unsigned char* bits2;   // [M * N / 8]
+  const float* mean2; const float* rstd2;
+  float* partial;               // [groups][2][N]
 };
 
 template <int DT> struct BbMfma;
@@ -47,12 +53,36 @@ __device__ __forceinline__ int bb_pos(int nl) {                       // (the in
 }
 
 // KS = K / 32 k steps, NB 16-column blocks (N = 16 NB, one column tile), NW wavefronts of 16 rows each
-template <int DT, int KS, int NB, int NW, bool MASK>
-__global__ __launch_bounds__(NW * 64) void conv_bnbwd_kernel(BnbArgs p) {
+// v[16] per lane, 16 lanes (fr = lane & 15) -> acc += sum over the 16 lanes of v[fr] (reduce-scatter: xor-8 / 4 / 2 / 1 exchanges)
+__device__ __forceinline__ void bb_reduce_scatter16(const float* v, int fr, float& acc) {
+  float w8[8], w4[4], w2[2];
+  const bool h8 = fr & 8, h4 = fr & 4, h2 = fr & 2, h1 = fr & 1;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float keep = h8 ? v[8 + q] : v[q], send = h8 ? v[q] : v[8 + q];
+    w8[q] = keep + __shfl_xor(send, 8, 64);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float keep = h4 ? w8[4 + q] : w8[q], send = h4 ? w8[q] : w8[4 + q];
+    w4[q] = keep + __shfl_xor(send, 4, 64);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float keep = h2 ? w4[2 + q] : w4[q], send = h2 ? w4[q] : w4[2 + q];
+    w2[q] = keep + __shfl_xor(send, 2, 64);
+  }
+  const float keep = h1 ? w2[1] : w2[0], send = h1 ? w2[0] : w2[1];
+  acc += keep + __shfl_xor(send, 1, 64);
+}
+
+template <int DT, int KS, int NB, int NW, bool MASK, bool BRED>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3))) void conv_bnbwd_kernel(BnbArgs p) {
   constexpr int K = KS * 32, LDW = K + BB_PAD, TM = NW * 16, TN = NB * 16, NP = NB / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned short* wl = (unsigned short*)smem_raw;                      // [TN][LDW]
   float* cf = (float*)(smem_raw + TN * LDW * 2);                       // [5][K]: ka | mean | rstd | kb | kg
+  float* mu2 = cf + 5 * K;                                            // BRED: mean2 | rstd2 [TN] each
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, kg = lane >> 4;
   const int g = blockIdx.x;
@@ -70,11 +100,17 @@ __global__ __launch_bounds__(NW * 64) void conv_bnbwd_kernel(BnbArgs p) {
     cf[3 * K + c] = p.dbeta[c] * p.inv_m;
     cf[4 * K + c] = p.dgamma[c] * p.inv_m;
   }
+  if (BRED) {
+    for (int c = threadIdx.x; c < TN; c += NW * 64) { mu2[c] = p.mean2[c]; mu2[TN + c] = p.rstd2[c]; }
+  }
   __syncthreads();
   const unsigned short* wrow = wl + fr * LDW + kg * 8;
   const int mrow = wave * 16 + fr;
   ushort8_t fg[KS], fx[KS];
   uint4_t mb0, mb1;                                                    // the row's K / 8 = 32 mask bytes (K = 256)
+  ushort8_t t2c[BRED ? NP : 1];                                        // BRED: the row of t2
+  uint2_t m2c;                                                         // ... and its N / 8 = 8 bytes of bits2
+  float r1 = 0.f, r2 = 0.f;                                            // BRED: this lane's column (value fr of its 16) over every tile so far
   auto load_rows = [&](int m) __attribute__((always_inline)) {
     const long long mr = m < p.M ? m : p.M - 1;
     const long long o = mr * K + kg * 8;
@@ -87,6 +123,11 @@ __global__ __launch_bounds__(NW * 64) void conv_bnbwd_kernel(BnbArgs p) {
       const uint4_t* mp = (const uint4_t*)(p.bits + mr * (K / 8));
       mb0 = mp[0];
       if (KS > 4) mb1 = mp[1];
+    }
+    if (BRED) {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) t2c[j] = *(const ushort8_t*)(p.t2 + mr * TN + 32 * j + kg * 8);
+      m2c = *(const uint2_t*)(p.bits2 + mr * (TN / 8));
     }
   };
   load_rows(g * TM + mrow);
@@ -128,7 +169,6 @@ __global__ __launch_bounds__(NW * 64) void conv_bnbwd_kernel(BnbArgs p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    load_rows((tm + p.groups) * TM + mrow);          // the next tile's rows, in front of this tile's output stores (vmcnt is in order)
     // ---- epilogue: pair j = blocks 2j, 2j + 1 -> columns 32 j + 8 kg + {0..7}
     ushort8_t outv[NP];
 #pragma unroll
@@ -138,6 +178,29 @@ __global__ __launch_bounds__(NW * 64) void conv_bnbwd_kernel(BnbArgs p) {
       for (int r = 0; r < 4; ++r) { v[r] = acc[2 * j][r]; v[4 + r] = acc[2 * j + 1][r]; }
       outv[j] = pack8<DT>(v);
     }
+    if constexpr (BRED) {
+      static_assert(NP == 2, "16 output columns per lane");
+      float tg[16], tx[16];
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        float z[8], tf[8];
+        unpack8<DT>(outv[j], z);
+        unpack8<DT>(t2c[j], tf);
+        const unsigned b2 = (m2c[j] >> (8 * kg)) & 0xffu;               // byte 4 j + kg of the row's 8
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int cl = 32 * j + 8 * kg + r;
+          const float gz = (live && ((b2 >> r) & 1u)) ? z[r] : 0.f;
+          tg[8 * j + r] = gz;
+          tx[8 * j + r] = gz * (tf[r] - mu2[cl]) * mu2[TN + cl];
+        }
+      }
+      bb_reduce_scatter16(tg, fr, r1);
+      bb_reduce_scatter16(tx, fr, r2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the next tile's rows, in front of this tile's output stores (vmcnt is in order) and behind the last use of this tile's t2 row
+    load_rows((tm + p.groups) * TM + mrow);
     __builtin_amdgcn_sched_barrier(0);
     {
       // full 128-byte lines per store instruction (gemm_expand.hip): neighbouring rows swap half of their pieces
@@ -161,14 +224,40 @@ __global__ __launch_bounds__(NW * 64) void conv_bnbwd_kernel(BnbArgs p) {
       }
     }
   }
+  if (BRED) {
+    // lane fr holds value fr of its column group's 16: value i = column 32 (i >> 3) + 8 kg + (i & 7)
+    __syncthreads();
+    float* red = (float*)smem_raw;                                      // [NW waves][2][TN]
+    const int col = 32 * (fr >> 3) + 8 * kg + (fr & 7);
+    red[(wave * 2 + 0) * TN + col] = r1;
+    red[(wave * 2 + 1) * TN + col] = r2;
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * TN; t += NW * 64) {
+      const int which = t / TN, col2 = t - which * TN;
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) tot += red[(w * 2 + which) * TN + col2];
+      p.partial[((long long)g * 2 + which) * p.N + col2] = tot;
+    }
+  }
 }
 
 // dt [M, K] = BatchNorm backward of (dy under the keep bits, t), dx [M, N] = dt W with W [K][N] n-contiguous.
 // 1: launched; 0: outside the envelope (K = 256, N = 64, M >= 4096, dense 16-byte aligned operands; the caller runs
 // dle_bn_bwd_apply + dle_gemm); > 1: launch error.  dgamma / dbeta: the sums dle_bn_bwd_reduce left (fp32 [K]).
+// 768 three-per-CU workgroups at most: the rows of `partial` the BRED form writes
+extern "C" int dle_conv1x1_bnbwd_groups(int M) {
+  const int row_tiles = (M + 63) / 64;
+  return row_tiles < 768 ? row_tiles : 768;
+}
+
+// t2 / bits2 / mean2 / rstd2 / partial (all or none): dx is the gradient that enters a SECOND BatchNorm (bn2 of the bottleneck);
+// partial [dle_conv1x1_bnbwd_groups(M)][2][N] receives its backward reduction (fold with dle_bn_bwd_finish).
 extern "C" int dle_conv1x1_bnbwd_dgrad(const void* dy, const void* t, const void* relu_mask, const void* w, void* dt, void* dx,
                                        const float* mean, const float* rstd, const float* gamma, const float* dgamma,
-                                       const float* dbeta, int M, int N, int K, int dtype, hipStream_t stream) {
+                                       const float* dbeta, const void* t2, const void* bits2, const float* mean2,
+                                       const float* rstd2, float* partial, int64_t partial_bytes, int M, int N, int K, int dtype,
+                                       hipStream_t stream) {
   static const char* pin = getenv("DLE_CONV_BNBWD");
   if (pin && atoi(pin) == 0) return 0;
   if (dtype != DLE_F16 && dtype != DLE_BF16) return 0;
@@ -176,8 +265,11 @@ extern "C" int dle_conv1x1_bnbwd_dgrad(const void* dy, const void* t, const void
   if (!dy || !t || !w || !dt || !dx || !mean || !rstd || !gamma || !dgamma || !dbeta) return 0;
   if (((((uintptr_t)dy) | ((uintptr_t)t) | ((uintptr_t)w) | ((uintptr_t)dt) | ((uintptr_t)dx) | ((uintptr_t)relu_mask)) & 15) != 0)
     return 0;
+  const bool bred = t2 != nullptr;
+  if (bred && (!bits2 || !mean2 || !rstd2 || !partial || ((((uintptr_t)t2) | ((uintptr_t)bits2)) & 15) != 0)) return 0;
   constexpr int NWv = 4, TMv = NWv * 16;
   BnbArgs p;
+  p.t2 = (const unsigned short*)t2; p.bits2 = (const unsigned char*)bits2; p.mean2 = mean2; p.rstd2 = rstd2; p.partial = partial;
   p.DY = (const unsigned short*)dy; p.T = (const unsigned short*)t; p.bits = (const unsigned char*)relu_mask;
   p.B = (const unsigned short*)w; p.DT = (unsigned short*)dt; p.C = (unsigned short*)dx;
   p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.dgamma = dgamma; p.dbeta = dbeta; p.inv_m = 1.0f / (float)M;
@@ -186,12 +278,14 @@ extern "C" int dle_conv1x1_bnbwd_dgrad(const void* dy, const void* t, const void
   int groups = 256 * 3;                                                // three 4-wave workgroups per CU (34 KiB weights + coefficients)
   if (groups > p.row_tiles) groups = p.row_tiles;
   p.groups = groups;
-  const size_t lds = (size_t)N * (K + BB_PAD) * 2 + 5 * K * 4;
+  if (bred && partial_bytes < (long long)groups * 2 * N * 4) return 0;
+  const size_t lds = (size_t)N * (K + BB_PAD) * 2 + 5 * K * 4 + 2 * N * 4;
   const dim3 grid((unsigned)groups), block(NWv * 64);
-#define BB_GO(DT, MK) do { static bool attr_set = false; \
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_bnbwd_kernel<DT, 8, 4, NWv, MK>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr_set = true; } \
-    hipLaunchKernelGGL((conv_bnbwd_kernel<DT, 8, 4, NWv, MK>), grid, block, lds, stream, p); } while (0)
-#define BB_M(DT) do { if (relu_mask) BB_GO(DT, true); else BB_GO(DT, false); } while (0)
+#define BB_GO(DT, MK, BR) do { static bool attr_set = false; \
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_bnbwd_kernel<DT, 8, 4, NWv, MK, BR>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr_set = true; } \
+    hipLaunchKernelGGL((conv_bnbwd_kernel<DT, 8, 4, NWv, MK, BR>), grid, block, lds, stream, p); } while (0)
+#define BB_M(DT) do { if (relu_mask) { if (bred) BB_GO(DT, true, true); else BB_GO(DT, true, false); } \
+                      else { if (bred) BB_GO(DT, false, true); else BB_GO(DT, false, false); } } while (0)
   if (dtype == DLE_F16) BB_M(DLE_F16); else BB_M(DLE_BF16);
 #undef BB_M
 #undef BB_GO

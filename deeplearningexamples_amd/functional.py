@@ -917,10 +917,13 @@ def gemm_masked_add_bnred(g2, w, m, n, k, addend, bits, t2, bits2, mean2, rstd2,
     return out
 
 
-def bn_bwd_conv1x1_dgrad(dy, x, mean, rstd, gamma, dgamma, dbeta, w, relu_mask=None, reduce_done=False):
+def bn_bwd_conv1x1_dgrad(dy, x, mean, rstd, gamma, dgamma, dbeta, w, relu_mask=None, reduce_done=False, bnred=None):
     """BatchNorm backward of a conv + BN unit whose convolution is 1x1 / stride 1, with the unit's data gradient in the same
     pass: the reduction (dgamma, dbeta) as in bn_bwd, then ONE kernel that applies the backward on the operand load of
     dx = dt W (csrc/conv_bnbwd.hip).  x: the convolution output [.., K]; w: the 16-bit weight [K, N] (n contiguous).
+    bnred = (t2 [.., N], bits2, mean2, rstd2, dgamma2, dbeta2): dx is the gradient that enters a second BatchNorm (bn2 of the
+    bottleneck, behind a ReLU with keep bits bits2); its backward reduction is taken from dx in the same kernel and left in
+    dgamma2 / dbeta2 (the caller's second unit then skips its own first pass).
     -> (dt, dx [m, N]) or None outside the kernel's envelope (nothing has been launched then: run bn_bwd + gemm)."""
     C.require_cuda(dy, x, mean, rstd, gamma, dgamma, dbeta, w, relu_mask)
     k = x.shape[-1]
@@ -939,14 +942,24 @@ def bn_bwd_conv1x1_dgrad(dy, x, mean, rstd, gamma, dgamma, dbeta, w, relu_mask=N
                C.ptr(dbeta), m, k, 0, C.ptr(ws), ws.numel() * 4, C.dt(x), C.stream())
     dt = torch.empty_like(x)
     dx = torch.empty((m, n), dtype=x.dtype, device=x.device)
-    C.annotate(bytes=float(x.numel()) * (6 + act_bytes) + dx.numel() * 2.0, flops=2.0 * m * n * k,
-               tag="bn_bwd+dgrad %dx%dx%d%s" % (m, n, k, relu_tag))
+    t2 = bits2 = mean2 = rstd2 = part = None
+    groups = 0
+    if bnred is not None and bnred[0].numel() == m * n and bnred[0].is_contiguous() and bnred[1] is not None \
+            and os.environ.get("DLE_RN50_FUSE_BNRED", "1") != "0" and os.environ.get("DLE_RN50_FUSE_BNRED2", "1") != "0":
+        t2, bits2, mean2, rstd2 = bnred[:4]
+        groups = int(C.lib().dle_conv1x1_bnbwd_groups(m))
+        part = splitk_workspace(x.device, groups * 2 * n * 4)
+    C.annotate(bytes=float(x.numel()) * (6 + act_bytes) + dx.numel() * (2.0 + (2.125 if t2 is not None else 0.0)),
+               flops=2.0 * m * n * k, tag="bn_bwd+dgrad %dx%dx%d%s%s" % (m, n, k, relu_tag, "+bnred" if t2 is not None else ""))
     rc = _timed_optional("dle_conv1x1_bnbwd_dgrad", C.lib().dle_conv1x1_bnbwd_dgrad,
                          (C.ptr(dy), C.ptr(x), C.ptr(relu_mask), C.ptr(w), C.ptr(dt), C.ptr(dx), C.ptr(mean), C.ptr(rstd),
-                          C.ptr(gamma), C.ptr(dgamma), C.ptr(dbeta), m, n, k, C.dt(x), C.stream()))
+                          C.ptr(gamma), C.ptr(dgamma), C.ptr(dbeta), C.ptr(t2), C.ptr(bits2), C.ptr(mean2), C.ptr(rstd2),
+                          C.ptr(part), part.numel() * 4 if part is not None else 0, m, n, k, C.dt(x), C.stream()))
     if rc != 1:
         C.check(rc - 1000 if rc > 1000 else -1, "dle_conv1x1_bnbwd_dgrad")       # (the envelope was checked above)
-    return dt, dx
+    if t2 is not None:
+        C.call("dle_bn_bwd_finish", C.ptr(part), groups, n, C.ptr(bnred[4]), C.ptr(bnred[5]), 0, C.stream())
+    return dt, dx, t2 is not None
 
 
 def maxpool_fwd(x, ksize=3, stride=2, pad=1):

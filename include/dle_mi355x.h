@@ -321,10 +321,15 @@ int dle_conv1x1_bnload_fwd(const void* t, const void* res, const void* w, void* 
  * that consumes it -- the conv3 / bn3 unit of a bottleneck (models/resnet.py:148-175 backward).  dt [M, K] = ka (g - dbeta / M -
  * xhat dgamma / M) with g = dy under relu_mask (bit-packed, may be NULL), dx [M, N] = dt W, W [K][N] n-contiguous; dgamma / dbeta
  * = the sums dle_bn_bwd_reduce left.  dt and dx are bit-identical to dle_bn_bwd_apply + dle_gemm; dt is never re-read.
+ * t2 / bits2 / mean2 / rstd2 / partial (all or none, NULL: off): dx is itself the gradient that enters a second BatchNorm (bn2 of the
+ * bottleneck, ReLU keep bits bits2); partial [dle_conv1x1_bnbwd_groups(M)][2][N] receives its backward reduction (sum g, sum g xhat
+ * per workgroup; fold with dle_bn_bwd_finish), as dle_gemm_expand_masked_bnred does for bn3.
  * 1: launched; 0: outside the envelope (K = 256, N = 64, M >= 4096, 16-byte aligned dense operands). */
 int dle_conv1x1_bnbwd_dgrad(const void* dy, const void* t, const void* relu_mask, const void* w, void* dt, void* dx,
                             const float* mean, const float* rstd, const float* gamma, const float* dgamma, const float* dbeta,
-                            int M, int N, int K, int dtype, hipStream_t stream);
+                            const void* t2, const void* bits2, const float* mean2, const float* rstd2, float* partial,
+                            int64_t partial_bytes, int M, int N, int K, int dtype, hipStream_t stream);
+int dle_conv1x1_bnbwd_groups(int M);
 /* The backward reduction of a BatchNorm taken where its input gradient is PRODUCED (csrc/gemm_expand.hip, BRED): conv1's data
  * gradient of the next bottleneck, C = A B^T + src under `bits` (the DLE_ACT_ADD_MASKED form of dle_gemm), is the gradient of the
  * previous block's output; with g = C under bits2 and xhat = (t2 - mean2) rstd2 the kernel also leaves partial [groups][2][N] rows
