@@ -416,7 +416,8 @@ extern "C" int dle_gemm_expand_masked_bnred(const void* A, const void* B, void* 
   if (pin && atoi(pin) == 0) return 0;
   // (K = 256 is built and correct, but its 8-wave workgroup spills and runs slower than the two launches: 104 us against 60 + 39 at
   //  50176 x 1024 x 256; DLE_GEMM_BNRED_K256=1 lets it through for measurement)
-  static const int k256 = getenv("DLE_GEMM_BNRED_K256") ? atoi(getenv("DLE_GEMM_BNRED_K256")) : 0;
+  const char* k256e = getenv("DLE_GEMM_BNRED_K256");                     // (read per call: tests switch it inside one process)
+  const int k256 = k256e ? atoi(k256e) : 0;
   if (M < 4096 || (K != 64 && K != 128 && !(K == 256 && k256)) || (N % EX_TN) != 0 || N < 2 * K) return 0;
   if (dtype != DLE_F16 && dtype != DLE_BF16) return 0;
   if (!A || !B || !C || !src || !bits || !t2 || !bits2 || !mean2 || !rstd2 || !partial) return 0;
