@@ -258,13 +258,16 @@ extern "C" int dle_emb_grad_values(const void* grad, float* values, const float*
 // Duplicate-free sparse SGD (the fast path of the train step).
 //
 // fp32 atomics run at ~0.77 TB/s on this part, 10x under the HBM roofline, and tiny tables (4..100 rows,
-// hit by every sample) serialise on a handful of L2 lines.  Instead:
-//   * tables with <= LDS-capacity rows: each workgroup reduces a slice of the batch for one table into
-//     an LDS-resident dense [rows, dim] fp32 image (ds_add_f32) and flushes it once.
+// hit by every sample) serialise on a handful of L2 lines.  Instead, by table size (the paths of dle_emb_sgd_dedup_ws):
+//   * <= 128 rows at dim 128, 16-bit gradients, scratch given: OneHot(ids)^T G on the matrix pipe (emb_onehot.hip);
+//     without scratch / for other dims: the register form (emb_sgd_tiny) or the LDS form (emb_sgd_small: each workgroup reduces
+//     a slice of the batch for one table into an LDS-resident dense [rows, dim] fp32 image and flushes it once);
 //   * every other table: one pass threads the batch's lookups into per-row linked lists
 //     (head[row] <- atomicExch, next[i] <- previous head: one 4 B atomic per lookup), a second pass lets
 //     the list head of each touched row sum its duplicates in fp32 and do ONE plain read-modify-write of
-//     the 512 B row -- no float atomics, HBM sees row read + row write + one grad read per lookup.
+//     the 512 B row -- no float atomics, HBM sees row read + row write + one grad read per lookup;
+//   * of those, tables of <= 4096 rows (with scratch): EIGHT lists per row and a third pass that adds their partial sums
+//     (MidMap below) -- their ~70 duplicates per row were one ~95-hop dependent chain per row otherwise.
 // head[] (int32 per table row, all -1 between calls) is persistent workspace owned by the caller.
 struct SmallTables {
   int n;
