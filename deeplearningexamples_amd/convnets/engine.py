@@ -296,6 +296,10 @@ class ResNetTrainer:
         self._maybe_reduce("fc.weight"); self._maybe_reduce("fc.bias")
         gp = F.gemm(dlogits, fcw, n, fcw.shape[1], fcw.shape[0], True, False)
         g = F.avgpool_bwd(gp, self._feat_hw)
+        for blk in self.blocks:                  # (a backward pass that was abandoned half way must not leave a unit believing its
+            for u in blk:                        #  BatchNorm reduction has been taken by its neighbour)
+                if u is not None:
+                    u.reduce_done = False
         for bi in range(len(self.blocks) - 1, -1, -1):
             u1, u2, u3, ud = self.blocks[bi]
             # the block ends in relu(bn3(conv3) + shortcut): g * (out > 0) flows into BOTH branches.  It is never written:
