@@ -1,0 +1,111 @@
+// Launcher of the persistent eight-phase GEMM (kernel and design notes: gemm8_kernel.h) + its store-only instantiations.
+#include "gemm8_kernel.h"
+
+// ---- launcher ----------------------------------------------------------------------------------------------------------------
+static int g8_mode_value = -2;          // -2: read DLE_GEMM_8PH on first use; 0 off; 1 on
+extern "C" int dle_gemm8_mode(int mode) {
+  if (g8_mode_value == -2) g8_mode_value = getenv("DLE_GEMM_8PH") ? atoi(getenv("DLE_GEMM_8PH")) : 1;
+  const int prev = g8_mode_value;
+  if (mode >= 0) g8_mode_value = mode;
+  return prev;
+}
+
+#ifdef G8_TIMING
+unsigned long long* g8_dbg_ptr = nullptr;
+int g8_dbg_items = 0;
+#endif
+// instantiation units: gemm8.hip (store-only epilogues), gemm8_epi1.hip (bias / forward activations), gemm8_epi2.hip
+// (source-tensor epilogues); each returns 0 for a combination it does not carry
+extern "C" int g8_launch_epi1(const Gemm8Args* p, int dt, int am, int bm, int act, int grid, hipStream_t stream);
+extern "C" int g8_launch_epi2(const Gemm8Args* p, int dt, int am, int bm, int act, int grid, hipStream_t stream);
+static int g8_launch_epi0(const Gemm8Args* p, int dt, int am, int bm, int grid, hipStream_t stream) {
+#define G8_E0(DT) do { if (am == 0 && bm == 0) g8_launch<DT, 0, 0, 0, ACT_NONE>(*p, grid, stream); \
+    else if (am == 0) g8_launch<DT, 0, 1, 0, ACT_NONE>(*p, grid, stream); else g8_launch<DT, 1, 1, 0, ACT_NONE>(*p, grid, stream); } while (0)
+  if (dt == DLE_F16) G8_E0(DLE_F16); else G8_E0(DLE_BF16);
+#undef G8_E0
+  return 1;
+}
+
+// 1: launched; 0: outside the envelope (the caller continues with the kernels of gemm_dma.hip); > 1: error.
+// stats != NULL: column sums of the rounded output into stats[2 * ceil(M / 256)][N] (act = ReLU mask / stored derivative only).
+extern "C" int dle_gemm8_try(const void* A, const void* B, void* C, void* aux, const float* bias, const void* src, int M, int N,
+                             int K, int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc, int in_dtype, int out_dtype,
+                             int act, int splitk, int accumulate, float alpha, float* ws, float* stats, hipStream_t stream) {
+  if (dle_gemm8_mode(-1) <= 0) return 0;
+  if (in_dtype != DLE_F16 && in_dtype != DLE_BF16) return 0;
+  if (!a_kc && b_kc) return 0;
+  if (M < 256 || N < 256 || K < 2 * BK || (K % BK) != 0 || (N & 7) != 0) return 0;
+  if (!a_kc && (M & 7) != 0) return 0;
+  const bool al = ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)aux) | ((uintptr_t)src) | ((uintptr_t)bias) |
+                    ((uintptr_t)ws)) & 15) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && (ldc & 7) == 0;
+  if (!al) return 0;
+  // operand extents (range-checked DMA) and 32-bit lane offsets
+  const long long a_rows = a_kc ? M : K, b_rows = b_kc ? N : K;
+  const long long a_bytes = a_rows * lda * 2, b_bytes = b_rows * ldb * 2;
+  // (a half-tile may start up to 256 rows past the end of an operand: its 32-bit byte offset must not wrap)
+  if ((a_rows + 256) * lda * 2 >= 0xFFFFFFFFLL || (b_rows + 256) * ldb * 2 >= 0xFFFFFFFFLL) return 0;
+  if ((long long)M * ldc * 4 >= 0x7FFFFFFFFFFFLL) return 0;
+  if (splitk < 1) splitk = 1;
+  const int ktiles = K / BK;
+  if (splitk > ktiles) return 0;
+  int epi;
+  if (splitk > 1) {
+    if (!ws || out_dtype != DLE_F32 || bias || act != ACT_NONE || aux || stats) return 0;
+    epi = 0;
+  } else if (act == ACT_RELU_BWD || act == ACT_ADD || act == ACT_MUL || act == ACT_GELU_BWD || act == ACT_TANH_BWD) {
+    if (!src || bias || aux || out_dtype != in_dtype || accumulate) return 0;
+    if (stats && !(act == ACT_RELU_BWD || act == ACT_MUL)) return 0;
+    if (stats && (M & 255) != 0) return 0;
+    epi = 2;
+  } else if (act == ACT_NONE || act == ACT_RELU || act == ACT_GELU || act == ACT_TANH || act == ACT_GELU_DAUX) {
+    if (stats) return 0;
+    if (out_dtype == DLE_F32) {
+      if (act != ACT_NONE || aux) return 0;
+    } else if (out_dtype != in_dtype || accumulate) return 0;
+    if (act == ACT_GELU_DAUX && !aux) return 0;
+    epi = (bias || act != ACT_NONE || aux) ? 1 : 0;
+  } else return 0;
+  // the three operand layouts of a linear layer, each with the epilogues its pass uses (the instantiation units decide)
+  const int am = a_kc ? 0 : 1, bm = b_kc ? 0 : 1;
+  static const int tn_mode = getenv("DLE_GEMM_8PH_TN") ? atoi(getenv("DLE_GEMM_8PH_TN")) : 1;
+  if (am == 1 && !tn_mode) return 0;
+  const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  const long long nitems = tiles * splitk;
+  static const int min_items = getenv("DLE_GEMM_8PH_MIN_ITEMS") ? atoi(getenv("DLE_GEMM_8PH_MIN_ITEMS")) : 128;
+  if (nitems < min_items || nitems > 0x3FFFFFFF || (long long)(splitk + 1) * ktiles >= 0x7FFFFFFFLL) return 0;
+  static const int ncu = [] { int dev = 0, v = 0; hipGetDevice(&dev);
+                              hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
+  static const int lds_max = [] { int dev = 0, v = 0; hipGetDevice(&dev);
+                                  hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev); return v; }();
+  if (lds_max < G8_LDS_BYTES) return 0;
+  Gemm8Args p = {};
+  p.A = (const unsigned short*)A; p.B = (const unsigned short*)B; p.C = C; p.aux = aux; p.bias = bias;
+  p.src = (const unsigned short*)src; p.ws = splitk > 1 ? ws : nullptr; p.stats = stats;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.a_bytes = (unsigned)a_bytes; p.b_bytes = (unsigned)b_bytes;
+  p.out_dtype = out_dtype; p.act = act; p.splitk = splitk; p.accumulate = accumulate; p.alpha = alpha;
+  static const int gm_env = getenv("DLE_GEMM_GM") ? atoi(getenv("DLE_GEMM_GM")) : 8;
+  p.gm = gm_env > 0 ? gm_env : 8;
+  {
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+    p.d_ntiles = make_fastdiv(tiles_m * tiles_n);
+    p.d_group = make_fastdiv(p.gm * tiles_n);
+    p.d_rows_full = make_fastdiv(p.gm);
+    p.d_rows_last = make_fastdiv(tiles_m % p.gm ? tiles_m % p.gm : p.gm);
+    p.d_splitk = make_fastdiv(splitk);
+    const long long cb = splitk > 1 ? (long long)M * N * 4 : (long long)M * ldc * (out_dtype == DLE_F32 ? 4 : 2);
+    p.c_bytes = cb < 0xFFFFFFFFLL ? (unsigned)cb : 0u;           // 0: the interior fast path is off (c_bytes == 0 below)
+  }
+#ifdef G8_TIMING
+  p.dbg = g8_dbg_ptr; p.dbg_items = g8_dbg_items;
+#endif
+  const int grid = (int)(nitems < ncu ? nitems : ncu);
+  int launched;
+  if (epi == 0) launched = g8_launch_epi0(&p, in_dtype, am, bm, grid, stream);
+  else if (epi == 1) launched = g8_launch_epi1(&p, in_dtype, am, bm, act, grid, stream);
+  else launched = g8_launch_epi2(&p, in_dtype, am, bm, act, grid, stream);
+  if (!launched) return 0;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { dle_set_error("gemm8 launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
+  return 1;
+}

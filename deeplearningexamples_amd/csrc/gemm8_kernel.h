@@ -1,0 +1,702 @@
+// The 256 x 256 "eight-phase" MFMA GEMM for gfx950 -- the kernel behind dle_gemm / dle_gemm_colsum for the big linear layers
+// (LanguageModeling/BERT/modeling.py:130-160,340-384 LinearActivation / BertSelfOutput / BertIntermediate / BertOutput and
+//  their backward; Recommendation/DLRM/dlrm/nn/mlps.py:38-43): forward X W^T, data gradient dY W, weight gradient dY^T X.
+//
+//   C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )        (contract of gemm_dma.hip, which stays for every other shape)
+//
+// What is different from gemm_dma.hip's 256 x 256 tile (one barrier + vmcnt(0) per K tile, fp32 tile transposed through LDS in
+// the epilogue: 0.88-0.92 PFLOP/s on the K = 1024 layers, ~29 % of a tile's time outside the K loop):
+//  * PERSISTENT: one workgroup per CU walks a list of (tile, K slice) items; the operand stream never drains between items --
+//    the first K tiles of the next item are already in flight while the current one's results are stored.
+//  * HALF-TILE STREAM, COUNTED WAITS: a K tile (64 deep) is four 16 KiB half-tiles (A rows 0-127 / 128-255, B rows 0-127 /
+//    128-255), each staged by ONE LDS-DMA piece pair per wavefront; one half-tile is issued per phase, three are always in
+//    flight across the barriers, and the only wait for them is ONE s_waitcnt vmcnt(6) per K tile (never 0).
+//  * PING-PONG: the eight wavefronts are two groups of four (one wavefront of each group per SIMD), staggered by one barrier:
+//    while a group runs its eight MFMAs of a phase (one 64 x 32 quadrant x K = 64) the other group issues its LDS fragment reads
+//    and its DMA pieces.  A wavefront owns rows {0,128} + 64 wr .. +63 and columns {0,128} + 32 wc .. +31 of the tile, i.e. one
+//    64 x 32 block of each (A half, B half) pair, so every phase consumes one freshly landed half-tile.
+//  * REGISTER EPILOGUE: the B fragment rows are permuted (MFMA row 8q + 4h + e <- tile column 16h + 4q + e) so that a lane's 16
+//    accumulators of a 32 x 32 block are 16 CONSECUTIVE output columns of one row: bias / activation / source math runs in
+//    the accumulator layout and the results leave as 16-byte stores (64 contiguous bytes per row and lane pair) -- no LDS
+//    transposition, no barrier, nothing of the epilogue touches the operand stages the stream is already refilling.
+// LDS images, swizzles and the transpose reads of row-contiguous operands are the ones of gemm_tiles.h (half-tile = the
+// TILE = 128 image).  Hazards (RAW on LDS-DMA data, WAR on restaged half-tiles) are argued next to the phases below.
+#pragma once
+#include "gemm_tiles.h"
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_ADD = 4, ACT_GELU_BWD = 5, ACT_TANH = 6,
+       ACT_TANH_BWD = 7, ACT_ADD_MASKED = 8, ACT_MUL = 9, ACT_GELU_DAUX = 10 };
+
+#define G8_HALF 8192                 // 16-bit elements per half-tile image (128 rows x 64 k)
+#define G8_BUF (4 * G8_HALF)         // one K tile: A0 | A1 | B0 | B1
+#define G8_LDS_BYTES (2 * G8_BUF * 2)
+
+struct Gemm8Args {
+  const unsigned short* A;
+  const unsigned short* B;
+  void* C;
+  void* aux;
+  const float* bias;
+  const unsigned short* src;
+  float* ws;                 // split-K: fp32 slabs [splitk][M][N]
+  float* stats;              // column sums of the rounded output: partial rows [2 * tiles_m][N] (row 2 tm + wr)
+  int M, N, K;
+  long long lda, ldb, ldc;
+  unsigned a_bytes, b_bytes; // extent of each operand (rows x pitch x 2): the DMA's range check zero-fills rows past the end
+  int out_dtype, act, splitk, accumulate;
+  float alpha;
+  int gm;
+  unsigned c_bytes;          // extent of C (and of aux / src, same pitch) in bytes; split-K: of the slab buffer
+  FastDiv d_ntiles, d_group, d_rows_full, d_rows_last, d_splitk;      // item decode without integer division
+#ifdef G8_TIMING
+  unsigned long long* dbg;   // tools/kbench/gemm8_bench.cpp: shader-clock stamps [block][group][item][4]
+  int dbg_items;
+#endif
+};
+#ifdef G8_TIMING
+#define G8_STAMP(slot) do { if ((wave & 3) == 0 && lane == 0 && p.dbg && item_seq < p.dbg_items) \
+    p.dbg[((((long long)blockIdx.x * 2 + wr) * p.dbg_items) + item_seq) * 4 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define G8_STAMP(slot) do { } while (0)
+#endif
+
+#ifndef G8_DMA_IN_MMA
+#define G8_DMA_IN_MMA -1               // probes: 0 / 1 pins where a phase's DMA pieces are issued (default: by operand layout)
+#endif
+#ifndef G8_ST_KEEP
+#define G8_ST_KEEP 16                  // store instructions per wavefront of an interior tile's epilogue (lower bound over all flavours)
+#endif
+#ifndef G8_DMA_SLOT0
+#define G8_DMA_SLOT0 1
+#define G8_DMA_SLOT1 4
+#endif
+#define G8_SB() __builtin_amdgcn_sched_barrier(0)
+#define G8_BARRIER() do { G8_SB(); asm volatile("s_barrier" ::: "memory"); G8_SB(); } while (0)
+#define G8_LGKM(N) do { G8_SB(); asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); G8_SB(); } while (0)
+#define G8_VM(N) do { G8_SB(); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); G8_SB(); } while (0)
+
+// tile column (within a wavefront's 32-column block) that MFMA row i of the B fragment holds
+__device__ __forceinline__ int g8_perm32(int i) { return 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); }
+
+// ---- fragment reads out of a half-tile image ---------------------------------------------------------------------
+// k-contiguous image [128 rows][64 k], 16-byte chunk c of row r at slot c ^ swz_kc(r) (gemm_tiles.h).  The permuted row set of
+// a ds_read_b128 lane group equals its lane set, so the B reads are as conflict-free as the A reads.
+template <bool PERM>
+__device__ __forceinline__ ushort8_t g8_frag_kc(const unsigned short* t, int rbase32, int ks, int lane) {
+  const int row = rbase32 + (PERM ? g8_perm32(lane & 31) : (lane & 31));
+  return *(const ushort8_t*)(t + row * BK + (((ks * 2 + (lane >> 5)) ^ swz_kc(row)) << 3));
+}
+// row-contiguous image [64 k][128 rows] read with the LDS transpose read; PERM: the four 4-row blocks a 16-lane group
+// fetches are {0, 16, 4, 20} + 8 (tg & 1) instead of {0, 4, 8, 12} + 16 (tg & 1)  (output lane r of the group receives
+// element r & 3 of the block fetched by the lanes with ti & 3 == r >> 2)
+template <bool PERM>
+__device__ __forceinline__ TrPair g8_frag_rc(const unsigned short* t, int rbase32, int ks, int lane) {
+  if constexpr (!PERM) {
+    return frag_issue<true, 128>(t, rbase32, ks, lane);
+  } else {
+    const int tg = lane >> 4, ti = lane & 15, c = ti & 3;
+    const int kb = ks * 16 + (tg >> 1) * 8 + (ti >> 2);
+    const int chunk = (rbase32 >> 3) + 2 * (c & 1) + (tg & 1);
+    const int sub = (c >> 1) << 2;
+    TrPair f;
+    {
+      const int cpos = (((chunk >> 1) ^ swz_rc<128>(kb)) << 1) | (chunk & 1);
+      f.lo = ds_read_tr16_asm(t + kb * 128 + cpos * 8 + sub);
+    }
+    {
+      const int k = kb + 4;
+      const int cpos = (((chunk >> 1) ^ swz_rc<128>(k)) << 1) | (chunk & 1);
+      f.hi = ds_read_tr16_asm(t + k * 128 + cpos * 8 + sub);
+    }
+    return f;
+  }
+}
+template <int MODE, bool PERM>
+__device__ __forceinline__ typename FragT<MODE == 1>::type g8_frag(const unsigned short* t, int rbase32, int ks, int lane) {
+  if constexpr (MODE == 0) return g8_frag_kc<PERM>(t, rbase32, ks, lane);
+  else return g8_frag_rc<PERM>(t, rbase32, ks, lane);
+}
+
+// one LDS-DMA piece (1 KiB per wavefront) to LDS byte address m0v; hidden from hipcc's wait-count pass like dma16_raw
+__device__ __forceinline__ void g8_dma(int4v_t rs, unsigned m0v, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(m0v), "v"(voff), "s"(rs) : "memory");
+}
+
+// per-lane constants of one operand's two DMA pieces (identical for both halves and every tile)
+template <int MODE>
+struct G8Lane {
+  unsigned voff[2];
+  int c8[2];               // row-contiguous operands: first row (inside the half-tile) of the lane's 8-row chunk
+  __device__ __forceinline__ void init(int wave, int lane, long long ld) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (MODE == 0) {
+        const int r = (wave * 2 + j) * 8 + (lane >> 3), cpos = lane & 7;
+        const int chunk = cpos ^ swz_kc(r);
+        voff[j] = (unsigned)(((long long)r * ld + chunk * 8) * 2);
+        c8[j] = 0;
+      } else {
+        const int kr = (wave * 2 + j) * 4 + (lane >> 4), cpos = lane & 15;
+        const int chunk = (((cpos >> 1) ^ swz_rc<128>(kr)) << 1) | (cpos & 1);
+        voff[j] = (unsigned)(((long long)kr * ld + chunk * 8) * 2);
+        c8[j] = chunk * 8;
+      }
+    }
+  }
+};
+
+__device__ __forceinline__ float g8_gelu(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  return 0.5f * x * (1.0f + fast_tanh(k0 * (x + k1 * x * x * x)));
+}
+__device__ __forceinline__ float g8_gelu_d(float x, float& d) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  const float x2 = x * x;
+  const float th = fast_tanh(k0 * (x + k1 * x2 * x));
+  const float hp = 0.5f * (1.0f + th);
+  d = hp + 0.5f * x * (1.f - th * th) * k0 * (1.f + 3.f * k1 * x2);
+  return x * hp;
+}
+
+// EPI: 0 = store only (16-bit, fp32 (+ accumulate), split-K slab); 1 = bias + forward activation (+ side output);
+//      2 = source-tensor epilogues (ReLU mask, addend, stored derivative, GELU' / tanh' of a stored value) (+ column sums)
+// ACT: the epilogue's activation / source operation, a compile-time constant (one switch per 16 elements per block per flavour
+// made the EPI 2 kernel 60 KB of code: its epilogue ran from the instruction cache misses)
+template <int DT, int AM, int BMD, int EPI, int ACT>
+__global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* lds = (unsigned short*)smem_raw;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;            // group (= row block) / column block; waves w and w + 4 share a SIMD
+  constexpr bool RCA = AM == 1, RCB = BMD == 1;
+  constexpr int NRA = RCA ? 16 : 8;                   // LDS instructions of one A half (8 fragments)
+
+  const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
+  const int ntiles = tiles_m * tiles_n, nitems = ntiles * p.splitk;
+  const int ktiles = p.K / BK;
+  const int GM = p.gm;
+  // item -> (tile, K slice).  Each XCD (private L2) owns a contiguous chunk of the item list; inside it, tiles are ordered in
+  // groups of GM tile rows walked column by column (gemm_dma.hip: tile_coords), K slices slowest.
+  auto decode = [&](int vb, int& m0, int& n0, int& kt0, int& kt1, int& ky) __attribute__((always_inline)) {
+    const int q = nitems >> 3, r8 = nitems & 7, xcd = vb & 7, loc = vb >> 3;
+    int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+    ky = fd_div(id, p.d_ntiles);
+    id -= ky * ntiles;
+    const int per_group = GM * tiles_n;
+    const int g = fd_div(id, p.d_group), r = id - g * per_group;
+    const bool last = (tiles_m - g * GM) < GM;          // the last, shorter group of tile rows
+    const int rows = last ? (tiles_m - g * GM) : GM;
+    const int tn = last ? fd_div(r, p.d_rows_last) : fd_div(r, p.d_rows_full), tm = g * GM + (r - tn * rows);
+    m0 = tm << 8;
+    n0 = tn << 8;
+    kt0 = fd_div(ky * ktiles, p.d_splitk);              // (splitk * ktiles < 2^31: launcher)
+    kt1 = fd_div((ky + 1) * ktiles, p.d_splitk);
+  };
+
+  G8Lane<AM> la;
+  G8Lane<BMD> lb;
+  la.init(wave, lane, p.lda);
+  lb.init(wave, lane, p.ldb);
+
+  // ---- the operand stream: ONE cursor walks (item, K tile, half-tile) in consumption order B0, A0, B1, A1 -----------------
+  int c_item = blockIdx.x, c_par = 0, c_m0 = 0, c_n0 = 0, c_k0 = 0, c_kend = 0;
+  bool c_valid = false;
+  auto cursor_load = [&]() __attribute__((always_inline)) {
+    c_valid = c_item < nitems;
+    if (c_valid) {
+      int kt0, kt1, ky;
+      decode(c_item, c_m0, c_n0, kt0, kt1, ky);
+      c_k0 = kt0 * BK;
+      c_kend = kt1 * BK;
+    } else {
+      c_k0 = 0;
+      c_kend = 0x7FFFFFFF;              // past the last item: every piece is out of range (zero-fills an idle half-tile)
+    }
+  };
+  auto cursor_next = [&]() __attribute__((always_inline)) {
+    c_par ^= 1;
+    c_k0 += BK;
+    if (c_k0 >= c_kend) {
+      c_item += (int)gridDim.x;
+      cursor_load();
+    }
+  };
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(lds_void*)lds;      // LDS byte address of the stages (M0 of the DMA)
+  // piece J (0 / 1) of this wavefront's share of half-tile HF of operand OP at the cursor
+  auto stage_piece = [&](auto OPC, auto HFC, auto JC) __attribute__((always_inline)) {
+    constexpr int OP = decltype(OPC)::value, HF = decltype(HFC)::value, j = decltype(JC)::value;
+    constexpr int MODE = OP == 0 ? AM : BMD;
+    const int R0 = (OP == 0 ? c_m0 : c_n0) + HF * 128;
+    const int nrows = OP == 0 ? p.M : p.N;
+    const unsigned ld = (unsigned)(OP == 0 ? p.lda : p.ldb);
+    // byte offset of the half-tile's first element; 32-bit by the launcher's extent check ((rows + 256) * pitch * 2 < 2^32)
+    const unsigned sb = (MODE == 0 ? (unsigned)R0 * ld + (unsigned)c_k0 : (unsigned)c_k0 * ld + (unsigned)R0) * 2u;
+    const unsigned total = OP == 0 ? p.a_bytes : p.b_bytes;
+    const unsigned nrec = (c_valid && sb < total) ? total - sb : 0u;
+    const unsigned long long base = (unsigned long long)(OP == 0 ? p.A : p.B) + sb;
+    int4v_t rs;
+    rs.x = (int)(unsigned)base;
+    rs.y = (int)(unsigned)(base >> 32);
+    rs.z = (int)nrec;
+    rs.w = 0x00020000;
+    const unsigned dst = lds0 + (unsigned)(c_par * G8_BUF + (OP == 0 ? 0 : 2 * G8_HALF) + HF * G8_HALF + wave * 1024) * 2u;
+    unsigned vo;
+    if constexpr (OP == 0) vo = (MODE == 0 || R0 + la.c8[j] < nrows) ? la.voff[j] : OOB_OFF;
+    else vo = (MODE == 0 || R0 + lb.c8[j] < nrows) ? lb.voff[j] : OOB_OFF;
+    g8_dma(rs, dst + j * 1024, vo);
+  };
+  auto stage = [&](auto OPC, auto HFC) __attribute__((always_inline)) {
+    stage_piece(OPC, HFC, std::integral_constant<int, 0>());
+    stage_piece(OPC, HFC, std::integral_constant<int, 1>());
+  };
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+
+  // prologue: the first two K tiles (all 8 half-tile slots); K tile 0 has landed when 8 pieces are left in flight
+  cursor_load();
+  stage(I1(), I0()); stage(I0(), I0()); stage(I1(), I1()); stage(I0(), I1());
+  cursor_next();
+  stage(I1(), I0()); stage(I0(), I0()); stage(I1(), I1()); stage(I0(), I1());
+  cursor_next();
+  G8_VM(8);
+  G8_BARRIER();
+  if (wr == 1) G8_BARRIER();            // the stagger: group 1 runs one barrier behind group 0 from here on
+
+  float16_t acc[2][2][2];               // [A half][B half][32-row block]
+  typename FragT<RCA>::type fa[2][4];   // one A half: [32-row block][k-step]
+  typename FragT<RCB>::type fb0[4], fb1[4];
+
+  // DMAM: where a phase's two DMA pieces are issued.  0: beside its LDS reads (k-contiguous A: ds_read_b128 fragments are
+  // cheap, the MFMA stream stays bare); 1: behind the 2nd and the 5th MFMA of the phase (row-contiguous A: 24 transpose reads
+  // in phase 0 -- the read side is the long one; measured -10 % cycles on the weight-gradient layout, +5 % on the forward one).
+  constexpr int DMAM = G8_DMA_IN_MMA >= 0 ? G8_DMA_IN_MMA : (RCA ? 1 : 0);
+  constexpr int VMW = DMAM ? 4 : 6;     // pieces in flight behind the K tile that phase 3 waits for
+
+  // the 8 MFMAs of one phase (+ its DMA pieces when DMAM; STG: this phase has a half-tile to issue)
+  auto mma = [&](auto IC, auto JC, auto& fbx, auto SOP, auto SHF, auto STG, auto ZC) __attribute__((always_inline)) {
+    constexpr int i = decltype(IC)::value, j = decltype(JC)::value;
+    constexpr bool stg = DMAM && decltype(STG)::value;
+    constexpr bool zc = decltype(ZC)::value;            // the item's first K tile: the first k-step starts from zero
+    const float16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        acc[i][j][b] = Mfma32x16<DT>::run(frag_value(fbx[ks]), frag_value(fa[b][ks]), (zc && ks == 0) ? zero : acc[i][j][b]);
+        if constexpr (stg) {
+          if (ks * 2 + b == G8_DMA_SLOT0) { G8_SB(); stage_piece(SOP, SHF, I0()); G8_SB(); }
+          if (ks * 2 + b == G8_DMA_SLOT1) { G8_SB(); stage_piece(SOP, SHF, I1()); G8_SB(); }
+        }
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // One K tile = four phases; each phase: {fragment reads | one half-tile of DMA} barrier {8 MFMAs} barrier.
+  // The stream, in issue order: ... A1(t+1) [phase 0 of K tile t], B0(t+2) [1], A0(t+2) [2], B1(t+2) [3], A1(t+2) ...
+  // RAW (DMA -> ds_read): every half-tile of K tile t + 1 was issued no later than phase 0 of tile t; each wavefront waits for
+  //   its own pieces with a counted vmcnt in phase 3 BEFORE that phase's first barrier (the half-tiles issued in phases 1-3
+  //   stay in flight); group 1's wait precedes the barrier that is group 0's SECOND barrier of phase 3, so both groups read
+  //   tile t + 1 only after every wavefront's wait.
+  // WAR (ds_read -> restage): B0 is read in phase 0 and restaged in phase 1: its reads are issued first and retired by the
+  //   counted lgkmcnt before phase 0's first barrier (the other group passes that barrier before it can issue phase 1);
+  //   A0 (read in phase 0, restaged in phase 2), B1 (1 -> 3) and A1 (2 -> next phase 0) have two phases in between, and
+  //   their reads are complete (lgkmcnt(0) after the first barrier) one full phase before any wavefront restages them.
+  // FIRST K tile of an item: A1(t+1) was issued BEFORE the previous item's epilogue stores (it is the one half-tile slot that
+  //   is free at the end of a K tile), so everything phase 3 waits for is OLDER than those stores: the wait leaves them in
+  //   flight (vmcnt retires in order; st_keep = a lower bound of the store instructions each wavefront issued).  The next
+  //   wait that needs them gone is phase 3 of the item's SECOND K tile, ~7 phases after they were issued.
+  auto ktile = [&](int cpar, auto FIRSTC, auto ZEROC, bool st_keep) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(FIRSTC)::value;
+    typedef std::integral_constant<bool, !FIRST> P0STG;
+    typedef std::integral_constant<bool, true> YES;
+    typedef decltype(ZEROC) ZC;
+    const unsigned short* bufc = lds + cpar * G8_BUF;
+    // ---- phase 0: C00 += A0 B0 | stream: A1 of the cursor's K tile (then the cursor moves on)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb0[ks] = g8_frag<BMD, true>(bufc + 2 * G8_HALF, wc * 32, ks, lane);
+    G8_SB();
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fa[b][ks] = g8_frag<AM, false>(bufc, wr * 64 + b * 32, ks, lane);
+    G8_SB();
+    if constexpr (!DMAM && !FIRST) {
+      stage(I0(), I1());
+      cursor_next();
+    }
+    G8_LGKM(NRA < 15 ? NRA : 15);
+    G8_BARRIER();
+    G8_LGKM(0);
+    mma(I0(), I0(), fb0, I0(), I1(), P0STG(), ZC());
+    if constexpr (DMAM && !FIRST) cursor_next();
+    G8_BARRIER();
+    // ---- phase 1: C01 += A0 B1 | stream: B0
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb1[ks] = g8_frag<BMD, true>(bufc + 3 * G8_HALF, wc * 32, ks, lane);
+    G8_SB();
+    if constexpr (!DMAM) stage(I1(), I0());
+    G8_BARRIER();
+    G8_LGKM(0);
+    mma(I0(), I1(), fb1, I1(), I0(), YES(), ZC());
+    G8_BARRIER();
+    // ---- phase 2: C11 += A1 B1 | stream: A0
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fa[b][ks] = g8_frag<AM, false>(bufc + G8_HALF, wr * 64 + b * 32, ks, lane);
+    G8_SB();
+    if constexpr (!DMAM) stage(I0(), I0());
+    G8_BARRIER();
+    G8_LGKM(0);
+    mma(I1(), I1(), fb1, I0(), I0(), YES(), ZC());
+    G8_BARRIER();
+    // ---- phase 3: C10 += A1 B0 (B0 still in registers) | stream: B1; the next K tile has landed
+    if constexpr (!DMAM) stage(I1(), I1());
+    if (FIRST && st_keep) G8_VM(VMW + G8_ST_KEEP);
+    else G8_VM(VMW);
+    G8_BARRIER();
+    mma(I1(), I0(), fb0, I1(), I1(), YES(), ZC());
+    G8_BARRIER();
+  };
+
+  const int fr = lane & 31, fh = lane >> 5;
+  int cpar = 0;
+  bool st_keep = false;
+#ifdef G8_TIMING
+  int item_seq = 0;
+#endif
+  for (int it = blockIdx.x; it < nitems; it += (int)gridDim.x) {
+    int m0, n0, kt0, kt1, ky;
+    decode(it, m0, n0, kt0, kt1, ky);
+    G8_STAMP(0);
+    const bool interior = m0 + 256 <= p.M && n0 + 256 <= p.N;
+    // EPI 1, interior tile, alpha = 1: the accumulators START from the bias row (scalar loads: the vector-memory queue, which
+    // retires in order and is full of the stream's pieces, is not involved); otherwise the first K tile starts from zero
+    // inside its first MFMAs.
+    bool bias_in_acc = false;
+    if constexpr (EPI == 1) bias_in_acc = interior && p.bias != nullptr && p.alpha == 1.0f;
+    if (EPI == 1 && bias_in_acc) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float* bp = p.bias + (n0 + j * 128 + wc * 32);          // wave-uniform address: s_load
+        float16_t bv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = fh ? bp[16 + r] : bp[r];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[i][j][b] = bv;
+      }
+      ktile(cpar, std::integral_constant<bool, true>(), std::integral_constant<bool, false>(), st_keep);
+    } else {
+      ktile(cpar, std::integral_constant<bool, true>(), std::integral_constant<bool, true>(), st_keep);
+    }
+    cpar ^= 1;
+    for (int kt = kt0 + 1; kt < kt1; ++kt) {
+#ifdef G8_TIMING_KT
+      if (item_seq == G8_TIMING_KT && kt - kt0 < 60 && (wave & 3) == 0 && lane == 0 && p.dbg)
+        p.dbg[((((long long)blockIdx.x * 2 + wr) * p.dbg_items) + p.dbg_items - 16) * 4 + (kt - kt0)] = __builtin_readcyclecounter();
+#endif
+      ktile(cpar, std::integral_constant<bool, false>(), std::integral_constant<bool, false>(), false);
+      cpar ^= 1;
+    }
+    // the one half-tile slot that is free now (A1 of the K tile just finished) is refilled BEFORE the stores below
+    stage(I0(), I1());
+    cursor_next();
+    st_keep = interior;                                // interior tile: every store instruction below is issued
+    G8_STAMP(1);
+
+    // ---- epilogue, in the accumulator layout: lane (fr, fh) of block (i, j, b) owns row m0 + 128 i + 64 wr + 32 b + fr,
+    // columns n0 + 128 j + 32 wc + 16 fh .. + 15
+    float st[2][16];                               // column sums of the rounded output over this lane's rows (EPI 2, p.stats)
+    if constexpr (EPI == 2) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[j][r] = 0.f;
+    }
+    // Interior tile, 16-bit output (every flavour) or fp32 output (plain / slab): no per-lane predicate, no 64-bit address
+    // arithmetic -- a lane's byte offset inside the tile is a constant (rows fr, columns 16 fh), the block's position is a
+    // scalar offset of the buffer instruction; the source tensor of EPI 2 is requested for all 8 blocks before the first use.
+    const bool fastpath = interior && p.alpha == 1.0f && p.c_bytes != 0 &&
+                          (p.out_dtype != DLE_F32 ? true : (EPI == 0 && !(p.accumulate && !p.ws)));
+    if (fastpath) {
+      const bool f32o = p.out_dtype == DLE_F32;
+      const unsigned esz = f32o ? 4u : 2u;
+      const unsigned pitch = (unsigned)((EPI == 0 && p.ws) ? p.N : (int)p.ldc) * esz;      // bytes per row
+      const unsigned lane_off = (unsigned)fr * pitch + (unsigned)fh * 16u * esz;
+      const void* cbase = (EPI == 0 && p.ws) ? (const void*)(p.ws + (long long)ky * p.M * p.N) : (const void*)p.C;
+      __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cbase, 0, (int)p.c_bytes, 0x00020000);
+      auto blk_off = [&](int i, int j, int b) __attribute__((always_inline)) {
+        return (unsigned)(m0 + i * 128 + wr * 64 + b * 32) * pitch + (unsigned)(n0 + j * 128 + wc * 32) * esz;
+      };
+      if (f32o) {
+        if constexpr (EPI == 0) {
+          static_for<0, 8>([&](auto BI) __attribute__((always_inline)) {
+            constexpr int bi = decltype(BI)::value, i = bi >> 2, j = (bi >> 1) & 1, b = bi & 1;
+            const unsigned so = blk_off(i, j, b);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4_t v = {acc[i][j][b][4 * q], acc[i][j][b][4 * q + 1], acc[i][j][b][4 * q + 2], acc[i][j][b][4 * q + 3]};
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v), rc, lane_off + 16 * q, so, 0);
+            }
+          });
+        }
+      } else {
+        ushort8_t sv[EPI == 2 ? 8 : 1][2];
+        if constexpr (EPI == 2) {
+          __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)p.c_bytes, 0x00020000);
+          static_for<0, 8>([&](auto BI) __attribute__((always_inline)) {
+            constexpr int bi = decltype(BI)::value, i = bi >> 2, j = (bi >> 1) & 1, b = bi & 1;
+            const unsigned so = blk_off(i, j, b);
+            sv[bi][0] = __builtin_bit_cast(ushort8_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, lane_off, so, 0));
+            sv[bi][1] = __builtin_bit_cast(ushort8_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, lane_off + 16, so, 0));
+          });
+        }
+        __amdgpu_buffer_rsrc_t ra = rc;
+        if constexpr (EPI == 1) { if (p.aux) ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.aux, 0, (int)p.c_bytes, 0x00020000); }
+        static_for<0, 8>([&](auto BI) __attribute__((always_inline)) {
+          constexpr int bi = decltype(BI)::value, i = bi >> 2, j = (bi >> 1) & 1, b = bi & 1;
+          const unsigned so = blk_off(i, j, b);
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = acc[i][j][b][r];
+          if constexpr (EPI == 1) {
+            if (p.bias && !bias_in_acc) {                 // (alpha == 1 here: only reached without a bias row in the accumulators)
+              const float* bp = p.bias + (n0 + j * 128 + wc * 32);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) v[r] += fh ? bp[16 + r] : bp[r];
+            }
+            float side[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) side[r] = v[r];
+            if (ACT == ACT_RELU) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+            } else if (ACT == ACT_GELU) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) v[r] = g8_gelu(v[r]);
+            } else if (ACT == ACT_TANH) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) v[r] = fast_tanh(v[r]);
+            } else if (ACT == ACT_GELU_DAUX) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) v[r] = g8_gelu_d(v[r], side[r]);
+            }
+            if (p.aux) {
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, pack8<DT>(side)), ra, lane_off, so, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, pack8<DT>(side + 8)), ra, lane_off + 16, so, 0);
+            }
+          } else if constexpr (EPI == 2) {
+            float y[16];
+            unpack8<DT>(sv[bi][0], y);
+            unpack8<DT>(sv[bi][1], y + 8);
+            if (ACT == ACT_RELU_BWD) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) v[r] = y[r] > 0.f ? v[r] : 0.f;
+            } else if (ACT == ACT_ADD) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) v[r] += y[r];
+            } else if (ACT == ACT_MUL) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) v[r] *= y[r];
+            } else if (ACT == ACT_TANH_BWD) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) v[r] *= (1.f - y[r] * y[r]);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                float d;
+                g8_gelu_d(y[r], d);
+                v[r] *= d;
+              }
+            }
+          }
+          const ushort8_t o0 = pack8<DT>(v), o1 = pack8<DT>(v + 8);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o0), rc, lane_off, so, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o1), rc, lane_off + 16, so, 0);
+          if constexpr (EPI == 2) {
+            if (p.stats) {
+              float vr[16];
+              unpack8<DT>(o0, vr);
+              unpack8<DT>(o1, vr + 8);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) st[j][r] += vr[r];
+            }
+          }
+        });
+      }
+    } else
+    static_for<0, 8>([&](auto BI) __attribute__((always_inline)) {
+      constexpr int bi = decltype(BI)::value, i = bi >> 2, j = (bi >> 1) & 1, b = bi & 1;
+      const int m = m0 + i * 128 + wr * 64 + b * 32 + fr;
+      const int n = n0 + j * 128 + wc * 32 + fh * 16;
+      if (m < p.M && n < p.N) {
+        const bool hi_ok = n + 8 < p.N;            // N is a multiple of 8: each 8-column group is entirely in or out
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[i][j][b][r];
+        if (p.alpha != 1.0f) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] *= p.alpha;
+        }
+        if (EPI == 0 && p.ws) {                    // split-K partial -> fp32 slab
+          float* c = p.ws + ((long long)ky * p.M + m) * p.N + n;
+          *(float4_t*)c = (float4_t){v[0], v[1], v[2], v[3]};
+          *(float4_t*)(c + 4) = (float4_t){v[4], v[5], v[6], v[7]};
+          if (hi_ok) {
+            *(float4_t*)(c + 8) = (float4_t){v[8], v[9], v[10], v[11]};
+            *(float4_t*)(c + 12) = (float4_t){v[12], v[13], v[14], v[15]};
+          }
+        } else {
+          const long long off = (long long)m * p.ldc + n;
+          if (EPI == 1 && p.bias && !bias_in_acc) {
+            const float4_t b0 = *(const float4_t*)(p.bias + n), b1 = *(const float4_t*)(p.bias + n + 4);
+            float4_t b2 = {0.f, 0.f, 0.f, 0.f}, b3 = {0.f, 0.f, 0.f, 0.f};
+            if (hi_ok) { b2 = *(const float4_t*)(p.bias + n + 8); b3 = *(const float4_t*)(p.bias + n + 12); }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] += b0[r]; v[4 + r] += b1[r]; v[8 + r] += b2[r]; v[12 + r] += b3[r]; }
+          }
+          if (p.out_dtype == DLE_F32) {            // (EPI 0 / 1 with act none: checked by the launcher)
+            float* c = (float*)p.C + off;
+            if (p.accumulate) {
+              const float4_t c0 = *(const float4_t*)c, c1 = *(const float4_t*)(c + 4);
+              float4_t c2 = {0.f, 0.f, 0.f, 0.f}, c3 = {0.f, 0.f, 0.f, 0.f};
+              if (hi_ok) { c2 = *(const float4_t*)(c + 8); c3 = *(const float4_t*)(c + 12); }
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { v[r] += c0[r]; v[4 + r] += c1[r]; v[8 + r] += c2[r]; v[12 + r] += c3[r]; }
+            }
+            *(float4_t*)c = (float4_t){v[0], v[1], v[2], v[3]};
+            *(float4_t*)(c + 4) = (float4_t){v[4], v[5], v[6], v[7]};
+            if (hi_ok) {
+              *(float4_t*)(c + 8) = (float4_t){v[8], v[9], v[10], v[11]};
+              *(float4_t*)(c + 12) = (float4_t){v[12], v[13], v[14], v[15]};
+            }
+          } else {
+            float side[16];
+            bool has_side = false;
+            if constexpr (EPI == 1) {
+              has_side = p.aux != nullptr;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) side[r] = v[r];           // pre-activation
+              if (ACT == ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+              } else if (ACT == ACT_GELU) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = g8_gelu(v[r]);
+              } else if (ACT == ACT_TANH) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fast_tanh(v[r]);
+              } else if (ACT == ACT_GELU_DAUX) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = g8_gelu_d(v[r], side[r]);   // side = the derivative
+              }
+            } else if constexpr (EPI == 2) {
+              const unsigned short* s = p.src + off;
+              ushort8_t s0 = *(const ushort8_t*)s, s1 = {0, 0, 0, 0, 0, 0, 0, 0};
+              if (hi_ok) s1 = *(const ushort8_t*)(s + 8);
+              float y[16];
+              unpack8<DT>(s0, y);
+              unpack8<DT>(s1, y + 8);
+              if (ACT == ACT_RELU_BWD) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = y[r] > 0.f ? v[r] : 0.f;
+              } else if (ACT == ACT_ADD) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += y[r];
+              } else if (ACT == ACT_MUL) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] *= y[r];
+              } else if (ACT == ACT_TANH_BWD) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] *= (1.f - y[r] * y[r]);
+              } else {                                               // ACT_GELU_BWD: y = the pre-activation
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                  float d;
+                  g8_gelu_d(y[r], d);
+                  v[r] *= d;
+                }
+              }
+            }
+            const ushort8_t o0 = pack8<DT>(v), o1 = pack8<DT>(v + 8);
+            unsigned short* c = (unsigned short*)p.C + off;
+            *(ushort8_t*)c = o0;
+            if (hi_ok) *(ushort8_t*)(c + 8) = o1;
+            if (EPI == 1 && has_side) {
+              unsigned short* a = (unsigned short*)p.aux + off;
+              *(ushort8_t*)a = pack8<DT>(side);
+              if (hi_ok) *(ushort8_t*)(a + 8) = pack8<DT>(side + 8);
+            }
+            if constexpr (EPI == 2) {
+              if (p.stats) {
+                float vr[16];
+                unpack8<DT>(o0, vr);
+                unpack8<DT>(o1, vr + 8);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[j][r] += (r < 8 || hi_ok) ? vr[r] : 0.f;
+              }
+            }
+          }
+        }
+      }
+    });
+    if constexpr (EPI == 2) {
+      if (p.stats) {
+        // the 32 row lanes of a column group reduce-scatter their 16 sums: after the xor-16 / 8 / 4 / 2 exchanges a lane keeps
+        // ONE column (index = bits 4..1 of fr), the xor-1 exchange completes it; even lanes store.  One partial row per
+        // (tile row, wavefront row group), folded in a fixed order by colsum_fold_kernel.
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float a8[8], a4[4], a2[2], a1;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const bool up = (fr & 16) != 0;
+            const float keep = up ? st[j][8 + r] : st[j][r], send = up ? st[j][r] : st[j][8 + r];
+            a8[r] = keep + __shfl_xor(send, 16, 64);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool up = (fr & 8) != 0;
+            const float keep = up ? a8[4 + r] : a8[r], send = up ? a8[r] : a8[4 + r];
+            a4[r] = keep + __shfl_xor(send, 8, 64);
+          }
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const bool up = (fr & 4) != 0;
+            const float keep = up ? a4[2 + r] : a4[r], send = up ? a4[r] : a4[2 + r];
+            a2[r] = keep + __shfl_xor(send, 4, 64);
+          }
+          {
+            const bool up = (fr & 2) != 0;
+            const float keep = up ? a2[1] : a2[0], send = up ? a2[0] : a2[1];
+            a1 = keep + __shfl_xor(send, 2, 64);
+          }
+          a1 += __shfl_xor(a1, 1, 64);
+          const int col = n0 + j * 128 + wc * 32 + fh * 16 + ((fr >> 1) & 15);
+          if ((fr & 1) == 0 && col < p.N) p.stats[((long long)((m0 >> 8) * 2 + wr)) * p.N + col] = a1;
+        }
+      }
+    }
+#ifdef G8_TIMING
+    G8_STAMP(2);
+    ++item_seq;
+#endif
+  }
+  if (wr == 0) G8_BARRIER();            // pairs with group 1's last barrier
+  G8_VM(0);                             // the idle pieces of the stream's tail
+}
+
+
+template <int DT, int AM, int BMD, int EPI, int ACT>
+static void g8_launch(const Gemm8Args& p, int grid, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm8_kernel<DT, AM, BMD, EPI, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm8_kernel<DT, AM, BMD, EPI, ACT>), dim3(grid), dim3(512), G8_LDS_BYTES, stream, p);
+}

@@ -939,6 +939,10 @@ static bool launch_splitk_reduce_shallow(const float* ws, float* C, int M, int N
   return true;
 }
 
+extern "C" int dle_gemm8_try(const void* A, const void* B, void* C, void* aux, const float* bias, const void* src, int M, int N,
+                             int K, int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc, int in_dtype, int out_dtype,
+                             int act, int splitk, int accumulate, float alpha, float* ws, float* stats, hipStream_t stream);   // gemm8.hip
+
 // Returns 1 when the DMA kernel took the launch, 0 when the shape/alignment is outside its envelope
 // (caller falls back to gemm.hip), <0 / >1 on error.  Called from dle_gemm.
 extern "C" int dle_gemm_dma_try(const void* A, const void* B, void* C, void* aux, const float* bias,
@@ -973,7 +977,15 @@ extern "C" int dle_gemm_dma_try(const void* A, const void* B, void* C, void* aux
   }
   const int amode = a_kc ? 0 : 1, bmode = b_kc ? 0 : 1;
   if (!a_kc && b_kc) return 0;
-  { const int rc = launch_gemm(p, in_dtype, amode, bmode, 0, stream); if (rc) return rc + 1000; }
+  {
+    // the big linear layers: the persistent eight-phase kernel of gemm8.hip (split-K only with slabs)
+    int r8 = 0;
+    if (splitk == 1 || p.ws)
+      r8 = dle_gemm8_try(A, B, C, aux, bias, mask_src, M, N, K, lda, ldb, ldc, a_kc, b_kc, in_dtype, out_dtype, act, splitk,
+                         accumulate, alpha, p.ws, nullptr, stream);
+    if (r8 > 1) return r8;
+    if (r8 == 0) { const int rc = launch_gemm(p, in_dtype, amode, bmode, 0, stream); if (rc) return rc + 1000; }
+  }
   if (p.ws) {
     long long items = ((long long)M * N + 3) / 4;
     long long g = ((N & 3) == 0 && (ldc & 3) == 0) ? (items + 15) / 16 : (items + 63) / 64;
@@ -1042,7 +1054,14 @@ extern "C" int dle_gemm_colsum(const void* A, const void* B, void* C, const void
   p.cg = make_geom(1, 1, 1, 1, 1, 1, 1, 1, 0, 1);
   p.stats = (float*)workspace; p.stats_sums = 1;
   int tile_rows = 0;
-  { const int rc = launch_gemm(p, dtype, 0, 1, 0, stream, &tile_rows); if (rc) return rc + 1000; }
+  {
+    // eight-phase kernel: two partial rows per 256-row tile row (one per wavefront row group) = ceil(M / 128) rows when 256 | M
+    const int r8 = dle_gemm8_try(A, B, C, nullptr, nullptr, mask_src, M, N, K, lda, ldb, ldc, 1, 0, dtype, dtype, act, 1, 0, 1.0f,
+                                 nullptr, (float*)workspace, stream);
+    if (r8 > 1) return r8;
+    if (r8 == 1) tile_rows = 128;
+    else { const int rc = launch_gemm(p, dtype, 0, 1, 0, stream, &tile_rows); if (rc) return rc + 1000; }
+  }
   hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, (const float*)workspace, colsum_out, N,
                      (M + tile_rows - 1) / tile_rows, accumulate_colsum);
   hipError_t e = hipGetLastError();
