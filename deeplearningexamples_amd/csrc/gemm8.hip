@@ -53,7 +53,8 @@ extern "C" int dle_gemm8_try(const void* A, const void* B, void* C, void* aux, c
     if (!ws || out_dtype != DLE_F32 || bias || act != ACT_NONE || aux || stats) return 0;
     epi = 0;
   } else if (act == ACT_RELU_BWD || act == ACT_ADD || act == ACT_MUL || act == ACT_GELU_BWD || act == ACT_TANH_BWD) {
-    if (!src || bias || aux || out_dtype != in_dtype || accumulate) return 0;
+    if (!src || bias || aux || out_dtype != in_dtype || accumulate || alpha != 1.0f) return 0;
+    if ((long long)(M + 256) * ldc * 2 >= 0xFFFFFFFFLL) return 0;      // 32-bit byte offsets of the range-checked source loads
     if (stats && !(act == ACT_RELU_BWD || act == ACT_MUL)) return 0;
     if (stats && (M & 255) != 0) return 0;
     epi = 2;

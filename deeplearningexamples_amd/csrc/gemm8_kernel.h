@@ -117,6 +117,41 @@ __device__ __forceinline__ typename FragT<MODE == 1>::type g8_frag(const unsigne
   else return g8_frag_rc<PERM>(t, rbase32, ks, lane);
 }
 
+// Transpose reads with IMMEDIATE offsets: the swizzle term (k & 3) of a lane's address is the same for every k-step and for
+// both 64-bit halves of a fragment, so all 8 reads of a 32-row block are lane base + {k-step * 4096 + half * 1024} bytes, and
+// the half-tile's position inside the K tile buffer is a constant too: one address register per block (two for A, one for B)
+// instead of one VALU add in front of every read (48 per K tile on the weight-gradient layout, whose read side is the long one).
+template <bool PERM>
+__device__ __forceinline__ unsigned g8_tr_lane_base(int rbase32, int lane) {
+  const int tg = lane >> 4, ti = lane & 15;
+  const int kb = (tg >> 1) * 8 + (ti >> 2);
+  int chunk, sub;
+  if (!PERM) {
+    const int rbase = rbase32 + ((tg & 1) << 4);
+    chunk = (rbase >> 3) + ((ti & 3) >> 1);
+    sub = (ti & 1) << 2;
+  } else {
+    const int c = ti & 3;
+    chunk = (rbase32 >> 3) + 2 * (c & 1) + (tg & 1);
+    sub = (c >> 1) << 2;
+  }
+  const int cpos = (((chunk >> 1) ^ swz_rc<128>(kb)) << 1) | (chunk & 1);
+  return (unsigned)(kb * 128 + cpos * 8 + sub) * 2u;
+}
+template <int OFF>
+__device__ __forceinline__ short4_t g8_tr_read(unsigned addr) {
+  short4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int IMG, int KS>
+__device__ __forceinline__ TrPair g8_frag_rc_imm(unsigned base) {
+  TrPair f;
+  f.lo = g8_tr_read<IMG + KS * 4096>(base);
+  f.hi = g8_tr_read<IMG + KS * 4096 + 1024>(base);
+  return f;
+}
+
 // one LDS-DMA piece (1 KiB per wavefront) to LDS byte address m0v; hidden from hipcc's wait-count pass like dma16_raw
 __device__ __forceinline__ void g8_dma(int4v_t rs, unsigned m0v, unsigned voff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(m0v), "v"(voff), "s"(rs) : "memory");
@@ -293,6 +328,42 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     __builtin_amdgcn_s_setprio(0);
   };
 
+  // row-contiguous operands: a lane's first transpose-read address inside a half-tile image (bytes)
+  unsigned trA0 = 0, trA1 = 0, trB = 0;
+  if constexpr (RCA) { trA0 = g8_tr_lane_base<false>(wr * 64, lane); trA1 = g8_tr_lane_base<false>(wr * 64 + 32, lane); }
+  if constexpr (RCB) trB = g8_tr_lane_base<true>(wc * 32, lane);
+  // fragment reads of one half-tile: H = its index inside the K tile buffer (A0, A1, B0, B1)
+  auto read_a = [&](auto HC, const unsigned short* bufc, unsigned lbase) __attribute__((always_inline)) {
+    constexpr int H = decltype(HC)::value;
+    if constexpr (RCA) {
+      static_for<0, 4>([&](auto KS) __attribute__((always_inline)) {
+        constexpr int ks = decltype(KS)::value;
+        fa[0][ks] = g8_frag_rc_imm<H * G8_HALF * 2, ks>(lbase + trA0);
+      });
+      static_for<0, 4>([&](auto KS) __attribute__((always_inline)) {
+        constexpr int ks = decltype(KS)::value;
+        fa[1][ks] = g8_frag_rc_imm<H * G8_HALF * 2, ks>(lbase + trA1);
+      });
+    } else {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fa[b][ks] = g8_frag_kc<false>(bufc + H * G8_HALF, wr * 64 + b * 32, ks, lane);
+    }
+  };
+  auto read_b = [&](auto HC, auto& fbx, const unsigned short* bufc, unsigned lbase) __attribute__((always_inline)) {
+    constexpr int H = decltype(HC)::value;
+    if constexpr (RCB) {
+      static_for<0, 4>([&](auto KS) __attribute__((always_inline)) {
+        constexpr int ks = decltype(KS)::value;
+        fbx[ks] = g8_frag_rc_imm<H * G8_HALF * 2, ks>(lbase + trB);
+      });
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fbx[ks] = g8_frag_kc<true>(bufc + H * G8_HALF, wc * 32, ks, lane);
+    }
+  };
+
   // One K tile = four phases; each phase: {fragment reads | one half-tile of DMA} barrier {8 MFMAs} barrier.
   // The stream, in issue order: ... A1(t+1) [phase 0 of K tile t], B0(t+2) [1], A0(t+2) [2], B1(t+2) [3], A1(t+2) ...
   // RAW (DMA -> ds_read): every half-tile of K tile t + 1 was issued no later than phase 0 of tile t; each wavefront waits for
@@ -313,14 +384,13 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     typedef std::integral_constant<bool, true> YES;
     typedef decltype(ZEROC) ZC;
     const unsigned short* bufc = lds + cpar * G8_BUF;
+    const unsigned lbase = lds0 + (unsigned)cpar * (G8_BUF * 2u);
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
     // ---- phase 0: C00 += A0 B0 | stream: A1 of the cursor's K tile (then the cursor moves on)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fb0[ks] = g8_frag<BMD, true>(bufc + 2 * G8_HALF, wc * 32, ks, lane);
+    read_b(I2(), fb0, bufc, lbase);
     G8_SB();
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fa[b][ks] = g8_frag<AM, false>(bufc, wr * 64 + b * 32, ks, lane);
+    read_a(I0(), bufc, lbase);
     G8_SB();
     if constexpr (!DMAM && !FIRST) {
       stage(I0(), I1());
@@ -333,8 +403,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     if constexpr (DMAM && !FIRST) cursor_next();
     G8_BARRIER();
     // ---- phase 1: C01 += A0 B1 | stream: B0
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fb1[ks] = g8_frag<BMD, true>(bufc + 3 * G8_HALF, wc * 32, ks, lane);
+    read_b(I3(), fb1, bufc, lbase);
     G8_SB();
     if constexpr (!DMAM) stage(I1(), I0());
     G8_BARRIER();
@@ -342,10 +411,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     mma(I0(), I1(), fb1, I1(), I0(), YES(), ZC());
     G8_BARRIER();
     // ---- phase 2: C11 += A1 B1 | stream: A0
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fa[b][ks] = g8_frag<AM, false>(bufc + G8_HALF, wr * 64 + b * 32, ks, lane);
+    read_a(I1(), bufc, lbase);
     G8_SB();
     if constexpr (!DMAM) stage(I0(), I0());
     G8_BARRIER();
