@@ -81,6 +81,7 @@ _SIGS = {
     "dle_bn_relu_maxpool_fwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dle_wgrad1x1_workspace": (c_i64, []),
     "dle_wgrad1x1_mode": (c_int, [c_int]),
+    "dle_wgrad1x1_workspace_for": (c_i64, [c_int, c_int, c_int]),
     "dle_gemm8_mode": (c_int, [c_int]),
     "dle_wgrad1x1_try": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_i64, c_void_p]),
     "dle_conv3x3_wgrad_workspace": (c_i64, []),
@@ -318,7 +319,8 @@ def set_timer(t):
 
 
 def annotate(**meta):
-    """Attach algorithmic work (bytes=..., flops=..., tag=...) to the NEXT call() when a timer is active."""
+    """Attach algorithmic work (bytes=..., flops=..., tag=...) to the NEXT call() when a timer is active; replay=False marks a
+    launch that is not a pure function of its inputs (it adds into its output): timed, never re-launched by KernelTimer.replay."""
     if _timer is not None:
         _timer.meta = meta
 
@@ -335,7 +337,8 @@ def call(name, *args):
     rc = fn(*args)
     e.record()
     t.records.append((name, s, e, t.meta))
-    t.last[(name, t.meta.get("tag") if t.meta else None)] = (fn, args, torch.cuda.current_stream())
+    if not (t.meta and t.meta.get("replay") is False):      # (replay=False: the launch accumulates into a live buffer)
+        t.last[(name, t.meta.get("tag") if t.meta else None)] = (fn, args, torch.cuda.current_stream())
     t.meta = None
     check(rc, name)
 

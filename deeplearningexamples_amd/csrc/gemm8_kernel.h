@@ -302,10 +302,10 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
   typename FragT<RCA>::type fa[2][4];   // one A half: [32-row block][k-step]
   typename FragT<RCB>::type fb0[4], fb1[4];
 
-  // DMAM: where a phase's two DMA pieces are issued.  0: beside its LDS reads (k-contiguous A: ds_read_b128 fragments are
-  // cheap, the MFMA stream stays bare); 1: behind the 2nd and the 5th MFMA of the phase (row-contiguous A: 24 transpose reads
-  // in phase 0 -- the read side is the long one; measured -10 % cycles on the weight-gradient layout, +5 % on the forward one).
-  constexpr int DMAM = G8_DMA_IN_MMA >= 0 ? G8_DMA_IN_MMA : (RCA ? 1 : 0);
+  // DMAM: where a phase's two DMA pieces are issued.  0 (default): beside its LDS reads, the MFMA stream stays bare; 1: behind
+  // the 2nd and the 5th MFMA of the phase.  Measured (8192^3, cycles per K tile): forward layout 2440 / 2530, data gradient
+  // 2400 / 2680, weight gradient 2670 / 2760 -- 1 only paid while every transpose read carried its own address add.
+  constexpr int DMAM = G8_DMA_IN_MMA > 0 ? 1 : 0;
   constexpr int VMW = DMAM ? 4 : 6;     // pieces in flight behind the K tile that phase 3 waits for
 
   // the 8 MFMAs of one phase (+ its DMA pieces when DMAM; STG: this phase has a half-tile to issue)
@@ -495,6 +495,10 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
       const unsigned lane_off = (unsigned)fr * pitch + (unsigned)fh * 16u * esz;
       const void* cbase = (EPI == 0 && p.ws) ? (const void*)(p.ws + (long long)ky * p.M * p.N) : (const void*)p.C;
       __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cbase, 0, (int)p.c_bytes, 0x00020000);
+      // (the block offset goes into the VECTOR offset of the stores, not into their scalar offset field: with a scalar-register
+      //  soffset hipcc assumes the wide-store data hazard away and may overwrite a store's data registers in the very next
+      //  instruction -- on gfx950 the last data register then reaches memory corrupted: the fp16 GELU side output had garbage in
+      //  every 8th column, a few thousand different elements per run)
       auto blk_off = [&](int i, int j, int b) __attribute__((always_inline)) {
         return (unsigned)(m0 + i * 128 + wr * 64 + b * 32) * pitch + (unsigned)(n0 + j * 128 + wc * 32) * esz;
       };
@@ -506,7 +510,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const float4_t v = {acc[i][j][b][4 * q], acc[i][j][b][4 * q + 1], acc[i][j][b][4 * q + 2], acc[i][j][b][4 * q + 3]};
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v), rc, lane_off + 16 * q, so, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v), rc, lane_off + so + 16 * q, 0, 0);
             }
           });
         }
@@ -552,8 +556,8 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
               for (int r = 0; r < 16; ++r) v[r] = g8_gelu_d(v[r], side[r]);
             }
             if (p.aux) {
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, pack8<DT>(side)), ra, lane_off, so, 0);
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, pack8<DT>(side + 8)), ra, lane_off + 16, so, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, pack8<DT>(side)), ra, lane_off + so, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, pack8<DT>(side + 8)), ra, lane_off + so + 16, 0, 0);
             }
           } else if constexpr (EPI == 2) {
             float y[16];
@@ -581,8 +585,8 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
             }
           }
           const ushort8_t o0 = pack8<DT>(v), o1 = pack8<DT>(v + 8);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o0), rc, lane_off, so, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o1), rc, lane_off + 16, so, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o0), rc, lane_off + so, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o1), rc, lane_off + so + 16, 0, 0);
           if constexpr (EPI == 2) {
             if (p.stats) {
               float vr[16];

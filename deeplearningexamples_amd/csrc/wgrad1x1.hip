@@ -191,6 +191,23 @@ extern "C" int dle_wgrad1x1_mode(int mode) {
 // largest workspace any supported shape needs: 512 workgroups x 256 x 64 x 4 B = 32 MB, 256 x 512 x 128 x 4 B = 64 MB
 extern "C" int64_t dle_wgrad1x1_workspace(void) { return 64LL << 20; }
 
+// workspace of ONE shape (bytes), 0 when (M, Ko, C) is outside the kernel's envelope -- so that a caller does not grow its
+// per-stream scratch to the 64 MB maximum for shapes the kernel declines
+extern "C" int64_t dle_wgrad1x1_workspace_for(int M, int Ko, int C) {
+  static const int env_mode = getenv("DLE_WGRAD1X1") ? atoi(getenv("DLE_WGRAD1X1")) : -1;
+  if (g_w1_mode == 0 || (g_w1_mode < 0 && env_mode == 0)) return 0;
+  if (M < 8192 || (long long)M * (Ko > C ? Ko : C) * 2 >= 0xFFFFFFE0LL) return 0;
+  int tg = 0, wgs = 0;
+#define W1_CFG(KOv, CCv, TGv, WGSv) if (Ko == KOv && C == CCv) { tg = TGv; wgs = WGSv; }
+  W1_CFG(256, 64, 64, 512) W1_CFG(64, 256, 64, 512) W1_CFG(64, 64, 128, 512) W1_CFG(128, 256, 64, 256) W1_CFG(256, 128, 64, 256)
+  W1_CFG(512, 128, 32, 256) W1_CFG(128, 512, 32, 256)
+#undef W1_CFG
+  if (!tg) return 0;
+  const int ntiles = (M + tg - 1) / tg;
+  if (wgs > ntiles) wgs = ntiles;
+  return (int64_t)wgs * Ko * C * 4;
+}
+
 // 1: launched; 0: outside the envelope (the caller uses the split-K tile GEMM); > 1: error.
 extern "C" int dle_wgrad1x1_try(const void* dy, const void* x, float* dw, int M, int Ko, int C, int dtype, int accumulate,
                                 void* workspace, int64_t workspace_bytes, hipStream_t stream) {

@@ -330,7 +330,8 @@ def gemm(a, b, m, n, k, a_kc, b_kc, out=None, out_dtype=None, bias=None, act=C.A
             (float(aux.numel()) * aux.element_size() if aux is not None else 0.0)
     C.annotate(flops=2.0 * m * n * k,
                bytes=float(m * k + n * k) * a.element_size() + float(m * n) * out.element_size() + extra,
-               tag="%dx%dx%d%s%s" % (m, n, k, "+src" if mask_src is not None else "", "+aux" if aux is not None else ""))
+               tag="%dx%dx%d%s%s" % (m, n, k, "+src" if mask_src is not None else "", "+aux" if aux is not None else ""),
+               replay=not accumulate)
     ws = splitk_workspace(a.device, splitk * m * n * 4) if splitk > 1 else None
     C.call("dle_gemm", C.ptr(a), C.ptr(b), C.ptr(out), C.ptr(aux), C.ptr(bias), C.ptr(mask_src), m, n, k,
            lda, ldb, out.stride(0) if out.dim() == 2 else n, int(a_kc), int(b_kc), C.dt(a), C.dt(out), act,
@@ -372,7 +373,8 @@ def gemm_colsum(g, w, m, n, k, src, colsum_out, act=C.ACT_RELU_BWD, accumulate=F
     # (recorded in the family of the GEMM it replaces)
     rc = _timed_optional("dle_gemm", C.lib().dle_gemm_colsum,
                          (C.ptr(g), C.ptr(w), C.ptr(out), C.ptr(src), C.ptr(colsum_out), m, n, k, g.stride(0), w.stride(0),
-                          out.stride(0), C.dt(g), int(act), int(accumulate), C.ptr(ws), ws.numel() * 4, C.stream()))
+                          out.stride(0), C.dt(g), int(act), int(accumulate), C.ptr(ws), ws.numel() * 4, C.stream()),
+                         replayable=not accumulate)
     if rc > 1:
         C.check(rc - 1000 if rc > 1000 else -1, "dle_gemm_colsum")
     return out if rc == 1 else None
@@ -556,9 +558,11 @@ def upsample_zero(compact, in_hw, stride):
     return out
 
 
-def _timed_optional(name, fn, args):
+def _timed_optional(name, fn, args, replayable=True):
     """A C-ABI call that may DECLINE (return 0) cannot go through C.call (which raises on non-zero): run it, and when bench.py's
-    kernel timer is installed record it like C.call does (event pair on the launch stream, replayable) if it launched.  -> rc"""
+    kernel timer is installed record it like C.call does (event pair on the launch stream, replayable) if it launched.  -> rc
+    replayable=False: the launch ADDS into a live buffer (an accumulating bias-gradient / weight-gradient epilogue): it is
+    timed, but KernelTimer.replay must never re-launch it."""
     tm = C._timer
     if tm is None:
         return fn(*args)
@@ -569,7 +573,8 @@ def _timed_optional(name, fn, args):
     meta, tm.meta = tm.meta, None
     if rc == 1:
         tm.records.append((name, s, e, meta))
-        tm.last[(name, meta.get("tag") if meta else None)] = (fn, args, torch.cuda.current_stream())
+        if replayable:
+            tm.last[(name, meta.get("tag") if meta else None)] = (fn, args, torch.cuda.current_stream())
     return rc
 
 
@@ -614,11 +619,15 @@ def wgrad1x1(dy2d, x2d, out, accumulate=False):
     if x2d.shape[0] != m or not dy2d.is_contiguous() or not x2d.is_contiguous() or not out.is_contiguous() or \
             out.numel() != ko * c or out.dtype != torch.float32 or dy2d.dtype != x2d.dtype:
         return False
-    ws = splitk_workspace(dy2d.device, int(C.lib().dle_wgrad1x1_workspace()))
+    need = int(C.lib().dle_wgrad1x1_workspace_for(m, ko, c))     # 0: outside the envelope -- no 64 MB scratch for a declined shape
+    if need == 0:
+        return False
+    ws = splitk_workspace(dy2d.device, need)
     C.annotate(flops=2.0 * m * ko * c, tag="%dx%dx%d" % (ko, c, m), bytes=float(dy2d.numel() + x2d.numel()) * 2 + out.numel() * 4.0)
     # (recorded in the family of the split-K GEMM it replaces: the 1x1 gradients)
     rc = _timed_optional("dle_gemm", C.lib().dle_wgrad1x1_try,
-                         (C.ptr(dy2d), C.ptr(x2d), C.ptr(out), m, ko, c, C.dt(dy2d), int(accumulate), C.ptr(ws), ws.numel() * 4, C.stream()))
+                         (C.ptr(dy2d), C.ptr(x2d), C.ptr(out), m, ko, c, C.dt(dy2d), int(accumulate), C.ptr(ws), ws.numel() * 4, C.stream()),
+                         replayable=not accumulate)
     if rc > 1:
         C.check(rc - 1000 if rc > 1000 else -1, "dle_wgrad1x1_try")
     return rc == 1
@@ -924,14 +933,16 @@ def bn_bwd_conv1x1_dgrad(dy, x, mean, rstd, gamma, dgamma, dbeta, w, relu_mask=N
     bnred = (t2 [.., N], bits2, mean2, rstd2, dgamma2, dbeta2): dx is the gradient that enters a second BatchNorm (bn2 of the
     bottleneck, behind a ReLU with keep bits bits2); its backward reduction is taken from dx in the same kernel and left in
     dgamma2 / dbeta2 (the caller's second unit then skips its own first pass).
-    -> (dt, dx [m, N]) or None outside the kernel's envelope (nothing has been launched then: run bn_bwd + gemm)."""
+    -> (dt, dx [m, N], bnred taken) or None outside the kernel's envelope (nothing has been launched then: run bn_bwd + gemm)
+    or the string "reduced" (the kernel declined AFTER the reduction was launched: run bn_bwd with reduce_done=True + gemm)."""
     C.require_cuda(dy, x, mean, rstd, gamma, dgamma, dbeta, w, relu_mask)
     k = x.shape[-1]
     m = x.numel() // k
     n = w.shape[-1]
     if (m < 4096 or k != 256 or n != 64 or w.numel() != k * n or not (dy.is_contiguous() and x.is_contiguous() and w.is_contiguous())
             or x.dtype not in (torch.float16, torch.bfloat16) or dy.dtype != x.dtype or w.dtype != x.dtype
-            or os.environ.get("DLE_CONV_BNBWD", "1") == "0"):
+            or os.environ.get("DLE_CONV_BNBWD", "1") == "0"
+            or any(t is not None and t.data_ptr() % 16 for t in (dy, x, w, relu_mask))):     # (a view with a storage offset)
         return None
     ws = _bn_ws(x.reshape(m, k))
     act_bytes = 0.125 if relu_mask is not None else 0.0
@@ -955,8 +966,12 @@ def bn_bwd_conv1x1_dgrad(dy, x, mean, rstd, gamma, dgamma, dbeta, w, relu_mask=N
                          (C.ptr(dy), C.ptr(x), C.ptr(relu_mask), C.ptr(w), C.ptr(dt), C.ptr(dx), C.ptr(mean), C.ptr(rstd),
                           C.ptr(gamma), C.ptr(dgamma), C.ptr(dbeta), C.ptr(t2), C.ptr(bits2), C.ptr(mean2), C.ptr(rstd2),
                           C.ptr(part), part.numel() * 4 if part is not None else 0, m, n, k, C.dt(x), C.stream()))
+    if rc > 1:
+        C.check(rc - 1000 if rc > 1000 else -1, "dle_conv1x1_bnbwd_dgrad")
     if rc != 1:
-        C.check(rc - 1000 if rc > 1000 else -1, "dle_conv1x1_bnbwd_dgrad")       # (the envelope was checked above)
+        # the C side declined (a condition the envelope above cannot see, e.g. its statically cached DLE_CONV_BNBWD pin): the
+        # reduction has been launched and dgamma / dbeta are final -- the caller continues with the unfused apply + GEMM
+        return "reduced"
     if t2 is not None:
         C.call("dle_bn_bwd_finish", C.ptr(part), groups, n, C.ptr(bnred[4]), C.ptr(bnred[5]), 0, C.stream())
     return dt, dx, t2 is not None

@@ -114,7 +114,13 @@ def parse_args(argv=None):
     w.add_argument("--wn-kernel-size", default=3, type=int)
     w.add_argument("--wn-channels", default=512, type=int)
     w.add_argument("--wn-layers", default=8, type=int)
-    return p.parse_args(argv)          # (parse_known_args swallowed typos: an unknown flag is an error, as in the reference)
+    # parse_known_args, as the reference does (Tacotron2/train.py:349,382): a command line shared by both models, or a launcher's
+    # --local_rank, must not abort the run; what is ignored is said on stderr
+    args, unknown = p.parse_known_args(argv)
+    if unknown:
+        import sys
+        print("warning: ignored command-line arguments (not used by this model): %s" % " ".join(unknown), file=sys.stderr)
+    return args
 
 
 def get_model_config(args):

@@ -157,6 +157,8 @@ int dle_conv2d_wgrad(const void* dy, const void* x, float* dw, int N, int H, int
  * dle_wgrad1x1_mode(0 / 1): off / on for A/B measurements. */
 int64_t dle_wgrad1x1_workspace(void);
 int dle_wgrad1x1_mode(int mode);
+/* workspace of one shape in bytes; 0: (M, Ko, C) is outside the envelope of dle_wgrad1x1_try (do not allocate, do not call) */
+int64_t dle_wgrad1x1_workspace_for(int M, int Ko, int C);
 int dle_wgrad1x1_try(const void* dy, const void* x, float* dw, int M, int Ko, int C, int dtype, int accumulate, void* workspace,
                      int64_t workspace_bytes, hipStream_t stream);
 /* 3x3 / stride 1 / pad 1 weight gradients with C, Ko multiples of 64 run on the halo-tile kernel of csrc/conv3x3_wgrad.hip when the

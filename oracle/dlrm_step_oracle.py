@@ -146,6 +146,27 @@ DLRM_STEP_CONFIGS = {
                  num=13, batch=256, lr=1.0, steps=10, seed=11),
     "criteo_shape": dict(sizes=[min(s, 3000) for s in CRITEO_F15_SIZES], dim=128, bottom=[512, 256, 128],
                          top=[1024, 1024, 512, 256, 1], num=13, batch=2048, lr=1.0, steps=8, seed=12),
+    # every sparse-update path of the HIP engine inside ONE step that is compared with the reference's DistributedDlrm: the
+    # one-hot MFMA segment sum (tables of <= 128 rows: 4, 97), the eight-lists-per-row form (<= 4096 rows: 968, 2209, the
+    # capped tail), the one-list form with its LookupMap multiply-shift division, the end-first walk and emb_link (5000,
+    # 20046, 200000, 1000000 rows) -- batch 8192 so that the small tables see ~10-2000 duplicates per row and the big ones few
+    "mixed_paths": dict(sizes=[4, 97, 968, 2209, 5000, 20046, 200000, 1000000] + [min(s, 3000) for s in CRITEO_F15_SIZES[10:18]],
+                        dim=128, bottom=[512, 256, 128], top=[1024, 1024, 512, 256, 1], num=13, batch=8192, lr=1.0, steps=4,
+                        seed=13),
 }
+MIXED_PATHS_PROBE_TABLES = (0, 1, 2, 3, 4, 5, 6, 7)     # tables whose final rows the fixture keeps (<= 256 touched rows each)
+
+
+def probe_rows(cfg, cat):
+    """Rows of the joint embedding the mixed_paths fixture keeps: per probed table the first <= 256 distinct rows the batch looks
+    up (in order of first appearance) -- touched rows of every update path, few enough for a small fixture."""
+    off = np.concatenate([[0], np.cumsum(cfg["sizes"])]).astype(np.int64)
+    out = []
+    c = cat.numpy() if hasattr(cat, "numpy") else np.asarray(cat)
+    for t in MIXED_PATHS_PROBE_TABLES:
+        _, first = np.unique(c[:, t], return_index=True)
+        ids = c[np.sort(first)[:256], t]
+        out.append(ids + off[t])
+    return np.concatenate(out).astype(np.int64)
 
 

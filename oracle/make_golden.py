@@ -95,7 +95,13 @@ def gen_dlrm():
     print("dlrm golden written")
 
 
-def gen_dlrm_step():
+def gen_dlrm_step_mixed():
+    """Only the mixed_paths case (the others are pinned already; it allocates a 1.2 M-row table three times over)."""
+    gen_dlrm_step(only=("mixed_paths",))
+    gen_floors(bert=False, dlrm_only=("mixed_paths",))
+
+
+def gen_dlrm_step(only=None):
     """Per-step losses (+ final weights for the tiny case) of the REFERENCE's DistributedDlrm on CPU, fp32."""
     from oracle import dlrm_step_oracle as SO
     from oracle.dlrm_step_oracle import seeded_dlrm_state, seeded_dlrm_batch, DLRM_STEP_CONFIGS
@@ -103,6 +109,10 @@ def gen_dlrm_step():
     from dlrm.utils import distributed as du
     du.get_world_size = lambda: 1          # no process group in the build container
     for name, c in DLRM_STEP_CONFIGS.items():
+        if only is not None and name not in only:
+            continue
+        if only is None and name == "mixed_paths":
+            continue                       # (gen_dlrm_step_mixed)
         model = ref.model.DistributedDlrm(
             num_numerical_features=c["num"], categorical_feature_sizes=c["sizes"], bottom_mlp_sizes=c["bottom"],
             top_mlp_sizes=c["top"], embedding_type="joint", embedding_dim=c["dim"], interaction_op="dot",
@@ -142,6 +152,13 @@ def gen_dlrm_step():
         if name == "tiny":
             for k, v in SO.state_to_numpy(final).items():
                 arrs["final." + k] = v
+        elif name == "mixed_paths":
+            arrs["final.out.weight"] = final["out.weight"].numpy()
+            arrs["final.bottom_mlp.0.weight"] = final["bottom_mlp.0.weight"].numpy()
+            rows = SO.probe_rows(c, cat)
+            arrs["probe_rows"] = rows
+            arrs["final.embedding_probe"] = final["embedding"][torch.from_numpy(rows)].numpy()
+            arrs["init.embedding_probe"] = state0["embedding"][torch.from_numpy(rows)].numpy()
         else:
             arrs["final.out.weight"] = final["out.weight"].numpy()
             arrs["final.bottom_mlp.0.weight"] = final["bottom_mlp.0.weight"].numpy()
@@ -392,13 +409,13 @@ def gen_bert(cfg_name="BERT_STEP_CONFIG", out_name="bert_step.npz", last_layer=1
     print(out_name, "losses", losses)
 
 
-def gen_floors():
+def gen_floors(bert=True, dlrm_only=None):
     """Append the measured 16-bit STORAGE floors to the BERT / DLRM step fixtures: the step oracle re-run with every tensor
     the AMP path keeps in fp16 / bf16 rounded where it is produced (oracle/storage.py).  The fp32 oracle must first reproduce
     the fixture's reference losses (it is what was pinned against the reference module when the fixture was written)."""
     from oracle import bert_oracle as BO
     from oracle import dlrm_step_oracle as SO
-    for cfg_name, out_name in (("BERT_STEP_CONFIG", "bert_step.npz"), ("BERT_STEP_CONFIG_LARGE", "bert_step_large1l.npz")):
+    for cfg_name, out_name in ((("BERT_STEP_CONFIG", "bert_step.npz"), ("BERT_STEP_CONFIG_LARGE", "bert_step_large1l.npz")) if bert else ()):
         c = getattr(BO, cfg_name)
         path = os.path.join(GOLD, out_name)
         arrs = dict(np.load(path))
@@ -414,6 +431,8 @@ def gen_floors():
         np.savez_compressed(path, **arrs)
         print(out_name, "reference", arrs["losses"], "fp16 storage", arrs["losses_fp16_storage"], "bf16 storage", arrs["losses_bf16_storage"])
     for name, c in SO.DLRM_STEP_CONFIGS.items():
+        if (dlrm_only is not None and name not in dlrm_only) or (dlrm_only is None and name == "mixed_paths"):
+            continue
         path = os.path.join(GOLD, "dlrm_step_%s.npz" % name)
         arrs = dict(np.load(path))
         state0 = SO.seeded_dlrm_state(c["sizes"], c["dim"], c["bottom"], c["top"], c["num"], c["seed"])

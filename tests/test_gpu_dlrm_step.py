@@ -26,7 +26,7 @@ def _build(cfg, device, dtype):
     return model, trainer, state
 
 
-@pytest.mark.parametrize("name", ["tiny", "criteo_shape"])
+@pytest.mark.parametrize("name", ["tiny", "criteo_shape", "mixed_paths"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_step_losses_match_reference(cuda, golden_dir, name, dtype):
     cfg = SO.DLRM_STEP_CONFIGS[name]
@@ -59,6 +59,23 @@ def test_step_losses_match_reference(cuda, golden_dir, name, dtype):
         touched[(cat.cpu().numpy() + off[:-1]).reshape(-1)] = True
         assert np.array_equal(np.any(emb != init, axis=1) | ~touched, np.ones_like(touched))
         assert np.array_equal(emb[~touched], init[~touched])
+    if name == "mixed_paths":
+        # all three sparse-update paths inside the step (one-hot MFMA <= 128 rows, eight lists <= 4096, one list above):
+        # the rows the reference's DistributedDlrm ends with, per probed table, as UPDATES (final - initial: the tables are
+        # fp32 on both sides, the gradients that moved them are 16-bit on this side)
+        rows = torch.from_numpy(gold["probe_rows"]).to(cuda)
+        emb = model.bottom_model.embeddings.weight.detach()[rows].cpu().numpy()
+        init = gold["init.embedding_probe"]
+        np.testing.assert_array_equal(state["embedding"].numpy()[gold["probe_rows"]], init)
+        d_ref, d_hip = gold["final.embedding_probe"] - init, emb - init
+        off = np.concatenate([[0], np.cumsum(cfg["sizes"])])
+        for t in SO.MIXED_PATHS_PROBE_TABLES:
+            m = (gold["probe_rows"] >= off[t]) & (gold["probe_rows"] < off[t + 1])
+            scale = np.abs(d_ref[m]).max()
+            assert m.sum() > 0 and scale > 0
+            err = np.abs(d_hip[m] - d_ref[m]).max()
+            print("table", t, "rows", cfg["sizes"][t], "max |update|", scale, "max error", err)
+            assert err <= (0.03 if dtype == torch.float16 else 0.08) * scale, (t, cfg["sizes"][t], err, scale)
     # the workspace invariant of the duplicate-free update
     assert int((model.bottom_model.embeddings.workspace().head != -1).sum().item()) == 0
 

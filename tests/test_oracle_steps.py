@@ -62,7 +62,7 @@ def test_storage_floors_in_fixtures_are_what_the_oracles_measure():
         o = SO.DlrmOracle(st, d["sizes"], d["lr"], storage_dtype=dt)
         ls = [o.step(num, cat, click) for _ in range(d["steps"])]
         np.testing.assert_allclose(ls, gd["losses_%s_storage" % nm], rtol=2e-5)
-    for f, keys in (("bert_step.npz", 1), ("bert_step_large1l.npz", 1), ("dlrm_step_tiny.npz", 1), ("dlrm_step_criteo_shape.npz", 1)):
+    for f, keys in (("bert_step.npz", 1), ("bert_step_large1l.npz", 1), ("dlrm_step_tiny.npz", 1), ("dlrm_step_criteo_shape.npz", 1), ("dlrm_step_mixed_paths.npz", 1)):
         g = np.load(os.path.join(HERE, "golden", f))
         for nm in ("fp16", "bf16"):
             floor = np.abs(g["losses_%s_storage" % nm] - g["losses"]) / g["losses"]
