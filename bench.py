@@ -511,6 +511,25 @@ def lookup_traffic(kernel_key):
     return float(rec["traffic_bytes_per_launch"]) if rec else None
 
 
+def traffic_source():
+    """Where `roofline.traffic` comes from: it is a LOOKUP in the committed counter table, not a counter read in this run."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+    try:
+        meta = json.load(open(path)).get("_meta", {})
+    except (OSError, ValueError):
+        return None
+    return "profiles/traffic.json (rocprofv3 --pmc passes of round %s, tools/collect_traffic.sh; looked up by launch shape, " \
+           "not measured in this run)" % meta.get("round", "4")
+
+
+def comm_info():
+    """The process group this line was measured under (a SCALE record can be checked against it)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return {"backend": dist.get_backend(), "world": dist.get_world_size()}
+    return {"backend": None, "world": 1}
+
+
 def roofline_from(timer, steps, wl_name, samples_per_step_per_gpu, ms_per_step):
     """Roofline of the workload's DOMINANT KERNEL FAMILY plus the whole-step fraction.
 
@@ -801,6 +820,9 @@ def main():
                "higher_is_better": True, "scaling": rec["scaling"], "vs_baseline": None, "dtype": rec["dtype"],
                "data": "synthetic", "config": rec["config"], "final_loss": rec["final_loss"],
                "roofline": {k: r.get(k) for k in keep} if r else None}
+        if out["roofline"] is not None:
+            out["roofline"]["traffic_source"] = traffic_source() if out["roofline"].get("traffic") is not None else None
+        out["comm"] = comm_info()
         if args.workload in cpu:
             out["cpu_baseline"] = cpu[args.workload]
         if note:

@@ -290,6 +290,8 @@ class ResNetTrainer:
     def backward(self, dlogits):
         n = dlogits.shape[0]
         fcw = self.fc_w16
+        if self.buckets is not None:
+            self.buckets.fired = 0               # (a backward pass abandoned half way had launched some of its buckets)
         F.gemm(dlogits, self._pooled, fcw.shape[0], fcw.shape[1], n, False, False,
                out=self.gview["fc.weight"].view(fcw.shape), splitk=F.pick_splitk(fcw.shape[0], fcw.shape[1], n))
         F.colsum(dlogits, out=self.gview["fc.bias"])

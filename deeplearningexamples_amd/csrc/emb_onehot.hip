@@ -220,11 +220,12 @@ extern "C" int dle_emb_onehot_try(float* weight, const int64_t* rows, const void
                                   int grad_dtype, void* ws, int64_t ws_bytes, hipStream_t stream) {
   static const int mode = getenv("DLE_EMB_ONEHOT") ? atoi(getenv("DLE_EMB_ONEHOT")) : 1;
   if (!mode || n_tab <= 0 || n_tab > 64 || dim != OH_D || !ws) return 0;
-  // dW = OneHot^T G multiplies EVERY gradient row into every table row (by 0 or 1): one inf / NaN gradient row would poison the
-  // whole tiny table (0 * inf = NaN), where the register / LDS forms and the reference's atomicAdd only touch the row that was
-  // looked up.  With a skip flag (the GradScaler's found_inf, set before this launch) such a step is dropped as a whole; without
-  // one the caller keeps its row-local forms.
-  if (!skip_flag_dev) return 0;
+  // NON-FINITE GRADIENTS: dW = OneHot^T G multiplies EVERY gradient row into every row of the tiny table (by 0 or 1), so one
+  // inf / NaN gradient row poisons the whole table (0 * inf = NaN), where the register / LDS forms and the reference's atomicAdd
+  // only touch the row that was looked up.  The fp16 path is protected by ordering: the GradScaler's found_inf is final BEFORE
+  // this launch (dle_check_nonfinite runs on the gradient first) and arrives here as skip_flag_dev, which drops the whole step.
+  // A caller without a scaler (bf16, skip_flag_dev == NULL) gets a poisoned table instead of a poisoned row from a non-finite
+  // gradient -- the run is lost either way; DLE_EMB_ONEHOT=0 keeps the row-local forms.
   if (grad_dtype != DLE_F16 && grad_dtype != DLE_BF16) return 0;
   if ((grad_batch_stride % 8) != 0 || ((((uintptr_t)grad) | ((uintptr_t)ws)) & 15) != 0) return 0;
   if (batch * grad_batch_stride * 2 >= 0xFFFFFFE0LL || batch < OH_TG) return 0;

@@ -29,7 +29,8 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_ADD = 4, 
 
 #define G8_HALF 8192                 // 16-bit elements per half-tile image (128 rows x 64 k)
 #define G8_BUF (4 * G8_HALF)         // one K tile: A0 | A1 | B0 | B1
-#define G8_LDS_BYTES (2 * G8_BUF * 2)
+#define G8_STAGE_BYTES (2 * G8_BUF * 2)
+#define G8_LDS_BYTES (G8_STAGE_BYTES + 8 * 256)      // + one 256-byte bias slot per wavefront (EPI 1)
 
 struct Gemm8Args {
   const unsigned short* A;
@@ -155,6 +156,11 @@ __device__ __forceinline__ TrPair g8_frag_rc_imm(unsigned base) {
 // one LDS-DMA piece (1 KiB per wavefront) to LDS byte address m0v; hidden from hipcc's wait-count pass like dma16_raw
 __device__ __forceinline__ void g8_dma(int4v_t rs, unsigned m0v, unsigned voff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(m0v), "v"(voff), "s"(rs) : "memory");
+}
+
+// 4 bytes per lane (256 B per wavefront) by LDS-DMA: the wavefront's 64 bias values
+__device__ __forceinline__ void g8_dma4(int4v_t rs, unsigned m0v, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" :: "s"(m0v), "v"(voff), "s"(rs) : "memory");
 }
 
 // per-lane constants of one operand's two DMA pieces (identical for both halves and every tile)
@@ -438,27 +444,28 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     decode(it, m0, n0, kt0, kt1, ky);
     G8_STAMP(0);
     const bool interior = m0 + 256 <= p.M && n0 + 256 <= p.N;
-    // EPI 1, interior tile, alpha = 1: the accumulators START from the bias row (scalar loads: the vector-memory queue, which
-    // retires in order and is full of the stream's pieces, is not involved); otherwise the first K tile starts from zero
-    // inside its first MFMAs.
-    bool bias_in_acc = false;
-    if constexpr (EPI == 1) bias_in_acc = interior && p.bias != nullptr && p.alpha == 1.0f;
-    if (EPI == 1 && bias_in_acc) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float* bp = p.bias + (n0 + j * 128 + wc * 32);          // wave-uniform address: s_load
-        float16_t bv;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bv[r] = fh ? bp[16 + r] : bp[r];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) acc[i][j][b] = bv;
+    // (EPI 1: the bias row is added in the epilogue from SCALAR loads -- wave-uniform addresses, lgkmcnt, not the vector-memory
+    //  queue that retires in order behind the stream's pieces.  Starting the accumulators from the bias instead is one rounding
+    //  different from `sum + bias`: enough to move the reference-size WaveGlow loss by 1e-3, so the order of the tile kernels
+    //  is kept and the results stay bit-identical to theirs.)
+    constexpr bool bias_in_acc = false;
+    if constexpr (EPI == 1) {
+      // The bias values of this wavefront's 64 columns (2 x 32) travel with the stream: ONE 4-byte LDS-DMA piece per wavefront
+      // into its own 256-byte slot behind the stages, issued here, landed (in-order vmcnt) by the second K tile's wait at the
+      // latest, read back with four ds_read_b128 per column half in the epilogue.  (Vector loads in the epilogue sit behind
+      // the stream's prefetch in the in-order queue: their wait drained it, +2.6 k cycles per tile; scalar loads of 32
+      // values per block cost more than that in s_load latency.)  Columns past N read zero through the range check.
+      if (p.bias) {
+        int4v_t rsb;
+        rsb.x = (int)(unsigned)(unsigned long long)p.bias;
+        rsb.y = (int)(unsigned)((unsigned long long)p.bias >> 32);
+        rsb.z = p.N * 4;
+        rsb.w = 0x00020000;
+        const unsigned col = (unsigned)(n0 + (lane >> 5) * 128 + wc * 32 + (lane & 31));
+        g8_dma4(rsb, lds0 + G8_STAGE_BYTES + (unsigned)wave * 256u, col * 4u);
       }
-      ktile(cpar, std::integral_constant<bool, true>(), std::integral_constant<bool, false>(), st_keep);
-    } else {
-      ktile(cpar, std::integral_constant<bool, true>(), std::integral_constant<bool, true>(), st_keep);
     }
+    ktile(cpar, std::integral_constant<bool, true>(), std::integral_constant<bool, true>(), st_keep);
     cpar ^= 1;
     for (int kt = kt0 + 1; kt < kt1; ++kt) {
 #ifdef G8_TIMING_KT
@@ -474,9 +481,22 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     st_keep = interior;                                // interior tile: every store instruction below is issued
     G8_STAMP(1);
 
+    // The epilogue's arguments (output / side / source pointers, pitch, bias, flags) are read from the kernel-argument segment
+    // HERE, once per item, through a pointer the compiler cannot see through: kept in scalar registers across the K loop they
+    // pushed the flavoured instantiations 30-50 SGPRs over the budget, and the spills (v_readlane / v_writelane and argument
+    // re-loads inside the phases) cost the K loop of the bias / source flavours ~8 % against the store-only one.
+    const __attribute__((address_space(4))) Gemm8Args* q = (const __attribute__((address_space(4))) Gemm8Args*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));
+    // ... each read ONCE (pinned in a scalar register for the length of the epilogue: left to the compiler, every use inside
+    // the 8 blocks became its own s_load + wait)
+    unsigned long long e_C = (unsigned long long)q->C, e_aux = (unsigned long long)q->aux, e_bias = (unsigned long long)q->bias,
+                       e_src = (unsigned long long)q->src;
+    int e_ldc = (int)q->ldc;
+    unsigned e_cbytes = q->c_bytes;
+    asm volatile("" : "+s"(e_C), "+s"(e_aux), "+s"(e_bias), "+s"(e_src), "+s"(e_ldc), "+s"(e_cbytes));
     // ---- epilogue, in the accumulator layout: lane (fr, fh) of block (i, j, b) owns row m0 + 128 i + 64 wr + 32 b + fr,
     // columns n0 + 128 j + 32 wc + 16 fh .. + 15
-    float st[2][16];                               // column sums of the rounded output over this lane's rows (EPI 2, p.stats)
+    float st[2][16];                               // column sums of the rounded output over this lane's rows (EPI 2, q->stats)
     if constexpr (EPI == 2) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -486,15 +506,15 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     // Interior tile, 16-bit output (every flavour) or fp32 output (plain / slab): no per-lane predicate, no 64-bit address
     // arithmetic -- a lane's byte offset inside the tile is a constant (rows fr, columns 16 fh), the block's position is a
     // scalar offset of the buffer instruction; the source tensor of EPI 2 is requested for all 8 blocks before the first use.
-    const bool fastpath = interior && p.alpha == 1.0f && p.c_bytes != 0 &&
-                          (p.out_dtype != DLE_F32 ? true : (EPI == 0 && !(p.accumulate && !p.ws)));
+    const bool fastpath = interior && q->alpha == 1.0f && e_cbytes != 0 &&
+                          (q->out_dtype != DLE_F32 ? true : (EPI == 0 && !(q->accumulate && !q->ws)));
     if (fastpath) {
-      const bool f32o = p.out_dtype == DLE_F32;
+      const bool f32o = q->out_dtype == DLE_F32;
       const unsigned esz = f32o ? 4u : 2u;
-      const unsigned pitch = (unsigned)((EPI == 0 && p.ws) ? p.N : (int)p.ldc) * esz;      // bytes per row
+      const unsigned pitch = (unsigned)((EPI == 0 && q->ws) ? p.N : e_ldc) * esz;      // bytes per row
       const unsigned lane_off = (unsigned)fr * pitch + (unsigned)fh * 16u * esz;
-      const void* cbase = (EPI == 0 && p.ws) ? (const void*)(p.ws + (long long)ky * p.M * p.N) : (const void*)p.C;
-      __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cbase, 0, (int)p.c_bytes, 0x00020000);
+      const void* cbase = (EPI == 0 && q->ws) ? (const void*)(q->ws + (long long)ky * p.M * p.N) : (const void*)e_C;
+      __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cbase, 0, (int)e_cbytes, 0x00020000);
       // (the block offset goes into the VECTOR offset of the stores, not into their scalar offset field: with a scalar-register
       //  soffset hipcc assumes the wide-store data hazard away and may overwrite a store's data registers in the very next
       //  instruction -- on gfx950 the last data register then reaches memory corrupted: the fp16 GELU side output had garbage in
@@ -517,7 +537,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
       } else {
         ushort8_t sv[EPI == 2 ? 8 : 1][2];
         if constexpr (EPI == 2) {
-          __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)p.c_bytes, 0x00020000);
+          __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)e_src, 0, (int)e_cbytes, 0x00020000);
           static_for<0, 8>([&](auto BI) __attribute__((always_inline)) {
             constexpr int bi = decltype(BI)::value, i = bi >> 2, j = (bi >> 1) & 1, b = bi & 1;
             const unsigned so = blk_off(i, j, b);
@@ -526,7 +546,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
           });
         }
         __amdgpu_buffer_rsrc_t ra = rc;
-        if constexpr (EPI == 1) { if (p.aux) ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.aux, 0, (int)p.c_bytes, 0x00020000); }
+        if constexpr (EPI == 1) { if (e_aux) ra = __builtin_amdgcn_make_buffer_rsrc((void*)e_aux, 0, (int)e_cbytes, 0x00020000); }
         static_for<0, 8>([&](auto BI) __attribute__((always_inline)) {
           constexpr int bi = decltype(BI)::value, i = bi >> 2, j = (bi >> 1) & 1, b = bi & 1;
           const unsigned so = blk_off(i, j, b);
@@ -534,10 +554,14 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = acc[i][j][b][r];
           if constexpr (EPI == 1) {
-            if (p.bias && !bias_in_acc) {                 // (alpha == 1 here: only reached without a bias row in the accumulators)
-              const float* bp = p.bias + (n0 + j * 128 + wc * 32);
+            if (e_bias) {
+              const float* bl = (const float*)(smem_raw + G8_STAGE_BYTES + wave * 256) + j * 32 + fh * 16;    // (see the item head)
 #pragma unroll
-              for (int r = 0; r < 16; ++r) v[r] += fh ? bp[16 + r] : bp[r];
+              for (int r4 = 0; r4 < 4; ++r4) {
+                const float4_t bq = *(const float4_t*)(bl + 4 * r4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * r4 + r] += bq[r];
+              }
             }
             float side[16];
 #pragma unroll
@@ -555,7 +579,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) v[r] = g8_gelu_d(v[r], side[r]);
             }
-            if (p.aux) {
+            if (e_aux) {
               __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, pack8<DT>(side)), ra, lane_off + so, 0, 0);
               __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, pack8<DT>(side + 8)), ra, lane_off + so + 16, 0, 0);
             }
@@ -588,7 +612,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o0), rc, lane_off + so, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o1), rc, lane_off + so + 16, 0, 0);
           if constexpr (EPI == 2) {
-            if (p.stats) {
+            if (q->stats) {
               float vr[16];
               unpack8<DT>(o0, vr);
               unpack8<DT>(o1, vr + 8);
@@ -608,12 +632,12 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = acc[i][j][b][r];
-        if (p.alpha != 1.0f) {
+        if (q->alpha != 1.0f) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] *= p.alpha;
+          for (int r = 0; r < 16; ++r) v[r] *= q->alpha;
         }
-        if (EPI == 0 && p.ws) {                    // split-K partial -> fp32 slab
-          float* c = p.ws + ((long long)ky * p.M + m) * p.N + n;
+        if (EPI == 0 && q->ws) {                    // split-K partial -> fp32 slab
+          float* c = q->ws + ((long long)ky * p.M + m) * p.N + n;
           *(float4_t*)c = (float4_t){v[0], v[1], v[2], v[3]};
           *(float4_t*)(c + 4) = (float4_t){v[4], v[5], v[6], v[7]};
           if (hi_ok) {
@@ -621,17 +645,17 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
             *(float4_t*)(c + 12) = (float4_t){v[12], v[13], v[14], v[15]};
           }
         } else {
-          const long long off = (long long)m * p.ldc + n;
-          if (EPI == 1 && p.bias && !bias_in_acc) {
-            const float4_t b0 = *(const float4_t*)(p.bias + n), b1 = *(const float4_t*)(p.bias + n + 4);
+          const long long off = (long long)m * e_ldc + n;
+          if (EPI == 1 && e_bias && !bias_in_acc) {
+            const float4_t b0 = *(const float4_t*)((const float*)e_bias + n), b1 = *(const float4_t*)((const float*)e_bias + n + 4);
             float4_t b2 = {0.f, 0.f, 0.f, 0.f}, b3 = {0.f, 0.f, 0.f, 0.f};
-            if (hi_ok) { b2 = *(const float4_t*)(p.bias + n + 8); b3 = *(const float4_t*)(p.bias + n + 12); }
+            if (hi_ok) { b2 = *(const float4_t*)((const float*)e_bias + n + 8); b3 = *(const float4_t*)((const float*)e_bias + n + 12); }
 #pragma unroll
             for (int r = 0; r < 4; ++r) { v[r] += b0[r]; v[4 + r] += b1[r]; v[8 + r] += b2[r]; v[12 + r] += b3[r]; }
           }
-          if (p.out_dtype == DLE_F32) {            // (EPI 0 / 1 with act none: checked by the launcher)
-            float* c = (float*)p.C + off;
-            if (p.accumulate) {
+          if (q->out_dtype == DLE_F32) {            // (EPI 0 / 1 with act none: checked by the launcher)
+            float* c = (float*)e_C + off;
+            if (q->accumulate) {
               const float4_t c0 = *(const float4_t*)c, c1 = *(const float4_t*)(c + 4);
               float4_t c2 = {0.f, 0.f, 0.f, 0.f}, c3 = {0.f, 0.f, 0.f, 0.f};
               if (hi_ok) { c2 = *(const float4_t*)(c + 8); c3 = *(const float4_t*)(c + 12); }
@@ -648,7 +672,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
             float side[16];
             bool has_side = false;
             if constexpr (EPI == 1) {
-              has_side = p.aux != nullptr;
+              has_side = e_aux != 0;
 #pragma unroll
               for (int r = 0; r < 16; ++r) side[r] = v[r];           // pre-activation
               if (ACT == ACT_RELU) {
@@ -665,7 +689,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
                 for (int r = 0; r < 16; ++r) v[r] = g8_gelu_d(v[r], side[r]);   // side = the derivative
               }
             } else if constexpr (EPI == 2) {
-              const unsigned short* s = p.src + off;
+              const unsigned short* s = (const unsigned short*)e_src + off;
               ushort8_t s0 = *(const ushort8_t*)s, s1 = {0, 0, 0, 0, 0, 0, 0, 0};
               if (hi_ok) s1 = *(const ushort8_t*)(s + 8);
               float y[16];
@@ -693,16 +717,16 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
               }
             }
             const ushort8_t o0 = pack8<DT>(v), o1 = pack8<DT>(v + 8);
-            unsigned short* c = (unsigned short*)p.C + off;
+            unsigned short* c = (unsigned short*)e_C + off;
             *(ushort8_t*)c = o0;
             if (hi_ok) *(ushort8_t*)(c + 8) = o1;
             if (EPI == 1 && has_side) {
-              unsigned short* a = (unsigned short*)p.aux + off;
+              unsigned short* a = (unsigned short*)e_aux + off;
               *(ushort8_t*)a = pack8<DT>(side);
               if (hi_ok) *(ushort8_t*)(a + 8) = pack8<DT>(side + 8);
             }
             if constexpr (EPI == 2) {
-              if (p.stats) {
+              if (q->stats) {
                 float vr[16];
                 unpack8<DT>(o0, vr);
                 unpack8<DT>(o1, vr + 8);
@@ -715,7 +739,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
       }
     });
     if constexpr (EPI == 2) {
-      if (p.stats) {
+      if (q->stats) {
         // the 32 row lanes of a column group reduce-scatter their 16 sums: after the xor-16 / 8 / 4 / 2 exchanges a lane keeps
         // ONE column (index = bits 4..1 of fr), the xor-1 exchange completes it; even lanes store.  One partial row per
         // (tile row, wavefront row group), folded in a fixed order by colsum_fold_kernel.
@@ -747,7 +771,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
           }
           a1 += __shfl_xor(a1, 1, 64);
           const int col = n0 + j * 128 + wc * 32 + fh * 16 + ((fr >> 1) & 15);
-          if ((fr & 1) == 0 && col < p.N) p.stats[((long long)((m0 >> 8) * 2 + wr)) * p.N + col] = a1;
+          if ((fr & 1) == 0 && col < p.N) q->stats[((long long)((m0 >> 8) * 2 + wr)) * p.N + col] = a1;
         }
       }
     }

@@ -96,7 +96,10 @@ int dle_emb_sgd_dedup(float* weight, const int64_t* rows, const void* grad, int3
  * (one per residue of the sample index: the ~70-deep duplicate chains of 1-2 k-row tables become 8 chains walked side by side),
  * whose partial sums meet in a third small pass.  ws: dle_emb_sgd_workspace_bytes() bytes of scratch, 256-byte aligned, or NULL
  * (= dle_emb_sgd_dedup).  dle_emb_onehot_try is the one-hot kernel's own entry (1 launched, 0 outside its envelope; scratch
- * dle_emb_onehot_workspace_bytes): tab_t / tab_base / tab_rows = column index, first joint row, row count of each table (host). */
+ * dle_emb_onehot_workspace_bytes): tab_t / tab_base / tab_rows = column index, first joint row, row count of each table (host).
+ * Non-finite gradients: the one-hot product multiplies every gradient row into every row of a tiny table, so an inf / NaN gradient
+ * row turns the WHOLE table NaN (row-local in the reference).  skip_flag_dev must therefore be final before the call (the fp16
+ * path: dle_check_nonfinite on the gradient first); without a scaler a non-finite gradient loses the table instead of the row. */
 int64_t dle_emb_sgd_workspace_bytes(const int64_t* table_offsets_host, int tables, int dim, int64_t batch);
 int64_t dle_emb_onehot_workspace_bytes(int n_tables, int64_t batch);
 int dle_emb_sgd_dedup_ws(float* weight, const int64_t* rows, const void* grad, int32_t* head, int32_t* next,

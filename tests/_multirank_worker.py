@@ -100,6 +100,46 @@ def run_rn50(rank, world, dev, steps):
     return {"losses": losses, "probe": probe, "nbuckets": len(tr.buckets.buckets) if tr.buckets else 0}
 
 
+def run_rn50_abandon(rank, world, dev, steps):
+    """A step that dies between forward and backward, and one that dies INSIDE its backward pass (after some units have set their
+    cross-unit state -- a BatchNorm reduction taken by the neighbour's kernel, gradient buckets already launched), must not
+    poison the steps that follow: same losses and weights as on one rank that went through the same sequence."""
+    from oracle import resnet_oracle as RO
+    from deeplearningexamples_amd import functional as F
+    from deeplearningexamples_amd.convnets.resnet import ResNet50
+    from deeplearningexamples_amd.convnets.engine import ResNetTrainer
+    c = RO.RN50_STEP_CONFIG
+    torch.manual_seed(300 + rank)
+    model = ResNet50(device=dev)
+    if rank == 0:
+        model.load_state_dict({k: v.clone() for k, v in RO.seeded_state(c["seed"]).items()}, strict=False)
+    tr = ResNetTrainer(model, lr=c["lr"], compute_dtype=torch.bfloat16, static_loss_scale=128.0, world_size=world, bucket_mb=4)
+    x, y = RO.seeded_batch(c["seed"] + 100, 8, c["size"])
+    x, y = x.to(dev), y.to(dev)
+    losses = [float(tr.train_step(x, y).item())]
+    tr.forward(x)                                            # (1) the exception arrives between forward and backward
+    logits = tr.forward(x)                                   # (2) ... or inside the backward pass, half way down the network
+    _, dlogits = F.softmax_xent(logits, y, smoothing=tr.smoothing, grad_scale=tr.scaler.scale if tr.scaler.enabled else None,
+                                grad_dtype=tr.dtype)
+    victim = tr.blocks[len(tr.blocks) // 2][0]
+    orig = victim.backward
+
+    def boom(*a, **k):
+        raise RuntimeError("injected failure inside the backward pass")
+    victim.backward = boom
+    tr._reduce_now = True
+    raised = False
+    try:
+        tr.backward(dlogits)
+    except RuntimeError:
+        raised = True
+    victim.backward = orig
+    torch.cuda.synchronize(dev)
+    losses += [float(tr.train_step(x, y).item()) for _ in range(2)]
+    probe = model.fc.bias.detach().cpu().numpy()[:8].tolist()
+    return {"losses": losses, "probe": probe, "nbuckets": len(tr.buckets.buckets) if tr.buckets else 0, "raised": raised}
+
+
 DLRM_MR = dict(num=13, sizes=[300, 50, 7, 2000, 11, 640], dim=128, bottom=[64, 128], top=[128, 64, 1], lr=0.5, batch=256,
                seed=5)
 
@@ -252,7 +292,7 @@ def _bert_flag2(dev, steps):
     return {"losses": losses, "probe": probe, "nbuckets": len(tr.buckets.buckets)}
 
 
-SCENARIOS = {"bert_acc": run_bert_acc, "bert": run_bert, "rn50": run_rn50, "dlrm": run_dlrm, "waveglow": run_waveglow, "rccl1": run_rccl_single_rank}
+SCENARIOS = {"bert_acc": run_bert_acc, "bert": run_bert, "rn50": run_rn50, "rn50_abandon": run_rn50_abandon, "dlrm": run_dlrm, "waveglow": run_waveglow, "rccl1": run_rccl_single_rank}
 
 
 def main():

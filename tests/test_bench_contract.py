@@ -108,3 +108,12 @@ def test_nested_steps_time_enough_steps():
     for name, (steps, warm) in bench.NESTED_STEPS.items():
         assert steps >= (8 if name == "tacotron2" else 10 if name == "waveglow" else 20), (name, steps)
         assert warm >= 2
+
+
+def test_line_says_where_traffic_comes_from_and_which_process_group_ran():
+    """`roofline.traffic` is a lookup in the committed counter table (the line says so, with the round it was collected in), and
+    the line names the process group it was measured under (backend, world) so that a scaling record can be checked against it."""
+    import bench
+    src = bench.traffic_source()
+    assert src is not None and "profiles/traffic.json" in src and "round" in src and "not measured in this run" in src
+    assert bench.comm_info() == {"backend": None, "world": 1}          # no process group in this test

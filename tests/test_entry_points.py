@@ -339,7 +339,9 @@ def test_bert_lr_schedule_matches_reference_scheduler():
 
 def test_flags_without_effect_are_reported_and_typos_are_errors():
     """A flag that parses must not silently do nothing (run_pretraining.py:557-570 --input_dir feeds the lddl loader in the reference;
-    here the batches are synthetic and the run says so), and an unknown flag is an error in every entry point."""
+    here the batches are synthetic and the run says so).  The two speech CLIs parse like the reference (Tacotron2/train.py:349,382
+    parse_known_args: a command line shared by both models or a launcher's --local_rank must not abort the run) and SAY what
+    they ignored."""
     from deeplearningexamples_amd.bert import run_pretraining as bp
     from deeplearningexamples_amd.tacotron2 import train as t2
     from deeplearningexamples_amd.waveglow import train as wg
@@ -351,5 +353,8 @@ def test_flags_without_effect_are_reported_and_typos_are_errors():
     b = bp.parse_arguments(["--bf16"])
     assert bp.warn_ignored_flags(b, b._defaults, log=lines.append) == []
     for mod in (t2, wg):
-        with pytest.raises(SystemExit):
-            mod.parse_args(["-o", "x", "-lr", "1", "--epochs", "1", "-bs", "1", "--no-such-flag"])
+        import contextlib, io
+        err = io.StringIO()
+        with contextlib.redirect_stderr(err):
+            a = mod.parse_args(["-o", "x", "-lr", "1", "--epochs", "1", "-bs", "1", "--no-such-flag", "--local_rank", "3"])
+        assert a.epochs == 1 and "--no-such-flag" in err.getvalue() and "--local_rank" in err.getvalue()

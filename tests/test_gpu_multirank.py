@@ -45,7 +45,8 @@ def _one_rank(scenario, cuda):
     return W.SCENARIOS[scenario](0, 1, cuda, 3)
 
 
-@pytest.mark.parametrize("scenario,rtol", [("bert", 3e-4), ("bert_acc", 3e-4), ("rn50", 3e-4), ("dlrm", 3e-4), ("waveglow", 1e-3)])
+@pytest.mark.parametrize("scenario,rtol", [("bert", 3e-4), ("bert_acc", 3e-4), ("rn50", 3e-4), ("rn50_abandon", 3e-4), ("dlrm", 3e-4),
+                                           ("waveglow", 1e-3)])
 def test_two_ranks_match_one_rank(cuda, tmp_path, scenario, rtol):
     two, backend = _two_ranks(scenario, tmp_path)
     one = _one_rank(scenario, cuda)
@@ -55,7 +56,9 @@ def test_two_ranks_match_one_rank(cuda, tmp_path, scenario, rtol):
     assert two[0]["probe"] == two[1]["probe"], "data-parallel replicas diverged"
     ref = np.asarray(one["probe"])
     np.testing.assert_allclose(np.asarray(two[0]["probe"]), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
-    if scenario in ("bert", "bert_acc", "rn50", "waveglow"):
+    if scenario == "rn50_abandon":
+        assert two[0]["raised"] and two[1]["raised"] and one["raised"]      # the injected failure did interrupt the backward pass
+    if scenario in ("bert", "bert_acc", "rn50", "rn50_abandon", "waveglow"):
         assert two[0]["nbuckets"] > 1          # several gradient buckets were reduced during the backward pass
 
 
