@@ -64,6 +64,9 @@ struct Gemm8Args {
 #ifndef G8_DMA_IN_MMA
 #define G8_DMA_IN_MMA -1               // probes: 0 / 1 pins where a phase's DMA pieces are issued (default: by operand layout)
 #endif
+#ifndef G8_PRIO_MODE
+#define G8_PRIO_MODE 0                 // probes: 0 = priority 1 around each MFMA cluster; 1 = none; 2 = ... and waves 4-7 stay at 1; 3 = waves 4-7 at 1 only
+#endif
 #ifndef G8_ST_KEEP
 #define G8_ST_KEEP 16                  // store instructions per wavefront of an interior tile's epilogue (lower bound over all flavours)
 #endif
@@ -186,6 +189,10 @@ struct G8Lane {
   }
 };
 
+// (the same expressions, in the same order, as gelu_tanh2 / gelu_tanh2_d of gemm_dma.hip: results bit-identical to the tile kernels.
+//  An algebraically shorter form -- hp = 1 - r, 1 - tanh^2 = 4 r hp, 12 instead of 22 operations -- was measured: -7 % epilogue cycles
+//  on the GELU + side-output flavour, whose epilogue is bound by its two stores per block, and one rounding different, which moved
+//  a 2-element gradient of the 24-layer parity test across its bar; not kept.)
 __device__ __forceinline__ float g8_gelu(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
   return 0.5f * x * (1.0f + fast_tanh(k0 * (x + k1 * x * x * x)));
@@ -303,6 +310,9 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
   G8_VM(8);
   G8_BARRIER();
   if (wr == 1) G8_BARRIER();            // the stagger: group 1 runs one barrier behind group 0 from here on
+#if G8_PRIO_MODE == 2 || G8_PRIO_MODE == 3
+  if (wr == 1) __builtin_amdgcn_s_setprio(1);
+#endif
 
   float16_t acc[2][2][2];               // [A half][B half][32-row block]
   typename FragT<RCA>::type fa[2][4];   // one A half: [32-row block][k-step]
@@ -320,7 +330,9 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     constexpr bool stg = DMAM && decltype(STG)::value;
     constexpr bool zc = decltype(ZC)::value;            // the item's first K tile: the first k-step starts from zero
     const float16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#if G8_PRIO_MODE == 0 || G8_PRIO_MODE == 2
     __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -331,7 +343,11 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
           if (ks * 2 + b == G8_DMA_SLOT1) { G8_SB(); stage_piece(SOP, SHF, I1()); G8_SB(); }
         }
       }
+#if G8_PRIO_MODE == 0
     __builtin_amdgcn_s_setprio(0);
+#elif G8_PRIO_MODE == 2
+    if (wr == 0) __builtin_amdgcn_s_setprio(0);
+#endif
   };
 
   // row-contiguous operands: a lane's first transpose-read address inside a half-tile image (bytes)
