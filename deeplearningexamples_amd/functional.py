@@ -431,6 +431,8 @@ def pick_splitk(m_out, n_out, k, target_blocks=512):
         if tiles_big >= 160:
             return 1
         s = min(ktiles // 4, max(256 // tiles_big, 1))
+        if tiles_big <= 2:
+            s = min(s, 64)      # (256x512x65536: 46 us at 64 slices, 56 at 128 -- each slice writes a whole fp32 slab of the output)
         if s >= 2 and tiles_big * s >= 128:
             return s
     target_blocks = int(os.environ.get("DLE_SPLITK_TARGET", target_blocks))      # tuning knob (tools/, not the product default)
