@@ -87,6 +87,55 @@ __global__ __launch_bounds__(256) void dot_fwd_mfma(const unsigned short* __rest
   }
 }
 
+// Persistent form (C = 16 NK known at compile time): a wavefront walks samples b = wave, wave + #waves, ... on its own LDS slice
+// (no workgroup barrier: LDS operations of one wavefront execute in order) and requests the NK 16-byte pieces of sample
+// b + #waves -- into registers -- before the products of sample b.  The one-shot form above is a chain per sample of NK dependent
+// HBM round trips (load -> MFMA in a run-time loop) -> LDS -> store, hidden only by occupancy: 139 us for batch 65536 (3.7 TB/s).
+template <int DT, int NK>
+__global__ __launch_bounds__(256) void dot_fwd_mfma_walk(const unsigned short* __restrict__ x, unsigned short* __restrict__ out, int B,
+                                                         int R, int OW) {
+  constexpr int C = 16 * NK;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned short* so = (unsigned short*)smem_raw + (size_t)wave * OW;
+  const int row = lane & 31, h = lane >> 5;
+  const int nwaves = gridDim.x * 4;
+  const bool live = row < R;
+  const int ntril = R * (R - 1) / 2;
+  ushort8_t xv[NK];
+  auto issue = [&](int b) __attribute__((always_inline)) {      // unconditional (clamped) addresses, masked at use
+    const unsigned short* xr = x + ((size_t)b * R + (live ? row : 0)) * C + h * 8;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) xv[k] = *(const ushort8_t*)(xr + k * 16);
+  };
+  int b = blockIdx.x * 4 + wave;
+  if (b < B) issue(b);
+  for (; b < B; b += nwaves) {
+    ushort8_t cur[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) cur[k] = live ? xv[k] : (ushort8_t){0, 0, 0, 0, 0, 0, 0, 0};
+    const int bn = b + nwaves;
+    if (bn < B) issue(bn);
+    float16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      acc = Mfma32<DT>::run(cur[k], cur[k], acc);
+      if (row == 0) *(ushort8_t*)(so + k * 16 + h * 8) = cur[k];   // bottom-MLP slice = row 0 of X
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int j = row;
+      if (i < R && j < i) so[C + i * (i - 1) / 2 + j] = Elem<DT>::from_f32(acc[r]);
+    }
+    for (int p = C + ntril + lane; p < OW; p += 64) so[p] = 0;
+    unsigned short* o = out + (size_t)b * OW;
+    for (int q = lane * 8; q < OW; q += 512) *(ushort8_t*)(o + q) = *(const ushort8_t*)(so + q);
+  }
+}
+
 // ------------------------------------------------------------------ backward, MFMA path
 // requires R <= 32, C % 32 == 0, C <= 256, OW % 8 == 0.
 #define DOT_BWD_USTRIDE 40   // halves per U row (32 + 8 pad -> 80 B, keeps 16 B alignment)
@@ -349,7 +398,17 @@ extern "C" int dle_dot_interact_fwd(const void* x, void* out, int batch, int row
     const size_t lds = (size_t)4 * OW * 2;
     DLE_CHECK_ARG(lds <= 64 * 1024, "dot_interact_fwd: row too wide for LDS (%d)", OW);
     dim3 grid((batch + 3) / 4), block(256);
-    if (dtype == DLE_F16)
+    // persistent walk with register prefetch for the widths of the metric (C = 128) and its neighbours
+    static const int walk = getenv("DLE_DOT_FWD_WALK") ? atoi(getenv("DLE_DOT_FWD_WALK")) : 1;
+    static const int per_cu = getenv("DLE_DOT_FWD_WG_PER_CU") ? atoi(getenv("DLE_DOT_FWD_WG_PER_CU")) : 2;     // (65536 x 27 x 128: 92 us at 2, 97 at 3, 103 at 4-8; one-shot form 125)
+    if (walk && (cols == 64 || cols == 128) && batch >= 4096) {
+      dim3 wgrid((unsigned)(grid.x < 256u * per_cu ? grid.x : 256u * per_cu));
+#define GOW(DT, NK) hipLaunchKernelGGL((dot_fwd_mfma_walk<DT, NK>), wgrid, block, lds, stream, (const unsigned short*)x, \
+                                       (unsigned short*)out, batch, rows, OW)
+      if (dtype == DLE_F16) { if (cols == 64) GOW(DLE_F16, 4); else GOW(DLE_F16, 8); }
+      else { if (cols == 64) GOW(DLE_BF16, 4); else GOW(DLE_BF16, 8); }
+#undef GOW
+    } else if (dtype == DLE_F16)
       hipLaunchKernelGGL(dot_fwd_mfma<DLE_F16>, grid, block, lds, stream, (const unsigned short*)x,
                          (unsigned short*)out, batch, rows, cols, OW);
     else

@@ -26,7 +26,8 @@ def _round(x, dtype):
 
 # (batch, rows, cols): the reference's test grid (dot_based_interact_ops_test.py:89-112) + Criteo shape
 SHAPES = [(16, 32, 32), (17, 31, 37), (15, 31, 37), (16, 31, 33), (16, 32, 31), (8, 27, 128), (5, 27, 128),
-          (3, 2, 8), (4, 27, 16), (1, 1, 16), (2048, 27, 128)]
+          (3, 2, 8), (4, 27, 16), (1, 1, 16), (2048, 27, 128),
+          (4099, 27, 128), (9001, 20, 64)]      # >= 4096 samples: the persistent forward walk (ragged last round of wavefronts)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
