@@ -34,7 +34,8 @@ extern "C" int dle_gemm8_try(const void* A, const void* B, void* C, void* aux, c
   if (dle_gemm8_mode(-1) <= 0) return 0;
   if (in_dtype != DLE_F16 && in_dtype != DLE_BF16) return 0;
   if (!a_kc && b_kc) return 0;
-  if (M < 256 || N < 256 || K < 2 * BK || (K % BK) != 0 || (N & 7) != 0) return 0;
+  if (M < 256 || N < 256 || K < 2 * BK || (K & 7) != 0 || (N & 7) != 0) return 0;
+  if ((K % BK) != 0 && !(a_kc && lda >= K && (!b_kc || ldb >= K))) return 0;      // (K tail: per-lane predicate of k-contiguous operands)
   if (!a_kc && (M & 7) != 0) return 0;
   const bool al = ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)aux) | ((uintptr_t)src) | ((uintptr_t)bias) |
                     ((uintptr_t)ws)) & 15) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && (ldc & 7) == 0;
@@ -46,7 +47,7 @@ extern "C" int dle_gemm8_try(const void* A, const void* B, void* C, void* aux, c
   if ((a_rows + 256) * lda * 2 >= 0xFFFFFFFFLL || (b_rows + 256) * ldb * 2 >= 0xFFFFFFFFLL) return 0;
   if ((long long)M * ldc * 4 >= 0x7FFFFFFFFFFFLL) return 0;
   if (splitk < 1) splitk = 1;
-  const int ktiles = K / BK;
+  const int ktiles = (K + BK - 1) / BK;
   if (splitk > ktiles) return 0;
   int epi;
   if (splitk > 1) {

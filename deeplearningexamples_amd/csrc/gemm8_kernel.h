@@ -178,7 +178,7 @@ struct G8Lane {
         const int r = (wave * 2 + j) * 8 + (lane >> 3), cpos = lane & 7;
         const int chunk = cpos ^ swz_kc(r);
         voff[j] = (unsigned)(((long long)r * ld + chunk * 8) * 2);
-        c8[j] = 0;
+        c8[j] = chunk * 8;            // k-contiguous operands: the lane's k offset inside the K tile (K tail predicate)
       } else {
         const int kr = (wave * 2 + j) * 4 + (lane >> 4), cpos = lane & 15;
         const int chunk = (((cpos >> 1) ^ swz_rc<128>(kr)) << 1) | (cpos & 1);
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
 
   const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
   const int ntiles = tiles_m * tiles_n, nitems = ntiles * p.splitk;
-  const int ktiles = p.K / BK;
+  const int ktiles = (p.K + BK - 1) / BK;            // (K % 64 != 0: the chunks of the last K tile past K read zero, stage_piece)
   const int GM = p.gm;
   // item -> (tile, K slice).  Each XCD (private L2) owns a contiguous chunk of the item list; inside it, tiles are ordered in
   // groups of GM tile rows walked column by column (gemm_dma.hip: tile_coords), K slices slowest.
@@ -290,8 +290,9 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     rs.w = 0x00020000;
     const unsigned dst = lds0 + (unsigned)(c_par * G8_BUF + (OP == 0 ? 0 : 2 * G8_HALF) + HF * G8_HALF + wave * 1024) * 2u;
     unsigned vo;
-    if constexpr (OP == 0) vo = (MODE == 0 || R0 + la.c8[j] < nrows) ? la.voff[j] : OOB_OFF;
-    else vo = (MODE == 0 || R0 + lb.c8[j] < nrows) ? lb.voff[j] : OOB_OFF;
+    // row-contiguous: the lane's 8 rows are inside the operand; k-contiguous: its 8 k values are below K (rows: range check)
+    if constexpr (OP == 0) vo = ((MODE == 0 ? c_k0 + la.c8[j] < p.K : R0 + la.c8[j] < nrows)) ? la.voff[j] : OOB_OFF;
+    else vo = ((MODE == 0 ? c_k0 + lb.c8[j] < p.K : R0 + lb.c8[j] < nrows)) ? lb.voff[j] : OOB_OFF;
     g8_dma(rs, dst + j * 1024, vo);
   };
   auto stage = [&](auto OPC, auto HFC) __attribute__((always_inline)) {

@@ -145,6 +145,9 @@ def main():
     case("ragged_tn_splitk2_acc", 264, 1000, 2048, "tn", splitk=2, accumulate=True, do_time=False)
     case("tn_f32_nosplit_acc", 512, 768, 640, "tn", out_f32=True, accumulate=True, do_time=False)
     case("nn_mul_colsum", 1024, 512, 256, "nn", act=C.ACT_MUL, src=True, colsum=True, do_time=False)
+    case("ktail_nt_bias_relu_f16", 1000, 1024, 480, "nt", dtype=hf, bias=True, act=C.ACT_RELU, do_time=False)
+    case("ktail_nn_add", 777, 520, 1000, "nn", act=C.ACT_ADD, src=True, do_time=False)
+    case("dlrm_top0_fwd_f16", 65536, 1024, 480, "nt", dtype=hf, bias=True, act=C.ACT_RELU)
     # the layers of the metric workloads
     case("bert_ffn1_fwd", 32768, 4096, 1024, "nt", bias=True, act=C.ACT_GELU_DAUX, aux=True)
     case("bert_plain_fwd", 32768, 4096, 1024, "nt")
