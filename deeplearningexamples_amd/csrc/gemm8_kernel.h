@@ -30,7 +30,18 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_ADD = 4, 
 #define G8_HALF 8192                 // 16-bit elements per half-tile image (128 rows x 64 k)
 #define G8_BUF (4 * G8_HALF)         // one K tile: A0 | A1 | B0 | B1
 #define G8_STAGE_BYTES (2 * G8_BUF * 2)
-#define G8_LDS_BYTES (G8_STAGE_BYTES + 8 * 256)      // + one 256-byte bias slot per wavefront (EPI 1)
+#define G8_TS_PITCH 80                               // bytes per row of a wavefront's transposition scratch (64 + 16: conflict-free)
+#define G8_TS_BYTES (32 * G8_TS_PITCH)
+#define G8_TS_BASE (G8_STAGE_BYTES + 8 * 256)
+// + one 256-byte bias slot per wavefront (EPI 1) + one 32-row x 64-byte transposition scratch per wavefront (epilogue)
+#define G8_LDS_BYTES (G8_TS_BASE + 8 * G8_TS_BYTES)
+// Lanes exchange data through the scratch without a barrier (one wavefront, in-order LDS): the compiler must be told -- thread
+// by thread it may forward a lane's earlier load over another lane's store (it did: the reads of the second half-block were
+// sunk into the writers' exec-masked region).  A wavefront-scope fence costs no instruction.
+#define G8_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+#ifndef G8_TSTORE
+#define G8_TSTORE 1                                  // 0: probe -- stores in the accumulator layout (2 x 16 bytes per row and instruction)
+#endif
 
 struct Gemm8Args {
   const unsigned short* A;
@@ -48,7 +59,8 @@ struct Gemm8Args {
   float alpha;
   int gm;
   unsigned c_bytes;          // extent of C (and of aux / src, same pitch) in bytes; split-K: of the slab buffer
-  FastDiv d_ntiles, d_group, d_rows_full, d_rows_last, d_splitk;      // item decode without integer division
+  const int* items;          // item table [nitems][4] = {m0, n0, first K tile, (K slice << 16) | K tiles}, in walk order (gemm8.hip)
+  int nitems, grid;
 #ifdef G8_TIMING
   unsigned long long* dbg;   // tools/kbench/gemm8_bench.cpp: shader-clock stamps [block][group][item][4]
   int dbg_items;
@@ -193,6 +205,29 @@ struct G8Lane {
 //  An algebraically shorter form -- hp = 1 - r, 1 - tanh^2 = 4 r hp, 12 instead of 22 operations -- was measured: -7 % epilogue cycles
 //  on the GELU + side-output flavour, whose epilogue is bound by its two stores per block, and one rounding different, which moved
 //  a 2-element gradient of the 24-layer parity test across its bar; not kept.)
+// The epilogue's tanh-GELU on PAIRS of values: v_pk_mul / v_pk_add / v_pk_fma_f32 carry two fp32 lanes per instruction at the
+// scalar rate (the GELU epilogue is VALU-bound: ~20 full-rate operations + exp + rcp per element, 128 elements per lane and tile);
+// per element the same operations in the same order as the scalar forms below (= those of gemm_dma.hip): bit-identical results.
+typedef float float2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2v_t g8_tanh2(float2v_t x) {
+  const float2v_t a = x * 2.885390081777927f;
+  const float2v_t e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+  const float2v_t ep = e + 1.0f;
+  const float2v_t r = {__builtin_amdgcn_rcpf(ep.x), __builtin_amdgcn_rcpf(ep.y)};
+  return 1.0f - 2.0f * r;
+}
+__device__ __forceinline__ float2v_t g8_gelu2(float2v_t x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  return 0.5f * x * (1.0f + g8_tanh2(k0 * (x + k1 * x * x * x)));
+}
+__device__ __forceinline__ float2v_t g8_gelu_d2(float2v_t x, float2v_t& d) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  const float2v_t x2 = x * x;
+  const float2v_t th = g8_tanh2(k0 * (x + k1 * x2 * x));
+  const float2v_t hp = 0.5f * (1.0f + th);
+  d = hp + 0.5f * x * (1.f - th * th) * k0 * (1.f + 3.f * k1 * x2);
+  return x * hp;
+}
 __device__ __forceinline__ float g8_gelu(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
   return 0.5f * x * (1.0f + fast_tanh(k0 * (x + k1 * x * x * x)));
@@ -220,26 +255,20 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
   constexpr bool RCA = AM == 1, RCB = BMD == 1;
   constexpr int NRA = RCA ? 16 : 8;                   // LDS instructions of one A half (8 fragments)
 
-  const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
-  const int ntiles = tiles_m * tiles_n, nitems = ntiles * p.splitk;
-  const int ktiles = (p.K + BK - 1) / BK;            // (K % 64 != 0: the chunks of the last K tile past K read zero, stage_piece)
-  const int GM = p.gm;
-  // item -> (tile, K slice).  Each XCD (private L2) owns a contiguous chunk of the item list; inside it, tiles are ordered in
-  // groups of GM tile rows walked column by column (gemm_dma.hip: tile_coords), K slices slowest.
+  // item -> (tile, K slice): ONE 16-byte scalar load from the table the launcher built for this shape (XCD-chunked order, groups of
+  // gm tile rows walked column by column, K slices slowest -- gemm8.hip: g8_item_table).  Decoding in the kernel (five divisions
+  // by launch constants, even as multiply-high) kept ~18 scalars alive across the K loop or re-loaded them from the argument
+  // segment inside the item switch: 4-8 dependent scalar loads, ~1000 cycles in phase 0 of the K tile in which the stream moves
+  // on to the next item.
+  const int nitems = p.nitems, G = p.grid;
   auto decode = [&](int vb, int& m0, int& n0, int& kt0, int& kt1, int& ky) __attribute__((always_inline)) {
-    const int q = nitems >> 3, r8 = nitems & 7, xcd = vb & 7, loc = vb >> 3;
-    int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
-    ky = fd_div(id, p.d_ntiles);
-    id -= ky * ntiles;
-    const int per_group = GM * tiles_n;
-    const int g = fd_div(id, p.d_group), r = id - g * per_group;
-    const bool last = (tiles_m - g * GM) < GM;          // the last, shorter group of tile rows
-    const int rows = last ? (tiles_m - g * GM) : GM;
-    const int tn = last ? fd_div(r, p.d_rows_last) : fd_div(r, p.d_rows_full), tm = g * GM + (r - tn * rows);
-    m0 = tm << 8;
-    n0 = tn << 8;
-    kt0 = fd_div(ky * ktiles, p.d_splitk);              // (splitk * ktiles < 2^31: launcher)
-    kt1 = fd_div((ky + 1) * ktiles, p.d_splitk);
+    typedef const __attribute__((address_space(4))) int4v_t* items_p;
+    const int4v_t r = ((items_p)p.items)[vb];
+    m0 = r.x;
+    n0 = r.y;
+    kt0 = r.z;
+    kt1 = r.z + (r.w & 0xFFFF);
+    ky = (int)((unsigned)r.w >> 16);
   };
 
   G8Lane<AM> la;
@@ -266,7 +295,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     c_par ^= 1;
     c_k0 += BK;
     if (c_k0 >= c_kend) {
-      c_item += (int)gridDim.x;
+      c_item += G;
       cursor_load();
     }
   };
@@ -456,7 +485,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
 #ifdef G8_TIMING
   int item_seq = 0;
 #endif
-  for (int it = blockIdx.x; it < nitems; it += (int)gridDim.x) {
+  for (int it = blockIdx.x; it < nitems; it += G) {
     int m0, n0, kt0, kt1, ky;
     decode(it, m0, n0, kt0, kt1, ky);
     G8_STAMP(0);
@@ -482,21 +511,31 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
         g8_dma4(rsb, lds0 + G8_STAGE_BYTES + (unsigned)wave * 256u, col * 4u);
       }
     }
+#ifdef G8_TIMING_KT
+#define G8_KT_STAMP(k) do { if (item_seq == G8_TIMING_KT && (k) < 60 && (wave & 3) == 0 && lane == 0 && p.dbg) \
+    p.dbg[((((long long)blockIdx.x * 2 + wr) * p.dbg_items) + p.dbg_items - 16) * 4 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define G8_KT_STAMP(k) do { } while (0)
+#endif
+    G8_KT_STAMP(0);
     ktile(cpar, std::integral_constant<bool, true>(), std::integral_constant<bool, true>(), st_keep);
     cpar ^= 1;
     for (int kt = kt0 + 1; kt < kt1; ++kt) {
-#ifdef G8_TIMING_KT
-      if (item_seq == G8_TIMING_KT && kt - kt0 < 60 && (wave & 3) == 0 && lane == 0 && p.dbg)
-        p.dbg[((((long long)blockIdx.x * 2 + wr) * p.dbg_items) + p.dbg_items - 16) * 4 + (kt - kt0)] = __builtin_readcyclecounter();
-#endif
+      G8_KT_STAMP(kt - kt0);
       ktile(cpar, std::integral_constant<bool, false>(), std::integral_constant<bool, false>(), false);
       cpar ^= 1;
     }
+    G8_KT_STAMP(kt1 - kt0);
     // the one half-tile slot that is free now (A1 of the K tile just finished) is refilled BEFORE the stores below
     stage(I0(), I1());
     cursor_next();
     st_keep = interior;                                // interior tile: every store instruction below is issued
     G8_STAMP(1);
+    // The two groups run their epilogues AT THE SAME TIME: group 0 (one barrier ahead) gives group 1 the barrier its last MFMA
+    // phase is waiting on before it starts storing, group 1 gives one back after its stores (below), so the stagger of the K
+    // loop is the same on the other side.  Without the pair group 1 sat at that barrier through group 0's epilogue and group 0
+    // sat in phase 0 of the next tile through group 1's: two epilogues back to back per item with the matrix cores idle.
+    if (wr == 0) G8_BARRIER();
 
     // The epilogue's arguments (output / side / source pointers, pitch, bias, flags) are read from the kernel-argument segment
     // HERE, once per item, through a pointer the compiler cannot see through: kept in scalar registers across the K loop they
@@ -541,25 +580,82 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
       };
       if (f32o) {
         if constexpr (EPI == 0) {
+          // fp32 output (split-K slab / fp32 C): 128 bytes per row of a block.  Same exchange as the 16-bit path below, half a
+          // block (16 rows x 144-byte pitch) at a time: a store instruction then carries 8 full rows of 128 bytes instead of
+          // 32 rows x two separate 16-byte pieces.
+          unsigned char* ts = smem_raw + G8_TS_BASE + wave * G8_TS_BYTES;
+          const unsigned tw = (unsigned)(fr & 15) * 144u + (unsigned)fh * 64u;
+          const unsigned tr = (unsigned)(lane >> 3) * 144u + (unsigned)(lane & 7) * 16u;
+          const unsigned lane_off_f = (unsigned)(lane >> 3) * pitch + (unsigned)(lane & 7) * 16u;
           static_for<0, 8>([&](auto BI) __attribute__((always_inline)) {
             constexpr int bi = decltype(BI)::value, i = bi >> 2, j = (bi >> 1) & 1, b = bi & 1;
             const unsigned so = blk_off(i, j, b);
+            if constexpr (G8_TSTORE) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float4_t v = {acc[i][j][b][4 * q], acc[i][j][b][4 * q + 1], acc[i][j][b][4 * q + 2], acc[i][j][b][4 * q + 3]};
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v), rc, lane_off + so + 16 * q, 0, 0);
+              for (int h = 0; h < 2; ++h) {
+                if ((fr >> 4) == h) {
+#pragma unroll
+                  for (int q = 0; q < 4; ++q)
+                    *(float4_t*)(ts + tw + 16 * q) = (float4_t){acc[i][j][b][4 * q], acc[i][j][b][4 * q + 1], acc[i][j][b][4 * q + 2],
+                                                                acc[i][j][b][4 * q + 3]};
+                }
+                G8_WAVE_FENCE();
+                const float4_t t0 = *(const float4_t*)(ts + tr), t1 = *(const float4_t*)(ts + tr + 8 * 144);
+                G8_WAVE_FENCE();
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t0), rc, lane_off_f + so + (unsigned)(16 * h) * pitch, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t1), rc, lane_off_f + so + (unsigned)(16 * h + 8) * pitch, 0, 0);
+              }
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float4_t v = {acc[i][j][b][4 * q], acc[i][j][b][4 * q + 1], acc[i][j][b][4 * q + 2], acc[i][j][b][4 * q + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v), rc, lane_off + so + 16 * q, 0, 0);
+              }
             }
           });
         }
       } else {
+        // 16-bit output / side output / source tensor move through HBM in ROW-CONTIGUOUS pieces: lane l of a store (load)
+        // instruction carries bytes 16 (l & 3) .. + 15 of row l >> 2 (+ 16 for the second instruction) of the wavefront's
+        // 32 x 32 block -- 64 contiguous bytes per row, 16 rows per instruction.  In the accumulator layout a lane owns 32
+        // bytes of ONE row in two registers quads: an instruction then touches 32 rows with two separate 16-byte pieces each,
+        // 32 half-filled 64-byte requests, and the L2 request rate (not bytes) bounded the epilogue at ~15 bytes / clock / CU:
+        // 8.9 k cycles for the two groups' halves of a tile, 3.6 k with this pattern.  The exchange between the two layouts goes
+        // through a per-wavefront LDS scratch (32 rows x 80 bytes; written and read by this wavefront only: LDS instructions
+        // of one wavefront execute in order, no barrier).
+        unsigned char* ts = smem_raw + G8_TS_BASE + wave * G8_TS_BYTES;
+        const unsigned ts_acc = (unsigned)fr * G8_TS_PITCH + (unsigned)fh * 32u;                 // accumulator layout
+        const unsigned ts_row = (unsigned)(lane >> 2) * G8_TS_PITCH + (unsigned)(lane & 3) * 16u;  // memory layout (+ 16 rows)
+        const unsigned lane_off_t = G8_TSTORE ? (unsigned)(lane >> 2) * pitch + (unsigned)(lane & 3) * 16u : lane_off;
+        const unsigned second_t = G8_TSTORE ? 16u * pitch : 16u;
+        auto to_rows = [&](ushort8_t& a, ushort8_t& b2) __attribute__((always_inline)) {          // accumulator -> memory layout
+          if constexpr (G8_TSTORE) {
+            *(ushort8_t*)(ts + ts_acc) = a;
+            *(ushort8_t*)(ts + ts_acc + 16) = b2;
+            G8_WAVE_FENCE();
+            a = *(const ushort8_t*)(ts + ts_row);
+            b2 = *(const ushort8_t*)(ts + ts_row + 16 * G8_TS_PITCH);
+            G8_WAVE_FENCE();
+          }
+        };
+        auto from_rows = [&](ushort8_t& a, ushort8_t& b2) __attribute__((always_inline)) {        // memory -> accumulator layout
+          if constexpr (G8_TSTORE) {
+            *(ushort8_t*)(ts + ts_row) = a;
+            *(ushort8_t*)(ts + ts_row + 16 * G8_TS_PITCH) = b2;
+            G8_WAVE_FENCE();
+            a = *(const ushort8_t*)(ts + ts_acc);
+            b2 = *(const ushort8_t*)(ts + ts_acc + 16);
+            G8_WAVE_FENCE();
+          }
+        };
         ushort8_t sv[EPI == 2 ? 8 : 1][2];
         if constexpr (EPI == 2) {
           __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)e_src, 0, (int)e_cbytes, 0x00020000);
           static_for<0, 8>([&](auto BI) __attribute__((always_inline)) {
             constexpr int bi = decltype(BI)::value, i = bi >> 2, j = (bi >> 1) & 1, b = bi & 1;
             const unsigned so = blk_off(i, j, b);
-            sv[bi][0] = __builtin_bit_cast(ushort8_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, lane_off, so, 0));
-            sv[bi][1] = __builtin_bit_cast(ushort8_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, lane_off + 16, so, 0));
+            sv[bi][0] = __builtin_bit_cast(ushort8_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, lane_off_t, so, 0));
+            sv[bi][1] = __builtin_bit_cast(ushort8_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, lane_off_t + second_t, so, 0));
           });
         }
         __amdgpu_buffer_rsrc_t ra = rc;
@@ -588,20 +684,34 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
               for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
             } else if (ACT == ACT_GELU) {
 #pragma unroll
-              for (int r = 0; r < 16; ++r) v[r] = g8_gelu(v[r]);
+              for (int r = 0; r < 16; r += 2) {
+                const float2v_t y2 = g8_gelu2((float2v_t){v[r], v[r + 1]});
+                v[r] = y2.x; v[r + 1] = y2.y;
+              }
             } else if (ACT == ACT_TANH) {
 #pragma unroll
-              for (int r = 0; r < 16; ++r) v[r] = fast_tanh(v[r]);
+              for (int r = 0; r < 16; r += 2) {
+                const float2v_t y2 = g8_tanh2((float2v_t){v[r], v[r + 1]});
+                v[r] = y2.x; v[r + 1] = y2.y;
+              }
             } else if (ACT == ACT_GELU_DAUX) {
 #pragma unroll
-              for (int r = 0; r < 16; ++r) v[r] = g8_gelu_d(v[r], side[r]);
+              for (int r = 0; r < 16; r += 2) {
+                float2v_t d2;
+                const float2v_t y2 = g8_gelu_d2((float2v_t){v[r], v[r + 1]}, d2);
+                v[r] = y2.x; v[r + 1] = y2.y;
+                side[r] = d2.x; side[r + 1] = d2.y;
+              }
             }
             if (e_aux) {
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, pack8<DT>(side)), ra, lane_off + so, 0, 0);
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, pack8<DT>(side + 8)), ra, lane_off + so + 16, 0, 0);
+              ushort8_t x0 = pack8<DT>(side), x1 = pack8<DT>(side + 8);
+              to_rows(x0, x1);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, x0), ra, lane_off_t + so, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, x1), ra, lane_off_t + so + second_t, 0, 0);
             }
           } else if constexpr (EPI == 2) {
             float y[16];
+            from_rows(sv[bi][0], sv[bi][1]);
             unpack8<DT>(sv[bi][0], y);
             unpack8<DT>(sv[bi][1], y + 8);
             if (ACT == ACT_RELU_BWD) {
@@ -626,8 +736,12 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
             }
           }
           const ushort8_t o0 = pack8<DT>(v), o1 = pack8<DT>(v + 8);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o0), rc, lane_off + so, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o1), rc, lane_off + so + 16, 0, 0);
+          {
+            ushort8_t t0 = o0, t1 = o1;
+            to_rows(t0, t1);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t0), rc, lane_off_t + so, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t1), rc, lane_off_t + so + second_t, 0, 0);
+          }
           if constexpr (EPI == 2) {
             if (q->stats) {
               float vr[16];
@@ -792,6 +906,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
         }
       }
     }
+    if (wr == 1) G8_BARRIER();          // (the other half of the epilogue's barrier pair)
 #ifdef G8_TIMING
     G8_STAMP(2);
     ++item_seq;

@@ -80,11 +80,11 @@ int main(int argc, char** argv) {
     }
   }
 #ifdef G8_TIMING_KT
-  {  // per-K-tile stamps of item G8_TIMING_KT (slots NI-16.. hold up to 60 stamps; stamp k is taken BEFORE K tile k, k >= 1)
+  {  // per-K-tile stamps of item G8_TIMING_KT (slots NI-16.. hold up to 60 stamps; stamp k is taken BEFORE K tile k; the last one after the loop)
     const int base = NI - 16;
     for (int g = 0; g < 2; ++g) {
-      printf("  group %d, item %d: cycles per K tile (mean over blocks), K tiles 1..:", g, G8_TIMING_KT);
-      for (int k = 1; k < 59; ++k) {
+      printf("  group %d, item %d: cycles per K tile (mean over blocks), K tiles 0..:", g, G8_TIMING_KT);
+      for (int k = 0; k < 59; ++k) {
         double d = 0; int n = 0;
         for (int b = 0; b < NB; ++b) {
           const unsigned long long* q = &h[(((size_t)b * 2 + g) * NI + base) * 4];
