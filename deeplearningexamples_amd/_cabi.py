@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdle_mi355x.so")
+# DLE_LIB_PATH: another build of the same library (tools/build_lib_at.sh <git revision>) -- same-box A/B of two source trees
+LIB_PATH = os.environ.get("DLE_LIB_PATH") or os.path.join(_HERE, "lib", "libdle_mi355x.so")
 
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_ADD, ACT_GELU_BWD, ACT_TANH, ACT_TANH_BWD = 0, 1, 2, 3, 4, 5, 6, 7

@@ -82,6 +82,9 @@ struct Gemm8Args {
 #ifndef G8_ST_KEEP
 #define G8_ST_KEEP 16                  // store instructions per wavefront of an interior tile's epilogue (lower bound over all flavours)
 #endif
+#ifndef G8_PH16
+#define G8_PH16 1                      // 1: two 16-MFMA segments per K tile and group (ktile16 below); 0: four 8-MFMA phases
+#endif
 #ifndef G8_DMA_SLOT0
 #define G8_DMA_SLOT0 1
 #define G8_DMA_SLOT1 4
@@ -479,6 +482,82 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     G8_BARRIER();
   };
 
+  // ---- the same K tile as TWO segments of 16 MFMAs per group: {C00, C01} from A0 x {B0, B1}, then {C10, C11} from A1 x {B0, B1}
+  // (the B fragments stay in registers).  What a segment costs beyond its MFMA time -- the barrier round trip, the partner's
+  // load segment on the same SIMD, the change of roles: ~70 cycles -- is paid 4 times per K tile instead of 8.
+  //   load segment X(t): reads B0, A0, B1 of K tile t | streams A1(t + 1) into the slot A1(t - 1) left (then the cursor moves on)
+  //   load segment Y(t): reads A1 of K tile t         | streams B0, A0, B1 of K tile t + 2 into the slots X(t) has just read
+  // WAR: a load segment retires its reads (lgkmcnt(0)) BEFORE its closing barrier; the other group's next load segment, which
+  //   is the first that can restage those slots, starts behind that barrier.
+  // RAW: X(t + 1)'s half-tiles were issued in Y(t - 1), A1(t + 1) in X(t): at the end of every load segment exactly 8 younger
+  //   pieces are in flight behind the half-tiles the NEXT load segment reads -- vmcnt(8), then the closing barrier (both groups'
+  //   waits precede the barrier in front of the first read).
+  // After an interior tile's epilogue the three following load segments wait for half-tiles that are OLDER than its stores (the
+  //   hoisted A1 piece, the previous Y segment's pieces): vmcnt(8 + G8_ST_KEEP) leaves the stores in flight; the fourth needs
+  //   pieces issued behind the stores and waits them out, ~2 K tiles after they were issued.
+  int keep_segments = 0;
+  auto seg_wait = [&]() __attribute__((always_inline)) {
+    if (keep_segments > 0) { --keep_segments; G8_VM(8 + G8_ST_KEEP); }
+    else G8_VM(8);
+  };
+  auto mma16 = [&](auto IC, auto ZC) __attribute__((always_inline)) {
+    constexpr int i = decltype(IC)::value;
+    constexpr bool zc = decltype(ZC)::value;
+    const float16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#if G8_PRIO_MODE == 0 || G8_PRIO_MODE == 2
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        acc[i][0][b] = Mfma32x16<DT>::run(frag_value(fb0[ks]), frag_value(fa[b][ks]), (zc && ks == 0) ? zero : acc[i][0][b]);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        acc[i][1][b] = Mfma32x16<DT>::run(frag_value(fb1[ks]), frag_value(fa[b][ks]), (zc && ks == 0) ? zero : acc[i][1][b]);
+    }
+#if G8_PRIO_MODE == 0
+    __builtin_amdgcn_s_setprio(0);
+#elif G8_PRIO_MODE == 2
+    if (wr == 0) __builtin_amdgcn_s_setprio(0);
+#endif
+  };
+  auto ktile16 = [&](int cpar, auto FIRSTC, auto ZEROC) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(FIRSTC)::value;
+    typedef decltype(ZEROC) ZC;
+    const unsigned short* bufc = lds + cpar * G8_BUF;
+    const unsigned lbase = lds0 + (unsigned)cpar * (G8_BUF * 2u);
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+    // ---- load segment X
+    read_b(I2(), fb0, bufc, lbase);
+    G8_SB();
+    read_a(I0(), bufc, lbase);
+    G8_SB();
+    read_b(I3(), fb1, bufc, lbase);
+    G8_SB();
+    if constexpr (!FIRST) {
+      stage(I0(), I1());
+      cursor_next();
+    }
+    G8_LGKM(0);
+    seg_wait();
+    G8_BARRIER();
+    mma16(I0(), ZC());
+    G8_BARRIER();
+    // ---- load segment Y
+    read_a(I1(), bufc, lbase);
+    G8_SB();
+    stage(I1(), I0());
+    stage(I0(), I0());
+    stage(I1(), I1());
+    G8_LGKM(0);
+    seg_wait();
+    G8_BARRIER();
+    mma16(I1(), ZC());
+    G8_BARRIER();
+  };
+
   const int fr = lane & 31, fh = lane >> 5;
   int cpar = 0;
   bool st_keep = false;
@@ -518,11 +597,13 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
 #define G8_KT_STAMP(k) do { } while (0)
 #endif
     G8_KT_STAMP(0);
-    ktile(cpar, std::integral_constant<bool, true>(), std::integral_constant<bool, true>(), st_keep);
+    if constexpr (G8_PH16) ktile16(cpar, std::integral_constant<bool, true>(), std::integral_constant<bool, true>());
+    else ktile(cpar, std::integral_constant<bool, true>(), std::integral_constant<bool, true>(), st_keep);
     cpar ^= 1;
     for (int kt = kt0 + 1; kt < kt1; ++kt) {
       G8_KT_STAMP(kt - kt0);
-      ktile(cpar, std::integral_constant<bool, false>(), std::integral_constant<bool, false>(), false);
+      if constexpr (G8_PH16) ktile16(cpar, std::integral_constant<bool, false>(), std::integral_constant<bool, false>());
+      else ktile(cpar, std::integral_constant<bool, false>(), std::integral_constant<bool, false>(), false);
       cpar ^= 1;
     }
     G8_KT_STAMP(kt1 - kt0);
@@ -530,6 +611,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     stage(I0(), I1());
     cursor_next();
     st_keep = interior;                                // interior tile: every store instruction below is issued
+    keep_segments = interior ? 3 : 0;
     G8_STAMP(1);
     // The two groups run their epilogues AT THE SAME TIME: group 0 (one barrier ahead) gives group 1 the barrier its last MFMA
     // phase is waiting on before it starts storing, group 1 gives one back after its stores (below), so the stagger of the K
