@@ -82,6 +82,9 @@ struct Gemm8Args {
 #ifndef G8_ST_KEEP
 #define G8_ST_KEEP 16                  // store instructions per wavefront of an interior tile's epilogue (lower bound over all flavours)
 #endif
+#ifndef G8_ST_AUX
+#define G8_ST_AUX 0                    // probe: cache-policy bits of the epilogue's stores (1 = sc0, 2 = nt, 16 = sc1)
+#endif
 #ifndef G8_PH16
 #define G8_PH16 1                      // 1: two 16-MFMA segments per K tile and group (ktile16 below); 0: four 8-MFMA phases
 #endif
@@ -644,8 +647,9 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     // Interior tile, 16-bit output (every flavour) or fp32 output (plain / slab): no per-lane predicate, no 64-bit address
     // arithmetic -- a lane's byte offset inside the tile is a constant (rows fr, columns 16 fh), the block's position is a
     // scalar offset of the buffer instruction; the source tensor of EPI 2 is requested for all 8 blocks before the first use.
+    constexpr bool F32FAST = EPI == 0 || (EPI == 1 && ACT == ACT_NONE);      // fp32 output: plain / slab / bias only
     const bool fastpath = interior && q->alpha == 1.0f && e_cbytes != 0 &&
-                          (q->out_dtype != DLE_F32 ? true : (EPI == 0 && !(q->accumulate && !q->ws)));
+                          (q->out_dtype != DLE_F32 ? true : (F32FAST && !(q->accumulate && !q->ws)));
     if (fastpath) {
       const bool f32o = q->out_dtype == DLE_F32;
       const unsigned esz = f32o ? 4u : 2u;
@@ -661,8 +665,8 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
         return (unsigned)(m0 + i * 128 + wr * 64 + b * 32) * pitch + (unsigned)(n0 + j * 128 + wc * 32) * esz;
       };
       if (f32o) {
-        if constexpr (EPI == 0) {
-          // fp32 output (split-K slab / fp32 C): 128 bytes per row of a block.  Same exchange as the 16-bit path below, half a
+        if constexpr (F32FAST) {
+          // fp32 output (split-K slab / fp32 C (+ bias: the MLM decoder)): 128 bytes per row of a block.  Same exchange as the 16-bit path below, half a
           // block (16 rows x 144-byte pitch) at a time: a store instruction then carries 8 full rows of 128 bytes instead of
           // 32 rows x two separate 16-byte pieces.
           unsigned char* ts = smem_raw + G8_TS_BASE + wave * G8_TS_BYTES;
@@ -677,21 +681,28 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
               for (int h = 0; h < 2; ++h) {
                 if ((fr >> 4) == h) {
 #pragma unroll
-                  for (int q = 0; q < 4; ++q)
-                    *(float4_t*)(ts + tw + 16 * q) = (float4_t){acc[i][j][b][4 * q], acc[i][j][b][4 * q + 1], acc[i][j][b][4 * q + 2],
-                                                                acc[i][j][b][4 * q + 3]};
+                  for (int q = 0; q < 4; ++q) {
+                    float4_t v = {acc[i][j][b][4 * q], acc[i][j][b][4 * q + 1], acc[i][j][b][4 * q + 2], acc[i][j][b][4 * q + 3]};
+                    if constexpr (EPI == 1) {
+                      if (e_bias) v += *(const float4_t*)((const float*)(smem_raw + G8_STAGE_BYTES + wave * 256) + j * 32 + fh * 16 + 4 * q);
+                    }
+                    *(float4_t*)(ts + tw + 16 * q) = v;
+                  }
                 }
                 G8_WAVE_FENCE();
                 const float4_t t0 = *(const float4_t*)(ts + tr), t1 = *(const float4_t*)(ts + tr + 8 * 144);
                 G8_WAVE_FENCE();
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t0), rc, lane_off_f + so + (unsigned)(16 * h) * pitch, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t1), rc, lane_off_f + so + (unsigned)(16 * h + 8) * pitch, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t0), rc, lane_off_f + so + (unsigned)(16 * h) * pitch, 0, G8_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t1), rc, lane_off_f + so + (unsigned)(16 * h + 8) * pitch, 0, G8_ST_AUX);
               }
             } else {
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                const float4_t v = {acc[i][j][b][4 * q], acc[i][j][b][4 * q + 1], acc[i][j][b][4 * q + 2], acc[i][j][b][4 * q + 3]};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v), rc, lane_off + so + 16 * q, 0, 0);
+                float4_t v = {acc[i][j][b][4 * q], acc[i][j][b][4 * q + 1], acc[i][j][b][4 * q + 2], acc[i][j][b][4 * q + 3]};
+                if constexpr (EPI == 1) {
+                  if (e_bias) v += *(const float4_t*)((const float*)(smem_raw + G8_STAGE_BYTES + wave * 256) + j * 32 + fh * 16 + 4 * q);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v), rc, lane_off + so + 16 * q, 0, G8_ST_AUX);
               }
             }
           });
@@ -788,8 +799,8 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
             if (e_aux) {
               ushort8_t x0 = pack8<DT>(side), x1 = pack8<DT>(side + 8);
               to_rows(x0, x1);
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, x0), ra, lane_off_t + so, 0, 0);
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, x1), ra, lane_off_t + so + second_t, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, x0), ra, lane_off_t + so, 0, G8_ST_AUX);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, x1), ra, lane_off_t + so + second_t, 0, G8_ST_AUX);
             }
           } else if constexpr (EPI == 2) {
             float y[16];
@@ -821,8 +832,8 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
           {
             ushort8_t t0 = o0, t1 = o1;
             to_rows(t0, t1);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t0), rc, lane_off_t + so, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t1), rc, lane_off_t + so + second_t, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t0), rc, lane_off_t + so, 0, G8_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t1), rc, lane_off_t + so + second_t, 0, G8_ST_AUX);
           }
           if constexpr (EPI == 2) {
             if (q->stats) {
