@@ -6,7 +6,9 @@
 #   traffic  tools/collect_traffic.sh rn50 bert dlrm -> gpurun_out/traffic_new.json
 #   gemm     tools/gemm8_check.py full, tools/gemm8_ksweep.py, tools/gemm8_splitk_sweep.py
 #   tests    tail of pytest -m gpu
+#   W="bert dlrm" limits the prof / traffic sections to those workloads
 R=${GRAFT_REPO_ROOT:-/root/repo}
+W=${W:-rn50 bert dlrm}
 cd $R; mkdir -p gpurun_out
 for sec in "$@"; do case $sec in
 bench)
@@ -14,10 +16,10 @@ bench)
   cp gpurun_out/bench_detail.json gpurun_out/r05_bench_default_detail.json
   tail -c 3000 gpurun_out/r05_bench_default.json ;;
 prof)
-  tools/profile_all.sh r05 rn50 bert dlrm
-  for w in rn50 bert dlrm; do mv gpurun_out/r05_${w}_kernel_stats.txt gpurun_out/r05_${w}_kernel_stats_multi_stream.txt; mv gpurun_out/r05_${w}_bench_under_rocprof.json gpurun_out/r05_${w}_bench_under_rocprof_multi_stream.json; done
-  DLE_RN50_WGRAD_STREAM=0 DLE_RN50_BRANCH_STREAM=0 DLE_BERT_WGRAD_STREAM=0 DLE_DLRM_TWO_STREAMS=0 tools/profile_all.sh r05 rn50 bert dlrm
-  for w in rn50 bert dlrm; do mv gpurun_out/r05_${w}_kernel_stats.txt gpurun_out/r05_${w}_kernel_stats_single_stream.txt; mv gpurun_out/r05_${w}_bench_under_rocprof.json gpurun_out/r05_${w}_bench_single_stream.json; done
+  tools/profile_all.sh r05 $W
+  for w in $W; do mv gpurun_out/r05_${w}_kernel_stats.txt gpurun_out/r05_${w}_kernel_stats_multi_stream.txt; mv gpurun_out/r05_${w}_bench_under_rocprof.json gpurun_out/r05_${w}_bench_under_rocprof_multi_stream.json; done
+  DLE_RN50_WGRAD_STREAM=0 DLE_RN50_BRANCH_STREAM=0 DLE_BERT_WGRAD_STREAM=0 DLE_DLRM_TWO_STREAMS=0 tools/profile_all.sh r05 $W
+  for w in $W; do mv gpurun_out/r05_${w}_kernel_stats.txt gpurun_out/r05_${w}_kernel_stats_single_stream.txt; mv gpurun_out/r05_${w}_bench_under_rocprof.json gpurun_out/r05_${w}_bench_single_stream.json; done
   head -30 gpurun_out/r05_bert_kernel_stats_single_stream.txt ;;
 pmc)
   B=$R/tools/kbench/bin/gemm8_bench_plain
@@ -29,7 +31,7 @@ pmc)
       echo "== gemm8_bench $c"; tools/pmc_bin.sh gemm8 "$G" -- $B $c; done; } > gpurun_out/r05_pmc_gemm8.txt 2>&1
   tail -40 gpurun_out/r05_pmc_gemm8.txt ;;
 traffic)
-  tools/collect_traffic.sh rn50 bert dlrm > gpurun_out/r05_traffic_collect.log 2>&1; tail -5 gpurun_out/r05_traffic_collect.log ;;
+  tools/collect_traffic.sh $W > gpurun_out/r05_traffic_collect.log 2>&1; tail -5 gpurun_out/r05_traffic_collect.log ;;
 gemm)
   python tools/gemm8_check.py full 2>/dev/null | grep -v amdgpu > gpurun_out/r05_gemm8_vs_tile_kernels.jsonl
   { python tools/gemm8_ksweep.py 4096 4096; python tools/gemm8_ksweep.py 32768 4096; } 2>/dev/null | grep -v amdgpu > gpurun_out/r05_gemm8_ksweep.jsonl
