@@ -26,50 +26,6 @@ static int g8_launch_epi0(const Gemm8Args* p, int dt, int am, int bm, int grid, 
   return 1;
 }
 
-// The walk order of a shape as a device table: entry vb = {m0, n0, first K tile, (K slice << 16) | K tiles} of the vb-th item.
-// Each XCD (private L2; workgroup b runs on XCD b % 8) owns a contiguous chunk of the item list; inside it tiles are ordered in
-// groups of gm tile rows walked column by column (the tiles an XCD runs at once form a gm x 32/gm block: per K step they pull
-// gm A half-tiles + a few B ones through L2 instead of 1 + 32), K slices slowest.  Built on the host once per shape, cached.
-#include <map>
-#include <mutex>
-#include <tuple>
-#include <vector>
-static const int* g8_item_table(int M, int N, int ktiles, int splitk, int gm, hipStream_t stream) {
-  typedef std::tuple<int, int, int, int, int, int> Key;
-  static std::map<Key, int*> cache;
-  static std::mutex mu;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const Key key(dev, M, N, ktiles, splitk, gm);
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = cache.find(key);
-  if (it != cache.end()) return it->second;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
-  const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256, ntiles = tiles_m * tiles_n, nitems = ntiles * splitk;
-  std::vector<int> h((size_t)nitems * 4);
-  const int q = nitems >> 3, r8 = nitems & 7;
-  for (int vb = 0; vb < nitems; ++vb) {
-    const int xcd = vb & 7, loc = vb >> 3;
-    int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
-    const int ky = id / ntiles;
-    id -= ky * ntiles;
-    const int per_group = gm * tiles_n, g = id / per_group, r = id - g * per_group;
-    const int rows = (tiles_m - g * gm) < gm ? (tiles_m - g * gm) : gm;
-    const int tn = r / rows, tm = g * gm + (r - tn * rows);
-    const int kt0 = (int)((long long)ky * ktiles / splitk), kt1 = (int)((long long)(ky + 1) * ktiles / splitk);
-    h[4 * vb + 0] = tm * 256;
-    h[4 * vb + 1] = tn * 256;
-    h[4 * vb + 2] = kt0;
-    h[4 * vb + 3] = (ky << 16) | (kt1 - kt0);
-  }
-  int* d = nullptr;
-  if (hipMalloc(&d, h.size() * sizeof(int)) != hipSuccess) return nullptr;
-  if (hipMemcpy(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
-  cache[key] = d;
-  return d;
-}
-
 // 1: launched; 0: outside the envelope (the caller continues with the kernels of gemm_dma.hip); > 1: error.
 // stats != NULL: column sums of the rounded output into stats[2 * ceil(M / 256)][N] (act = ReLU mask / stored derivative only).
 extern "C" int dle_gemm8_try(const void* A, const void* B, void* C, void* aux, const float* bias, const void* src, int M, int N,
@@ -118,7 +74,7 @@ extern "C" int dle_gemm8_try(const void* A, const void* B, void* C, void* aux, c
   const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
   const long long nitems = tiles * splitk;
   static const int min_items = getenv("DLE_GEMM_8PH_MIN_ITEMS") ? atoi(getenv("DLE_GEMM_8PH_MIN_ITEMS")) : 128;
-  if (nitems < min_items || nitems > (1 << 22) || splitk > 0x7FFF || ktiles > 0xFFFF) return 0;      // (item table fields)
+  if (nitems < min_items || nitems > (1 << 22) || splitk > 0x7FFF || ktiles > 0xFFFF) return 0;      // (walk table fields)
   static const int ncu = [] { int dev = 0, v = 0; hipGetDevice(&dev);
                               hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
   static const int lds_max = [] { int dev = 0, v = 0; hipGetDevice(&dev);
@@ -136,14 +92,14 @@ extern "C" int dle_gemm8_try(const void* A, const void* B, void* C, void* aux, c
     const long long cb = splitk > 1 ? (long long)M * N * 4 : (long long)M * ldc * (out_dtype == DLE_F32 ? 4 : 2);
     p.c_bytes = cb < 0xFFFFFFFFLL ? (unsigned)cb : 0u;           // 0: the interior fast path is off (c_bytes == 0 below)
   }
-  p.items = g8_item_table(M, N, ktiles, splitk, p.gm, stream);
-  if (!p.items) return 0;                                        // (first use of a shape under stream capture: the tile kernels)
   p.nitems = (int)nitems;
+  p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256; p.ktiles = ktiles;
 #ifdef G8_TIMING
   p.dbg = g8_dbg_ptr; p.dbg_items = g8_dbg_items;
 #endif
   const int grid = (int)(nitems < ncu ? nitems : ncu);
   p.grid = grid;
+  if ((nitems + grid - 1) / grid > G8_TBL_ITEMS) return 0;         // (the workgroup's walk table in LDS)
   int launched;
   if (epi == 0) launched = g8_launch_epi0(&p, in_dtype, am, bm, grid, stream);
   else if (epi == 1) launched = g8_launch_epi1(&p, in_dtype, am, bm, act, grid, stream);

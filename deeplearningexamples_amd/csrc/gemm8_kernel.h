@@ -34,7 +34,10 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_ADD = 4, 
 #define G8_TS_BYTES (32 * G8_TS_PITCH)
 #define G8_TS_BASE (G8_STAGE_BYTES + 8 * 256)
 // + one 256-byte bias slot per wavefront (EPI 1) + one 32-row x 64-byte transposition scratch per wavefront (epilogue)
-#define G8_LDS_BYTES (G8_TS_BASE + 8 * G8_TS_BYTES)
+#define G8_TBL_BASE (G8_TS_BASE + 8 * G8_TS_BYTES)
+#define G8_TBL_ITEMS 512                             // items per workgroup the LDS walk table holds (the launcher checks)
+// ... + the workgroup's walk table: 16 bytes per item
+#define G8_LDS_BYTES (G8_TBL_BASE + G8_TBL_ITEMS * 16)
 // Lanes exchange data through the scratch without a barrier (one wavefront, in-order LDS): the compiler must be told -- thread
 // by thread it may forward a lane's earlier load over another lane's store (it did: the reads of the second half-block were
 // sunk into the writers' exec-masked region).  A wavefront-scope fence costs no instruction.
@@ -59,8 +62,8 @@ struct Gemm8Args {
   float alpha;
   int gm;
   unsigned c_bytes;          // extent of C (and of aux / src, same pitch) in bytes; split-K: of the slab buffer
-  const int* items;          // item table [nitems][4] = {m0, n0, first K tile, (K slice << 16) | K tiles}, in walk order (gemm8.hip)
-  int nitems, grid;
+  int nitems, grid;          // (tile, K slice) items; workgroups (= min(nitems, #CUs)): workgroup b walks items b, b + grid, ...
+  int tiles_m, tiles_n, ktiles;
 #ifdef G8_TIMING
   unsigned long long* dbg;   // tools/kbench/gemm8_bench.cpp: shader-clock stamps [block][group][item][4]
   int dbg_items;
@@ -261,20 +264,42 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
   constexpr bool RCA = AM == 1, RCB = BMD == 1;
   constexpr int NRA = RCA ? 16 : 8;                   // LDS instructions of one A half (8 fragments)
 
-  // item -> (tile, K slice): ONE 16-byte scalar load from the table the launcher built for this shape (XCD-chunked order, groups of
-  // gm tile rows walked column by column, K slices slowest -- gemm8.hip: g8_item_table).  Decoding in the kernel (five divisions
-  // by launch constants, even as multiply-high) kept ~18 scalars alive across the K loop or re-loaded them from the argument
-  // segment inside the item switch: 4-8 dependent scalar loads, ~1000 cycles in phase 0 of the K tile in which the stream moves
-  // on to the next item.
-  const int nitems = p.nitems, G = p.grid;
-  auto decode = [&](int vb, int& m0, int& n0, int& kt0, int& kt1, int& ky) __attribute__((always_inline)) {
-    typedef const __attribute__((address_space(4))) int4v_t* items_p;
-    const int4v_t r = ((items_p)p.items)[vb];
-    m0 = r.x;
-    n0 = r.y;
-    kt0 = r.z;
-    kt1 = r.z + (r.w & 0xFFFF);
-    ky = (int)((unsigned)r.w >> 16);
+  // item -> (tile, K slice): the workgroup decodes ITS items once, in parallel (one lane per item), into a table in LDS
+  // {m0, n0, first K tile, (K slice << 16) | K tiles}; the walk reads one 16-byte record per item (same address in every lane:
+  // a broadcast).  Walk order: each XCD (private L2; workgroup b runs on XCD b % 8) owns a contiguous chunk of the item list;
+  // inside it tiles are ordered in groups of gm tile rows walked column by column (the tiles an XCD runs at once form a
+  // gm x 32 / gm block: per K step they pull gm A half-tiles + a few B ones through L2 instead of 1 + 32), K slices slowest.
+  // Decoding inside the walk (five divisions by launch constants, even as multiply-high) kept ~18 scalars alive across the K
+  // loop or re-loaded them from the argument segment inside the item switch: ~1000 cycles in the segment in which the stream
+  // moves on to the next item, and SGPR spills in the flavoured instantiations.
+  const int G = p.grid;
+  const int my_items = __builtin_amdgcn_readfirstlane((p.nitems - (int)blockIdx.x + G - 1) / G);
+  int* tbl = (int*)(smem_raw + G8_TBL_BASE);
+  {
+    const int nitems = p.nitems, ntiles = p.tiles_m * p.tiles_n, q8 = nitems >> 3, r8 = nitems & 7;
+    for (int i = tid; i < my_items; i += 512) {
+      const int vb = (int)blockIdx.x + i * G;
+      const int xcd = vb & 7, loc = vb >> 3;
+      int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+      const int ky = id / ntiles;
+      id -= ky * ntiles;
+      const int per_group = p.gm * p.tiles_n, g = id / per_group, r = id - g * per_group;
+      const int rows = (p.tiles_m - g * p.gm) < p.gm ? (p.tiles_m - g * p.gm) : p.gm;
+      const int tn = r / rows, tm = g * p.gm + (r - tn * rows);
+      const int kt0 = (int)((unsigned)ky * (unsigned)p.ktiles / (unsigned)p.splitk);
+      const int kt1 = (int)((unsigned)(ky + 1) * (unsigned)p.ktiles / (unsigned)p.splitk);
+      *(int4v_t*)(tbl + 4 * i) = (int4v_t){tm * 256, tn * 256, kt0, (ky << 16) | (kt1 - kt0)};
+    }
+  }
+  __syncthreads();
+  auto decode = [&](int li, int& m0, int& n0, int& kt0, int& kt1, int& ky) __attribute__((always_inline)) {
+    const int4v_t r = *(const int4v_t*)(tbl + 4 * li);
+    m0 = __builtin_amdgcn_readfirstlane(r.x);
+    n0 = __builtin_amdgcn_readfirstlane(r.y);
+    kt0 = __builtin_amdgcn_readfirstlane(r.z);
+    const int w = __builtin_amdgcn_readfirstlane(r.w);
+    kt1 = kt0 + (w & 0xFFFF);
+    ky = (int)((unsigned)w >> 16);
   };
 
   G8Lane<AM> la;
@@ -283,10 +308,10 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
   lb.init(wave, lane, p.ldb);
 
   // ---- the operand stream: ONE cursor walks (item, K tile, half-tile) in consumption order B0, A0, B1, A1 -----------------
-  int c_item = blockIdx.x, c_par = 0, c_m0 = 0, c_n0 = 0, c_k0 = 0, c_kend = 0;
+  int c_item = 0, c_par = 0, c_m0 = 0, c_n0 = 0, c_k0 = 0, c_kend = 0;
   bool c_valid = false;
   auto cursor_load = [&]() __attribute__((always_inline)) {
-    c_valid = c_item < nitems;
+    c_valid = c_item < my_items;
     if (c_valid) {
       int kt0, kt1, ky;
       decode(c_item, c_m0, c_n0, kt0, kt1, ky);
@@ -301,7 +326,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     c_par ^= 1;
     c_k0 += BK;
     if (c_k0 >= c_kend) {
-      c_item += G;
+      ++c_item;
       cursor_load();
     }
   };
@@ -567,7 +592,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
 #ifdef G8_TIMING
   int item_seq = 0;
 #endif
-  for (int it = blockIdx.x; it < nitems; it += G) {
+  for (int it = 0; it < my_items; ++it) {
     int m0, n0, kt0, kt1, ky;
     decode(it, m0, n0, kt0, kt1, ky);
     G8_STAMP(0);
