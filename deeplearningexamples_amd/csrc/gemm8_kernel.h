@@ -88,6 +88,9 @@ struct Gemm8Args {
 #ifndef G8_ST_AUX
 #define G8_ST_AUX 0                    // probe: cache-policy bits of the epilogue's stores (1 = sc0, 2 = nt, 16 = sc1)
 #endif
+#ifndef G8_SPLIT44
+#define G8_SPLIT44 0                   // probe: B1 restaged in load segment X (4 + 4 pieces per K tile) instead of Y (2 + 6)
+#endif
 #ifndef G8_PH16
 #define G8_PH16 1                      // 1: two 16-MFMA segments per K tile and group (ktile16 below); 0: four 8-MFMA phases
 #endif
@@ -524,9 +527,10 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
   //   hoisted A1 piece, the previous Y segment's pieces): vmcnt(8 + G8_ST_KEEP) leaves the stores in flight; the fourth needs
   //   pieces issued behind the stores and waits them out, ~2 K tiles after they were issued.
   int keep_segments = 0;
-  auto seg_wait = [&]() __attribute__((always_inline)) {
-    if (keep_segments > 0) { --keep_segments; G8_VM(8 + G8_ST_KEEP); }
-    else G8_VM(8);
+  auto seg_wait = [&](auto NC) __attribute__((always_inline)) {
+    constexpr int N = decltype(NC)::value;
+    if (keep_segments > 0) { --keep_segments; G8_VM(N + G8_ST_KEEP); }
+    else G8_VM(N);
   };
   auto mma16 = [&](auto IC, auto ZC) __attribute__((always_inline)) {
     constexpr int i = decltype(IC)::value;
@@ -564,12 +568,15 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     G8_SB();
     read_b(I3(), fb1, bufc, lbase);
     G8_SB();
+    typedef std::integral_constant<int, 8> W8;
+    typedef std::integral_constant<int, 6> W6;
     if constexpr (!FIRST) {
+      if constexpr (G8_SPLIT44) stage(I1(), I1());
       stage(I0(), I1());
       cursor_next();
     }
     G8_LGKM(0);
-    seg_wait();
+    seg_wait(W8());
     G8_BARRIER();
     mma16(I0(), ZC());
     G8_BARRIER();
@@ -578,9 +585,9 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     G8_SB();
     stage(I1(), I0());
     stage(I0(), I0());
-    stage(I1(), I1());
+    if constexpr (!G8_SPLIT44) stage(I1(), I1());
     G8_LGKM(0);
-    seg_wait();
+    if constexpr (G8_SPLIT44) seg_wait(W6()); else seg_wait(W8());
     G8_BARRIER();
     mma16(I1(), ZC());
     G8_BARRIER();
@@ -636,6 +643,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     }
     G8_KT_STAMP(kt1 - kt0);
     // the one half-tile slot that is free now (A1 of the K tile just finished) is refilled BEFORE the stores below
+    if constexpr (G8_PH16 && G8_SPLIT44) stage(I1(), I1());
     stage(I0(), I1());
     cursor_next();
     st_keep = interior;                                // interior tile: every store instruction below is issued
