@@ -84,6 +84,8 @@ _SIGS = {
     "dle_wgrad1x1_mode": (c_int, [c_int]),
     "dle_wgrad1x1_workspace_for": (c_i64, [c_int, c_int, c_int]),
     "dle_gemm8_mode": (c_int, [c_int]),
+    "dle_gemm8_min_items": (c_int, [c_int]),
+    "dle_gemm8_launch_count": (c_i64, []),
     "dle_wgrad1x1_try": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_i64, c_void_p]),
     "dle_conv3x3_wgrad_workspace": (c_i64, []),
     "dle_conv3x3_wgrad_mode": (c_int, [c_int]),

@@ -10,6 +10,16 @@ extern "C" int dle_gemm8_mode(int mode) {
   return prev;
 }
 
+static int g8_min_items_value = -1;     // -1: read DLE_GEMM_8PH_MIN_ITEMS on first use
+extern "C" int dle_gemm8_min_items(int n) {
+  if (g8_min_items_value < 0) g8_min_items_value = getenv("DLE_GEMM_8PH_MIN_ITEMS") ? atoi(getenv("DLE_GEMM_8PH_MIN_ITEMS")) : 128;
+  const int prev = g8_min_items_value;
+  if (n >= 0) g8_min_items_value = n;
+  return prev;
+}
+static long long g8_launches = 0;
+extern "C" int64_t dle_gemm8_launch_count(void) { return __atomic_load_n(&g8_launches, __ATOMIC_RELAXED); }
+
 #ifdef G8_TIMING
 unsigned long long* g8_dbg_ptr = nullptr;
 int g8_dbg_items = 0;
@@ -73,7 +83,7 @@ extern "C" int dle_gemm8_try(const void* A, const void* B, void* C, void* aux, c
   if (am == 1 && !tn_mode) return 0;
   const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
   const long long nitems = tiles * splitk;
-  static const int min_items = getenv("DLE_GEMM_8PH_MIN_ITEMS") ? atoi(getenv("DLE_GEMM_8PH_MIN_ITEMS")) : 128;
+  const int min_items = dle_gemm8_min_items(-1);
   if (nitems < min_items || nitems > (1 << 22) || splitk > 0x7FFF || ktiles > 0xFFFF) return 0;      // (walk table fields)
   static const int ncu = [] { int dev = 0, v = 0; hipGetDevice(&dev);
                               hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
@@ -107,5 +117,6 @@ extern "C" int dle_gemm8_try(const void* A, const void* B, void* C, void* aux, c
   if (!launched) return 0;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { dle_set_error("gemm8 launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
+  __atomic_fetch_add(&g8_launches, 1, __ATOMIC_RELAXED);
   return 1;
 }

@@ -124,10 +124,15 @@ int dle_gemm(const void* A, const void* B, void* C, void* aux, const float* bias
              const void* mask_src, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
              int a_kc, int b_kc, int in_dtype, int out_dtype, int act, int splitk, int accumulate,
              float alpha, void* workspace, int64_t workspace_bytes, hipStream_t stream);
-/* The big linear layers (M, N >= 256, K a multiple of 64, >= 128 (tile, K slice) items) run on the persistent eight-phase
- * 256 x 256 kernel of csrc/gemm8.hip; dle_gemm8_mode(0 / 1) switches it off / on for A/B measurements and parity tests
- * (-1: query), returns the previous setting; environment default DLE_GEMM_8PH (1). */
+/* The big linear layers (M, N >= 256, K >= 128 and a multiple of 8, >= 128 (tile, K slice) items) run on the persistent
+ * ping-pong 256 x 256 kernel of csrc/gemm8.hip; dle_gemm8_mode(0 / 1) switches it off / on for A/B measurements and parity
+ * tests (-1: query), returns the previous setting; environment default DLE_GEMM_8PH (1).
+ * dle_gemm8_min_items(n): the item count from which dle_gemm routes a shape to that kernel (n < 0: query; environment default
+ * DLE_GEMM_8PH_MIN_ITEMS, 128) -- the parity tests set 1 so that small and ragged shapes reach it; returns the previous value.
+ * dle_gemm8_launch_count(): launches of that kernel by this process so far (tests assert that a call was NOT declined).  */
 int dle_gemm8_mode(int mode);
+int dle_gemm8_min_items(int n);
+int64_t dle_gemm8_launch_count(void);
 /* Epilogues that read mask_src (same shape/ld as C): RELU_BWD (mask by mask_src > 0), ADD (C = acc + mask_src),
  * GELU_BWD (acc * gelu'(mask_src), mask_src = saved pre-activation), TANH_BWD (acc * (1 - mask_src^2)).
  * Batched form (attention contractions, torch.bmm at LanguageModeling/BERT/modeling.py:354,373):

@@ -9,7 +9,7 @@ import json
 import os
 import sys
 
-os.environ.setdefault("DLE_GEMM_8PH_MIN_ITEMS", "1")          # let the small / ragged cases through the new kernel
+os.environ.setdefault("DLE_GEMM_8PH_MIN_ITEMS", "1")          # let the small / ragged cases through the new kernel (read at first use)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch                                                   # noqa: E402
 from deeplearningexamples_amd import functional as F, _cabi as C   # noqa: E402
