@@ -189,20 +189,30 @@ class Rn50Workload:
         self.scaling = "weak"
         self.loss = None
         self.it = 0
+        # DLE_RN50_GRAPH=1: the step captured in a HIP graph (utils/graph.py; the learning rate is a device word written before
+        # every replay).  Opt-in: DESIGN.md section 5 has the A/B.  Multi-rank runs are always eager.
+        from deeplearningexamples_amd.utils.graph import GraphedStep
+        self.graphed = world == 1 and os.environ.get("DLE_RN50_GRAPH", "0") == "1"
+        self._step = GraphedStep(self.trainer.train_step, enabled=self.graphed, warmup_steps=2)
 
     def single_stream(self, on):
         self.trainer.set_side_streams(not on)
 
     def step(self):
+        from deeplearningexamples_amd import _cabi
         self.trainer.set_lr(float(self.lr_fn(self.it, 0)))
-        self.loss = self.trainer.train_step(self.x, self.y)
+        if self.graphed and _cabi._timer is None:          # (the per-launch event pass of bench.py needs real launches)
+            self.loss = self._step(self.x, self.y)
+        else:
+            self.loss = self.trainer.train_step(self.x, self.y)
         self.it += 1
 
     def config(self):
         return {"workload": "ResNet-50 v1.5 (PyTorch/Classification/ConvNets) synthetic ImageNet 224x224, "
                             "label smoothing 0.1, SGD momentum 0.875 (BASELINE.json configs[1])",
                 "batch_per_gpu": self.batch, "global_batch": self.batch * self.world, "image": [3, 224, 224],
-                "layout": "NHWC", "parallelism": "single GPU" if self.world == 1 else "dp%d" % self.world}
+                "layout": "NHWC", "hip_graph": bool(self.graphed),
+                "parallelism": "single GPU" if self.world == 1 else "dp%d" % self.world}
 
     def dtype_name(self):
         return "fp16" if self.dtype == torch.float16 else "bf16"
@@ -241,8 +251,14 @@ class BertWorkload:
         self.dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
         torch.manual_seed(0)
         self.model = BertForPreTraining(LARGE, device=device)
+        # DLE_BERT_GRAPH=1: the step captured in a HIP graph (the masked-row selection made static by max_predictions_per_seq = the
+        # 20 masked tokens every sequence of this batch has; utils/graph.py).  Opt-in, single rank only.
+        self.graphed = world == 1 and os.environ.get("DLE_BERT_GRAPH", "0") == "1"
         self.trainer = BertTrainer(self.model, lr=6e-3, warmup=0.2843, total_steps=7038, compute_dtype=self.dtype,
-                                   world_size=world, hidden_dropout=0.1, attention_dropout=0.1, seed=42, rank=rank)
+                                   world_size=world, hidden_dropout=0.1, attention_dropout=0.1, seed=42, rank=rank,
+                                   max_predictions_per_seq=20 if self.graphed else None)
+        from deeplearningexamples_amd.utils.graph import GraphedStep
+        self._step = GraphedStep(self.trainer.train_step, enabled=self.graphed, warmup_steps=2)
         g = torch.Generator(device="cpu").manual_seed(500 + rank)
         b, s, v = self.batch, 128, LARGE["real_vocab"]
         ids = torch.randint(0, v, (b, s), generator=g)
@@ -264,13 +280,18 @@ class BertWorkload:
         os.environ["DLE_BERT_WGRAD_STREAM"] = "0" if on else "1"          # read per call by BertTrainer._leaf_stream
 
     def step(self):
-        self.loss = self.trainer.train_step(*self.data)
+        from deeplearningexamples_amd import _cabi
+        if self.graphed and _cabi._timer is None:          # (the per-launch event pass of bench.py needs real launches)
+            self.loss = self._step(*self.data)
+        else:
+            self.loss = self.trainer.train_step(*self.data)
 
     def config(self):
         return {"workload": "BERT-Large phase-1 pre-training (PyTorch/LanguageModeling/BERT), seq 128, 20 masked "
                             "tokens/sequence, LAMB, synthetic Wikipedia-shaped batch (BASELINE.json configs[2])",
                 "batch_per_gpu": self.batch, "global_batch": self.batch * self.world, "seq_len": 128,
-                "dropout": 0.1, "parallelism": "single GPU" if self.world == 1 else "dp%d" % self.world}
+                "dropout": 0.1, "hip_graph": bool(self.graphed),
+                "parallelism": "single GPU" if self.world == 1 else "dp%d" % self.world}
 
     def dtype_name(self):
         return "fp16" if self.dtype == torch.float16 else "bf16"
