@@ -1,4 +1,4 @@
-// Launcher of the persistent eight-phase GEMM (kernel and design notes: gemm8_kernel.h) + its store-only instantiations.
+// Launcher of the persistent ping-pong GEMM (kernel and design notes: gemm8_kernel.h) + its store-only instantiations.
 #include "gemm8_kernel.h"
 
 // ---- launcher ----------------------------------------------------------------------------------------------------------------

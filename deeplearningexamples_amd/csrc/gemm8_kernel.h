@@ -1,26 +1,31 @@
-// The 256 x 256 "eight-phase" MFMA GEMM for gfx950 -- the kernel behind dle_gemm / dle_gemm_colsum for the big linear layers
+// The persistent ping-pong 256 x 256 MFMA GEMM for gfx950 -- the kernel behind dle_gemm / dle_gemm_colsum for the big linear layers
 // (LanguageModeling/BERT/modeling.py:130-160,340-384 LinearActivation / BertSelfOutput / BertIntermediate / BertOutput and
 //  their backward; Recommendation/DLRM/dlrm/nn/mlps.py:38-43): forward X W^T, data gradient dY W, weight gradient dY^T X.
+// (File and symbol names keep the "8" of its first version's eight phases per K tile.)
 //
 //   C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )        (contract of gemm_dma.hip, which stays for every other shape)
 //
 // What is different from gemm_dma.hip's 256 x 256 tile (one barrier + vmcnt(0) per K tile, fp32 tile transposed through LDS in
 // the epilogue: 0.88-0.92 PFLOP/s on the K = 1024 layers, ~29 % of a tile's time outside the K loop):
-//  * PERSISTENT: one workgroup per CU walks a list of (tile, K slice) items; the operand stream never drains between items --
-//    the first K tiles of the next item are already in flight while the current one's results are stored.
+//  * PERSISTENT: one workgroup per CU walks a list of (tile, K slice) items, decoded once per workgroup into an LDS table; the
+//    operand stream never drains between items -- the first K tiles of the next item are already in flight while the current
+//    one's results are stored.
 //  * HALF-TILE STREAM, COUNTED WAITS: a K tile (64 deep) is four 16 KiB half-tiles (A rows 0-127 / 128-255, B rows 0-127 /
-//    128-255), each staged by ONE LDS-DMA piece pair per wavefront; one half-tile is issued per phase, three are always in
-//    flight across the barriers, and the only wait for them is ONE s_waitcnt vmcnt(6) per K tile (never 0).
+//    128-255), each staged by ONE LDS-DMA piece pair per wavefront; 8 half-tile slots (two K tiles) are in flight or in use at
+//    any time, and the only wait for them is s_waitcnt vmcnt(8) at the end of a load segment (never 0).
 //  * PING-PONG: the eight wavefronts are two groups of four (one wavefront of each group per SIMD), staggered by one barrier:
-//    while a group runs its eight MFMAs of a phase (one 64 x 32 quadrant x K = 64) the other group issues its LDS fragment reads
-//    and its DMA pieces.  A wavefront owns rows {0,128} + 64 wr .. +63 and columns {0,128} + 32 wc .. +31 of the tile, i.e. one
-//    64 x 32 block of each (A half, B half) pair, so every phase consumes one freshly landed half-tile.
-//  * REGISTER EPILOGUE: the B fragment rows are permuted (MFMA row 8q + 4h + e <- tile column 16h + 4q + e) so that a lane's 16
-//    accumulators of a 32 x 32 block are 16 CONSECUTIVE output columns of one row: bias / activation / source math runs in
-//    the accumulator layout and the results leave as 16-byte stores (64 contiguous bytes per row and lane pair) -- no LDS
-//    transposition, no barrier, nothing of the epilogue touches the operand stages the stream is already refilling.
+//    while a group runs the 16 MFMAs of a segment (A half i x both B halves, K = 64) the other group issues its LDS fragment
+//    reads and its DMA pieces.  A wavefront owns rows {0,128} + 64 wr .. +63 and columns {0,128} + 32 wc .. +31 of the tile, i.e.
+//    one 64 x 32 block of each (A half, B half) pair.  (ktile16 below; the first version's four 8-MFMA phases per K tile --
+//    ktile, G8_PH16 = 0 -- paid the per-segment cost of the barrier round trip twice as often: 2600 against 2216 cycles.)
+//  * REGISTER EPILOGUE, ROW-CONTIGUOUS MEMORY: the B fragment rows are permuted (MFMA row 8q + 4h + e <- tile column
+//    16h + 4q + e) so that a lane's 16 accumulators of a 32 x 32 block are 16 CONSECUTIVE output columns of one row: bias /
+//    activation / source math runs in the accumulator layout; the rounded block then crosses a per-wavefront LDS scratch (no
+//    barrier) so that every store / source-load instruction moves 64 contiguous bytes of 16 rows (128 bytes of 8 rows for fp32
+//    output) -- the CU's store path is bound by requests, not bytes.  Nothing of the epilogue touches the operand stages the
+//    stream is already refilling, and the two groups' epilogues run at the same time.
 // LDS images, swizzles and the transpose reads of row-contiguous operands are the ones of gemm_tiles.h (half-tile = the
-// TILE = 128 image).  Hazards (RAW on LDS-DMA data, WAR on restaged half-tiles) are argued next to the phases below.
+// TILE = 128 image).  Hazards (RAW on LDS-DMA data, WAR on restaged half-tiles) are argued next to the segments below.
 #pragma once
 #include "gemm_tiles.h"
 

@@ -978,7 +978,7 @@ extern "C" int dle_gemm_dma_try(const void* A, const void* B, void* C, void* aux
   const int amode = a_kc ? 0 : 1, bmode = b_kc ? 0 : 1;
   if (!a_kc && b_kc) return 0;
   {
-    // the big linear layers: the persistent eight-phase kernel of gemm8.hip (split-K only with slabs)
+    // the big linear layers: the persistent ping-pong kernel of gemm8.hip (split-K only with slabs)
     int r8 = 0;
     if (splitk == 1 || p.ws)
       r8 = dle_gemm8_try(A, B, C, aux, bias, mask_src, M, N, K, lda, ldb, ldc, a_kc, b_kc, in_dtype, out_dtype, act, splitk,
@@ -1055,7 +1055,7 @@ extern "C" int dle_gemm_colsum(const void* A, const void* B, void* C, const void
   p.stats = (float*)workspace; p.stats_sums = 1;
   int tile_rows = 0;
   {
-    // eight-phase kernel: two partial rows per 256-row tile row (one per wavefront row group) = ceil(M / 128) rows when 256 | M
+    // ping-pong kernel: two partial rows per 256-row tile row (one per wavefront row group) = ceil(M / 128) rows when 256 | M
     const int r8 = dle_gemm8_try(A, B, C, nullptr, nullptr, mask_src, M, N, K, lda, ldb, ldc, 1, 0, dtype, dtype, act, 1, 0, 1.0f,
                                  nullptr, (float*)workspace, stream);
     if (r8 > 1) return r8;

@@ -1,4 +1,4 @@
-"""A/B of the persistent eight-phase GEMM (csrc/gemm8.hip) against the tile kernels of gemm_dma.hip and an fp32 reference.
+"""A/B of the persistent ping-pong GEMM (csrc/gemm8.hip) against the tile kernels of gemm_dma.hip and an fp32 reference.
 
     python tools/gemm8_check.py [quick|full] [--time]
 

@@ -1,4 +1,4 @@
-"""K sweep of the eight-phase GEMM vs the tile kernel: time = a + b * ktiles per layout (us per K tile = slope).
+"""K sweep of the ping-pong GEMM (gemm8) vs the tile kernel: time = a + b * ktiles per layout (us per K tile = slope).
     python tools/gemm8_ksweep.py [M N]"""
 import json, os, sys
 os.environ.setdefault("DLE_GEMM_8PH_MIN_ITEMS", "1")

@@ -1,4 +1,4 @@
-"""Split-K sweep of the weight-gradient layout (tn) on the eight-phase kernel: us per call incl. the slab reduce.
+"""Split-K sweep of the weight-gradient layout (tn) on the ping-pong kernel (gemm8): us per call incl. the slab reduce.
     python tools/gemm8_splitk_sweep.py"""
 import json, os, sys
 os.environ.setdefault("DLE_GEMM_8PH_MIN_ITEMS", "1")

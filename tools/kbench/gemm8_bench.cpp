@@ -1,4 +1,4 @@
-// Standalone harness for the eight-phase GEMM (csrc/gemm8.hip compiled INTO this file, optionally with -DG8_TIMING):
+// Standalone harness for the ping-pong GEMM (gemm8) (csrc/gemm8.hip compiled INTO this file, optionally with -DG8_TIMING):
 // HIP-event time per shape and, with G8_TIMING, shader-clock stamps around every item's K loop and epilogue.
 //   gemm8_bench M N K layout(nt|nn|tn) [epi: plain|bias|gelu|add|mul] [splitk]
 #include "../../deeplearningexamples_amd/csrc/gemm8.hip"

@@ -2,7 +2,7 @@
 # Round-5 evidence, run through gpurun from the repo root:  tools/r05_evidence.sh <section> ...
 #   bench    python bench.py (the driver's command) -> gpurun_out/r05_bench_default{,_detail}.json
 #   prof     rocprofv3 --kernel-trace --stats tables of rn50 / bert / dlrm, multi-stream and single-stream
-#   pmc      SQ / LDS / GRBM counters + FETCH_SIZE / WRITE_SIZE of the eight-phase GEMM (standalone harness, tools/kbench)
+#   pmc      SQ / LDS / GRBM counters + FETCH_SIZE / WRITE_SIZE of the ping-pong GEMM (gemm8) (standalone harness, tools/kbench)
 #   traffic  tools/collect_traffic.sh rn50 bert dlrm -> gpurun_out/traffic_new.json
 #   gemm     tools/gemm8_check.py full, tools/gemm8_ksweep.py, tools/gemm8_splitk_sweep.py
 #   tests    tail of pytest -m gpu
