@@ -28,6 +28,7 @@
 // TILE = 128 image).  Hazards (RAW on LDS-DMA data, WAR on restaged half-tiles) are argued next to the segments below.
 #pragma once
 #include "gemm_tiles.h"
+#include "gemm8_walk.h"
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_ADD = 4, ACT_GELU_BWD = 5, ACT_TANH = 6,
        ACT_TANH_BWD = 7, ACT_ADD_MASKED = 8, ACT_MUL = 9, ACT_GELU_DAUX = 10 };
@@ -274,30 +275,17 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
 
   // item -> (tile, K slice): the workgroup decodes ITS items once, in parallel (one lane per item), into a table in LDS
   // {m0, n0, first K tile, (K slice << 16) | K tiles}; the walk reads one 16-byte record per item (same address in every lane:
-  // a broadcast).  Walk order: each XCD (private L2; workgroup b runs on XCD b % 8) owns a contiguous chunk of the item list;
-  // inside it tiles are ordered in groups of gm tile rows walked column by column (the tiles an XCD runs at once form a
-  // gm x 32 / gm block: per K step they pull gm A half-tiles + a few B ones through L2 instead of 1 + 32), K slices slowest.
+  // a broadcast).  The walk order (XCD-chunked, groups of gm tile rows, K slices slowest) is g8_walk_item of gemm8_walk.h, which
+  // tests/test_gemm8_walk.py compiles for the host and checks (every item exactly once, slices partition K, chunk locality).
   // Decoding inside the walk (five divisions by launch constants, even as multiply-high) kept ~18 scalars alive across the K
   // loop or re-loaded them from the argument segment inside the item switch: ~1000 cycles in the segment in which the stream
   // moves on to the next item, and SGPR spills in the flavoured instantiations.
   const int G = p.grid;
   const int my_items = __builtin_amdgcn_readfirstlane((p.nitems - (int)blockIdx.x + G - 1) / G);
   int* tbl = (int*)(smem_raw + G8_TBL_BASE);
-  {
-    const int nitems = p.nitems, ntiles = p.tiles_m * p.tiles_n, q8 = nitems >> 3, r8 = nitems & 7;
-    for (int i = tid; i < my_items; i += 512) {
-      const int vb = (int)blockIdx.x + i * G;
-      const int xcd = vb & 7, loc = vb >> 3;
-      int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-      const int ky = id / ntiles;
-      id -= ky * ntiles;
-      const int per_group = p.gm * p.tiles_n, g = id / per_group, r = id - g * per_group;
-      const int rows = (p.tiles_m - g * p.gm) < p.gm ? (p.tiles_m - g * p.gm) : p.gm;
-      const int tn = r / rows, tm = g * p.gm + (r - tn * rows);
-      const int kt0 = (int)((unsigned)ky * (unsigned)p.ktiles / (unsigned)p.splitk);
-      const int kt1 = (int)((unsigned)(ky + 1) * (unsigned)p.ktiles / (unsigned)p.splitk);
-      *(int4v_t*)(tbl + 4 * i) = (int4v_t){tm * 256, tn * 256, kt0, (ky << 16) | (kt1 - kt0)};
-    }
+  for (int i = tid; i < my_items; i += 512) {
+    const G8WalkItem w = g8_walk_item((int)blockIdx.x + i * G, p.nitems, p.tiles_m, p.tiles_n, p.ktiles, p.splitk, p.gm);
+    *(int4v_t*)(tbl + 4 * i) = (int4v_t){w.m0, w.n0, w.kt0, w.slice_and_tiles};
   }
   __syncthreads();
   auto decode = [&](int li, int& m0, int& n0, int& kt0, int& kt1, int& ky) __attribute__((always_inline)) {
