@@ -65,6 +65,10 @@ CASES = [
     ("wgrad_splitk2_accumulate", "tn", (264, 1000, 2048), torch.bfloat16, dict(splitk=2, accumulate=True)),
     ("wgrad_fp32_accumulate", "tn", (512, 768, 640), torch.bfloat16, dict(out_f32=True, accumulate=True)),
     ("wgrad_16bit_out_f16", "tn", (512, 512, 1024), torch.float16, {}),
+    # K slices of ONE K tile (the first K tile of an item is also its last: stream hand-over between back-to-back epilogues)
+    ("wgrad_single_tile_slices", "tn", (768, 512, 256), torch.bfloat16, dict(splitk=4)),
+    ("wgrad_one_and_two_tile_slices", "tn", (512, 768, 192), torch.bfloat16, dict(splitk=2)),
+    ("two_k_tiles_bias_relu", "nt", (2048, 1280, 128), torch.bfloat16, dict(bias=True, act="relu")),
 ]
 
 
