@@ -659,6 +659,40 @@ def roofline_from(timer, steps, wl_name, samples_per_step_per_gpu, ms_per_step):
     return r, breakdown
 
 
+def sample_shader_clock(wl, steps, sample=True):
+    """The shader clock (MHz) while the workload runs, sampled on the host every 20 ms over `steps` UNTIMED steps after the
+    timed region (torch.cuda.clock_rate() = amdsmi's current gfx clock).  Context for `roofline.frac`: the MFMA peak of
+    MI355X_MICROARCH.md assumes 2.4 GHz; under sustained matrix load the power management runs the chip well below that
+    (DESIGN.md 0.1).  None when the box has no amdsmi binding."""
+    import threading
+    try:
+        first = int(torch.cuda.clock_rate()) if sample else None
+    except Exception:
+        first = None
+    vals, stop = [first], threading.Event()
+
+    def loop():
+        while not stop.is_set():
+            try:
+                vals.append(int(torch.cuda.clock_rate()))
+            except Exception:
+                return
+            stop.wait(0.02)
+    th = threading.Thread(target=loop, daemon=True) if first is not None else None
+    if th is not None:
+        th.start()
+    for _ in range(steps):                              # (every rank runs them: the collectives inside a step need all ranks)
+        wl.step()
+    torch.cuda.synchronize()
+    if th is None:
+        return None
+    stop.set()
+    th.join(timeout=2.0)
+    busy = vals[1:] or vals
+    return {"mean": round(sum(busy) / len(busy), 1), "min": min(busy), "max": max(busy), "samples": len(busy),
+            "source": "torch.cuda.clock_rate() (amdsmi current gfx clock) every 20 ms over %d untimed steps" % steps}
+
+
 def run_workload(name, args, rank, world, device, steps, warmup):
     """Build the workload, warm up, time exactly `steps` steps (barrier + synchronize on both sides, nothing else
     inside), then the instrumented pass for the roofline.  Returns the record of this workload (rank 0) or None."""
@@ -681,6 +715,9 @@ def run_workload(name, args, rank, world, device, steps, warmup):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    sclk = None
+    if os.environ.get("DLE_BENCH_SCLK", "1") == "1":
+        sclk = sample_shader_clock(wl, max(2, min(steps, 10)), sample=rank == 0)
     # the same K steps again with a HIP-event pair around every C-ABI launch (on the launch stream) for the per-kernel
     # durations behind "roofline"; kept out of the region above (the event pairs inflate the step); every rank runs it
     timer = None
@@ -710,6 +747,8 @@ def run_workload(name, args, rank, world, device, steps, warmup):
     if rank == 0:
         ms = elapsed / steps * 1e3
         roof, breakdown = roofline_from(timer, steps, name, wl.samples_per_step / world, ms)
+        if roof is not None:
+            roof["sclk_mhz"] = sclk
         rec = {"value": round(wl.samples_per_step * steps / elapsed, 1), "unit": "samples/s", "steps": steps,
                "warmup": warmup, "ms_per_step": round(ms, 4), "scaling": wl.scaling, "dtype": wl.dtype_name(),
                "config": wl.config(), "final_loss": loss, "roofline": roof, "kernel_breakdown": breakdown,
@@ -749,6 +788,8 @@ def compact(name, rec, cpu):
            "roofline": {k: r.get(k) for k in ("bound", "frac", "step_frac", "kernel", "ms_per_step", "traffic")} if r else None}
     if r.get("kernel_sum_ms_per_step") is not None:
         out["kernel_sum_ms"] = round(r["kernel_sum_ms_per_step"], 2)
+    if r.get("sclk_mhz"):
+        out["sclk_mhz"] = r["sclk_mhz"]["mean"]           # shader clock while the workload ran (sample_shader_clock)
     if cpu:
         out["cpu_baseline"] = {k: cpu.get(k) for k in ("value", "cores", "kind", "steps")}
     return out
@@ -835,7 +876,7 @@ def main():
         r = rec["roofline"] or {}
         keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_shape", "traffic_over_algorithmic", "kernel",
                 "ms_per_step", "launches_per_step", "avg_launch_us", "heaviest_shape", "arithmetic_intensity", "frac_mfma",
-                "frac_hbm", "step_bound", "step_achieved", "step_unit", "step_frac")
+                "frac_hbm", "step_bound", "step_achieved", "step_unit", "step_frac", "sclk_mhz")
         out = {"metric": "training samples/sec", "value": rec["value"], "unit": "samples/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
                "higher_is_better": True, "scaling": rec["scaling"], "vs_baseline": None, "dtype": rec["dtype"],
