@@ -101,6 +101,8 @@ _SIGS = {
     "dle_bn_stats_from_partials": (c_int, [c_void_p, c_int, c_i64, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_i64, c_void_p]),
     "dle_bn_fwd_apply": (c_int, [c_void_p] * 8 + [c_i64, c_int, c_int, c_int, c_void_p]),
+    "dle_bn_fwd_apply2": (c_int, [c_void_p] * 12 + [c_i64, c_int, c_int, c_void_p]),
+    "dle_conv1x1_bnload_fwd2": (c_int, [c_void_p] * 15 + [c_i64, c_int, c_int, c_int, c_int, c_void_p]),
     "dle_bn_bwd_reduce": (c_int, [c_void_p] * 8 + [c_i64, c_int, c_int, c_void_p, c_i64, c_int, c_void_p]),
     "dle_bn_bwd_apply": (c_int, [c_void_p] * 11 + [c_i64, c_int, c_int, c_void_p]),
     "dle_maxpool_fwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),

@@ -146,6 +146,9 @@ class ResNetTrainer:
         self.fuse_bn = os.environ.get("DLE_RN50_FUSE_BN", "1") != "0"
         # the backward reduction of a block's bn3 taken in the epilogue of the NEXT block's conv1 data gradient (gemm_expand BRED)
         self.fuse_bnred = os.environ.get("DLE_RN50_FUSE_BNRED", "1") != "0"
+        # the downsample branch's BatchNorm (no ReLU) applied where bn3's apply LOADS the residual (bn_apply2_pf_kernel, conv_bnload
+        # RES = 2): the branch's 16-bit output is never written; DLE_RN50_FUSE_DSBN=0 keeps its stand-alone apply pass
+        self.fuse_dsbn = os.environ.get("DLE_RN50_FUSE_DSBN", "1") != "0"
         self.stem.w2 = torch.zeros((64, 7, 8, 4), dtype=compute_dtype, device=self.dev)
         self.stem.gw_flat = self.gview["conv1.weight"]
         self.fc_w16 = torch.empty(model.fc.weight.shape, dtype=compute_dtype, device=self.dev)
@@ -270,12 +273,12 @@ class ResNetTrainer:
                 bs.wait_stream(cur)
                 self._branch_keep.clear()        # (what the branch stream produced earlier has been consumed before this point)
                 with torch.cuda.stream(bs):
-                    res = ud.forward(hy)
+                    res = ud.forward(hy, defer=self.fuse_dsbn)
                 o2 = u2.forward(o1, defer=fuse)
                 cur.wait_stream(bs)
                 self._branch_keep.append(res)    # allocated on the branch stream, read on this one: alive until the next fork
             else:
-                res = ud.forward(hy) if ud is not None else hy
+                res = ud.forward(hy, defer=self.fuse_dsbn) if ud is not None else hy
                 o2 = u2.forward(o1, defer=fuse)
             h = u3.forward(o2, residual=res, defer=fuse)
         if isinstance(h, Deferred):

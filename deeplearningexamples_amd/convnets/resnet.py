@@ -47,6 +47,15 @@ class Deferred:
     def __init__(self, unit, t, mean, rstd, residual):
         self.unit, self.t, self.mean, self.rstd, self.residual, self.y = unit, t, mean, rstd, residual, None
 
+    def residual_args(self):
+        """-> (residual tensor or None, its BatchNorm (mean, rstd, gamma, beta) or None).  A residual that is itself a Deferred is
+        the downsample branch (conv -> BatchNorm, no ReLU, models/resnet.py:166-173): its BatchNorm is applied where the residual
+        is LOADED (bn_apply2_pf_kernel / conv_bnload_kernel<RES = 2>) and its 16-bit output never exists."""
+        r = self.residual
+        if isinstance(r, Deferred):
+            return r.t, (r.mean, r.rstd, r.unit.bn.weight.data, r.unit.bn.bias.data)
+        return r, None
+
     def _done(self, y, mask):
         u = self.unit
         u.saved = (u.saved[0], self.t, mask, self.mean, self.rstd)
@@ -55,8 +64,9 @@ class Deferred:
     def materialize(self):
         if self.y is None:
             u = self.unit
-            y, mask = F.bn_fwd_apply(self.t, self.mean, self.rstd, u.bn.weight.data, u.bn.bias.data, residual=self.residual,
-                                     relu=u.relu, want_mask=True)
+            res, res_bn = self.residual_args()
+            y, mask = F.bn_fwd_apply(self.t, self.mean, self.rstd, u.bn.weight.data, u.bn.bias.data, residual=res,
+                                     relu=u.relu, want_mask=True, residual_bn=res_bn)
             self._done(y, mask)
         return self.y
 
@@ -90,8 +100,10 @@ class ConvBN:
         if isinstance(x, Deferred):
             d, r = x, None
             if self.k == 1 and self.stride == 1 and d.unit.relu and d.y is None:
-                r = F.conv1x1_bnload_fwd(d.t, d.residual, self.w16, d.mean, d.rstd, d.unit.bn.weight.data, d.unit.bn.bias.data,
-                                         self.bn.running_mean, self.bn.running_var, eps=self.bn.eps, momentum=self.bn.momentum)
+                res, res_bn = d.residual_args()
+                r = F.conv1x1_bnload_fwd(d.t, res, self.w16, d.mean, d.rstd, d.unit.bn.weight.data, d.unit.bn.bias.data,
+                                         self.bn.running_mean, self.bn.running_var, eps=self.bn.eps, momentum=self.bn.momentum,
+                                         res_bn=res_bn)
             if r is not None:
                 t, x, bits, mean, rstd = r
                 d._done(x, bits)
@@ -107,6 +119,10 @@ class ConvBN:
         if defer:
             self.saved = (x, t, None, mean, rstd)
             return Deferred(self, t, mean, rstd, residual)
+        if isinstance(residual, Deferred):          # (the downsample branch left deferred, this unit not: apply both here)
+            d = Deferred(self, t, mean, rstd, residual)
+            self.saved = (x, t, None, mean, rstd)
+            return d.materialize()
         y, mask = F.bn_fwd_apply(t, mean, rstd, self.bn.weight.data, self.bn.bias.data, residual=residual,
                                  relu=self.relu, want_mask=True)
         self.saved = (x, t, mask, mean, rstd)

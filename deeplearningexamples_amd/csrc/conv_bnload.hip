@@ -26,6 +26,7 @@ struct BnlArgs {
   unsigned short* Y;            // [M, K]
   unsigned char* bits;          // [M * K / 8]
   const float* mean; const float* rstd; const float* gamma; const float* beta;
+  const float* mean_r; const float* rstd_r; const float* gamma_r; const float* beta_r;   // RES == 2: the residual's own BatchNorm
   float* stats;                 // [groups][2][N] or NULL
   int M, N, K;
   int row_tiles, groups, col_tiles;
@@ -51,13 +52,17 @@ __device__ __forceinline__ int bl_pos(int nl) {
 }
 
 // NB: 16-column blocks per workgroup tile (4 -> 64 output columns, 8 -> 128); NW wavefronts of 16 rows each.
-template <int DT, int KS, bool RES, int NB, int NW>
+// RES: 0 no residual, 1 residual tensor R, 2 residual = bn_r(R) rounded to the activation dtype (the downsample branch's BatchNorm,
+// which has no ReLU of its own, taken on the residual's load: bit-identical to its stand-alone apply pass followed by RES == 1).
+template <int DT, int KS, int RES, int NB, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_bnload_kernel(BnlArgs p) {
   constexpr int K = KS * 32, LDW = K + BL_PAD, TM = NW * 16, TN = NB * 16, NP = NB / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned short* wl = (unsigned short*)smem_raw;                      // [TN][LDW]
   float* scl = (float*)(smem_raw + TN * LDW * 2);                      // [K] scale | [K] shift
   float* shl = scl + K;
+  float* scr = shl + K;                                                // RES == 2: [K] scale | [K] shift of the residual's BatchNorm
+  float* shr = scr + K;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, kg = lane >> 4;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -74,6 +79,11 @@ __global__ __launch_bounds__(NW * 64) void conv_bnload_kernel(BnlArgs p) {
       const float sc = p.rstd[c] * p.gamma[c];                         // (the same two roundings as bn_apply_pf_kernel)
       scl[c] = sc;
       shl[c] = p.beta[c] - p.mean[c] * sc;
+      if constexpr (RES == 2) {
+        const float sr = p.rstd_r[c] * p.gamma_r[c];
+        scr[c] = sr;
+        shr[c] = p.beta_r[c] - p.mean_r[c] * sr;
+      }
     }
   }
   __syncthreads();
@@ -109,6 +119,15 @@ __global__ __launch_bounds__(NW * 64) void conv_bnload_kernel(BnlArgs p) {
         float xf[8], rf[8], of[8];
         unpack8<DT>(fa[ks], xf);
         if (RES) unpack8<DT>(fr_[ks], rf);
+        if constexpr (RES == 2) {
+          const float4_t d0 = *(const float4_t*)(scr + ks * 32 + kg * 8), d1 = *(const float4_t*)(scr + ks * 32 + kg * 8 + 4);
+          const float4_t e0 = *(const float4_t*)(shr + ks * 32 + kg * 8), e1 = *(const float4_t*)(shr + ks * 32 + kg * 8 + 4);
+          const float sr[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+          const float hr[8] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
+#pragma unroll
+          for (int k = 0; k < 8; ++k) rf[k] = rf[k] * sr[k] + hr[k];
+          unpack8<DT>(pack8<DT>(rf), rf);                               // (the rounding point of the stand-alone branch output)
+        }
         unsigned bits = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -232,9 +251,10 @@ extern "C" int dle_conv1x1_bnload_groups(int M, int N, int K) {
 // out [M, N] = relu(bn(t) (+ res)) W^T with the side outputs y [M, K], bits [M K / 8] and the column statistics of out
 // (stats [dle_conv1x1_bnload_groups][2][N], may be NULL).  Returns 1 when launched, 0 outside the envelope (K in {64, 128, 256},
 // N a multiple of 64, M >= 4096, dense 16-byte aligned operands), > 1 on a launch error.
-extern "C" int dle_conv1x1_bnload_fwd(const void* t, const void* res, const void* w, void* out, void* y, void* bits, const float* mean,
-                                      const float* rstd, const float* gamma, const float* beta, float* stats, int64_t stats_bytes,
-                                      int M, int N, int K, int dtype, hipStream_t stream) {
+static int bnload_launch(const void* t, const void* res, const void* w, void* out, void* y, void* bits, const float* mean,
+                         const float* rstd, const float* gamma, const float* beta, const float* mean_r, const float* rstd_r,
+                         const float* gamma_r, const float* beta_r, float* stats, int64_t stats_bytes,
+                         int M, int N, int K, int dtype, hipStream_t stream) {
   static const char* pin = getenv("DLE_CONV_BNLOAD");
   if (pin && atoi(pin) == 0) return 0;
   if (dtype != DLE_F16 && dtype != DLE_BF16) return 0;
@@ -245,17 +265,19 @@ extern "C" int dle_conv1x1_bnload_fwd(const void* t, const void* res, const void
   BnlArgs p;
   p.T = (const unsigned short*)t; p.R = (const unsigned short*)res; p.B = (const unsigned short*)w; p.C = (unsigned short*)out;
   p.Y = (unsigned short*)y; p.bits = (unsigned char*)bits; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.stats = stats;
+  p.mean_r = mean_r; p.rstd_r = rstd_r; p.gamma_r = gamma_r; p.beta_r = beta_r;
+  const int resmode = !res ? 0 : (mean_r ? 2 : 1);
   p.M = M; p.N = N; p.K = K;
   const int TN = bl_tn(N), NWv = bl_nw(K, N), tm = NWv * 16;
   p.row_tiles = (M + tm - 1) / tm; p.col_tiles = N / TN; p.groups = groups;
-  size_t lds = (size_t)TN * (K + BL_PAD) * 2 + 2 * K * 4;
+  size_t lds = (size_t)TN * (K + BL_PAD) * 2 + 4 * K * 4;
   if (lds < (size_t)NWv * 2 * TN * 4) lds = (size_t)NWv * 2 * TN * 4;
   const dim3 grid((unsigned)(groups * p.col_tiles)), block(NWv * 64);
 #define BL_GO(DT, KS, RS, NBV, NWV) do { static bool attr_set = false; \
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_bnload_kernel<DT, KS, RS, NBV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set = true; } \
     hipLaunchKernelGGL((conv_bnload_kernel<DT, KS, RS, NBV, NWV>), grid, block, lds, stream, p); } while (0)
 #define BL_NB(DT, KS, RS, NWV) do { if (TN == 128) BL_GO(DT, KS, RS, 8, NWV); else BL_GO(DT, KS, RS, 4, NWV); } while (0)
-#define BL_RES(DT, KS, NWV) do { if (res) BL_NB(DT, KS, true, NWV); else BL_NB(DT, KS, false, NWV); } while (0)
+#define BL_RES(DT, KS, NWV) do { if (resmode == 2) BL_NB(DT, KS, 2, NWV); else if (resmode == 1) BL_NB(DT, KS, 1, NWV); else BL_NB(DT, KS, 0, NWV); } while (0)
 #define BL_K(DT) do { if (K == 64) BL_RES(DT, 2, 4); else if (K == 128) BL_RES(DT, 4, 4); else if (NWv == 8) BL_RES(DT, 8, 8); else BL_RES(DT, 8, 4); } while (0)
   if (dtype == DLE_F16) BL_K(DLE_F16); else BL_K(DLE_BF16);
 #undef BL_K
@@ -265,4 +287,23 @@ extern "C" int dle_conv1x1_bnload_fwd(const void* t, const void* res, const void
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { dle_set_error("conv1x1_bnload_fwd launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
   return 1;
+}
+
+extern "C" int dle_conv1x1_bnload_fwd(const void* t, const void* res, const void* w, void* out, void* y, void* bits, const float* mean,
+                                      const float* rstd, const float* gamma, const float* beta, float* stats, int64_t stats_bytes,
+                                      int M, int N, int K, int dtype, hipStream_t stream) {
+  return bnload_launch(t, res, w, out, y, bits, mean, rstd, gamma, beta, nullptr, nullptr, nullptr, nullptr, stats, stats_bytes, M, N, K,
+                       dtype, stream);
+}
+
+// The same with the residual taken through ITS OWN BatchNorm on load: y = relu(bn(t) + round16(bn_r(res))) -- `res` is then the
+// downsample branch's convolution output and (mean_r, rstd_r, gamma_r, beta_r) that branch's BatchNorm (models/resnet.py:166-173);
+// bit-identical to dle_bn_fwd_apply(res) followed by dle_conv1x1_bnload_fwd.  Same return convention.
+extern "C" int dle_conv1x1_bnload_fwd2(const void* t, const void* res, const void* w, void* out, void* y, void* bits, const float* mean,
+                                       const float* rstd, const float* gamma, const float* beta, const float* mean_r, const float* rstd_r,
+                                       const float* gamma_r, const float* beta_r, float* stats, int64_t stats_bytes,
+                                       int M, int N, int K, int dtype, hipStream_t stream) {
+  if (!res || !mean_r || !rstd_r || !gamma_r || !beta_r) return 0;
+  return bnload_launch(t, res, w, out, y, bits, mean, rstd, gamma, beta, mean_r, rstd_r, gamma_r, beta_r, stats, stats_bytes, M, N, K,
+                       dtype, stream);
 }

@@ -666,6 +666,87 @@ extern "C" int dle_bn_fwd_apply(const void* x, const void* residual, void* y, vo
   return 0;
 }
 
+// y = relu(bn(x) + bn_r(xr)) with the keep bits: a bottleneck's bn3 apply with the downsample branch's BatchNorm (no ReLU of its
+// own, models/resnet.py:166-173) taken on the residual's load -- the branch's 16-bit output is never written or re-read.  The
+// residual term is rounded to the activation dtype exactly where the stand-alone pass stored it, so y and the bits are
+// bit-identical to dle_bn_fwd_apply(xr -> res) followed by dle_bn_fwd_apply(x, res).  Same trip structure as bn_apply_pf_kernel.
+template <int DT>
+__global__ __launch_bounds__(256) void bn_apply2_pf_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ xr,
+                                                           unsigned short* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ mean_r,
+                                                           const float* __restrict__ rstd_r, const float* __restrict__ gamma_r,
+                                                           const float* __restrict__ beta_r, long long total8, int C8,
+                                                           unsigned char* __restrict__ mask_out) {
+  const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  if (first >= total8) return;
+  float sc[8], sh[8], scr[8], shr[8];
+  const int c0 = (int)(first % C8) * 8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sc[k] = rstd[c0 + k] * gamma[c0 + k]; sh[k] = beta[c0 + k] - mean[c0 + k] * sc[k];
+    scr[k] = rstd_r[c0 + k] * gamma_r[c0 + k]; shr[k] = beta_r[c0 + k] - mean_r[c0 + k] * scr[k];
+  }
+  auto one = [&](long long i, ushort8_t xv, ushort8_t rv) __attribute__((always_inline)) {
+    float xf[8], rf[8], of[8];
+    unpack8<DT>(xv, xf);
+    unpack8<DT>(rv, rf);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rf[k] = rf[k] * scr[k] + shr[k];
+    unpack8<DT>(pack8<DT>(rf), rf);                       // (the rounding point of the stand-alone branch output)
+    unsigned bits = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float v = xf[k] * sc[k] + sh[k];
+      v += rf[k];
+      v = v > 0.f ? v : 0.f;
+      of[k] = v;
+      bits |= (v > 0.f ? 1u : 0u) << k;
+    }
+    ((ushort8_t*)y)[i] = pack8<DT>(of);
+    mask_out[i] = (unsigned char)bits;
+  };
+  long long i = first;
+  ushort8_t xc = ((const ushort8_t*)x)[i], rc = ((const ushort8_t*)xr)[i];
+  auto trip = [&]() __attribute__((always_inline)) {
+    const ushort8_t xn = ((const ushort8_t*)x)[i + stride];
+    const ushort8_t rn = ((const ushort8_t*)xr)[i + stride];
+    __builtin_amdgcn_sched_barrier(0);
+    one(i, xc, rc);
+    xc = xn; rc = rn;
+    i += stride;
+  };
+  if (i + stride < total8) {
+    trip();
+    while (i + stride < total8) trip();
+  }
+  one(i, xc, rc);
+}
+
+// y = relu(bn(x) + bn_r(xr)), relu_mask = keep bits: see bn_apply2_pf_kernel.  All four statistics / affine vectors of both
+// BatchNorms are fp32 [C]; x, xr, y 16-bit [M, C]; relu_mask [M C / 8].
+extern "C" int dle_bn_fwd_apply2(const void* x, const void* xr, void* y, void* relu_mask, const float* mean, const float* rstd,
+                                 const float* gamma, const float* beta, const float* mean_r, const float* rstd_r, const float* gamma_r,
+                                 const float* beta_r, int64_t M, int C, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "bn_fwd_apply2: 16-bit activations only");
+  DLE_CHECK_ARG(M >= 0 && C > 0 && C % 8 == 0, "bn_fwd_apply2: bad shape");
+  if (M == 0) return 0;
+  DLE_CHECK_ARG(x && xr && y && relu_mask && mean && rstd && gamma && beta && mean_r && rstd_r && gamma_r && beta_r,
+                "bn_fwd_apply2: null pointer");
+  const long long total8 = (long long)M * (C / 8);
+  int grid = cn_grid(total8, 256, g_bn_apply_cap);
+  while (((long long)grid * 256) % (C / 8) != 0) ++grid;   // a lane keeps its 8 channels for the whole sweep
+  if (dtype == DLE_F16)
+    hipLaunchKernelGGL((bn_apply2_pf_kernel<DLE_F16>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)xr,
+                       (unsigned short*)y, mean, rstd, gamma, beta, mean_r, rstd_r, gamma_r, beta_r, total8, C / 8, (unsigned char*)relu_mask);
+  else
+    hipLaunchKernelGGL((bn_apply2_pf_kernel<DLE_BF16>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (const unsigned short*)xr,
+                       (unsigned short*)y, mean, rstd, gamma, beta, mean_r, rstd_r, gamma_r, beta_r, total8, C / 8, (unsigned char*)relu_mask);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
 // backward pass 1: dgamma / dbeta (fp32) with the ReLU mask taken from the saved output y (NULL: no ReLU)
 extern "C" int dle_bn_bwd_reduce(const void* dy, const void* y, const void* relu_mask, const void* x, const float* mean, const float* rstd,
                                  float* dgamma, float* dbeta, int64_t M, int C, int accumulate, void* workspace,

@@ -746,12 +746,14 @@ def conv2d_fwd_bnstats(x, w, stride=1, pad=0, running_mean=None, running_var=Non
     return y, mean, rstd
 
 
-def conv1x1_bnload_fwd(t, res, w, mean, rstd, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+def conv1x1_bnload_fwd(t, res, w, mean, rstd, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, res_bn=None):
     """The producer's BatchNorm-apply (+ residual) + ReLU on the operand load of a 1x1 convolution (csrc/conv_bnload.hip).
     t [.., K] pre-BatchNorm activations, res like t or None, w [N, 1, 1, K]; mean / rstd / gamma / beta: the PRODUCER's BatchNorm;
     running_mean / running_var / eps / momentum: THIS convolution's BatchNorm (its batch statistics come out of the epilogue).
+    res_bn = (mean_r, rstd_r, gamma_r, beta_r): `res` is the downsample branch's CONVOLUTION output and its BatchNorm is applied on
+    the residual's load (bit-identical to bn_fwd_apply(res, relu=False) in front).
     -> (out [.., N], y [.., K], bits, mean_out, rstd_out), or None when the shape is outside the kernel's envelope."""
-    C.require_cuda(t, res, w, mean, rstd, gamma, beta, running_mean, running_var)
+    C.require_cuda(t, res, w, mean, rstd, gamma, beta, running_mean, running_var, *(res_bn or ()))
     k = t.shape[-1]
     n = w.shape[0]
     m = t.numel() // k
@@ -768,9 +770,19 @@ def conv1x1_bnload_fwd(t, res, w, mean, rstd, gamma, beta, running_mean=None, ru
     part, fold = ws[:groups * 2 * n], ws[groups * 2 * n:(groups + 32) * 2 * n]
     C.annotate(flops=2.0 * m * n * k, tag="bn+conv %dx%dx%d%s" % (m, n, k, "+res" if res is not None else ""),
                bytes=float(t.numel() * (3 if res is not None else 2) + out.numel() + w.numel()) * 2 + bits.numel())
-    rc = _timed_optional("dle_conv1x1_bnload_fwd", C.lib().dle_conv1x1_bnload_fwd,
-                         (C.ptr(t), C.ptr(res), C.ptr(w), C.ptr(out), C.ptr(y), C.ptr(bits), C.ptr(mean), C.ptr(rstd), C.ptr(gamma),
-                          C.ptr(beta), C.ptr(part), part.numel() * 4, m, n, k, C.dt(t), C.stream()))
+    if res_bn is not None:
+        if res is None:
+            raise ValueError("conv1x1_bnload_fwd: res_bn without a residual")
+        C.annotate(flops=2.0 * m * n * k, tag="bn+conv %dx%dx%d+bnres" % (m, n, k),
+                   bytes=float(t.numel() * 3 + out.numel() + w.numel()) * 2 + bits.numel())
+        rc = _timed_optional("dle_conv1x1_bnload_fwd", C.lib().dle_conv1x1_bnload_fwd2,
+                             (C.ptr(t), C.ptr(res), C.ptr(w), C.ptr(out), C.ptr(y), C.ptr(bits), C.ptr(mean), C.ptr(rstd), C.ptr(gamma),
+                              C.ptr(beta), C.ptr(res_bn[0]), C.ptr(res_bn[1]), C.ptr(res_bn[2]), C.ptr(res_bn[3]),
+                              C.ptr(part), part.numel() * 4, m, n, k, C.dt(t), C.stream()))
+    else:
+        rc = _timed_optional("dle_conv1x1_bnload_fwd", C.lib().dle_conv1x1_bnload_fwd,
+                             (C.ptr(t), C.ptr(res), C.ptr(w), C.ptr(out), C.ptr(y), C.ptr(bits), C.ptr(mean), C.ptr(rstd), C.ptr(gamma),
+                              C.ptr(beta), C.ptr(part), part.numel() * 4, m, n, k, C.dt(t), C.stream()))
     if rc == 0:
         return None
     if rc != 1:
@@ -844,12 +856,23 @@ def stem_conv_wgrad(dy, x4, out, accumulate=False):
     return out
 
 
-def bn_fwd_apply(x, mean, rstd, gamma, beta, residual=None, relu=True, want_mask=False):
-    """y = act((x - mean) * rstd * gamma + beta (+ residual)) with given statistics -> (y, relu_mask or None)."""
-    C.require_cuda(x, mean, rstd, gamma, beta, residual)
+def bn_fwd_apply(x, mean, rstd, gamma, beta, residual=None, relu=True, want_mask=False, residual_bn=None):
+    """y = act((x - mean) * rstd * gamma + beta (+ residual)) with given statistics -> (y, relu_mask or None).
+    residual_bn = (mean_r, rstd_r, gamma_r, beta_r): `residual` is the downsample branch's convolution output, its BatchNorm (no
+    ReLU) is applied on load (csrc/convnet.hip bn_apply2_pf_kernel; needs relu and want_mask)."""
+    C.require_cuda(x, mean, rstd, gamma, beta, residual, *(residual_bn or ()))
     c = x.shape[-1]
     m = x.numel() // c
     y = torch.empty_like(x)
+    if residual_bn is not None:
+        if residual is None or not relu or not want_mask or residual.shape != x.shape or residual.dtype != x.dtype \
+                or not (x.is_contiguous() and residual.is_contiguous()):
+            raise ValueError("bn_fwd_apply: residual_bn needs a dense residual of x's shape / dtype, relu and want_mask")
+        mask = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device)
+        C.annotate(bytes=float(x.numel()) * (6 + 0.125), tag="M%dxC%d+bnres" % (m, c))
+        C.call("dle_bn_fwd_apply2", C.ptr(x), C.ptr(residual), C.ptr(y), C.ptr(mask), C.ptr(mean), C.ptr(rstd), C.ptr(gamma), C.ptr(beta),
+               C.ptr(residual_bn[0]), C.ptr(residual_bn[1]), C.ptr(residual_bn[2]), C.ptr(residual_bn[3]), m, c, C.dt(x), C.stream())
+        return y, mask
     mask = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device) if (want_mask and relu) else None
     C.annotate(bytes=float(x.numel()) * (2 * (3 if residual is not None else 2) + (0.125 if mask is not None else 0)),
                tag="M%dxC%d%s" % (m, c, "+res" if residual is not None else ""))

@@ -311,6 +311,13 @@ int dle_bn_stats_from_partials(const float* partial, int groups, int64_t M, int 
 int dle_bn_fwd_apply(const void* x, const void* residual, void* y, void* relu_mask, const float* mean,
                      const float* rstd, const float* gamma, const float* beta, int64_t M, int C, int relu,
                      int dtype, hipStream_t stream);
+/* y = relu(bn(x) + round16(bn_r(xr))) + keep bits: the bn3 apply of a bottleneck whose residual comes from the downsample branch
+ * (conv -> BatchNorm, no ReLU: models/resnet.py:166-173, `residual = self.downsample(x)`) with that branch's BatchNorm taken on
+ * the residual's load -- its 16-bit output is never written.  Bit-identical to dle_bn_fwd_apply(xr -> res, relu = 0) followed by
+ * dle_bn_fwd_apply(x, res, relu = 1).  mean_r / rstd_r / gamma_r / beta_r: the branch's BatchNorm, fp32 [C].                  */
+int dle_bn_fwd_apply2(const void* x, const void* xr, void* y, void* relu_mask, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, const float* mean_r, const float* rstd_r, const float* gamma_r,
+                      const float* beta_r, int64_t M, int C, int dtype, hipStream_t stream);
 /* g = dy * relu'(y): from relu_mask when given, else from y > 0 (both NULL: g = dy);
  * dgamma = sum g*xhat, dbeta = sum g */
 int dle_bn_bwd_reduce(const void* dy, const void* y, const void* relu_mask, const void* x, const float* mean,
@@ -331,6 +338,12 @@ int dle_conv1x1_bnload_groups(int M, int N, int K);
 int dle_conv1x1_bnload_fwd(const void* t, const void* res, const void* w, void* out, void* y, void* bits, const float* mean,
                            const float* rstd, const float* gamma, const float* beta, float* stats, int64_t stats_bytes, int M,
                            int N, int K, int dtype, hipStream_t stream);
+/* The same with the residual taken through its own BatchNorm on load (the downsample branch, as dle_bn_fwd_apply2):
+ * y = relu(bn(t) + round16(bn_r(res))); bit-identical to dle_bn_fwd_apply(res) followed by dle_conv1x1_bnload_fwd.            */
+int dle_conv1x1_bnload_fwd2(const void* t, const void* res, const void* w, void* out, void* y, void* bits, const float* mean,
+                            const float* rstd, const float* gamma, const float* beta, const float* mean_r, const float* rstd_r,
+                            const float* gamma_r, const float* beta_r, float* stats, int64_t stats_bytes, int M, int N, int K,
+                            int dtype, hipStream_t stream);
 /* The backward counterpart (csrc/conv_bnbwd.hip): BatchNorm backward (second pass) on the operand load of the 1x1 data gradient
  * that consumes it -- the conv3 / bn3 unit of a bottleneck (models/resnet.py:148-175 backward).  dt [M, K] = ka (g - dbeta / M -
  * xhat dgamma / M) with g = dy under relu_mask (bit-packed, may be NULL), dx [M, N] = dt W, W [K][N] n-contiguous; dgamma / dbeta

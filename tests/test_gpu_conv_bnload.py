@@ -83,3 +83,70 @@ def test_rn50_step_with_and_without_the_fused_units(cuda, dtype, monkeypatch):
     assert abs(losses["1"][0] - losses["0"][0]) <= 2e-4 * abs(losses["0"][0])
     for a, b in zip(losses["1"], losses["0"]):
         assert abs(a - b) <= 3e-3 * abs(b)
+
+
+def _bn_vectors(g, k, cuda):
+    return ((torch.randn(k, generator=g) * 0.1).to(cuda), (torch.rand(k, generator=g) + 0.5).to(cuda),
+            (torch.rand(k, generator=g) + 0.5).to(cuda), (torch.randn(k, generator=g) * 0.1).to(cuda))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("nhw,c", [((2, 28, 28), 512), ((3, 14, 14), 1024), ((5, 7, 7), 2048), ((2, 9, 9), 24)])
+def test_dual_apply_equals_branch_apply_then_apply(cuda, dtype, nhw, c):
+    """relu(bn3(t) + bn_ds(t_ds)) in one pass (bn_apply2_pf_kernel: the downsample branch's BatchNorm on the residual's load,
+    models/resnet.py:166-173) == the branch's stand-alone apply followed by bn3's apply with a residual tensor, bit for bit."""
+    from deeplearningexamples_amd import functional as F
+    g = torch.Generator().manual_seed(c)
+    t = torch.randn(nhw + (c,), generator=g).to(dtype).to(cuda)
+    td = torch.randn(nhw + (c,), generator=g).to(dtype).to(cuda)
+    bn, bnr = _bn_vectors(g, c, cuda), _bn_vectors(g, c, cuda)
+    res, _ = F.bn_fwd_apply(td, *bnr, relu=False)
+    y_ref, bits_ref = F.bn_fwd_apply(t, *bn, residual=res, relu=True, want_mask=True)
+    y, bits = F.bn_fwd_apply(t, *bn, residual=td, relu=True, want_mask=True, residual_bn=bnr)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref) and torch.equal(bits, bits_ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("nhw,k,n", [((2, 56, 56), 256, 64), ((2, 56, 56), 256, 128), ((3, 40, 40), 64, 64), ((4, 32, 32), 128, 128)])
+def test_fused_unit_with_branch_batchnorm_on_the_residual_load(cuda, dtype, nhw, k, n):
+    """conv_bnload_kernel<RES = 2> == the branch's stand-alone apply followed by the RES = 1 kernel: y, keep bits, out, statistics
+    all bit-identical (the same kernel after the residual's rounding point)."""
+    from deeplearningexamples_amd import functional as F
+    g = torch.Generator().manual_seed(k * 17 + n)
+    t = torch.randn(nhw + (k,), generator=g).to(dtype).to(cuda)
+    td = torch.randn(nhw + (k,), generator=g).to(dtype).to(cuda)
+    w = (torch.randn((n, 1, 1, k), generator=g) * 0.1).to(dtype).to(cuda)
+    bn, bnr = _bn_vectors(g, k, cuda), _bn_vectors(g, k, cuda)
+    res, _ = F.bn_fwd_apply(td, *bnr, relu=False)
+    ref = F.conv1x1_bnload_fwd(t, res, w, *bn)
+    got = F.conv1x1_bnload_fwd(t, td, w, *bn, res_bn=bnr)
+    torch.cuda.synchronize()
+    assert ref is not None and got is not None
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16])
+def test_rn50_step_with_and_without_the_downsample_batchnorm_on_load(cuda, dtype, monkeypatch):
+    """DLE_RN50_FUSE_DSBN=1 (the downsample branch's BatchNorm applied where bn3's apply loads the residual) vs 0 (its own pass):
+    every activation of the forward pass is bit-identical, so the first loss is EQUAL; the later ones agree to the last fp32 digits
+    (the step's fp32 loss / gradient reductions are not order-deterministic from run to run)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import resnet_oracle as RO
+    import test_gpu_rn50_step as T
+    c = RO.RN50_STEP_CONFIG
+    state = RO.seeded_state(c["seed"])
+    x, y = RO.seeded_batch(c["seed"] + 1, 16, 64)
+    losses = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DLE_RN50_FUSE_DSBN", mode)
+        model, tr = T._build(cuda, dtype, c["lr"], state)
+        assert tr.fuse_dsbn == (mode == "1")
+        losses[mode] = [float(tr.train_step(x.to(cuda), y.to(cuda)).item()) for _ in range(3)]
+    print(dtype, losses)
+    assert losses["1"][0] == losses["0"][0]
+    for a, b in zip(losses["1"], losses["0"]):
+        assert abs(a - b) <= 2e-6 * abs(b)
