@@ -150,9 +150,11 @@ class DlrmTrainer:
             copies = top.mlp.working_copies() + [top.out_working_copy()]
             F.cast_rows(lin.weight.data, copies[i].dtype, cols_out=copies[i].shape[1], out=copies[i])
         if self.bot_grads is not None:
+            # (row-sharded placement, dlrm/row_sharded.py: the bottom MLP is data parallel there)
+            lr_bot = self.lr_dp if getattr(self, "bottom_dp", False) else self.lr_mp
             if self.t_bot_w is not None:
-                mt.sgd(self.t_bot_w, self.lr_mp, skip_flag=skip, inv_scale=inv, has_momentum=False, model_copy=True)
-            mt.sgd(self.t_bot_b, self.lr_mp, skip_flag=skip, inv_scale=inv, has_momentum=False)
+                mt.sgd(self.t_bot_w, lr_bot, skip_flag=skip, inv_scale=inv, has_momentum=False, model_copy=True)
+            mt.sgd(self.t_bot_b, lr_bot, skip_flag=skip, inv_scale=inv, has_momentum=False)
             bm = self.model.bottom_model.mlp
             for i in self.bot_padded:
                 c = bm.working_copies()[i]

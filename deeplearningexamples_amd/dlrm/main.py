@@ -85,6 +85,9 @@ def parse_flags(argv=None):
     p.add_argument("--bottom_features_ordered", action="store_true")
     p.add_argument("--freeze_mlps", action="store_true")
     p.add_argument("--freeze_embeddings", action="store_true")
+    p.add_argument("--embedding_sharding", default="table", choices=["table", "row"],
+                   help="table: whole tables per rank, the reference's get_device_mapping (default); row: every table cut into "
+                        "row ranges over the ranks, ids routed by value and exchanged before the vectors (dlrm/row_sharded.py)")
     f = p.parse_args(argv)
     if f.mode == "inference_benchmark":
         raise SystemExit("--mode inference_benchmark: inference is outside this path (the train step and its validation pass)")
@@ -103,6 +106,8 @@ def main(argv=None):
         sizes = FeatureSpec.from_yaml(os.path.join(flags.dataset, flags.feature_spec)).get_categorical_sizes()
     if flags.max_table_size:
         sizes = [min(s, flags.max_table_size) for s in sizes]
+    if flags.embedding_sharding == "row":
+        return main_row_sharded(flags, sizes, rank, world, device)
     mapping = P.get_device_mapping(sizes, num_gpus=world)
     batch_sizes = P.get_gpu_batch_sizes(flags.batch_size, num_gpus=world) if world > 1 else (flags.batch_size,)
     mine = mapping["embedding"][rank]
@@ -237,6 +242,48 @@ def main(argv=None):
         avg = flags.batch_size / (sum(times) / max(len(times), 1)) if times else 0.0
         dllogger.log(step=tuple(), data={"best_auc": best_auc, "best_validation_loss": best_loss, "best_epoch": best_epoch,
                                          "average_train_throughput": avg, "training_loss": float(moving_loss.item())})
+        dllogger.flush()
+    return trainer
+
+
+def main_row_sharded(flags, sizes, rank, world, device):
+    """--embedding_sharding row (BASELINE.json configs[3] as worded; dlrm/row_sharded.py): synthetic data, training loop only --
+    checkpoints and the validation pass follow the reference's table-wise layout and stay with the default placement."""
+    from .row_sharded import RowShardedDlrmTrainer, build_row_sharded_model
+    if flags.dataset_type != "synthetic_gpu" or flags.load_checkpoint_path or flags.save_checkpoint_path or flags.mode != "train":
+        raise SystemExit("--embedding_sharding row: synthetic training only (checkpoints / validation use the table-wise placement)")
+    batch_sizes = P.get_gpu_batch_sizes(flags.batch_size, num_gpus=world) if world > 1 else (flags.batch_size,)
+    if is_main_process():
+        dllogger.init([dllogger.JSONStreamBackend(dllogger.Verbosity.VERBOSE, flags.log_path),
+                       dllogger.StdOutBackend(dllogger.Verbosity.DEFAULT)])
+        dllogger.log(step="PARAMETER", data=vars(flags))
+    model, plan = build_row_sharded_model(flags.synthetic_dataset_numerical_features, sizes, flags.bottom_mlp_sizes, flags.top_mlp_sizes,
+                                          rank, world, embedding_dim=flags.embedding_dim, device=device,
+                                          compute_dtype=torch.float16 if flags.amp else torch.bfloat16)
+    trainer = RowShardedDlrmTrainer(model, plan, flags.lr, batch_sizes, rank=rank, world_size=world, amp=flags.amp,
+                                    freeze_mlps=flags.freeze_mlps, freeze_embeddings=flags.freeze_embeddings)
+    sched = LearningRateScheduler(flags.warmup_steps, flags.warmup_factor, flags.decay_steps, flags.decay_start_step,
+                                  flags.decay_power, flags.decay_end_lr / flags.lr)
+    g = torch.Generator(device="cpu").manual_seed(flags.seed)                     # the same global batch on every rank
+    num = torch.rand((flags.batch_size, flags.synthetic_dataset_numerical_features), generator=g).to(device)
+    cat = torch.cat([torch.randint(0, s, (flags.batch_size, 1), generator=g) for s in sizes], dim=1).to(device)
+    click = torch.randint(0, 2, (flags.batch_size,), generator=g).float().to(device)
+    steps = flags.max_steps or max(flags.synthetic_dataset_num_entries // flags.batch_size - 1, 1)
+    timer, times, moving_loss = StepTimer(), [], torch.zeros(1, device=device)
+    for step in range(1, steps + 1):
+        timer.click(synchronize=True)
+        trainer.set_lr_factor(sched.step())
+        moving_loss += trainer.train_step(num, cat, click)
+        if timer.measured is not None and step > flags.benchmark_warmup_steps:
+            times.append(timer.measured)
+        if step % flags.print_freq == 0 and is_main_process():
+            dllogger.log(step=(0, step), data={"loss": float(moving_loss.item()) / flags.print_freq, "step_time": timer.measured})
+            moving_loss.zero_()
+    torch.cuda.synchronize()
+    if is_main_process():
+        avg = flags.batch_size / (sum(times) / max(len(times), 1)) if times else 0.0
+        dllogger.log(step=tuple(), data={"average_train_throughput": avg, "training_loss": float(moving_loss.item()),
+                                         "embedding_sharding": "row"})
         dllogger.flush()
     return trainer
 

@@ -449,7 +449,8 @@ class DistributedDlrm(nn.Module):
             self._device_feature_order = order if bottom_features_ordered else None
             self._feature_order = order.argsort() if bottom_features_ordered else None
         else:
-            world_num_categorical_features = len(categorical_feature_sizes)
+            if world_num_categorical_features is None:      # (the row-sharded placement keeps ONE joint matrix for all T tables)
+                world_num_categorical_features = len(categorical_feature_sizes)
             self._device_feature_order = self._feature_order = None
         interaction = DotInteraction(world_num_categorical_features, embedding_dim)
         self.bottom_model = DlrmBottom(num_numerical_features, categorical_feature_sizes, bottom_mlp_sizes,

@@ -100,3 +100,51 @@ class ExchangePlan:
 
     def source_of_feature(self, slot: int) -> int:
         return bisect.bisect_right(self.recv_feature_base, slot) - 1
+
+
+class RowShardPlan:
+    """Row-wise placement of EVERY embedding table over the ranks (BASELINE.json configs[3] "embedding tables row-sharded over 8
+    GPUs"; SURVEY.md 8(e): "index bucketing by row range + a2a of indices and vectors").  The reference itself places whole tables
+    (get_device_mapping above); this is the opt-in alternative (`--embedding_sharding row`).
+
+    Table t (N_t rows) is cut into `world` contiguous ranges of shard_t = ceil(N_t / world) rows; rank r owns rows
+    [r * shard_t, min(N_t, (r + 1) * shard_t)) and keeps its ranges of all tables stacked in table order in ONE joint matrix
+    (local_offsets[r][t] = first joint row of table t on rank r).  Pure integer logic; `route` works on any torch device."""
+
+    def __init__(self, table_sizes: Sequence[int], world: int):
+        if world < 1 or any(n < 1 for n in table_sizes):
+            raise ValueError("RowShardPlan: world >= 1 and non-empty tables expected")
+        self.sizes, self.world = [int(n) for n in table_sizes], int(world)
+        self.shard = [-(-n // world) for n in self.sizes]
+        self.local_sizes = [[max(0, min(n - r * s, s)) for n, s in zip(self.sizes, self.shard)] for r in range(world)]
+        self.local_offsets = [[0] + list(itertools.accumulate(ls))[:-1] for ls in self.local_sizes]
+        self.local_rows = [sum(ls) for ls in self.local_sizes]
+
+    def rows_of(self, rank: int, table: int) -> Tuple[int, int]:
+        """[first, last) GLOBAL row of `table` that `rank` owns."""
+        lo = rank * self.shard[table]
+        return min(lo, self.sizes[table]), min(lo + self.shard[table], self.sizes[table])
+
+    def tensors(self, device):
+        """(shard [T], local_offsets [world, T]) as int64 tensors on `device` (the operands of route())."""
+        import torch
+        return (torch.tensor(self.shard, dtype=torch.int64, device=device),
+                torch.tensor(self.local_offsets, dtype=torch.int64, device=device))
+
+    @staticmethod
+    def route(ids, shard, local_offsets):
+        """ids int64 [B, T] (0 <= ids[:, t] < N_t) -> (owner [B, T], joint row on the owner [B, T]), both int64."""
+        import torch
+        owner = torch.div(ids, shard, rounding_mode="floor")
+        t_idx = torch.arange(ids.shape[1], device=ids.device).expand_as(ids)
+        row = ids - owner * shard + local_offsets[owner, t_idx]
+        return owner, row
+
+    @staticmethod
+    def bucket(owner, world):
+        """owner int64 [n] -> (order, counts): a STABLE permutation that groups the lookups by owner rank (lookups bound for the
+        same rank keep their (sample, table) order) and the number of lookups per rank (int64 [world])."""
+        import torch
+        order = torch.argsort(owner, stable=True)
+        counts = torch.bincount(owner, minlength=world)
+        return order, counts

@@ -207,6 +207,67 @@ def run_dlrm(rank, world, dev, steps):
     return {"losses": losses, "probe": probe}
 
 
+def run_dlrm_row(rank, world, dev, steps):
+    """world 2: every table ROW-SHARDED over the ranks (dlrm/row_sharded.py: ids routed by row range, all-to-all of ids, then of the
+    vectors; data-parallel bottom + top MLP).  world 1: the default trainer holding every table whole.  Same weights, same batch."""
+    from oracle import dlrm_step_oracle as SO
+    from deeplearningexamples_amd.dlrm import placement as P
+    from deeplearningexamples_amd.dlrm.model import DistributedDlrm
+    from deeplearningexamples_amd.dlrm.engine import DlrmTrainer
+    from deeplearningexamples_amd.dlrm import row_sharded as RS
+    c = DLRM_MR
+    sizes = c["sizes"]
+    state = SO.seeded_dlrm_state(sizes, c["dim"], c["bottom"], c["top"], c["num"], c["seed"])
+    num, cat, click = SO.seeded_dlrm_batch(sizes, c["num"], c["batch"], c["seed"] + 1)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    torch.manual_seed(300 + rank)
+    if world == 1:
+        model = DistributedDlrm(num_numerical_features=c["num"], categorical_feature_sizes=sizes, bottom_mlp_sizes=c["bottom"],
+                                top_mlp_sizes=c["top"], embedding_dim=c["dim"], device=dev, compute_dtype=torch.float16)
+    else:
+        model, plan = RS.build_row_sharded_model(c["num"], sizes, c["bottom"], c["top"], rank, world, embedding_dim=c["dim"], device=dev,
+                                                 compute_dtype=torch.float16)
+    with torch.no_grad():
+        if rank == 0:                                        # data-parallel MLPs: only rank 0 gets the seeded weights
+            for i, l in enumerate(model.bottom_model.mlp.linears):
+                l.weight.copy_(state["bottom_mlp.%d.weight" % i]); l.bias.copy_(state["bottom_mlp.%d.bias" % i])
+            for i, l in enumerate(model.top_model.mlp.linears):
+                l.weight.copy_(state["top_mlp.%d.weight" % i]); l.bias.copy_(state["top_mlp.%d.bias" % i])
+            model.top_model.out.weight.copy_(state["out.weight"]); model.top_model.out.bias.copy_(state["out.bias"])
+        full = [state["embedding"][int(off[t]):int(off[t + 1])] for t in range(len(sizes))]
+        if world == 1:
+            model.bottom_model.embeddings.weight.copy_(state["embedding"])
+        else:
+            RS.load_row_shards(model, plan, rank, full)
+    model.refresh_working_copies()
+    if world == 1:
+        tr = DlrmTrainer(model, lr=c["lr"], batch_sizes_per_gpu=[c["batch"]], amp=True)
+    else:
+        tr = RS.RowShardedDlrmTrainer(model, plan, c["lr"], P.get_gpu_batch_sizes(c["batch"], world), rank=rank, world_size=world,
+                                      amp=True)
+    numd, catd, clickd = num.to(dev), cat.to(dev), click.to(dev)
+    losses = []
+    for _ in range(steps):
+        loss = tr.train_step(numd, catd, clickd)
+        if world > 1:
+            from deeplearningexamples_amd.utils import comm
+            loss = comm.allreduce_mean_(loss.clone())        # equal per-rank batch sizes -> mean of means
+        losses.append(float(loss.item()))
+    probe = model.top_model.out.weight.detach().float().cpu().numpy().reshape(-1)[:8].tolist()
+    # the touched embedding rows after the steps, in GLOBAL row order (rank-local shards are re-assembled by the test)
+    emb = model.bottom_model.embeddings.weight.detach().float().cpu()
+    if world == 1:
+        rows = {t: emb[int(off[t]):int(off[t]) + min(sizes[t], 16), :4].numpy().tolist() for t in range(len(sizes))}
+    else:
+        rows = {}
+        for t in range(len(sizes)):
+            lo, hi = plan.rows_of(rank, t)
+            o = plan.local_offsets[rank][t]
+            keep = [i for i in range(lo, hi) if i < min(sizes[t], 16)]
+            rows[t] = {i: emb[o + i - lo, :4].numpy().tolist() for i in keep}
+    return {"losses": losses, "probe": probe, "rows": rows}
+
+
 def run_waveglow(rank, world, dev, steps):
     from oracle import waveglow_oracle as WO
     from deeplearningexamples_amd.waveglow.engine import WaveGlowTrainer
@@ -292,7 +353,7 @@ def _bert_flag2(dev, steps):
     return {"losses": losses, "probe": probe, "nbuckets": len(tr.buckets.buckets)}
 
 
-SCENARIOS = {"bert_acc": run_bert_acc, "bert": run_bert, "rn50": run_rn50, "rn50_abandon": run_rn50_abandon, "dlrm": run_dlrm, "waveglow": run_waveglow, "rccl1": run_rccl_single_rank}
+SCENARIOS = {"bert_acc": run_bert_acc, "bert": run_bert, "rn50": run_rn50, "rn50_abandon": run_rn50_abandon, "dlrm": run_dlrm, "dlrm_row": run_dlrm_row, "waveglow": run_waveglow, "rccl1": run_rccl_single_rank}
 
 
 def main():

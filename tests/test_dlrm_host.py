@@ -120,3 +120,83 @@ def test_roc_auc_matches_sklearn_and_reference():
         exec(compile(src[start:], spec.origin, "exec"), ns)                                # the function alone (the module imports dllogger)
         for yt, ys in cases[:2]:
             assert abs(roc_auc_score(yt, ys) - ns["roc_auc_score"](yt.clone(), ys.clone())) < 1e-6
+
+
+# ---- row-sharded placement (BASELINE.json configs[3] as worded; deeplearningexamples_amd/dlrm/row_sharded.py)
+def test_row_shard_plan_partitions_every_table():
+    sizes = [300, 50, 7, 2000, 11, 640, 1, 8]
+    for world in (1, 2, 3, 8):
+        plan = P.RowShardPlan(sizes, world)
+        for t, n in enumerate(sizes):
+            owned = []
+            for r in range(world):
+                lo, hi = plan.rows_of(r, t)
+                assert hi - lo == plan.local_sizes[r][t]
+                owned += list(range(lo, hi))
+            assert owned == list(range(n)), "every row of every table is owned exactly once, in order"
+        shard, off = plan.tensors("cpu")
+        g = torch.Generator().manual_seed(world)
+        ids = torch.stack([torch.randint(0, n, (64,), generator=g) for n in sizes], 1)
+        owner, row = P.RowShardPlan.route(ids, shard, off)
+        for b in range(ids.shape[0]):
+            for t in range(len(sizes)):
+                r = int(owner[b, t])
+                lo, hi = plan.rows_of(r, t)
+                assert lo <= int(ids[b, t]) < hi
+                assert int(row[b, t]) == plan.local_offsets[r][t] + int(ids[b, t]) - lo
+                assert 0 <= int(row[b, t]) < plan.local_rows[r]
+        order, counts = P.RowShardPlan.bucket(owner.reshape(-1), world)
+        flat = owner.reshape(-1)[order]
+        assert torch.equal(flat, flat.sort().values) and counts.tolist() == [int((flat == r).sum()) for r in range(world)]
+        for r in range(world):                                   # stable: lookups bound for one rank keep their order
+            sel = order[flat == r]
+            assert torch.equal(sel, sel.sort().values)
+
+
+def _row_shard_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from deeplearningexamples_amd.dlrm import row_sharded as RS
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sizes, dim, batches = [37, 5, 1, 260, 11], 4, [6, 10]
+        plan = P.RowShardPlan(sizes, world)
+        g = torch.Generator().manual_seed(7)                                     # the same on every rank
+        full = [torch.randn(n, dim, generator=g) for n in sizes]
+        cat = torch.stack([torch.randint(0, n, (sum(batches),), generator=g) for n in sizes], 1)
+        lo = sum(batches[:rank])
+        mine = cat[lo:lo + batches[rank]].contiguous()
+        local = torch.cat([full[t][slice(*plan.rows_of(rank, t))] for t in range(len(sizes))])
+        shard, off = plan.tensors("cpu")
+        back, (order, c_send, c_recv, recv_rows) = RS.lookup_exchange(mine, shard, off, world, None, lambda rows: local[rows], dim,
+                                                                      torch.float32)
+        got = torch.empty(mine.numel(), dim)
+        got[order] = back                                                        # undo the send order
+        exp = torch.stack([full[t][mine[b, t]] for b in range(mine.shape[0]) for t in range(len(sizes))])
+        ok_fwd = torch.equal(got, exp)
+        # backward: "gradient" of lookup (b, t) = its vector + 1; the owners accumulate what they receive on their joint rows
+        g_send = (exp + 1.0)[order]
+        g_recv = RS.grad_exchange(g_send, c_send, c_recv, world, None)
+        acc = torch.zeros_like(local).index_add_(0, recv_rows, g_recv)
+        # brute force over the GLOBAL batch: what this rank's rows must have received
+        want = torch.zeros_like(local)
+        for b in range(cat.shape[0]):
+            for t in range(len(sizes)):
+                i = int(cat[b, t])
+                a, z = plan.rows_of(rank, t)
+                if a <= i < z:
+                    want[plan.local_offsets[rank][t] + i - a] += full[t][i] + 1.0
+        ret[rank] = bool(ok_fwd and torch.allclose(acc, want, atol=1e-5) and sum(c_send) == mine.numel())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_exchange_two_ranks_gloo():
+    """ids routed by row range, all-to-all of the ids, gather on the owner, all-to-all of the vectors back == a direct lookup in the
+    full tables; the reverse exchange delivers every gradient row to the owner of its table row (world size 2, gloo)."""
+    import torch.multiprocessing as mp
+    port = 31500 + os.getpid() % 2000
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_row_shard_worker, args=(2, port, ret), nprocs=2, join=True)
+        assert ret[0] and ret[1]

@@ -62,6 +62,27 @@ def test_two_ranks_match_one_rank(cuda, tmp_path, scenario, rtol):
         assert two[0]["nbuckets"] > 1          # several gradient buckets were reduced during the backward pass
 
 
+def test_row_sharded_dlrm_two_ranks_match_one_rank_table_wise(cuda, tmp_path):
+    """BASELINE.json configs[3] "embedding tables row-sharded": two ranks with every table cut by row range (ids exchanged, then
+    vectors: dlrm/row_sharded.py) against ONE rank holding every table whole on the default trainer -- per-step losses, the
+    data-parallel weights, and the UPDATED embedding rows (each owned by exactly one of the two ranks)."""
+    two, backend = _two_ranks("dlrm_row", tmp_path)
+    one = _one_rank("dlrm_row", cuda)
+    print("dlrm_row", backend, "2-rank", two[0]["losses"], "1-rank", one["losses"])
+    np.testing.assert_allclose(two[0]["losses"], one["losses"], rtol=3e-4)
+    assert two[0]["probe"] == two[1]["probe"], "data-parallel replicas diverged"
+    ref = np.asarray(one["probe"])
+    np.testing.assert_allclose(np.asarray(two[0]["probe"]), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    checked = 0
+    for t, ref_rows in one["rows"].items():
+        for i, want in enumerate(ref_rows):
+            got = [r["rows"][str(t)][str(i)] for r in two if str(i) in r["rows"][str(t)]]
+            assert len(got) == 1, "row %d of table %s owned by exactly one rank" % (i, t)
+            np.testing.assert_allclose(got[0], want, rtol=2e-3, atol=2e-4)
+            checked += 1
+    assert checked >= 60
+
+
 def test_rccl_branch_on_a_single_rank_communicator(cuda, tmp_path):
     """the `nccl` branches of utils/comm.py and the engines' bucket hooks on a real RCCL communicator (one rank:
     a one-GPU box cannot host two), see _multirank_worker.run_rccl_single_rank."""
