@@ -92,7 +92,7 @@ def build(force=False, verbose=True):
         res = list(ex.map(lambda s: _compile(s, force), srcs))
     objs = [o for o, _ in res]
     if any(c for _, c in res) or not os.path.exists(LIB) or _stale(LIB, objs):
-        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", LIB]
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-ldl", "-o", LIB]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-8000:])

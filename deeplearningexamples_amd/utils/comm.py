@@ -11,13 +11,39 @@ the gloo call.  It moves bytes; no arithmetic of the product path runs on the CP
 import torch
 import torch.distributed as dist
 
+from . import rccl as _rccl
+
 
 def _staged(t, group):
     return t.is_cuda and dist.get_backend(group) != "nccl"
 
 
+def _direct(t, group):
+    """DLE_COMM=rccl: device tensors go through the C-ABI RCCL wrappers (utils/rccl.py, csrc/rccl_comm.hip) on the current stream
+    instead of torch's ProcessGroupNCCL -- SURVEY.md 8 row b4.  The default (`torch`) keeps the reference's own boundary."""
+    return _rccl.comm_for(group) if (t.is_cuda and _rccl.enabled()) else None
+
+
+def ranks_seen(device=None, group=None):
+    """How many ranks actually take part in a collective of this process group: a SUM all-reduce of ones over the path the train
+    steps use (RCCL's own ncclCommCount when the direct path is on).  bench.py prints it next to the world size."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    dev = device if (device is not None and dist.get_backend(group) == "nccl") else "cpu"
+    t = torch.ones(1, dtype=torch.float32, device=dev)
+    if t.is_cuda and _rccl.enabled():
+        c = _rccl.comm_for(group)
+        c.allreduce_(t, _rccl.SUM)
+        return min(int(t.item()), c.count())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(t.item())
+
+
 def allreduce_mean_(t: torch.Tensor, group=None):
     """In-place mean over the ranks.  RCCL has a native AVG; gloo sums and scales."""
+    c = _direct(t, group)
+    if c is not None:
+        return c.allreduce_(t, _rccl.AVG)
     if dist.get_backend(group) == "nccl":
         dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
     elif t.is_cuda:
@@ -32,6 +58,9 @@ def allreduce_mean_(t: torch.Tensor, group=None):
 
 def allreduce_sum_(t: torch.Tensor, group=None):
     """In-place sum over the ranks (16-bit wire buffers of the gradient buckets: pre-divided by the world size)."""
+    c = _direct(t, group)
+    if c is not None:
+        return c.allreduce_(t, _rccl.SUM)
     if _staged(t, group):
         h = t.detach().cpu()
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
@@ -43,6 +72,9 @@ def allreduce_sum_(t: torch.Tensor, group=None):
 
 def allreduce_max_(t: torch.Tensor, group=None):
     """In-place maximum over the ranks (the found-inf flag of model-parallel parts)."""
+    c = _direct(t, group)
+    if c is not None:
+        return c.allreduce_(t, _rccl.MAX)
     if _staged(t, group):
         h = t.detach().cpu()
         dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
@@ -53,6 +85,9 @@ def allreduce_max_(t: torch.Tensor, group=None):
 
 
 def broadcast_(t: torch.Tensor, src=0, group=None):
+    c = _direct(t, group)
+    if c is not None and t.is_contiguous():
+        return c.broadcast_(t, src)
     if _staged(t, group):
         h = t.detach().cpu()
         dist.broadcast(h, src=src, group=group)
@@ -84,6 +119,9 @@ def _pairwise_exchange_host(ho, hi, out_splits, in_splits, group=None):
 
 def all_to_all_single(out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits, group=None):
     """torch.distributed.all_to_all_single with element split lists (DLRM bottom -> top exchange and its reverse)."""
+    c = _direct(out, group)
+    if c is not None:
+        return c.all_to_all_single(out, inp, out_splits, in_splits)
     if _staged(out, group):
         ho = torch.empty(out.shape, dtype=out.dtype)
         out.copy_(_pairwise_exchange_host(ho, inp.detach().cpu(), out_splits, in_splits, group))

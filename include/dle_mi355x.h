@@ -631,6 +631,26 @@ int dle_t2_mel_loss(const float* out_all, int64_t ld_out, const void* post, cons
 int dle_t2_mask_rows(void* x, int64_t ld, int cols, const int64_t* lengths, int64_t B, int To, float value, int dtype,
                      hipStream_t stream);
 
+/* ---- collectives over librccl.so (csrc/rccl_comm.hip) -------------------------------------------------
+ * What the reference reaches through torch.distributed's ProcessGroupNCCL: the gradient all-reduce of the DDP reducer
+ * (Classification/ConvNets/image_classification/training.py:78-84), BERT's comm hook (LanguageModeling/BERT/run_pretraining.py:
+ * 461-470: `dist.all_reduce(bucket, async_op=True)` behind a pre-division) and DLRM's `dist.all_to_all` of the bottom -> top
+ * exchange and its backward (Recommendation/DLRM/dlrm/model/distributed.py:68,95).  RCCL is bound with dlopen at first use (the
+ * copy the process already holds, else /opt/rocm/lib); every call is enqueued on the stream the caller names and returns at
+ * once; 0 = ok.  The 128-byte unique id of rank 0 travels over the caller's rendezvous (utils/rccl.py: torch.distributed's
+ * MASTER_ADDR / MASTER_PORT store).  dtype: DLE_F32 / DLE_F16 / DLE_BF16, 100 = int32, 101 = int64, 102 = uint8.            */
+int dle_rccl_available(void);
+int dle_rccl_unique_id(void* id128);
+int dle_rccl_init(const void* id128, int rank, int world, void** comm_out);          /* ncclCommInitRank on the current device */
+int dle_rccl_count(void* comm);                                                       /* ncclCommCount: ranks that joined      */
+int dle_rccl_destroy(void* comm);
+int dle_rccl_allreduce(void* comm, void* buf, int64_t count, int dtype, int op, hipStream_t stream);   /* op: 0 sum, 2 max, 4 avg */
+int dle_rccl_broadcast(void* comm, void* buf, int64_t bytes, int root, hipStream_t stream);
+/* all_to_all_single with split lists: peer p gets send_bytes[p] bytes from send + sum(send_bytes[:p]) and delivers recv_bytes[p]
+ * bytes at recv + sum(recv_bytes[:p]); one grouped ncclSend / ncclRecv pair per peer; the size arrays are HOST memory.       */
+int dle_rccl_alltoallv(void* comm, const void* send, const int64_t* send_bytes, void* recv, const int64_t* recv_bytes, int world,
+                       hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

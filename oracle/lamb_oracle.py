@@ -170,3 +170,52 @@ def lamb_golden_inputs(case=LAMB_GOLDEN_CASE):
     grads = [{k: (rng.standard_normal(shape) * 0.3).astype(np.float32) for k, (shape, _) in case["shapes"].items()}
              for _ in range(case["steps"])]
     return params, grads
+
+
+# ---- call trace of the reference's FusedLAMBAMP.step (oracle/make_golden.py gen_lamb_trace): a flat .npz of plain arrays ---------
+_TRACE_SCALARS = ("chunk", "beta1", "beta2", "eps", "bias_correction", "weight_decay", "grad_averaging", "mode")
+_TRACE_ARRAYS = ("noop_in", "noop_out", "total", "per", "lr", "step", "global_grad_norm", "max_grad_norm", "found_inf", "inv_scale")
+
+
+def save_call_trace(path, calls, calls_after_step):
+    out = {"n_calls": np.int64(len(calls)), "calls_after_step": np.asarray(calls_after_step, np.int64)}
+    for i, c in enumerate(calls):
+        pre = "c%d." % i
+        out[pre + "fn"] = np.asarray(c["fn"])
+        for k in ("per_tensor", "use_nvlamb"):                       # Optional[bool] arguments: -1 = None
+            if k in c:
+                out[pre + k] = np.int64(-1 if c[k] is None else int(bool(c[k])))
+        for k in _TRACE_SCALARS:
+            if k in c:
+                out[pre + k] = np.float64(c[k])
+        for k in _TRACE_ARRAYS:
+            if k in c:
+                out[pre + k] = np.asarray(c[k])
+        for which in ("lists", "out"):
+            if which in c:
+                out[pre + which + ".n"] = np.asarray([len(l) for l in c[which]], np.int64)
+                for li, l in enumerate(c[which]):
+                    for ti, a in enumerate(l):
+                        out["%s%s.%d.%d" % (pre, which, li, ti)] = a
+    np.savez_compressed(path, **out)
+
+
+def load_call_trace(path):
+    z = np.load(path)
+    calls = []
+    for i in range(int(z["n_calls"])):
+        pre = "c%d." % i
+        c = {"fn": str(z[pre + "fn"])}
+        for k in ("per_tensor", "use_nvlamb"):
+            if pre + k in z.files:
+                v = int(z[pre + k])
+                c[k] = None if v < 0 else bool(v)
+        for k in _TRACE_SCALARS + _TRACE_ARRAYS:
+            if pre + k in z.files:
+                c[k] = z[pre + k] if k in _TRACE_ARRAYS else float(z[pre + k])
+        for which in ("lists", "out"):
+            if pre + which + ".n" in z.files:
+                c[which] = [[z["%s%s.%d.%d" % (pre, which, li, ti)] for ti in range(int(n))]
+                            for li, n in enumerate(z[pre + which + ".n"])]
+        calls.append(c)
+    return calls, z["calls_after_step"].tolist()

@@ -280,6 +280,76 @@ def gen_lamb():
     print("lamb: steps", rec["step"], "scales", rec["scale"], "lr", rec["lr"])
 
 
+def gen_lamb_trace():
+    """CALL TRACE of the reference's unmodified FusedLAMBAMP.step (fused_lamb.py:131-260): every call the class makes into
+    `fused_lamb_CUDA` over the golden scenario -- entry point, the tensor lists and scalar arguments AS THE CLASS PASSED THEM, and
+    what the call left behind (returned norms / the lists it mutates, from oracle/lamb_cpu_ext.py) -- as a fixture the GPU box can
+    replay through shims/fused_lamb_CUDA.py without the reference tree (tests/test_gpu_lamb_reference.py).  Data only: argument
+    values and results, no reference source."""
+    from oracle import lamb_oracle as L
+    from oracle import lamb_cpu_ext
+    calls = []
+
+    def arr(t):
+        return t.detach().clone().numpy()
+
+    orig_l2, orig_lamb = lamb_cpu_ext.multi_tensor_l2norm, lamb_cpu_ext.multi_tensor_lamb
+
+    def rec_l2(chunk_size, noop_flag, tensor_lists, per_tensor=False):
+        c = {"fn": "l2norm", "chunk": int(chunk_size), "noop_in": arr(noop_flag), "lists": [[arr(t) for t in l] for l in tensor_lists],
+             "per_tensor": per_tensor}
+        tot, per = orig_l2(chunk_size, noop_flag, tensor_lists, per_tensor)
+        c.update(noop_out=arr(noop_flag), total=arr(tot), per=arr(per))
+        calls.append(c)
+        return tot, per
+
+    def rec_lamb(chunk_size, noop_flag, tensor_lists, lr, beta1, beta2, epsilon, step, bias_correction, weight_decay, grad_averaging,
+                 mode, global_grad_norm, max_grad_norm, use_nvlamb, found_inf, inv_scale):
+        c = {"fn": "lamb", "chunk": int(chunk_size), "noop_in": arr(noop_flag), "lists": [[arr(t) for t in l] for l in tensor_lists],
+             "lr": arr(lr), "beta1": float(beta1), "beta2": float(beta2), "eps": float(epsilon), "step": arr(step),
+             "bias_correction": int(bias_correction), "weight_decay": float(weight_decay), "grad_averaging": int(grad_averaging),
+             "mode": int(mode), "global_grad_norm": arr(global_grad_norm), "max_grad_norm": arr(max_grad_norm),
+             "use_nvlamb": use_nvlamb, "found_inf": arr(found_inf), "inv_scale": arr(inv_scale)}
+        orig_lamb(chunk_size, noop_flag, tensor_lists, lr, beta1, beta2, epsilon, step, bias_correction, weight_decay, grad_averaging,
+                  mode, global_grad_norm, max_grad_norm, use_nvlamb, found_inf, inv_scale)
+        c["out"] = [[arr(t) for t in l] for l in tensor_lists]
+        calls.append(c)
+
+    lamb_cpu_ext.multi_tensor_l2norm, lamb_cpu_ext.multi_tensor_lamb = rec_l2, rec_lamb
+    try:
+        FusedLAMBAMP = R.import_fused_lamb()                              # binds fused_lamb_CUDA to the (now recording) functions
+        sched = R.import_bert().schedulers
+        case = L.LAMB_GOLDEN_CASE
+        params0, grads = L.lamb_golden_inputs(case)
+        tp = {k: torch.nn.Parameter(torch.from_numpy(a.copy()).to(torch.float16 if half else torch.float32))
+              for k, (a, half) in params0.items()}
+        opt = FusedLAMBAMP([{"params": [tp[k] for k in names], "weight_decay": wd} for wd, names in case["groups"]], lr=case["lr"])
+        opt.setup_fp32_params()
+        lr_sched = sched.PolyWarmUpScheduler(opt, warmup=case["warmup"], total_steps=case["total_steps"], base_lr=case["lr"], device="cpu")
+        scaler = torch.amp.GradScaler("cpu", init_scale=case["init_scale"], growth_interval=case["growth_interval"])
+        marks = []
+        for it, g in enumerate(grads):
+            scaler.scale(torch.zeros(1))
+            scale = float(scaler.get_scale())
+            for k, p in tp.items():
+                gs = (g[k] * np.float32(scale)).astype(np.float16 if p.dtype == torch.float16 else np.float32)
+                if it in case["overflow_at"] and k == "w_c":
+                    gs = gs.copy(); gs.reshape(-1)[5] = np.inf
+                p.grad = torch.from_numpy(gs.copy())
+            lr_sched.step()
+            scaler.step(opt)
+            scaler.update()
+            opt.zero_grad(set_to_none=True)
+            marks.append(len(calls))
+    finally:
+        lamb_cpu_ext.multi_tensor_l2norm, lamb_cpu_ext.multi_tensor_lamb = orig_l2, orig_lamb
+    path = os.path.join(GOLD, "lamb_ref_trace.npz")
+    L.save_call_trace(path, calls, marks)
+    kinds = [c["fn"] for c in calls]
+    print("lamb trace: %d calls (%d l2norm, %d lamb) over %d optimizer steps -> %s (%d bytes)"
+          % (len(calls), kinds.count("l2norm"), kinds.count("lamb"), len(marks), path, os.path.getsize(path)))
+
+
 def gen_bert_large():
     """One encoder layer at BERT-Large width (BASELINE configs[2] shapes) through the reference's module."""
     gen_bert(cfg_name="BERT_STEP_CONFIG_LARGE", out_name="bert_step_large1l.npz", last_layer=0)

@@ -326,6 +326,33 @@ def run_rccl_single_rank(rank, world, dev, steps):
         tol = 0.0 if wire is None else 4e-3
         out["buckets_%s" % ("fp32" if wire is None else "bf16wire")] = bool((flat - keep).abs().max() <= tol * keep.abs().max())
         flat.copy_(keep)
+    # ---- the same wrappers over the C-ABI RCCL path (DLE_COMM=rccl: csrc/rccl_comm.hip through utils/rccl.py)
+    os.environ["DLE_COMM"] = "rccl"
+    try:
+        from deeplearningexamples_amd.utils import rccl
+        c = rccl.comm_for(None)
+        out["direct_count"] = c.count()
+        out["direct_ranks_seen"] = comm.ranks_seen(dev)
+        t = ref.clone()
+        comm.allreduce_mean_(t); comm.allreduce_sum_(t); comm.allreduce_max_(t); comm.broadcast_(t, 0)
+        f = torch.full((1,), 3.0, device=dev); comm.allreduce_max_(f)
+        i64 = torch.arange(5, device=dev); i64b = torch.zeros_like(i64); comm.all_to_all_single(i64b, i64, [5], [5])
+        dst = torch.zeros_like(src)
+        comm.all_to_all_single(dst, src, [7 * 128], [7 * 128])
+        torch.cuda.synchronize()
+        out["direct_identity"] = bool(torch.equal(t, ref) and float(f.item()) == 3.0 and torch.equal(i64b, i64))
+        out["direct_a2a"] = bool(torch.equal(dst, src))
+        b = GradBuckets(flat, [("p%d" % i, 1 << 20) for i in range(3)], bucket_mb=2, comm_stream=stream, reverse=True, wire_dtype=torch.bfloat16)
+        for i in (2, 1, 0):
+            b.grad_ready("p%d" % i)
+        b.wait()
+        torch.cuda.synchronize()
+        out["direct_buckets"] = bool((flat - keep).abs().max() <= 4e-3 * keep.abs().max())
+        flat.copy_(keep)
+        d = run_rn50(0, 2, dev, steps)                       # the RN50 trainer's multi-rank path over the direct wrappers
+        out["direct_rn50"] = {"losses": d["losses"], "nbuckets": d["nbuckets"]}
+    finally:
+        os.environ["DLE_COMM"] = "torch"
     # the trainers: world_size flag 2 over the one-rank RCCL group == world_size 1
     for name, fn in (("rn50", run_rn50), ("bert", run_bert)):
         a = fn(0, 1, dev, steps)

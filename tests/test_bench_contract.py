@@ -106,6 +106,9 @@ def test_compact_record_is_small_and_complete():
 def test_nested_steps_time_enough_steps():
     # nested workloads are timed for >= 20 steps (Tacotron2 >= 8)
     for name, (steps, warm) in bench.NESTED_STEPS.items():
+        if name == "bert_acc32":           # a step = 32 micro-batches (~2.2 s): 3 timed steps = 96 forward / backward passes
+            assert steps >= 3 and warm >= 1
+            continue
         assert steps >= (8 if name == "tacotron2" else 10 if name == "waveglow" else 20), (name, steps)
         assert warm >= 2
 
@@ -116,4 +119,5 @@ def test_line_says_where_traffic_comes_from_and_which_process_group_ran():
     import bench
     src = bench.traffic_source()
     assert src is not None and "profiles/traffic.json" in src and "round" in src and "not measured in this run" in src
-    assert bench.comm_info() == {"backend": None, "world": 1}          # no process group in this test
+    info = bench.comm_info()                                           # no process group in this test
+    assert (info["backend"], info["world"], info["ranks_seen"]) == (None, 1, 1) and "torch.distributed" in info["path"]

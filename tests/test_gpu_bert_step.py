@@ -43,8 +43,8 @@ def test_bert_losses_match_reference(cuda, golden_dir, dtype, which):
     ref = gold["losses"]
     rel = np.abs(np.asarray(losses) - ref) / ref
     floor = np.abs(gold["losses_%s_storage" % ("fp16" if dtype == torch.float16 else "bf16")] - ref) / ref
-    print(dtype, "losses", losses, "reference", ref.tolist(), "rel err", rel.tolist(), "storage floor", floor.tolist())
-    assert np.all(rel <= 1e-3 + floor), (rel, floor)
+    print(dtype, "losses", losses, "reference", ref.tolist(), "rel err / 1e-3", (rel / 1e-3).tolist(), "storage floor", floor.tolist())
+    assert np.all(rel <= 1e-3), (rel, floor)      # the BARE 1e-3 of north_star; the storage floor is context only (printed)
     assert losses[-1] < losses[0] - (0.2 if which == "tiny" else 0.0)
     named = dict(model.named_parameters())
     ref = gold["final_pooler_bias"]
@@ -302,8 +302,8 @@ def test_bert_large_24_layers_vs_reference(cuda, golden_dir, dtype):
     ref = gold["losses"]
     rel = np.abs(np.asarray(losses) - ref) / ref
     floor = np.abs(gold["losses_%s_storage" % tag] - ref) / ref
-    print(tag, "24-layer losses", losses, "reference", ref.tolist(), "rel err", rel.tolist(), "storage floor", floor.tolist())
-    assert np.all(rel <= 1e-3 + floor), (rel, floor)
+    print(tag, "24-layer losses", losses, "reference", ref.tolist(), "rel err / 1e-3", (rel / 1e-3).tolist(), "storage floor", floor.tolist())
+    assert np.all(rel <= 1e-3), (rel, floor)      # the BARE 1e-3 of north_star; the storage floor is context only (printed)
     named = dict(model.named_parameters())
     r = gold["final_pooler_bias"]
     assert np.abs(named["bert.pooler.dense_act.bias"].detach().cpu().numpy() - r).max() <= 0.05 * np.abs(r).max() + 1e-4

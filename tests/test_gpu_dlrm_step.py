@@ -39,8 +39,8 @@ def test_step_losses_match_reference(cuda, golden_dir, name, dtype):
     rel = np.abs(np.asarray(losses) - ref) / ref
     # 1e-3 (north_star) + the 16-bit storage floor the oracle measures on this network (oracle/storage.py, fixture arrays)
     floor = np.abs(gold["losses_%s_storage" % ("fp16" if dtype == torch.float16 else "bf16")] - ref) / ref
-    print(dtype, name, "rel err", rel.tolist(), "storage floor", floor.tolist())
-    assert np.all(rel <= 1e-3 + floor), (rel, floor)
+    print(dtype, name, "rel err / 1e-3", (rel / 1e-3).tolist(), "storage floor", floor.tolist())
+    assert np.all(rel <= 1e-3), (rel, floor)      # the BARE 1e-3 of north_star; the storage floor is context only (printed)
     assert trainer.scaler.found_inf.item() == 0
     # weights after the last step vs the reference's (fp32) weights
     got = {"out.weight": model.top_model.out.weight, "bottom_mlp.0.weight": model.bottom_model.mlp.linears[0].weight}

@@ -126,3 +126,53 @@ def test_reference_class_steps_on_hip_kernels(cuda):
         if q.dtype == torch.float16:
             p16[k] = q.detach().cpu().numpy()
     _check_against_gold(gold, case, p, m, v, p16)
+
+
+def test_reference_class_call_trace_replayed_through_the_shims(cuda):
+    """The reference's unmodified FusedLAMBAMP.step CANNOT be imported on the GPU box (no reference tree there), so its calls travel
+    as data: tests/golden/lamb_ref_trace.npz holds every call the class made into `fused_lamb_CUDA` over the golden scenario --
+    the tensor lists and scalar arguments exactly as fused_lamb.py:147-258 passed them (7 optimizer steps incl. the overflow step:
+    21 multi_tensor_l2norm + 28 multi_tensor_lamb calls) and what each call left behind (oracle/make_golden.py gen_lamb_trace,
+    run where the tree is mounted).  Each call is replayed here through shims/fused_lamb_CUDA.py (argument order of
+    csrc/frontend.cpp:3-32, HIP kernels underneath) on device tensors and compared with the recorded result: returned norms,
+    the noop flag, and the in-place results g (-> update), p, m, v and the fp16 model copy."""
+    import fused_lamb_CUDA as FL
+    calls, marks = L.load_call_trace(os.path.join(ROOT, "tests", "golden", "lamb_ref_trace.npz"))
+    assert len(marks) == L.LAMB_GOLDEN_CASE["steps"] and marks[-1] == len(calls)
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+    n_l2 = n_lamb = n_skipped_by_flag = 0
+    for i, c in enumerate(calls):
+        lists = [[dev(a) for a in l] for l in c["lists"]]
+        noop = dev(c["noop_in"])
+        if c["fn"] == "l2norm":
+            tot, per = FL.multi_tensor_l2norm(int(c["chunk"]), noop, lists, c["per_tensor"])
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(tot.cpu().numpy(), c["total"], rtol=2e-6, err_msg="call %d total" % i)
+            np.testing.assert_allclose(per.cpu().numpy(), c["per"], rtol=2e-6, err_msg="call %d per-tensor" % i)
+            assert np.array_equal(noop.cpu().numpy(), c["noop_out"]), "call %d: noop flag" % i
+            n_l2 += 1
+            continue
+        FL.multi_tensor_lamb(int(c["chunk"]), noop, lists, dev(c["lr"]), c["beta1"], c["beta2"], c["eps"], dev(c["step"]),
+                             int(c["bias_correction"]), c["weight_decay"], int(c["grad_averaging"]), int(c["mode"]),
+                             dev(c["global_grad_norm"]), dev(c["max_grad_norm"]), c["use_nvlamb"], dev(c["found_inf"]),
+                             dev(c["inv_scale"]))
+        torch.cuda.synchronize()
+        n_lamb += 1
+        n_skipped_by_flag += int(c["noop_in"].reshape(-1)[0] != 0)
+        for li, (got_l, want_l) in enumerate(zip(lists, c["out"])):
+            for ti, (got, want) in enumerate(zip(got_l, want_l)):
+                g = got.float().cpu().numpy()
+                w = want.astype(np.float32)
+                if want.dtype == np.float16:                 # 16-bit results: one fp16 ulp where an fp32 value sits on a rounding edge
+                    fin = np.isfinite(w)
+                    assert np.array_equal(np.isfinite(g), fin), "call %d list %d tensor %d" % (i, li, ti)
+                    assert np.all(np.abs(g[fin] - w[fin]) <= np.abs(w[fin]) * 2.0 ** -10 + 1e-7), "call %d list %d tensor %d" % (i, li, ti)
+                else:
+                    # fp32 results: device pow / rsqrt / division against numpy's, one call deep (measured <= 1.9e-5 relative)
+                    np.testing.assert_allclose(g, w, rtol=4e-5, atol=2e-7, equal_nan=True,
+                                               err_msg="call %d list %d tensor %d" % (i, li, ti))
+    print("replayed %d l2norm + %d lamb calls of the reference class (%d under a set noop flag)" % (n_l2, n_lamb, n_skipped_by_flag))
+    assert n_l2 == 21 and n_lamb == 28

@@ -95,6 +95,13 @@ def test_rccl_branch_on_a_single_rank_communicator(cuda, tmp_path):
     res = json.load(open(out))[0]
     print(res)
     assert res["identity"] and res["a2a"] and res["buckets_fp32"] and res["buckets_bf16wire"]
+    # DLE_COMM=rccl: the same wrappers through the C-ABI binding of librccl.so (csrc/rccl_comm.hip, utils/rccl.py): ncclCommCount
+    # reports the one rank that joined, every collective is the identity, the bucket hooks and the RN50 trainer's multi-rank path
+    # reproduce the torch-ProcessGroup results
+    assert res["direct_count"] == 1 and res["direct_ranks_seen"] == 1
+    assert res["direct_identity"] and res["direct_a2a"] and res["direct_buckets"]
+    np.testing.assert_allclose(res["direct_rn50"]["losses"], res["rn50"]["one"], rtol=1e-4)
+    assert res["direct_rn50"]["nbuckets"] > 1
     for name in ("rn50", "bert"):
         np.testing.assert_allclose(res[name]["flag2"], res[name]["one"], rtol=1e-4)
         ref = np.asarray(res[name]["probe_one"])

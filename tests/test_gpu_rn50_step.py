@@ -41,8 +41,10 @@ def test_rn50_losses_match_reference(cuda, golden_dir, dtype):
     ref = gold["losses"]
     floor = np.abs(gold["losses_%s_storage" % ("fp16" if dtype == torch.float16 else "bf16")] - ref) / ref
     rel = np.abs(np.asarray(losses) - ref) / ref
-    print(dtype, "losses", losses, "reference", ref.tolist(), "rel err", rel.tolist(), "storage floor", floor.tolist())
-    assert np.all(rel <= 1e-3 + floor), (rel, floor)
+    print(dtype, "losses", losses, "reference", ref.tolist(), "rel err / 1e-3", (rel / 1e-3).tolist(), "storage floor", floor.tolist())
+    # the BARE 1e-3 of north_star (measured: fp16 <= 3e-5, bf16 <= 3.2e-4); the 16-bit storage floor the oracle measured for this
+    # network is printed for context and no longer part of the bar
+    assert np.all(rel <= 1e-3), (rel, floor)
     assert losses[-1] < losses[0]
     tr.sync_counters()
     assert int(model.bn1.num_batches_tracked.item()) == c["steps"]
@@ -83,7 +85,7 @@ def test_rn50_first_step_gradients_vs_oracle(cuda, dtype):
     print("max logit error / max logit %.3e (storage floor %.3e), loss hip %.6f oracle %.6f (storage floor %.3e)"
           % (err, efloor, loss.item(), lo, lfloor))
     assert err <= 2e-2 + 1.5 * efloor
-    assert abs(loss.item() - lo) <= (1e-3 + lfloor) * lo
+    assert abs(loss.item() - lo) <= 1e-3 * lo                  # bare north_star bar; lfloor printed above for context
     scale = float(tr.scaler.scale.item())
     tr.backward(dl)
     torch.cuda.synchronize()
