@@ -163,8 +163,6 @@ class ConvBN:
                 b2 = (bnred.saved[1], bnred.saved[2], bnred.saved[3], bnred.saved[4], bnred.ggamma, bnred.gbeta)
             fused = F.bn_bwd_conv1x1_dgrad(dy, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta,
                                            self.w16.view(self.cout, c), relu_mask=rmask, reduce_done=reduce_done, bnred=b2)
-            if isinstance(fused, str):               # "reduced": the fused kernel declined after the reduction had been launched
-                fused, reduce_done = None, True
         if fused is not None:
             gt = fused[0]
             if fused[2]:

@@ -131,8 +131,13 @@ __global__ __launch_bounds__(256) void dot_fwd_mfma_walk(const unsigned short* _
       if (i < R && j < i) so[C + i * (i - 1) / 2 + j] = Elem<DT>::from_f32(acc[r]);
     }
     for (int p = C + ntril + lane; p < OW; p += 64) so[p] = 0;
+    // lanes exchange data through `so` without a barrier (one wavefront: its LDS instructions execute in order): the compiler
+    // must see the ordering too -- thread by thread it may forward a lane's earlier load across ANOTHER lane's exec-masked
+    // store (it did in gemm8_kernel.h, see G8_WAVE_FENCE).  A wavefront-scope fence costs no instruction.
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     unsigned short* o = out + (size_t)b * OW;
     for (int q = lane * 8; q < OW; q += 512) *(ushort8_t*)(o + q) = *(const ushort8_t*)(so + q);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");       // ... and before the next sample's writes
   }
 }
 

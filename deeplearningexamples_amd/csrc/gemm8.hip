@@ -85,10 +85,19 @@ extern "C" int dle_gemm8_try(const void* A, const void* B, void* C, void* aux, c
   const long long nitems = tiles * splitk;
   const int min_items = dle_gemm8_min_items(-1);
   if (nitems < min_items || nitems > (1 << 22) || splitk > 0x7FFF || ktiles > 0xFFFF) return 0;      // (walk table fields)
-  static const int ncu = [] { int dev = 0, v = 0; hipGetDevice(&dev);
-                              hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
-  static const int lds_max = [] { int dev = 0, v = 0; hipGetDevice(&dev);
-                                  hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev); return v; }();
+  // device properties cached PER DEVICE (a process that drives a second GPU must not launch with the first one's CU count /
+  // LDS limit; g8_launch keys its MaxDynamicSharedMemorySize attribute the same way)
+  static int ncu_of[G8_MAX_DEVICES], lds_of[G8_MAX_DEVICES];
+  const int dev = g8_current_device();
+  if (dev < 0) return 0;
+  if (ncu_of[dev] == 0) {
+    int v = 0, l = 0;
+    hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+    hipDeviceGetAttribute(&l, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+    lds_of[dev] = l;
+    __atomic_store_n(&ncu_of[dev], v > 0 ? v : 256, __ATOMIC_RELEASE);
+  }
+  const int ncu = ncu_of[dev], lds_max = lds_of[dev];
   if (lds_max < G8_LDS_BYTES) return 0;
   Gemm8Args p = {};
   p.A = (const unsigned short*)A; p.B = (const unsigned short*)B; p.C = C; p.aux = aux; p.bias = bias;

@@ -1036,12 +1036,22 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
 }
 
 
+#define G8_MAX_DEVICES 64
+// current device index, or -1 when it cannot be cached per device (the launcher then declines: gemm_dma.hip takes the shape)
+static inline int g8_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= G8_MAX_DEVICES) return -1;
+  return dev;
+}
+
 template <int DT, int AM, int BMD, int EPI, int ACT>
 static void g8_launch(const Gemm8Args& p, int grid, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only: one flag per device
+  static bool attr_set[G8_MAX_DEVICES];
+  const int dev = g8_current_device();
+  if (dev >= 0 && !attr_set[dev]) {
     (void)hipFuncSetAttribute((const void*)gemm8_kernel<DT, AM, BMD, EPI, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS_BYTES);
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL((gemm8_kernel<DT, AM, BMD, EPI, ACT>), dim3(grid), dim3(512), G8_LDS_BYTES, stream, p);
 }

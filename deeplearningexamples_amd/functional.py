@@ -958,8 +958,8 @@ def bn_bwd_conv1x1_dgrad(dy, x, mean, rstd, gamma, dgamma, dbeta, w, relu_mask=N
     bnred = (t2 [.., N], bits2, mean2, rstd2, dgamma2, dbeta2): dx is the gradient that enters a second BatchNorm (bn2 of the
     bottleneck, behind a ReLU with keep bits bits2); its backward reduction is taken from dx in the same kernel and left in
     dgamma2 / dbeta2 (the caller's second unit then skips its own first pass).
-    -> (dt, dx [m, N], bnred taken) or None outside the kernel's envelope (nothing has been launched then: run bn_bwd + gemm)
-    or the string "reduced" (the kernel declined AFTER the reduction was launched: run bn_bwd with reduce_done=True + gemm)."""
+    -> (dt, dx [m, N], bnred taken) or None outside the kernel's envelope (nothing has been launched then: run bn_bwd + gemm).
+    (When the C side declines AFTER the reduction was launched the unfused apply + GEMM run here: same triple, taken = False.)"""
     C.require_cuda(dy, x, mean, rstd, gamma, dgamma, dbeta, w, relu_mask)
     k = x.shape[-1]
     m = x.numel() // k
@@ -995,8 +995,11 @@ def bn_bwd_conv1x1_dgrad(dy, x, mean, rstd, gamma, dgamma, dbeta, w, relu_mask=N
         C.check(rc - 1000 if rc > 1000 else -1, "dle_conv1x1_bnbwd_dgrad")
     if rc != 1:
         # the C side declined (a condition the envelope above cannot see, e.g. its statically cached DLE_CONV_BNBWD pin): the
-        # reduction has been launched and dgamma / dbeta are final -- the caller continues with the unfused apply + GEMM
-        return "reduced"
+        # reduction has been launched and dgamma / dbeta are final -- continue HERE with the unfused apply + GEMM, so that a
+        # caller only ever sees None (nothing launched) or the (dt, dx, taken) triple
+        dt, _ = bn_bwd(dy, None, x, mean, rstd, gamma, dgamma, dbeta, relu_mask=relu_mask, reduce_done=True, dx_out=dt)
+        gemm(dt.view(m, k), w, m, n, k, True, False, out=dx)
+        return dt, dx, False
     if t2 is not None:
         C.call("dle_bn_bwd_finish", C.ptr(part), groups, n, C.ptr(bnred[4]), C.ptr(bnred[5]), 0, C.stream())
     return dt, dx, t2 is not None

@@ -171,8 +171,12 @@ def test_reference_class_call_trace_replayed_through_the_shims(cuda):
                     assert np.array_equal(np.isfinite(g), fin), "call %d list %d tensor %d" % (i, li, ti)
                     assert np.all(np.abs(g[fin] - w[fin]) <= np.abs(w[fin]) * 2.0 ** -10 + 1e-7), "call %d list %d tensor %d" % (i, li, ti)
                 else:
-                    # fp32 results: device pow / rsqrt / division against numpy's, one call deep (measured <= 1.9e-5 relative)
-                    np.testing.assert_allclose(g, w, rtol=4e-5, atol=2e-7, equal_nan=True,
+                    # fp32 results: device pow / rsqrt / division against numpy's, one call deep (measured <= 1.9e-5 relative).
+                    # Masters (list 1) of HALF parameters: the update is rounded to fp16 inside the gradient buffer
+                    # (multi_tensor_lamb.cu:163), so an fp32-ulp difference upstream can flip one fp16 rounding of it:
+                    # lr x trust ratio x 2^-11 |u| ~ 5e-6 absolute (the same allowance as _check_against_gold)
+                    half_call = c["lists"][0][0].dtype == np.float16
+                    np.testing.assert_allclose(g, w, rtol=4e-5, atol=1e-5 if (half_call and li == 1) else 2e-7, equal_nan=True,
                                                err_msg="call %d list %d tensor %d" % (i, li, ti))
     print("replayed %d l2norm + %d lamb calls of the reference class (%d under a set noop flag)" % (n_l2, n_lamb, n_skipped_by_flag))
     assert n_l2 == 21 and n_lamb == 28
