@@ -233,16 +233,20 @@ static int bl_tn(int N) { return (N % 128) == 0 ? 128 : 64; }
 // wavefronts per workgroup: 8 only where the weight tile is large (K = 256 x 128 columns: 66 KiB, two workgroups per CU); the
 // 64-column tiles of K = 256 (34 KiB, 140 registers: three wavefronts per SIMD) run three 4-wave workgroups per CU
 static int bl_nw(int K, int N) { return (K > 128 && bl_tn(N) == 128) ? 8 : 4; }
+// K = 512 (the conv1 of a 28 x 28 bottleneck consuming bn3 of the block before it: 512 -> 128 channels): the 128 x 520 weight tile
+// is 133 KiB -- ONE 8-wave workgroup per CU, 16 k steps of fragments per lane (64 + 64 registers with the residual);
+// DLE_CONV_BNLOAD_K512=0 keeps the two-launch sequence
+static int bl_k512() { static const int v = getenv("DLE_CONV_BNLOAD_K512") ? atoi(getenv("DLE_CONV_BNLOAD_K512")) : 1; return v; }
 
 // Number of statistics rows dle_conv1x1_bnload_fwd writes for (M, N, K); 0: the shape is outside the kernel's envelope.
 extern "C" int dle_conv1x1_bnload_groups(int M, int N, int K) {
-  if (M < 4096 || (K != 64 && K != 128 && K != 256) || (N % 64) != 0 || N < 64) return 0;
+  if (M < 4096 || (K != 64 && K != 128 && K != 256 && !(K == 512 && N == 128 && bl_k512())) || (N % 64) != 0 || N < 64) return 0;
   const int tm = bl_nw(K, N) * 16, row_tiles = (M + tm - 1) / tm, col_tiles = N / bl_tn(N);
   // every column tile re-reads the rows (through L2) and REPEATS the BatchNorm arithmetic on them: with more than two column
   // tiles the two-launch sequence wins (measured, batch-256 ResNet-50: 50176 x 1024 x 256 fused 87 us vs 12 + 55 us apart,
   // 200704 x 512 x 128 96 vs 20 + 69; 802816 x 256 x 64 142 vs 46 + 127, 802816 x 64 x 256 + residual 301 vs 233 + 122)
   if (col_tiles > 2) return 0;
-  const int per_cu = K > 128 ? (bl_tn(N) == 128 ? 2 : 3) : 4;
+  const int per_cu = K > 256 ? 1 : K > 128 ? (bl_tn(N) == 128 ? 2 : 3) : 4;
   int groups = (256 * per_cu + col_tiles - 1) / col_tiles;
   if (groups > row_tiles) groups = row_tiles;
   return (groups + 7) / 8 * 8;
@@ -267,6 +271,7 @@ static int bnload_launch(const void* t, const void* res, const void* w, void* ou
   p.Y = (unsigned short*)y; p.bits = (unsigned char*)bits; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.stats = stats;
   p.mean_r = mean_r; p.rstd_r = rstd_r; p.gamma_r = gamma_r; p.beta_r = beta_r;
   const int resmode = !res ? 0 : (mean_r ? 2 : 1);
+  if (K == 512 && resmode != 1) return 0;                 // (instantiated for the residual form only: bn3 + identity)
   p.M = M; p.N = N; p.K = K;
   const int TN = bl_tn(N), NWv = bl_nw(K, N), tm = NWv * 16;
   p.row_tiles = (M + tm - 1) / tm; p.col_tiles = N / TN; p.groups = groups;
@@ -274,11 +279,12 @@ static int bnload_launch(const void* t, const void* res, const void* w, void* ou
   if (lds < (size_t)NWv * 2 * TN * 4) lds = (size_t)NWv * 2 * TN * 4;
   const dim3 grid((unsigned)(groups * p.col_tiles)), block(NWv * 64);
 #define BL_GO(DT, KS, RS, NBV, NWV) do { static bool attr_set = false; \
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_bnload_kernel<DT, KS, RS, NBV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set = true; } \
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_bnload_kernel<DT, KS, RS, NBV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); attr_set = true; } \
     hipLaunchKernelGGL((conv_bnload_kernel<DT, KS, RS, NBV, NWV>), grid, block, lds, stream, p); } while (0)
 #define BL_NB(DT, KS, RS, NWV) do { if (TN == 128) BL_GO(DT, KS, RS, 8, NWV); else BL_GO(DT, KS, RS, 4, NWV); } while (0)
 #define BL_RES(DT, KS, NWV) do { if (resmode == 2) BL_NB(DT, KS, 2, NWV); else if (resmode == 1) BL_NB(DT, KS, 1, NWV); else BL_NB(DT, KS, 0, NWV); } while (0)
-#define BL_K(DT) do { if (K == 64) BL_RES(DT, 2, 4); else if (K == 128) BL_RES(DT, 4, 4); else if (NWv == 8) BL_RES(DT, 8, 8); else BL_RES(DT, 8, 4); } while (0)
+#define BL_K(DT) do { if (K == 64) BL_RES(DT, 2, 4); else if (K == 128) BL_RES(DT, 4, 4); else if (K == 512) BL_GO(DT, 16, 1, 8, 8); \
+                      else if (NWv == 8) BL_RES(DT, 8, 8); else BL_RES(DT, 8, 4); } while (0)
   if (dtype == DLE_F16) BL_K(DLE_F16); else BL_K(DLE_BF16);
 #undef BL_K
 #undef BL_RES

@@ -489,6 +489,10 @@ extern "C" int dle_gemm_dma_try(const void* A, const void* B, void* C, void* aux
                                 int accumulate, float alpha, void* workspace, int64_t workspace_bytes,
                                 hipStream_t stream);
 
+extern "C" int dle_gemm8_try(const void* A, const void* B, void* C, void* aux, const float* bias, const void* src, int M, int N,
+                             int K, int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc, int in_dtype, int out_dtype,
+                             int act, int splitk, int accumulate, float alpha, float* ws, float* stats, hipStream_t stream);   // gemm8.hip
+
 extern "C" int dle_gemm_smallm_try(const void* A, const void* B, void* C, const float* bias, const void* src, int M, int N, int K,
                                    int64_t lda, int64_t ldb, int64_t ldc, int in_dtype, int out_dtype, int act_add, int accumulate,
                                    float alpha, hipStream_t stream);     // gemm_smallm.hip
@@ -535,6 +539,19 @@ extern "C" int dle_gemm(const void* A, const void* B, void* C, void* aux, const 
                                         alpha, stream);
       if (r == 1) return 0;
       if (r != 0) return r;
+    }
+    // the masked-addend data gradient of the deep stages' conv1 (K >= 256, M <= 65536 rows: 14 x 14 and 7 x 7 at batch 256): the
+    // ping-pong kernel's source-tensor epilogue with the keep bits (gemm8_kernel.h, ACT_ADD_MASKED); DLE_GEMM8_MASKED=0 keeps the
+    // streaming kernel below
+    if (!legacy && act == 8 && a_kc && !b_kc && splitk == 1 && !accumulate && !bias && alpha == 1.0f && K >= 256) {
+      static const int on = getenv("DLE_GEMM8_MASKED") ? atoi(getenv("DLE_GEMM8_MASKED")) : 1;
+      static const long long maxm = getenv("DLE_GEMM8_MASKED_MAXM") ? atoll(getenv("DLE_GEMM8_MASKED_MAXM")) : 65536;
+      if (on && M <= maxm) {
+        const int r = dle_gemm8_try(A, B, C, aux, bias, mask_src, M, N, K, lda, ldb, ldc, a_kc, b_kc, in_dtype, out_dtype, act, 1, 0,
+                                    alpha, nullptr, nullptr, stream);
+        if (r == 1) return 0;
+        if (r > 1) return r;
+      }
     }
     // many rows, K <= 256, N >= 2 K (the channel-widening 1x1 convolutions): the streaming kernel of gemm_expand.hip
     // (store-only products with K = 64 stay on the tile kernel's PLAIN epilogue: 135 vs 152 us at 802816 x 256 x 64)

@@ -38,17 +38,18 @@ static int g8_launch_epi0(const Gemm8Args* p, int dt, int am, int bm, int grid, 
 
 // 1: launched; 0: outside the envelope (the caller continues with the kernels of gemm_dma.hip); > 1: error.
 // stats != NULL: column sums of the rounded output into stats[2 * ceil(M / 256)][N] (act = ReLU mask / stored derivative only).
-extern "C" int dle_gemm8_try(const void* A, const void* B, void* C, void* aux, const float* bias, const void* src, int M, int N,
-                             int K, int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc, int in_dtype, int out_dtype,
-                             int act, int splitk, int accumulate, float alpha, float* ws, float* stats, hipStream_t stream) {
+static int g8_try(const void* A, const void* B, void* C, void* aux, const float* bias, const void* src, int M, int N,
+                  int K, int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc, int in_dtype, int out_dtype,
+                  int act, int splitk, int accumulate, float alpha, float* ws, float* stats, int stats_sq, hipStream_t stream) {
   if (dle_gemm8_mode(-1) <= 0) return 0;
   if (in_dtype != DLE_F16 && in_dtype != DLE_BF16) return 0;
   if (!a_kc && b_kc) return 0;
   if (M < 256 || N < 256 || K < 2 * BK || (K & 7) != 0 || (N & 7) != 0) return 0;
   if ((K % BK) != 0 && !(a_kc && lda >= K && (!b_kc || ldb >= K))) return 0;      // (K tail: per-lane predicate of k-contiguous operands)
   if (!a_kc && (M & 7) != 0) return 0;
-  const bool al = ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)aux) | ((uintptr_t)src) | ((uintptr_t)bias) |
-                    ((uintptr_t)ws)) & 15) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && (ldc & 7) == 0;
+  const bool al = ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)src) | ((uintptr_t)bias) |
+                    ((uintptr_t)ws)) & 15) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && (ldc & 7) == 0 &&
+                  (((uintptr_t)aux) & (act == ACT_ADD_MASKED ? 1 : 15)) == 0;
   if (!al) return 0;
   // operand extents (range-checked DMA) and 32-bit lane offsets
   const long long a_rows = a_kc ? M : K, b_rows = b_kc ? N : K;
@@ -63,12 +64,17 @@ extern "C" int dle_gemm8_try(const void* A, const void* B, void* C, void* aux, c
   if (splitk > 1) {
     if (!ws || out_dtype != DLE_F32 || bias || act != ACT_NONE || aux || stats) return 0;
     epi = 0;
-  } else if (act == ACT_RELU_BWD || act == ACT_ADD || act == ACT_MUL || act == ACT_GELU_BWD || act == ACT_TANH_BWD) {
-    if (!src || bias || aux || out_dtype != in_dtype || accumulate || alpha != 1.0f) return 0;
+  } else if (act == ACT_RELU_BWD || act == ACT_ADD || act == ACT_ADD_MASKED || act == ACT_MUL || act == ACT_GELU_BWD || act == ACT_TANH_BWD) {
+    if (!src || bias || (aux != nullptr) != (act == ACT_ADD_MASKED) || out_dtype != in_dtype || accumulate || alpha != 1.0f) return 0;
+    if (act == ACT_ADD_MASKED && (ldc != N || b_kc)) return 0;            // (keep bits of a dense [M, N] addend; the conv1 data gradient)
     if ((long long)(M + 256) * ldc * 2 >= 0xFFFFFFFFLL) return 0;      // 32-bit byte offsets of the range-checked source loads
     if (stats && !(act == ACT_RELU_BWD || act == ACT_MUL)) return 0;
     if (stats && (M & 255) != 0) return 0;
     epi = 2;
+  } else if (stats && act == ACT_NONE && stats_sq) {
+    // column sums + sums of squares of the rounded 16-bit output (a 1x1 convolution forward with its BatchNorm statistics)
+    if (bias || aux || out_dtype != in_dtype || accumulate || alpha != 1.0f || !a_kc || !b_kc || (M & 255) != 0) return 0;
+    epi = 3;
   } else if (act == ACT_NONE || act == ACT_RELU || act == ACT_GELU || act == ACT_TANH || act == ACT_GELU_DAUX) {
     if (stats) return 0;
     if (out_dtype == DLE_F32) {
@@ -120,7 +126,10 @@ extern "C" int dle_gemm8_try(const void* A, const void* B, void* C, void* aux, c
   p.grid = grid;
   if ((nitems + grid - 1) / grid > G8_TBL_ITEMS) return 0;         // (the workgroup's walk table in LDS)
   int launched;
-  if (epi == 0) launched = g8_launch_epi0(&p, in_dtype, am, bm, grid, stream);
+  if (epi == 3) {
+    if (in_dtype == DLE_F16) g8_launch<DLE_F16, 0, 0, 3, ACT_NONE>(p, grid, stream); else g8_launch<DLE_BF16, 0, 0, 3, ACT_NONE>(p, grid, stream);
+    launched = 1;
+  } else if (epi == 0) launched = g8_launch_epi0(&p, in_dtype, am, bm, grid, stream);
   else if (epi == 1) launched = g8_launch_epi1(&p, in_dtype, am, bm, act, grid, stream);
   else launched = g8_launch_epi2(&p, in_dtype, am, bm, act, grid, stream);
   if (!launched) return 0;
@@ -128,4 +137,22 @@ extern "C" int dle_gemm8_try(const void* A, const void* B, void* C, void* aux, c
   if (e != hipSuccess) { dle_set_error("gemm8 launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
   __atomic_fetch_add(&g8_launches, 1, __ATOMIC_RELAXED);
   return 1;
+}
+
+extern "C" int dle_gemm8_try(const void* A, const void* B, void* C, void* aux, const float* bias, const void* src, int M, int N,
+                             int K, int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc, int in_dtype, int out_dtype,
+                             int act, int splitk, int accumulate, float alpha, float* ws, float* stats, hipStream_t stream) {
+  return g8_try(A, B, C, aux, bias, src, M, N, K, lda, ldb, ldc, a_kc, b_kc, in_dtype, out_dtype, act, splitk, accumulate, alpha, ws,
+                stats, 0, stream);
+}
+
+// C [M, N] = A [M, K] B [N, K]^T (16-bit, both k-contiguous) AND, per 128 output rows, the column sums and sums of squares of the
+// ROUNDED output: stats [M / 128][2][N] (row r = rows 128 r .. 128 r + 127) -- the 1x1 convolution forward with the batch
+// statistics of the BatchNorm behind it (dle_conv2d_fwd_colstats; fold with dle_bn_stats_from_partials, groups = M / 128).
+// M a multiple of 256.  1: launched; 0: outside the envelope; > 1: error.
+extern "C" int dle_gemm8_colstats_try(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                                      int dtype, float* stats, hipStream_t stream) {
+  if (!stats) return 0;
+  return g8_try(A, B, C, nullptr, nullptr, nullptr, M, N, K, lda, ldb, ldc, 1, 1, dtype, dtype, ACT_NONE, 1, 0, 1.0f, nullptr, stats, 1,
+                stream);
 }

@@ -260,7 +260,10 @@ __device__ __forceinline__ float g8_gelu_d(float x, float& d) {
 }
 
 // EPI: 0 = store only (16-bit, fp32 (+ accumulate), split-K slab); 1 = bias + forward activation (+ side output);
-//      2 = source-tensor epilogues (ReLU mask, addend, stored derivative, GELU' / tanh' of a stored value) (+ column sums)
+//      2 = source-tensor epilogues (ReLU mask, addend, addend under keep bits, stored derivative, GELU' / tanh' of a stored value)
+//          (+ column sums);
+//      3 = 16-bit store + per-(tile row, wavefront row group) column sums AND sums of squares of the rounded output: the batch
+//          statistics of the BatchNorm behind a 1x1 convolution (dle_conv2d_fwd_colstats' contract, 128 rows per partial row)
 // ACT: the epilogue's activation / source operation, a compile-time constant (one switch per 16 elements per block per flavour
 // made the EPI 2 kernel 60 KB of code: its epilogue ran from the instruction cache misses)
 template <int DT, int AM, int BMD, int EPI, int ACT>
@@ -663,12 +666,13 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     asm volatile("" : "+s"(e_C), "+s"(e_aux), "+s"(e_bias), "+s"(e_src), "+s"(e_ldc), "+s"(e_cbytes));
     // ---- epilogue, in the accumulator layout: lane (fr, fh) of block (i, j, b) owns row m0 + 128 i + 64 wr + 32 b + fr,
     // columns n0 + 128 j + 32 wc + 16 fh .. + 15
-    float st[2][16];                               // column sums of the rounded output over this lane's rows (EPI 2, q->stats)
-    if constexpr (EPI == 2) {
+    float st[2][16];                               // column sums of the rounded output over this lane's rows (EPI 2 / 3, q->stats)
+    float st2[EPI == 3 ? 2 : 1][16];               // ... and the sums of squares (EPI 3)
+    if constexpr (EPI == 2 || EPI == 3) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) { st[j][r] = 0.f; if constexpr (EPI == 3) st2[j][r] = 0.f; }
     }
     // Interior tile, 16-bit output (every flavour) or fp32 output (plain / slab): no per-lane predicate, no 64-bit address
     // arithmetic -- a lane's byte offset inside the tile is a constant (rows fr, columns 16 fh), the block's position is a
@@ -768,6 +772,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
           }
         };
         ushort8_t sv[EPI == 2 ? 8 : 1][2];
+        unsigned short kb[(EPI == 2 && ACT == ACT_ADD_MASKED) ? 8 : 1];      // the lane's 16 keep bits of each block (accumulator layout)
         if constexpr (EPI == 2) {
           __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)e_src, 0, (int)e_cbytes, 0x00020000);
           static_for<0, 8>([&](auto BI) __attribute__((always_inline)) {
@@ -776,6 +781,15 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
             sv[bi][0] = __builtin_bit_cast(ushort8_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, lane_off_t, so, 0));
             sv[bi][1] = __builtin_bit_cast(ushort8_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, lane_off_t + second_t, so, 0));
           });
+          if constexpr (ACT == ACT_ADD_MASKED) {
+            // keep bits: bit (m ldc + n) & 7 of byte (m ldc + n) >> 3 -- a lane's 16 columns are two bytes (ldc and the column
+            // base are multiples of 8: the launcher checks); byte offsets are the 16-bit element offsets / 8 = byte offsets / 16
+            __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc((void*)e_aux, 0, (int)(e_cbytes >> 4), 0x00020000);
+            static_for<0, 8>([&](auto BI) __attribute__((always_inline)) {
+              constexpr int bi = decltype(BI)::value, i = bi >> 2, j = (bi >> 1) & 1, b = bi & 1;
+              kb[bi] = __builtin_amdgcn_raw_buffer_load_b16(rsrc_k, (lane_off + blk_off(i, j, b)) >> 4, 0, 0);
+            });
+          }
         }
         __amdgpu_buffer_rsrc_t ra = rc;
         if constexpr (EPI == 1) { if (e_aux) ra = __builtin_amdgcn_make_buffer_rsrc((void*)e_aux, 0, (int)e_cbytes, 0x00020000); }
@@ -839,6 +853,10 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
             } else if (ACT == ACT_ADD) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) v[r] += y[r];
+            } else if (ACT == ACT_ADD_MASKED) {
+              const unsigned bits = kb[(EPI == 2 && ACT == ACT_ADD_MASKED) ? bi : 0];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) { if ((bits >> r) & 1u) v[r] += y[r]; }
             } else if (ACT == ACT_MUL) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) v[r] *= y[r];
@@ -861,13 +879,13 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t0), rc, lane_off_t + so, 0, G8_ST_AUX);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t1), rc, lane_off_t + so + second_t, 0, G8_ST_AUX);
           }
-          if constexpr (EPI == 2) {
+          if constexpr (EPI == 2 || EPI == 3) {
             if (q->stats) {
               float vr[16];
               unpack8<DT>(o0, vr);
               unpack8<DT>(o1, vr + 8);
 #pragma unroll
-              for (int r = 0; r < 16; ++r) st[j][r] += vr[r];
+              for (int r = 0; r < 16; ++r) { st[j][r] += vr[r]; if constexpr (EPI == 3) st2[j][r] += vr[r] * vr[r]; }
             }
           }
         });
@@ -951,6 +969,11 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
               } else if (ACT == ACT_ADD) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] += y[r];
+              } else if (ACT == ACT_ADD_MASKED) {
+                const unsigned char* kbp = (const unsigned char*)e_aux + (off >> 3);
+                const unsigned bits = (unsigned)kbp[0] | (hi_ok ? (unsigned)kbp[1] << 8 : 0u);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { if ((bits >> r) & 1u) v[r] += y[r]; }
               } else if (ACT == ACT_MUL) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] *= y[r];
@@ -975,31 +998,35 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
               *(ushort8_t*)a = pack8<DT>(side);
               if (hi_ok) *(ushort8_t*)(a + 8) = pack8<DT>(side + 8);
             }
-            if constexpr (EPI == 2) {
+            if constexpr (EPI == 2 || EPI == 3) {
               if (q->stats) {
                 float vr[16];
                 unpack8<DT>(o0, vr);
                 unpack8<DT>(o1, vr + 8);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st[j][r] += (r < 8 || hi_ok) ? vr[r] : 0.f;
+                for (int r = 0; r < 16; ++r) {
+                  const float z = (r < 8 || hi_ok) ? vr[r] : 0.f;
+                  st[j][r] += z;
+                  if constexpr (EPI == 3) st2[j][r] += z * z;
+                }
               }
             }
           }
         }
       }
     });
-    if constexpr (EPI == 2) {
+    if constexpr (EPI == 2 || EPI == 3) {
       if (q->stats) {
         // the 32 row lanes of a column group reduce-scatter their 16 sums: after the xor-16 / 8 / 4 / 2 exchanges a lane keeps
         // ONE column (index = bits 4..1 of fr), the xor-1 exchange completes it; even lanes store.  One partial row per
-        // (tile row, wavefront row group), folded in a fixed order by colsum_fold_kernel.
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        // (tile row, wavefront row group), folded in a fixed order by colsum_fold_kernel (EPI 2: [row][N]) or by
+        // bn_stats_from_partials (EPI 3: [row][2][N], sums then sums of squares).
+        auto reduce_store = [&](float (&sx)[16], int j, int which) __attribute__((always_inline)) {
           float a8[8], a4[4], a2[2], a1;
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
             const bool up = (fr & 16) != 0;
-            const float keep = up ? st[j][8 + r] : st[j][r], send = up ? st[j][r] : st[j][8 + r];
+            const float keep = up ? sx[8 + r] : sx[r], send = up ? sx[r] : sx[8 + r];
             a8[r] = keep + __shfl_xor(send, 16, 64);
           }
 #pragma unroll
@@ -1021,7 +1048,16 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
           }
           a1 += __shfl_xor(a1, 1, 64);
           const int col = n0 + j * 128 + wc * 32 + fh * 16 + ((fr >> 1) & 15);
-          if ((fr & 1) == 0 && col < p.N) q->stats[((long long)((m0 >> 8) * 2 + wr)) * p.N + col] = a1;
+          const long long prow = (long long)((m0 >> 8) * 2 + wr);
+          if ((fr & 1) == 0 && col < p.N) {
+            if constexpr (EPI == 3) q->stats[(prow * 2 + which) * p.N + col] = a1;
+            else q->stats[prow * p.N + col] = a1;
+          }
+        };
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          reduce_store(st[j], j, 0);
+          if constexpr (EPI == 3) reduce_store(st2[j], j, 1);
         }
       }
     }

@@ -1112,6 +1112,8 @@ extern "C" int dle_conv2d_fwd(const void* x, const void* w, void* y, const float
   return conv_launch(p, dtype, 2, 0, stream);
 }
 
+extern "C" int dle_gemm8_colstats_try(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                                      int dtype, float* stats, hipStream_t stream);   // gemm8.hip
 extern "C" int dle_gemm_expand_groups(int M, int N, int K);                // gemm_expand.hip
 extern "C" int dle_gemm_expand_try(const void* A, const void* B, void* C, const void* src, const void* bits, float* stats, int M,
                                    int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_kc, int in_dtype, int out_dtype,
@@ -1138,6 +1140,18 @@ extern "C" int dle_conv2d_fwd_colstats(const void* x, const void* w, void* y, in
     if (rc > 1) return rc;
   }
   const bool plain = R == 1 && S == 1 && stride == 1 && pad == 0;
+  if (plain && M < 0x7FFFFFFF && (M & 255) == 0) {
+    // the deep stages (14 x 14, 7 x 7: M <= 65536 rows, K >= 128): the persistent ping-pong kernel with the statistics in its
+    // register epilogue (gemm8_kernel.h EPI 3) -- the streaming / tile kernels run these shapes at 0.4 of their HBM floor.
+    // DLE_CONV_STATS_GEMM8=0 pins the older kernels; DLE_CONV_STATS_GEMM8_MAXM moves the row limit (A/B measurements).
+    static const int g8on = getenv("DLE_CONV_STATS_GEMM8") ? atoi(getenv("DLE_CONV_STATS_GEMM8")) : 1;
+    static const long long g8maxm = getenv("DLE_CONV_STATS_GEMM8_MAXM") ? atoll(getenv("DLE_CONV_STATS_GEMM8_MAXM")) : 65536;
+    if (g8on && M <= g8maxm && C >= 128 && Ko >= 256) {
+      const int rc = dle_gemm8_colstats_try(x, w, y, (int)M, Ko, C, C, C, Ko, dtype, col_partial, stream);
+      if (rc == 1) { *groups = g; return 0; }
+      if (rc > 1) return rc;
+    }
+  }
   if (plain && M < 0x7FFFFFFF) {
     // channel-widening 1x1 convolutions: the streaming kernel of gemm_expand.hip (one partial row per workgroup group)
     const char* pin = getenv("DLE_GEMM_EXPAND");                          // probes / tests: "0" pins the tile kernels

@@ -29,8 +29,8 @@ def _bench(extra_env, timeout=900):
     return r, lines
 
 
-def test_bench_two_ranks_prints_one_line_with_five_records():
-    r, lines = _bench({})
+def test_bench_two_ranks_prints_one_line_with_six_records():
+    r, lines = _bench({"DLE_BERT_ACC_STEPS": "2"})          # (the accumulation record with 2 instead of 32 micro-batches per step)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-6000:])
     assert len(lines) == 1, (lines, r.stderr[-3000:])
     d = json.loads(lines[0])
@@ -39,7 +39,7 @@ def test_bench_two_ranks_prints_one_line_with_five_records():
     assert abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]      # whole-job rate over both ranks
     assert "cpu_baseline" not in d                                                     # rank 0 at N = 1 only
     w = d["workloads"]
-    assert list(w) == ["waveglow", "tacotron2", "dlrm", "bert", "rn50"]
+    assert list(w) == ["waveglow", "tacotron2", "bert_acc32", "dlrm", "bert", "rn50"]
     for name, rec in w.items():
         assert "error" not in rec, (name, rec, r.stderr[-3000:])
         assert rec["value"] > 0 and rec["ms_per_step"] > 0 and rec["roofline"]["frac"] > 0, (name, rec)

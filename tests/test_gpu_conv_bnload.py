@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 # (rows M as n x h x w, K, N, residual)
 SHAPES = [((4, 32, 32), 64, 256, False), ((4, 32, 32), 128, 256, False), ((2, 56, 56), 256, 256, False),
-          ((2, 56, 56), 256, 64, True), ((2, 56, 56), 256, 128, True), ((3, 40, 40), 64, 64, True), ((8, 28, 28), 128, 128, False)]
+          ((2, 56, 56), 256, 64, True), ((2, 56, 56), 256, 128, True), ((3, 40, 40), 64, 64, True), ((8, 28, 28), 128, 128, False),
+          ((8, 28, 28), 512, 128, True)]          # K = 512: the 28 x 28 stage's conv1 consuming bn3 + identity (one 8-wave workgroup per CU)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

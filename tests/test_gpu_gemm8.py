@@ -59,6 +59,9 @@ CASES = [
     ("addend", "nn", (900, 520, 384), torch.bfloat16, dict(act="add", src=True)),
     ("addend_ktail", "nn", (777, 520, 1000), torch.bfloat16, dict(act="add", src=True)),
     ("relu_mask_f16", "nn", (1031, 264, 128), torch.float16, dict(act="relu_bwd", src=True)),
+    # the conv1 data gradient of a bottleneck: + the residual-branch gradient under the block's keep bits (1 bit per element)
+    ("addend_under_keep_bits", "nn", (900, 520, 384), torch.bfloat16, dict(act="add_masked", src=True, bits=True)),
+    ("addend_under_keep_bits_f16", "nn", (1024, 768, 512), torch.float16, dict(act="add_masked", src=True, bits=True)),
     ("stored_derivative_colsum", "nn", (1024, 512, 256), torch.bfloat16, dict(act="mul", src=True, colsum=True)),
     ("relu_mask_colsum_f16", "nn", (768, 1024, 512), torch.float16, dict(act="relu_bwd", src=True, colsum=True)),
     ("wgrad_splitk3", "tn", (520, 776, 1536), torch.bfloat16, dict(splitk=3)),
@@ -85,12 +88,13 @@ def test_against_tile_kernels_fp32_and_itself(g8, cuda, name, layout, mnk, dtype
     odt = torch.float32 if (kw.get("out_f32") or splitk > 1) else dtype
     init = torch.randn(m, n, generator=gen).to(cuda) if accumulate else None
     act = {None: C.ACT_NONE, "relu": C.ACT_RELU, "gelu": C.ACT_GELU, "gelu_daux": C.ACT_GELU_DAUX, "tanh": C.ACT_TANH,
-           "add": C.ACT_ADD, "relu_bwd": C.ACT_RELU_BWD, "mul": C.ACT_MUL}[kw.get("act")]
+           "add": C.ACT_ADD, "relu_bwd": C.ACT_RELU_BWD, "mul": C.ACT_MUL, "add_masked": C.ACT_ADD_MASKED}[kw.get("act")]
+    bits = torch.randint(0, 256, (m * n // 8,), generator=gen, dtype=torch.uint8).to(cuda) if kw.get("bits") else None
 
     def run(mode):
         g8.dle_gemm8_mode(mode)
         out = init.clone() if accumulate else torch.empty(m, n, dtype=odt, device=cuda)
-        aux = torch.empty(m, n, dtype=dtype, device=cuda) if kw.get("aux") else None
+        aux = torch.empty(m, n, dtype=dtype, device=cuda) if kw.get("aux") else bits
         cs = torch.zeros(n, dtype=torch.float32, device=cuda) if colsum else None
         if colsum:
             out = F.gemm_colsum(a, b, m, n, k, src, cs, act=act)
@@ -107,7 +111,7 @@ def test_against_tile_kernels_fp32_and_itself(g8, cuda, name, layout, mnk, dtype
     assert g8.dle_gemm8_launch_count() > before, "the ping-pong kernel declined the shape: nothing was tested"
     # bit-identical to the tile kernels
     assert torch.equal(o_new, o_tile)
-    if x_new is not None:
+    if x_new is not None and bits is None:
         assert torch.equal(x_new, x_tile)
     if c_new is not None:          # (column sums: the two kernels fold the same rounded values in different fp32 orders)
         mag_t = o_tile.to(torch.float64).abs().sum(0)
@@ -123,6 +127,9 @@ def test_against_tile_kernels_fp32_and_itself(g8, cuda, name, layout, mnk, dtype
         want = torch.tanh(pre)
     elif kw.get("act") == "add":
         want = pre + src.float()
+    elif kw.get("act") == "add_masked":
+        keep = ((bits.view(-1, 1) >> torch.arange(8, device=cuda, dtype=torch.uint8)) & 1).view(m, n).float()
+        want = pre + src.float() * keep
     elif kw.get("act") == "relu_bwd":
         want = pre * (src.float() > 0)
     elif kw.get("act") == "mul":
@@ -133,7 +140,7 @@ def test_against_tile_kernels_fp32_and_itself(g8, cuda, name, layout, mnk, dtype
     tol = 1e-5 if odt == torch.float32 else (4e-3 if dtype == torch.bfloat16 else 6e-4)
     scale = float(want.abs().max()) + 1e-30
     assert float((o_new.float() - want).abs().max()) <= tol * scale
-    if x_new is not None:
+    if x_new is not None and bits is None:
         side = _gelu_d(pre) if kw.get("act") == "gelu_daux" else pre
         assert float((x_new.float() - side).abs().max()) <= tol * (float(side.abs().max()) + 1e-30)
     if c_new is not None:
@@ -144,7 +151,7 @@ def test_against_tile_kernels_fp32_and_itself(g8, cuda, name, layout, mnk, dtype
     for _ in range(3):
         o2, x2, c2 = run(1)
         assert torch.equal(o2, o_new)
-        assert x2 is None or torch.equal(x2, x_new)
+        assert x2 is None or bits is not None or torch.equal(x2, x_new)
         assert c2 is None or torch.equal(c2, c_new)
 
 
@@ -192,3 +199,33 @@ def test_switches(g8):
     assert g8.dle_gemm8_min_items(-1) == 1 and g8.dle_gemm8_mode(-1) == 1
     assert g8.dle_gemm8_min_items(64) == 1 and g8.dle_gemm8_min_items(1) == 64
     assert g8.dle_gemm8_mode(0) == 1 and g8.dle_gemm8_mode(1) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("nhw,c,ko", [((4, 16, 16), 256, 1024), ((8, 8, 8), 1024, 256), ((5, 16, 16), 512, 520)])
+def test_conv1x1_forward_with_batchnorm_statistics(g8, cuda, dtype, nhw, c, ko):
+    """dle_conv2d_fwd_colstats on the ping-pong kernel (gemm8_kernel.h EPI 3: the column sums / sums of squares of the rounded
+    output leave from the register epilogue) vs the same entry point on the older kernels (dle_gemm8_mode(0)): the convolution
+    output is BIT-IDENTICAL, the batch statistics agree to fp32 summation order, and mean / variance match a float64 reduction of
+    the stored output (models/common.py:31-128: conv -> BatchNorm(train))."""
+    from deeplearningexamples_amd import functional as F
+    gen = torch.Generator().manual_seed(c + ko)
+    x = (torch.randn(nhw + (c,), generator=gen) * 0.5).to(dtype).to(cuda)
+    w = (torch.randn((ko, 1, 1, c), generator=gen) / c ** 0.5).to(dtype).to(cuda)
+    res = []
+    for mode in (0, 1):
+        g8.dle_gemm8_mode(mode)
+        before = g8.dle_gemm8_launch_count()
+        rm, rv = torch.zeros(ko, device=cuda), torch.ones(ko, device=cuda)
+        y, mean, rstd = F.conv2d_fwd_bnstats(x, w, 1, 0, rm, rv)
+        torch.cuda.synchronize()
+        assert (g8.dle_gemm8_launch_count() > before) == (mode == 1), "mode %d: wrong kernel took the launch" % mode
+        res.append((y, mean, rstd, rm, rv))
+    (y0, m0, r0, rm0, rv0), (y1, m1, r1, rm1, rv1) = res
+    assert torch.equal(y0, y1)
+    y64 = y1.double().view(-1, ko)
+    mu, var = y64.mean(0), y64.var(0, unbiased=False)
+    assert torch.allclose(m1.double(), mu, atol=2e-6 * float(y64.abs().max()) + 1e-7, rtol=1e-5)
+    assert torch.allclose(r1.double(), 1.0 / torch.sqrt(var + 1e-5), rtol=2e-5)
+    assert torch.allclose(m1, m0, atol=1e-6, rtol=1e-5) and torch.allclose(r1, r0, rtol=1e-5)
+    assert torch.allclose(rm1, rm0, atol=1e-6, rtol=1e-5) and torch.allclose(rv1, rv0, rtol=1e-5)
