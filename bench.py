@@ -684,10 +684,17 @@ def roofline_from(timer, steps, wl_name, samples_per_step_per_gpu, ms_per_step):
               "step_frac": round(step_rate / step_peak, 4),
               "step_work_per_sample": work})
     nb = int(os.environ.get("DLE_BENCH_BREAKDOWN", "12"))
+    def counter_gbs(f):
+        """HBM-side GB/s of a family from the committed PMC record of its launch (profiles/traffic.json), when there is one: the
+        ALGORITHMIC figure beside it charges e.g. the sparse update a full row read-modify-write per LOOKUP, which
+        duplicate-heavy batches never move -- dle_emb_sgd_dedup: 33.5 KB / sample algorithmic, 1.40 GB per launch counted."""
+        tb = lookup_traffic(f["name"]) or lookup_traffic(f["name"].replace("_ws", ""))
+        return round(tb * f["calls"] / (f["ms"] * 1e-3) / 1e9, 1) if (tb and f["ms"]) else None
     breakdown = [{"kernel": f["name"], "ms_per_step": round(f["ms"] / steps, 4),
                   "calls_per_step": round(f["calls"] / steps, 2),
                   "tflops": round(f["flops"] / (f["ms"] * 1e-3) / 1e12, 1) if f["flops"] else None,
-                  "gbs": round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1) if f["bytes"] else None}
+                  "gbs": round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1) if f["bytes"] else None,
+                  "gbs_counter": counter_gbs(f)}
                  for f in fams[:nb]]
     if len(fams) > nb:          # everything below the cut in ONE row, so that the rows add up to the timed kernel total
         rest = fams[nb:]

@@ -16,8 +16,8 @@
 //  * PING-PONG: the eight wavefronts are two groups of four (one wavefront of each group per SIMD), staggered by one barrier:
 //    while a group runs the 16 MFMAs of a segment (A half i x both B halves, K = 64) the other group issues its LDS fragment
 //    reads and its DMA pieces.  A wavefront owns rows {0,128} + 64 wr .. +63 and columns {0,128} + 32 wc .. +31 of the tile, i.e.
-//    one 64 x 32 block of each (A half, B half) pair.  (ktile16 below; the first version's four 8-MFMA phases per K tile --
-//    ktile, G8_PH16 = 0 -- paid the per-segment cost of the barrier round trip twice as often: 2600 against 2216 cycles.)
+//    one 64 x 32 block of each (A half, B half) pair.  (ktile16 below; the first version's four 8-MFMA phases per K tile
+//    paid the per-segment cost of the barrier round trip twice as often: 2600 against 2216 cycles.)
 //  * REGISTER EPILOGUE, ROW-CONTIGUOUS MEMORY: the B fragment rows are permuted (MFMA row 8q + 4h + e <- tile column
 //    16h + 4q + e) so that a lane's 16 accumulators of a 32 x 32 block are 16 CONSECUTIVE output columns of one row: bias /
 //    activation / source math runs in the accumulator layout; the rounded block then crosses a per-wavefront LDS scratch (no
@@ -48,9 +48,6 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_ADD = 4, 
 // by thread it may forward a lane's earlier load over another lane's store (it did: the reads of the second half-block were
 // sunk into the writers' exec-masked region).  A wavefront-scope fence costs no instruction.
 #define G8_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
-#ifndef G8_TSTORE
-#define G8_TSTORE 1                                  // 0: probe -- stores in the accumulator layout (2 x 16 bytes per row and instruction)
-#endif
 
 struct Gemm8Args {
   const unsigned short* A;
@@ -82,28 +79,9 @@ struct Gemm8Args {
 #define G8_STAMP(slot) do { } while (0)
 #endif
 
-#ifndef G8_DMA_IN_MMA
-#define G8_DMA_IN_MMA -1               // probes: 0 / 1 pins where a phase's DMA pieces are issued (default: by operand layout)
-#endif
-#ifndef G8_PRIO_MODE
-#define G8_PRIO_MODE 0                 // probes: 0 = priority 1 around each MFMA cluster; 1 = none; 2 = ... and waves 4-7 stay at 1; 3 = waves 4-7 at 1 only
-#endif
-#ifndef G8_ST_KEEP
+// (decided probe variants removed in round 6: the four-phase K tile, DMA pieces between the MFMAs, the priority modes, the 4 + 4
+//  restaging split, accumulator-layout stores, store cache-policy bits -- measured numbers in DESIGN.md, section 4)
 #define G8_ST_KEEP 16                  // store instructions per wavefront of an interior tile's epilogue (lower bound over all flavours)
-#endif
-#ifndef G8_ST_AUX
-#define G8_ST_AUX 0                    // probe: cache-policy bits of the epilogue's stores (1 = sc0, 2 = nt, 16 = sc1)
-#endif
-#ifndef G8_SPLIT44
-#define G8_SPLIT44 0                   // probe: B1 restaged in load segment X (4 + 4 pieces per K tile) instead of Y (2 + 6)
-#endif
-#ifndef G8_PH16
-#define G8_PH16 1                      // 1: two 16-MFMA segments per K tile and group (ktile16 below); 0: four 8-MFMA phases
-#endif
-#ifndef G8_DMA_SLOT0
-#define G8_DMA_SLOT0 1
-#define G8_DMA_SLOT1 4
-#endif
 #define G8_SB() __builtin_amdgcn_sched_barrier(0)
 #define G8_BARRIER() do { G8_SB(); asm volatile("s_barrier" ::: "memory"); G8_SB(); } while (0)
 #define G8_LGKM(N) do { G8_SB(); asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); G8_SB(); } while (0)
@@ -370,45 +348,10 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
   G8_VM(8);
   G8_BARRIER();
   if (wr == 1) G8_BARRIER();            // the stagger: group 1 runs one barrier behind group 0 from here on
-#if G8_PRIO_MODE == 2 || G8_PRIO_MODE == 3
-  if (wr == 1) __builtin_amdgcn_s_setprio(1);
-#endif
 
   float16_t acc[2][2][2];               // [A half][B half][32-row block]
   typename FragT<RCA>::type fa[2][4];   // one A half: [32-row block][k-step]
   typename FragT<RCB>::type fb0[4], fb1[4];
-
-  // DMAM: where a phase's two DMA pieces are issued.  0 (default): beside its LDS reads, the MFMA stream stays bare; 1: behind
-  // the 2nd and the 5th MFMA of the phase.  Measured (8192^3, cycles per K tile): forward layout 2440 / 2530, data gradient
-  // 2400 / 2680, weight gradient 2670 / 2760 -- 1 only paid while every transpose read carried its own address add.
-  constexpr int DMAM = G8_DMA_IN_MMA > 0 ? 1 : 0;
-  constexpr int VMW = DMAM ? 4 : 6;     // pieces in flight behind the K tile that phase 3 waits for
-
-  // the 8 MFMAs of one phase (+ its DMA pieces when DMAM; STG: this phase has a half-tile to issue)
-  auto mma = [&](auto IC, auto JC, auto& fbx, auto SOP, auto SHF, auto STG, auto ZC) __attribute__((always_inline)) {
-    constexpr int i = decltype(IC)::value, j = decltype(JC)::value;
-    constexpr bool stg = DMAM && decltype(STG)::value;
-    constexpr bool zc = decltype(ZC)::value;            // the item's first K tile: the first k-step starts from zero
-    const float16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#if G8_PRIO_MODE == 0 || G8_PRIO_MODE == 2
-    __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        acc[i][j][b] = Mfma32x16<DT>::run(frag_value(fbx[ks]), frag_value(fa[b][ks]), (zc && ks == 0) ? zero : acc[i][j][b]);
-        if constexpr (stg) {
-          if (ks * 2 + b == G8_DMA_SLOT0) { G8_SB(); stage_piece(SOP, SHF, I0()); G8_SB(); }
-          if (ks * 2 + b == G8_DMA_SLOT1) { G8_SB(); stage_piece(SOP, SHF, I1()); G8_SB(); }
-        }
-      }
-#if G8_PRIO_MODE == 0
-    __builtin_amdgcn_s_setprio(0);
-#elif G8_PRIO_MODE == 2
-    if (wr == 0) __builtin_amdgcn_s_setprio(0);
-#endif
-  };
 
   // row-contiguous operands: a lane's first transpose-read address inside a half-tile image (bytes)
   unsigned trA0 = 0, trA1 = 0, trB = 0;
@@ -446,70 +389,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     }
   };
 
-  // One K tile = four phases; each phase: {fragment reads | one half-tile of DMA} barrier {8 MFMAs} barrier.
-  // The stream, in issue order: ... A1(t+1) [phase 0 of K tile t], B0(t+2) [1], A0(t+2) [2], B1(t+2) [3], A1(t+2) ...
-  // RAW (DMA -> ds_read): every half-tile of K tile t + 1 was issued no later than phase 0 of tile t; each wavefront waits for
-  //   its own pieces with a counted vmcnt in phase 3 BEFORE that phase's first barrier (the half-tiles issued in phases 1-3
-  //   stay in flight); group 1's wait precedes the barrier that is group 0's SECOND barrier of phase 3, so both groups read
-  //   tile t + 1 only after every wavefront's wait.
-  // WAR (ds_read -> restage): B0 is read in phase 0 and restaged in phase 1: its reads are issued first and retired by the
-  //   counted lgkmcnt before phase 0's first barrier (the other group passes that barrier before it can issue phase 1);
-  //   A0 (read in phase 0, restaged in phase 2), B1 (1 -> 3) and A1 (2 -> next phase 0) have two phases in between, and
-  //   their reads are complete (lgkmcnt(0) after the first barrier) one full phase before any wavefront restages them.
-  // FIRST K tile of an item: A1(t+1) was issued BEFORE the previous item's epilogue stores (it is the one half-tile slot that
-  //   is free at the end of a K tile), so everything phase 3 waits for is OLDER than those stores: the wait leaves them in
-  //   flight (vmcnt retires in order; st_keep = a lower bound of the store instructions each wavefront issued).  The next
-  //   wait that needs them gone is phase 3 of the item's SECOND K tile, ~7 phases after they were issued.
-  auto ktile = [&](int cpar, auto FIRSTC, auto ZEROC, bool st_keep) __attribute__((always_inline)) {
-    constexpr bool FIRST = decltype(FIRSTC)::value;
-    typedef std::integral_constant<bool, !FIRST> P0STG;
-    typedef std::integral_constant<bool, true> YES;
-    typedef decltype(ZEROC) ZC;
-    const unsigned short* bufc = lds + cpar * G8_BUF;
-    const unsigned lbase = lds0 + (unsigned)cpar * (G8_BUF * 2u);
-    typedef std::integral_constant<int, 2> I2;
-    typedef std::integral_constant<int, 3> I3;
-    // ---- phase 0: C00 += A0 B0 | stream: A1 of the cursor's K tile (then the cursor moves on)
-    read_b(I2(), fb0, bufc, lbase);
-    G8_SB();
-    read_a(I0(), bufc, lbase);
-    G8_SB();
-    if constexpr (!DMAM && !FIRST) {
-      stage(I0(), I1());
-      cursor_next();
-    }
-    G8_LGKM(NRA < 15 ? NRA : 15);
-    G8_BARRIER();
-    G8_LGKM(0);
-    mma(I0(), I0(), fb0, I0(), I1(), P0STG(), ZC());
-    if constexpr (DMAM && !FIRST) cursor_next();
-    G8_BARRIER();
-    // ---- phase 1: C01 += A0 B1 | stream: B0
-    read_b(I3(), fb1, bufc, lbase);
-    G8_SB();
-    if constexpr (!DMAM) stage(I1(), I0());
-    G8_BARRIER();
-    G8_LGKM(0);
-    mma(I0(), I1(), fb1, I1(), I0(), YES(), ZC());
-    G8_BARRIER();
-    // ---- phase 2: C11 += A1 B1 | stream: A0
-    read_a(I1(), bufc, lbase);
-    G8_SB();
-    if constexpr (!DMAM) stage(I0(), I0());
-    G8_BARRIER();
-    G8_LGKM(0);
-    mma(I1(), I1(), fb1, I0(), I0(), YES(), ZC());
-    G8_BARRIER();
-    // ---- phase 3: C10 += A1 B0 (B0 still in registers) | stream: B1; the next K tile has landed
-    if constexpr (!DMAM) stage(I1(), I1());
-    if (FIRST && st_keep) G8_VM(VMW + G8_ST_KEEP);
-    else G8_VM(VMW);
-    G8_BARRIER();
-    mma(I1(), I0(), fb0, I1(), I1(), YES(), ZC());
-    G8_BARRIER();
-  };
-
-  // ---- the same K tile as TWO segments of 16 MFMAs per group: {C00, C01} from A0 x {B0, B1}, then {C10, C11} from A1 x {B0, B1}
+  // ---- one K tile = TWO segments of 16 MFMAs per group: {C00, C01} from A0 x {B0, B1}, then {C10, C11} from A1 x {B0, B1}
   // (the B fragments stay in registers).  What a segment costs beyond its MFMA time -- the barrier round trip, the partner's
   // load segment on the same SIMD, the change of roles: ~70 cycles -- is paid 4 times per K tile instead of 8.
   //   load segment X(t): reads B0, A0, B1 of K tile t | streams A1(t + 1) into the slot A1(t - 1) left (then the cursor moves on)
@@ -532,9 +412,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     constexpr int i = decltype(IC)::value;
     constexpr bool zc = decltype(ZC)::value;
     const float16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#if G8_PRIO_MODE == 0 || G8_PRIO_MODE == 2
     __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -544,11 +422,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
       for (int b = 0; b < 2; ++b)
         acc[i][1][b] = Mfma32x16<DT>::run(frag_value(fb1[ks]), frag_value(fa[b][ks]), (zc && ks == 0) ? zero : acc[i][1][b]);
     }
-#if G8_PRIO_MODE == 0
     __builtin_amdgcn_s_setprio(0);
-#elif G8_PRIO_MODE == 2
-    if (wr == 0) __builtin_amdgcn_s_setprio(0);
-#endif
   };
   auto ktile16 = [&](int cpar, auto FIRSTC, auto ZEROC) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(FIRSTC)::value;
@@ -565,9 +439,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     read_b(I3(), fb1, bufc, lbase);
     G8_SB();
     typedef std::integral_constant<int, 8> W8;
-    typedef std::integral_constant<int, 6> W6;
     if constexpr (!FIRST) {
-      if constexpr (G8_SPLIT44) stage(I1(), I1());
       stage(I0(), I1());
       cursor_next();
     }
@@ -581,9 +453,9 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
     G8_SB();
     stage(I1(), I0());
     stage(I0(), I0());
-    if constexpr (!G8_SPLIT44) stage(I1(), I1());
+    stage(I1(), I1());
     G8_LGKM(0);
-    if constexpr (G8_SPLIT44) seg_wait(W6()); else seg_wait(W8());
+    seg_wait(W8());
     G8_BARRIER();
     mma16(I1(), ZC());
     G8_BARRIER();
@@ -591,7 +463,6 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
 
   const int fr = lane & 31, fh = lane >> 5;
   int cpar = 0;
-  bool st_keep = false;
 #ifdef G8_TIMING
   int item_seq = 0;
 #endif
@@ -628,22 +499,18 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
 #define G8_KT_STAMP(k) do { } while (0)
 #endif
     G8_KT_STAMP(0);
-    if constexpr (G8_PH16) ktile16(cpar, std::integral_constant<bool, true>(), std::integral_constant<bool, true>());
-    else ktile(cpar, std::integral_constant<bool, true>(), std::integral_constant<bool, true>(), st_keep);
+    ktile16(cpar, std::integral_constant<bool, true>(), std::integral_constant<bool, true>());
     cpar ^= 1;
     for (int kt = kt0 + 1; kt < kt1; ++kt) {
       G8_KT_STAMP(kt - kt0);
-      if constexpr (G8_PH16) ktile16(cpar, std::integral_constant<bool, false>(), std::integral_constant<bool, false>());
-      else ktile(cpar, std::integral_constant<bool, false>(), std::integral_constant<bool, false>(), false);
+      ktile16(cpar, std::integral_constant<bool, false>(), std::integral_constant<bool, false>());
       cpar ^= 1;
     }
     G8_KT_STAMP(kt1 - kt0);
     // the one half-tile slot that is free now (A1 of the K tile just finished) is refilled BEFORE the stores below
-    if constexpr (G8_PH16 && G8_SPLIT44) stage(I1(), I1());
     stage(I0(), I1());
     cursor_next();
-    st_keep = interior;                                // interior tile: every store instruction below is issued
-    keep_segments = interior ? 3 : 0;
+    keep_segments = interior ? 3 : 0;                  // interior tile: every store instruction below is issued
     G8_STAMP(1);
     // The two groups run their epilogues AT THE SAME TIME: group 0 (one barrier ahead) gives group 1 the barrier its last MFMA
     // phase is waiting on before it starts storing, group 1 gives one back after its stores (below), so the stagger of the K
@@ -706,7 +573,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
           static_for<0, 8>([&](auto BI) __attribute__((always_inline)) {
             constexpr int bi = decltype(BI)::value, i = bi >> 2, j = (bi >> 1) & 1, b = bi & 1;
             const unsigned so = blk_off(i, j, b);
-            if constexpr (G8_TSTORE) {
+            {
 #pragma unroll
               for (int h = 0; h < 2; ++h) {
                 if ((fr >> 4) == h) {
@@ -722,17 +589,8 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
                 G8_WAVE_FENCE();
                 const float4_t t0 = *(const float4_t*)(ts + tr), t1 = *(const float4_t*)(ts + tr + 8 * 144);
                 G8_WAVE_FENCE();
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t0), rc, lane_off_f + so + (unsigned)(16 * h) * pitch, 0, G8_ST_AUX);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t1), rc, lane_off_f + so + (unsigned)(16 * h + 8) * pitch, 0, G8_ST_AUX);
-              }
-            } else {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                float4_t v = {acc[i][j][b][4 * q], acc[i][j][b][4 * q + 1], acc[i][j][b][4 * q + 2], acc[i][j][b][4 * q + 3]};
-                if constexpr (EPI == 1) {
-                  if (e_bias) v += *(const float4_t*)((const float*)(smem_raw + G8_STAGE_BYTES + wave * 256) + j * 32 + fh * 16 + 4 * q);
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v), rc, lane_off + so + 16 * q, 0, G8_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t0), rc, lane_off_f + so + (unsigned)(16 * h) * pitch, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t1), rc, lane_off_f + so + (unsigned)(16 * h + 8) * pitch, 0, 0);
               }
             }
           });
@@ -749,27 +607,23 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
         unsigned char* ts = smem_raw + G8_TS_BASE + wave * G8_TS_BYTES;
         const unsigned ts_acc = (unsigned)fr * G8_TS_PITCH + (unsigned)fh * 32u;                 // accumulator layout
         const unsigned ts_row = (unsigned)(lane >> 2) * G8_TS_PITCH + (unsigned)(lane & 3) * 16u;  // memory layout (+ 16 rows)
-        const unsigned lane_off_t = G8_TSTORE ? (unsigned)(lane >> 2) * pitch + (unsigned)(lane & 3) * 16u : lane_off;
-        const unsigned second_t = G8_TSTORE ? 16u * pitch : 16u;
+        const unsigned lane_off_t = (unsigned)(lane >> 2) * pitch + (unsigned)(lane & 3) * 16u;
+        const unsigned second_t = 16u * pitch;
         auto to_rows = [&](ushort8_t& a, ushort8_t& b2) __attribute__((always_inline)) {          // accumulator -> memory layout
-          if constexpr (G8_TSTORE) {
-            *(ushort8_t*)(ts + ts_acc) = a;
-            *(ushort8_t*)(ts + ts_acc + 16) = b2;
-            G8_WAVE_FENCE();
-            a = *(const ushort8_t*)(ts + ts_row);
-            b2 = *(const ushort8_t*)(ts + ts_row + 16 * G8_TS_PITCH);
-            G8_WAVE_FENCE();
-          }
+          *(ushort8_t*)(ts + ts_acc) = a;
+          *(ushort8_t*)(ts + ts_acc + 16) = b2;
+          G8_WAVE_FENCE();
+          a = *(const ushort8_t*)(ts + ts_row);
+          b2 = *(const ushort8_t*)(ts + ts_row + 16 * G8_TS_PITCH);
+          G8_WAVE_FENCE();
         };
         auto from_rows = [&](ushort8_t& a, ushort8_t& b2) __attribute__((always_inline)) {        // memory -> accumulator layout
-          if constexpr (G8_TSTORE) {
-            *(ushort8_t*)(ts + ts_row) = a;
-            *(ushort8_t*)(ts + ts_row + 16 * G8_TS_PITCH) = b2;
-            G8_WAVE_FENCE();
-            a = *(const ushort8_t*)(ts + ts_acc);
-            b2 = *(const ushort8_t*)(ts + ts_acc + 16);
-            G8_WAVE_FENCE();
-          }
+          *(ushort8_t*)(ts + ts_row) = a;
+          *(ushort8_t*)(ts + ts_row + 16 * G8_TS_PITCH) = b2;
+          G8_WAVE_FENCE();
+          a = *(const ushort8_t*)(ts + ts_acc);
+          b2 = *(const ushort8_t*)(ts + ts_acc + 16);
+          G8_WAVE_FENCE();
         };
         ushort8_t sv[EPI == 2 ? 8 : 1][2];
         unsigned short kb[(EPI == 2 && ACT == ACT_ADD_MASKED) ? 8 : 1];      // the lane's 16 keep bits of each block (accumulator layout)
@@ -839,8 +693,8 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
             if (e_aux) {
               ushort8_t x0 = pack8<DT>(side), x1 = pack8<DT>(side + 8);
               to_rows(x0, x1);
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, x0), ra, lane_off_t + so, 0, G8_ST_AUX);
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, x1), ra, lane_off_t + so + second_t, 0, G8_ST_AUX);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, x0), ra, lane_off_t + so, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, x1), ra, lane_off_t + so + second_t, 0, 0);
             }
           } else if constexpr (EPI == 2) {
             float y[16];
@@ -876,8 +730,8 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
           {
             ushort8_t t0 = o0, t1 = o1;
             to_rows(t0, t1);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t0), rc, lane_off_t + so, 0, G8_ST_AUX);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t1), rc, lane_off_t + so + second_t, 0, G8_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t0), rc, lane_off_t + so, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, t1), rc, lane_off_t + so + second_t, 0, 0);
           }
           if constexpr (EPI == 2 || EPI == 3) {
             if (q->stats) {
