@@ -439,7 +439,7 @@ class BertTrainer:
             dctx = F.gemm(dao, self.w16[pre + "attention.output.dense.weight"], t, h, h, True, False)
             qkv, probs = a["qkv"], a["probs"]
             if sv["fused_attn"]:
-                cs = torch.empty((b, 3 * h), dtype=torch.float32, device=self.dev)
+                cs = torch.empty((b * (s // 128), 3 * h), dtype=torch.float32, device=self.dev)     # per (sequence, 128-row block)
                 dqkv = F.attention_bwd(qkv, dctx, self._mask_add, a["stats"], b, s, nh, scale, self.p_attn,
                                        self.rng_seed, a["off_a"], offset_base=self._rng_base, colsum_partial=cs)
             else:

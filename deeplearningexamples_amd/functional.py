@@ -1247,7 +1247,8 @@ def attention_supported(seq_len, head_dim):
 def attention_fwd(qkv, mask_add, batch, seq_len, heads, scale, p=0.0, seed=0, offset=0, want_mask=False,
                   offset_base=None):
     """context = dropout(softmax(q k^T * scale + mask_add)) v for every (sequence, head) of qkv [T, 3H] in ONE kernel
-    (BertSelfAttention.forward, modeling.py:340-384).  -> (ctx [T, H], stats [B*heads, S, 2] fp32, keep mask or None)."""
+    (BertSelfAttention.forward, modeling.py:340-384).  -> (ctx [T, H], stats [B*heads, S, 2 or 4] fp32, keep mask or None).
+    seq_len 128, or a multiple of 128 up to 1024 (K / V then stream through LDS in 128-key blocks: csrc/attention.hip)."""
     C.require_cuda(qkv, mask_add)
     t, h3 = qkv.shape
     h = h3 // 3
@@ -1255,7 +1256,8 @@ def attention_fwd(qkv, mask_add, batch, seq_len, heads, scale, p=0.0, seed=0, of
     if not qkv.is_contiguous() or t != batch * seq_len or heads * d * 3 != h3:
         raise ValueError("attention_fwd: qkv must be a contiguous [batch * seq_len, 3 * heads * head_dim] tensor")
     ctx = torch.empty((t, h), dtype=qkv.dtype, device=qkv.device)
-    stats = torch.empty((batch * heads, seq_len, 2), dtype=torch.float32, device=qkv.device)
+    stats = torch.empty((batch * heads, seq_len, int(C.lib().dle_attention_stats_floats(int(seq_len)))), dtype=torch.float32,
+                        device=qkv.device)
     mask = torch.empty(batch * heads * seq_len * seq_len // 8, dtype=torch.uint8, device=qkv.device) \
         if (want_mask and p > 0) else None
     bh = batch * heads
@@ -1269,7 +1271,8 @@ def attention_fwd(qkv, mask_add, batch, seq_len, heads, scale, p=0.0, seed=0, of
 def attention_bwd(qkv, dctx, mask_add, stats, batch, seq_len, heads, scale, p=0.0, seed=0, offset=0, offset_base=None,
                   colsum_partial=None):
     """dqkv [T, 3H] from dctx [T, H]: probabilities and dropout mask are recomputed from (qkv, stats, seed, offset).
-    colsum_partial (optional fp32 [batch, 3H]) receives the per-sequence column sums of dqkv (QKV bias gradient partials)."""
+    colsum_partial (optional fp32 [batch * seq_len / 128, 3H]) receives the column sums of dqkv per (sequence, 128-row block): the
+    QKV bias gradient partials."""
     C.require_cuda(qkv, dctx, mask_add, stats)
     t, h3 = qkv.shape
     h = h3 // 3
@@ -1278,6 +1281,9 @@ def attention_bwd(qkv, dctx, mask_add, stats, batch, seq_len, heads, scale, p=0.
         raise ValueError("attention_bwd: qkv [T, 3H] and dctx [T, H] must be contiguous")
     dqkv = torch.empty_like(qkv)
     bh = batch * heads
+    if colsum_partial is not None and (colsum_partial.numel() != batch * (seq_len // 128) * h3 or colsum_partial.dtype != torch.float32
+                                       or not colsum_partial.is_contiguous()):
+        raise ValueError("attention_bwd: colsum_partial must be fp32 [batch * seq_len / 128, 3H]")
     C.annotate(flops=10.0 * bh * seq_len * seq_len * d, bytes=float(t) * h * 2 * 7 + stats.numel() * 4,
                tag="B%dxh%dxS%dxd%d" % (batch, heads, seq_len, d))
     C.require_cuda(colsum_partial)

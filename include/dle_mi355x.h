@@ -492,15 +492,19 @@ int dle_u8_nchw_normalize_nhwc(const void* x, void* y, const float* mean, const 
 int dle_conv2d_dgrad_s2(const void* dy, const void* w, void* dx, int N, int H, int W, int C, int Ko, void* workspace,
                         int64_t workspace_bytes, int dtype, hipStream_t stream);
 
-/* ---- fused self-attention (S = 128, 64-wide heads): replaces BertSelfAttention.forward between the QKV and the output
- * projection, LanguageModeling/BERT/modeling.py:340-384 (torch.bmm + softmax + nn.Dropout + torch.bmm) and its autograd
- * backward.  qkv [T = B*S, 3H] (q | k | v, head h at columns h*64 of each third), ctx / dctx [T, H], dqkv [T, 3H];
- * mask_add fp32 [B, S] (0 / -10000) or NULL; stats fp32 [B*heads, S, 2] = (row max, 1 / row sum) saved for backward;
- * keep_mask (optional, B*heads*S*S/8 bytes) = the dropout keep bits in the layout of dle_softmax_dropout_fwd.  The
- * backward regenerates probabilities and mask from (qkv, stats, seed, offset): nothing of shape [B, heads, S, S] is
- * stored.  colsum_partial (optional, fp32 [B, 3H]): per-sequence column sums of dqkv -- their sum over B is the bias gradient of
- * the QKV projection.  dle_attention_supported: 1 when (S, head_dim) is inside the kernels' envelope. */
+/* ---- fused self-attention (64-wide heads; S = 128, or a multiple of 128 up to 1024 -- phase 2 runs S = 512): replaces
+ * BertSelfAttention.forward between the QKV and the output projection, LanguageModeling/BERT/modeling.py:340-384 (torch.bmm +
+ * softmax + nn.Dropout + torch.bmm) and its autograd backward.  qkv [T = B*S, 3H] (q | k | v, head h at columns h*64 of each
+ * third), ctx / dctx [T, H], dqkv [T, 3H]; mask_add fp32 [B, S] (0 / -10000) or NULL; stats fp32 [B*heads, S, W] with
+ * W = dle_attention_stats_floats(S): (row max, 1 / row sum) saved for backward (+ for S > 128 a third word the backward pass
+ * uses as scratch: the row's delta); keep_mask (optional, B*heads*S*S/8 bytes) = the dropout keep bits in the layout of
+ * dle_softmax_dropout_fwd.  The backward regenerates probabilities and mask from (qkv, stats, seed, offset): nothing of shape
+ * [B, heads, S, S] is stored -- for S > 128 K / V are streamed through LDS in 128-key blocks (forward: online max / sum, then a
+ * second pass with the final statistics; backward: a per-query-block kernel for delta and dQ, a per-key-block kernel for dK / dV).
+ * colsum_partial (optional, fp32 [B * S / 128, 3H]): column sums of dqkv per (sequence, 128-row block) -- their sum over the rows
+ * is the bias gradient of the QKV projection.  dle_attention_supported: 1 when (S, head_dim) is inside the kernels' envelope. */
 int dle_attention_supported(int S, int head_dim);
+int dle_attention_stats_floats(int S);
 int dle_attention_fwd(const void* qkv, const float* mask_add, void* ctx, float* stats, void* keep_mask, int B, int S,
                       int heads, int head_dim, float scale, float p, uint64_t seed, uint64_t offset,
                       const uint64_t* offset_base, int dtype,

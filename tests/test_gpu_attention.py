@@ -38,18 +38,22 @@ def _relerr(got, ref):
 
 @pytest.mark.parametrize("dtype,bar_f,bar_b", [(torch.float16, 1.5e-3, 4e-3), (torch.bfloat16, 1e-2, 2.5e-2)])
 @pytest.mark.parametrize("p", [0.0, 0.1])
-def test_attention_fwd_bwd_vs_fp64(cuda, dtype, bar_f, bar_b, p):
+@pytest.mark.parametrize("s", [128, 256, 512])
+def test_attention_fwd_bwd_vs_fp64(cuda, dtype, bar_f, bar_b, p, s):
+    """s = 128: one kernel each way.  s = 256 / 512 (BERT phase 2): K / V streamed in 128-key blocks -- forward with online max /
+    sum then a second pass under the final statistics, backward as a per-query-block kernel (delta, dQ) and a per-key-block kernel
+    (dK, dV); same bars, same mask contract (bit-exact against the Philox oracle on the [B, heads, S, S] chunk index)."""
     from deeplearningexamples_amd import functional as F
     from oracle import philox_oracle as P
-    b, s, nh, d = 3, 128, 4, 64
+    b, nh, d = 3, 4, 64
     h = nh * d
     g = torch.Generator().manual_seed(5)
     qkv = (torch.randn(b * s, 3 * h, generator=g) * 0.8).to(dtype).to(cuda)
     dctx = (torch.randn(b * s, h, generator=g) * 0.5).to(dtype).to(cuda)
     # additive mask as the engine builds it (modeling.py:868-869): the tail of sequences 1, 2 is padding
     att = torch.ones(b, s)
-    att[1, 100:] = 0
-    att[2, 37:] = 0
+    att[1, (100 * s) // 128:] = 0
+    att[2, (37 * s) // 128:] = 0
     mask_add = ((1.0 - att) * -10000.0).to(cuda)
     scale = 1.0 / math.sqrt(d)
     seed, off = 0x1234567887654321, (1 << 34) + 9
@@ -75,15 +79,16 @@ def test_attention_fwd_bwd_vs_fp64(cuda, dtype, bar_f, bar_b, p):
     x = qkv.double().cpu().view(b, s, 3, nh, d).permute(2, 0, 3, 1, 4)
     sc = torch.matmul(x[0], x[1].transpose(-1, -2)) * scale + mask_add.double().cpu()[:, None, None, :]
     mx = sc.max(-1).values
-    st = stats.double().cpu().view(b, nh, s, 2)
+    st = stats.double().cpu().view(b, nh, s, -1)
+    assert st.shape[-1] == (2 if s == 128 else 4)
     assert float((st[..., 0] - mx).abs().max()) < 1e-4 * (1 + float(mx.abs().max()))
     inv = 1.0 / torch.exp(sc - mx[..., None]).sum(-1)
     assert float(((st[..., 1] - inv) / inv).abs().max()) < 1e-4
     # per-sequence column sums of dqkv (the QKV bias gradient partials), from the rounded values the kernel stored
-    cs = torch.empty((b, 3 * h), dtype=torch.float32, device=cuda)
+    cs = torch.empty((b * (s // 128), 3 * h), dtype=torch.float32, device=cuda)
     dqkv_c = F.attention_bwd(qkv, dctx, mask_add, stats, b, s, nh, scale, p, seed, off, colsum_partial=cs)
     assert torch.equal(dqkv_c, dqkv)
-    ref_cs = dqkv.float().view(b, s, 3 * h).sum(1)
+    ref_cs = dqkv.float().view(b * (s // 128), 128, 3 * h).sum(1)
     assert float((cs - ref_cs).abs().max()) <= 1e-4 * (1.0 + float(ref_cs.abs().max()))
     # determinism: the same call gives the same bits
     ctx2, stats2, _ = F.attention_fwd(qkv, mask_add, b, s, nh, scale, p, seed, off)
@@ -91,12 +96,13 @@ def test_attention_fwd_bwd_vs_fp64(cuda, dtype, bar_f, bar_b, p):
     assert torch.equal(ctx, ctx2) and torch.equal(dqkv, dqkv2)
 
 
-def test_attention_matches_unfused_path(cuda):
+@pytest.mark.parametrize("s", [128, 512])
+def test_attention_matches_unfused_path(cuda, s):
     """Fused kernels vs the batched-GEMM + softmax kernels of the same library (they round the scores and the
-    probabilities to 16 bits; the fused path keeps them in fp32): same masks, close values."""
+    probabilities to 16 bits; the fused path keeps them in fp32): same masks, close values.  (s = 512: the phase-2 shape.)"""
     from deeplearningexamples_amd import functional as F
     dtype = torch.bfloat16
-    b, s, nh, d = 2, 128, 16, 64
+    b, nh, d = 2, 16, 64
     h = nh * d
     t = b * s
     g = torch.Generator().manual_seed(8)
@@ -151,5 +157,7 @@ def test_attention_argument_errors(cuda):
     from deeplearningexamples_amd import functional as F
     qkv = torch.zeros(2 * 64, 3 * 128, dtype=torch.bfloat16, device=cuda)
     assert not F.attention_supported(64, 64) and not F.attention_supported(128, 32) and F.attention_supported(128, 64)
+    assert F.attention_supported(512, 64) and F.attention_supported(1024, 64) and not F.attention_supported(192, 64) \
+        and not F.attention_supported(2048, 64)
     with pytest.raises((ValueError, RuntimeError)):
         F.attention_fwd(qkv, None, 2, 64, 2, 0.125)                          # S = 64 is outside the envelope
