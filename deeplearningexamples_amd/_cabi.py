@@ -145,6 +145,7 @@ _SIGS = {
     "dle_attention_stats_floats": (c_int, [c_int]),
     "dle_attention_fwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_float, c_float, c_u64, c_u64, c_void_p, c_int, c_void_p]),
     "dle_attention_bwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_float, c_float, c_u64, c_u64, c_void_p, c_int, c_void_p]),
+    "dle_attention_bwd_keep": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_float, c_u64, c_u64, c_void_p, c_int, c_void_p]),
     "dle_colsum": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p, c_i64, c_void_p]),
     "dle_colsum_batched_workspace_bytes": (c_i64, [c_int, c_i64, c_int]),
     "dle_colsum_batched": (c_int, [c_void_p, c_int, c_i64, c_int, c_i64, c_int, c_void_p, c_i64, c_void_p]),

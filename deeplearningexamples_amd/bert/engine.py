@@ -72,6 +72,10 @@ class BertTrainer:
         # capturable.  None: the masked rows are counted on the host like the reference's index_select (modeling.py:590).
         self.max_pred = max_predictions_per_seq
         self.fused_attention = True     # False: batched GEMMs + softmax kernels (also taken for shapes outside the fused envelope)
+        # the S = 128 attention backward READING the forward pass's keep bits instead of re-drawing them (dle_attention_bwd_keep):
+        # measured 68.10 / 67.99 ms per step against 68.12 / 68.19 re-drawn (batch 256, same box, alternating runs) -- the kernel is
+        # not bound by its Philox calls after all; opt-in (DLE_BERT_ATTN_KEEP=1), the default keeps no mask
+        self.attn_keep_mask = os.environ.get("DLE_BERT_ATTN_KEEP", "0") == "1"
         self.keep_activations = False   # tests: keep the dropout keep masks of the last step
         model.fuse_qkv_storage()
         if world_size > 1:
@@ -236,8 +240,11 @@ class BertTrainer:
             off_a = self._next_offset() if pa > 0 else 0
             if fused_attn:
                 # QK^T, scale + mask, softmax, dropout and P V in one kernel: no [B, heads, S, S] tensor in HBM
+                # (DLE_BERT_ATTN_KEEP=1, S = 128: the keep bits are kept -- 1 bit per probability, 8 MB per layer at batch 256 -- and
+                #  READ by the backward kernel instead of re-drawn)
+                keep_bits = self.keep_activations or (self.attn_keep_mask and s == 128 and pa > 0)
                 ctx, stats, mask_a = F.attention_fwd(qkv, self._mask_add, b, s, nh, scale, pa, seed, off_a,
-                                                     want_mask=self.keep_activations, offset_base=self._rng_base)
+                                                     want_mask=keep_bits, offset_base=self._rng_base)
             else:
                 probs = torch.empty((b * nh, s, s), dtype=dt, device=self.dev)
                 F.gemm_batched(qkv, qkv[:, h:], probs, s, s, d, 3 * h, 3 * h, s, True, True, b * nh, nh,
@@ -441,7 +448,8 @@ class BertTrainer:
             if sv["fused_attn"]:
                 cs = torch.empty((b * (s // 128), 3 * h), dtype=torch.float32, device=self.dev)     # per (sequence, 128-row block)
                 dqkv = F.attention_bwd(qkv, dctx, self._mask_add, a["stats"], b, s, nh, scale, self.p_attn,
-                                       self.rng_seed, a["off_a"], offset_base=self._rng_base, colsum_partial=cs)
+                                       self.rng_seed, a["off_a"], offset_base=self._rng_base, colsum_partial=cs,
+                                       keep_mask=a["mask_a"] if (self.attn_keep_mask and s == 128) else None)
             else:
                 dprobs = torch.empty_like(probs)
                 F.gemm_batched(dctx, qkv[:, 2 * h:], dprobs, s, s, d, h, 3 * h, s, True, True, b * nh, nh,

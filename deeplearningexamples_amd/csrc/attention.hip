@@ -38,7 +38,8 @@ struct AttnArgs {
   unsigned short* ctx;          // [T, H]   (forward out)
   unsigned short* dqkv;         // [T, 3H]  (backward out)
   float* stats;                 // [B * heads, S, 2]: row max of the scaled+masked scores, 1 / sum of exp
-  unsigned char* mask_out;      // optional bit-packed keep mask [B * heads * S * S / 8] (tests), forward only
+  unsigned char* mask_out;      // optional bit-packed keep mask [B * heads * S * S / 8], forward only
+  const unsigned char* mask_in; // optional (backward, S = 128): the keep mask the forward pass wrote -- read instead of re-drawn
   float* colsum;                // optional (backward): [B, 3H] column sums of this sequence's rows of dqkv (QKV bias gradient partials)
   int B, nh, H;
   float scale;
@@ -337,7 +338,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   const bool drop = p.drop.thr != 0;
   const unsigned chunk0 = ((unsigned)bh * AT_S + (unsigned)q) * 16u;
   unsigned keepw[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-  if (drop) at_keep_row(p.drop, chunk0, hf, keepw);
+  if (drop && p.mask_in) {
+    // the forward pass left the keep bits (1 bit per probability): 16 bytes per query row instead of 8 Philox calls per lane --
+    // byte rq of word kb holds chunk (kb, rq): low nibble = the hf = 0 lane's four elements, high nibble = the hf = 1 lane's
+    const uint4_t mw = *(const uint4_t*)(p.mask_in + chunk0);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      unsigned bits = 0;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) bits |= ((mw[kb] >> (8 * rq + 4 * hf)) & 0xFu) << (4 * rq);
+      keepw[kb] = bits;
+    }
+  } else if (drop) at_keep_row(p.drop, chunk0, hf, keepw);
   float delta = 0.f;
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
@@ -888,15 +900,16 @@ extern "C" int dle_attention_fwd(const void* qkv, const float* mask_add, void* c
 // dqkv[T, 3H] (dq | dk | dv) from dctx[T, H]; recomputes the probabilities from qkv + stats and the dropout mask from
 // (seed, offset) -- the same values dle_attention_fwd was called with.  colsum_partial (optional, fp32 [B, 3H]): per-sequence
 // column sums of dqkv; their sum over B is the bias gradient of the QKV projection (no column-sum pass over dqkv).
-extern "C" int dle_attention_bwd(const void* qkv, const void* dctx, const float* mask_add, const float* stats, void* dqkv,
-                                 float* colsum_partial, int B, int S, int heads, int head_dim, float scale, float p,
-                                 uint64_t seed, uint64_t offset, const uint64_t* offset_base, int dtype, hipStream_t stream) {
+static int attention_bwd_impl(const void* qkv, const void* dctx, const float* mask_add, const float* stats, const void* keep_mask,
+                              void* dqkv, float* colsum_partial, int B, int S, int heads, int head_dim, float scale, float p,
+                              uint64_t seed, uint64_t offset, const uint64_t* offset_base, int dtype, hipStream_t stream) {
   if (int rc = attn_check("attention_bwd", B, S, heads, head_dim, dtype, p)) return rc;
   DLE_CHECK_ARG(qkv && dctx && stats && dqkv, "attention_bwd: null pointer");
   DLE_CHECK_ARG(((((uintptr_t)qkv) | ((uintptr_t)dctx) | ((uintptr_t)dqkv)) & 15) == 0, "attention_bwd: tensors must be 16-byte aligned");
   AttnArgs a = {};
   a.qkv = (const unsigned short*)qkv; a.dctx = (const unsigned short*)dctx; a.mask_add = mask_add;
   a.stats = (float*)stats; a.dqkv = (unsigned short*)dqkv; a.colsum = colsum_partial; a.B = B; a.nh = heads; a.H = heads * head_dim; a.scale = scale;
+  a.mask_in = S == AT_S ? (const unsigned char*)keep_mask : nullptr;       // (the long-sequence kernels re-draw the mask)
   a.drop = make_drop(nullptr, p, seed, offset, offset_base);
   a.S = S; a.nblk = S / AT_S; a.sw = dle_attention_stats_floats(S);
   const size_t lds = 4 * AT_TILE * 2;
@@ -925,4 +938,23 @@ extern "C" int dle_attention_bwd(const void* qkv, const void* dctx, const float*
   else hipLaunchKernelGGL(attn_bwd_kernel<DLE_BF16>, dim3(B * heads), dim3(256), lds, stream, a);
   DLE_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int dle_attention_bwd(const void* qkv, const void* dctx, const float* mask_add, const float* stats, void* dqkv,
+                                 float* colsum_partial, int B, int S, int heads, int head_dim, float scale, float p,
+                                 uint64_t seed, uint64_t offset, const uint64_t* offset_base, int dtype, hipStream_t stream) {
+  return attention_bwd_impl(qkv, dctx, mask_add, stats, nullptr, dqkv, colsum_partial, B, S, heads, head_dim, scale, p, seed, offset,
+                            offset_base, dtype, stream);
+}
+
+// dle_attention_bwd with the keep mask dle_attention_fwd wrote (keep_mask, B*heads*S*S/8 bytes, 16-byte aligned) READ instead of
+// re-drawn: the S = 128 backward kernel is bound by the 32-bit multiplies of its 8 Philox calls per lane; 16 bytes per query row
+// replace them.  keep_mask = NULL (or S > 128): identical to dle_attention_bwd.  Same results bit for bit.
+extern "C" int dle_attention_bwd_keep(const void* qkv, const void* dctx, const float* mask_add, const float* stats,
+                                      const void* keep_mask, void* dqkv, float* colsum_partial, int B, int S, int heads,
+                                      int head_dim, float scale, float p, uint64_t seed, uint64_t offset,
+                                      const uint64_t* offset_base, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG((((uintptr_t)keep_mask) & 15) == 0, "attention_bwd_keep: keep_mask must be 16-byte aligned");
+  return attention_bwd_impl(qkv, dctx, mask_add, stats, keep_mask, dqkv, colsum_partial, B, S, heads, head_dim, scale, p, seed, offset,
+                            offset_base, dtype, stream);
 }

@@ -1269,7 +1269,7 @@ def attention_fwd(qkv, mask_add, batch, seq_len, heads, scale, p=0.0, seed=0, of
 
 
 def attention_bwd(qkv, dctx, mask_add, stats, batch, seq_len, heads, scale, p=0.0, seed=0, offset=0, offset_base=None,
-                  colsum_partial=None):
+                  colsum_partial=None, keep_mask=None):
     """dqkv [T, 3H] from dctx [T, H]: probabilities and dropout mask are recomputed from (qkv, stats, seed, offset).
     colsum_partial (optional fp32 [batch * seq_len / 128, 3H]) receives the column sums of dqkv per (sequence, 128-row block): the
     QKV bias gradient partials."""
@@ -1286,7 +1286,13 @@ def attention_bwd(qkv, dctx, mask_add, stats, batch, seq_len, heads, scale, p=0.
         raise ValueError("attention_bwd: colsum_partial must be fp32 [batch * seq_len / 128, 3H]")
     C.annotate(flops=10.0 * bh * seq_len * seq_len * d, bytes=float(t) * h * 2 * 7 + stats.numel() * 4,
                tag="B%dxh%dxS%dxd%d" % (batch, heads, seq_len, d))
-    C.require_cuda(colsum_partial)
+    C.require_cuda(colsum_partial, keep_mask)
+    if keep_mask is not None:
+        # the keep mask attention_fwd(want_mask=True) returned: read by the S = 128 kernel instead of re-drawing it (same bits)
+        C.call("dle_attention_bwd_keep", C.ptr(qkv), C.ptr(dctx), C.ptr(mask_add), C.ptr(stats), C.ptr(keep_mask), C.ptr(dqkv),
+               C.ptr(colsum_partial), batch, seq_len, heads, d, float(scale), float(p), int(seed), int(offset), C.ptr(offset_base),
+               C.dt(qkv), C.stream())
+        return dqkv
     C.call("dle_attention_bwd", C.ptr(qkv), C.ptr(dctx), C.ptr(mask_add), C.ptr(stats), C.ptr(dqkv), C.ptr(colsum_partial),
            batch, seq_len,
            heads, d, float(scale), float(p), int(seed), int(offset), C.ptr(offset_base), C.dt(qkv), C.stream())

@@ -512,6 +512,11 @@ int dle_attention_fwd(const void* qkv, const float* mask_add, void* ctx, float* 
 int dle_attention_bwd(const void* qkv, const void* dctx, const float* mask_add, const float* stats, void* dqkv,
                       float* colsum_partial, int B, int S, int heads, int head_dim, float scale, float p, uint64_t seed,
                       uint64_t offset, const uint64_t* offset_base, int dtype, hipStream_t stream);
+/* The same with the keep mask the forward pass wrote (keep_mask of dle_attention_fwd) READ instead of re-drawn from the Philox
+ * counters (S = 128: 16 bytes per query row replace 8 generator calls per lane); identical results.  keep_mask may be NULL. */
+int dle_attention_bwd_keep(const void* qkv, const void* dctx, const float* mask_add, const float* stats, const void* keep_mask,
+                           void* dqkv, float* colsum_partial, int B, int S, int heads, int head_dim, float scale, float p,
+                           uint64_t seed, uint64_t offset, const uint64_t* offset_base, int dtype, hipStream_t stream);
 
 /* ---- torch.optim.Adam over a tensor table (csrc/multi_tensor.hip): GradScaler.unscale_ + clip_grad_norm_ + Adam.step of
  * SpeechSynthesis/Tacotron2/train.py:400-401,487-497 in one pass.  lists: g, p, exp_avg, exp_avg_sq (all fp32).

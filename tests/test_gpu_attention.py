@@ -90,6 +90,9 @@ def test_attention_fwd_bwd_vs_fp64(cuda, dtype, bar_f, bar_b, p, s):
     assert torch.equal(dqkv_c, dqkv)
     ref_cs = dqkv.float().view(b * (s // 128), 128, 3 * h).sum(1)
     assert float((cs - ref_cs).abs().max()) <= 1e-4 * (1.0 + float(ref_cs.abs().max()))
+    if p > 0:          # the keep mask READ by the backward kernel instead of re-drawn (dle_attention_bwd_keep): the same bits
+        dqkv_k = F.attention_bwd(qkv, dctx, mask_add, stats, b, s, nh, scale, p, seed, off, keep_mask=mbits)
+        assert torch.equal(dqkv_k, dqkv)
     # determinism: the same call gives the same bits
     ctx2, stats2, _ = F.attention_fwd(qkv, mask_add, b, s, nh, scale, p, seed, off)
     dqkv2 = F.attention_bwd(qkv, dctx, mask_add, stats2, b, s, nh, scale, p, seed, off)
