@@ -540,10 +540,12 @@ extern "C" int dle_gemm(const void* A, const void* B, void* C, void* aux, const 
       if (r == 1) return 0;
       if (r != 0) return r;
     }
-    // the masked-addend data gradient of the deep stages' conv1 (K >= 256, M <= 65536 rows: 14 x 14 and 7 x 7 at batch 256): the
+    // the masked-addend data gradient of the deepest stage's conv1 (K >= 512, M <= 65536 rows: 7 x 7 at batch 256): the
     // ping-pong kernel's source-tensor epilogue with the keep bits (gemm8_kernel.h, ACT_ADD_MASKED); DLE_GEMM8_MASKED=0 keeps the
     // streaming kernel below
-    if (!legacy && act == 8 && a_kc && !b_kc && splitk == 1 && !accumulate && !bias && alpha == 1.0f && K >= 256) {
+    // (K >= 512 only: at K = 256 -- 50176 x 1024 x 256, four K tiles per item -- the item is all epilogue and the streaming kernel
+    //  below is faster, 63 against 71 us; at K = 512 the ping-pong kernel wins, 57 against 63 us: profiles/r06_rn50_shapes_*.txt)
+    if (!legacy && act == 8 && a_kc && !b_kc && splitk == 1 && !accumulate && !bias && alpha == 1.0f && K >= 512) {
       static const int on = getenv("DLE_GEMM8_MASKED") ? atoi(getenv("DLE_GEMM8_MASKED")) : 1;
       static const long long maxm = getenv("DLE_GEMM8_MASKED_MAXM") ? atoll(getenv("DLE_GEMM8_MASKED_MAXM")) : 65536;
       if (on && M <= maxm) {
