@@ -234,9 +234,10 @@ static int bl_tn(int N) { return (N % 128) == 0 ? 128 : 64; }
 // 64-column tiles of K = 256 (34 KiB, 140 registers: three wavefronts per SIMD) run three 4-wave workgroups per CU
 static int bl_nw(int K, int N) { return (K > 128 && bl_tn(N) == 128) ? 8 : 4; }
 // K = 512 (the conv1 of a 28 x 28 bottleneck consuming bn3 of the block before it: 512 -> 128 channels): the 128 x 520 weight tile
-// is 133 KiB -- ONE 8-wave workgroup per CU, 16 k steps of fragments per lane (64 + 64 registers with the residual);
-// DLE_CONV_BNLOAD_K512=0 keeps the two-launch sequence
-static int bl_k512() { static const int v = getenv("DLE_CONV_BNLOAD_K512") ? atoi(getenv("DLE_CONV_BNLOAD_K512")) : 1; return v; }
+// is 133 KiB -- ONE 8-wave workgroup per CU, 16 k steps of fragments per lane (64 + 64 registers with the residual).  Measured
+// at batch 256 (200704 x 128 x 512 + residual): 172 us fused against 117 + 52 us apart -- no gain at two wavefronts per SIMD, so
+// the two-launch sequence stays the default; DLE_CONV_BNLOAD_K512=1 (read per call) lets the fused form through (tests, A/B runs)
+static int bl_k512() { const char* e = getenv("DLE_CONV_BNLOAD_K512"); return e ? atoi(e) : 0; }
 
 // Number of statistics rows dle_conv1x1_bnload_fwd writes for (M, N, K); 0: the shape is outside the kernel's envelope.
 extern "C" int dle_conv1x1_bnload_groups(int M, int N, int K) {

@@ -17,8 +17,10 @@ SHAPES = [((4, 32, 32), 64, 256, False), ((4, 32, 32), 128, 256, False), ((2, 56
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("nhw,k,n,with_res", SHAPES)
-def test_fused_unit_equals_apply_then_conv(cuda, dtype, nhw, k, n, with_res):
+def test_fused_unit_equals_apply_then_conv(cuda, dtype, nhw, k, n, with_res, monkeypatch):
     from deeplearningexamples_amd import functional as F
+    if k == 512:
+        monkeypatch.setenv("DLE_CONV_BNLOAD_K512", "1")          # (opt-in instantiation: no gain measured at batch 256)
     g = torch.Generator().manual_seed(k * 31 + n)
     shape = nhw + (k,)
     t = torch.randn(shape, generator=g).to(dtype).to(cuda)
