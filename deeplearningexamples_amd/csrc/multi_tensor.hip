@@ -145,7 +145,16 @@ __global__ __launch_bounds__(MT_BLOCK) void mt_l2norm_finish(const float* __rest
                                                              float* __restrict__ ret,
                                                              float* __restrict__ ret_per_tensor,
                                                              const int* __restrict__ noop) {
-  if (noop && *noop) return;
+  if (noop && *noop) {
+    // the reference returns its ZERO-INITIALISED outputs untouched when the flag is set -- before the launch (an overflow step:
+    // fused_lamb.py copies found_inf into the flag) or by the partial pass that met a non-finite value (multi_tensor_l2norm_kernel.cu:
+    // 40-42, 103-104, 121-123; the outputs are at::zeros).  The callers here hand over uninitialised buffers: write the zeros.
+    if (threadIdx.x == 0) {
+      if (blockIdx.x == 0) ret[0] = 0.f;
+      else ret_per_tensor[blockIdx.x - 1] = 0.f;
+    }
+    return;
+  }
   __shared__ float red[16];
   const MtTable t = mt_view(table, n);
   if (blockIdx.x == 0) {

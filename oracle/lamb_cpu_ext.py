@@ -27,7 +27,9 @@ def multi_tensor_l2norm(chunk_size, noop_flag, tensor_lists, per_tensor=False):
         return total, per
     tot, pn = L.l2norm([_np(t) for t in ts])
     if not np.isfinite(tot):
+        # :103-104 the functor raises the flag; `cleanup` (:121-123) then returns before it writes: the outputs stay at::zeros
         noop_flag.fill_(1)
+        return total, per
     total[0] = float(tot)
     if per_tensor:
         per.copy_(torch.from_numpy(np.asarray(pn, np.float32)))

@@ -35,5 +35,5 @@ prof)
 traffic)
   tools/collect_traffic.sh $W > gpurun_out/r06_traffic_collect.log 2>&1; tail -5 gpurun_out/r06_traffic_collect.log ;;
 tests)
-  python -m pytest tests -m gpu -q -x 2>&1 | tail -15 > gpurun_out/r06_gpu_tests_tail.log; tail -5 gpurun_out/r06_gpu_tests_tail.log ;;
+  python -m pytest tests -m gpu -q 2>&1 | tail -15 > gpurun_out/r06_gpu_tests_tail.log; tail -5 gpurun_out/r06_gpu_tests_tail.log ;;
 esac; done
