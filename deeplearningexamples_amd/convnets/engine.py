@@ -149,6 +149,10 @@ class ResNetTrainer:
         # the downsample branch's BatchNorm (no ReLU) applied where bn3's apply LOADS the residual (bn_apply2_pf_kernel, conv_bnload
         # RES = 2): the branch's 16-bit output is never written; DLE_RN50_FUSE_DSBN=0 keeps its stand-alone apply pass
         self.fuse_dsbn = os.environ.get("DLE_RN50_FUSE_DSBN", "1") != "0"
+        # ... and in the backward direction: bn3 and the downsample BatchNorm of a layer's first block receive the SAME gradient
+        # (g under the block's output keep bits); their two reductions read g and the mask once (bn_reduce2_kernel);
+        # DLE_RN50_FUSE_DSRED=0 keeps the two launches
+        self.fuse_dsred = os.environ.get("DLE_RN50_FUSE_DSRED", "1") != "0"
         self.stem.w2 = torch.zeros((64, 7, 8, 4), dtype=compute_dtype, device=self.dev)
         self.stem.gw_flat = self.gview["conv1.weight"]
         self.fc_w16 = torch.empty(model.fc.weight.shape, dtype=compute_dtype, device=self.dev)
@@ -310,6 +314,11 @@ class ResNetTrainer:
             # the block ends in relu(bn3(conv3) + shortcut): g * (out > 0) flows into BOTH branches.  It is never written:
             # bn3's backward applies the mask on load, the shortcut side gets (g, mask) and applies it where it is consumed
             mask3 = u3.relu_mask()
+            if ud is not None and self.fuse_dsred and u3.saved is not None and ud.saved is not None and mask3 is not None \
+                    and not u3.reduce_done and u3.saved[1].shape == ud.saved[1].shape:
+                F.bn_bwd_reduce2(g, mask3, u3.saved[1], u3.saved[3], u3.saved[4], u3.ggamma, u3.gbeta,
+                                 ud.saved[1], ud.saved[3], ud.saved[4], ud.ggamma, ud.gbeta)
+                u3.reduce_done = ud.reduce_done = True
             bs = self.branch_stream if ud is not None else None
             if bs is not None:                   # the downsample branch's backward beside bn3 / conv3 / conv2's
                 cur = torch.cuda.current_stream()

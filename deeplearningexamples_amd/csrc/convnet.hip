@@ -776,6 +776,123 @@ extern "C" int dle_bn_bwd_reduce(const void* dy, const void* y, const void* relu
   return 0;
 }
 
+// The backward reduction of TWO BatchNorms that receive the same gradient: bn3 and the downsample branch's BatchNorm of a
+// bottleneck's first block both see g = dy under the block's output keep bits (out = relu(bn3(t3) + bn_ds(t_ds)),
+// models/resnet.py:166-173).  Two dle_bn_bwd_reduce launches read dy and the mask twice; this one reads them once:
+// sum g (shared), sum g xhat_1, sum g xhat_2.  Per BatchNorm the partial rows and the fold are those of bn_reduce_kernel<.., 1, 2, 1>
+// + bn_bwd_finish_kernel: the same products in the same order, results bit-identical to the two launches.
+struct BnRed2Args {
+  const unsigned short* x1; const unsigned short* x2; const unsigned short* dy; const unsigned char* mask;
+  const float* mean1; const float* rstd1; const float* mean2; const float* rstd2;
+  float* partial1; float* partial2;   // [groups][2][C] each
+  long long M; int C; long long rows_per_block; int lpr;
+};
+template <int DT>
+__global__ __launch_bounds__(256) void bn_reduce2_kernel(BnRed2Args a) {
+  __shared__ float red[3][256 * 8];
+  const int cl = threadIdx.x % a.lpr, rl = threadIdx.x / a.lpr, rstep = 256 / a.lpr;
+  const int c0 = (blockIdx.x * a.lpr + cl) * 8;
+  const long long r0 = (long long)blockIdx.y * a.rows_per_block;
+  long long r1 = r0 + a.rows_per_block;
+  if (r1 > a.M) r1 = a.M;
+  float s0[8], s1[8], s2[8], mu1[8], rs1[8], mu2[8], rs2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s0[k] = 0.f; s1[k] = 0.f; s2[k] = 0.f; mu1[k] = 0.f; rs1[k] = 1.f; mu2[k] = 0.f; rs2[k] = 1.f; }
+  if (c0 < a.C) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { mu1[k] = a.mean1[c0 + k]; rs1[k] = a.rstd1[c0 + k]; mu2[k] = a.mean2[c0 + k]; rs2[k] = a.rstd2[c0 + k]; }
+    constexpr int U = 2;
+    auto load_batch = [&](long long rb, ushort8_t (&xv)[U], ushort8_t (&zv)[U], ushort8_t (&gv)[U], unsigned (&mb)[U])
+        __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long o = (rb + (long long)u * rstep) * a.C + c0;
+        xv[u] = *(const ushort8_t*)(a.x1 + o);
+        zv[u] = *(const ushort8_t*)(a.x2 + o);
+        gv[u] = *(const ushort8_t*)(a.dy + o);
+        mb[u] = a.mask[o >> 3];
+      }
+    };
+    auto accum = [&](ushort8_t xv, ushort8_t zv, ushort8_t gv, unsigned bits) __attribute__((always_inline)) {
+      float xf[8], zf[8], gf[8];
+      unpack8<DT>(xv, xf);
+      unpack8<DT>(zv, zf);
+      unpack8<DT>(gv, gf);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float g = gf[k];
+        if (!((bits >> k) & 1u)) g = 0.f;
+        s0[k] += g;
+        s1[k] += g * (xf[k] - mu1[k]) * rs1[k];
+        s2[k] += g * (zf[k] - mu2[k]) * rs2[k];
+      }
+    };
+    long long r = r0 + rl;
+    const long long bstep = (long long)U * rstep;
+    if (r + (long long)(U - 1) * rstep < r1) {
+      ushort8_t xv[U], zv[U], gv[U], xn[U], zn[U], gn[U];
+      unsigned mb[U], mn[U];
+      load_batch(r, xv, zv, gv, mb);
+      for (; r + bstep + (long long)(U - 1) * rstep < r1; r += bstep) {
+        load_batch(r + bstep, xn, zn, gn, mn);
+#pragma unroll
+        for (int u = 0; u < U; ++u) accum(xv[u], zv[u], gv[u], mb[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) { xv[u] = xn[u]; zv[u] = zn[u]; gv[u] = gn[u]; mb[u] = mn[u]; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) accum(xv[u], zv[u], gv[u], mb[u]);
+      r += bstep;
+    }
+    for (; r < r1; r += rstep) {
+      const long long o = r * a.C + c0;
+      accum(*(const ushort8_t*)(a.x1 + o), *(const ushort8_t*)(a.x2 + o), *(const ushort8_t*)(a.dy + o), a.mask[o >> 3]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][threadIdx.x * 8 + k] = s0[k]; red[1][threadIdx.x * 8 + k] = s1[k]; red[2][threadIdx.x * 8 + k] = s2[k]; }
+  __syncthreads();
+  if (rl == 0 && c0 < a.C) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+      for (int q = 0; q < rstep; ++q) {
+        t0 += red[0][(q * a.lpr + cl) * 8 + k]; t1 += red[1][(q * a.lpr + cl) * 8 + k]; t2 += red[2][(q * a.lpr + cl) * 8 + k];
+      }
+      a.partial1[((long long)blockIdx.y * 2 + 0) * a.C + c0 + k] = t0;
+      a.partial1[((long long)blockIdx.y * 2 + 1) * a.C + c0 + k] = t1;
+      a.partial2[((long long)blockIdx.y * 2 + 0) * a.C + c0 + k] = t0;
+      a.partial2[((long long)blockIdx.y * 2 + 1) * a.C + c0 + k] = t2;
+    }
+  }
+}
+
+// dgamma1 / dbeta1 of (x1, mean1, rstd1) and dgamma2 / dbeta2 of (x2, mean2, rstd2) from ONE pass over dy and relu_mask (bit-packed,
+// required).  workspace: fp32, >= 2 * dle_bn_workspace_bytes(M, C).  Bit-identical to two dle_bn_bwd_reduce calls.
+extern "C" int dle_bn_bwd_reduce2(const void* dy, const void* relu_mask, const void* x1, const float* mean1, const float* rstd1,
+                                  float* dgamma1, float* dbeta1, const void* x2, const float* mean2, const float* rstd2,
+                                  float* dgamma2, float* dbeta2, int64_t M, int C, void* workspace, int64_t workspace_bytes,
+                                  int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "bn_bwd_reduce2: 16-bit activations only");
+  DLE_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0, "bn_bwd_reduce2: bad shape");
+  DLE_CHECK_ARG(dy && relu_mask && x1 && x2 && mean1 && rstd1 && mean2 && rstd2 && dgamma1 && dbeta1 && dgamma2 && dbeta2 && workspace,
+                "bn_bwd_reduce2: null pointer");
+  int lpr, gx; long long rpb, gy;
+  bn_reduce_geometry(M, C, lpr, gx, rpb, gy);
+  const long long one = gy * 2 * (long long)C;
+  DLE_CHECK_ARG(workspace_bytes >= 2 * one * 4, "bn_bwd_reduce2: workspace too small");
+  BnRed2Args a = {(const unsigned short*)x1, (const unsigned short*)x2, (const unsigned short*)dy, (const unsigned char*)relu_mask,
+                  mean1, rstd1, mean2, rstd2, (float*)workspace, (float*)workspace + one, (long long)M, C, rpb, lpr};
+  dim3 grid(gx, (unsigned)gy), block(256);
+  if (dtype == DLE_F16) hipLaunchKernelGGL(bn_reduce2_kernel<DLE_F16>, grid, block, 0, stream, a);
+  else hipLaunchKernelGGL(bn_reduce2_kernel<DLE_BF16>, grid, block, 0, stream, a);
+  DLE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, (const float*)workspace, (int)gy, C, dgamma1, dbeta1, 0);
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, (const float*)workspace + one, (int)gy, C, dgamma2, dbeta2, 0);
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
 // The fold half of dle_bn_bwd_reduce on its own: dgamma / dbeta from `groups` partial rows [groups][2][C] of (sum g, sum g xhat)
 // that another kernel left (dle_gemm_expand_masked_bnred takes the reduction in the epilogue that PRODUCES the gradient).
 extern "C" int dle_bn_bwd_finish(const float* partial, int groups, int C, float* dgamma, float* dbeta, int accumulate,

@@ -921,6 +921,22 @@ def bn_bwd(dy, y, x, mean, rstd, gamma, dgamma, dbeta, want_skip_grad=False, dx_
     return dx, g
 
 
+def bn_bwd_reduce2(dy, relu_mask, x1, mean1, rstd1, dgamma1, dbeta1, x2, mean2, rstd2, dgamma2, dbeta2):
+    """The backward reduction (dgamma, dbeta) of TWO BatchNorms fed by the same gradient dy under the same keep bits -- bn3 and the
+    downsample branch's BatchNorm of a bottleneck's first block -- in one pass over dy and the mask (csrc/convnet.hip
+    bn_reduce2_kernel); bit-identical to two bn_bwd reductions.  The callers then run their apply passes with reduce_done=True."""
+    C.require_cuda(dy, relu_mask, x1, mean1, rstd1, dgamma1, dbeta1, x2, mean2, rstd2, dgamma2, dbeta2)
+    c = x1.shape[-1]
+    m = x1.numel() // c
+    if x2.shape != x1.shape or dy.shape != x1.shape or not (dy.is_contiguous() and x1.is_contiguous() and x2.is_contiguous()) \
+            or x1.dtype != dy.dtype or x2.dtype != dy.dtype:
+        raise ValueError("bn_bwd_reduce2: dy, x1, x2 must be dense tensors of one shape / dtype")
+    ws = splitk_workspace(x1.device, 2 * int(C.lib().dle_bn_workspace_bytes(m, c)))
+    C.annotate(bytes=float(x1.numel()) * (6 + 0.125), tag="M%dxC%d+relu x2" % (m, c))
+    C.call("dle_bn_bwd_reduce2", C.ptr(dy), C.ptr(relu_mask), C.ptr(x1), C.ptr(mean1), C.ptr(rstd1), C.ptr(dgamma1), C.ptr(dbeta1),
+           C.ptr(x2), C.ptr(mean2), C.ptr(rstd2), C.ptr(dgamma2), C.ptr(dbeta2), m, c, C.ptr(ws), ws.numel() * 4, C.dt(x1), C.stream())
+
+
 def gemm_masked_add_bnred(g2, w, m, n, k, addend, bits, t2, bits2, mean2, rstd2, dgamma2, dbeta2):
     """dx [m, n] = g2 [m, k] w [k, n] + addend under `bits` (the masked residual gradient, as gemm(act=ACT_ADD_MASKED)) AND the
     backward reduction of the BatchNorm that dx flows into: dgamma2 / dbeta2 (fp32 [n], overwritten) from g = dx under bits2 and

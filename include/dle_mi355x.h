@@ -323,6 +323,12 @@ int dle_bn_fwd_apply2(const void* x, const void* xr, void* y, void* relu_mask, c
 int dle_bn_bwd_reduce(const void* dy, const void* y, const void* relu_mask, const void* x, const float* mean,
                       const float* rstd, float* dgamma, float* dbeta, int64_t M, int C, int accumulate,
                       void* workspace, int64_t workspace_bytes, int dtype, hipStream_t stream);
+/* The same reduction for TWO BatchNorms that receive the same gradient (bn3 and the downsample branch's BatchNorm of a
+ * bottleneck's first block, models/resnet.py:166-173: both see dy under the block's output keep bits): dy and relu_mask are read
+ * ONCE.  Bit-identical to two dle_bn_bwd_reduce calls.  workspace >= 2 * dle_bn_workspace_bytes(M, C). */
+int dle_bn_bwd_reduce2(const void* dy, const void* relu_mask, const void* x1, const float* mean1, const float* rstd1, float* dgamma1,
+                       float* dbeta1, const void* x2, const float* mean2, const float* rstd2, float* dgamma2, float* dbeta2,
+                       int64_t M, int C, void* workspace, int64_t workspace_bytes, int dtype, hipStream_t stream);
 /* dx = gamma*rstd*(g - dbeta/M - xhat*dgamma/M); g_out (optional) = g, the skip-branch gradient */
 int dle_bn_bwd_apply(const void* dy, const void* y, const void* relu_mask, const void* x, void* dx, void* g_out,
                      const float* mean, const float* rstd, const float* gamma, const float* dgamma,

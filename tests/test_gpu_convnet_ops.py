@@ -200,3 +200,30 @@ def test_bn_relu_maxpool_fused_equals_two_passes_and_pool_backward_patch(cuda, d
     gr.scatter_add_(2, idx.reshape(n, c, -1), dy.float().cpu().permute(0, 3, 1, 2).reshape(n, c, -1))
     ref = gr.reshape(n, c, h, w).permute(0, 2, 3, 1)
     assert torch.allclose(dx.float().cpu(), ref.to(dtype).float(), atol=0.02, rtol=0.01)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,c", [(50176, 1024), (3000, 2048), (777, 24)])
+def test_bn_bwd_reduce2_equals_two_reductions(cuda, dtype, m, c):
+    """bn3 and the downsample BatchNorm of a bottleneck's first block receive the same gradient under the same keep bits
+    (models/resnet.py:166-173): the dual reduction reads dy and the mask once and leaves both (dgamma, dbeta) pairs BIT-IDENTICAL to
+    two dle_bn_bwd_reduce launches."""
+    from deeplearningexamples_amd import functional as F
+    g = torch.Generator().manual_seed(m + c)
+    dy = torch.randn(m, c, generator=g).to(dtype).to(cuda)
+    x1 = torch.randn(m, c, generator=g).to(dtype).to(cuda)
+    x2 = torch.randn(m, c, generator=g).to(dtype).to(cuda)
+    bits = torch.randint(0, 256, (m * c // 8,), generator=g, dtype=torch.uint8).to(cuda)
+    st = [(torch.randn(c, generator=g) * 0.1).to(cuda) for _ in range(2)] + [(torch.rand(c, generator=g) + 0.5).to(cuda) for _ in range(2)]
+    mean1, mean2, rstd1, rstd2 = st
+    gamma = torch.ones(c, device=cuda)
+    ref = []
+    for x, mu, rs in ((x1, mean1, rstd1), (x2, mean2, rstd2)):
+        dg, db = torch.empty(c, device=cuda), torch.empty(c, device=cuda)
+        F.bn_bwd(dy, None, x, mu, rs, gamma, dg, db, relu_mask=bits)
+        ref.append((dg, db))
+    out = [torch.empty(c, device=cuda) for _ in range(4)]
+    F.bn_bwd_reduce2(dy, bits, x1, mean1, rstd1, out[0], out[1], x2, mean2, rstd2, out[2], out[3])
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], ref[0][0]) and torch.equal(out[1], ref[0][1])
+    assert torch.equal(out[2], ref[1][0]) and torch.equal(out[3], ref[1][1])
