@@ -109,6 +109,8 @@ _SIGS = {
     "dle_rccl_allreduce": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p]),
     "dle_rccl_broadcast": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "dle_rccl_alltoallv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dle_gemm8_relu_bits_try": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_i64, c_i64, c_int, c_void_p]),
+    "dle_gemm_colsum_bits": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_i64, c_i64, c_int, c_int, c_void_p, c_i64, c_void_p]),
     "dle_bn_bwd_reduce2": (c_int, [c_void_p] * 12 + [c_i64, c_int, c_void_p, c_i64, c_int, c_void_p]),
     "dle_bn_fwd_apply2": (c_int, [c_void_p] * 12 + [c_i64, c_int, c_int, c_void_p]),
     "dle_conv1x1_bnload_fwd2": (c_int, [c_void_p] * 15 + [c_i64, c_int, c_int, c_int, c_int, c_void_p]),

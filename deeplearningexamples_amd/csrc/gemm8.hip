@@ -49,7 +49,7 @@ static int g8_try(const void* A, const void* B, void* C, void* aux, const float*
   if (!a_kc && (M & 7) != 0) return 0;
   const bool al = ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)src) | ((uintptr_t)bias) |
                     ((uintptr_t)ws)) & 15) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && (ldc & 7) == 0 &&
-                  (((uintptr_t)aux) & (act == ACT_ADD_MASKED ? 1 : 15)) == 0;
+                  (((uintptr_t)aux) & ((act == ACT_ADD_MASKED || act == ACT_RELU_BITS || act == ACT_RELU_BWD_BITS) ? 1 : 15)) == 0;
   if (!al) return 0;
   // operand extents (range-checked DMA) and 32-bit lane offsets
   const long long a_rows = a_kc ? M : K, b_rows = b_kc ? N : K;
@@ -64,9 +64,20 @@ static int g8_try(const void* A, const void* B, void* C, void* aux, const float*
   if (splitk > 1) {
     if (!ws || out_dtype != DLE_F32 || bias || act != ACT_NONE || aux || stats) return 0;
     epi = 0;
+  } else if (act == ACT_RELU_BWD_BITS) {
+    // C = product under keep bits (aux), no source tensor; optional column sums (the bias gradient of the layer below)
+    if (src || !aux || bias || out_dtype != in_dtype || accumulate || alpha != 1.0f || ldc != N || (N & 15) != 0 || b_kc) return 0;
+    if ((long long)(M + 256) * ldc * 2 >= 0xFFFFFFFFLL) return 0;
+    if (stats && (M & 255) != 0) return 0;
+    epi = 2;
+  } else if (act == ACT_RELU_BITS) {
+    // bias + ReLU forward that also leaves the keep bits of its (dense [M, N]) output in aux
+    if (!aux || stats || out_dtype != in_dtype || accumulate || ldc != N || (N & 15) != 0 || !a_kc || !b_kc) return 0;
+    if ((long long)(M + 256) * ldc * 2 >= 0xFFFFFFFFLL) return 0;
+    epi = 1;
   } else if (act == ACT_RELU_BWD || act == ACT_ADD || act == ACT_ADD_MASKED || act == ACT_MUL || act == ACT_GELU_BWD || act == ACT_TANH_BWD) {
     if (!src || bias || (aux != nullptr) != (act == ACT_ADD_MASKED) || out_dtype != in_dtype || accumulate || alpha != 1.0f) return 0;
-    if (act == ACT_ADD_MASKED && (ldc != N || b_kc)) return 0;            // (keep bits of a dense [M, N] addend; the conv1 data gradient)
+    if (act == ACT_ADD_MASKED && (ldc != N || (N & 15) != 0 || b_kc)) return 0;   // (keep bits of a dense [M, N] addend: two aligned bytes per lane)
     if ((long long)(M + 256) * ldc * 2 >= 0xFFFFFFFFLL) return 0;      // 32-bit byte offsets of the range-checked source loads
     if (stats && !(act == ACT_RELU_BWD || act == ACT_MUL)) return 0;
     if (stats && (M & 255) != 0) return 0;
@@ -155,4 +166,24 @@ extern "C" int dle_gemm8_colstats_try(const void* A, const void* B, void* C, int
   if (!stats) return 0;
   return g8_try(A, B, C, nullptr, nullptr, nullptr, M, N, K, lda, ldb, ldc, 1, 1, dtype, dtype, ACT_NONE, 1, 0, 1.0f, nullptr, stats, 1,
                 stream);
+}
+
+// Y [M, N] = relu(X [M, K] W [N, K]^T + bias) AND the keep bits of Y (bits [M N / 8]: bit (m N + n) & 7 of byte (m N + n) >> 3 =
+// rounded Y > 0) -- the forward of one (Linear + ReLU) layer of an MLP (Recommendation/DLRM/dlrm/nn/mlps.py:38-43,106-114) whose
+// backward then reads 1 bit per element instead of the 16-bit activation.  Dense Y (ldc = N), N a multiple of 16.
+// 1: launched; 0: outside the envelope (the caller runs dle_gemm with DLE_ACT_RELU and keeps Y as the mask source); > 1: error.
+extern "C" int dle_gemm8_relu_bits_try(const void* X, const void* W, void* Y, void* bits, const float* bias, int M, int N, int K,
+                                       int64_t ldx, int64_t ldw, int dtype, hipStream_t stream) {
+  return g8_try(X, W, Y, bits, bias, nullptr, M, N, K, ldx, ldw, N, 1, 1, dtype, dtype, ACT_RELU_BITS, 1, 0, 1.0f, nullptr, nullptr, 0,
+                stream);
+}
+
+// dX [M, N] = (dY [M, K] W [K, N]) under the keep bits of the layer below (bits as written by dle_gemm8_relu_bits_try for ITS
+// output [M, N]) AND, when colsum_partial != NULL, the per-128-row column sums of the rounded dX (fold with colsum_fold_kernel via
+// dle_gemm_colsum_bits) -- the data gradient through the ReLU of the layer below with that layer's bias gradient, no 16-bit mask
+// source read.  M a multiple of 256 with column sums.  Same return convention.
+extern "C" int dle_gemm8_relu_bwd_bits_try(const void* dY, const void* W, void* dX, const void* bits, float* colsum_partial, int M,
+                                           int N, int K, int64_t lddy, int64_t ldw, int dtype, hipStream_t stream) {
+  return g8_try(dY, W, dX, (void*)bits, nullptr, nullptr, M, N, K, lddy, ldw, N, 1, 0, dtype, dtype, ACT_RELU_BWD_BITS, 1, 0, 1.0f,
+                nullptr, colsum_partial, 0, stream);
 }

@@ -7,6 +7,7 @@ extern "C" int g8_launch_epi1(const Gemm8Args* p, int dt, int am, int bm, int ac
 #define G8_E1(DT) do { switch (act) { \
     case ACT_NONE: g8_launch<DT, 0, 0, 1, ACT_NONE>(*p, grid, stream); break; \
     case ACT_RELU: g8_launch<DT, 0, 0, 1, ACT_RELU>(*p, grid, stream); break; \
+    case ACT_RELU_BITS: g8_launch<DT, 0, 0, 1, ACT_RELU_BITS>(*p, grid, stream); break; \
     case ACT_GELU: g8_launch<DT, 0, 0, 1, ACT_GELU>(*p, grid, stream); break; \
     case ACT_GELU_DAUX: g8_launch<DT, 0, 0, 1, ACT_GELU_DAUX>(*p, grid, stream); break; \
     case ACT_TANH: g8_launch<DT, 0, 0, 1, ACT_TANH>(*p, grid, stream); break; \

@@ -9,6 +9,7 @@ extern "C" int g8_launch_epi2(const Gemm8Args* p, int dt, int am, int bm, int ac
     case ACT_RELU_BWD: g8_launch<DT, 0, BM_, 2, ACT_RELU_BWD>(*p, grid, stream); break; \
     case ACT_ADD: g8_launch<DT, 0, BM_, 2, ACT_ADD>(*p, grid, stream); break; \
     case ACT_ADD_MASKED: if (BM_ != 1) return 0; g8_launch<DT, 0, 1, 2, ACT_ADD_MASKED>(*p, grid, stream); break; \
+    case ACT_RELU_BWD_BITS: if (BM_ != 1) return 0; g8_launch<DT, 0, 1, 2, ACT_RELU_BWD_BITS>(*p, grid, stream); break; \
     case ACT_MUL: g8_launch<DT, 0, BM_, 2, ACT_MUL>(*p, grid, stream); break; \
     default: return 0; } } while (0)
   if (dt == DLE_F16) { if (bm == 0) G8_E2(DLE_F16, 0); else G8_E2(DLE_F16, 1); }

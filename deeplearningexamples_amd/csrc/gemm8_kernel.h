@@ -31,7 +31,11 @@
 #include "gemm8_walk.h"
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_ADD = 4, ACT_GELU_BWD = 5, ACT_TANH = 6,
-       ACT_TANH_BWD = 7, ACT_ADD_MASKED = 8, ACT_MUL = 9, ACT_GELU_DAUX = 10 };
+       ACT_TANH_BWD = 7, ACT_ADD_MASKED = 8, ACT_MUL = 9, ACT_GELU_DAUX = 10,
+       // the ReLU of a linear layer as ONE BIT per element (this kernel only: dle_gemm8_relu_bits_try / ..._bwd_bits_try):
+       // forward (EPI 1): bias + ReLU, aux RECEIVES the keep bits (bit (m N + n) & 7 of byte (m N + n) >> 3 = rounded output > 0);
+       // backward (EPI 2): C = product where the bit is set, aux = those bits, NO source tensor is read
+       ACT_RELU_BITS = 11, ACT_RELU_BWD_BITS = 12 };
 
 #define G8_HALF 8192                 // 16-bit elements per half-tile image (128 rows x 64 k)
 #define G8_BUF (4 * G8_HALF)         // one K tile: A0 | A1 | B0 | B1
@@ -626,16 +630,19 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
           G8_WAVE_FENCE();
         };
         ushort8_t sv[EPI == 2 ? 8 : 1][2];
-        unsigned short kb[(EPI == 2 && ACT == ACT_ADD_MASKED) ? 8 : 1];      // the lane's 16 keep bits of each block (accumulator layout)
+        constexpr bool KBITS = EPI == 2 && (ACT == ACT_ADD_MASKED || ACT == ACT_RELU_BWD_BITS);
+        unsigned short kb[KBITS ? 8 : 1];      // the lane's 16 keep bits of each block (accumulator layout)
         if constexpr (EPI == 2) {
-          __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)e_src, 0, (int)e_cbytes, 0x00020000);
-          static_for<0, 8>([&](auto BI) __attribute__((always_inline)) {
-            constexpr int bi = decltype(BI)::value, i = bi >> 2, j = (bi >> 1) & 1, b = bi & 1;
-            const unsigned so = blk_off(i, j, b);
-            sv[bi][0] = __builtin_bit_cast(ushort8_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, lane_off_t, so, 0));
-            sv[bi][1] = __builtin_bit_cast(ushort8_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, lane_off_t + second_t, so, 0));
-          });
-          if constexpr (ACT == ACT_ADD_MASKED) {
+          if constexpr (ACT != ACT_RELU_BWD_BITS) {
+            __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)e_src, 0, (int)e_cbytes, 0x00020000);
+            static_for<0, 8>([&](auto BI) __attribute__((always_inline)) {
+              constexpr int bi = decltype(BI)::value, i = bi >> 2, j = (bi >> 1) & 1, b = bi & 1;
+              const unsigned so = blk_off(i, j, b);
+              sv[bi][0] = __builtin_bit_cast(ushort8_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, lane_off_t, so, 0));
+              sv[bi][1] = __builtin_bit_cast(ushort8_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, lane_off_t + second_t, so, 0));
+            });
+          }
+          if constexpr (KBITS) {
             // keep bits: bit (m ldc + n) & 7 of byte (m ldc + n) >> 3 -- a lane's 16 columns are two bytes (ldc and the column
             // base are multiples of 8: the launcher checks); byte offsets are the 16-bit element offsets / 8 = byte offsets / 16
             __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc((void*)e_aux, 0, (int)(e_cbytes >> 4), 0x00020000);
@@ -646,7 +653,8 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
           }
         }
         __amdgpu_buffer_rsrc_t ra = rc;
-        if constexpr (EPI == 1) { if (e_aux) ra = __builtin_amdgcn_make_buffer_rsrc((void*)e_aux, 0, (int)e_cbytes, 0x00020000); }
+        if constexpr (EPI == 1 && ACT != ACT_RELU_BITS) { if (e_aux) ra = __builtin_amdgcn_make_buffer_rsrc((void*)e_aux, 0, (int)e_cbytes, 0x00020000); }
+        if constexpr (EPI == 1 && ACT == ACT_RELU_BITS) ra = __builtin_amdgcn_make_buffer_rsrc((void*)e_aux, 0, (int)(e_cbytes >> 4), 0x00020000);
         static_for<0, 8>([&](auto BI) __attribute__((always_inline)) {
           constexpr int bi = decltype(BI)::value, i = bi >> 2, j = (bi >> 1) & 1, b = bi & 1;
           const unsigned so = blk_off(i, j, b);
@@ -666,7 +674,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
             float side[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) side[r] = v[r];
-            if (ACT == ACT_RELU) {
+            if (ACT == ACT_RELU || ACT == ACT_RELU_BITS) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
             } else if (ACT == ACT_GELU) {
@@ -690,12 +698,18 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
                 side[r] = d2.x; side[r + 1] = d2.y;
               }
             }
-            if (e_aux) {
-              ushort8_t x0 = pack8<DT>(side), x1 = pack8<DT>(side + 8);
-              to_rows(x0, x1);
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, x0), ra, lane_off_t + so, 0, 0);
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, x1), ra, lane_off_t + so + second_t, 0, 0);
+            if constexpr (ACT != ACT_RELU_BITS) {
+              if (e_aux) {
+                ushort8_t x0 = pack8<DT>(side), x1 = pack8<DT>(side + 8);
+                to_rows(x0, x1);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, x0), ra, lane_off_t + so, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, x1), ra, lane_off_t + so + second_t, 0, 0);
+              }
             }
+          } else if constexpr (EPI == 2 && ACT == ACT_RELU_BWD_BITS) {
+            const unsigned bits = kb[KBITS ? bi : 0];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { if (!((bits >> r) & 1u)) v[r] = 0.f; }
           } else if constexpr (EPI == 2) {
             float y[16];
             from_rows(sv[bi][0], sv[bi][1]);
@@ -708,7 +722,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) v[r] += y[r];
             } else if (ACT == ACT_ADD_MASKED) {
-              const unsigned bits = kb[(EPI == 2 && ACT == ACT_ADD_MASKED) ? bi : 0];
+              const unsigned bits = kb[KBITS ? bi : 0];
 #pragma unroll
               for (int r = 0; r < 16; ++r) { if ((bits >> r) & 1u) v[r] += y[r]; }
             } else if (ACT == ACT_MUL) {
@@ -727,6 +741,14 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
             }
           }
           const ushort8_t o0 = pack8<DT>(v), o1 = pack8<DT>(v + 8);
+          if constexpr (EPI == 1 && ACT == ACT_RELU_BITS) {
+            // keep bits of the ROUNDED output (what a mask derived from the stored 16-bit activation would say; v >= 0 here, so
+            // "positive" = a non-zero bit pattern): two bytes per lane and block, in the accumulator layout
+            unsigned kbits = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) kbits |= (o0[r] != 0 ? 1u : 0u) << r | (o1[r] != 0 ? 1u : 0u) << (8 + r);
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)kbits, ra, (lane_off + so) >> 4, 0, 0);
+          }
           {
             ushort8_t t0 = o0, t1 = o1;
             to_rows(t0, t1);
@@ -794,10 +816,10 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
             float side[16];
             bool has_side = false;
             if constexpr (EPI == 1) {
-              has_side = e_aux != 0;
+              has_side = e_aux != 0 && ACT != ACT_RELU_BITS;
 #pragma unroll
               for (int r = 0; r < 16; ++r) side[r] = v[r];           // pre-activation
-              if (ACT == ACT_RELU) {
+              if (ACT == ACT_RELU || ACT == ACT_RELU_BITS) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
               } else if (ACT == ACT_GELU) {
@@ -810,6 +832,11 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = g8_gelu_d(v[r], side[r]);   // side = the derivative
               }
+            } else if constexpr (EPI == 2 && ACT == ACT_RELU_BWD_BITS) {
+              const unsigned char* kbp = (const unsigned char*)e_aux + (off >> 3);
+              const unsigned bits = (unsigned)kbp[0] | (hi_ok ? (unsigned)kbp[1] << 8 : 0u);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) { if (!((bits >> r) & 1u)) v[r] = 0.f; }
             } else if constexpr (EPI == 2) {
               const unsigned short* s = (const unsigned short*)e_src + off;
               ushort8_t s0 = *(const ushort8_t*)s, s1 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -847,6 +874,14 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Args p) {
             unsigned short* c = (unsigned short*)e_C + off;
             *(ushort8_t*)c = o0;
             if (hi_ok) *(ushort8_t*)(c + 8) = o1;
+            if constexpr (EPI == 1 && ACT == ACT_RELU_BITS) {
+              unsigned kbits = 0;
+#pragma unroll
+              for (int r = 0; r < 8; ++r) kbits |= (o0[r] != 0 ? 1u : 0u) << r | (o1[r] != 0 ? 1u : 0u) << (8 + r);
+              unsigned char* kbp = (unsigned char*)e_aux + (off >> 3);
+              kbp[0] = (unsigned char)(kbits & 0xffu);
+              if (hi_ok) kbp[1] = (unsigned char)(kbits >> 8);
+            }
             if (EPI == 1 && has_side) {
               unsigned short* a = (unsigned short*)e_aux + off;
               *(ushort8_t*)a = pack8<DT>(side);

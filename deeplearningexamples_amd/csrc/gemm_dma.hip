@@ -1069,6 +1069,28 @@ extern "C" int dle_gemm_colsum(const void* A, const void* B, void* C, const void
   return 1;
 }
 
+extern "C" int dle_gemm8_relu_bwd_bits_try(const void* dY, const void* W, void* dX, const void* bits, float* colsum_partial, int M,
+                                           int N, int K, int64_t lddy, int64_t ldw, int dtype, hipStream_t stream);   // gemm8.hip
+
+// dle_gemm_colsum with the ReLU mask of the layer below as ONE BIT per element (the keep bits dle_gemm8_relu_bits_try left
+// beside that layer's forward output) instead of the 16-bit activation: C [M, N] = (A [M, K] B [K, N]) where the bit is set,
+// colsum_out[n] (+)= sum_m C[m, n] of the rounded output.  The masked data gradient of an MLP layer read 2 bytes per element to
+// learn 1 bit (134 MB per 1024-wide layer at batch 65536: Recommendation/DLRM/dlrm/nn/mlps.py:38-43 backward).
+// 1: launched; 0: outside the ping-pong kernel's envelope (the caller uses dle_gemm_colsum with the activation); > 1: error.
+extern "C" int dle_gemm_colsum_bits(const void* A, const void* B, void* C, const void* bits, float* colsum_out, int M, int N, int K,
+                                    int64_t lda, int64_t ldb, int dtype, int accumulate_colsum, void* workspace,
+                                    int64_t workspace_bytes, hipStream_t stream) {
+  if (!A || !B || !C || !bits || !colsum_out || !workspace) return 0;
+  if ((M & 255) != 0 || workspace_bytes < (long long)((M + 127) / 128) * N * 4) return 0;
+  const int r8 = dle_gemm8_relu_bwd_bits_try(A, B, C, bits, (float*)workspace, M, N, K, lda, ldb, dtype, stream);
+  if (r8 != 1) return r8;
+  hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, (const float*)workspace, colsum_out, N,
+                     (M + 127) / 128, accumulate_colsum);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { dle_set_error("colsum_fold launch failed: %s", hipGetErrorString(e)); return (int)e + 1000; }
+  return 1;
+}
+
 
 // ---- convolutions as implicit GEMM (NHWC activations, KRSC weights, 16-bit in, fp32 accumulate) -------------
 // Replace cuDNN's conv fwd / bwd-data / bwd-filter behind nn.Conv2d(bias=False)

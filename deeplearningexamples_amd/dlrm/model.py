@@ -48,6 +48,11 @@ class Mlp(nn.Module):
         self._initialize_weights()
         self._w16: List[torch.Tensor] = []
         self._saved = None
+        self._bits = None
+        # the ReLU masks of the hidden layers as ONE BIT per element, written by the forward GEMM's epilogue and read by the masked
+        # data gradient instead of the 16-bit activation (csrc/gemm8_kernel.h ACT_RELU_BITS / ACT_RELU_BWD_BITS);
+        # DLE_DLRM_RELU_BITS=0 keeps the activation as the mask source
+        self.relu_bits = os.environ.get("DLE_DLRM_RELU_BITS", "1") != "0"
 
     def _initialize_weights(self):
         for m in self.modules():
@@ -100,16 +105,26 @@ class Mlp(nn.Module):
         """x16 [B, k_padded(0)] 16-bit.  `out` (optional, may be a strided view) receives the last layer."""
         w16 = self.working_copies()
         acts = [x16]
+        bits = [None]                               # bits[i]: keep bits of acts[i] (None: the backward masks with acts[i] itself)
         h = x16
         lins = self.linears
         for i, lin in enumerate(lins):
             m, k = h.shape[0], w16[i].shape[1]
             n = lin.out_features
             dst = out if (i == len(lins) - 1 and out is not None) else None
-            h = F.gemm(h, w16[i], m, n, k, True, True, out=dst, out_dtype=self.compute_dtype,
-                       bias=lin.bias.data, act=C.ACT_RELU)
+            r = None
+            # (only a layer whose mask is consumed by the NEXT layer's masked data gradient: not the last one)
+            if self.relu_bits and dst is None and i < len(lins) - 1 and h.is_cuda:
+                r = F.gemm_relu_bits(h, w16[i], m, n, k, lin.bias.data)
+            if r is not None:
+                h, b = r
+            else:
+                h, b = F.gemm(h, w16[i], m, n, k, True, True, out=dst, out_dtype=self.compute_dtype,
+                              bias=lin.bias.data, act=C.ACT_RELU), None
             acts.append(h)
+            bits.append(b)
         self._saved = acts
+        self._bits = bits
         return h
 
     def backward(self, gy: torch.Tensor, need_input_grad: bool = False, grads=None, masked: bool = False, defer_wgrad: bool = False,
@@ -157,8 +172,12 @@ class Mlp(nn.Module):
                 # dX = g W, masked by the ReLU of the previous layer in the epilogue -- which also leaves the column sums of dX,
                 # the bias gradient of the layer below (one pass less over every dX)
                 gb_prev = grads[i - 1][1] if grads is not None else _grad_buf(lins[i - 1].bias)
-                gn = F.gemm_colsum(g, w16[i], m, kp, lin.out_features, acts[i], gb_prev) \
-                    if kp == lins[i - 1].out_features else None
+                gn = None
+                if kp == lins[i - 1].out_features:
+                    if self._bits is not None and self._bits[i] is not None:
+                        gn = F.gemm_colsum_bits(g, w16[i], m, kp, lin.out_features, self._bits[i], gb_prev)
+                    if gn is None:
+                        gn = F.gemm_colsum(g, w16[i], m, kp, lin.out_features, acts[i], gb_prev)
                 if gn is not None:
                     bias_done.add(i - 1)
                     g = gn

@@ -380,6 +380,47 @@ def gemm_colsum(g, w, m, n, k, src, colsum_out, act=C.ACT_RELU_BWD, accumulate=F
     return out if rc == 1 else None
 
 
+def gemm_relu_bits(x, w, m, n, k, bias):
+    """y [m, n] = relu(x [m, k] w [n, k]^T + bias) together with the KEEP BITS of y (uint8 [m n / 8]: bit (i n + j) & 7 of byte
+    (i n + j) >> 3 = y[i, j] > 0) -- one (Linear + ReLU) layer whose backward reads 1 bit per element instead of y
+    (csrc/gemm8_kernel.h ACT_RELU_BITS; dlrm/nn/mlps.py:38-43).  -> (y, bits), or None outside the ping-pong kernel's envelope
+    (the caller runs gemm(act=ACT_RELU) and keeps y as the mask source).  y is bit-identical to gemm(act=ACT_RELU)."""
+    C.require_cuda(x, w, bias)
+    if (x.dtype not in (torch.float16, torch.bfloat16) or w.dtype != x.dtype or x.stride(1) != 1 or w.stride(1) != 1
+            or n % 16 != 0 or bias is None or bias.dtype != torch.float32):
+        return None
+    y = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    bits = torch.empty(m * n // 8, dtype=torch.uint8, device=x.device)
+    C.annotate(bytes=float(m) * (k + n) * x.element_size() + float(k) * n * w.element_size() + bits.numel(), flops=2.0 * m * n * k,
+               tag="%dx%dx%d+bits" % (m, n, k))
+    rc = _timed_optional("dle_gemm", C.lib().dle_gemm8_relu_bits_try,
+                         (C.ptr(x), C.ptr(w), C.ptr(y), C.ptr(bits), C.ptr(bias), m, n, k, x.stride(0), w.stride(0), C.dt(x), C.stream()))
+    if rc > 1:
+        C.check(rc - 1000 if rc > 1000 else -1, "dle_gemm8_relu_bits_try")
+    return (y, bits) if rc == 1 else None
+
+
+def gemm_colsum_bits(g, w, m, n, k, bits, colsum_out, accumulate=False):
+    """gemm_colsum(act=ACT_RELU_BWD) with the mask given as the keep bits gemm_relu_bits left (1 bit per element) instead of the
+    16-bit activation: dX [m, n] = (g [m, k] w [k, n]) where the bit is set, colsum_out [n] (+)= column sums of the rounded dX.
+    -> dX, or None outside the envelope (the caller uses gemm_colsum with the activation)."""
+    C.require_cuda(g, w, bits, colsum_out)
+    if (g.dtype not in (torch.float16, torch.bfloat16) or w.dtype != g.dtype or g.stride(1) != 1 or w.stride(1) != 1
+            or bits.dtype != torch.uint8 or bits.numel() != m * n // 8 or n % 16 != 0 or m % 256 != 0
+            or colsum_out.dtype != torch.float32 or not colsum_out.is_contiguous() or colsum_out.numel() != n):
+        return None
+    out = torch.empty((m, n), dtype=g.dtype, device=g.device)
+    ws = splitk_workspace(g.device, ((m + 127) // 128) * n * 4)
+    by = float(m) * (k + n) * g.element_size() + float(k) * n * w.element_size() + bits.numel()
+    C.annotate(bytes=by, flops=2.0 * m * n * k, tag="%dx%dx%d+bits+colsum" % (m, n, k))
+    rc = _timed_optional("dle_gemm", C.lib().dle_gemm_colsum_bits,
+                         (C.ptr(g), C.ptr(w), C.ptr(out), C.ptr(bits), C.ptr(colsum_out), m, n, k, g.stride(0), w.stride(0), C.dt(g),
+                          int(accumulate), C.ptr(ws), ws.numel() * 4, C.stream()), replayable=not accumulate)
+    if rc > 1:
+        C.check(rc - 1000 if rc > 1000 else -1, "dle_gemm_colsum_bits")
+    return out if rc == 1 else None
+
+
 def colsum(x, out=None, accumulate=False):
     """fp32 column sums of a 2-D tensor (bias gradient)."""
     C.require_cuda(x, out)

@@ -646,6 +646,19 @@ int dle_t2_mel_loss(const float* out_all, int64_t ld_out, const void* post, cons
 int dle_t2_mask_rows(void* x, int64_t ld, int cols, const int64_t* lengths, int64_t B, int To, float value, int dtype,
                      hipStream_t stream);
 
+/* ---- the ReLU of an MLP layer as one bit per element (csrc/gemm8_kernel.h, round 6; Recommendation/DLRM/dlrm/nn/mlps.py:38-43,
+ * 106-114 = apex mlp_cuda forward / backward).  dle_gemm8_relu_bits_try: Y [M, N] = relu(X [M, K] W [N, K]^T + bias) AND the keep
+ * bits of Y (bits [M N / 8]: bit (m N + n) & 7 of byte (m N + n) >> 3 = rounded Y > 0); dense Y, N % 16 == 0.
+ * dle_gemm_colsum_bits: the masked data gradient C = (A B) under those bits + the column sums of the rounded C (the bias gradient
+ * of the layer below), as dle_gemm_colsum but reading 1 bit per element instead of the 16-bit activation; M % 256 == 0,
+ * workspace >= ceil(M / 128) * N floats.  Both: 1 = launched, 0 = outside the ping-pong kernel's envelope (use dle_gemm with
+ * DLE_ACT_RELU / dle_gemm_colsum with the activation), > 1 = error. */
+int dle_gemm8_relu_bits_try(const void* X, const void* W, void* Y, void* bits, const float* bias, int M, int N, int K, int64_t ldx,
+                            int64_t ldw, int dtype, hipStream_t stream);
+int dle_gemm_colsum_bits(const void* A, const void* B, void* C, const void* bits, float* colsum_out, int M, int N, int K, int64_t lda,
+                         int64_t ldb, int dtype, int accumulate_colsum, void* workspace, int64_t workspace_bytes,
+                         hipStream_t stream);
+
 /* ---- collectives over librccl.so (csrc/rccl_comm.hip) -------------------------------------------------
  * What the reference reaches through torch.distributed's ProcessGroupNCCL: the gradient all-reduce of the DDP reducer
  * (Classification/ConvNets/image_classification/training.py:78-84), BERT's comm hook (LanguageModeling/BERT/run_pretraining.py:

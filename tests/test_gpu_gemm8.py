@@ -60,7 +60,7 @@ CASES = [
     ("addend_ktail", "nn", (777, 520, 1000), torch.bfloat16, dict(act="add", src=True)),
     ("relu_mask_f16", "nn", (1031, 264, 128), torch.float16, dict(act="relu_bwd", src=True)),
     # the conv1 data gradient of a bottleneck: + the residual-branch gradient under the block's keep bits (1 bit per element)
-    ("addend_under_keep_bits", "nn", (900, 520, 384), torch.bfloat16, dict(act="add_masked", src=True, bits=True)),
+    ("addend_under_keep_bits", "nn", (900, 528, 384), torch.bfloat16, dict(act="add_masked", src=True, bits=True)),
     ("addend_under_keep_bits_f16", "nn", (1024, 768, 512), torch.float16, dict(act="add_masked", src=True, bits=True)),
     ("stored_derivative_colsum", "nn", (1024, 512, 256), torch.bfloat16, dict(act="mul", src=True, colsum=True)),
     ("relu_mask_colsum_f16", "nn", (768, 1024, 512), torch.float16, dict(act="relu_bwd", src=True, colsum=True)),
@@ -229,3 +229,39 @@ def test_conv1x1_forward_with_batchnorm_statistics(g8, cuda, dtype, nhw, c, ko):
     assert torch.allclose(r1.double(), 1.0 / torch.sqrt(var + 1e-5), rtol=2e-5)
     assert torch.allclose(m1, m0, atol=1e-6, rtol=1e-5) and torch.allclose(r1, r0, rtol=1e-5)
     assert torch.allclose(rm1, rm0, atol=1e-6, rtol=1e-5) and torch.allclose(rv1, rv0, rtol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("m,n,k", [(1024, 512, 256), (2048, 1024, 480), (768, 528, 320)])
+def test_relu_as_keep_bits_forward_and_masked_data_gradient(g8, cuda, dtype, m, n, k):
+    """One (Linear + ReLU) layer of an MLP with its ReLU mask as ONE BIT per element (dlrm/nn/mlps.py:38-43): the forward epilogue
+    leaves y AND the keep bits of the rounded y; the masked data gradient of the layer above reads the bits instead of y.
+    y == gemm(act=ReLU) bit for bit, bits == (y > 0), dX == gemm_colsum(src=y) bit for bit, the bias gradient to fp32 order."""
+    from deeplearningexamples_amd import functional as F
+    from deeplearningexamples_amd import _cabi as C
+    gen = torch.Generator().manual_seed(m + n + k)
+    x = (torch.randn(m, k, generator=gen) * 0.5).to(dtype).to(cuda)
+    w = (torch.randn(n, k, generator=gen) * 0.1).to(dtype).to(cuda)
+    bias = (torch.randn(n, generator=gen) * 0.1).to(cuda)
+    before = g8.dle_gemm8_launch_count()
+    r = F.gemm_relu_bits(x, w, m, n, k, bias)
+    assert r is not None and g8.dle_gemm8_launch_count() > before
+    y, bits = r
+    y_ref = F.gemm(x, w, m, n, k, True, True, bias=bias, act=C.ACT_RELU)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref)
+    keep = ((bits.view(-1, 1) >> torch.arange(8, device=cuda, dtype=torch.uint8)) & 1).view(m, n).bool()
+    assert torch.equal(keep, y > 0)
+    # the layer above: g [m, n2] w2 [n2, n] -> dX [m, n] under the mask of y, + column sums
+    n2 = 256
+    g = (torch.randn(m, n2, generator=gen) * 0.5).to(dtype).to(cuda)
+    w2 = (torch.randn(n2, n, generator=gen) * 0.1).to(dtype).to(cuda)
+    cs_ref, cs = torch.zeros(n, device=cuda), torch.zeros(n, device=cuda)
+    dx_ref = F.gemm_colsum(g, w2, m, n, n2, y, cs_ref)
+    dx = F.gemm_colsum_bits(g, w2, m, n, n2, bits, cs)
+    torch.cuda.synchronize()
+    assert dx_ref is not None and dx is not None
+    assert torch.equal(dx, dx_ref)
+    mag = dx.double().abs().sum(0)
+    assert torch.all((cs.double() - cs_ref.double()).abs() <= 4e-6 * mag + 1e-9)
+    assert torch.all((cs.double() - dx.double().sum(0)).abs() <= 2e-6 * mag + 1e-9)
