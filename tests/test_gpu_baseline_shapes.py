@@ -188,17 +188,19 @@ def test_rn50_224_batch32_losses_match_reference(cuda, golden_dir, dtype):
 
 
 def test_rn50_224_batch256_bf16_losses_vs_live_oracle(cuda, golden_dir):
-    """BASELINE.json configs[1] at the BENCHED shape: batch 256, 224 x 224, bf16 -- two train steps on the HIP path against the CPU
-    oracle run LIVE on this box's host cores (oracle/resnet_oracle.py, fp32, pinned against the reference module by the goldens).
-    Every fused envelope of the step (conv_bnload / conv_bnbwd / BRED / the dual BatchNorm apply / the 4-channel stem) is taken at
-    exactly the launch shapes bench.py times.  Bar: the bare 1e-3 of north_star for both losses (the second one is taken after one SGD
-    update through every backward kernel)."""
+    """BASELINE.json configs[1] at the BENCHED shape: batch 256, 224 x 224, bf16 -- the HIP path against the CPU oracle run LIVE on
+    this box's host cores (oracle/resnet_oracle.py, fp32, pinned against the reference module by the goldens).  Every fused envelope
+    of the forward pass (conv_bnload, the dual BatchNorm apply, the 4-channel stem, the ping-pong kernel's statistics epilogue) is
+    taken at exactly the launch shapes bench.py times.  Default: the loss of the first step (one oracle forward, ~1 min on 128
+    cores).  DLE_TEST_BS256_FULL=1 adds the loss AFTER one SGD update through every backward kernel (one oracle forward + backward +
+    update more, ~4 min; measured on the round-6 tree: 6e-7 and 1.3e-5 relative).  Bar: the bare 1e-3 of north_star."""
+    import psutil
     from oracle import resnet_oracle as RO
     from deeplearningexamples_amd.convnets.resnet import ResNet50
     from deeplearningexamples_amd.convnets.engine import ResNetTrainer
-    import psutil
-    if psutil.virtual_memory().available < 96e9:          # the fp32 autograd graph of batch 256 at 224 x 224 holds ~40 GB on the host
-        pytest.skip("less than 96 GB of free host memory for the live batch-256 oracle")
+    full = os.environ.get("DLE_TEST_BS256_FULL", "0") == "1"
+    if psutil.virtual_memory().available < (96e9 if full else 48e9):      # the fp32 autograd graph of batch 256 at 224 x 224: ~40 GB
+        pytest.skip("not enough free host memory for the live batch-256 oracle")
     c = dict(RO.RN50_STEP_CONFIG_224, batch=256)
     state = RO.seeded_state(c["seed"])
     x, y = RO.seeded_batch(c["seed"] + 100, c["batch"], c["size"])
@@ -206,19 +208,20 @@ def test_rn50_224_batch256_bf16_losses_vs_live_oracle(cuda, golden_dir):
     model.load_state_dict({k: v.clone() for k, v in state.items()}, strict=False)
     tr = ResNetTrainer(model, lr=c["lr"], compute_dtype=torch.bfloat16, static_loss_scale=128.0)
     xd, yd = x.to(cuda), y.to(cuda)
-    losses = np.asarray([float(tr.train_step(xd, yd).item()) for _ in range(2)])
+    losses = np.asarray([float(tr.train_step(xd, yd).item()) for _ in range(2 if full else 1)])
     threads = torch.get_num_threads()
     torch.set_num_threads(max(threads, os.cpu_count() or 1))
     try:
         orc = RO.ResNet50Oracle(state, lr=c["lr"])
-        first = orc.step(x, y)                          # forward + backward + SGD update (~2.5 min on the box's 128 cores)
-        with torch.no_grad():                           # the second loss needs the forward pass only
-            second = float(orc.loss(orc.forward(x), y))
-        ref = np.asarray([first, second])
+        if full:
+            first = orc.step(x, y)                      # forward + backward + SGD update
+            with torch.no_grad():
+                ref = np.asarray([first, float(orc.loss(orc.forward(x), y))])
+        else:
+            with torch.no_grad():                       # the first loss needs the forward pass only
+                ref = np.asarray([float(orc.loss(orc.forward(x), y))])
     finally:
         torch.set_num_threads(threads)
-    gold = np.load(os.path.join(golden_dir, "rn50_step_224.npz"))
-    floor = np.abs(gold["losses_bf16_storage"] - gold["losses"]) / gold["losses"]
     rel = np.abs(losses - ref) / ref
-    print("bs256 224^2 bf16: hip", losses, "oracle", ref, "rel err / 1e-3", rel / 1e-3, "storage floor (bs 32 golden)", floor)
-    assert np.all(rel <= 1e-3), (losses, ref)           # the bare bar of north_star (measured: 6e-7 and 1.3e-5)
+    print("bs256 224^2 bf16: hip", losses, "oracle", ref, "rel err / 1e-3", rel / 1e-3)
+    assert np.all(rel <= 1e-3), (losses, ref)           # the bare bar of north_star
