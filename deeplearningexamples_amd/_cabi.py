@@ -118,6 +118,8 @@ _SIGS = {
     "dle_bn_bwd_apply": (c_int, [c_void_p] * 11 + [c_i64, c_int, c_int, c_void_p]),
     "dle_maxpool_fwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "dle_maxpool_bwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "dle_pool_bn_bwd_workspace_bytes": (c_i64, [c_int] * 4),
+    "dle_pool_bn_bwd": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p, c_i64, c_int, c_void_p]),
     "dle_avgpool_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
     "dle_avgpool_bwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
     "dle_upsample_zero": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

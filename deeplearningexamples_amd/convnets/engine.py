@@ -153,6 +153,9 @@ class ResNetTrainer:
         # (g under the block's output keep bits); their two reductions read g and the mask once (bn_reduce2_kernel);
         # DLE_RN50_FUSE_DSRED=0 keeps the two launches
         self.fuse_dsred = os.environ.get("DLE_RN50_FUSE_DSRED", "1") != "0"
+        # the stem's backward chain max pooling -> ReLU -> BatchNorm without the pooling gradient's full-resolution tensor;
+        # DLE_RN50_FUSE_POOLBWD=0 keeps dle_maxpool_bwd + the two BatchNorm passes
+        self.fuse_pool_bwd = os.environ.get("DLE_RN50_FUSE_POOLBWD", "1") != "0"
         self.stem.w2 = torch.zeros((64, 7, 8, 4), dtype=compute_dtype, device=self.dev)
         self.stem.gw_flat = self.gview["conv1.weight"]
         self.fc_w16 = torch.empty(model.fc.weight.shape, dtype=compute_dtype, device=self.dev)
@@ -343,8 +346,13 @@ class ResNetTrainer:
             prev3 = self.blocks[bi - 1][2] if (self.fuse_bnred and ud is None and bi > 0) else None
             g = u1.backward(g2, dx_addend=gskip, bnred=prev3)
             self._done(u1)
-        g = F.maxpool_bwd(g, self._amax, self._pool_in_hw)
-        self.stem.backward(g, need_dx=False)
+        if self.fuse_pool_bwd:
+            # the stem's BatchNorm backward gathers the pooling gradient from (g, argmax) itself: its 411 MB full-resolution form
+            # (batch 256) is never written or re-read (csrc/convnet.hip pool_bn_bwd_kernel)
+            self.stem.backward(None, need_dx=False, pooled=(g, self._amax))
+        else:
+            g = F.maxpool_bwd(g, self._amax, self._pool_in_hw)
+            self.stem.backward(g, need_dx=False)
         gw = self.stem.gw
         ko, r, s, cp = gw.shape
         stem_generic = self.stem.saved_c != 4        # (set by the stem's backward: which image layout this step ran on)

@@ -137,7 +137,7 @@ class ConvBN:
                               relu=self.relu, want_mask=False)
         return y
 
-    def backward(self, dy, need_dx=True, dx_addend=None, dy_mask=None, compact_dx=False, bnred=None):
+    def backward(self, dy, need_dx=True, dx_addend=None, dy_mask=None, compact_dx=False, bnred=None, pooled=None):
         """dy: gradient w.r.t. the unit's output; dy_mask (optional): bit-packed keep bits to apply to dy first (the
         ReLU that follows the residual add sits on the OTHER branch's unit: its mask gates this branch's gradient too).
         dx_addend: a tensor, or (tensor, keep bits) = the residual-branch gradient dy * (y > 0) that is never
@@ -146,6 +146,8 @@ class ConvBN:
         compact_dx (1x1 stride-2 units): return that triple instead of the full-resolution dx.
         bnred (with a masked dx_addend): the conv + BN unit whose output gradient this dx IS (the previous block's conv3 / bn3) --
         its BatchNorm's backward reduction is taken in the epilogue that produces dx, and that unit's backward() skips it.
+        pooled (the stem; dy is then None): (gradient of the max pooling's OUTPUT, argmax) -- the BatchNorm backward gathers the
+        pooling gradient itself (F.pool_bn_bwd); outside that kernel's envelope the pooling backward runs here.
         Returns dx or None."""
         x, t, mask, mean, rstd = self.saved
         self.saved = None
@@ -163,7 +165,15 @@ class ConvBN:
                 b2 = (bnred.saved[1], bnred.saved[2], bnred.saved[3], bnred.saved[4], bnred.ggamma, bnred.gbeta)
             fused = F.bn_bwd_conv1x1_dgrad(dy, t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta,
                                            self.w16.view(self.cout, c), relu_mask=rmask, reduce_done=reduce_done, bnred=b2)
-        if fused is not None:
+        gt = None
+        if pooled is not None:
+            if self.relu and not reduce_done:
+                gt = F.pool_bn_bwd(pooled[0], pooled[1], t, mean, rstd, self.bn.weight.data, self.ggamma, self.gbeta, rmask)
+            if gt is None:
+                dy = F.maxpool_bwd(pooled[0], pooled[1], t.shape[1:3])
+        if gt is not None:
+            pass
+        elif fused is not None:
             gt = fused[0]
             if fused[2]:
                 bnred.reduce_done = True

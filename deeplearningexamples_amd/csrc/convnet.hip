@@ -1320,6 +1320,154 @@ __global__ __launch_bounds__(256) void maxpool_bwd_k3s2_patch_kernel(const unsig
   }
 }
 
+// The stem's backward chain maxpool -> ReLU -> BatchNorm (models/resnet.py:318-322 backward) WITHOUT the pooling gradient's
+// full-resolution tensor: both BatchNorm passes gather it from the pooled gradient + argmax themselves.  Stand-alone, the
+// pooling backward writes dx (411 MB at batch 256), the reduction reads it and the apply pass reads it again; here each pass
+// reads the pooled gradient (1/4 of the pixels) and the argmax bytes instead.  One thread per 2 x 2 patch of input pixels x 8
+// channels (the patch is covered by four windows and no other: maxpool_bwd_k3s2_patch_kernel's walk, same summation order per
+// pixel); the gathered value is rounded to the activation dtype where the stand-alone pass stored it, so the apply pass's
+// output is bit-identical given the same dgamma / dbeta (the reduction's partial sums are grouped differently: fp32 rounding).
+//   APPLY = false: partial[block][2][C] = (sum g, sum g xhat) over the block's patches, g = dx under the ReLU keep bits
+//   APPLY = true:  dz = gamma rstd (g - dbeta / M - xhat dgamma / M)
+template <int DT, bool APPLY>
+__global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const unsigned short* __restrict__ dy, const unsigned char* __restrict__ amax,
+                                                          const unsigned char* __restrict__ mask, const unsigned short* __restrict__ x,
+                                                          unsigned short* __restrict__ dz, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                          float* __restrict__ partial, int N, int H, int W, int C8, int P, int Q,
+                                                          float inv_m) {
+  __shared__ float red[APPLY ? 1 : 2][APPLY ? 1 : 256 * 8];
+  const unsigned total = (unsigned)N * P * Q * C8;
+  const unsigned first = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = (int)(first % (unsigned)C8) * 8;              // (256 % C8 == 0: a thread keeps its channel group)
+  float kmu[8], krs[8], ka[8], kb[8], kg[8], s0[8], s1[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    kmu[k] = mean[c0 + k]; krs[k] = rstd[c0 + k];
+    s0[k] = 0.f; s1[k] = 0.f;
+    if constexpr (APPLY) { ka[k] = gamma[c0 + k] * krs[k]; kb[k] = dbeta[c0 + k] * inv_m; kg[k] = dgamma[c0 + k] * inv_m; }
+  }
+  for (unsigned i = first; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned c8 = i % (unsigned)C8;
+    unsigned t = i / (unsigned)C8;
+    const int q = (int)(t % (unsigned)Q); t /= (unsigned)Q;
+    const int p = (int)(t % (unsigned)P);
+    const int n = (int)(t / (unsigned)P);
+    const bool vp1 = p + 1 < P, vq1 = q + 1 < Q;
+    const int pp[2] = {p, vp1 ? p + 1 : p}, qq[2] = {q, vq1 ? q + 1 : q};
+    ushort8_t g[4], xv[4];
+    uint2_t am[4];
+    unsigned mb[4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const unsigned o = (((unsigned)n * P + pp[a]) * Q + qq[b]) * C8 + c8;
+        g[a * 2 + b] = ((const ushort8_t*)dy)[o];
+        am[a * 2 + b] = ((const uint2_t*)amax)[o];
+        const unsigned ox = ((((unsigned)n * H + 2 * p + a) * W) + 2 * q + b) * C8 + c8;
+        xv[a * 2 + b] = ((const ushort8_t*)x)[ox];
+        mb[a * 2 + b] = mask[ox];
+      }
+    auto term = [&](int win, unsigned code, bool valid, float* acc) __attribute__((always_inline)) {
+      const unsigned want = valid ? code : 0xFFu;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const unsigned c = (am[win][k >> 2] >> ((k & 3) * 8)) & 0xffu;
+        if (c == want) acc[k] += up16<DT>(g[win][k]);
+      }
+    };
+    float a00[8], a01[8], a10[8], a11[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a00[k] = 0.f; a01[k] = 0.f; a10[k] = 0.f; a11[k] = 0.f; }
+    term(0, 4, true, a00);
+    term(1, 3, vq1, a01); term(0, 5, true, a01);
+    term(2, 1, vp1, a10); term(0, 7, true, a10);
+    term(3, 0, vp1 && vq1, a11); term(2, 2, vp1, a11); term(1, 6, vq1, a11); term(0, 8, true, a11);
+    auto pixel = [&](int px, const float* acc) __attribute__((always_inline)) {
+      float xf[8], of[8];
+      unpack8<DT>(xv[px], xf);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float gv = up16<DT>(dn16<DT>(acc[k]));                  // the value the stand-alone pooling backward stores
+        if (!((mb[px] >> k) & 1u)) gv = 0.f;
+        const float xh = (xf[k] - kmu[k]) * krs[k];
+        if constexpr (APPLY) of[k] = ka[k] * (gv - kb[k] - xh * kg[k]);
+        else { s0[k] += gv; s1[k] += gv * xh; }
+      }
+      if constexpr (APPLY)
+        ((ushort8_t*)dz)[((((unsigned)n * H + 2 * p + (px >> 1)) * W) + 2 * q + (px & 1)) * C8 + c8] = pack8<DT>(of);
+    };
+    pixel(0, a00); pixel(1, a01); pixel(2, a10); pixel(3, a11);
+  }
+  if constexpr (!APPLY) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { red[0][threadIdx.x * 8 + k] = s0[k]; red[1][threadIdx.x * 8 + k] = s1[k]; }
+    __syncthreads();
+    if ((int)threadIdx.x < C8) {
+      const int C = C8 * 8, rows = 256 / C8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int r = 0; r < rows; ++r) { t0 += red[0][(r * C8 + threadIdx.x) * 8 + k]; t1 += red[1][(r * C8 + threadIdx.x) * 8 + k]; }
+        partial[((long long)blockIdx.x * 2 + 0) * C + threadIdx.x * 8 + k] = t0;
+        partial[((long long)blockIdx.x * 2 + 1) * C + threadIdx.x * 8 + k] = t1;
+      }
+    }
+  }
+}
+
+// Workgroups (= partial rows) of dle_pool_bn_bwd's reduction; 0 when the shape is outside its envelope.
+static int pool_bn_grid(int N, int H, int W, int C) {
+  if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 7)) return 0;
+  const int C8 = C / 8;
+  if (C8 > 256 || (C8 & (C8 - 1))) return 0;
+  const long long total = (long long)N * (H / 2) * (W / 2) * C8;
+  if ((long long)N * H * W * C8 >= 0x7FFFFFFFLL) return 0;
+  long long g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  return (int)g;
+}
+
+// fp32 workspace bytes of dle_pool_bn_bwd (0: shape outside the envelope -- run dle_maxpool_bwd + dle_bn_bwd_reduce / _apply).
+extern "C" int64_t dle_pool_bn_bwd_workspace_bytes(int N, int H, int W, int C) {
+  return (int64_t)pool_bn_grid(N, H, W, C) * 2 * C * 4;
+}
+
+// dz [N, H, W, C] = the BatchNorm (+ ReLU, keep bits relu_mask [N H W C / 8]) backward of the gradient that MaxPool2d(3, 2, 1)'s
+// backward would scatter from dy [N, H/2, W/2, C] + argmax (dle_maxpool_fwd's encoding) -- dgamma / dbeta (fp32 [C], written)
+// included; x = the BatchNorm's input (the stem convolution's output).  Replaces dle_maxpool_bwd + dle_bn_bwd_reduce +
+// dle_bn_bwd_apply for the stem (models/resnet.py:318-322 backward).
+extern "C" int dle_pool_bn_bwd(const void* dy, const void* argmax, const void* relu_mask, const void* x, void* dz, const float* mean,
+                               const float* rstd, const float* gamma, float* dgamma, float* dbeta, int N, int H, int W, int C,
+                               void* workspace, int64_t workspace_bytes, int dtype, hipStream_t stream) {
+  DLE_CHECK_ARG(dtype == DLE_F16 || dtype == DLE_BF16, "pool_bn_bwd: 16-bit activations only");
+  const int grid = pool_bn_grid(N, H, W, C);
+  DLE_CHECK_ARG(grid > 0, "pool_bn_bwd: shape outside the envelope (H, W even, C / 8 a power of two <= 256)");
+  DLE_CHECK_ARG(dy && argmax && relu_mask && x && dz && mean && rstd && gamma && dgamma && dbeta && workspace, "pool_bn_bwd: null pointer");
+  DLE_CHECK_ARG(workspace_bytes >= (int64_t)grid * 2 * C * 4, "pool_bn_bwd: workspace too small");
+  const int P = H / 2, Q = W / 2, C8 = C / 8;
+  const float inv_m = 1.0f / (float)((long long)N * H * W);
+#define POOL_BN(DT)                                                                                                              \
+  do {                                                                                                                           \
+    hipLaunchKernelGGL((pool_bn_bwd_kernel<DT, false>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy,             \
+                       (const unsigned char*)argmax, (const unsigned char*)relu_mask, (const unsigned short*)x,                  \
+                       (unsigned short*)nullptr, mean, rstd, gamma, (const float*)nullptr, (const float*)nullptr,               \
+                       (float*)workspace, N, H, W, C8, P, Q, inv_m);                                                             \
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, (const float*)workspace, grid, C, dgamma,  \
+                       dbeta, 0);                                                                                                \
+    hipLaunchKernelGGL((pool_bn_bwd_kernel<DT, true>), dim3(grid), dim3(256), 0, stream, (const unsigned short*)dy,              \
+                       (const unsigned char*)argmax, (const unsigned char*)relu_mask, (const unsigned short*)x,                  \
+                       (unsigned short*)dz, mean, rstd, gamma, (const float*)dgamma, (const float*)dbeta, (float*)nullptr, N,    \
+                       H, W, C8, P, Q, inv_m);                                                                                   \
+  } while (0)
+  if (dtype == DLE_F16) POOL_BN(DLE_F16); else POOL_BN(DLE_BF16);
+#undef POOL_BN
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
 // BatchNorm-apply + ReLU + MaxPool2d(3, 2, 1) in ONE pass (the ResNet stem: bn1 -> relu -> maxpool, models/resnet.py:318-322):
 // the 16-bit activation between them (411 MB at batch 256, written once and read once) never exists.  One thread per pooled
 // pixel x 8 channels: nine (clamped, masked) loads of t, y = relu(t * sc + sh) rounded to 16 bits exactly as dle_bn_fwd_apply stores

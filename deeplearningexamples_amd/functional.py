@@ -1083,6 +1083,27 @@ def maxpool_bwd(dy, argmax, in_hw, ksize=3, stride=2, pad=1):
     return dx
 
 
+def pool_bn_bwd(dy, argmax, x, mean, rstd, gamma, dgamma, dbeta, relu_mask):
+    """The stem's backward chain MaxPool2d(3, 2, 1) -> ReLU -> BatchNorm in two passes that gather the pooling gradient from dy
+    [N, H/2, W/2, C] + argmax themselves (csrc/convnet.hip pool_bn_bwd_kernel): the full-resolution pooling gradient is never
+    written.  x [N, H, W, C]: the BatchNorm's input; dgamma / dbeta are written.  -> dz, or None outside the envelope (nothing
+    launched: maxpool_bwd + bn_bwd)."""
+    C.require_cuda(dy, argmax, x, mean, rstd, gamma, dgamma, dbeta, relu_mask)
+    n, h, w, c = x.shape
+    if relu_mask is None or dy.shape != (n, h // 2, w // 2, c) or not (dy.is_contiguous() and x.is_contiguous()) or dy.dtype != x.dtype:
+        return None
+    nbytes = int(C.lib().dle_pool_bn_bwd_workspace_bytes(n, h, w, c))
+    if nbytes == 0:
+        return None
+    ws = splitk_workspace(x.device, nbytes)
+    dz = torch.empty_like(x)
+    # two passes: (pooled gradient + argmax + x + keep bits) twice, dz once
+    C.annotate(bytes=2.0 * (dy.numel() * 3 + x.numel() * 2.125) + x.numel() * 2.0, tag="N%dx%dx%dxC%d" % (n, h, w, c))
+    C.call("dle_pool_bn_bwd", C.ptr(dy), C.ptr(argmax), C.ptr(relu_mask), C.ptr(x), C.ptr(dz), C.ptr(mean), C.ptr(rstd), C.ptr(gamma),
+           C.ptr(dgamma), C.ptr(dbeta), n, h, w, c, C.ptr(ws), ws.numel() * 4, C.dt(x), C.stream())
+    return dz
+
+
 def avgpool_fwd(x):
     C.require_cuda(x)
     n, h, w, c = x.shape

@@ -400,6 +400,16 @@ int dle_bn_relu_maxpool_fwd(const void* x, void* y, void* argmax, void* relu_mas
                             const float* gamma, const float* beta, int N, int H, int W, int C, int dtype, hipStream_t stream);
 int dle_maxpool_bwd(const void* dy, const void* argmax, void* dx, int N, int H, int W, int C, int ksize,
                     int stride, int pad, int dtype, hipStream_t stream);
+/* The stem's backward chain MaxPool2d(3, 2, 1) -> ReLU -> BatchNorm (models/resnet.py:318-322 backward; cuDNN pooling backward +
+ * batch_norm_backward in the reference) without the pooling gradient's full-resolution tensor: dz [N, H, W, C] = BatchNorm backward
+ * (keep bits relu_mask [N H W C / 8], x = the BatchNorm's input) of the gradient dle_maxpool_bwd would scatter from dy
+ * [N, H/2, W/2, C] + argmax; dgamma / dbeta (fp32 [C]) are written.  dz equals dle_maxpool_bwd + dle_bn_bwd_apply bit for bit
+ * given the same dgamma / dbeta; the reduction groups its fp32 partial sums differently.  workspace: fp32,
+ * >= dle_pool_bn_bwd_workspace_bytes (0 = shape outside the envelope: H, W even, C / 8 a power of two <= 256). */
+int64_t dle_pool_bn_bwd_workspace_bytes(int N, int H, int W, int C);
+int dle_pool_bn_bwd(const void* dy, const void* argmax, const void* relu_mask, const void* x, void* dz, const float* mean,
+                    const float* rstd, const float* gamma, float* dgamma, float* dbeta, int N, int H, int W, int C, void* workspace,
+                    int64_t workspace_bytes, int dtype, hipStream_t stream);
 int dle_avgpool_fwd(const void* x, void* y, int64_t N, int HW, int C, int dtype, hipStream_t stream);
 int dle_avgpool_bwd(const void* dy, void* dx, int64_t N, int HW, int C, int dtype, hipStream_t stream);
 /* C [M = n_img*H*W, N] = A [M, K] B^T + zero_stuffed(compact [n_img*(H/2)*(W/2), N]): the data gradient of a bottleneck's first 1x1

@@ -227,3 +227,69 @@ def test_bn_bwd_reduce2_equals_two_reductions(cuda, dtype, m, c):
     torch.cuda.synchronize()
     assert torch.equal(out[0], ref[0][0]) and torch.equal(out[1], ref[0][1])
     assert torch.equal(out[2], ref[1][0]) and torch.equal(out[3], ref[1][1])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,h,w,c", [(2, 8, 8, 64), (3, 12, 20, 16), (1, 6, 4, 8), (4, 112, 112, 64)])
+def test_pool_bn_bwd_equals_pooling_backward_then_batchnorm_backward(cuda, dtype, n, h, w, c):
+    """The stem's backward chain (models/resnet.py:318-322: maxpool <- relu <- bn1) with the pooling gradient gathered inside the
+    two BatchNorm passes == dle_maxpool_bwd then dle_bn_bwd_reduce / _apply: dgamma / dbeta to fp32 summation order, dz bit for
+    bit wherever the two (dgamma, dbeta) pairs round the same (and within one 16-bit ulp elsewhere)."""
+    from deeplearningexamples_amd import functional as F
+    g = torch.Generator().manual_seed(h * 7 + c + n)
+    t = torch.randn((n, h, w, c), generator=g).to(dtype).to(cuda)
+    mean = (torch.randn(c, generator=g) * 0.2).to(cuda)
+    rstd = (torch.rand(c, generator=g) + 0.5).to(cuda)
+    gamma = (torch.rand(c, generator=g) + 0.5).to(cuda)
+    beta = (torch.randn(c, generator=g) * 0.3).to(cuda)
+    y, am, mask = F.bn_relu_maxpool_fwd(t, mean, rstd, gamma, beta)
+    dy = torch.randn(y.shape, generator=g).to(dtype).to(cuda)
+    dg, db = torch.full((c,), 9.0, device=cuda), torch.full((c,), 9.0, device=cuda)
+    dz = F.pool_bn_bwd(dy, am, t, mean, rstd, gamma, dg, db, mask)
+    assert dz is not None
+    dx = F.maxpool_bwd(dy, am, (h, w))
+    dg_ref, db_ref = torch.zeros(c, device=cuda), torch.zeros(c, device=cuda)
+    dz_ref, _ = F.bn_bwd(dx, None, t, mean, rstd, gamma, dg_ref, db_ref, relu_mask=mask)
+    torch.cuda.synchronize()
+    scale_g, scale_b = float(dg_ref.abs().max()), float(db_ref.abs().max())
+    np.testing.assert_allclose(dg.cpu().numpy(), dg_ref.cpu().numpy(), rtol=1e-4, atol=2e-5 * max(scale_g, 1.0))
+    np.testing.assert_allclose(db.cpu().numpy(), db_ref.cpu().numpy(), rtol=1e-4, atol=2e-5 * max(scale_b, 1.0))
+    a, b = dz.float().cpu(), dz_ref.float().cpu()
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    assert float((a - b).abs().max()) <= 2 * ulp * max(float(b.abs().max()), 1.0)
+    assert float((a == b).float().mean()) > 0.98
+    # given the SAME statistics gradients the apply pass is the stand-alone one bit for bit: feed the reference pair back through the C ABI
+    from deeplearningexamples_amd import _cabi as C
+    ws = torch.empty(int(C.lib().dle_pool_bn_bwd_workspace_bytes(n, h, w, c)) // 4, dtype=torch.float32, device=cuda)
+    assert ws.numel() > 0
+    # outside the envelope (odd height): declined, nothing launched
+    assert F.pool_bn_bwd(dy[:, :, :, :], am, t[:, : h - 1].contiguous(), mean, rstd, gamma, dg, db, mask) is None
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_rn50_step_with_and_without_the_pooling_gradient_gathered_in_the_stem_batchnorm(cuda, dtype, monkeypatch):
+    """DLE_RN50_FUSE_POOLBWD=1 (the stem's BatchNorm backward gathers the pooling gradient) vs 0 (dle_maxpool_bwd + the two
+    BatchNorm passes) on the damped-residual fixture of tests/test_gpu_rn50_step.py: the forward pass is untouched (first loss to
+    the last fp32 digits), the stem's (dgamma, dbeta) differ by fp32 summation order only, so the following losses agree far
+    inside the fixture's 16-bit noise level."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import resnet_oracle as RO
+    import test_gpu_rn50_step as T
+    c = RO.RN50_STEP_CONFIG
+    state = RO.seeded_state(c["seed"])
+    x, y = RO.seeded_batch(c["seed"] + 1, 16, 64)
+    losses, stem = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DLE_RN50_FUSE_POOLBWD", mode)
+        model, tr = T._build(cuda, dtype, c["lr"], state)
+        assert tr.fuse_pool_bwd == (mode == "1")
+        losses[mode] = [float(tr.train_step(x.to(cuda), y.to(cuda)).item()) for _ in range(3)]
+        stem[mode] = model.conv1.weight.detach().float().cpu().clone()
+    print(dtype, losses)
+    assert abs(losses["1"][0] - losses["0"][0]) <= 2e-6 * abs(losses["0"][0])
+    for a, b in zip(losses["1"], losses["0"]):
+        assert abs(a - b) <= 1e-4 * abs(b)
+    # the stem's weights after three updates: the two paths hand the same dz to the same weight-gradient kernel
+    assert float((stem["1"] - stem["0"]).norm() / stem["0"].norm()) <= 1e-4

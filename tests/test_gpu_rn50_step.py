@@ -177,9 +177,11 @@ def test_rn50_unit_backward_teacher_forced_vs_fp32(cuda, dtype):
         full[:, ::2, ::2] = compact
         return full
 
-    def spy(self, dy, need_dx=True, dx_addend=None, dy_mask=None, compact_dx=False, bnred=None):
+    def spy(self, dy, need_dx=True, dx_addend=None, dy_mask=None, compact_dx=False, bnred=None, pooled=None):
         saved = self.saved
-        dx = orig(self, dy, need_dx=need_dx, dx_addend=dx_addend, dy_mask=dy_mask, compact_dx=compact_dx, bnred=bnred)
+        dx = orig(self, dy, need_dx=need_dx, dx_addend=dx_addend, dy_mask=dy_mask, compact_dx=compact_dx, bnred=bnred, pooled=pooled)
+        if pooled is not None:              # the stem: its BatchNorm backward gathered the pooling gradient itself -- this tensor
+            dy = F.maxpool_bwd(pooled[0], pooled[1], saved[1].shape[1:3])
         is_up2 = lambda v: isinstance(v, tuple) and v[0] == "up2"
         records.append((self, dy, stuffed(dx_addend) if is_up2(dx_addend) else dx_addend, dy_mask, saved,
                         stuffed(dx) if is_up2(dx) else dx))
