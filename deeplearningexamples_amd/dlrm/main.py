@@ -32,7 +32,25 @@ def _int_list(s):
     return [int(x) for x in s.split(",")] if isinstance(s, str) else list(s)
 
 
-def parse_flags(argv=None):
+def _absl_bool(v):
+    """absl.flags boolean values (flags.DEFINE_boolean; scripts/main.py:81-143): true / t / 1 / false / f / 0, any case."""
+    t = str(v).strip().lower()
+    if t in ("true", "t", "1"):
+        return True
+    if t in ("false", "f", "0"):
+        return False
+    raise argparse.ArgumentTypeError("Non-boolean argument to boolean flag: %r" % (v,))
+
+
+def _add_bool(p, name, default, help=None, short_name=None):
+    """A boolean flag with absl's three spellings: --name, --name=True|False (the reference's own test scripts write
+    --amp=True --cuda_graphs=True --optimized_mlp=False, tests/test_all_configs.sh:17-27) and --noname."""
+    names = ["--" + name] + (["--" + short_name] if short_name else [])
+    p.add_argument(*names, dest=name, nargs="?", const=True, default=default, type=_absl_bool, help=help)
+    p.add_argument(*["--no" + n[2:] for n in names], dest=name, action="store_false", help=argparse.SUPPRESS)
+
+
+def build_parser():
     p = argparse.ArgumentParser()
     p.add_argument("--mode", default="train", choices=["train", "test", "inference_benchmark"])
     p.add_argument("--seed", type=int, default=12345)
@@ -47,23 +65,23 @@ def parse_flags(argv=None):
     p.add_argument("--decay_start_step", type=int, default=48000)
     p.add_argument("--decay_power", type=int, default=2)
     p.add_argument("--decay_end_lr", type=float, default=0)
-    p.add_argument("--embedding_type", default="joint_fused",
+    p.add_argument("--embedding_type", default="custom_cuda",
                    choices=["joint", "custom_cuda", "multi_table", "joint_sparse", "joint_fused"])
     p.add_argument("--embedding_dim", type=int, default=128)
     p.add_argument("--top_mlp_sizes", type=_int_list, default=[1024, 1024, 512, 256, 1])
     p.add_argument("--bottom_mlp_sizes", type=_int_list, default=[512, 256, 128])
-    p.add_argument("--interaction_op", default="cuda_dot", choices=["cuda_dot", "dot"])
-    p.add_argument("--dataset_type", default="synthetic_gpu", choices=["synthetic_gpu", "parametric"],
+    p.add_argument("--interaction_op", default="cuda_dot", choices=["cuda_dot", "dot", "cat"])
+    p.add_argument("--dataset_type", default="parametric", choices=["synthetic_gpu", "parametric"],
                    help="parametric: the split-binary files a feature_spec.yaml describes (dlrm/data/datasets.py:64-223)")
     p.add_argument("--dataset", default=None, help="directory holding feature_spec.yaml and the train/ test/ files")
     p.add_argument("--feature_spec", default="feature_spec.yaml")
     p.add_argument("--synthetic_dataset_num_entries", type=int, default=int(2 ** 15 * 1024))
-    p.add_argument("--synthetic_dataset_table_sizes", type=_int_list, default=CRITEO_F15)
+    p.add_argument("--synthetic_dataset_table_sizes", type=_int_list, default=26 * [10 ** 5])
     p.add_argument("--synthetic_dataset_numerical_features", type=int, default=13)
     p.add_argument("--max_table_size", type=int, default=None)
-    p.add_argument("--hash_indices", action="store_true")
-    p.add_argument("--shuffle_batch_order", action="store_true")
-    p.add_argument("--synthetic_dataset_use_feature_spec", action="store_true")
+    _add_bool(p, "hash_indices", False)
+    _add_bool(p, "shuffle_batch_order", False, short_name="shuffle")
+    _add_bool(p, "synthetic_dataset_use_feature_spec", False)
     p.add_argument("--load_checkpoint_path", default=None, help="directory written by --save_checkpoint_path (or by the reference)")
     p.add_argument("--save_checkpoint_path", default=None)
     p.add_argument("--test_freq", type=int, default=None, help="validation pass every N steps (default: once per epoch)")
@@ -74,25 +92,34 @@ def parse_flags(argv=None):
     p.add_argument("--backend", default="nccl")
     p.add_argument("--inference_benchmark_batch_sizes", type=_int_list, default=[1, 64, 4096])
     p.add_argument("--inference_benchmark_steps", type=int, default=200)
-    p.add_argument("--Adam_embedding_optimizer", action="store_true")
-    p.add_argument("--Adam_MLP_optimizer", action="store_true")
+    _add_bool(p, "Adam_embedding_optimizer", False)
+    _add_bool(p, "Adam_MLP_optimizer", False)
     p.add_argument("--log_path", default="./log.json")
     p.add_argument("--print_freq", type=int, default=200)
     p.add_argument("--benchmark_warmup_steps", type=int, default=0)
-    p.add_argument("--amp", action="store_true")
-    p.add_argument("--cuda_graphs", action="store_true", help="capture the train step in a HIP graph (main.py:120,194-274)")
-    p.add_argument("--optimized_mlp", action="store_true", default=True)
-    p.add_argument("--bottom_features_ordered", action="store_true")
-    p.add_argument("--freeze_mlps", action="store_true")
-    p.add_argument("--freeze_embeddings", action="store_true")
+    _add_bool(p, "amp", False)
+    _add_bool(p, "cuda_graphs", False, help="capture the train step in a HIP graph (main.py:120,194-274)")
+    _add_bool(p, "optimized_mlp", True)
+    _add_bool(p, "bottom_features_ordered", False)
+    _add_bool(p, "freeze_mlps", False)
+    _add_bool(p, "freeze_embeddings", False)
     p.add_argument("--embedding_sharding", default="table", choices=["table", "row"],
                    help="table: whole tables per rank, the reference's get_device_mapping (default); row: every table cut into "
                         "row ranges over the ranks, ids routed by value and exchanged before the vectors (dlrm/row_sharded.py)")
-    f = p.parse_args(argv)
+    return p
+
+
+def parse_flags(argv=None):
+    f = build_parser().parse_args(argv)
     if f.mode == "inference_benchmark":
         raise SystemExit("--mode inference_benchmark: inference is outside this path (the train step and its validation pass)")
     if f.Adam_embedding_optimizer or f.Adam_MLP_optimizer:
         raise SystemExit("--Adam_*_optimizer: the path implements the reference's default SGD recipe")
+    if f.interaction_op == "cat":
+        raise SystemExit("--interaction_op cat: the path implements the dot interaction (cuda_dot / dot), the reference's default")
+    if (f.dataset_type == "parametric" or f.synthetic_dataset_use_feature_spec) and f.dataset is None:
+        raise SystemExit("--dataset: a directory with feature_spec.yaml is required for --dataset_type parametric (the default); "
+                         "--dataset_type synthetic_gpu needs none")
     return f
 
 
@@ -101,9 +128,14 @@ def main(argv=None):
     rank, world, local = init_from_env()
     device = torch.device("cuda", local)
     torch.manual_seed(flags.seed)
-    sizes = list(flags.synthetic_dataset_table_sizes)
-    if flags.dataset_type == "parametric":
-        sizes = FeatureSpec.from_yaml(os.path.join(flags.dataset, flags.feature_spec)).get_categorical_sizes()
+    # load_feature_spec (scripts/main.py:183-190): table cardinalities AND the number of numerical features come from the spec
+    # unless the data is synthetic without --synthetic_dataset_use_feature_spec
+    if flags.dataset_type == "synthetic_gpu" and not flags.synthetic_dataset_use_feature_spec:
+        sizes = list(flags.synthetic_dataset_table_sizes)
+    else:
+        fspec = FeatureSpec.from_yaml(os.path.join(flags.dataset, flags.feature_spec))
+        sizes = fspec.get_categorical_sizes()
+        flags.synthetic_dataset_numerical_features = fspec.get_number_of_numerical_features()
     if flags.max_table_size:
         sizes = [min(s, flags.max_table_size) for s in sizes]
     if flags.embedding_sharding == "row":

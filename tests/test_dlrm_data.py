@@ -12,6 +12,17 @@ from deeplearningexamples_amd.dlrm import data as D  # noqa: E402
 from oracle import _ref_import as R  # noqa: E402
 
 
+def _restore(mods, path, saved):
+    """Undo oracle/_ref_import.import_dlrm: the reference's modules leave sys.modules, the patched torch entry points come back."""
+    torch.cuda.current_device, torch.Tensor.cuda, torch.cuda.synchronize = saved
+    for k in list(sys.modules):
+        if k not in mods and not k.startswith(("torch", "numpy", "scipy", "_pytest", "pytest")):
+            del sys.modules[k]
+    for k, v in mods.items():
+        sys.modules[k] = v
+    sys.path[:] = path
+
+
 def _make(tmp_path, rows=1000, sizes=(7, 300, 40000, 5)):
     spec = D.FeatureSpec.get_default_feature_spec(13, list(sizes))
     spec.base_directory = str(tmp_path)
@@ -69,10 +80,66 @@ def test_same_batches_as_the_reference_dataset(tmp_path):
             (n0, c0, l0), (n1, c1, l1) = ours[i], ref[i]
             assert torch.equal(n0, n1) and torch.equal(c0, c1) and torch.equal(l0, l1), i
     finally:
-        torch.cuda.current_device, torch.Tensor.cuda, torch.cuda.synchronize = saved
-        for k in list(sys.modules):
-            if k not in mods and not k.startswith(("torch", "numpy", "scipy", "_pytest", "pytest")):
-                del sys.modules[k]
-        for k, v in mods.items():
-            sys.modules[k] = v
-        sys.path[:] = path
+        _restore(mods, path, saved)
+
+
+FSPEC_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "feature_specs")
+FSPECS = sorted(f for f in os.listdir(FSPEC_DIR) if f.endswith(".yaml"))
+
+
+def synth_from_fixture(name, out_dir, rows, seed=0):
+    """dlrm/scripts/prepare_synthetic_dataset.py on one of the reference's feature-spec fixtures (DLRM/tests/feature_specs/*.yaml,
+    committed as data under tests/golden/feature_specs/): uniform ids below each cardinality, uniform numericals, coin-flip labels,
+    written where the spec's source_spec says.  -> (spec, numerical, categorical, labels)."""
+    import shutil
+    os.makedirs(out_dir, exist_ok=True)
+    shutil.copy(os.path.join(FSPEC_DIR, name), os.path.join(out_dir, "feature_spec.yaml"))
+    spec = D.FeatureSpec.from_yaml(os.path.join(out_dir, "feature_spec.yaml"))
+    spec.check_feature_spec()
+    rng = np.random.default_rng(seed)
+    sizes = spec.get_categorical_sizes()
+    num = rng.random((rows, spec.get_number_of_numerical_features())).astype(np.float16)
+    cat = np.stack([rng.integers(0, s, rows) for s in sizes], axis=1)
+    lab = rng.integers(0, 2, rows).astype(bool)
+    for m in (D.TRAIN_MAPPING, D.TEST_MAPPING):
+        D.write_split_binary(spec, m, num, cat, lab)
+    return spec, num, cat, lab
+
+
+@pytest.mark.parametrize("name", FSPECS)
+def test_reference_feature_spec_fixtures_round_trip(tmp_path, name):
+    """Every feature spec the reference's own DLRM tests train on (tests/test_fspecs.sh, test_all_configs.sh: 10 / 13 / 20
+    numerical features, 10 / 26 / 30 tables, other feature names and file paths, int8 .. int64 storage): parsed, validated, a
+    synthetic dataset written in its layout and read back batch by batch."""
+    spec, num, cat, lab = synth_from_fixture(name, str(tmp_path), rows=300)
+    assert len(FSPECS) == 10
+    names = spec.get_categorical_feature_names()
+    assert cat.shape[1] == len(names) and num.shape[1] == spec.get_number_of_numerical_features()
+    ds = D.ParametricDataset(spec, "test", batch_size=128, numerical_features_enabled=True, categorical_features_to_read=names)
+    got = list(ds)
+    assert [b[2].shape[0] for b in got] == [128, 128, 44]
+    assert torch.equal(torch.cat([b[0] for b in got]), torch.from_numpy(num))
+    assert torch.equal(torch.cat([b[1] for b in got]), torch.from_numpy(cat))
+    assert torch.equal(torch.cat([b[2] for b in got]), torch.from_numpy(lab).float())
+    for i, n in enumerate(names):                     # each table's file holds the storage type the spec names
+        _, _, paths = spec.get_mapping_paths("train")
+        assert os.path.getsize(paths[n]) == 300 * np.dtype(spec.feature_spec[n]["dtype"]).itemsize
+    if R.have_reference():                            # the reference's classes read the same files to the same batches
+        mods, path = dict(sys.modules), list(sys.path)
+        saved = (torch.cuda.current_device, torch.Tensor.cuda, torch.cuda.synchronize)
+        try:
+            R.import_dlrm()
+            from dlrm.data.datasets import ParametricDataset as RefDataset
+            from dlrm.data.feature_spec import FeatureSpec as RefSpec
+            rspec = RefSpec.from_yaml(str(tmp_path / "feature_spec.yaml"))
+            rspec.check_feature_spec()
+            assert rspec.get_categorical_sizes() == spec.get_categorical_sizes()
+            assert rspec.get_number_of_numerical_features() == spec.get_number_of_numerical_features()
+            ref = RefDataset(rspec, mapping="test", batch_size=128, numerical_features_enabled=True,
+                             categorical_features_to_read=names, prefetch_depth=1)
+            assert len(ref) == len(ds)
+            for i in range(len(ref)):
+                (n0, c0, l0), (n1, c1, l1) = ds[i], ref[i]
+                assert torch.equal(n0, n1) and torch.equal(c0, c1) and torch.equal(l0, l1), (name, i)
+        finally:
+            _restore(mods, path, saved)

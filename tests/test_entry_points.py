@@ -43,8 +43,29 @@ def test_cli_parsers():
     with pytest.raises(ValueError):
         parse_arguments(["--train_batch_size", "10", "--gradient_accumulation_steps", "4"])
     from deeplearningexamples_amd.dlrm.main import parse_flags
-    f = parse_flags(["--top_mlp_sizes", "64,32,1", "--synthetic_dataset_table_sizes", "100,200", "--amp"])
+    f = parse_flags(["--top_mlp_sizes", "64,32,1", "--synthetic_dataset_table_sizes", "100,200", "--amp", "--dataset_type",
+                     "synthetic_gpu"])
     assert f.top_mlp_sizes == [64, 32, 1] and f.synthetic_dataset_table_sizes == [100, 200] and f.amp
+
+
+def test_dlrm_flags_follow_absl_boolean_syntax_and_the_reference_defaults():
+    """dlrm/scripts/main.py:43-143 defines its flags with absl: booleans are written --amp, --noamp or --amp=True|False (the
+    reference's own test scripts use the last form, tests/test_all_configs.sh:17-27); --dataset_type defaults to parametric,
+    --embedding_type to custom_cuda, the synthetic table sizes to 26 x 100000, --optimized_mlp to True."""
+    from deeplearningexamples_amd.dlrm.main import parse_flags
+    f = parse_flags(["--mode", "train", "--dataset", "/d", "--optimized_mlp=False", "--cuda_graphs=True", "--interaction_op=dot",
+                     "--embedding_type=joint_sparse", "--amp=False", "--hash_indices", "--noshuffle"])
+    assert (f.optimized_mlp, f.cuda_graphs, f.amp, f.hash_indices, f.shuffle_batch_order) == (False, True, False, True, False)
+    assert f.dataset_type == "parametric" and f.embedding_type == "joint_sparse" and f.interaction_op == "dot"
+    d = parse_flags(["--dataset", "/d"])
+    assert d.embedding_type == "custom_cuda" and d.synthetic_dataset_table_sizes == 26 * [100000] and d.optimized_mlp is True
+    assert d.amp is False and d.cuda_graphs is False and d.lr == 24 and d.batch_size == 65536
+    s = parse_flags(["--dataset_type=synthetic_gpu", "--amp=1", "--shuffle", "--nooptimized_mlp", "--freeze_mlps=t"])
+    assert s.amp is True and s.shuffle_batch_order is True and s.optimized_mlp is False and s.freeze_mlps is True
+    for bad in (["--dataset", "/d", "--amp=maybe"], [], ["--dataset", "/d", "--interaction_op=cat"],
+                ["--dataset_type=synthetic_gpu", "--synthetic_dataset_use_feature_spec"]):
+        with pytest.raises(SystemExit):
+            parse_flags(bad)
 
 
 def test_reference_command_lines_parse():
@@ -91,9 +112,12 @@ def test_reference_command_lines_parse():
         src = open(ref + "/Recommendation/DLRM/dlrm/scripts/main.py").read()
         flags = set(re.findall(r'DEFINE_[a-z]+\(\s*"([a-zA-Z0-9_]+)"', src))
         import deeplearningexamples_amd.dlrm.main as dm
-        psrc = open(dm.__file__).read()
-        missing = [x for x in flags if '"--%s"' % x not in psrc]
-        assert not missing, missing
+        known = {o for act in dm.build_parser()._actions for o in act.option_strings}
+        missing = [x for x in flags if "--" + x not in known]
+        assert not missing and len(flags) >= 45, (missing, len(flags))
+        # absl gives every boolean flag a --no<name> twin (and shuffle_batch_order the short name --shuffle)
+        booleans = set(re.findall(r'DEFINE_boolean\(\s*"([a-zA-Z0-9_]+)"', src))
+        assert len(booleans) >= 10 and not [x for x in booleans if "--no" + x not in known] and "--shuffle" in known
         # SpeechSynthesis/Tacotron2: train.py:45-160 + tacotron2/arg_parser.py:40-107 + waveglow/arg_parser.py:30-64
         from deeplearningexamples_amd.tacotron2 import train as t2
         from deeplearningexamples_amd.waveglow import train as wg
@@ -269,7 +293,8 @@ def test_entry_points_save_and_resume_on_gpu(cuda, tmp_path):
     assert t3.opt_steps == 2                       # step and LR restart (run_pretraining.py:437-445)
     # ---- DLRM: train with validation passes + save; test mode from the saved directory; resume training from it
     ckd = tmp_path / "dlrm_ck"
-    dbase = ["--batch_size", "2048", "--synthetic_dataset_table_sizes", "1000,50,7,20000", "--amp", "--print_freq", "2",
+    dbase = ["--dataset_type", "synthetic_gpu", "--batch_size", "2048", "--synthetic_dataset_table_sizes", "1000,50,7,20000", "--amp",
+             "--print_freq", "2",
              "--synthetic_dataset_num_entries", "16384", "--test_batch_size", "4096"]
     dl.main(dbase + ["--max_steps", "6", "--log_path", str(tmp_path / "dlrm.json"), "--test_freq", "3",
                      "--save_checkpoint_path", str(ckd)])
@@ -300,7 +325,8 @@ def test_entry_points_run_on_gpu(cuda, tmp_path):
                  "--json-summary", str(tmp_path / "bert.json"), "--bf16"])
     recs = [json.loads(l[5:]) for l in open(tmp_path / "bert.json")]
     assert "training_sequences_per_second" in recs[-1]["data"] and t.opt_steps == 3
-    dl.main(["--batch_size", "2048", "--synthetic_dataset_table_sizes", "1000,50,7,20000", "--max_steps", "5", "--amp",
+    dl.main(["--dataset_type", "synthetic_gpu", "--batch_size", "2048", "--synthetic_dataset_table_sizes", "1000,50,7,20000",
+             "--max_steps", "5", "--amp",
              "--log_path", str(tmp_path / "dlrm.json"), "--print_freq", "2", "--synthetic_dataset_num_entries", "16384"])
     recs = [json.loads(l[5:]) for l in open(tmp_path / "dlrm.json")]
     assert "average_train_throughput" in recs[-1]["data"]
