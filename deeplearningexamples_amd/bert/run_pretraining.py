@@ -33,8 +33,8 @@ def parse_arguments(argv=None):
     p.add_argument("--output_dir", default=None, type=str, help="where ckpt_{step}.pt files are written / resumed from")
     p.add_argument("--vocab_file", default=None, type=str)
     p.add_argument("--init_checkpoint", default=None, type=str, help="start from this checkpoint's weights (step and LR reset)")
-    p.add_argument("--max_seq_length", default=128, type=int)
-    p.add_argument("--max_predictions_per_seq", default=20, type=int)
+    p.add_argument("--max_seq_length", default=512, type=int)
+    p.add_argument("--max_predictions_per_seq", default=80, type=int)
     p.add_argument("--num_train_epochs", default=3.0, type=float)
     p.add_argument("--local_rank", type=int, default=int(os.getenv("LOCAL_RANK", -1)))
     p.add_argument("--amp", action="store_true", help="accepted: 16-bit compute is always on (--fp16 / --bf16 pick the type)")
@@ -54,9 +54,9 @@ def parse_arguments(argv=None):
     p.add_argument("--no_dense_sequence_output", action="store_true")
     p.add_argument("--disable_jit_fusions", action="store_true", help="accepted: there is no TorchScript in this path")
     p.add_argument("--train_batch_size", default=32, type=int, help="per-GPU batch of one optimizer step")
-    p.add_argument("--learning_rate", default=6e-3, type=float)
+    p.add_argument("--learning_rate", default=5e-5, type=float)
     p.add_argument("--max_steps", default=1000, type=float)
-    p.add_argument("--warmup_proportion", default=0.2843, type=float)
+    p.add_argument("--warmup_proportion", default=0.01, type=float)
     p.add_argument("--gradient_accumulation_steps", type=int, default=1)
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--fp16", action="store_true")
@@ -64,7 +64,7 @@ def parse_arguments(argv=None):
     p.add_argument("--init_loss_scale", type=int, default=2 ** 20)
     p.add_argument("--log_freq", type=float, default=1.0)
     p.add_argument("--steps_this_run", type=int, default=-1)
-    p.add_argument("--json-summary", type=str, default="dllogger.json")
+    p.add_argument("--json-summary", type=str, default="results/dllogger.json")
     p.add_argument("--disable_progress_bar", action="store_true")
     p.add_argument("--skip_checkpoint", action="store_true")
     p.add_argument("--allreduce_post_accumulation", action="store_true",
@@ -129,6 +129,8 @@ def main(argv=None):
     torch.manual_seed(args.seed)
     cfg = dict(config_from_json(args.config_file) if args.config_file else LARGE, seq=args.max_seq_length)
     if is_main_process():
+        if os.path.dirname(args.json_summary):
+            os.makedirs(os.path.dirname(args.json_summary), exist_ok=True)
         dllogger.init([dllogger.JSONStreamBackend(dllogger.Verbosity.VERBOSE, args.json_summary),
                        dllogger.StdOutBackend(dllogger.Verbosity.DEFAULT)])
         dllogger.log(step="PARAMETER", data={"Config": [str({k: v for k, v in vars(args).items() if k != "_defaults"})]})

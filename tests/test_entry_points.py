@@ -148,6 +148,124 @@ def _known_flags(mod):
     return {o for act in seen["p"]._actions for o in act.option_strings}
 
 
+def _captured_parser(fn, argv):
+    """The argparse parser `fn(argv)` builds, captured at its parse call."""
+    import argparse
+    seen = {}
+    real, real_known = argparse.ArgumentParser.parse_args, argparse.ArgumentParser.parse_known_args
+
+    def grab_known(self, args=None, namespace=None):
+        seen.setdefault("p", self)
+        return real_known(self, args, namespace)
+
+    def grab(self, args=None, namespace=None):
+        seen.setdefault("p", self)
+        return real(self, args, namespace)
+
+    argparse.ArgumentParser.parse_args, argparse.ArgumentParser.parse_known_args = grab, grab_known
+    try:
+        fn(argv)
+    finally:
+        argparse.ArgumentParser.parse_args, argparse.ArgumentParser.parse_known_args = real, real_known
+    return seen["p"]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/PyTorch"), reason="reference tree not mounted")
+def test_flag_defaults_choices_and_kinds_match_the_reference_sources():
+    """Same names is not yet a drop-in: every flag's DEFAULT, its choices and whether it is a switch are read out of the reference's
+    sources (ast over the add_argument / absl DEFINE_* calls of ConvNets/main.py, BERT/run_pretraining.py, Tacotron2/train.py +
+    arg_parser.py files, DLRM/dlrm/scripts/main.py) and compared with the parsers here.  The deviations are the ones listed."""
+    import argparse
+    import ast
+    ref = "/root/reference/PyTorch"
+
+    def literal(node):
+        try:
+            return ast.literal_eval(node)
+        except Exception:
+            return Ellipsis                                   # an expression: not comparable
+
+    def argparse_flags(*paths):
+        out = {}
+        for path in paths:
+            for node in ast.walk(ast.parse(open(path).read())):
+                if isinstance(node, ast.Call) and getattr(node.func, "attr", None) == "add_argument":
+                    kw = {k.arg: literal(k.value) for k in node.keywords}
+                    for a in node.args:
+                        if isinstance(a, ast.Constant) and isinstance(a.value, str) and a.value.startswith("--"):
+                            out[a.value] = kw
+        return out
+
+    def check(title, flags, parser, allowed):
+        mine = {o: a for a in parser._actions for o in a.option_strings}
+        bad = []
+        for name, kw in sorted(flags.items()):
+            a = mine.get(name)
+            if a is None:
+                bad.append((name, "missing"))
+                continue
+            switch = kw.get("action") in ("store_true", "store_false")
+            if switch != (a.nargs == 0):
+                bad.append((name, "switch" if switch else "takes a value"))
+            want = kw.get("default", False if kw.get("action") == "store_true" else (True if kw.get("action") == "store_false" else None))
+            if want is not Ellipsis and name not in allowed and want != a.default and not (want is None and a.default is False):
+                bad.append((name, "default", want, a.default))
+            ch = kw.get("choices")
+            if ch not in (None, Ellipsis) and (a.choices is None or list(ch) != list(a.choices)):
+                bad.append((name, "choices", ch, a.choices))
+        assert not bad, (title, bad)
+        return len(flags)
+
+    from deeplearningexamples_amd.convnets.main import add_parser_arguments
+    n = check("convnets", argparse_flags(ref + "/Classification/ConvNets/main.py"), add_parser_arguments(argparse.ArgumentParser()),
+              # no DALI on ROCm: the synthetic loader is the default backend; 224 is what the reference fills in for resnet50 when
+              # --image-size is None; "0" / 0
+              {"--data-backend", "--image-size", "--gather-checkpoints"})
+    assert n >= 40
+    import deeplearningexamples_amd.bert.run_pretraining as bp
+    n = check("bert", argparse_flags(ref + "/LanguageModeling/BERT/run_pretraining.py"), _captured_parser(bp.parse_arguments, ["--bf16"]), set())
+    assert n >= 40
+    from deeplearningexamples_amd.tacotron2 import train as t2
+    from deeplearningexamples_amd.waveglow import train as wg
+    base = ref + "/SpeechSynthesis/Tacotron2/"
+    argv = ["-o", "x", "-lr", "1", "--epochs", "1", "-bs", "1"]
+    for mod, extra in ((t2, "tacotron2/arg_parser.py"), (wg, "waveglow/arg_parser.py")):
+        # one entry point per model here: --model-name defaults to it (required, no default, in the reference's shared train.py)
+        n = check(mod.__name__, argparse_flags(base + "train.py", base + extra), _captured_parser(mod.parse_args, argv), {"--model-name"})
+        assert n >= 40
+    # DLRM: absl DEFINE_<kind>(name, default, ...)
+    from deeplearningexamples_amd.dlrm.main import build_parser
+    mine = {o: a for a in build_parser()._actions for o in a.option_strings}
+    bad, seen = [], 0
+    for node in ast.walk(ast.parse(open(ref + "/Recommendation/DLRM/dlrm/scripts/main.py").read())):
+        if isinstance(node, ast.Call) and getattr(node.func, "attr", "").startswith("DEFINE_"):
+            kind = node.func.attr[len("DEFINE_"):]
+            kw = {k.arg: literal(k.value) for k in node.keywords}
+            pos = [literal(a) for a in node.args]
+            name = pos[0] if pos else kw["name"]
+            default = kw["default"] if "default" in kw else pos[1]
+            a = mine.get("--" + name)
+            seen += 1
+            if a is None:
+                bad.append((name, "missing"))
+                continue
+            if kind == "list" and isinstance(default, str):
+                default = default.split(",")
+            if kind == "list" and default is not Ellipsis:
+                default = [int(x) for x in default]
+            if kind == "integer" and isinstance(default, str):
+                default = int(default)
+            if default is not Ellipsis and default != a.default:
+                bad.append((name, "default", default, a.default))
+            if kind == "enum":
+                ch = kw.get("enum_values", pos[2] if len(pos) > 2 else None)
+                if ch is not Ellipsis and list(ch) != list(a.choices):
+                    bad.append((name, "choices", ch, a.choices))
+            if kind == "boolean" and ("--no" + name not in mine or a.nargs != "?"):
+                bad.append((name, "not an absl boolean"))
+    assert not bad and seen >= 45, (bad, seen)
+
+
 def test_speech_command_lines_parse_and_config_file(tmp_path):
     """scripts/train_tacotron2.sh / train_waveglow.sh of the reference + --config-file (tacotron2_common/utils.py:36-49)."""
     from deeplearningexamples_amd.tacotron2 import train as t2
@@ -279,6 +397,7 @@ def test_entry_points_save_and_resume_on_gpu(cuda, tmp_path):
                                    intermediate_size=1024, max_position_embeddings=512, type_vocab_size=2)))
     out = tmp_path / "bert_out"
     base = ["--config_file", str(cfg), "--train_batch_size", "8", "--gradient_accumulation_steps", "2", "--max_steps", "6",
+            "--max_seq_length", "128", "--max_predictions_per_seq", "20", "--learning_rate", "6e-3", "--warmup_proportion", "0.2843",
             "--json-summary", str(tmp_path / "bert.json"), "--bf16", "--output_dir", str(out), "--num_steps_per_checkpoint", "2",
             "--do_train"]
     t = bp.main(base + ["--steps_this_run", "4"])
@@ -322,7 +441,7 @@ def test_entry_points_run_on_gpu(cuda, tmp_path):
     cfg.write_text(json.dumps(dict(vocab_size=1000, hidden_size=256, num_attention_heads=4, num_hidden_layers=2,
                                    intermediate_size=1024, max_position_embeddings=512, type_vocab_size=2)))
     t = bp.main(["--config_file", str(cfg), "--train_batch_size", "8", "--gradient_accumulation_steps", "2", "--max_steps", "3",
-                 "--json-summary", str(tmp_path / "bert.json"), "--bf16"])
+                 "--max_seq_length", "128", "--max_predictions_per_seq", "20", "--json-summary", str(tmp_path / "bert.json"), "--bf16"])
     recs = [json.loads(l[5:]) for l in open(tmp_path / "bert.json")]
     assert "training_sequences_per_second" in recs[-1]["data"] and t.opt_steps == 3
     dl.main(["--dataset_type", "synthetic_gpu", "--batch_size", "2048", "--synthetic_dataset_table_sizes", "1000,50,7,20000",
