@@ -277,9 +277,13 @@ class DotInteraction(nn.Module):
 
 
 class DlrmBottom(nn.Module):
-    def __init__(self, num_numerical_features, categorical_feature_sizes, bottom_mlp_sizes=None,
-                 embedding_dim=128, hash_indices=False, device="cuda", compute_dtype=torch.float16):
+    def __init__(self, num_numerical_features, categorical_feature_sizes, bottom_mlp_sizes=None, embedding_type="multi_table",
+                 embedding_dim=128, hash_indices=False, use_cpp_mlp=False, fp16=False, device="cuda", compute_dtype=None):
+        """The reference's argument list and order (nn/parts.py:25-35); embedding_type / use_cpp_mlp select among the reference's
+        implementations of the same functions and are accepted for that reason only (one implementation here: the HIP kernels);
+        the 16-bit compute type is compute_dtype, else fp16."""
         super().__init__()
+        compute_dtype = compute_dtype or torch.float16
         assert bottom_mlp_sizes is None or embedding_dim == bottom_mlp_sizes[-1], \
             "The last bottom MLP layer must have same size as embedding."
         self._embedding_dim = embedding_dim
@@ -353,7 +357,8 @@ class DlrmBottom(nn.Module):
 
 
 class DlrmTop(nn.Module):
-    def __init__(self, top_mlp_sizes, interaction: DotInteraction, device="cuda", compute_dtype=torch.float16):
+    def __init__(self, top_mlp_sizes, interaction: DotInteraction, use_cpp_mlp=False, device="cuda", compute_dtype=torch.float16):
+        """(nn/parts.py:95-100: top_mlp_sizes, interaction, use_cpp_mlp -- the last accepted and unused, see DlrmBottom.)"""
         super().__init__()
         self.interaction = interaction
         self.mlp = Mlp(interaction.num_interactions, top_mlp_sizes[:-1], device, compute_dtype)
@@ -473,11 +478,27 @@ class DistributedDlrm(nn.Module):
             self._device_feature_order = self._feature_order = None
         interaction = DotInteraction(world_num_categorical_features, embedding_dim)
         self.bottom_model = DlrmBottom(num_numerical_features, categorical_feature_sizes, bottom_mlp_sizes,
-                                       embedding_dim, hash_indices=hash_indices, device=device, compute_dtype=cd)
-        self.top_model = DlrmTop(top_mlp_sizes, interaction, device=device, compute_dtype=cd)
+                                       embedding_type, embedding_dim, hash_indices=hash_indices, use_cpp_mlp=use_cpp_mlp,
+                                       fp16=fp16, device=device, compute_dtype=cd)
+        self.top_model = DlrmTop(top_mlp_sizes, interaction, use_cpp_mlp=use_cpp_mlp, device=device, compute_dtype=cd)
 
     def extra_repr(self):
         return f"interaction_op={self._interaction_op}, hash_indices={self._hash_indices}"
+
+    @classmethod
+    def from_dict(cls, obj_dict, **kwargs):
+        """(model/distributed.py:155-158)"""
+        return cls(**obj_dict, **kwargs)
+
+    def forward(self, numerical_input, categorical_inputs, batch_sizes_per_gpu=None):
+        """Inference-mode forward (model/distributed.py:160-180): numerical_input [B, num_numerical] (None on a rank without the
+        bottom MLP), categorical_inputs int64 [B, tables of this rank] -> logits [B, 1] in the compute type.  Nothing is kept for a
+        backward pass: the train step is DlrmTrainer.train_step (explicit forward / backward / update).  With several ranks the
+        bottom -> top all-to-all lives in the trainer (engine.DlrmTrainer.evaluate runs this forward around it)."""
+        if self.distributed:
+            raise RuntimeError("DistributedDlrm.forward: with world_size > 1 the bottom -> top exchange belongs to DlrmTrainer "
+                               "(train_step / evaluate)")
+        return self.top_model(self.bottom_model(numerical_input, categorical_inputs))
 
     def refresh_working_copies(self):
         if self.bottom_model.mlp is not None:

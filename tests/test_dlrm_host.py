@@ -200,3 +200,29 @@ def test_row_sharded_exchange_two_ranks_gloo():
         ret = mgr.dict()
         mp.spawn(_row_shard_worker, args=(2, port, ret), nprocs=2, join=True)
         assert ret[0] and ret[1]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/PyTorch"), reason="reference tree not mounted")
+def test_module_signatures_follow_the_reference_classes():
+    """DistributedDlrm / DlrmBottom / DlrmTop (model/distributed.py:106-180, nn/parts.py:25-100): the reference's argument NAMES in
+    the reference's ORDER (extra, defaulted arguments may follow), read out of its sources."""
+    import ast
+    import inspect
+    from deeplearningexamples_amd.dlrm import model as M
+    root = "/root/reference/PyTorch/Recommendation/DLRM/dlrm/"
+
+    def ref_args(path, cls, fn):
+        for n in ast.walk(ast.parse(open(root + path).read())):
+            if isinstance(n, ast.ClassDef) and n.name == cls:
+                for f in n.body:
+                    if isinstance(f, ast.FunctionDef) and f.name == fn:
+                        return [a.arg for a in f.args.args[1:]]
+        raise AssertionError((path, cls, fn))
+
+    for path, cls, fn in (("model/distributed.py", "DistributedDlrm", "__init__"), ("model/distributed.py", "DistributedDlrm", "forward"),
+                          ("nn/parts.py", "DlrmBottom", "__init__"), ("nn/parts.py", "DlrmBottom", "forward"),
+                          ("nn/parts.py", "DlrmTop", "__init__")):
+        want = ref_args(path, cls, fn)
+        got = list(inspect.signature(getattr(getattr(M, cls), fn)).parameters)[1:]
+        assert got[:len(want)] == want or (fn == "forward" and cls == "DlrmBottom" and got[:2] == want[:2]), (cls, fn, want, got)
+    assert hasattr(M.DistributedDlrm, "from_dict")

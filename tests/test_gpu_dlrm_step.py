@@ -176,6 +176,10 @@ def test_evaluate_auc_and_loss(cuda):
     assert 0.0 < auc < 1.0 and np.isfinite(loss)
     _, loss0 = evaluate(model, batches[:1])
     assert abs(loss0 - float(trainer.train_step(*batches[0]).item())) <= 1e-3 * loss0
+    # the module's own forward (model/distributed.py:160-180) is the validation pass's forward
+    lg = model(batches[1][0], batches[1][1], [cfg["batch"]]).reshape(-1).float()
+    want = model.top_model(model.bottom_model(batches[1][0], batches[1][1])).reshape(-1).float()
+    assert torch.equal(lg, want) and lg.shape[0] == cfg["batch"]
     orc = SO.DlrmOracle(state, cfg["sizes"], cfg["lr"])
     if hasattr(orc, "forward"):
         logits = torch.cat([orc.forward(*[t.cpu() for t in b[:2]]).reshape(-1) for b in batches])
