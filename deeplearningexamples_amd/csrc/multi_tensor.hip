@@ -328,7 +328,10 @@ __global__ __launch_bounds__(MT_BLOCK) void mt_sgd(const long long* __restrict__
   float* p = (float*)t.ptr[1 * n + ti] + off;
   float* mb = HAS_MOM ? (float*)t.ptr[2 * n + ti] + off : nullptr;
   // optional low-precision working copy of the parameter (the AMP "model weights"), last list
-  unsigned short* pc = CT >= 0 ? (unsigned short*)t.ptr[(HAS_MOM ? 3 : 2) * n + ti] + off : nullptr;
+  // (a tensor without one -- a bias next to weights in one table -- carries pointer 0)
+  unsigned short* pc0 = CT >= 0 ? (unsigned short*)t.ptr[(HAS_MOM ? 3 : 2) * n + ti] : nullptr;
+  const bool has_pc = CT >= 0 && pc0 != nullptr;
+  unsigned short* pc = has_pc ? pc0 + off : nullptr;
   const bool vec = ((((uintptr_t)g) | ((uintptr_t)p) | ((uintptr_t)mb)) & 15) == 0 && ((((uintptr_t)pc) & 7) == 0);
   const long long len4 = len & ~3LL;
   for (long long i = (long long)threadIdx.x * 4; i < len; i += MT_BLOCK * 4) {
@@ -360,12 +363,12 @@ __global__ __launch_bounds__(MT_BLOCK) void mt_sgd(const long long* __restrict__
     if (full) {
       st4<DLE_F32>(p + i, rp, vec);
       if (HAS_MOM) st4<DLE_F32>(mb + i, rb, vec);
-      if (CT >= 0) st4<(CT >= 0 ? CT : DLE_F16)>(pc + i, rp, vec);
+      if (has_pc) st4<(CT >= 0 ? CT : DLE_F16)>(pc + i, rp, vec);
     } else {
       for (int k = 0; k < cnt; ++k) {
         p[i + k] = rp[k];
         if (HAS_MOM) mb[i + k] = rb[k];
-        if (CT >= 0) MtIO<(CT >= 0 ? CT : DLE_F16)>::st(pc + i + k, rp[k]);
+        if (has_pc) MtIO<(CT >= 0 ? CT : DLE_F16)>::st(pc + i + k, rp[k]);
       }
     }
   }

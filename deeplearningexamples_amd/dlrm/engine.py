@@ -16,6 +16,8 @@ with the dense one (found_inf gates both), the scale is backed off exactly as Gr
 """
 from typing import Optional, Sequence
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -49,9 +51,10 @@ class GradScalerState:
 class _FlatGrads:
     """fp32 gradients of a list of Linear layers as views of ONE flat buffer (a single all-reduce bucket)."""
 
-    def __init__(self, linears, device):
+    def __init__(self, linears, device, storage=None):
         n = sum(l.weight.numel() + l.bias.numel() for l in linears)
-        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=device) if storage is None else storage
+        assert self.flat.numel() == n
         self.views = []
         o = 0
         for l in linears:
@@ -88,10 +91,16 @@ class DlrmTrainer:
         self.lr_mp = torch.full((1,), lr / world_size, dtype=torch.float32, device=self.device)  # bottom parts
         top = model.top_model
         self.top_linears = top.mlp.linears + [top.out]
-        self.top_grads = _FlatGrads(self.top_linears, self.device)
         bm = model.bottom_model.mlp
         self.bot_linears = bm.linears if bm is not None else []
-        self.bot_grads = _FlatGrads(self.bot_linears, self.device) if bm is not None else None
+        # ONE buffer behind the dense gradients of both MLPs (top first: the data-parallel all-reduce bucket stays a contiguous
+        # view): the GradScaler's inf / nan sweep over them is one launch
+        count = lambda ls: sum(l.weight.numel() + l.bias.numel() for l in ls)
+        n_top, n_bot = count(self.top_linears), count(self.bot_linears)
+        pad = (n_top + 63) // 64 * 64                 # (the second view starts on a 256-byte boundary; the gap stays zero)
+        self.dense_grads = torch.zeros(pad + n_bot, dtype=torch.float32, device=self.device)
+        self.top_grads = _FlatGrads(self.top_linears, self.device, self.dense_grads[:n_top])
+        self.bot_grads = _FlatGrads(self.bot_linears, self.device, self.dense_grads[pad:]) if bm is not None else None
         if world_size > 1:
             # the top MLP is the data-parallel part: every replica starts from rank 0's weights (the reference wraps it
             # in torch DDP, dlrm/scripts/main.py:463-466); embeddings / bottom MLP are model parallel and stay local
@@ -129,6 +138,20 @@ class DlrmTrainer:
             bw16 = self.model.bottom_model.mlp.working_copies()
             self.t_bot_w, self.t_bot_b, self.bot_padded = split(self.bot_linears, self.bot_grads, bw16)
         self.t_top_all = mt.TensorTable([[self.top_grads.flat]])
+        # One learning rate for both MLPs (one rank, or the row-sharded placement's data-parallel bottom MLP): ONE update launch
+        # over every dense tensor -- weights with a same-shape 16-bit copy refresh it in the kernel, biases and the K-padded first
+        # layers carry no copy (their padded copies follow by cast_rows).  Nine launches at the tail of the step become four.
+        self.t_dense = None
+        if self.bot_grads is not None and (self.world == 1 or getattr(self, "bottom_dp", False)) and \
+                os.environ.get("DLE_DLRM_ONE_DENSE_STEP", "1") != "0":
+            bw = self.model.bottom_model.mlp.working_copies()
+            g, pp, c = [], [], []
+            for lins, grads, copies in ((self.top_linears, self.top_grads, w16), (self.bot_linears, self.bot_grads, bw)):
+                for i, l in enumerate(lins):
+                    g += [grads.views[i][0], grads.views[i][1]]
+                    pp += [l.weight.data, l.bias.data]
+                    c += [copies[i] if copies[i].shape == l.weight.shape else None, None]
+            self.t_dense = mt.TensorTable([g, pp, c], mt.streaming_chunk([g]))
 
     def set_lr_factor(self, factor: float):
         """LearningRateScheduler.step() (dlrm/scripts/utils.py:278-286): lr = base * factor per group."""
@@ -141,6 +164,17 @@ class DlrmTrainer:
         sc = self.scaler
         skip = sc.found_inf if sc.enabled else None
         inv = sc.inv_scale if sc.enabled else None
+        if self.t_dense is not None:
+            mt.sgd(self.t_dense, self.lr_dp, skip_flag=skip, inv_scale=inv, has_momentum=False, model_copy=True)
+            top = self.model.top_model
+            copies = top.mlp.working_copies() + [top.out_working_copy()]
+            for i in self.top_padded:
+                F.cast_rows(self.top_linears[i].weight.data, copies[i].dtype, cols_out=copies[i].shape[1], out=copies[i])
+            bm = self.model.bottom_model.mlp
+            for i in self.bot_padded:
+                cp = bm.working_copies()[i]
+                F.cast_rows(self.bot_linears[i].weight.data, cp.dtype, cols_out=cp.shape[1], out=cp)
+            return
         if self.t_top_w is not None:
             mt.sgd(self.t_top_w, self.lr_dp, skip_flag=skip, inv_scale=inv, has_momentum=False, model_copy=True)
         mt.sgd(self.t_top_b, self.lr_dp, skip_flag=skip, inv_scale=inv, has_momentum=False)
@@ -311,9 +345,7 @@ class DlrmTrainer:
         elif self._wgrad_stream() is not None:
             torch.cuda.current_stream().wait_stream(self._wgrad_stream())
         if sc.enabled:
-            F.check_nonfinite_(self.top_grads.flat, sc.found_inf)
-            if self.bot_grads is not None:
-                F.check_nonfinite_(self.bot_grads.flat, sc.found_inf)
+            F.check_nonfinite_(self.dense_grads, sc.found_inf)      # the dense gradients of both MLPs: one buffer, one sweep
             if self.world > 1:
                 comm.allreduce_max_(sc.found_inf, self.pg)
         if not self.freeze_mlps:

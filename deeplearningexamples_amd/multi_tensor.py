@@ -33,30 +33,34 @@ class TensorTable:
             if len(lst) != n:
                 raise ValueError("tensor lists must have equal length")
         dev = lists[0][0].device if n else torch.device("cuda")
-        for lst in lists:
+        for li, lst in enumerate(lists):
             for t, ref in zip(lst, lists[0]):
+                if t is None:                    # an OPTIONAL list entry (SGD's 16-bit model copy of a tensor that has none): pointer 0
+                    if li == 0:
+                        raise ValueError("the first list holds every tensor")
+                    continue
                 if not t.is_contiguous():
                     raise ValueError("multi-tensor kernels need contiguous tensors")
                 if t.numel() != ref.numel() or t.device != dev:
                     raise ValueError("tensors at the same list position must match in size and device")
-        C.require_cuda(*[t for lst in lists for t in lst])
+        C.require_cuda(*[t for lst in lists for t in lst if t is not None])
         self.n, self.n_lists, self.chunk = n, len(lists), chunk
         sizes = np.asarray([t.numel() for t in lists[0]], dtype=np.int64)
         nchunks = (sizes + chunk - 1) // chunk
         start = np.concatenate([[0], np.cumsum(nchunks)]).astype(np.int64)
-        ptrs = np.asarray([[t.data_ptr() for t in lst] for lst in lists], dtype=np.int64).reshape(-1)
+        ptrs = np.asarray([[t.data_ptr() if t is not None else 0 for t in lst] for lst in lists], dtype=np.int64).reshape(-1)
         host = np.concatenate([sizes, start, ptrs]).astype(np.int64)
         self.total_chunks = int(start[-1])
         self.total_elems = int(sizes.sum())
         self.key = host.tobytes()
         self.table = torch.from_numpy(host).to(dev)
-        self.dtypes = [lst[0].dtype if n else torch.float32 for lst in lists]
+        self.dtypes = [next((t.dtype for t in lst if t is not None), torch.float32) for lst in lists]
         self.device = dev
         self._keep = lists   # keep the tensors alive while the table exists
 
     @staticmethod
     def key_of(lists, chunk=CHUNK):
-        return (chunk,) + tuple(t.data_ptr() for lst in lists for t in lst) + tuple(t.numel() for t in lists[0])
+        return (chunk,) + tuple(t.data_ptr() if t is not None else 0 for lst in lists for t in lst) + tuple(t.numel() for t in lists[0])
 
 
 def _note(table, bytes_per_elem):
@@ -112,7 +116,7 @@ def lamb_stage2(table, noop_flag, param_norm, update_norm, lr, weight_decay, use
 
 def sgd(table, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, first_step=False,
         skip_flag=None, inv_scale=None, has_momentum=None, model_copy=False):
-    """lists: g, p [, momentum buffer] [, 16-bit model copy (model_copy=True -> last list)]."""
+    """lists: g, p [, momentum buffer] [, 16-bit model copy (model_copy=True -> last list; None entries: tensors without one)]."""
     lr_dev = lr if isinstance(lr, torch.Tensor) else None
     if has_momentum is None:
         has_momentum = (table.n_lists - int(model_copy)) >= 3
