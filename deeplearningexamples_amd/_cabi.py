@@ -161,6 +161,9 @@ _SIGS = {
     "dle_mt_lamb_stage1": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_void_p, c_float, c_float, c_float,
                                    c_void_p, c_int, c_float, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
+    "dle_mt_lamb_stage1_norms": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_void_p, c_float, c_float, c_float,
+                                         c_void_p, c_int, c_float, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p]),
     "dle_mt_lamb_stage2": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_float, c_int, c_void_p]),
     "dle_mt_sgd": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float,

@@ -174,6 +174,9 @@ class BertTrainer:
                 lst.append(t)
             if key == "decay_copy":
                 lists[4].append(self.w16[n])
+        # LAMB's per-tensor norms taken inside stage 1 (csrc/multi_tensor.hip mt_lamb_stage1<NORMS>); DLE_BERT_LAMB_NORMS=0 keeps the
+        # two l2norm sweeps of the reference's call sequence
+        self.fuse_lamb_norms = os.environ.get("DLE_BERT_LAMB_NORMS", "1") != "0"
         self.tables = {}
         for key, lists in groups.items():
             if not lists[0]:
@@ -536,6 +539,12 @@ class BertTrainer:
         lr = torch.where(progress < warm, base * progress / warm, base * torch.clamp(1.0 - progress, min=0.0) ** 0.5)
         self.lr_t.copy_(lr.reshape(()))
 
+    def _unused_norms(self, n):
+        buf = getattr(self, "_norm_pad", None)
+        if buf is None or buf.numel() < n:
+            buf = self._norm_pad = torch.ones(n, dtype=torch.float32, device=self.dev)
+        return buf
+
     def optimizer_step(self):
         sc = self.scaler
         if self.buckets is not None:
@@ -559,6 +568,18 @@ class BertTrainer:
             inv = inv * (1.0 / self.grad_divisor)
         max_norm = self.max_norm_t * scale
         for key, tb in self.tables.items():
+            if self.fuse_lamb_norms:
+                # the per-tensor norms of p and of the update leave with stage 1 (two sweeps over 1.34 GB each less); a group
+                # without weight decay steps with ratio = lr (multi_tensor_lamb.cu:277-282): its norms are never read
+                if tb["wd"] != 0.0:
+                    pn, un = mt.lamb_stage1_norms(tb["t_s1"], self.noop, 0.9, 0.999, 1.0 - 0.9, self.step_t, True, 1e-6, 1,
+                                                  tb["wd"], gnorm, max_norm, inv)
+                else:
+                    mt.lamb_stage1(tb["t_s1"], self.noop, 0.9, 0.999, 1.0 - 0.9, self.step_t, True, 1e-6, 1, tb["wd"], gnorm,
+                                   max_norm, inv)
+                    pn = un = self._unused_norms(tb["t_s1"].n)
+                mt.lamb_stage2(tb["t_s2"], self.noop, pn, un, self.lr_t, tb["wd"], False)
+                continue
             _, pn = mt.l2norm(tb["t_p"], self.noop, per_tensor=True)
             mt.lamb_stage1(tb["t_s1"], self.noop, 0.9, 0.999, 1.0 - 0.9, self.step_t, True, 1e-6, 1, tb["wd"], gnorm,
                            max_norm, inv)

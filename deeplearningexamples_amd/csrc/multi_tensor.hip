@@ -106,6 +106,16 @@ __device__ __forceinline__ void st4(typename MtIO<DT>::T* p, float4_t v, bool ve
   }
 }
 
+// s + (v0^2 + v1^2 + v2^2 + v3^2) with the roundings pinned (explicit fused multiply-adds): the l2norm sweep and the LAMB stage that
+// takes the same sums on the fly must agree to the bit, whatever hipcc's contraction makes of the code around them
+__device__ __forceinline__ float mt_sumsq4(float s, float4_t v) {
+  float t = v[0] * v[0];
+  t = __builtin_fmaf(v[1], v[1], t);
+  t = __builtin_fmaf(v[2], v[2], t);
+  t = __builtin_fmaf(v[3], v[3], t);
+  return s + t;
+}
+
 // -------------------------------------------------------------------- L2 norm
 // partial[c] = sum over chunk c of x^2  (multi_tensor_l2norm_kernel.cu:28-110)
 template <int DT>
@@ -125,8 +135,7 @@ __global__ __launch_bounds__(MT_BLOCK) void mt_l2norm_partial(const long long* _
   float s = 0.f;
   const long long len4 = len & ~3LL;
   for (long long i = (long long)threadIdx.x * 4; i < len4; i += MT_BLOCK * 4) {
-    const float4_t v = ld4<DT>(x + i, vec);
-    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    s = mt_sumsq4(s, ld4<DT>(x + i, vec));
   }
   for (long long i = len4 + threadIdx.x; i < len; i += MT_BLOCK) {
     const float v = MtIO<DT>::ld(x + i);
@@ -175,15 +184,22 @@ __global__ __launch_bounds__(MT_BLOCK) void mt_l2norm_finish(const float* __rest
 // -------------------------------------------------------------------- LAMB stage 1
 // lists: 0 = g (GT, overwritten with the update), 1 = p, 2 = m, 3 = v (fp32)
 // multi_tensor_lamb.cu:43-245
-template <int GT>
+// NORMS: the per-chunk sums of squares of p (as read) and of the update (as stored) leave with the pass -- the two per-tensor
+// l2norm sweeps multi_tensor_lamb_cuda runs around this stage (multi_tensor_lamb.cu:380-420: param norms before, update norms
+// after; 2 x 1.34 GB re-read for BERT-Large) become a fold over `partial_p` / `partial_u` (mt_lamb_norms_finish, which also raises
+// the noop flag on a non-finite sum, as the l2norm pass does).
+template <int GT, bool NORMS>
 __global__ __launch_bounds__(MT_BLOCK) void mt_lamb_stage1(const long long* __restrict__ table, int n, int chunk,
-                                                           const int* __restrict__ noop, float beta1, float beta2,
+                                                           int* noop, float beta1, float beta2,
                                                            float beta3, const int* __restrict__ step_ptr,
                                                            int bias_correction, float eps, int mode, float decay,
                                                            const float* __restrict__ global_grad_norm,
                                                            const float* __restrict__ max_global_grad_norm,
-                                                           const float* __restrict__ inv_scale) {
+                                                           const float* __restrict__ inv_scale,
+                                                           float* __restrict__ partial_p, float* __restrict__ partial_u) {
   if (noop && *noop) return;   // :63-65
+  __shared__ float red[16];
+  float sp = 0.f, su = 0.f;
   const MtTable t = mt_view(table, n);
   const long long c = blockIdx.x;
   const int ti = mt_find(t, c);
@@ -242,6 +258,19 @@ __global__ __launch_bounds__(MT_BLOCK) void mt_lamb_stage1(const long long* __re
         upd[k] = mh / (sqrtf(vh) + eps) + decay * rp[k];
       }
     }
+    if (NORMS) {
+      float4_t us = upd;                       // the value the update-norm sweep would read back
+      if (GT != DLE_F32) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) us[k] = Cvt<GT>::up(Cvt<GT>::down(upd[k]));
+      }
+      if (full) {
+        sp = mt_sumsq4(sp, rp);
+        su = mt_sumsq4(su, us);
+      } else {
+        for (int k = 0; k < cnt; ++k) { sp += rp[k] * rp[k]; su += us[k] * us[k]; }
+      }
+    }
     if (full) {
       st4<GT>(g + i, upd, vec);   // the update goes back into the grad buffer (:163,168)
       st4<DLE_F32>(m + i, rm, vec);
@@ -252,6 +281,14 @@ __global__ __launch_bounds__(MT_BLOCK) void mt_lamb_stage1(const long long* __re
         m[i + k] = rm[k];
         v[i + k] = rv[k];
       }
+    }
+  }
+  if (NORMS) {
+    sp = block_sum(sp, red);
+    su = block_sum(su, red);
+    if (threadIdx.x == 0) {            // (a non-finite partial raises the flag in the FOLD: raised here, workgroups that start
+      partial_p[c] = sp;               //  later would leave at the top and their m / v stay behind)
+      partial_u[c] = su;
     }
   }
 }
@@ -420,6 +457,30 @@ __global__ __launch_bounds__(MT_BLOCK) void mt_adam(const long long* __restrict_
   }
 }
 
+// param_norm[t] / update_norm[t] = sqrt of tensor t's chunk partials (the fold of mt_l2norm_finish, both arrays in one launch)
+__global__ __launch_bounds__(MT_BLOCK) void mt_lamb_norms_finish(const float* __restrict__ partial_p, const float* __restrict__ partial_u,
+                                                                 const long long* __restrict__ table, int n,
+                                                                 float* __restrict__ param_norm, float* __restrict__ update_norm,
+                                                                 int* noop) {
+  const int ti = blockIdx.x;
+  __shared__ float red[16];
+  const MtTable t = mt_view(table, n);
+  float sp = 0.f, su = 0.f;
+  // (the flag may have been set before stage 1: its workgroups then left at the top and the partials are stale -- the norms are
+  //  not read in that case, stage 2 leaves at the top too; they are written as zeros like the l2norm pass's outputs)
+  const bool skipped = noop && *noop;
+  if (!skipped)
+    for (long long i = t.chunk_start[ti] + threadIdx.x; i < t.chunk_start[ti + 1]; i += MT_BLOCK) { sp += partial_p[i]; su += partial_u[i]; }
+  sp = block_sum(sp, red);
+  su = block_sum(su, red);
+  if (threadIdx.x == 0) {
+    const bool bad = !isfinite(sp) || !isfinite(su);
+    if (bad && noop) *noop = 1;
+    param_norm[ti] = (skipped || bad) ? 0.f : sqrtf(sp);
+    update_norm[ti] = (skipped || bad) ? 0.f : sqrtf(su);
+  }
+}
+
 // -------------------------------------------------------------------- C ABI
 extern "C" int64_t dle_mt_table_len(int n_tensors, int n_lists) {
   return (int64_t)n_tensors + (n_tensors + 1) + (int64_t)n_lists * n_tensors;
@@ -472,12 +533,41 @@ extern "C" int dle_mt_lamb_stage1(const int64_t* table_dev, int n_tensors, int64
   DLE_CHECK_ARG(table_dev && step_dev && global_grad_norm && max_grad_norm && inv_scale, "mt_lamb_stage1: null pointer");
   if (n_tensors == 0 || total_chunks == 0) return 0;
   dim3 grid((unsigned)total_chunks), block(MT_BLOCK);
-#define GO(GT) hipLaunchKernelGGL(mt_lamb_stage1<GT>, grid, block, 0, stream, (const long long*)table_dev, n_tensors, chunk, noop_flag, beta1, beta2, beta3, step_dev, bias_correction, eps, mode, weight_decay, global_grad_norm, max_grad_norm, inv_scale)
+#define GO(GT) hipLaunchKernelGGL((mt_lamb_stage1<GT, false>), grid, block, 0, stream, (const long long*)table_dev, n_tensors, chunk, (int*)noop_flag, beta1, beta2, beta3, step_dev, bias_correction, eps, mode, weight_decay, global_grad_norm, max_grad_norm, inv_scale, (float*)nullptr, (float*)nullptr)
   if (grad_dtype == DLE_F32) GO(DLE_F32);
   else if (grad_dtype == DLE_F16) GO(DLE_F16);
   else if (grad_dtype == DLE_BF16) GO(DLE_BF16);
   else { dle_set_error("mt_lamb_stage1: bad dtype %d", grad_dtype); return -1; }
 #undef GO
+  DLE_LAUNCH_CHECK();
+  return 0;
+}
+
+// Stage 1 + the per-tensor norms multi_tensor_lamb_cuda takes in two l2norm sweeps around it (multi_tensor_lamb.cu:380-420): param_norm[t]
+// = ||p_t|| BEFORE the step, update_norm[t] = ||update_t||, both fp32 [n_tensors], from per-chunk partial sums the stage leaves
+// (partial: fp32 scratch of >= 2 * total_chunks).  weight_decay != 0 (the stage reads p only then; without decay and without
+// NVLAMB stage 2 ignores the norms: call dle_mt_lamb_stage1).  A non-finite partial sets noop_flag and the norms come back 0.
+extern "C" int dle_mt_lamb_stage1_norms(const int64_t* table_dev, int n_tensors, int64_t total_chunks, int chunk,
+                                        int grad_dtype, int* noop_flag, float beta1, float beta2, float beta3,
+                                        const int* step_dev, int bias_correction, float eps, int mode, float weight_decay,
+                                        const float* global_grad_norm, const float* max_grad_norm, const float* inv_scale,
+                                        float* partial, float* param_norm, float* update_norm, hipStream_t stream) {
+  DLE_CHECK_ARG(table_dev && step_dev && global_grad_norm && max_grad_norm && inv_scale && partial && param_norm && update_norm,
+                "mt_lamb_stage1_norms: null pointer");
+  DLE_CHECK_ARG(weight_decay != 0.f, "mt_lamb_stage1_norms: the stage reads the parameters only under weight decay");
+  if (n_tensors == 0 || total_chunks == 0) return 0;
+  dim3 grid((unsigned)total_chunks), block(MT_BLOCK);
+  float* pp = partial;
+  float* pu = partial + total_chunks;
+#define GO(GT) hipLaunchKernelGGL((mt_lamb_stage1<GT, true>), grid, block, 0, stream, (const long long*)table_dev, n_tensors, chunk, noop_flag, beta1, beta2, beta3, step_dev, bias_correction, eps, mode, weight_decay, global_grad_norm, max_grad_norm, inv_scale, pp, pu)
+  if (grad_dtype == DLE_F32) GO(DLE_F32);
+  else if (grad_dtype == DLE_F16) GO(DLE_F16);
+  else if (grad_dtype == DLE_BF16) GO(DLE_BF16);
+  else { dle_set_error("mt_lamb_stage1_norms: bad dtype %d", grad_dtype); return -1; }
+#undef GO
+  DLE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mt_lamb_norms_finish, dim3(n_tensors), block, 0, stream, pp, pu, (const long long*)table_dev, n_tensors,
+                     param_norm, update_norm, noop_flag);
   DLE_LAUNCH_CHECK();
   return 0;
 }

@@ -107,6 +107,23 @@ def lamb_stage1(table, noop_flag, beta1, beta2, beta3, step, bias_correction, ep
            C.stream())
 
 
+def lamb_stage1_norms(table, noop_flag, beta1, beta2, beta3, step, bias_correction, eps, mode, weight_decay,
+                      global_grad_norm, max_grad_norm, inv_scale):
+    """lamb_stage1 that also returns (param_norm, update_norm), fp32 [n] each: the per-tensor l2norm sweeps over p (before the
+    step) and over the update (after stage 1) that multi_tensor_lamb_cuda runs around the stage, taken from per-chunk partial sums
+    the stage leaves (include/dle_mi355x.h, dle_mt_lamb_stage1_norms).  weight_decay != 0."""
+    dev = table.device
+    pn = torch.empty(table.n, dtype=torch.float32, device=dev)
+    un = torch.empty(table.n, dtype=torch.float32, device=dev)
+    scratch = torch.empty(2 * max(table.total_chunks, 1), dtype=torch.float32, device=dev)
+    _note(table, 7 * 4)
+    C.call("dle_mt_lamb_stage1_norms", C.ptr(table.table), table.n, table.total_chunks, table.chunk,
+           C.dt(table.dtypes[0]), C.ptr(noop_flag), beta1, beta2, beta3, C.ptr(step), int(bias_correction),
+           eps, int(mode), weight_decay, C.ptr(global_grad_norm), C.ptr(max_grad_norm), C.ptr(inv_scale),
+           C.ptr(scratch), C.ptr(pn), C.ptr(un), C.stream())
+    return pn, un
+
+
 def lamb_stage2(table, noop_flag, param_norm, update_norm, lr, weight_decay, use_nvlamb):
     _note(table, 3 * 4 + (2 if table.n_lists == 3 else 0))      # reads the update and p, writes p (+ the 16-bit model copy)
     C.call("dle_mt_lamb_stage2", C.ptr(table.table), table.n, table.total_chunks, table.chunk,

@@ -209,6 +209,15 @@ int dle_mt_lamb_stage1(const int64_t* table_dev, int n_tensors, int64_t total_ch
                        float weight_decay, const float* global_grad_norm, const float* max_grad_norm,
                        const float* inv_scale, hipStream_t stream);
 /* lists: update (grad_dtype), p (fp32) [, model copy (copy_dtype; -1 = no copy list)] */
+/* Stage 1 that also leaves the two per-tensor norms multi_tensor_lamb_cuda takes in l2norm sweeps around it
+ * (lamb_amp_opt/csrc/multi_tensor_lamb.cu:380-420: ||p_t|| before the step, ||update_t|| after stage 1): per-chunk partial sums
+ * leave with the pass (partial: fp32 scratch, >= 2 * total_chunks), a fold writes param_norm / update_norm (fp32 [n_tensors]) and
+ * raises noop_flag on a non-finite sum -- two sweeps over 1.34 GB each less per BERT-Large step.  weight_decay != 0 (without decay
+ * and NVLAMB stage 2 ignores the norms).  The update, m and v are bit-identical to dle_mt_lamb_stage1. */
+int dle_mt_lamb_stage1_norms(const int64_t* table_dev, int n_tensors, int64_t total_chunks, int chunk, int grad_dtype,
+                             int* noop_flag, float beta1, float beta2, float beta3, const int* step_dev, int bias_correction,
+                             float eps, int mode, float weight_decay, const float* global_grad_norm, const float* max_grad_norm,
+                             const float* inv_scale, float* partial, float* param_norm, float* update_norm, hipStream_t stream);
 int dle_mt_lamb_stage2(const int64_t* table_dev, int n_tensors, int64_t total_chunks, int chunk,
                        int grad_dtype, int copy_dtype, const int* noop_flag,
                        const float* param_norm, const float* update_norm, const float* lr_dev,

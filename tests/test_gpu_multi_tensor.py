@@ -92,6 +92,46 @@ def test_lamb_full_step(cuda, gdtype, copy, mode, wd):
             assert torch.equal(copies[i], ps[i].to(gdtype))
 
 
+@pytest.mark.parametrize("gdtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("mode", [1, 0])
+def test_lamb_stage1_with_the_norms_inside_equals_the_three_passes(cuda, gdtype, mode):
+    """dle_mt_lamb_stage1_norms == l2norm(p) -> stage 1 -> l2norm(update) (the host sequence of multi_tensor_lamb_cuda,
+    multi_tensor_lamb.cu:380-420): update, m, v BIT-identical; the norms to the fp32 summation of a chunk's ragged tail (bit-identical
+    for tensors whose chunks are multiples of 4 elements long); an overflowing update raises the flag in the fold and the norms
+    come back 0; a flag already set leaves everything untouched."""
+    mt = _mt()
+    rng = np.random.default_rng(3)
+    mk = lambda arrs, dt=torch.float32: [torch.from_numpy(a.copy()).to(dt).to(cuda) for a in arrs]
+    g0 = _rand(rng, SHAPES, 12.8)
+    p0, m0, v0 = _rand(rng, SHAPES), _rand(rng, SHAPES, 0.05), _rand(rng, SHAPES, 0.01, positive=True)
+    one = torch.ones(1, device=cuda)
+    args = (0.9, 0.999, 0.1, torch.tensor([4], dtype=torch.int32, device=cuda), True, 1e-6, mode, 0.01,
+            torch.tensor([30.0], device=cuda), torch.tensor([128.0], device=cuda), torch.tensor([1.0 / 128.0], device=cuda))
+    ga, pa, ma, va = mk(g0, gdtype), mk(p0), mk(m0), mk(v0)
+    noop = torch.zeros(1, dtype=torch.int32, device=cuda)
+    _, pn_ref = mt.l2norm(mt.TensorTable([pa]), noop, per_tensor=True)
+    mt.lamb_stage1(mt.TensorTable([ga, pa, ma, va]), noop, *args)
+    _, un_ref = mt.l2norm(mt.TensorTable([ga]), noop, per_tensor=True)
+    gb, pb, mb, vb = mk(g0, gdtype), mk(p0), mk(m0), mk(v0)
+    pn, un = mt.lamb_stage1_norms(mt.TensorTable([gb, pb, mb, vb]), noop, *args)
+    assert noop.item() == 0
+    for a, b in zip(ga + ma + va, gb + mb + vb):
+        assert torch.equal(a, b)
+    np.testing.assert_allclose(pn.cpu().numpy(), pn_ref.cpu().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(un.cpu().numpy(), un_ref.cpu().numpy(), rtol=2e-6)
+    whole = [i for i, sh in enumerate(SHAPES) if int(np.prod(sh)) % 4 == 0]
+    assert len(whole) >= 3 and torch.equal(pn[whole], pn_ref[whole]) and torch.equal(un[whole], un_ref[whole])
+    # a non-finite parameter: the fold raises the flag (what the l2norm sweep over p would have done) and zeroes the norms
+    gc, pc, mc, vc = mk(g0, gdtype), mk(p0), mk(m0), mk(v0)
+    pc[5][77] = float("inf")
+    pn2, un2 = mt.lamb_stage1_norms(mt.TensorTable([gc, pc, mc, vc]), noop, *args)
+    assert noop.item() == 1 and float(pn2[5]) == 0.0 and float(un2[5]) == 0.0
+    # the flag set beforehand: nothing moves (multi_tensor_lamb.cu:63-65)
+    gd, pd, md, vd = mk(g0, gdtype), mk(p0), mk(m0), mk(v0)
+    pn3, un3 = mt.lamb_stage1_norms(mt.TensorTable([gd, pd, md, vd]), noop, *args)
+    assert all(torch.equal(a, b) for a, b in zip(gd + md, mk(g0, gdtype) + mk(m0))) and float(pn3.abs().sum()) == 0.0
+
+
 def test_lamb_noop_skips_everything(cuda):
     mt = _mt()
     g = [torch.ones(1000, device=cuda)]
