@@ -44,9 +44,11 @@ def test_all_configs_on_the_default_spec(cuda, tmp_path):
                 opts = ["--optimized_mlp=%s" % mlp, "--cuda_graphs=True", "--interaction_op=%s" % dot,
                         "--embedding_type=joint_sparse", "--amp=%s" % amp]
                 first[(mlp, dot, amp)] = _train(tmp_path, data, "default_%s_%s_%s" % (mlp, dot, amp), opts)[0]
-    # the same data and seed: every configuration starts from the same loss (to its arithmetic: fp16 AMP or fp32)
+    # the same data and seed: every configuration starts from the same loss, to its arithmetic (--amp=True computes in fp16 under the
+    # loss scaler, --amp=False in bf16 without one: there is no fp32 compute path here)
     ref = first[("True", "cuda_dot", "False")]
-    assert all(abs(v - ref) <= 2e-3 * abs(ref) for v in first.values()), first
+    print(first)
+    assert all(abs(v - ref) <= 5e-3 * abs(ref) for v in first.values()), first
 
 
 @pytest.mark.parametrize("name", [n for n in FSPECS if n != "default.yaml"])
