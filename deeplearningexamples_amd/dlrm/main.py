@@ -147,6 +147,11 @@ def main(argv=None):
         dllogger.init([dllogger.JSONStreamBackend(dllogger.Verbosity.VERBOSE, flags.log_path),
                        dllogger.StdOutBackend(dllogger.Verbosity.DEFAULT)])
         dllogger.log(step="PARAMETER", data=vars(flags))
+        if not flags.amp:
+            # the reference's --amp=False is an fp32 run; this path has 16-bit MFMA kernels only: fp32 master weights and
+            # optimizer as in the reference, bf16 activations / products (fp32 accumulation), no loss scaler
+            print("--amp=False: products and activations in bf16 with fp32 accumulation and fp32 master weights "
+                  "(there is no fp32 compute path); --amp=True is the reference's fp16 + GradScaler recipe")
     model = DistributedDlrm(
         num_numerical_features=flags.synthetic_dataset_numerical_features,
         categorical_feature_sizes=[sizes[t] for t in mine],
