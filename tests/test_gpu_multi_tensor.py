@@ -169,3 +169,28 @@ def test_sgd_momentum(cuda, gdtype, nesterov):
     mt.sgd(mt.TensorTable([gs, ps]), 0.1)
     for a, b, gg in zip(ps, before, gs):
         np.testing.assert_allclose(a.cpu().numpy(), (b - 0.1 * gg.float()).cpu().numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("cdtype", [torch.float16, torch.bfloat16])
+def test_sgd_with_an_optional_model_copy_per_tensor(cuda, cdtype):
+    """One SGD launch over weights that keep a 16-bit working copy AND tensors that have none (biases, K-padded first layers): a
+    None entry in the copy list is pointer 0 in the table -- the tensor is stepped, nothing else is written (apex FusedSGD with
+    materialize_master_grads over a model whose biases stay fp32, dlrm/scripts/main.py:469-471)."""
+    mt = _mt()
+    rng = np.random.default_rng(5)
+    p0, g0 = _rand(rng, SHAPES), _rand(rng, SHAPES, 0.1)
+    ps = [torch.from_numpy(a.copy()).to(cuda) for a in p0]
+    gs = [torch.from_numpy(a.copy()).to(cuda) for a in g0]
+    guard = torch.full((4096,), 7.0, dtype=cdtype, device=cuda)                    # nothing may be written through a null pointer
+    copies = [torch.zeros(s, dtype=cdtype, device=cuda) if i % 2 == 0 else None for i, s in enumerate(SHAPES)]
+    table = mt.TensorTable([gs, ps, copies])
+    assert table.dtypes[2] == cdtype
+    mt.sgd(table, torch.tensor(0.5, device=cuda), has_momentum=False, model_copy=True)
+    for i in range(len(SHAPES)):
+        want = torch.from_numpy(p0[i] - 0.5 * g0[i]).to(cuda)
+        np.testing.assert_allclose(ps[i].cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-7)
+        if copies[i] is not None:
+            assert torch.equal(copies[i], ps[i].to(cdtype))
+    assert bool((guard == 7.0).all())
+    with pytest.raises(ValueError):
+        mt.TensorTable([[None] + gs[1:], ps])                                       # the first list holds every tensor
