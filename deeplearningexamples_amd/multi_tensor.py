@@ -32,6 +32,8 @@ class TensorTable:
         for lst in lists:
             if len(lst) != n:
                 raise ValueError("tensor lists must have equal length")
+        if any(t is None for t in lists[0]):
+            raise ValueError("the first list holds every tensor")
         dev = lists[0][0].device if n else torch.device("cuda")
         for li, lst in enumerate(lists):
             for t, ref in zip(lst, lists[0]):
