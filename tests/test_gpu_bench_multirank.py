@@ -57,3 +57,21 @@ def test_bench_two_ranks_survives_a_nested_failure_on_one_rank():
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["workloads"]["rn50"]["value"] > 0
     assert "error" in d["workloads"]["dlrm"] and "error" in d["workloads"]["bert"]     # neither nested record was produced
     assert d.get("note") == "nested phase timed out" or "injected" in r.stderr or "failed" in r.stderr
+
+
+def test_dlrm_bench_with_eight_ranks_places_the_bottom_mlp_alone_on_rank_zero():
+    """`bench.py --gpus 8 --workload dlrm`: the reference's get_device_mapping puts the bottom MLP on rank 0 WITHOUT tables when more
+    than four GPUs share the 26 tables (dlrm/utils/distributed.py:102-176; tests/golden/dlrm_placement.json) -- the configuration the
+    driver's 8-GPU scaling run executes, with ranks that own no numerical features and a rank that owns no embedding.  On a box with
+    fewer than eight GPUs the ranks share the devices and the exchange is staged through gloo (see the module docstring)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    if torch.cuda.device_count() < 8:
+        env["DLE_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "dlrm", "--no-nested", "--steps", "3",
+           "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timer"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-4000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["comm"]["ranks_seen"] == 8 and d["value"] > 0
+    assert 0.6 < d["final_loss"] < 0.8                                   # random labels: ln 2, on every placement
